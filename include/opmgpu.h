@@ -1,0 +1,247 @@
+/*
+ * opmgpu.h -- C ABI of libopmgpu.so: the MI355X (gfx950) fully-implicit black-oil
+ * Newton step that drops in behind flow_legacy's BlackoilModel /
+ * NewtonIterationBlackoilInterface.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to
+ * the OPM/opm-simulators-legacy tree).  Conventions:
+ *   - plain C linkage, plain pointers + sizes, no C++/torch types cross the boundary;
+ *   - every call returns an int status: OPMGPU_OK (0) or an OPMGPU_E* code that the
+ *     C++ shim maps to the exception the reference would throw;
+ *   - the caller owns all host buffers, the library owns all device memory behind the
+ *     opaque handle; a handle is bound to ONE GPU and is not thread-safe;
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry
+ *     point returns OPMGPU_ENODEVICE;
+ *   - cell-indexed host arrays are in the CALLER's (natural) cell order, vectors of
+ *     unknowns are equation-major [all p | all sw | all xvar] exactly like the
+ *     reference's dx (BlackoilModelBase_impl.hpp:1162-1175);
+ *   - sign convention of the Newton update: x_new = x_old - dx (ibid. :1177-1183).
+ */
+#ifndef OPMGPU_H
+#define OPMGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes -> reference exceptions (AdaptiveTimeStepping_impl.hpp:244-281) ---- */
+enum {
+    OPMGPU_OK = 0,
+    OPMGPU_EINVAL = 1,            /* bad argument                      -> std::logic_error      */
+    OPMGPU_ENODEVICE = 2,         /* no HIP device / HIP runtime error -> std::runtime_error    */
+    OPMGPU_ENUMERICAL = 3,        /* NaN / too large residual          -> Opm::NumericalIssue   (BlackoilModelBase_impl.hpp:1828-1854) */
+    OPMGPU_ELINSOLVE = 4,         /* linear solver did not converge    -> Opm::LinearSolverProblem (ISTLSolver.hpp:358-368) */
+    OPMGPU_EBREAKDOWN = 5,        /* BiCGStab breakdown (rho/omega/h)  -> Dune::ISTLError       */
+    OPMGPU_ESINGULAR = 6,         /* singular diagonal block in ILU0   -> Dune::MatrixBlockError */
+    OPMGPU_ENOMEM = 7,
+    OPMGPU_ECOMM = 8              /* RCCL failure                                               */
+};
+
+/* HydroCarbonState, opm/core/simulator/BlackoilState.hpp:33-37 */
+enum { OPMGPU_HC_GAS_ONLY = 0, OPMGPU_HC_GAS_AND_OIL = 1, OPMGPU_HC_OIL_ONLY = 2 };
+
+/* ILU0 elimination order.  NATURAL reproduces serial dune-istl bilu0 in the caller's
+ * row order (level-scheduled on the device); MULTICOLOR is the reference's own
+ * ilu_redblack idea (ISTLSolver.hpp:204-209) generalised to greedy colouring. */
+enum { OPMGPU_ORDER_NATURAL = 0, OPMGPU_ORDER_MULTICOLOR = 1 };
+
+typedef struct opmgpu_ctx opmgpu_ctx;
+
+/* Static grid data = what the reference pulls from UnstructuredGrid + DerivedGeology
+ * (GeoProps.hpp:84-195) + HelperOps (AutoDiffHelpers.hpp:44-174).  Connections are the
+ * interior faces in grid face order followed by the NNCs; conn_cells[2*f+0] is the cell
+ * with ngrad coefficient +1 (c1), conn_cells[2*f+1] the one with -1 (c2). */
+typedef struct opmgpu_grid {
+    int32_t        nc;          /* number of (active) cells                                     */
+    int32_t        nconn;       /* interior faces + NNCs                                        */
+    const int32_t* conn_cells;  /* [nconn*2]                                                    */
+    const double*  trans;       /* [nconn]  transmissibility, SI                                */
+    const double*  pv;          /* [nc]     pore volume (geo_.poreVolume())                     */
+    const double*  z;           /* [nc]     cell centroid depth (geo_.z())                      */
+    double         gravity;     /* geo_.gravity()[2]                                            */
+    const double*  thpres;      /* [nconn] threshold pressures by connection, or NULL           */
+    const int32_t* pvtnum;      /* [nc] 0-based PVT region (cellPvtRegionIdx_), or NULL (=0)    */
+    const int32_t* satnum;      /* [nc] 0-based saturation region, or NULL (=0)                 */
+} opmgpu_grid;
+
+/* Fluid tables, already converted to SI and pre-processed the way opm-material stores
+ * them (call sites BlackoilPropsAdFromDeck.cpp:264-738, SaturationPropsFromDeck.cpp:74-204).
+ * All "ptr" arrays are CSR-style offsets with one extra trailing entry. */
+typedef struct opmgpu_tables {
+    int32_t n_pvt_regions, n_sat_regions;
+    int32_t has_disgas, has_vapoil;            /* DISGAS / VAPOIL                               */
+    const double*  surface_density;            /* [n_pvt][3]  water, oil, gas                   */
+    const double*  pvtw;                       /* [n_pvt][5]  pref, Bw_ref, Cw, mu_ref, Cv      */
+    /* oil: saturated curve nodes (PVTO rows; PVDO = nodes with rs == 0, has_disgas == 0)       */
+    const int32_t* oil_node_ptr;               /* [n_pvt+1]                                     */
+    const double  *oil_rs, *oil_psat, *oil_invb_sat, *oil_invbmu_sat;   /* per node             */
+    const int32_t* oil_col_ptr;                /* [n_nodes+1] undersaturated column of node     */
+    const double  *oil_col_p, *oil_col_invb, *oil_col_invbmu;           /* per column sample    */
+    /* gas: nodes keyed by gas pressure (PVTG; PVDG = nodes with rv == 0, has_vapoil == 0)      */
+    const int32_t* gas_node_ptr;               /* [n_pvt+1]                                     */
+    const double  *gas_pg, *gas_rvsat, *gas_invb_sat, *gas_invbmu_sat;  /* per node             */
+    const int32_t* gas_col_ptr;                /* [n_nodes+1] column over Rv, ascending         */
+    const double  *gas_col_rv, *gas_col_invb, *gas_col_invbmu;
+    /* SWOF / SGOF per saturation region                                                        */
+    const int32_t* swof_ptr;                   /* [n_sat+1]                                     */
+    const double  *swof_sw, *swof_krw, *swof_krow, *swof_pcow;
+    const int32_t* sgof_ptr;                   /* [n_sat+1]                                     */
+    const double  *sgof_sg, *sgof_krg, *sgof_krog, *sgof_pcgo;
+    /* ROCK (RockCompressibility.cpp:86-125, quadratic form)                                    */
+    double rock_pref, rock_comp;
+} opmgpu_tables;
+
+/* Newton + linear-solver knobs: BlackoilModelParameters.cpp:76-102, BlackoilModelBase_impl.hpp:139,
+ * FlowLinearSolverParameters fields read at ISTLSolver.hpp:142-270. */
+typedef struct opmgpu_params {
+    double dp_max_rel;              /* 0.3    */
+    double ds_max;                  /* 0.2    */
+    double dr_max_rel;              /* 1e9    */
+    double max_residual_allowed;    /* 1e7    */
+    double tolerance_mb;            /* 1e-5   */
+    double tolerance_cnv;           /* 1e-2   */
+    double matbalscale[3];          /* {1.1169, 1.0031, 0.0031}                                 */
+    double linear_solver_reduction; /* 1e-2   */
+    int32_t linear_solver_maxiter;  /* 150    */
+    double ilu_relaxation;          /* 0.9    */
+    int32_t ilu_ordering;           /* OPMGPU_ORDER_*                                           */
+    int32_t ignore_convergence_failure; /* 0  */
+} opmgpu_params;
+
+void opmgpu_default_params(opmgpu_params* p);
+
+/* ------------------------------------------------------------------------------------------
+ * B2 boundary: BlackoilModel hooks (BlackoilModelBase_impl.hpp:239-326: assemble ->
+ * getConvergence -> solveJacobianSystem -> updateState).
+ * ---------------------------------------------------------------------------------------- */
+
+/* Replaces the BlackoilModel constructor's static inputs (BlackoilModel.hpp:63-79): grid,
+ * BlackoilPropsAdFromDeck, DerivedGeology, RockCompressibility, model parameters.
+ * Persists across report steps (SimulatorBase_impl.hpp:201-203 rebuilds the model object,
+ * the device context lives with the linear solver, FlowMain.hpp:237). */
+int opmgpu_create(opmgpu_ctx** ctx, int device, const opmgpu_grid* grid,
+                  const opmgpu_tables* tables, const opmgpu_params* params);
+void opmgpu_destroy(opmgpu_ctx* ctx);
+const char* opmgpu_last_error(const opmgpu_ctx* ctx);
+
+/* Wells topology (Wells::well_connpos / well_cells).  The BSR pattern becomes
+ * stencil U per-well cliques, the fill eliminateVariable() creates
+ * (NewtonIterationUtilities.cpp:98-115).  Call before the first assemble of a report step. */
+int opmgpu_set_wells(opmgpu_ctx* ctx, int nw, const int32_t* well_connpos /*nw+1*/,
+                     const int32_t* well_cells /*nperf*/);
+
+/* ReservoirState in/out (BlackoilState.hpp:40-90): pressure[nc], saturation[nc*3]
+ * cell-major interleaved (w,o,g), gasoilratio[nc], rv[nc], hydroCarbonState[nc]. */
+int opmgpu_set_state(opmgpu_ctx* ctx, const double* p, const double* sat, const double* rs,
+                     const double* rv, const int8_t* hcstate);
+int opmgpu_get_state(opmgpu_ctx* ctx, double* p, double* sat, double* rs, double* rv,
+                     int8_t* hcstate);
+
+/* BlackoilModelBase::assemble (BlackoilModelBase_impl.hpp:757-840) minus the host well model:
+ * variableState -> [initial: computeAccum(state0,0)] -> assembleMassBalanceEq.
+ * State pointers may all be NULL to use the device-resident state.  `initial` is the
+ * reference's initial_assembly flag (iteration == 0): accum0 is (re)computed, which is what
+ * makes re-entry with a rolled-back state and a chopped dt safe. */
+int opmgpu_assemble(opmgpu_ctx* ctx, double dt, int initial, const double* p, const double* sat,
+                    const double* rs, const double* rv, const int8_t* hcstate);
+
+/* Per-perforation cell quantities the host StandardWells model needs
+ * (extractWellPerfProperties, StandardWells_impl.hpp:396-571).  out is [nperf][OPMGPU_PERF_K]:
+ * for q in {p_o, rs, rv, b_w, b_o, b_g, mob_w, mob_o, mob_g}: value, d/dP, d/dSw, d/dXvar. */
+#define OPMGPU_PERF_K 36
+int opmgpu_perf_props(opmgpu_ctx* ctx, double* out);
+
+/* addWellContributionToMassBalanceEq (BlackoilModelBase_impl.hpp:953-975) + the Schur
+ * complement of eliminateVariable (NewtonIterationUtilities.cpp:45-128), computed on the host:
+ * resid_delta[nperf*3] is ADDED to the (unscaled) residual of the perforated cells (phase
+ * fastest), schur blocks (UNSCALED, row-major 3x3, d eq / d var) are ADDED to J at
+ * (schur_rc[2k], schur_rc[2k+1]) in caller cell numbering; the library applies matbalscale. */
+int opmgpu_add_well_terms(opmgpu_ctx* ctx, const double* resid_delta, int nblk,
+                          const int32_t* schur_rc, const double* schur_blocks);
+
+/* getConvergence / convergenceReduction (BlackoilModelBase_impl.hpp:1633-1857) for the reservoir
+ * equations: B_avg, CNV, MB per phase plus the L-inf residual norms of computeResidualNorms
+ * (:1551-1589).  *converged = all MB < tol_mb && all CNV < tol_cnv.  Returns OPMGPU_ENUMERICAL
+ * on NaN or > max_residual_allowed exactly where the reference throws NumericalIssue. */
+int opmgpu_convergence(opmgpu_ctx* ctx, double dt, double* B_avg3, double* CNV3, double* MB3,
+                       double* linf3, int* converged);
+
+/* solveJacobianSystem -> NewtonIterationBlackoilInterleaved::computeNewtonIncrement
+ * (NewtonIterationBlackoilInterleaved.cpp:202-292, :467-487) on the assembled, matbal-scaled
+ * device system: block-ILU0 + BiCGStab in float if single_precision (the reference's
+ * dt < 20 d switch, :478-480), else double.  dx (3*nc, equation-major, caller cell order) may be
+ * NULL to keep the increment resident for opmgpu_update_state. */
+int opmgpu_solve(opmgpu_ctx* ctx, int single_precision, double* dx, int* iters, double* reduction);
+
+/* updateState (BlackoilModelBase_impl.hpp:1147-1389): dp/ds chopping, saturation
+ * renormalisation, rs/rv limits, phase-state switching.  dx NULL = use the resident increment
+ * of the last opmgpu_solve.  relax multiplies dx first (NonlinearSolver_impl.hpp:283-301, dampen). */
+int opmgpu_update_state(opmgpu_ctx* ctx, const double* dx, double relax);
+
+/* ------------------------------------------------------------------------------------------
+ * B1 boundary: NewtonIterationBlackoilInterface::computeNewtonIncrement
+ * (NewtonIterationBlackoilInterface.hpp:31-52) with the matrix supplied by the reference's own
+ * AD assembly after formInterleavedSystem (NewtonIterationBlackoilInterleaved.cpp:110-194):
+ * BCRSMatrix<3x3> as BSR (rowptr[nb+1], col[nnzb], val[nnzb*9] row-major blocks), rhs/x
+ * block-interleaved [nb][3] like Dune BlockVector.  The context may come from
+ * opmgpu_create_solver (no grid/tables).  The sparsity plan is cached while the pattern
+ * is unchanged. */
+int opmgpu_create_solver(opmgpu_ctx** ctx, int device, const opmgpu_params* params);
+int opmgpu_solve_bsr(opmgpu_ctx* ctx, int nb, const int32_t* rowptr, const int32_t* col,
+                     const double* val9, const double* rhs3, int single_precision, double* x3,
+                     int* iters, double* reduction);
+
+/* ------------------------------------------------------------------------------------------
+ * Kernel-level entry points (parity tests, roofline bench).  They operate on the matrix held
+ * by the context: the last opmgpu_solve_bsr / opmgpu_load_bsr / opmgpu_assemble system.
+ * ---------------------------------------------------------------------------------------- */
+int opmgpu_load_bsr(opmgpu_ctx* ctx, int nb, const int32_t* rowptr, const int32_t* col,
+                    const double* val9, int single_precision);
+/* y = A x, x/y block-interleaved [nb][3] (MatrixAdapter::apply, used at ISTLSolver.hpp:267). */
+int opmgpu_spmv(opmgpu_ctx* ctx, const double* x3, double* y3);
+/* ILU0 of the loaded matrix (ParallelOverlappingILU0 ctor) and one application
+ * v = w * U^-1 L^-1 d (its apply()). */
+int opmgpu_ilu0_factor(opmgpu_ctx* ctx);
+int opmgpu_ilu0_apply(opmgpu_ctx* ctx, const double* d3, double* v3);
+/* factors back in the caller's BSR layout: L strictly lower / U strictly upper blocks in the
+ * slots of the input pattern w.r.t. the ELIMINATION order, diagonal slot = inverted pivot. */
+int opmgpu_ilu0_get(opmgpu_ctx* ctx, double* val9);
+/* elimination position of every caller row (perm[row] = position) and its level. */
+int opmgpu_get_ordering(opmgpu_ctx* ctx, int32_t* position, int32_t* level, int32_t* nlevels);
+/* assembled reservoir system back to the host in caller numbering: residual (unscaled,
+ * equation-major 3*nc), and the matbal-scaled Jacobian in BSR. */
+int opmgpu_get_residual(opmgpu_ctx* ctx, double* r);
+int opmgpu_get_jacobian_nnzb(opmgpu_ctx* ctx, int32_t* nnzb);
+int opmgpu_get_jacobian_bsr(opmgpu_ctx* ctx, int32_t* rowptr, int32_t* col, double* val9);
+/* timing of device work: runs `reps` launches of one kernel on the context's stream between two
+ * hipEvents and returns the average milliseconds per launch (HIP events on the launch stream). */
+enum { OPMGPU_K_SPMV = 0, OPMGPU_K_ILU_APPLY = 1, OPMGPU_K_ILU_FACTOR = 2, OPMGPU_K_ASSEMBLE = 3,
+       OPMGPU_K_DOT = 4, OPMGPU_K_AXPY = 5, OPMGPU_K_PROPS = 6, OPMGPU_K_STREAM_COPY = 7 };
+int opmgpu_time_kernel(opmgpu_ctx* ctx, int kernel, int reps, double* ms_per_launch);
+/* elapsed device milliseconds of the last assemble / solve / update_state call. */
+int opmgpu_last_timings(opmgpu_ctx* ctx, double* assemble_ms, double* solve_ms, double* update_ms);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU (domain decomposition with a one-cell halo; mirrors owner/overlap of
+ * ParallelISTLInformation, ISTLSolver.hpp:286-298).  One process per GPU; the RCCL unique id
+ * is created on rank 0 and handed to the other ranks by the caller (torch.distributed / MPI).
+ * Cells [0, n_owned) of the rank-local grid are owned, [n_owned, nc) are ghosts.
+ * send lists name owned local cells, recv lists name ghost local cells, grouped per
+ * neighbour rank.
+ * ---------------------------------------------------------------------------------------- */
+#define OPMGPU_UNIQUE_ID_BYTES 128
+int opmgpu_comm_unique_id(uint8_t* id /*OPMGPU_UNIQUE_ID_BYTES*/);
+int opmgpu_comm_init(opmgpu_ctx* ctx, int rank, int nranks, const uint8_t* id, int32_t n_owned,
+                     int n_neigh, const int32_t* neigh_rank, const int32_t* send_ptr,
+                     const int32_t* send_cells, const int32_t* recv_ptr, const int32_t* recv_cells);
+
+/* library / build information */
+const char* opmgpu_version(void);
+int opmgpu_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPMGPU_H */

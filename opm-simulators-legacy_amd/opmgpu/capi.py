@@ -1,0 +1,147 @@
+"""ctypes view of include/opmgpu.h (the C ABI of libopmgpu.so).
+
+The library is the product; this module only loads it and declares signatures.  There is no
+CPU fallback: if the HIP extension is missing, `load()` raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libopmgpu.so")
+
+OK, EINVAL, ENODEVICE, ENUMERICAL, ELINSOLVE, EBREAKDOWN, ESINGULAR, ENOMEM, ECOMM = range(9)
+HC_GAS_ONLY, HC_GAS_AND_OIL, HC_OIL_ONLY = 0, 1, 2
+ORDER_NATURAL, ORDER_MULTICOLOR = 0, 1
+K_SPMV, K_ILU_APPLY, K_ILU_FACTOR, K_ASSEMBLE, K_DOT, K_AXPY, K_PROPS, K_STREAM_COPY = range(8)
+PERF_K = 36
+UNIQUE_ID_BYTES = 128
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_bp = C.POINTER(C.c_int8)
+
+
+class Grid(C.Structure):
+    _fields_ = [("nc", C.c_int32), ("nconn", C.c_int32), ("conn_cells", _ip), ("trans", _dp),
+                ("pv", _dp), ("z", _dp), ("gravity", C.c_double), ("thpres", _dp),
+                ("pvtnum", _ip), ("satnum", _ip)]
+
+
+class Tables(C.Structure):
+    _fields_ = [("n_pvt_regions", C.c_int32), ("n_sat_regions", C.c_int32),
+                ("has_disgas", C.c_int32), ("has_vapoil", C.c_int32),
+                ("surface_density", _dp), ("pvtw", _dp),
+                ("oil_node_ptr", _ip), ("oil_rs", _dp), ("oil_psat", _dp), ("oil_invb_sat", _dp),
+                ("oil_invbmu_sat", _dp), ("oil_col_ptr", _ip), ("oil_col_p", _dp),
+                ("oil_col_invb", _dp), ("oil_col_invbmu", _dp),
+                ("gas_node_ptr", _ip), ("gas_pg", _dp), ("gas_rvsat", _dp), ("gas_invb_sat", _dp),
+                ("gas_invbmu_sat", _dp), ("gas_col_ptr", _ip), ("gas_col_rv", _dp),
+                ("gas_col_invb", _dp), ("gas_col_invbmu", _dp),
+                ("swof_ptr", _ip), ("swof_sw", _dp), ("swof_krw", _dp), ("swof_krow", _dp),
+                ("swof_pcow", _dp),
+                ("sgof_ptr", _ip), ("sgof_sg", _dp), ("sgof_krg", _dp), ("sgof_krog", _dp),
+                ("sgof_pcgo", _dp),
+                ("rock_pref", C.c_double), ("rock_comp", C.c_double)]
+
+
+class Params(C.Structure):
+    _fields_ = [("dp_max_rel", C.c_double), ("ds_max", C.c_double), ("dr_max_rel", C.c_double),
+                ("max_residual_allowed", C.c_double), ("tolerance_mb", C.c_double),
+                ("tolerance_cnv", C.c_double), ("matbalscale", C.c_double * 3),
+                ("linear_solver_reduction", C.c_double), ("linear_solver_maxiter", C.c_int32),
+                ("ilu_relaxation", C.c_double), ("ilu_ordering", C.c_int32),
+                ("ignore_convergence_failure", C.c_int32)]
+
+
+def default_params(**over):
+    """BlackoilModelParameters.cpp:76-102 / FlowLinearSolverParameters defaults."""
+    p = Params()
+    p.dp_max_rel, p.ds_max, p.dr_max_rel = 0.3, 0.2, 1e9
+    p.max_residual_allowed, p.tolerance_mb, p.tolerance_cnv = 1e7, 1e-5, 1e-2
+    p.matbalscale[:] = [1.1169, 1.0031, 0.0031]
+    p.linear_solver_reduction, p.linear_solver_maxiter = 1e-2, 150
+    p.ilu_relaxation, p.ilu_ordering, p.ignore_convergence_failure = 0.9, ORDER_MULTICOLOR, 0
+    for k, v in over.items():
+        if k == "matbalscale":
+            p.matbalscale[:] = list(v)
+        else:
+            setattr(p, k, v)
+    return p
+
+
+def dptr(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def iptr(a):
+    return None if a is None else a.ctypes.data_as(_ip)
+
+
+def bptr(a):
+    return None if a is None else a.ctypes.data_as(_bp)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+SIGNATURES = {
+    # name: (restype, argtypes)
+    "opmgpu_default_params": (None, [C.POINTER(Params)]),
+    "opmgpu_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(Grid), C.POINTER(Tables), C.POINTER(Params)]),
+    "opmgpu_destroy": (None, [C.c_void_p]),
+    "opmgpu_last_error": (C.c_char_p, [C.c_void_p]),
+    "opmgpu_set_wells": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip]),
+    "opmgpu_set_state": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _bp]),
+    "opmgpu_get_state": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _bp]),
+    "opmgpu_assemble": (C.c_int, [C.c_void_p, C.c_double, C.c_int, _dp, _dp, _dp, _dp, _bp]),
+    "opmgpu_perf_props": (C.c_int, [C.c_void_p, _dp]),
+    "opmgpu_add_well_terms": (C.c_int, [C.c_void_p, _dp, C.c_int, _ip, _dp]),
+    "opmgpu_convergence": (C.c_int, [C.c_void_p, C.c_double, _dp, _dp, _dp, _dp, C.POINTER(C.c_int)]),
+    "opmgpu_solve": (C.c_int, [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int), _dp]),
+    "opmgpu_update_state": (C.c_int, [C.c_void_p, _dp, C.c_double]),
+    "opmgpu_create_solver": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(Params)]),
+    "opmgpu_solve_bsr": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _dp, _dp, C.c_int, _dp, C.POINTER(C.c_int), _dp]),
+    "opmgpu_load_bsr": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _dp, C.c_int]),
+    "opmgpu_spmv": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "opmgpu_ilu0_factor": (C.c_int, [C.c_void_p]),
+    "opmgpu_ilu0_apply": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "opmgpu_ilu0_get": (C.c_int, [C.c_void_p, _dp]),
+    "opmgpu_get_ordering": (C.c_int, [C.c_void_p, _ip, _ip, _ip]),
+    "opmgpu_get_residual": (C.c_int, [C.c_void_p, _dp]),
+    "opmgpu_get_jacobian_nnzb": (C.c_int, [C.c_void_p, _ip]),
+    "opmgpu_get_jacobian_bsr": (C.c_int, [C.c_void_p, _ip, _ip, _dp]),
+    "opmgpu_time_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp]),
+    "opmgpu_last_timings": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
+    "opmgpu_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "opmgpu_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint8), C.c_int32, C.c_int, _ip, _ip, _ip, _ip, _ip]),
+    "opmgpu_version": (C.c_char_p, []),
+    "opmgpu_device_count": (C.c_int, []),
+}
+
+_lib = None
+
+
+def load(path=None):
+    """Load libopmgpu.so and attach signatures.  Raises if the HIP extension is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "libopmgpu.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback)" % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

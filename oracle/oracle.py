@@ -1,0 +1,172 @@
+"""ctypes wrapper of the CPU oracle (TEST INFRASTRUCTURE -- see oracle/oracle.h).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG = os.path.join(os.path.dirname(_HERE), "opm-simulators-legacy_amd")
+if _PKG not in sys.path:
+    sys.path.insert(0, _PKG)
+from opmgpu import capi  # noqa: E402  (data schema only: Grid / Tables / Params structs)
+
+LIB = os.path.join(_HERE, "_build", "liboracle.so")
+NPROP = 23
+PROP_NAMES = ["p_w", "p_o", "p_g", "b_w", "b_o", "b_g", "mu_w", "mu_o", "mu_g", "kr_w", "kr_o", "kr_g",
+              "rho_w", "rho_o", "rho_g", "mob_w", "mob_o", "mob_g", "rs", "rv", "accum_w", "accum_o", "accum_g"]
+
+_dp, _ip, _bp = capi._dp, capi._ip, capi._bp
+_G, _T, _P = C.POINTER(capi.Grid), C.POINTER(capi.Tables), C.POINTER(capi.Params)
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        L = C.CDLL(LIB)
+        L.oracle_relperm.argtypes = [_T, C.c_int, _dp, _ip, _dp, _dp]
+        L.oracle_cappress.argtypes = [_T, C.c_int, _dp, _ip, _dp, _dp]
+        L.oracle_pvt.argtypes = [_T, C.c_int, C.c_int, _dp, _dp, _bp, _ip, _dp]
+        L.oracle_cell_props.argtypes = [_G, _T, _dp, _dp, _dp, _dp, _bp, _dp]
+        L.oracle_pattern.argtypes = [_G, C.c_int, _ip, _ip, _ip, _ip]
+        L.oracle_pattern.restype = C.c_int
+        L.oracle_assemble.argtypes = [_G, _T, C.c_double, C.c_int, _dp, _dp, _dp, _dp, _bp, _dp, _dp, _ip, _ip, _dp, _dp, _dp]
+        L.oracle_convergence.argtypes = [_G, _P, C.c_double, _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_int)]
+        L.oracle_convergence.restype = C.c_int
+        L.oracle_update_state.argtypes = [_G, _T, _P, _dp, _dp, _dp, _dp, _dp, _bp]
+        L.oracle_spmv.argtypes = [C.c_int, _ip, _ip, _dp, _dp, _dp, C.c_int]
+        L.oracle_ilu0.argtypes = [C.c_int, _ip, _ip, _dp, _ip, C.c_int, _dp]
+        L.oracle_ilu0.restype = C.c_int
+        L.oracle_ilu0_apply.argtypes = [C.c_int, _ip, _ip, _dp, _ip, C.c_double, C.c_int, _dp, _dp]
+        L.oracle_bicgstab_ilu0.argtypes = [C.c_int, _ip, _ip, _dp, _dp, _ip, _P, C.c_int, _dp, C.POINTER(C.c_int), _dp, _dp, C.c_int, C.POINTER(C.c_int)]
+        L.oracle_bicgstab_ilu0.restype = C.c_int
+        L.oracle_set_threads.argtypes = [C.c_int]
+        L.oracle_get_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def set_threads(n):
+    lib().oracle_set_threads(int(n))
+
+
+def relperm(tables, s, satnum=None):
+    s = capi.f64(s).reshape(-1, 3)
+    n = s.shape[0]
+    kr, dkr = np.zeros((n, 3)), np.zeros((n, 9))
+    lib().oracle_relperm(C.byref(tables.struct()), n, capi.dptr(s), capi.iptr(satnum), capi.dptr(kr), capi.dptr(dkr))
+    return kr, dkr
+
+
+def cappress(tables, s, satnum=None):
+    s = capi.f64(s).reshape(-1, 3)
+    n = s.shape[0]
+    pc, dpc = np.zeros((n, 3)), np.zeros((n, 9))
+    lib().oracle_cappress(C.byref(tables.struct()), n, capi.dptr(s), capi.iptr(satnum), capi.dptr(pc), capi.dptr(dpc))
+    return pc, dpc
+
+
+PVT_WHICH = {"bWat": 0, "bOil": 1, "bGas": 2, "muWat": 3, "muOil": 4, "muGas": 5, "rsSat": 6, "rvSat": 7}
+
+
+def pvt(tables, which, p, r=None, saturated=None, pvtnum=None):
+    p = capi.f64(p)
+    n = p.size
+    r = None if r is None else capi.f64(r)
+    sat = None if saturated is None else np.ascontiguousarray(saturated, dtype=np.int8)
+    out = np.zeros((n, 3))
+    lib().oracle_pvt(C.byref(tables.struct()), PVT_WHICH[which], n, capi.dptr(p), capi.dptr(r), capi.bptr(sat), capi.iptr(pvtnum), capi.dptr(out))
+    return out
+
+
+def cell_props(grid, tables, st):
+    out = np.zeros((grid.nc, NPROP, 4))
+    lib().oracle_cell_props(C.byref(grid.struct()), C.byref(tables.struct()), capi.dptr(st.p), capi.dptr(st.sat),
+                            capi.dptr(st.rs), capi.dptr(st.rv), capi.bptr(st.hc), capi.dptr(out))
+    return out
+
+
+def pattern(grid, well_connpos=None, well_cells=None):
+    nw = 0 if well_connpos is None else len(well_connpos) - 1
+    wp = None if well_connpos is None else capi.i32(well_connpos)
+    wc = None if well_cells is None else capi.i32(well_cells)
+    nnz = lib().oracle_pattern(C.byref(grid.struct()), nw, capi.iptr(wp), capi.iptr(wc), None, None)
+    rowptr, col = np.zeros(grid.nc + 1, np.int32), np.zeros(nnz, np.int32)
+    lib().oracle_pattern(C.byref(grid.struct()), nw, capi.iptr(wp), capi.iptr(wc), capi.iptr(rowptr), capi.iptr(col))
+    return rowptr, col
+
+
+def assemble(grid, tables, dt, st, rowptr, col, scale=(1.0, 1.0, 1.0), accum0=None):
+    """Returns r (3*nc eq-major, unscaled), val9 (scaled rows), accum0, binv."""
+    nc = grid.nc
+    initial = accum0 is None
+    accum0 = np.zeros(3 * nc) if initial else capi.f64(accum0)
+    r, val, binv = np.zeros(3 * nc), np.zeros((col.size, 9)), np.zeros(3 * nc)
+    sc = capi.f64(scale)
+    lib().oracle_assemble(C.byref(grid.struct()), C.byref(tables.struct()), float(dt), int(initial), capi.dptr(st.p),
+                          capi.dptr(st.sat), capi.dptr(st.rs), capi.dptr(st.rv), capi.bptr(st.hc), capi.dptr(sc),
+                          capi.dptr(accum0), capi.iptr(rowptr), capi.iptr(col), capi.dptr(r), capi.dptr(val), capi.dptr(binv))
+    return r, val, accum0, binv
+
+
+def convergence(grid, params, dt, r, binv):
+    B, CNV, MB, linf = np.zeros(3), np.zeros(3), np.zeros(3), np.zeros(3)
+    conv = C.c_int(0)
+    st = lib().oracle_convergence(C.byref(grid.struct()), C.byref(params), float(dt), capi.dptr(capi.f64(r)), capi.dptr(capi.f64(binv)),
+                                  capi.dptr(B), capi.dptr(CNV), capi.dptr(MB), capi.dptr(linf), C.byref(conv))
+    return st, B, CNV, MB, linf, bool(conv.value)
+
+
+def update_state(grid, tables, params, dx, st):
+    out = st.copy()
+    dx = capi.f64(dx)
+    lib().oracle_update_state(C.byref(grid.struct()), C.byref(tables.struct()), C.byref(params), capi.dptr(dx), capi.dptr(out.p),
+                              capi.dptr(out.sat), capi.dptr(out.rs), capi.dptr(out.rv), capi.bptr(out.hc))
+    return out
+
+
+def spmv(rowptr, col, val9, x3, single=False):
+    nb = rowptr.size - 1
+    y = np.zeros(3 * nb)
+    lib().oracle_spmv(nb, capi.iptr(rowptr), capi.iptr(col), capi.dptr(capi.f64(val9)), capi.dptr(capi.f64(x3)), capi.dptr(y), int(single))
+    return y
+
+
+def ilu0(rowptr, col, val9, position=None, single=False):
+    nb = rowptr.size - 1
+    lu = np.zeros((col.size, 9))
+    pos = None if position is None else capi.i32(position)
+    st = lib().oracle_ilu0(nb, capi.iptr(rowptr), capi.iptr(col), capi.dptr(capi.f64(val9)), capi.iptr(pos), int(single), capi.dptr(lu))
+    return st, lu
+
+
+def ilu0_apply(rowptr, col, lu9, d3, position=None, relax=0.9, single=False):
+    nb = rowptr.size - 1
+    v = np.zeros(3 * nb)
+    pos = None if position is None else capi.i32(position)
+    lib().oracle_ilu0_apply(nb, capi.iptr(rowptr), capi.iptr(col), capi.dptr(capi.f64(lu9)), capi.iptr(pos), float(relax), int(single),
+                            capi.dptr(capi.f64(d3)), capi.dptr(v))
+    return v
+
+
+def bicgstab(rowptr, col, val9, rhs3, params, position=None, single=False, nhist=0):
+    nb = rowptr.size - 1
+    x = np.zeros(3 * nb)
+    it, red, nh = C.c_int(0), C.c_double(0), C.c_int(0)
+    hist = np.zeros(max(nhist, 1))
+    pos = None if position is None else capi.i32(position)
+    st = lib().oracle_bicgstab_ilu0(nb, capi.iptr(rowptr), capi.iptr(col), capi.dptr(capi.f64(val9)), capi.dptr(capi.f64(rhs3)),
+                                    capi.iptr(pos), C.byref(params), int(single), capi.dptr(x), C.byref(it), C.byref(red),
+                                    capi.dptr(hist) if nhist else None, nhist, C.byref(nh))
+    return st, x, it.value, red.value, hist[:min(nh.value, nhist)]
