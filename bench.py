@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- Mcell-updates/s per Newton step (assembly + solve) on MI355X, with the SpMV roofline
+and the CPU baseline timed beside it.
+
+A "step" is one Newton iteration of the fully-implicit black-oil model on the synthetic
+100x100x100 three-phase deck (BASELINE.json configs[2], the configuration the metric is quoted
+on): assemble -> getConvergence -> solveJacobianSystem (block-ILU0 + BiCGStab, float because
+dt < 20 d exactly as the reference switches) -> updateState, state resident in HBM.  Time steps
+follow each other like in the simulator: when a step converges the next one starts from the
+updated state with a fresh accum0.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "opm-simulators-legacy_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
+
+
+def spmv_bytes(nb, nnzb, scalar_bytes):
+    """nnzb*(9*S + 4) + (nb+1)*4 + nb*3*S (x read once) + nb*3*S (y write)."""
+    return nnzb * (9 * scalar_bytes + 4) + (nb + 1) * 4 + 2 * nb * 3 * scalar_bytes
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nx", type=int, default=100)
+    ap.add_argument("--ny", type=int, default=100)
+    ap.add_argument("--nz", type=int, default=100)
+    ap.add_argument("--dt-days", type=float, default=5.0)
+    ap.add_argument("--ordering", choices=["multicolor", "natural"], default="multicolor")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=1)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from opmgpu import capi, decks
+    from opmgpu.model import GpuBlackoilModel, GpuNewtonIteration
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    ordering = capi.ORDER_MULTICOLOR if args.ordering == "multicolor" else capi.ORDER_NATURAL
+    prm = capi.default_params(ilu_ordering=ordering)
+    tab = decks.satfunc_standard_tables()
+    dt = args.dt_days * decks.DAY
+    single = dt < 20 * decks.DAY            # BlackoilModelBase_impl.hpp:284
+
+    if world > 1:
+        from opmgpu import partition
+        model, grid, st, info = partition.build_distributed_model(args.nx, args.ny, args.nz, tab, prm, rank, world, local_rank)
+    else:
+        grid = decks.cartesian_grid(args.nx, args.ny, args.nz, lognormal_sigma=0.5, seed=12345)
+        st = decks.initial_state(grid, tab, perturb=0.002, seed=12345)
+        model = GpuBlackoilModel(grid, tab, prm, device=local_rank)
+        info = {"n_owned": grid.nc, "n_global": grid.nc}
+    nc_global = info["n_global"]
+
+    # ---- timed region: exactly K Newton iterations ----
+    model.prepareStep(dt, st)
+    it = 0
+    newton_total, lin_total, steps_done = 0, 0, 0
+    t_asm = t_sol = t_upd = 0.0
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    t0 = None
+    for step in range(args.warmup + args.steps):
+        if step == args.warmup:
+            barrier()
+            t0 = time.perf_counter()
+            lin_total = 0
+            t_asm = t_sol = t_upd = 0.0
+        converged, lin = model.nonlinearIteration(it)
+        a, s, u = model.timings()
+        t_asm += a; t_sol += s; t_upd += u
+        lin_total += lin
+        it += 1
+        if (converged and it >= 1) or it > 10:
+            model.prepareStep(dt)           # next time step from the resident state
+            it = 0
+            steps_done += 1
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = nc_global / (elapsed / args.steps) / 1e6
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel: the 3x3-block SpMV, HIP events on the launch stream ----
+        nb = grid.nc
+        rowptr, col, _ = model.jacobian()
+        nnzb = int(col.size)
+        roof = {}
+        for name, sp in (("f32", True), ("f64", False)):
+            # micro-run on the same matrix in a solver-only context (its own stream), values = assembled Jacobian
+            _, _, val = model.jacobian()
+            s = GpuNewtonIteration(prm, device=local_rank)
+            s.load(rowptr, col, val, sp)
+            ms = s.time_kernel(capi.K_SPMV, reps=50)
+            s.ilu0_factor()
+            ms_ilu = s.time_kernel(capi.K_ILU_APPLY, reps=20)
+            ms_copy = s.time_kernel(capi.K_STREAM_COPY, reps=20)
+            sb = 4 if sp else 8
+            nbytes = spmv_bytes(nb, nnzb, sb)
+            roof[name] = {"bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "k_spmv<%s,0>" % ("float" if sp else "double"),
+                          "ms_per_launch": ms, "algorithmic_bytes": nbytes,
+                          "ilu0_apply_ms": ms_ilu, "stream_copy_GBs": 2 * nnzb * 9 * sb / (ms_copy * 1e-3) / 1e9}
+            s.close()
+            del val
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_spmv.json")
+        if os.path.exists(pmc):
+            try:
+                d = json.load(open(pmc))
+                for name in roof:
+                    roof[name]["traffic"] = d.get(name)
+            except Exception:
+                pass
+        main_roof = roof["f32" if single else "f64"]
+
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(args, grid, tab, st, prm, dt, single)
+
+        out = {
+            "metric": "Mcell-updates/sec per Newton step (assembly+solve)", "value": value, "unit": "Mcell-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64 assembly + %s linear solve" % ("f32" if single else "f64"), "data": "synthetic",
+            "config": {"workload": "cart%dx%dx%d_3phase_blackoil" % (args.nx, args.ny, args.nz), "cells": nc_global, "nnzb": nnzb,
+                       "dt_days": args.dt_days, "ilu0_ordering": args.ordering, "linear_iterations_per_newton": lin_total / args.steps,
+                       "time_steps_completed": steps_done, "tables": "tests/satfuncStandard.DATA PROPS (reference's own test deck)",
+                       "parallelism": "1 GPU" if world == 1 else "domain decomposition x%d, RCCL halo" % world},
+            "breakdown_ms_per_step": {"assemble": t_asm / args.steps, "linear_solve": t_sol / args.steps, "update": t_upd / args.steps},
+            "roofline": main_roof, "roofline_f64_spmv": roof["f64"], "roofline_f32_spmv": roof["f32"],
+            "cpu_baseline": cpu,
+        }
+    model.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def cpu_baseline(args, grid, tab, st, prm, dt, single):
+    """The oracle (CPU restatement of the reference's algorithm: AD assembly into BSR, natural-order
+    block-ILU0, BiCGStab, same precision switch) timed on the host cores for a bounded sample:
+    ONE Newton iteration of the same deck from the same initial state."""
+    import numpy as np
+    from oracle import oracle as orc
+    from opmgpu import capi
+    orc.set_threads(args.cpu_threads)
+    nc = grid.nc
+    scale = np.asarray(prm.matbalscale[:])
+    t0 = time.perf_counter()
+    rowptr, col = orc.pattern(grid)
+    t1 = time.perf_counter()
+    r, val, acc0, binv = orc.assemble(grid, tab, dt, st, rowptr, col, scale=tuple(scale))
+    t2 = time.perf_counter()
+    b = np.ascontiguousarray((r * np.repeat(scale, nc)).reshape(3, nc).T).ravel()
+    prm_nat = capi.default_params(ilu_ordering=capi.ORDER_NATURAL)
+    sto, x, it, red, _ = orc.bicgstab(rowptr, col, val, b, prm_nat, position=None, single=single)
+    t3 = time.perf_counter()
+    dx = np.ascontiguousarray(x.reshape(nc, 3).T).ravel()
+    orc.update_state(grid, tab, prm, dx, st)
+    t4 = time.perf_counter()
+    tot = (t2 - t1) + (t3 - t2) + (t4 - t3)
+    return {"value": nc / tot / 1e6, "unit": "Mcell-updates/s", "cores": args.cpu_threads, "kind": "port",
+            "sample": "1 Newton iteration (assembly %.2fs + natural-order ILU0/BiCGStab %s %d its %.2fs + update %.2fs) of the same deck and initial state"
+                      % (t2 - t1, "f32" if single else "f64", it, t3 - t2, t4 - t3),
+            "linear_iterations": it, "status": sto}
+
+
+if __name__ == "__main__":
+    main()

@@ -237,6 +237,11 @@ int opmgpu_comm_init(opmgpu_ctx* ctx, int rank, int nranks, const uint8_t* id, i
                      int n_neigh, const int32_t* neigh_rank, const int32_t* send_ptr,
                      const int32_t* send_cells, const int32_t* recv_ptr, const int32_t* recv_cells);
 
+/* Host-only planning entry (no device needed): elimination position and level of every row for
+ * the given ordering -- the same plan opmgpu_get_ordering reports for a loaded matrix. */
+int opmgpu_plan_ordering(int nb, const int32_t* rowptr, const int32_t* col, int ordering,
+                         int32_t* position, int32_t* level, int32_t* nlevels);
+
 /* library / build information */
 const char* opmgpu_version(void);
 int opmgpu_device_count(void);

@@ -1,0 +1,839 @@
+// blackoil.hip -- gfx950 kernels for the black-oil assembly / convergence / update (see blackoil.hpp).
+//
+// Two kernels per assembly, both one-thread-per-cell over the solver's internal (level-major)
+// numbering so that every per-cell plane access of a wavefront is one contiguous segment:
+//   k_cell_props : state -> PVT / relperm / pc with d/d(P,Sw,Xvar); writes the 37 "face input"
+//                  planes, the accumulation part of the residual and of the diagonal block.
+//   k_flux       : per row, walks the row's SELL slots; for every connection recomputes the TPFA
+//                  flux from both cells' planes (each face is evaluated from both sides: 2x the
+//                  flops, zero atomics, each Jacobian block written exactly once, coalesced).
+// Algorithmic HBM bytes per cell are given in DESIGN.md; the Jacobian write dominates.
+#include "blackoil.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace opmgpu {
+
+// ------------------------------------------------------------------------------------------
+// device-side fluid property evaluation.  Written independently of oracle/ (explicit chain rule,
+// branch-free linear scans over the small tables instead of bisection).
+// ------------------------------------------------------------------------------------------
+struct V4 { double v, p, w, x; };      // value, d/dP, d/dSw, d/dXvar
+
+__device__ __forceinline__ V4 mk(double v, double p, double w, double x) { V4 r; r.v = v; r.p = p; r.w = w; r.x = x; return r; }
+__device__ __forceinline__ V4 vmul(const V4& a, const V4& b) { return mk(a.v * b.v, a.p * b.v + a.v * b.p, a.w * b.v + a.v * b.w, a.x * b.v + a.v * b.x); }
+__device__ __forceinline__ V4 vadd(const V4& a, const V4& b) { return mk(a.v + b.v, a.p + b.p, a.w + b.w, a.x + b.x); }
+__device__ __forceinline__ V4 vscale(double s, const V4& a) { return mk(s * a.v, s * a.p, s * a.w, s * a.x); }
+__device__ __forceinline__ V4 vdiv(const V4& a, const V4& b)
+{
+    const double q = a.v / b.v, ib = 1.0 / b.v;
+    return mk(q, (a.p - q * b.p) * ib, (a.w - q * b.w) * ib, (a.x - q * b.x) * ib);
+}
+// f(g): f value, df = f'(g.v)
+__device__ __forceinline__ V4 vchain(double f, double df, const V4& g) { return mk(f, df * g.p, df * g.w, df * g.x); }
+__device__ __forceinline__ V4 vchain2(double f, double dfa, const V4& a, double dfb, const V4& b)
+{
+    return mk(f, dfa * a.p + dfb * b.p, dfa * a.w + dfb * b.w, dfa * a.x + dfb * b.x);
+}
+
+// saturation tables: constant extrapolation; LEFT = segment x[i] < xv <= x[i+1] (SWOF by Sw),
+// RIGHT = x[i] <= xv < x[i+1] (SGOF by Sg: opm-material tabulates those against So).
+template <bool RIGHT>
+__device__ __forceinline__ void sat_eval(const double* __restrict__ x, const double* __restrict__ y, int n, double xv, double& f, double& df)
+{
+    if (xv <= x[0]) { f = y[0]; df = 0.0; return; }
+    if (xv >= x[n - 1]) { f = y[n - 1]; df = 0.0; return; }
+    int i = 0;
+    for (int k = 1; k < n - 1; ++k) i += (RIGHT ? (x[k] <= xv) : (x[k] < xv)) ? 1 : 0;
+    df = (y[i + 1] - y[i]) / (x[i + 1] - x[i]);
+    f = y[i] + df * (xv - x[i]);
+}
+// PVT tables: linear extrapolation, opm-material Tabulated1DFunction segment rule
+__device__ __forceinline__ int pvt_seg(const double* __restrict__ x, int n, double xv)
+{
+    int i = 0;
+    if (n > 2) i = (x[1] < xv) ? 1 : 0;
+    for (int k = 2; k <= n - 2; ++k) i += (x[k] <= xv) ? 1 : 0;
+    return i;
+}
+__device__ __forceinline__ void pvt1(const double* __restrict__ x, const double* __restrict__ y, int n, double xv, double& f, double& df)
+{
+    const int i = pvt_seg(x, n, xv);
+    df = (y[i + 1] - y[i]) / (x[i + 1] - x[i]);
+    f = y[i] + df * (xv - x[i]);
+}
+// UniformXTabulated2DFunction::eval: f(xnode, ycol)
+__device__ __forceinline__ void pvt2(const double* __restrict__ xs, int nn, const int32_t* __restrict__ cp, const double* __restrict__ cy,
+                                     const double* __restrict__ cv, double xv, double yv, double& f, double& dfx, double& dfy)
+{
+    const int i = pvt_seg(xs, nn, xv);
+    const double h = xs[i + 1] - xs[i];
+    const double alpha = (xv - xs[i]) / h;
+    double s1, d1, s2, d2;
+    pvt1(cy + cp[i], cv + cp[i], cp[i + 1] - cp[i], yv, s1, d1);
+    pvt1(cy + cp[i + 1], cv + cp[i + 1], cp[i + 2] - cp[i + 1], yv, s2, d2);
+    f = s1 * (1.0 - alpha) + s2 * alpha;
+    dfx = (s2 - s1) / h;
+    dfy = d1 * (1.0 - alpha) + d2 * alpha;
+}
+
+__device__ __forceinline__ void rs_sat_d(const opmgpu_tables& T, int reg, double p, double& f, double& df)
+{
+    if (!T.has_disgas) { f = 0.0; df = 0.0; return; }
+    const int a = T.oil_node_ptr[reg];
+    pvt1(T.oil_psat + a, T.oil_rs + a, T.oil_node_ptr[reg + 1] - a, p, f, df);
+}
+__device__ __forceinline__ void rv_sat_d(const opmgpu_tables& T, int reg, double p, double& f, double& df)
+{
+    if (!T.has_vapoil) { f = 0.0; df = 0.0; return; }
+    const int a = T.gas_node_ptr[reg];
+    pvt1(T.gas_pg + a, T.gas_rvsat + a, T.gas_node_ptr[reg + 1] - a, p, f, df);
+}
+
+struct CellEval {
+    V4 pw, pg, rs, rv, sw, so, sg;
+    V4 b[3], mob[3], rho[3], accum[3];
+};
+
+// SolutionState + ReservoirResidualQuant of one cell (BlackoilModelBase_impl.hpp:614-751, 1484-1497, 2009-2027)
+__device__ void eval_cell(const opmgpu_tables& T, int preg, int sreg, double p, double sw_, double sg_, double rs_, double rv_, int hc, CellEval& q)
+{
+    const bool isSg = hc == OPMGPU_HC_GAS_AND_OIL, isRs = hc == OPMGPU_HC_OIL_ONLY, isRv = hc == OPMGPU_HC_GAS_ONLY;
+    const bool freeOil = isSg || isRs, freeGas = isSg || isRv;
+    const V4 P = mk(p, 1, 0, 0), W = mk(sw_, 0, 1, 0);
+    const V4 X = mk(isRs ? rs_ : (isRv ? rv_ : sg_), 0, 0, 1);
+    // sg = isSg*X + isRv*(1 - W);  so = 1 - W - sg
+    V4 sg = mk(0, 0, 0, 0);
+    if (isSg) sg = X;
+    else if (isRv) sg = mk(1.0 - sw_, 0, -1, 0);
+    const V4 so = mk((1.0 - sw_) - sg.v, 0, -1.0 - sg.w, -sg.x);
+    q.sw = W; q.so = so; q.sg = sg;
+    // saturation functions
+    const int wa = T.swof_ptr[sreg], nw = T.swof_ptr[sreg + 1] - wa;
+    const int ga = T.sgof_ptr[sreg], ng = T.sgof_ptr[sreg + 1] - ga;
+    const double* xsw = T.swof_sw + wa; const double* xsg = T.sgof_sg + ga;
+    double f, df;
+    sat_eval<false>(xsw, T.swof_pcow + wa, nw, sw_, f, df);
+    q.pw = mk(p - f, 1, -df, 0);
+    sat_eval<true>(xsg, T.sgof_pcgo + ga, ng, sg.v, f, df);
+    q.pg = mk(p + f, 1, df * sg.w, df * sg.x);
+    sat_eval<false>(xsw, T.swof_krw + wa, nw, sw_, f, df);
+    const V4 krw = mk(f, 0, df, 0);
+    sat_eval<true>(xsg, T.sgof_krg + ga, ng, sg.v, f, df);
+    const V4 krg = vchain(f, df, sg);
+    V4 kro;
+    {   // EclDefaultMaterial::krn
+        const double swco = xsw[0];
+        const V4 swp = (sw_ > swco) ? W : mk(swco, 0, 0, 0);
+        const V4 swow = vadd(sg, swp);
+        sat_eval<false>(xsw, T.swof_krow + wa, nw, swow.v, f, df);
+        const V4 kow = vchain(f, df, swow);
+        const V4 sgeq = mk(swow.v - swco, swow.p, swow.w, swow.x);
+        sat_eval<true>(xsg, T.sgof_krog + ga, ng, sgeq.v, f, df);
+        const V4 kgo = vchain(f, df, sgeq);
+        const double eps = 1e-5;
+        const V4 den = sgeq;                                    // Sw_ow - Swco
+        const V4 num = vadd(vmul(sg, kgo), vmul(mk(swp.v - swco, swp.p, swp.w, swp.x), kow));
+        if (swow.v - swco < eps) {
+            const V4 k2 = vscale(0.5, vadd(kow, kgo));
+            if (swow.v - swco > eps / 2) {
+                const V4 k1 = vdiv(num, den);
+                const V4 al = mk((eps - den.v) / (eps / 2), -den.p / (eps / 2), -den.w / (eps / 2), -den.x / (eps / 2));
+                const V4 oma = mk(1.0 - al.v, -al.p, -al.w, -al.x);
+                kro = vadd(vmul(k2, al), vmul(k1, oma));
+            } else kro = k2;
+        } else kro = vdiv(num, den);
+    }
+    // rs / rv
+    rs_sat_d(T, preg, p, f, df);
+    q.rs = (T.has_disgas && isRs) ? X : mk(f, df, 0, 0);
+    rv_sat_d(T, preg, q.pg.v, f, df);
+    q.rv = (T.has_vapoil && isRv) ? X : vchain(f, df, q.pg);
+    // water PVT (ConstantCompressibilityWaterPvt)
+    V4 mu[3];
+    {
+        const double* w = T.pvtw + 5 * preg;
+        const double Xc = w[2] * (q.pw.v - w[0]);
+        const double bw = (1.0 + Xc * (1.0 + Xc / 2.0)) / w[1];
+        const double dbw = w[2] * (1.0 + Xc) / w[1];
+        q.b[0] = vchain(bw, dbw, q.pw);
+        const double c = w[2] - w[4];
+        const double Y = c * (q.pw.v - w[0]);
+        const double den = 1.0 + Y * (1.0 + Y / 2.0);
+        const double BM = w[3] * w[1];
+        mu[0] = vchain(BM * bw / den, BM * (dbw * den - bw * c * (1.0 + Y)) / (den * den), q.pw);
+    }
+    // oil PVT (LiveOilPvt; saturated branch when free gas is present or no DISGAS)
+    {
+        const int a = T.oil_node_ptr[preg], nn = T.oil_node_ptr[preg + 1] - a;
+        double ib, dibp, dibr = 0.0, ibm, dibmp, dibmr = 0.0;
+        if (freeGas || !T.has_disgas) {
+            pvt1(T.oil_psat + a, T.oil_invb_sat + a, nn, p, ib, dibp);
+            pvt1(T.oil_psat + a, T.oil_invbmu_sat + a, nn, p, ibm, dibmp);
+        } else {
+            pvt2(T.oil_rs + a, nn, T.oil_col_ptr + a, T.oil_col_p, T.oil_col_invb, q.rs.v, p, ib, dibr, dibp);
+            pvt2(T.oil_rs + a, nn, T.oil_col_ptr + a, T.oil_col_p, T.oil_col_invbmu, q.rs.v, p, ibm, dibmr, dibmp);
+        }
+        q.b[1] = vchain2(ib, dibp, P, dibr, q.rs);
+        const double m = ib / ibm;
+        mu[1] = vchain2(m, (dibp - m * dibmp) / ibm, P, (dibr - m * dibmr) / ibm, q.rs);
+    }
+    // gas PVT (WetGasPvt; saturated branch when free oil is present or no VAPOIL)
+    {
+        const int a = T.gas_node_ptr[preg], nn = T.gas_node_ptr[preg + 1] - a;
+        double ib, dibp, dibr = 0.0, ibm, dibmp, dibmr = 0.0;
+        if (freeOil || !T.has_vapoil) {
+            pvt1(T.gas_pg + a, T.gas_invb_sat + a, nn, q.pg.v, ib, dibp);
+            pvt1(T.gas_pg + a, T.gas_invbmu_sat + a, nn, q.pg.v, ibm, dibmp);
+        } else {
+            pvt2(T.gas_pg + a, nn, T.gas_col_ptr + a, T.gas_col_rv, T.gas_col_invb, q.pg.v, q.rv.v, ib, dibp, dibr);
+            pvt2(T.gas_pg + a, nn, T.gas_col_ptr + a, T.gas_col_rv, T.gas_col_invbmu, q.pg.v, q.rv.v, ibm, dibmp, dibmr);
+        }
+        q.b[2] = vchain2(ib, dibp, q.pg, dibr, q.rv);
+        const double m = ib / ibm;
+        mu[2] = vchain2(m, (dibp - m * dibmp) / ibm, q.pg, (dibr - m * dibmr) / ibm, q.rv);
+    }
+    // densities, mobilities (tr_mult == 1: no ROCKTAB)
+    const double* rhos = T.surface_density + 3 * preg;
+    q.rho[0] = vscale(rhos[0], q.b[0]);
+    q.rho[1] = vadd(vscale(rhos[1], q.b[1]), vscale(rhos[2], vmul(q.rs, q.b[1])));
+    q.rho[2] = vadd(vscale(rhos[2], q.b[2]), vscale(rhos[1], vmul(q.rv, q.b[2])));
+    q.mob[0] = vdiv(krw, mu[0]); q.mob[1] = vdiv(kro, mu[1]); q.mob[2] = vdiv(krg, mu[2]);
+    // accumulation with rock compressibility (RockCompressibility.cpp:86-125)
+    V4 pvm = mk(1, 0, 0, 0);
+    if (T.rock_comp != 0.0) {
+        const double cp = T.rock_comp * (p - T.rock_pref);
+        pvm = mk(1.0 + cp + 0.5 * cp * cp, T.rock_comp + cp * T.rock_comp, 0, 0);
+    }
+    const V4 aw = vmul(vmul(pvm, q.b[0]), W);
+    const V4 ao = vmul(vmul(pvm, q.b[1]), so);
+    const V4 ag = vmul(vmul(pvm, q.b[2]), sg);
+    q.accum[0] = aw;
+    q.accum[1] = vadd(ao, vmul(q.rv, ag));
+    q.accum[2] = vadd(ag, vmul(q.rs, ao));
+}
+
+// ------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void st4(double* __restrict__ props, int plane, long nbp, int row, const V4& a)
+{
+    props[long(plane) * nbp + row] = a.v; props[long(plane + 1) * nbp + row] = a.p;
+    props[long(plane + 2) * nbp + row] = a.w; props[long(plane + 3) * nbp + row] = a.x;
+}
+
+__global__ __launch_bounds__(kBlock) void k_cell_props(int nb, int nbp, opmgpu_tables T, const int32_t* __restrict__ pvtnum,
+                                                       const int32_t* __restrict__ satnum, const double* __restrict__ pv,
+                                                       const double* __restrict__ p, const double* __restrict__ sw, const double* __restrict__ sg,
+                                                       const double* __restrict__ rs, const double* __restrict__ rv, const int8_t* __restrict__ hc,
+                                                       double inv_dt, int initial, double s0, double s1, double s2,
+                                                       const int32_t* __restrict__ slice_ptr, const int16_t* __restrict__ nlower,
+                                                       double* __restrict__ props, double* __restrict__ accum0, double* __restrict__ R,
+                                                       double* __restrict__ binv, double* __restrict__ A)
+{
+    const int row = blockIdx.x * kBlock + threadIdx.x;
+    if (row >= nb) return;
+    CellEval q;
+    eval_cell(T, pvtnum[row], satnum[row], p[row], sw[row], sg[row], rs[row], rv[row], hc[row], q);
+    props[long(PL_PW) * nbp + row] = q.pw.v; props[long(PL_PG) * nbp + row] = q.pg.v;
+    props[long(PL_DPW_W) * nbp + row] = q.pw.w; props[long(PL_DPG_W) * nbp + row] = q.pg.w; props[long(PL_DPG_X) * nbp + row] = q.pg.x;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        st4(props, PL_RHO + 4 * a, nbp, row, q.rho[a]);
+        st4(props, PL_U + 4 * a, nbp, row, vmul(q.b[a], q.mob[a]));
+        binv[long(a) * nbp + row] = 1.0 / q.b[a].v;
+    }
+    st4(props, PL_RS, nbp, row, q.rs); st4(props, PL_RV, nbp, row, q.rv);
+    // accumulation term pvdt * (accum1 - accum0) and its diagonal-block contribution
+    const double pvdt = pv[row] * inv_dt;
+    const double scale[3] = { s0, s1, s2 };
+    double* d = A + long(slice_ptr[row >> 6] + nlower[row]) * 576 + (row & 63);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (initial) accum0[long(a) * nbp + row] = q.accum[a].v;
+        const double a0 = initial ? q.accum[a].v : accum0[long(a) * nbp + row];
+        R[long(a) * nbp + row] = pvdt * (q.accum[a].v - a0);
+        d[(3 * a) * 64] = scale[a] * pvdt * q.accum[a].p;
+        d[(3 * a + 1) * 64] = scale[a] * pvdt * q.accum[a].w;
+        d[(3 * a + 2) * 64] = scale[a] * pvdt * q.accum[a].x;
+    }
+}
+
+struct PhaseIn { double p, dpw, dpx, rho, drp, drw, drx; };    // dp/dP == 1 for every phase
+
+__device__ __forceinline__ PhaseIn load_phase(const double* __restrict__ props, const double* __restrict__ pstate, long nbp, int c, int a)
+{
+    PhaseIn r;
+    if (a == 0) { r.p = props[long(PL_PW) * nbp + c]; r.dpw = props[long(PL_DPW_W) * nbp + c]; r.dpx = 0.0; }
+    else if (a == 1) { r.p = pstate[c]; r.dpw = 0.0; r.dpx = 0.0; }
+    else { r.p = props[long(PL_PG) * nbp + c]; r.dpw = props[long(PL_DPG_W) * nbp + c]; r.dpx = props[long(PL_DPG_X) * nbp + c]; }
+    const double* q = props + long(PL_RHO + 4 * a) * nbp + c;
+    r.rho = q[0]; r.drp = q[nbp]; r.drw = q[2 * nbp]; r.drx = q[3 * nbp];
+    return r;
+}
+__device__ __forceinline__ V4 load4(const double* __restrict__ props, int plane, long nbp, int c)
+{
+    const double* q = props + long(plane) * nbp + c;
+    return mk(q[0], q[nbp], q[2 * nbp], q[3 * nbp]);
+}
+
+// TPFA flux residual + 3x3 Jacobian blocks, one thread per row
+// (computeMassFlux :1484-1512, applyThresholdPressures :1518-1545, UpwindSelector AutoDiffHelpers.hpp:204-221,
+//  rs/rv cross terms :889-906, div = ngrad^T)
+__global__ __launch_bounds__(kBlock) void k_flux(int nb, int nbp, const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
+                                                 const int16_t* __restrict__ rowlen, const int16_t* __restrict__ nlower,
+                                                 const int32_t* __restrict__ conn_code, const double* __restrict__ trans,
+                                                 const double* __restrict__ gdz, const double* __restrict__ thpres,
+                                                 const double* __restrict__ pstate, const double* __restrict__ props,
+                                                 double s0, double s1, double s2, double* __restrict__ R, double* __restrict__ A)
+{
+    const int row = blockIdx.x * kBlock + threadIdx.x;
+    if (row >= nb) return;
+    const int base = slice_ptr[row >> 6], lane = row & 63, nl = nlower[row], len = rowlen[row];
+    const double scale[3] = { s0, s1, s2 };
+    double Rl[3] = { R[row], R[nbp + row], R[2 * long(nbp) + row] };
+    double D[9];
+    double* dptr = A + long(base + nl) * 576 + lane;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) D[q] = dptr[q * 64];
+    for (int k = 0; k < len; ++k) {
+        if (k == nl) continue;
+        const long e = long(base + k) * 64 + lane;
+        const int code = conn_code[e];
+        double* bptr = A + long(base + k) * 576 + lane;
+        if (code < 0) {          // pure well fill: the host adds the Schur block later
+#pragma unroll
+            for (int q = 0; q < 9; ++q) bptr[q * 64] = 0.0;
+            continue;
+        }
+        const int nbr = col[e];
+        const int conn = code >> 1, side = code & 1;
+        const int c1 = side ? nbr : row, c2 = side ? row : nbr;
+        const double Tf = trans[conn], g = gdz[conn];
+        const double thp = thpres ? thpres[conn] : 0.0;
+        // F[a], dF/d(c1 vars), dF/d(c2 vars)
+        double F[3], dF1[3][3], dF2[3][3];
+        int up[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const PhaseIn q1 = load_phase(props, pstate, nbp, c1, a);
+            const PhaseIn q2 = load_phase(props, pstate, nbp, c2, a);
+            double dh = (q1.p - q2.p) - g * (0.5 * q1.rho + 0.5 * q2.rho);
+            double keep = 1.0;
+            if (thpres) {
+                keep = (fabs(dh) >= thp) ? 1.0 : 0.0;
+                const double sg_ = (dh > 0.0) ? 1.0 : ((dh < 0.0) ? -1.0 : 0.0);
+                dh = keep * (dh - sg_ * thp);
+            }
+            const double hg = 0.5 * g;
+            const double d1[3] = { keep * (1.0 - hg * q1.drp), keep * (q1.dpw - hg * q1.drw), keep * (q1.dpx - hg * q1.drx) };
+            const double d2[3] = { keep * (-1.0 - hg * q2.drp), keep * (-q2.dpw - hg * q2.drw), keep * (-q2.dpx - hg * q2.drx) };
+            up[a] = (dh >= 0.0) ? 0 : 1;
+            const V4 U = load4(props, PL_U + 4 * a, nbp, up[a] == 0 ? c1 : c2);
+            const double Tdh = Tf * dh;
+            F[a] = U.v * Tdh;
+            const double dU[3] = { U.p, U.w, U.x };
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                dF1[a][v] = U.v * (Tf * d1[v]) + (up[a] == 0 ? dU[v] * Tdh : 0.0);
+                dF2[a][v] = U.v * (Tf * d2[v]) + (up[a] == 1 ? dU[v] * Tdh : 0.0);
+            }
+        }
+        // G_o = F_o + rv_up(g) F_g ; G_g = F_g + rs_up(o) F_o
+        const V4 rsu = load4(props, PL_RS, nbp, up[1] == 0 ? c1 : c2);
+        const V4 rvu = load4(props, PL_RV, nbp, up[2] == 0 ? c1 : c2);
+        const double drs[3] = { rsu.p, rsu.w, rsu.x }, drv[3] = { rvu.p, rvu.w, rvu.x };
+        double G[3] = { F[0], F[1] + rvu.v * F[2], F[2] + rsu.v * F[1] };
+        double dG1[3][3], dG2[3][3];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            dG1[0][v] = dF1[0][v]; dG2[0][v] = dF2[0][v];
+            dG1[1][v] = dF1[1][v] + rvu.v * dF1[2][v] + (up[2] == 0 ? drv[v] * F[2] : 0.0);
+            dG2[1][v] = dF2[1][v] + rvu.v * dF2[2][v] + (up[2] == 1 ? drv[v] * F[2] : 0.0);
+            dG1[2][v] = dF1[2][v] + rsu.v * dF1[1][v] + (up[1] == 0 ? drs[v] * F[1] : 0.0);
+            dG2[2][v] = dF2[2][v] + rsu.v * dF2[1][v] + (up[1] == 1 ? drs[v] * F[1] : 0.0);
+        }
+        const double s = side ? -1.0 : 1.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            Rl[a] += s * G[a];
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const double own = side ? dG2[a][v] : dG1[a][v];
+                const double oth = side ? dG1[a][v] : dG2[a][v];
+                D[3 * a + v] += s * scale[a] * own;
+                bptr[(3 * a + v) * 64] = s * scale[a] * oth;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) dptr[q * 64] = D[q];
+    R[row] = Rl[0]; R[nbp + row] = Rl[1]; R[2 * long(nbp) + row] = Rl[2];
+}
+
+// convergenceReduction (BlackoilModelBase_impl.hpp:1633-1714): per phase sum(1/b), max|R|/pv, sum R, max|R|, non-finite flag
+__global__ __launch_bounds__(kBlock) void k_conv_partial(int nb, int nbp, const double* __restrict__ R, const double* __restrict__ binv,
+                                                         const double* __restrict__ pv, double* __restrict__ part)
+{
+    __shared__ double sm[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double vals[13];
+#pragma unroll
+    for (int q = 0; q < 13; ++q) vals[q] = 0.0;
+    for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < nb; i += long(gridDim.x) * kBlock) {
+        const double ipv = 1.0 / pv[i];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double r = R[long(a) * nbp + i];
+            vals[a] += binv[long(a) * nbp + i];
+            vals[3 + a] = fmax(vals[3 + a], fabs(r) * ipv);
+            vals[6 + a] += r;
+            vals[9 + a] = fmax(vals[9 + a], fabs(r));
+            if (!(fabs(r) <= 1.79e308)) vals[12] = 1.0;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 13; ++q) {
+        const bool is_max = (q >= 3 && q < 6) || q >= 9;
+        const double s = is_max ? wave_max(vals[q]) : wave_sum(vals[q]);
+        __syncthreads();
+        if (lane == 0) sm[w] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) part[long(q) * gridDim.x + blockIdx.x] = is_max ? fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3])) : (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_conv_final(int nblocks, const double* __restrict__ part, double* __restrict__ out)
+{
+    __shared__ double sm[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int q = 0; q < 13; ++q) {
+        const bool is_max = (q >= 3 && q < 6) || q >= 9;
+        double v = 0.0;
+        for (int i = threadIdx.x; i < nblocks; i += kBlock) { const double x = part[long(q) * nblocks + i]; v = is_max ? fmax(v, x) : v + x; }
+        const double s = is_max ? wave_max(v) : wave_sum(v);
+        __syncthreads();
+        if (lane == 0) sm[w] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) out[q] = is_max ? fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3])) : (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    }
+}
+
+// updateState (BlackoilModelBase_impl.hpp:1147-1389), one thread per cell
+__global__ __launch_bounds__(kBlock) void k_update_state(int nb, int nbp, opmgpu_tables T, const int32_t* __restrict__ pvtnum,
+                                                         const int32_t* __restrict__ satnum, const double* __restrict__ dx, double relax,
+                                                         double dp_max_rel, double ds_max, double dr_max_rel,
+                                                         double* __restrict__ p, double* __restrict__ sw, double* __restrict__ so,
+                                                         double* __restrict__ sg, double* __restrict__ rs, double* __restrict__ rv, int8_t* __restrict__ hc)
+{
+    const int c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= nb) return;
+    const double eps = 1.4901161193847656e-08;      // sqrt(DBL_EPSILON)
+    const int preg = pvtnum[c], sreg = satnum[c];
+    const int h = hc[c];
+    const bool isSg = h == OPMGPU_HC_GAS_AND_OIL, isRs = h == OPMGPU_HC_OIL_ONLY, isRv = h == OPMGPU_HC_GAS_ONLY;
+    const double dp = relax * dx[c], dsw = relax * dx[nbp + c], dxv = relax * dx[2 * long(nbp) + c];
+    auto sgn = [](double x) { return (x > 0.0) ? 1.0 : ((x < 0.0) ? -1.0 : 0.0); };
+    const double p_old = p[c];
+    const double pn = fmax(p_old - sgn(dp) * fmin(fabs(dp), dp_max_rel * fabs(p_old)), 0.0);
+    const double sw_old = sw[c], so_old = so[c], sg_old = sg[c];
+    const double dsg = (isSg ? dxv : 0.0) - (isRv ? dsw : 0.0);
+    const double dso = -dsw - dsg;
+    const double maxVal = fmax(fabs(dso), fmax(fabs(dsg), fabs(dsw)));
+    const double step = fmin(ds_max / maxVal, 1.0);
+    double w_ = sw_old - step * dsw, g_ = sg_old - step * dsg, o_ = so_old - step * dso;
+    if (g_ < 0) { w_ = w_ / (1 - g_); o_ = o_ / (1 - g_); g_ = 0; }
+    if (o_ < 0) { w_ = w_ / (1 - o_); g_ = g_ / (1 - o_); o_ = 0; }
+    if (w_ < 0) { o_ = o_ / (1 - w_); g_ = g_ / (1 - w_); w_ = 0; }
+    const double rs_old = rs[c], rv_old = rv[c];
+    double rsn = rs_old, rvn = rv_old;
+    if (T.has_disgas) {
+        const double d = isRs ? dxv : 0.0;
+        rsn = fmax(rs_old - sgn(d) * fmin(fabs(d), fmax(fabs(rs_old) * dr_max_rel, 1.0)), 0.0);
+    }
+    if (T.has_vapoil) {
+        const double d = isRv ? dxv : 0.0;
+        rvn = fmax(rv_old - sgn(d) * fmin(fabs(d), fmax(fabs(rv_old) * dr_max_rel, 1e-3)), 0.0);
+    }
+    const bool watOnly = w_ > (1 - eps);
+    int hn = OPMGPU_HC_GAS_AND_OIL;
+    double f, df;
+    if (T.has_disgas) {
+        rs_sat_d(T, preg, p_old, f, df); const double rsSat0 = f;
+        rs_sat_d(T, preg, pn, f, df); const double rsSat = f;
+        const bool hasGas = (g_ > 0 && !isRs);
+        const bool gasVaporized = ((rsn > rsSat * (1 + eps) && isRs) && (rs_old > rsSat0 * (1 - eps)));
+        if (watOnly || hasGas || gasVaporized) { rsn = rsSat; if (watOnly) { o_ = 0; g_ = 0; rsn = 0; } }
+        else hn = OPMGPU_HC_OIL_ONLY;
+    }
+    if (T.has_vapoil) {
+        const int ga = T.sgof_ptr[sreg], ng = T.sgof_ptr[sreg + 1] - ga;
+        sat_eval<true>(T.sgof_sg + ga, T.sgof_pcgo + ga, ng, sg_old, f, df); const double pg_old = p_old + f;
+        sat_eval<true>(T.sgof_sg + ga, T.sgof_pcgo + ga, ng, g_, f, df); const double pg_new = pn + f;
+        rv_sat_d(T, preg, pg_old, f, df); const double rvSat0 = f;
+        rv_sat_d(T, preg, pg_new, f, df); const double rvSat = f;
+        const bool hasOil = (o_ > 0 && !isRv);
+        const bool oilCondensed = ((rvn > rvSat * (1 + eps) && isRv) && (rv_old > rvSat0 * (1 - eps)));
+        if (watOnly || hasOil || oilCondensed) { rvn = rvSat; if (watOnly) { o_ = 0; g_ = 0; rvn = 0; } }
+        else hn = OPMGPU_HC_GAS_ONLY;
+    }
+    p[c] = pn; sw[c] = w_; so[c] = o_; sg[c] = g_;
+    if (T.has_disgas) rs[c] = rsn;
+    if (T.has_vapoil) rv[c] = rvn;
+    hc[c] = int8_t(hn);
+}
+
+// b = matbalscale * R in the solver's precision (NewtonIterationBlackoilInterleaved.cpp:234-236, 263-269)
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_build_rhs(int nb, int nbp, double s0, double s1, double s2, const double* __restrict__ R, S* __restrict__ b)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nb) return;
+    b[i] = S(s0 * R[i]); b[nbp + i] = S(s1 * R[nbp + i]); b[2 * long(nbp) + i] = S(s2 * R[2 * long(nbp) + i]);
+}
+
+// per-perforation properties for the host well model (extractWellPerfProperties)
+__global__ __launch_bounds__(kBlock) void k_perf_props(int nperf, opmgpu_tables T, const int32_t* __restrict__ cells, const int32_t* __restrict__ pvtnum,
+                                                       const int32_t* __restrict__ satnum, const double* __restrict__ p, const double* __restrict__ sw,
+                                                       const double* __restrict__ sg, const double* __restrict__ rs, const double* __restrict__ rv,
+                                                       const int8_t* __restrict__ hc, double* __restrict__ out)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nperf) return;
+    const int c = cells[i];
+    CellEval q;
+    eval_cell(T, pvtnum[c], satnum[c], p[c], sw[c], sg[c], rs[c], rv[c], hc[c], q);
+    const V4 list[9] = { mk(p[c], 1, 0, 0), q.rs, q.rv, q.b[0], q.b[1], q.b[2], q.mob[0], q.mob[1], q.mob[2] };
+    double* o = out + long(i) * OPMGPU_PERF_K;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { o[4 * k] = list[k].v; o[4 * k + 1] = list[k].p; o[4 * k + 2] = list[k].w; o[4 * k + 3] = list[k].x; }
+}
+
+__global__ __launch_bounds__(kBlock) void k_add_well_resid(int nperf, int nbp, const int32_t* __restrict__ cells, const double* __restrict__ delta, double* __restrict__ R)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nperf) return;
+    for (int a = 0; a < 3; ++a) atomicAdd(&R[long(a) * nbp + cells[i]], delta[3 * i + a]);
+}
+__global__ __launch_bounds__(kBlock) void k_add_well_blocks(int nblk, const int32_t* __restrict__ entries, const double* __restrict__ blocks,
+                                                            double s0, double s1, double s2, double* __restrict__ A)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nblk) return;
+    const int e = entries[i];
+    const double scale[3] = { s0, s1, s2 };
+    double* o = A + long(e >> 6) * 576 + (e & 63);
+    for (int a = 0; a < 3; ++a) for (int v = 0; v < 3; ++v) atomicAdd(&o[(3 * a + v) * 64], scale[a] * blocks[9 * long(i) + 3 * a + v]);
+}
+
+template <class T_>
+__global__ __launch_bounds__(kBlock) void k_permute(int nb, const int32_t* __restrict__ nat, const T_* __restrict__ in, T_* __restrict__ out, int to_internal)
+{
+    const int r = blockIdx.x * kBlock + threadIdx.x;
+    if (r >= nb) return;
+    if (to_internal) out[r] = in[nat[r]]; else out[nat[r]] = in[r];
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+BlackoilDevice::BlackoilDevice(hipStream_t s, LinSolver& ls_, const opmgpu_grid* g, const opmgpu_tables* t, const opmgpu_params* prm_)
+    : prm(*prm_), stream(s), ls(ls_)
+{
+    nc = g->nc; nconn = g->nconn; gravity = g->gravity;
+    h_conn.assign(g->conn_cells, g->conn_cells + 2 * size_t(nconn));
+    h_trans.assign(g->trans, g->trans + nconn);
+    h_pv.assign(g->pv, g->pv + nc);
+    h_z.assign(g->z, g->z + nc);
+    use_thpres = g->thpres != nullptr;
+    if (use_thpres) h_thpres.assign(g->thpres, g->thpres + nconn);
+    h_pvtnum.assign(nc, 0); h_satnum.assign(nc, 0);
+    if (g->pvtnum) h_pvtnum.assign(g->pvtnum, g->pvtnum + nc);
+    if (g->satnum) h_satnum.assign(g->satnum, g->satnum + nc);
+    pvsum = 0.0;
+    for (int c = 0; c < nc; ++c) pvsum += h_pv[c];
+    upload_tables(t);
+    OPMGPU_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_red), 16 * sizeof(double)));
+    h_well_connpos.assign(1, 0);
+    rebuild_structure();
+}
+
+BlackoilDevice::~BlackoilDevice()
+{
+    for (DevArray<double>* a : tab_d) delete a;
+    for (DevArray<int32_t>* a : tab_i) delete a;
+    if (h_red) (void)hipHostFree(h_red);
+}
+
+void BlackoilDevice::upload_tables(const opmgpu_tables* t)
+{
+    dt_ = *t;
+    auto upd = [&](const double* src, size_t n) -> const double* {
+        DevArray<double>* a = new DevArray<double>(); tab_d.push_back(a);
+        a->upload(src, std::max<size_t>(n, 1), stream); return a->p;
+    };
+    auto upi = [&](const int32_t* src, size_t n) -> const int32_t* {
+        DevArray<int32_t>* a = new DevArray<int32_t>(); tab_i.push_back(a);
+        a->upload(src, n, stream); return a->p;
+    };
+    const int np = t->n_pvt_regions, ns = t->n_sat_regions;
+    const int non = t->oil_node_ptr[np], ngn = t->gas_node_ptr[np];
+    const int noc = t->oil_col_ptr[non], ngc = t->gas_col_ptr[ngn];
+    const int nsw = t->swof_ptr[ns], nsg = t->sgof_ptr[ns];
+    dt_.surface_density = upd(t->surface_density, 3 * np); dt_.pvtw = upd(t->pvtw, 5 * np);
+    dt_.oil_node_ptr = upi(t->oil_node_ptr, np + 1);
+    dt_.oil_rs = upd(t->oil_rs, non); dt_.oil_psat = upd(t->oil_psat, non);
+    dt_.oil_invb_sat = upd(t->oil_invb_sat, non); dt_.oil_invbmu_sat = upd(t->oil_invbmu_sat, non);
+    dt_.oil_col_ptr = upi(t->oil_col_ptr, non + 1);
+    dt_.oil_col_p = upd(t->oil_col_p, noc); dt_.oil_col_invb = upd(t->oil_col_invb, noc); dt_.oil_col_invbmu = upd(t->oil_col_invbmu, noc);
+    dt_.gas_node_ptr = upi(t->gas_node_ptr, np + 1);
+    dt_.gas_pg = upd(t->gas_pg, ngn); dt_.gas_rvsat = upd(t->gas_rvsat, ngn);
+    dt_.gas_invb_sat = upd(t->gas_invb_sat, ngn); dt_.gas_invbmu_sat = upd(t->gas_invbmu_sat, ngn);
+    dt_.gas_col_ptr = upi(t->gas_col_ptr, ngn + 1);
+    dt_.gas_col_rv = upd(t->gas_col_rv, ngc); dt_.gas_col_invb = upd(t->gas_col_invb, ngc); dt_.gas_col_invbmu = upd(t->gas_col_invbmu, ngc);
+    dt_.swof_ptr = upi(t->swof_ptr, ns + 1);
+    dt_.swof_sw = upd(t->swof_sw, nsw); dt_.swof_krw = upd(t->swof_krw, nsw); dt_.swof_krow = upd(t->swof_krow, nsw); dt_.swof_pcow = upd(t->swof_pcow, nsw);
+    dt_.sgof_ptr = upi(t->sgof_ptr, ns + 1);
+    dt_.sgof_sg = upd(t->sgof_sg, nsg); dt_.sgof_krg = upd(t->sgof_krg, nsg); dt_.sgof_krog = upd(t->sgof_krog, nsg); dt_.sgof_pcgo = upd(t->sgof_pcgo, nsg);
+    OPMGPU_HIP(hipStreamSynchronize(stream));
+}
+
+// pattern = stencil U well cliques -> solver plan -> internal numbering of every per-cell array
+void BlackoilDevice::rebuild_structure()
+{
+    std::vector<int32_t> rowptr, col, code;
+    const int nw = int(h_well_connpos.size()) - 1;
+    const int st = build_reservoir_pattern(nc, nconn, h_conn.data(), nw, h_well_connpos.data(), h_well_cells.data(), rowptr, col, code);
+    if (st != OPMGPU_OK) throw HipError(st, "invalid grid connections / wells (out of range or duplicate cell pair)");
+    // keep the state across a re-plan (wells change between report steps)
+    std::vector<double> sp, ssat, srs, srv; std::vector<int8_t> shc;
+    if (has_state) { sp.resize(nc); ssat.resize(3 * size_t(nc)); srs.resize(nc); srv.resize(nc); shc.resize(nc); get_state(sp.data(), ssat.data(), srs.data(), srv.data(), shc.data()); }
+    const int st2 = ls.set_pattern(nc, rowptr.data(), col.data(), prm.ilu_ordering);
+    if (st2 != OPMGPU_OK) throw HipError(st2, "sparsity plan failed");
+    const Plan& P = ls.plan;
+    const int nbp = P.nbp;
+    std::vector<int32_t> ccode(P.nentries, -2);
+    for (int b = 0; b < P.nnzb; ++b) ccode[P.entry_of_block[b]] = code[b];
+    d_conn_code.upload(ccode, stream);
+    std::vector<double> pvi(nbp, 1.0); std::vector<int32_t> pn(nbp, 0), sn(nbp, 0);
+    for (int r = 0; r < nc; ++r) { pvi[r] = h_pv[P.nat[r]]; pn[r] = h_pvtnum[P.nat[r]]; sn[r] = h_satnum[P.nat[r]]; }
+    d_pv.upload(pvi, stream); d_pvtnum.upload(pn, stream); d_satnum.upload(sn, stream);
+    std::vector<double> gdz(std::max(nconn, 1), 0.0);
+    for (int f = 0; f < nconn; ++f) gdz[f] = gravity * (h_z[h_conn[2 * f]] - h_z[h_conn[2 * f + 1]]);
+    d_gdz.upload(gdz, stream);
+    std::vector<double> tr(h_trans); if (tr.empty()) tr.push_back(0.0);
+    d_trans.upload(tr, stream);
+    if (use_thpres) d_thpres.upload(h_thpres, stream);
+    std::vector<int32_t> pc(std::max<size_t>(h_well_cells.size(), 1), 0);
+    for (size_t i = 0; i < h_well_cells.size(); ++i) pc[i] = P.pos[h_well_cells[i]];
+    d_perf_cells.upload(pc, stream);
+    nperf = int(h_well_cells.size());
+    d_perf.alloc(std::max(nperf, 1) * size_t(OPMGPU_PERF_K));
+    DevArray<double>* planes[] = { &d_p, &d_sw, &d_so, &d_sg, &d_rs, &d_rv };
+    for (DevArray<double>* a : planes) { a->alloc(nbp); a->zero(stream); }
+    d_hc.alloc(nbp); d_hc.zero(stream);
+    d_props.alloc(size_t(PL_COUNT) * nbp); d_props.zero(stream);
+    d_accum0.alloc(3 * size_t(nbp)); d_accum0.zero(stream);
+    d_R.alloc(3 * size_t(nbp)); d_R.zero(stream);
+    d_binv.alloc(3 * size_t(nbp)); d_binv.zero(stream);
+    d_dx.alloc(3 * size_t(nbp)); d_dx.zero(stream);
+    d_red.alloc(13 * size_t(kMaxRedBlocks) + 16);
+    OPMGPU_HIP(hipStreamSynchronize(stream));
+    has_dx = false;
+    if (has_state) set_state(sp.data(), ssat.data(), srs.data(), srv.data(), shc.data());
+}
+
+int BlackoilDevice::set_wells(int nw, const int32_t* connpos, const int32_t* cells)
+{
+    if (nw < 0 || (nw > 0 && (!connpos || !cells))) return OPMGPU_EINVAL;
+    std::vector<int32_t> cp(1, 0), wc;
+    if (nw > 0) { cp.assign(connpos, connpos + nw + 1); wc.assign(cells, cells + connpos[nw]); }
+    if (cp == h_well_connpos && wc == h_well_cells) return OPMGPU_OK;
+    h_well_connpos = cp; h_well_cells = wc;
+    rebuild_structure();
+    return OPMGPU_OK;
+}
+
+void BlackoilDevice::set_state(const double* p, const double* sat, const double* rs, const double* rv, const int8_t* hc)
+{
+    const Plan& P = ls.plan;
+    const int nbp = P.nbp;
+    hbuf.assign(6 * size_t(nbp), 0.0); hbuf8.assign(nbp, int8_t(OPMGPU_HC_GAS_AND_OIL));
+    for (int r = 0; r < nc; ++r) {
+        const int c = P.nat[r];
+        hbuf[r] = p[c]; hbuf[nbp + r] = sat[3 * size_t(c)]; hbuf[2 * size_t(nbp) + r] = sat[3 * size_t(c) + 1];
+        hbuf[3 * size_t(nbp) + r] = sat[3 * size_t(c) + 2]; hbuf[4 * size_t(nbp) + r] = rs[c]; hbuf[5 * size_t(nbp) + r] = rv[c];
+        hbuf8[r] = hc[c];
+    }
+    DevArray<double>* planes[] = { &d_p, &d_sw, &d_so, &d_sg, &d_rs, &d_rv };
+    for (int k = 0; k < 6; ++k) OPMGPU_HIP(hipMemcpyAsync(planes[k]->p, hbuf.data() + size_t(k) * nbp, nbp * sizeof(double), hipMemcpyHostToDevice, stream));
+    OPMGPU_HIP(hipMemcpyAsync(d_hc.p, hbuf8.data(), nbp, hipMemcpyHostToDevice, stream));
+    OPMGPU_HIP(hipStreamSynchronize(stream));
+    has_state = true;
+}
+
+void BlackoilDevice::get_state(double* p, double* sat, double* rs, double* rv, int8_t* hc)
+{
+    const Plan& P = ls.plan;
+    const int nbp = P.nbp;
+    hbuf.resize(6 * size_t(nbp)); hbuf8.resize(nbp);
+    DevArray<double>* planes[] = { &d_p, &d_sw, &d_so, &d_sg, &d_rs, &d_rv };
+    for (int k = 0; k < 6; ++k) OPMGPU_HIP(hipMemcpyAsync(hbuf.data() + size_t(k) * nbp, planes[k]->p, nbp * sizeof(double), hipMemcpyDeviceToHost, stream));
+    OPMGPU_HIP(hipMemcpyAsync(hbuf8.data(), d_hc.p, nbp, hipMemcpyDeviceToHost, stream));
+    OPMGPU_HIP(hipStreamSynchronize(stream));
+    for (int r = 0; r < nc; ++r) {
+        const int c = P.nat[r];
+        if (p) p[c] = hbuf[r];
+        if (sat) { sat[3 * size_t(c)] = hbuf[nbp + r]; sat[3 * size_t(c) + 1] = hbuf[2 * size_t(nbp) + r]; sat[3 * size_t(c) + 2] = hbuf[3 * size_t(nbp) + r]; }
+        if (rs) rs[c] = hbuf[4 * size_t(nbp) + r];
+        if (rv) rv[c] = hbuf[5 * size_t(nbp) + r];
+        if (hc) hc[c] = hbuf8[r];
+    }
+}
+
+void BlackoilDevice::assemble(double dt, bool initial)
+{
+    const Plan& P = ls.plan;
+    last_dt = dt;
+    const double* sc = prm.matbalscale;
+    hipLaunchKernelGGL(k_cell_props, dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_pv.p,
+                       d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, 1.0 / dt, int(initial), sc[0], sc[1], sc[2],
+                       ls.dp.slice_ptr.p, ls.dp.nlower.p, d_props.p, d_accum0.p, d_R.p, d_binv.p, ls.matrix_d());
+    hipLaunchKernelGGL(k_flux, dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, P.nbp, ls.dp.slice_ptr.p, ls.dp.col.p, ls.dp.rowlen.p,
+                       ls.dp.nlower.p, d_conn_code.p, d_trans.p, d_gdz.p, use_thpres ? d_thpres.p : (const double*)nullptr,
+                       d_p.p, d_props.p, sc[0], sc[1], sc[2], d_R.p, ls.matrix_d());
+}
+
+double BlackoilDevice::time_assemble(int reps, int props_only)
+{
+    const Plan& P = ls.plan;
+    const double* sc = prm.matbalscale;
+    const double dt = last_dt > 0 ? last_dt : 86400.0;
+    hipEvent_t e0, e1;
+    OPMGPU_HIP(hipEventCreate(&e0)); OPMGPU_HIP(hipEventCreate(&e1));
+    auto launch = [&]() {
+        if (props_only)
+            hipLaunchKernelGGL(k_cell_props, dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_pv.p,
+                               d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, 1.0 / dt, 0, sc[0], sc[1], sc[2],
+                               ls.dp.slice_ptr.p, ls.dp.nlower.p, d_props.p, d_accum0.p, d_R.p, d_binv.p, ls.matrix_d());
+        else assemble(dt, false);
+    };
+    launch();
+    OPMGPU_HIP(hipEventRecord(e0, stream));
+    for (int i = 0; i < reps; ++i) launch();
+    OPMGPU_HIP(hipEventRecord(e1, stream));
+    OPMGPU_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    OPMGPU_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return double(ms) / reps;
+}
+
+int BlackoilDevice::convergence(double dt, double* B3, double* CNV3, double* MB3, double* linf3, int* converged)
+{
+    const Plan& P = ls.plan;
+    const int g = std::min(grid_for(nc), kMaxRedBlocks);
+    hipLaunchKernelGGL(k_conv_partial, dim3(g), dim3(kBlock), 0, stream, nc, P.nbp, d_R.p, d_binv.p, d_pv.p, d_red.p + 16);
+    hipLaunchKernelGGL(k_conv_final, dim3(1), dim3(kBlock), 0, stream, g, d_red.p + 16, d_red.p);
+    OPMGPU_HIP(hipMemcpyAsync(h_red, d_red.p, 13 * sizeof(double), hipMemcpyDeviceToHost, stream));
+    OPMGPU_HIP(hipStreamSynchronize(stream));
+    bool conv = true; int status = OPMGPU_OK;
+    if (h_red[12] != 0.0) status = OPMGPU_ENUMERICAL;                                   // non-finite residual, :1562-1566
+    for (int a = 0; a < 3; ++a) {
+        const double B = h_red[a] / nc;
+        const double cnv = B * dt * h_red[3 + a], mb = std::fabs(B * h_red[6 + a]) * dt / pvsum;
+        if (B3) B3[a] = B; if (CNV3) CNV3[a] = cnv; if (MB3) MB3[a] = mb; if (linf3) linf3[a] = h_red[9 + a];
+        conv = conv && (mb < prm.tolerance_mb) && (cnv < prm.tolerance_cnv);
+        if (std::isnan(mb) || std::isnan(cnv)) status = OPMGPU_ENUMERICAL;              // :1828-1836
+        if (mb > prm.max_residual_allowed || cnv > prm.max_residual_allowed) status = OPMGPU_ENUMERICAL;   // :1837-1845
+    }
+    if (converged) *converged = conv ? 1 : 0;
+    return status;
+}
+
+void BlackoilDevice::perf_props(double* out)
+{
+    if (nperf == 0) return;
+    hipLaunchKernelGGL(k_perf_props, dim3(grid_for(nperf)), dim3(kBlock), 0, stream, nperf, dt_, d_perf_cells.p, d_pvtnum.p, d_satnum.p,
+                       d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, d_perf.p);
+    OPMGPU_HIP(hipMemcpyAsync(out, d_perf.p, size_t(nperf) * OPMGPU_PERF_K * sizeof(double), hipMemcpyDeviceToHost, stream));
+    OPMGPU_HIP(hipStreamSynchronize(stream));
+}
+
+int BlackoilDevice::add_well_terms(const double* resid_delta, int nblk, const int32_t* rc, const double* blocks)
+{
+    const Plan& P = ls.plan;
+    const double* sc = prm.matbalscale;
+    if (nperf > 0 && resid_delta) {
+        DevArray<double> dd; dd.upload(resid_delta, 3 * size_t(nperf), stream);
+        hipLaunchKernelGGL(k_add_well_resid, dim3(grid_for(nperf)), dim3(kBlock), 0, stream, nperf, P.nbp, d_perf_cells.p, dd.p, d_R.p);
+        OPMGPU_HIP(hipStreamSynchronize(stream));
+    }
+    if (nblk > 0) {
+        std::vector<int32_t> ent(nblk);
+        for (int k = 0; k < nblk; ++k) {
+            const int r = rc[2 * k], c = rc[2 * k + 1];
+            if (r < 0 || r >= nc) return OPMGPU_EINVAL;
+            const int32_t* b = P.col.data() + P.rowptr[r]; const int32_t* e = P.col.data() + P.rowptr[r + 1];
+            const int32_t* it = std::lower_bound(b, e, c);
+            if (it == e || *it != c) return OPMGPU_EINVAL;
+            ent[k] = P.entry_of_block[it - P.col.data()];
+        }
+        DevArray<int32_t> de; de.upload(ent, stream);
+        DevArray<double> db; db.upload(blocks, 9 * size_t(nblk), stream);
+        hipLaunchKernelGGL(k_add_well_blocks, dim3(grid_for(nblk)), dim3(kBlock), 0, stream, nblk, de.p, db.p, sc[0], sc[1], sc[2], ls.matrix_d());
+        OPMGPU_HIP(hipStreamSynchronize(stream));
+    }
+    return OPMGPU_OK;
+}
+
+__global__ __launch_bounds__(kBlock) void k_f2d(long n, const float* __restrict__ a, double* __restrict__ b)
+{
+    for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) b[i] = double(a[i]);
+}
+void launch_convert_f2d(long n, const float* a, double* b, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_f2d, dim3(std::min(grid_for(n), kMaxRedBlocks)), dim3(kBlock), 0, s, n, a, b);
+}
+
+template <class S> void BlackoilDevice::build_rhs()
+{
+    const Plan& P = ls.plan;
+    const double* sc = prm.matbalscale;
+    hipLaunchKernelGGL((k_build_rhs<S>), dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, P.nbp, sc[0], sc[1], sc[2], d_R.p, ls.work<S>().b.p);
+}
+template <class S> void BlackoilDevice::store_dx()
+{
+    const Plan& P = ls.plan;
+    const long n = 3 * long(P.nbp);
+    if (sizeof(S) == 8) OPMGPU_HIP(hipMemcpyAsync(d_dx.p, ls.work<S>().x.p, n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    else {
+        launch_convert_f2d(n, reinterpret_cast<const float*>(ls.work<S>().x.p), d_dx.p, stream);
+    }
+    has_dx = true;
+}
+template void BlackoilDevice::build_rhs<float>();
+template void BlackoilDevice::build_rhs<double>();
+template void BlackoilDevice::store_dx<float>();
+template void BlackoilDevice::store_dx<double>();
+
+void BlackoilDevice::dx_to_host(double* dx)
+{
+    ls.vec_to_host<double>(d_dx.p, VEC_EQUATION_MAJOR, dx);
+}
+
+void BlackoilDevice::update_state(const double* dx_host, double relax)
+{
+    const Plan& P = ls.plan;
+    if (dx_host) { ls.vec_from_host<double>(dx_host, VEC_EQUATION_MAJOR, d_dx.p); has_dx = true; }
+    hipLaunchKernelGGL(k_update_state, dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_dx.p, relax,
+                       prm.dp_max_rel, prm.ds_max, prm.dr_max_rel, d_p.p, d_sw.p, d_so.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p);
+}
+
+void BlackoilDevice::get_residual(double* r)
+{
+    ls.vec_to_host<double>(d_R.p, VEC_EQUATION_MAJOR, r);
+}
+
+} // namespace opmgpu

@@ -1,0 +1,380 @@
+// capi.hip -- the extern "C" boundary of libopmgpu.so (include/opmgpu.h).
+//
+// Every entry point catches C++ exceptions and converts them to the status codes the reference-side
+// shim maps back to the exception flow_legacy's time stepper expects.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "blackoil.hpp"
+#include "linsolver.hpp"
+
+using namespace opmgpu;
+
+struct opmgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    opmgpu_params prm;
+    std::unique_ptr<LinSolver> ls;
+    std::unique_ptr<BlackoilDevice> model;
+    std::string err;
+    int cur_single = 0;          // precision of the loaded / prepared matrix
+    bool matrix_loaded = false;
+    bool factored = false;
+    double t_assemble = 0, t_solve = 0, t_update = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // RCCL halo description (multi-GPU), see dist.hip
+    void* comm = nullptr;
+};
+
+namespace {
+
+int fail(opmgpu_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
+
+template <class F> int guarded(opmgpu_ctx* c, F&& f)
+{
+    try {
+        if (c) { if (hipSetDevice(c->device) != hipSuccess) return fail(c, OPMGPU_ENODEVICE, "hipSetDevice failed"); }
+        return f();
+    } catch (const HipError& e) { return fail(c, e.code, e.what()); }
+    catch (const std::bad_alloc&) { return fail(c, OPMGPU_ENOMEM, "host allocation failed"); }
+    catch (const std::exception& e) { return fail(c, OPMGPU_EINVAL, e.what()); }
+}
+
+int make_ctx(opmgpu_ctx** out, int device, const opmgpu_params* params)
+{
+    if (!out) return OPMGPU_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1 || device < 0 || device >= n) return OPMGPU_ENODEVICE;   // no CPU fallback
+    std::unique_ptr<opmgpu_ctx> c(new opmgpu_ctx());
+    c->device = device;
+    if (params) c->prm = *params; else opmgpu_default_params(&c->prm);
+    if (hipSetDevice(device) != hipSuccess) return OPMGPU_ENODEVICE;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return OPMGPU_ENODEVICE;
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return OPMGPU_ENODEVICE;
+    try { c->ls.reset(new LinSolver(c->stream)); } catch (const HipError& e) { return e.code; }
+    *out = c.release();
+    return OPMGPU_OK;
+}
+
+struct Timed {
+    opmgpu_ctx* c; double* dst;
+    Timed(opmgpu_ctx* c_, double* d) : c(c_), dst(d) { (void)hipEventRecord(c->ev0, c->stream); }
+    ~Timed() {
+        (void)hipEventRecord(c->ev1, c->stream); (void)hipEventSynchronize(c->ev1);
+        float ms = 0.f; (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); *dst = ms;
+    }
+};
+
+template <class S> int solve_loaded(opmgpu_ctx* c, bool matrix_changed, SolveResult& res)
+{
+    LinSolver& ls = *c->ls;
+    ls.prepare<S>(matrix_changed);
+    const int st = ls.factor<S>();
+    if (st != OPMGPU_OK) return fail(c, st, "singular diagonal block in ILU0");
+    c->factored = true;
+    res = ls.bicgstab<S>(c->prm);
+    if (res.status == OPMGPU_ELINSOLVE) c->err = "Convergence failure for linear solver.";
+    if (res.status == OPMGPU_EBREAKDOWN) c->err = "breakdown in BiCGSTAB";
+    return res.status;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* opmgpu_version(void) { return "opmgpu 0.1 (gfx950, HIP, SELL-64 block-ILU0/BiCGStab + black-oil assembly)"; }
+
+int opmgpu_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void opmgpu_default_params(opmgpu_params* p)
+{
+    if (!p) return;
+    p->dp_max_rel = 0.3; p->ds_max = 0.2; p->dr_max_rel = 1e9;                 // BlackoilModelParameters.cpp:76-102
+    p->max_residual_allowed = 1e7; p->tolerance_mb = 1e-5; p->tolerance_cnv = 1e-2;
+    p->matbalscale[0] = 1.1169; p->matbalscale[1] = 1.0031; p->matbalscale[2] = 0.0031;   // BlackoilModelBase_impl.hpp:139
+    p->linear_solver_reduction = 1e-2; p->linear_solver_maxiter = 150;                    // FlowLinearSolverParameters
+    p->ilu_relaxation = 0.9; p->ilu_ordering = OPMGPU_ORDER_MULTICOLOR; p->ignore_convergence_failure = 0;
+}
+
+int opmgpu_create_solver(opmgpu_ctx** ctx, int device, const opmgpu_params* params) { return make_ctx(ctx, device, params); }
+
+int opmgpu_create(opmgpu_ctx** ctx, int device, const opmgpu_grid* grid, const opmgpu_tables* tables, const opmgpu_params* params)
+{
+    if (!grid || !tables || grid->nc <= 0 || grid->nconn < 0) return OPMGPU_EINVAL;
+    const int st = make_ctx(ctx, device, params);
+    if (st != OPMGPU_OK) return st;
+    opmgpu_ctx* c = *ctx;
+    const int st2 = guarded(c, [&]() { c->model.reset(new BlackoilDevice(c->stream, *c->ls, grid, tables, &c->prm)); return OPMGPU_OK; });
+    if (st2 != OPMGPU_OK) { opmgpu_destroy(c); *ctx = nullptr; }
+    return st2;
+}
+
+void opmgpu_destroy(opmgpu_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->model.reset(); c->ls.reset();
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* opmgpu_last_error(const opmgpu_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int opmgpu_set_wells(opmgpu_ctx* c, int nw, const int32_t* well_connpos, const int32_t* well_cells)
+{
+    if (!c || !c->model) return OPMGPU_EINVAL;
+    return guarded(c, [&]() { c->matrix_loaded = false; return c->model->set_wells(nw, well_connpos, well_cells); });
+}
+
+int opmgpu_set_state(opmgpu_ctx* c, const double* p, const double* sat, const double* rs, const double* rv, const int8_t* hc)
+{
+    if (!c || !c->model || !p || !sat || !rs || !rv || !hc) return OPMGPU_EINVAL;
+    return guarded(c, [&]() { c->model->set_state(p, sat, rs, rv, hc); return OPMGPU_OK; });
+}
+int opmgpu_get_state(opmgpu_ctx* c, double* p, double* sat, double* rs, double* rv, int8_t* hc)
+{
+    if (!c || !c->model || !c->model->has_state) return OPMGPU_EINVAL;
+    return guarded(c, [&]() { c->model->get_state(p, sat, rs, rv, hc); return OPMGPU_OK; });
+}
+
+int opmgpu_assemble(opmgpu_ctx* c, double dt, int initial, const double* p, const double* sat, const double* rs, const double* rv, const int8_t* hc)
+{
+    if (!c || !c->model || !(dt > 0.0)) return OPMGPU_EINVAL;
+    return guarded(c, [&]() {
+        if (p || sat || rs || rv || hc) {
+            if (!(p && sat && rs && rv && hc)) return fail(c, OPMGPU_EINVAL, "state pointers must be all set or all NULL");
+            c->model->set_state(p, sat, rs, rv, hc);
+        }
+        if (!c->model->has_state) return fail(c, OPMGPU_EINVAL, "no reservoir state on the device");
+        {
+            Timed t(c, &c->t_assemble);
+            c->model->assemble(dt, initial != 0);
+        }
+        c->matrix_loaded = true; c->factored = false; c->cur_single = -1;
+        return int(OPMGPU_OK);
+    });
+}
+
+int opmgpu_perf_props(opmgpu_ctx* c, double* out)
+{
+    if (!c || !c->model || !out) return OPMGPU_EINVAL;
+    return guarded(c, [&]() { c->model->perf_props(out); return OPMGPU_OK; });
+}
+
+int opmgpu_add_well_terms(opmgpu_ctx* c, const double* resid_delta, int nblk, const int32_t* schur_rc, const double* schur_blocks)
+{
+    if (!c || !c->model || nblk < 0 || (nblk > 0 && (!schur_rc || !schur_blocks))) return OPMGPU_EINVAL;
+    return guarded(c, [&]() { c->factored = false; c->cur_single = -1; return c->model->add_well_terms(resid_delta, nblk, schur_rc, schur_blocks); });
+}
+
+int opmgpu_convergence(opmgpu_ctx* c, double dt, double* B_avg3, double* CNV3, double* MB3, double* linf3, int* converged)
+{
+    if (!c || !c->model || !c->matrix_loaded) return OPMGPU_EINVAL;
+    return guarded(c, [&]() {
+        const int st = c->model->convergence(dt, B_avg3, CNV3, MB3, linf3, converged);
+        if (st == OPMGPU_ENUMERICAL) c->err = "NaN or too large residual";
+        return st;
+    });
+}
+
+int opmgpu_solve(opmgpu_ctx* c, int single_precision, double* dx, int* iters, double* reduction)
+{
+    if (!c || !c->model || !c->matrix_loaded) return OPMGPU_EINVAL;
+    return guarded(c, [&]() {
+        SolveResult res;
+        int st;
+        {
+            Timed t(c, &c->t_solve);
+            if (single_precision) { c->ls->ensure_work<float>(); c->model->build_rhs<float>(); st = solve_loaded<float>(c, true, res); if (st == OPMGPU_OK || st == OPMGPU_ELINSOLVE) c->model->store_dx<float>(); }
+            else { c->ls->ensure_work<double>(); c->model->build_rhs<double>(); st = solve_loaded<double>(c, true, res); if (st == OPMGPU_OK || st == OPMGPU_ELINSOLVE) c->model->store_dx<double>(); }
+        }
+        c->cur_single = single_precision ? 1 : 0;
+        if (iters) *iters = res.iterations;
+        if (reduction) *reduction = res.reduction;
+        if (dx && (st == OPMGPU_OK || st == OPMGPU_ELINSOLVE)) c->model->dx_to_host(dx);
+        return st;
+    });
+}
+
+int opmgpu_update_state(opmgpu_ctx* c, const double* dx, double relax)
+{
+    if (!c || !c->model || !c->model->has_state) return OPMGPU_EINVAL;
+    if (!dx && !c->model->has_dx) return fail(c, OPMGPU_EINVAL, "no resident Newton increment");
+    return guarded(c, [&]() {
+        Timed t(c, &c->t_update);
+        c->model->update_state(dx, relax);
+        return OPMGPU_OK;
+    });
+}
+
+int opmgpu_load_bsr(opmgpu_ctx* c, int nb, const int32_t* rowptr, const int32_t* col, const double* val9, int single_precision)
+{
+    if (!c || nb <= 0 || !rowptr || !col || !val9) return OPMGPU_EINVAL;
+    if (c->model) return fail(c, OPMGPU_EINVAL, "opmgpu_load_bsr needs a solver-only context (opmgpu_create_solver)");
+    return guarded(c, [&]() {
+        const int st = c->ls->set_pattern(nb, rowptr, col, c->prm.ilu_ordering);
+        if (st != OPMGPU_OK) return fail(c, st, "invalid BSR pattern");
+        c->ls->load_host_bsr(val9);
+        if (single_precision) c->ls->prepare<float>(true); else c->ls->prepare<double>(true);
+        c->cur_single = single_precision ? 1 : 0;
+        c->matrix_loaded = true; c->factored = false;
+        return int(OPMGPU_OK);
+    });
+}
+
+int opmgpu_solve_bsr(opmgpu_ctx* c, int nb, const int32_t* rowptr, const int32_t* col, const double* val9, const double* rhs3,
+                     int single_precision, double* x3, int* iters, double* reduction)
+{
+    if (!c || !rhs3 || !x3) return OPMGPU_EINVAL;
+    const int st0 = opmgpu_load_bsr(c, nb, rowptr, col, val9, single_precision);
+    if (st0 != OPMGPU_OK) return st0;
+    return guarded(c, [&]() {
+        SolveResult res; int st;
+        {
+            Timed t(c, &c->t_solve);
+            if (single_precision) { c->ls->vec_from_host<float>(rhs3, VEC_BLOCK_INTERLEAVED, c->ls->work<float>().b.p); st = solve_loaded<float>(c, false, res); }
+            else { c->ls->vec_from_host<double>(rhs3, VEC_BLOCK_INTERLEAVED, c->ls->work<double>().b.p); st = solve_loaded<double>(c, false, res); }
+        }
+        if (iters) *iters = res.iterations;
+        if (reduction) *reduction = res.reduction;
+        if (st == OPMGPU_OK || st == OPMGPU_ELINSOLVE) {
+            if (single_precision) c->ls->vec_to_host<float>(c->ls->work<float>().x.p, VEC_BLOCK_INTERLEAVED, x3);
+            else c->ls->vec_to_host<double>(c->ls->work<double>().x.p, VEC_BLOCK_INTERLEAVED, x3);
+        }
+        return st;
+    });
+}
+
+// make sure the matrix exists in the precision the kernel-level entry points will use
+static int ensure_prepared(opmgpu_ctx* c)
+{
+    if (!c->matrix_loaded) return fail(c, OPMGPU_EINVAL, "no matrix loaded");
+    if (c->cur_single < 0) { c->ls->prepare<double>(true); c->cur_single = 0; }
+    return OPMGPU_OK;
+}
+
+int opmgpu_spmv(opmgpu_ctx* c, const double* x3, double* y3)
+{
+    if (!c || !x3 || !y3) return OPMGPU_EINVAL;
+    return guarded(c, [&]() {
+        const int st = ensure_prepared(c); if (st) return st;
+        LinSolver& ls = *c->ls;
+        if (c->cur_single) { auto& w = ls.work<float>(); ls.vec_from_host<float>(x3, VEC_BLOCK_INTERLEAVED, w.p.p); ls.spmv<float>(w.p.p, w.v.p); ls.vec_to_host<float>(w.v.p, VEC_BLOCK_INTERLEAVED, y3); }
+        else { auto& w = ls.work<double>(); ls.vec_from_host<double>(x3, VEC_BLOCK_INTERLEAVED, w.p.p); ls.spmv<double>(w.p.p, w.v.p); ls.vec_to_host<double>(w.v.p, VEC_BLOCK_INTERLEAVED, y3); }
+        return int(OPMGPU_OK);
+    });
+}
+
+int opmgpu_ilu0_factor(opmgpu_ctx* c)
+{
+    if (!c) return OPMGPU_EINVAL;
+    return guarded(c, [&]() {
+        const int st = ensure_prepared(c); if (st) return st;
+        const int s2 = c->cur_single ? c->ls->factor<float>() : c->ls->factor<double>();
+        c->factored = (s2 == OPMGPU_OK);
+        return s2 == OPMGPU_OK ? int(OPMGPU_OK) : fail(c, s2, "singular diagonal block in ILU0");
+    });
+}
+
+int opmgpu_ilu0_apply(opmgpu_ctx* c, const double* d3, double* v3)
+{
+    if (!c || !d3 || !v3) return OPMGPU_EINVAL;
+    if (!c->factored) return fail(c, OPMGPU_EINVAL, "call opmgpu_ilu0_factor first");
+    return guarded(c, [&]() {
+        LinSolver& ls = *c->ls;
+        if (c->cur_single) { auto& w = ls.work<float>(); ls.vec_from_host<float>(d3, VEC_BLOCK_INTERLEAVED, w.p.p); ls.ilu_apply<float>(w.p.p, w.y.p, c->prm.ilu_relaxation); ls.vec_to_host<float>(w.y.p, VEC_BLOCK_INTERLEAVED, v3); }
+        else { auto& w = ls.work<double>(); ls.vec_from_host<double>(d3, VEC_BLOCK_INTERLEAVED, w.p.p); ls.ilu_apply<double>(w.p.p, w.y.p, c->prm.ilu_relaxation); ls.vec_to_host<double>(w.y.p, VEC_BLOCK_INTERLEAVED, v3); }
+        return int(OPMGPU_OK);
+    });
+}
+
+int opmgpu_ilu0_get(opmgpu_ctx* c, double* val9)
+{
+    if (!c || !val9) return OPMGPU_EINVAL;
+    if (!c->factored) return fail(c, OPMGPU_EINVAL, "call opmgpu_ilu0_factor first");
+    return guarded(c, [&]() { if (c->cur_single) c->ls->get_lu_bsr<float>(val9); else c->ls->get_lu_bsr<double>(val9); return OPMGPU_OK; });
+}
+
+int opmgpu_get_ordering(opmgpu_ctx* c, int32_t* position, int32_t* level, int32_t* nlevels)
+{
+    if (!c || !c->ls->has_pattern()) return OPMGPU_EINVAL;
+    const Plan& P = c->ls->plan;
+    for (int i = 0; i < P.nb; ++i) { if (position) position[i] = P.pos[i]; if (level) level[i] = P.level[P.pos[i]]; }
+    if (nlevels) *nlevels = P.nlevels;
+    return OPMGPU_OK;
+}
+
+int opmgpu_get_residual(opmgpu_ctx* c, double* r)
+{
+    if (!c || !c->model || !r) return OPMGPU_EINVAL;
+    return guarded(c, [&]() { c->model->get_residual(r); return OPMGPU_OK; });
+}
+int opmgpu_get_jacobian_nnzb(opmgpu_ctx* c, int32_t* nnzb)
+{
+    if (!c || !nnzb || !c->ls->has_pattern()) return OPMGPU_EINVAL;
+    *nnzb = c->ls->plan.nnzb;
+    return OPMGPU_OK;
+}
+int opmgpu_get_jacobian_bsr(opmgpu_ctx* c, int32_t* rowptr, int32_t* col, double* val9)
+{
+    if (!c || !c->ls->has_pattern()) return OPMGPU_EINVAL;
+    return guarded(c, [&]() {
+        const Plan& P = c->ls->plan;
+        if (rowptr) std::memcpy(rowptr, P.rowptr.data(), sizeof(int32_t) * (P.nb + 1));
+        if (col) std::memcpy(col, P.col.data(), sizeof(int32_t) * P.nnzb);
+        if (val9) c->ls->get_matrix_bsr(c->ls->matrix_d(), val9);
+        return OPMGPU_OK;
+    });
+}
+
+int opmgpu_time_kernel(opmgpu_ctx* c, int kernel, int reps, double* ms_per_launch)
+{
+    if (!c || reps < 1 || !ms_per_launch) return OPMGPU_EINVAL;
+    return guarded(c, [&]() {
+        if (kernel == OPMGPU_K_ASSEMBLE || kernel == OPMGPU_K_PROPS) {
+            if (!c->model || !c->model->has_state) return fail(c, OPMGPU_EINVAL, "no model / state");
+            *ms_per_launch = c->model->time_assemble(reps, kernel == OPMGPU_K_PROPS);
+            c->factored = false; c->cur_single = -1; c->matrix_loaded = true;
+            return int(OPMGPU_OK);
+        }
+        const int st = ensure_prepared(c); if (st) return st;
+        if (c->cur_single) c->ls->ensure_work<float>(); else c->ls->ensure_work<double>();
+        if ((kernel == OPMGPU_K_ILU_APPLY) && !c->factored) return fail(c, OPMGPU_EINVAL, "call opmgpu_ilu0_factor first");
+        *ms_per_launch = c->ls->time_kernel(kernel, reps, c->cur_single);
+        return int(OPMGPU_OK);
+    });
+}
+
+int opmgpu_last_timings(opmgpu_ctx* c, double* assemble_ms, double* solve_ms, double* update_ms)
+{
+    if (!c) return OPMGPU_EINVAL;
+    if (assemble_ms) *assemble_ms = c->t_assemble;
+    if (solve_ms) *solve_ms = c->t_solve;
+    if (update_ms) *update_ms = c->t_update;
+    return OPMGPU_OK;
+}
+
+// host-only planning entry (no device needed): used by the CPU unit tests of the ordering logic
+int opmgpu_plan_ordering(int nb, const int32_t* rowptr, const int32_t* col, int ordering, int32_t* position, int32_t* level, int32_t* nlevels)
+{
+    Plan P;
+    const int st = build_plan(nb, rowptr, col, ordering, P);
+    if (st != OPMGPU_OK) return st;
+    for (int i = 0; i < nb; ++i) { if (position) position[i] = P.pos[i]; if (level) level[i] = P.level[P.pos[i]]; }
+    if (nlevels) *nlevels = P.nlevels;
+    return OPMGPU_OK;
+}
+
+} // extern "C"

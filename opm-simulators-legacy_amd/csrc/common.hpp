@@ -1,0 +1,95 @@
+// common.hpp -- small HIP utilities shared by the device sources.
+#ifndef OPMGPU_COMMON_HPP
+#define OPMGPU_COMMON_HPP
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/opmgpu.h"
+
+namespace opmgpu {
+
+struct HipError : std::runtime_error {
+    int code;
+    HipError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define OPMGPU_HIP(expr)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            throw ::opmgpu::HipError(e_ == hipErrorOutOfMemory ? OPMGPU_ENOMEM : OPMGPU_ENODEVICE, \
+                                     std::string(#expr) + ": " + hipGetErrorString(e_));         \
+    } while (0)
+
+// RAII device array
+template <class T>
+struct DevArray {
+    T* p = nullptr;
+    size_t n = 0;
+    DevArray() {}
+    DevArray(const DevArray&) = delete;
+    DevArray& operator=(const DevArray&) = delete;
+    ~DevArray() { release(); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    void alloc(size_t count) {
+        if (count == n && p) return;
+        release();
+        if (count == 0) return;
+        OPMGPU_HIP(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+        n = count;
+    }
+    void ensure(size_t count) { if (count > n) alloc(count); }
+    void upload(const T* h, size_t count, hipStream_t s) {
+        ensure(count);
+        if (count) OPMGPU_HIP(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, s));
+    }
+    void upload(const std::vector<T>& h, hipStream_t s) { upload(h.data(), h.size(), s); }
+    void download(T* h, size_t count, hipStream_t s) const {
+        if (count) OPMGPU_HIP(hipMemcpyAsync(h, p, count * sizeof(T), hipMemcpyDeviceToHost, s));
+    }
+    void zero(hipStream_t s) { if (n) OPMGPU_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
+};
+
+constexpr int kBlock = 256;          // 4 wavefronts = 4 SELL slices per workgroup
+constexpr int kMaxRedBlocks = 2048;  // grid cap of the reduction kernels (256 CUs x 8)
+
+inline int grid_for(long n, int block = kBlock) { return int((n + block - 1) / block); }
+
+// ---- wave64 / workgroup reductions (double accumulators; deterministic order) ----
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    return v;
+}
+// sum over a 256-thread block; result valid in thread 0.  `sm` = 4 doubles of LDS per value.
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* sm)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const double s = wave_sum(v[k]);
+        if (lane == 0) sm[k * 4 + w] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) v[k] = (sm[k * 4] + sm[k * 4 + 1]) + (sm[k * 4 + 2] + sm[k * 4 + 3]);
+    }
+}
+
+} // namespace opmgpu
+#endif

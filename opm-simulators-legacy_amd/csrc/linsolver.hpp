@@ -1,0 +1,99 @@
+// linsolver.hpp -- device block-ILU0 + BiCGStab on a SELL-64 3x3-block matrix.
+//
+// GPU replacement of the reference's inner solve:
+//   ISTLSolver::solve -> ParallelOverlappingILU0 + Dune::BiCGSTABSolver  (ISTLSolver.hpp:124-189,250-274)
+// in float or double (NewtonIterationBlackoilInterleaved.cpp:478-480).
+#ifndef OPMGPU_LINSOLVER_HPP
+#define OPMGPU_LINSOLVER_HPP
+
+#include "common.hpp"
+#include "plan.hpp"
+
+namespace opmgpu {
+
+struct DevPlan {
+    int nb = 0, nbp = 0, nslices = 0, nentries = 0, nlevels = 0, nnzb = 0;
+    DevArray<int32_t> slice_ptr, col, src, entry_of_block, nat, pos, trip_ptr, trip_l, trip_u, trip_t;
+    DevArray<int16_t> rowlen, nlower;
+    std::vector<int32_t> level_ptr;
+    void upload(const Plan& P, hipStream_t s);
+};
+
+enum { SC_RHO = 0, SC_RHONEW, SC_ALPHA, SC_OMEGA, SC_BETA, SC_H, SC_NORM2, SC_NORM0_2, SC_FLAG, SC_TR, SC_TT, SC_COUNT = 16 };
+enum { VEC_BLOCK_INTERLEAVED = 0, VEC_EQUATION_MAJOR = 1 };
+
+template <class S>
+struct SolverWork {
+    DevArray<S> A;      // float copy of the matrix (unused for double: the double matrix is used in place)
+    DevArray<S> LU;
+    DevArray<S> r, rt, p, v, t, y, x, b;
+    bool allocated = false;
+};
+
+struct SolveResult { int status = 0; int iterations = 0; double reduction = 0.0; bool converged = false; };
+
+class LinSolver {
+public:
+    explicit LinSolver(hipStream_t s);
+    ~LinSolver();
+
+    // (re)plan when the pattern changes; returns OPMGPU_* status
+    int set_pattern(int nb, const int32_t* rowptr, const int32_t* col, int ordering);
+    bool has_pattern() const { return plan.nb > 0; }
+
+    // matrix values: from a host BSR (B1) -- the assembly kernels write Ad directly (B2)
+    void load_host_bsr(const double* val9);
+    double* matrix_d() { return Ad.p; }
+    void zero_matrix() { Ad.zero(stream); }
+    // make the matrix available in precision S (float: converts Ad -> wf.A)
+    template <class S> void prepare(bool matrix_changed = true);
+    template <class S> const S* matrix();
+
+    template <class S> int factor();                                // ILU0 numeric factorisation
+    template <class S> void ilu_apply(const S* d, S* v, double relax);
+    template <class S> void spmv(const S* x, S* y);
+    // x0 = 0; rhs in work<S>().b; solution in work<S>().x
+    template <class S> SolveResult bicgstab(const opmgpu_params& prm);
+
+    // host <-> device vector staging (caller numbering <-> internal, component-major planes)
+    template <class S> void vec_from_host(const double* h, int layout, S* d);
+    template <class S> void vec_to_host(const S* d, int layout, double* h);
+    // device double vector in caller layout -> internal S vector and back (no PCIe)
+    template <class S> void vec_in(const double* dsrc, int layout, S* d);
+    template <class S> void vec_out(const S* d, int layout, double* ddst);
+
+    void get_matrix_bsr(const double* sell, double* val9);          // Ad-like (double) SELL -> host BSR
+    template <class S> void get_lu_bsr(double* val9);
+
+    template <class S> SolverWork<S>& work();
+    template <class S> void ensure_work();
+
+    // timing of a single kernel on this stream (HIP events), ms per launch
+    double time_kernel(int kernel, int reps, int single_precision);
+
+    Plan plan;
+    DevPlan dp;
+    hipStream_t stream;
+    DevArray<double> Ad;
+    DevArray<double> stage;        // host-BSR staging / vector staging
+    DevArray<double> partials;
+    DevArray<double> scalars;
+    DevArray<int32_t> flags;
+    double* h_scalars = nullptr;   // pinned
+    int32_t* h_flags = nullptr;    // pinned
+    int cur_ordering = -1;
+
+private:
+    SolverWork<double> wd;
+    SolverWork<float> wf;
+};
+
+template <> SolverWork<double>& LinSolver::work<double>();
+template <> SolverWork<float>& LinSolver::work<float>();
+template <> void LinSolver::prepare<double>(bool);
+template <> void LinSolver::prepare<float>(bool);
+template <> const double* LinSolver::matrix<double>();
+template <> const float* LinSolver::matrix<float>();
+
+} // namespace opmgpu
+#endif

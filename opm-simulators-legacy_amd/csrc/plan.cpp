@@ -1,0 +1,147 @@
+// plan.cpp -- see plan.hpp.  Pure host code (no HIP), unit-tested on the CPU.
+#include "plan.hpp"
+
+#include <algorithm>
+#include <numeric>
+
+#include "../../include/opmgpu.h"
+
+namespace opmgpu {
+
+int build_reservoir_pattern(int nc, int nconn, const int32_t* conn_cells, int nw, const int32_t* well_connpos,
+                            const int32_t* well_cells, std::vector<int32_t>& rowptr, std::vector<int32_t>& col,
+                            std::vector<int32_t>& conn_of_block)
+{
+    // (col, code) pairs per row; code as documented in plan.hpp
+    std::vector<std::vector<std::pair<int32_t, int32_t> > > adj(nc);
+    for (int c = 0; c < nc; ++c) adj[c].push_back(std::make_pair(c, -1));
+    for (int f = 0; f < nconn; ++f) {
+        const int a = conn_cells[2 * f], b = conn_cells[2 * f + 1];
+        if (a < 0 || b < 0 || a >= nc || b >= nc || a == b) return OPMGPU_EINVAL;
+        adj[a].push_back(std::make_pair(b, (f << 1) | 0));
+        adj[b].push_back(std::make_pair(a, (f << 1) | 1));
+    }
+    for (int w = 0; w < nw; ++w)
+        for (int i = well_connpos[w]; i < well_connpos[w + 1]; ++i)
+            for (int j = well_connpos[w]; j < well_connpos[w + 1]; ++j) {
+                const int a = well_cells[i], b = well_cells[j];
+                if (a < 0 || b < 0 || a >= nc || b >= nc) return OPMGPU_EINVAL;
+                if (a != b) adj[a].push_back(std::make_pair(b, -2));
+            }
+    rowptr.assign(nc + 1, 0); col.clear(); conn_of_block.clear();
+    for (int c = 0; c < nc; ++c) {
+        auto& v = adj[c];
+        // sort by column; a real connection (code >= 0) wins over well fill (-2) for the same column
+        std::sort(v.begin(), v.end(), [](const std::pair<int32_t, int32_t>& x, const std::pair<int32_t, int32_t>& y) {
+            return x.first != y.first ? x.first < y.first : x.second > y.second; });
+        int32_t last = -1;
+        for (size_t k = 0; k < v.size(); ++k) {
+            if (v[k].first == last) {
+                if (v[k].second >= 0) return OPMGPU_EINVAL;        // two connections between one cell pair
+                continue;
+            }
+            last = v[k].first;
+            col.push_back(v[k].first); conn_of_block.push_back(v[k].second);
+        }
+        rowptr[c + 1] = int32_t(col.size());
+    }
+    return OPMGPU_OK;
+}
+
+int build_plan(int nb, const int32_t* rowptr, const int32_t* col, int ordering, Plan& P)
+{
+    if (nb <= 0 || !rowptr || !col) return OPMGPU_EINVAL;
+    P = Plan();
+    P.nb = nb; P.nbp = (nb + 63) / 64 * 64; P.nnzb = rowptr[nb];
+    P.rowptr.assign(rowptr, rowptr + nb + 1); P.col.assign(col, col + P.nnzb);
+    // validate: ascending unique columns, diagonal present
+    for (int i = 0; i < nb; ++i) {
+        bool diag = false;
+        if (rowptr[i + 1] - rowptr[i] > 32767) return OPMGPU_EINVAL;
+        for (int s = rowptr[i]; s < rowptr[i + 1]; ++s) {
+            if (col[s] < 0 || col[s] >= nb) return OPMGPU_EINVAL;
+            if (s > rowptr[i] && col[s] <= col[s - 1]) return OPMGPU_EINVAL;
+            diag = diag || col[s] == i;
+        }
+        if (!diag) return OPMGPU_EINVAL;
+    }
+    // --- orientation key: NATURAL = caller index; MULTICOLOR = (greedy first-fit colour, caller index)
+    std::vector<int32_t> colour(nb, 0);
+    if (ordering == OPMGPU_ORDER_MULTICOLOR) {
+        std::vector<int32_t> mark(nb + 1, -1);          // mark[c] == i  <=> colour c used by a neighbour of i
+        for (int i = 0; i < nb; ++i) {
+            for (int s = rowptr[i]; s < rowptr[i + 1]; ++s) { const int j = col[s]; if (j < i) mark[colour[j]] = i; }
+            int c = 0; while (mark[c] == i) ++c;
+            colour[i] = c;
+        }
+    } else if (ordering != OPMGPU_ORDER_NATURAL) return OPMGPU_EINVAL;
+    auto before = [&](int a, int b) { return colour[a] != colour[b] ? colour[a] < colour[b] : a < b; };
+    // --- levels = longest path in the DAG oriented by `before`; visit rows in a topological order
+    std::vector<int32_t> topo(nb); std::iota(topo.begin(), topo.end(), 0);
+    if (ordering == OPMGPU_ORDER_MULTICOLOR) std::stable_sort(topo.begin(), topo.end(), [&](int a, int b) { return colour[a] < colour[b]; });
+    std::vector<int32_t> lev(nb, 0);
+    int nlev = 0;
+    for (int t = 0; t < nb; ++t) {
+        const int i = topo[t]; int l = 0;
+        for (int s = rowptr[i]; s < rowptr[i + 1]; ++s) { const int j = col[s]; if (j != i && before(j, i)) l = std::max(l, lev[j] + 1); }
+        lev[i] = l; nlev = std::max(nlev, l + 1);
+    }
+    // --- internal numbering: sort by (level, caller index)
+    P.nat.resize(nb); std::iota(P.nat.begin(), P.nat.end(), 0);
+    std::stable_sort(P.nat.begin(), P.nat.end(), [&](int a, int b) { return lev[a] < lev[b]; });
+    P.pos.resize(nb);
+    for (int r = 0; r < nb; ++r) P.pos[P.nat[r]] = r;
+    P.level.resize(nb); P.nlevels = nlev; P.level_ptr.assign(nlev + 1, 0);
+    for (int r = 0; r < nb; ++r) { P.level[r] = lev[P.nat[r]]; P.level_ptr[P.level[r] + 1]++; }
+    for (int l = 0; l < nlev; ++l) P.level_ptr[l + 1] += P.level_ptr[l];
+    // --- SELL-64
+    P.nslices = P.nbp / 64; P.slice_ptr.assign(P.nslices + 1, 0);
+    P.rowlen.assign(P.nbp, 0); P.nlower.assign(P.nbp, 0);
+    for (int s = 0; s < P.nslices; ++s) {
+        int w = 0;
+        for (int r = s * 64; r < std::min(nb, s * 64 + 64); ++r) { const int c = P.nat[r]; w = std::max(w, rowptr[c + 1] - rowptr[c]); }
+        P.slice_ptr[s + 1] = P.slice_ptr[s] + w;
+    }
+    P.nentries = P.slice_ptr[P.nslices] * 64;
+    P.sell_col.assign(P.nentries, 0); P.sell_src.assign(P.nentries, -1); P.entry_of_block.assign(P.nnzb, -1);
+    std::vector<std::pair<int32_t, int32_t> > tmp;
+    for (int r = 0; r < P.nbp; ++r) {
+        const int base = P.slice_ptr[r >> 6], w = P.slice_ptr[(r >> 6) + 1] - base;
+        int len = 0;
+        if (r < nb) {
+            const int c = P.nat[r];
+            tmp.clear();
+            for (int s = rowptr[c]; s < rowptr[c + 1]; ++s) tmp.push_back(std::make_pair(P.pos[col[s]], s));
+            std::sort(tmp.begin(), tmp.end());
+            len = int(tmp.size());
+            int nl = 0;
+            for (int k = 0; k < len; ++k) {
+                const int e = (base + k) * 64 + (r & 63);
+                P.sell_col[e] = tmp[k].first; P.sell_src[e] = tmp[k].second; P.entry_of_block[tmp[k].second] = e;
+                if (tmp[k].first < r) ++nl;
+            }
+            P.rowlen[r] = int16_t(len); P.nlower[r] = int16_t(nl);
+        }
+        for (int k = len; k < w; ++k) P.sell_col[(base + k) * 64 + (r & 63)] = std::min(r, nb - 1);   // padding: value 0, safe gather
+    }
+    // --- ILU0 update triples
+    P.trip_ptr.assign(nb + 1, 0);
+    std::vector<int32_t> slot_of(nb, -1);
+    for (int i = 0; i < nb; ++i) {
+        const int len = P.rowlen[i], nl = P.nlower[i];
+        for (int k = 0; k < len; ++k) slot_of[P.sell_col[P.entry(i, k)]] = k;
+        for (int a = 0; a < nl; ++a) {
+            const int eij = P.entry(i, a); const int j = P.sell_col[eij];
+            for (int b = P.nlower[j] + 1; b < P.rowlen[j]; ++b) {
+                const int ejk = P.entry(j, b); const int k = P.sell_col[ejk];
+                if (slot_of[k] < 0) continue;
+                P.trip_l.push_back(eij); P.trip_u.push_back(ejk); P.trip_t.push_back(P.entry(i, slot_of[k]));
+            }
+        }
+        for (int k = 0; k < len; ++k) slot_of[P.sell_col[P.entry(i, k)]] = -1;
+        P.trip_ptr[i + 1] = int32_t(P.trip_l.size());
+    }
+    return OPMGPU_OK;
+}
+
+} // namespace opmgpu

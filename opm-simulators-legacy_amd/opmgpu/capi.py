@@ -121,6 +121,7 @@ SIGNATURES = {
     "opmgpu_last_timings": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
     "opmgpu_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "opmgpu_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint8), C.c_int32, C.c_int, _ip, _ip, _ip, _ip, _ip]),
+    "opmgpu_plan_ordering": (C.c_int, [C.c_int, _ip, _ip, C.c_int, _ip, _ip, _ip]),
     "opmgpu_version": (C.c_char_p, []),
     "opmgpu_device_count": (C.c_int, []),
 }

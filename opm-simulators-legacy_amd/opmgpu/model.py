@@ -1,0 +1,265 @@
+"""Host-side mirror of the reference's model / solver interfaces over the C ABI.
+
+`GpuBlackoilModel` carries the method names and call order of Opm::BlackoilModelBase
+(opm/autodiff/BlackoilModelBase_impl.hpp:222-326: prepareStep, nonlinearIteration = assemble ->
+getConvergence -> solveJacobianSystem -> updateState) and `GpuNewtonIteration` those of
+NewtonIterationBlackoilInterface (NewtonIterationBlackoilInterface.hpp:31-52).  Error behaviour
+follows the reference: status codes of the C ABI become the exceptions flow_legacy's time stepper
+catches (AdaptiveTimeStepping_impl.hpp:244-281).  All compute happens in libopmgpu.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class NumericalIssue(RuntimeError):
+    """Opm::NumericalIssue"""
+
+
+class LinearSolverProblem(RuntimeError):
+    """Opm::LinearSolverProblem"""
+
+
+class ISTLError(RuntimeError):
+    """Dune::ISTLError / Dune::MatrixBlockError"""
+
+
+class TooManyIterations(RuntimeError):
+    """Opm::TooManyIterations"""
+
+
+def _raise(lib, ctx, st):
+    if st == capi.OK:
+        return
+    msg = lib.opmgpu_last_error(ctx)
+    msg = msg.decode() if msg else ""
+    if st == capi.ENUMERICAL:
+        raise NumericalIssue(msg)
+    if st == capi.ELINSOLVE:
+        raise LinearSolverProblem(msg)
+    if st in (capi.EBREAKDOWN, capi.ESINGULAR):
+        raise ISTLError(msg)
+    if st == capi.EINVAL:
+        raise ValueError("opmgpu: invalid argument: " + msg)
+    raise RuntimeError("opmgpu status %d: %s" % (st, msg))
+
+
+class GpuNewtonIteration:
+    """B1: computeNewtonIncrement on a BCRS<3x3> system handed over as BSR."""
+
+    def __init__(self, params=None, device=0):
+        self.lib = capi.load()
+        self.params = params or capi.default_params()
+        self.ctx = C.c_void_p()
+        st = self.lib.opmgpu_create_solver(C.byref(self.ctx), device, C.byref(self.params))
+        if st != capi.OK:
+            raise RuntimeError("opmgpu_create_solver failed with status %d (no GPU? there is no CPU fallback)" % st)
+        self._iterations = 0
+        self.reduction = 0.0
+
+    def close(self):
+        if self.ctx:
+            self.lib.opmgpu_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def iterations(self):
+        return self._iterations
+
+    def parallelInformation(self):
+        return None         # empty boost::any <=> serial
+
+    def computeNewtonIncrement(self, rowptr, col, val9, rhs3, single_precision):
+        nb = rowptr.size - 1
+        x = np.zeros(3 * nb)
+        it, red = C.c_int(0), C.c_double(0)
+        st = self.lib.opmgpu_solve_bsr(self.ctx, nb, capi.iptr(rowptr), capi.iptr(col), capi.dptr(capi.f64(val9)),
+                                       capi.dptr(capi.f64(rhs3)), int(single_precision), capi.dptr(x), C.byref(it), C.byref(red))
+        self._iterations, self.reduction = it.value, red.value
+        _raise(self.lib, self.ctx, st)
+        return x
+
+    # kernel-level helpers (parity tests / bench)
+    def load(self, rowptr, col, val9, single_precision=False):
+        nb = rowptr.size - 1
+        _raise(self.lib, self.ctx, self.lib.opmgpu_load_bsr(self.ctx, nb, capi.iptr(rowptr), capi.iptr(col), capi.dptr(capi.f64(val9)), int(single_precision)))
+        self.nb = nb
+
+    def spmv(self, x3):
+        y = np.zeros(3 * self.nb)
+        _raise(self.lib, self.ctx, self.lib.opmgpu_spmv(self.ctx, capi.dptr(capi.f64(x3)), capi.dptr(y)))
+        return y
+
+    def ilu0_factor(self):
+        _raise(self.lib, self.ctx, self.lib.opmgpu_ilu0_factor(self.ctx))
+
+    def ilu0_apply(self, d3):
+        v = np.zeros(3 * self.nb)
+        _raise(self.lib, self.ctx, self.lib.opmgpu_ilu0_apply(self.ctx, capi.dptr(capi.f64(d3)), capi.dptr(v)))
+        return v
+
+    def ilu0_get(self, nnzb):
+        lu = np.zeros((nnzb, 9))
+        _raise(self.lib, self.ctx, self.lib.opmgpu_ilu0_get(self.ctx, capi.dptr(lu)))
+        return lu
+
+    def ordering(self):
+        pos, lev = np.zeros(self.nb, np.int32), np.zeros(self.nb, np.int32)
+        nl = C.c_int32(0)
+        _raise(self.lib, self.ctx, self.lib.opmgpu_get_ordering(self.ctx, capi.iptr(pos), capi.iptr(lev), C.byref(nl)))
+        return pos, lev, nl.value
+
+    def time_kernel(self, kernel, reps=20):
+        ms = C.c_double(0)
+        _raise(self.lib, self.ctx, self.lib.opmgpu_time_kernel(self.ctx, kernel, reps, C.byref(ms)))
+        return ms.value
+
+
+class GpuBlackoilModel:
+    """B2: the BlackoilModel hooks, state resident on the device."""
+
+    def __init__(self, grid, tables, params=None, device=0, wells=None):
+        self.lib = capi.load()
+        self.grid, self.tables = grid, tables
+        self.params = params or capi.default_params()
+        self.ctx = C.c_void_p()
+        st = self.lib.opmgpu_create(C.byref(self.ctx), device, C.byref(grid.struct()), C.byref(tables.struct()), C.byref(self.params))
+        if st != capi.OK:
+            raise RuntimeError("opmgpu_create failed with status %d (no GPU? there is no CPU fallback)" % st)
+        self.nc = grid.nc
+        self.max_single_precision_days = 20.0       # BlackoilModelParameters.cpp:95
+        self.linear_iterations = 0
+        self.dt = None
+        if wells is not None:
+            self.setWells(*wells)
+
+    def close(self):
+        if self.ctx:
+            self.lib.opmgpu_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, st):
+        _raise(self.lib, self.ctx, st)
+
+    def setWells(self, well_connpos, well_cells):
+        cp, wc = capi.i32(well_connpos), capi.i32(well_cells)
+        self._chk(self.lib.opmgpu_set_wells(self.ctx, cp.size - 1, capi.iptr(cp), capi.iptr(wc)))
+
+    def setState(self, st):
+        self._chk(self.lib.opmgpu_set_state(self.ctx, capi.dptr(st.p), capi.dptr(st.sat), capi.dptr(st.rs), capi.dptr(st.rv), capi.bptr(st.hc)))
+
+    def getState(self):
+        from .decks import State
+        n = self.nc
+        st = State(np.zeros(n), np.zeros((n, 3)), np.zeros(n), np.zeros(n), np.zeros(n, np.int8))
+        self._chk(self.lib.opmgpu_get_state(self.ctx, capi.dptr(st.p), capi.dptr(st.sat), capi.dptr(st.rs), capi.dptr(st.rv), capi.bptr(st.hc)))
+        return st
+
+    # --- BlackoilModelBase hooks -------------------------------------------------------------
+    def prepareStep(self, dt, state=None):
+        """prepareStep (:222-232): pvdt = pv/dt is folded into assemble(); state upload if given."""
+        self.dt = float(dt)
+        if state is not None:
+            self.setState(state)
+
+    def assemble(self, initial_assembly):
+        self._chk(self.lib.opmgpu_assemble(self.ctx, self.dt, int(initial_assembly), None, None, None, None, None))
+
+    def getConvergence(self):
+        B, CNV, MB, linf = np.zeros(3), np.zeros(3), np.zeros(3), np.zeros(3)
+        conv = C.c_int(0)
+        st = self.lib.opmgpu_convergence(self.ctx, self.dt, capi.dptr(B), capi.dptr(CNV), capi.dptr(MB), capi.dptr(linf), C.byref(conv))
+        self.B_avg, self.CNV, self.MB, self.linf = B, CNV, MB, linf
+        self._chk(st)
+        return bool(conv.value)
+
+    def solveJacobianSystem(self, want_dx=False, single_precision=None):
+        if single_precision is None:     # residual_.singlePrecision = dt < maxSinglePrecisionTimeStep_ (:284)
+            single_precision = self.dt < self.max_single_precision_days * 86400.0
+        dx = np.zeros(3 * self.nc) if want_dx else None
+        it, red = C.c_int(0), C.c_double(0)
+        st = self.lib.opmgpu_solve(self.ctx, int(single_precision), capi.dptr(dx), C.byref(it), C.byref(red))
+        self.linear_iterations, self.linear_reduction = it.value, red.value
+        self._chk(st)
+        return dx
+
+    def updateState(self, dx=None, relax=1.0):
+        self._chk(self.lib.opmgpu_update_state(self.ctx, capi.dptr(None if dx is None else capi.f64(dx)), float(relax)))
+
+    def nonlinearIteration(self, iteration, single_precision=None):
+        """nonlinearIteration (:239-326). Returns (converged, linear_iterations)."""
+        self.assemble(iteration == 0)
+        converged = self.getConvergence()
+        lin = 0
+        if not converged or iteration < 1:         # min_iter = 1 (NonlinearSolver_impl.hpp:179-219)
+            self.solveJacobianSystem(single_precision=single_precision)
+            lin = self.linear_iterations
+            self.updateState()
+        return converged, lin
+
+    # --- parity / bench helpers --------------------------------------------------------------
+    def residual(self):
+        r = np.zeros(3 * self.nc)
+        self._chk(self.lib.opmgpu_get_residual(self.ctx, capi.dptr(r)))
+        return r
+
+    def jacobian(self):
+        n = C.c_int32(0)
+        self._chk(self.lib.opmgpu_get_jacobian_nnzb(self.ctx, C.byref(n)))
+        rowptr, col, val = np.zeros(self.nc + 1, np.int32), np.zeros(n.value, np.int32), np.zeros((n.value, 9))
+        self._chk(self.lib.opmgpu_get_jacobian_bsr(self.ctx, capi.iptr(rowptr), capi.iptr(col), capi.dptr(val)))
+        return rowptr, col, val
+
+    def perfProps(self, nperf):
+        out = np.zeros((nperf, capi.PERF_K))
+        self._chk(self.lib.opmgpu_perf_props(self.ctx, capi.dptr(out)))
+        return out
+
+    def addWellTerms(self, resid_delta, rc, blocks):
+        rc = capi.i32(rc)
+        nblk = rc.size // 2
+        self._chk(self.lib.opmgpu_add_well_terms(self.ctx, capi.dptr(capi.f64(resid_delta)), nblk, capi.iptr(rc), capi.dptr(capi.f64(blocks))))
+
+    def timings(self):
+        a, s, u = C.c_double(0), C.c_double(0), C.c_double(0)
+        self.lib.opmgpu_last_timings(self.ctx, C.byref(a), C.byref(s), C.byref(u))
+        return a.value, s.value, u.value
+
+    def time_kernel(self, kernel, reps=20):
+        ms = C.c_double(0)
+        self._chk(self.lib.opmgpu_time_kernel(self.ctx, kernel, reps, C.byref(ms)))
+        return ms.value
+
+    def ordering(self):
+        pos, lev = np.zeros(self.nc, np.int32), np.zeros(self.nc, np.int32)
+        nl = C.c_int32(0)
+        self._chk(self.lib.opmgpu_get_ordering(self.ctx, capi.iptr(pos), capi.iptr(lev), C.byref(nl)))
+        return pos, lev, nl.value
+
+
+def newton_step(model, max_iter=10, min_iter=1):
+    """NonlinearSolver::step (NonlinearSolver_impl.hpp:119-174) without the relaxation logic.
+    Returns (newton_iterations, linear_iterations)."""
+    it, lin_total = 0, 0
+    while True:
+        converged, lin = model.nonlinearIteration(it)
+        lin_total += lin
+        it += 1
+        if not ((not converged and it <= max_iter) or it <= min_iter):
+            break
+    if not converged:
+        raise TooManyIterations("Failed to complete a time step within %d iterations." % max_iter)
+    return it, lin_total

@@ -1,0 +1,97 @@
+"""CPU-side checks of the C ABI library: it loads, exports every declared symbol, refuses to
+compute without a GPU (no CPU fallback), and its host-side sparsity planner is sound."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from opmgpu import capi, decks
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return capi.load()
+
+
+def test_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "opmgpu.h")).read()
+    names = set(re.findall(r"\b(opmgpu_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 30
+    for n in sorted(names):
+        assert hasattr(lib, n), n
+    assert names == set(capi.SIGNATURES), names ^ set(capi.SIGNATURES)
+    assert b"gfx950" in lib.opmgpu_version()
+
+
+def test_default_params_match_reference(lib):
+    p = capi.Params()
+    lib.opmgpu_default_params(C.byref(p))
+    q = capi.default_params()
+    for name, _ in capi.Params._fields_:
+        a, b = getattr(p, name), getattr(q, name)
+        assert (list(a) == list(b)) if name == "matbalscale" else (a == b), name
+    # BlackoilModelParameters.cpp:76-102, BlackoilModelBase_impl.hpp:139
+    assert (p.dp_max_rel, p.ds_max, p.tolerance_mb, p.tolerance_cnv) == (0.3, 0.2, 1e-5, 1e-2)
+    assert list(p.matbalscale) == [1.1169, 1.0031, 0.0031]
+
+
+@pytest.mark.skipif(capi.load().opmgpu_device_count() > 0, reason="a GPU is present")
+def test_no_cpu_fallback(lib):
+    ctx = C.c_void_p()
+    assert lib.opmgpu_create_solver(C.byref(ctx), 0, None) == capi.ENODEVICE
+    g = decks.cartesian_grid(2, 2, 2)
+    t = decks.satfunc_standard_tables()
+    assert lib.opmgpu_create(C.byref(ctx), 0, C.byref(g.struct()), C.byref(t.struct()), None) == capi.ENODEVICE
+    assert not ctx
+
+
+def _plan(lib, rowptr, col, ordering):
+    nb = rowptr.size - 1
+    pos, lev = np.zeros(nb, np.int32), np.zeros(nb, np.int32)
+    nl = C.c_int32(0)
+    st = lib.opmgpu_plan_ordering(nb, capi.iptr(rowptr), capi.iptr(col), ordering, capi.iptr(pos), capi.iptr(lev), C.byref(nl))
+    return st, pos, lev, nl.value
+
+
+@pytest.mark.parametrize("ordering", [capi.ORDER_NATURAL, capi.ORDER_MULTICOLOR])
+def test_plan_ordering_properties(lib, oracle, ordering):
+    wells = (np.array([0, 4, 7], np.int32), np.array([3, 40, 77, 110, 5, 6, 90], np.int32))
+    grid = decks.cartesian_grid(7, 5, 4, nnc_fraction=0.05)
+    rowptr, col = oracle.pattern(grid, *wells)
+    st, pos, lev, nl = _plan(lib, rowptr, col, ordering)
+    assert st == 0
+    nb = grid.nc
+    assert sorted(pos.tolist()) == list(range(nb))              # a permutation
+    assert np.all(np.diff(lev[np.argsort(pos)]) >= 0)             # rows are level-major
+    for i in range(nb):                                           # a level only depends on lower levels
+        for j in col[rowptr[i]:rowptr[i + 1]]:
+            if j != i:
+                assert lev[i] != lev[j]
+                assert (pos[j] < pos[i]) == (lev[j] < lev[i])
+    if ordering == capi.ORDER_NATURAL:                            # orientation = caller order
+        for i in range(nb):
+            for j in col[rowptr[i]:rowptr[i + 1]]:
+                assert (pos[j] < pos[i]) == (j < i)
+
+
+def test_plan_red_black_on_cartesian(lib, oracle):
+    grid = decks.cartesian_grid(6, 5, 4)
+    rowptr, col = oracle.pattern(grid)
+    st, pos, lev, nl = _plan(lib, rowptr, col, capi.ORDER_MULTICOLOR)
+    assert st == 0 and nl == 2
+    i, j, k = np.unravel_index(np.arange(grid.nc), (4, 5, 6))[::-1]
+    assert np.array_equal(lev, (i + j + k) % 2)
+    st, pos, lev, nl = _plan(lib, rowptr, col, capi.ORDER_NATURAL)
+    assert nl == 6 + 5 + 4 - 2 and np.array_equal(lev, i + j + k)
+
+
+def test_plan_rejects_bad_patterns(lib):
+    rowptr = np.array([0, 1, 2], np.int32)
+    assert _plan(lib, rowptr, np.array([1, 1], np.int32), 0)[0] == capi.EINVAL      # missing diagonal
+    rowptr = np.array([0, 2, 3], np.int32)
+    assert _plan(lib, rowptr, np.array([1, 0, 1], np.int32), 0)[0] == capi.EINVAL   # unsorted columns
+    assert _plan(lib, np.array([0, 1, 2], np.int32), np.array([0, 1], np.int32), 7)[0] == capi.EINVAL

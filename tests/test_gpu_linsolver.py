@@ -1,0 +1,133 @@
+"""GPU parity: SELL-64 SpMV, level-scheduled block-ILU0 and BiCGStab vs the CPU oracle, through the C ABI."""
+import numpy as np
+import pytest
+import scipy.sparse.linalg as spla
+
+from opmgpu import capi, decks
+from opmgpu.model import GpuNewtonIteration, ISTLError, LinearSolverProblem
+from util import bsr_to_scipy, random_block_matrix, rel_err
+
+pytestmark = pytest.mark.gpu
+
+WELLS = (np.array([0, 5, 9], np.int32), np.array([3, 40, 77, 110, 200, 5, 6, 90, 301], np.int32))
+
+
+def _patterns(oracle):
+    g1 = decks.cartesian_grid(9, 7, 6)                                    # 378 rows: not a multiple of 64
+    g2 = decks.cartesian_grid(8, 8, 5, nnc_fraction=0.05)                 # NNC: unstructured rows
+    act = np.random.default_rng(3).random(10 * 9 * 6) > 0.4
+    g3 = decks.cartesian_grid(10, 9, 6, actnum=act)                       # holes: ragged rows
+    return [("cart", oracle.pattern(g1)), ("nnc+wells", oracle.pattern(g2, *WELLS)), ("actnum", oracle.pattern(g3))]
+
+
+@pytest.mark.parametrize("ordering", [capi.ORDER_NATURAL, capi.ORDER_MULTICOLOR])
+@pytest.mark.parametrize("single", [False, True])
+def test_spmv_ilu_parity(gpu_lib, oracle, ordering, single):
+    for name, (rowptr, col) in _patterns(oracle):
+        nb = rowptr.size - 1
+        val = random_block_matrix(rowptr, col, seed=nb)
+        rng = np.random.default_rng(nb + 1)
+        x = rng.uniform(-1, 1, 3 * nb)
+        s = GpuNewtonIteration(capi.default_params(ilu_ordering=ordering))
+        s.load(rowptr, col, val, single)
+        # SpMV
+        y, yo = s.spmv(x), oracle.spmv(rowptr, col, val, x, single)
+        assert rel_err(y, yo) < (2e-6 if single else 1e-14), name
+        # ordering reported by the library is a valid elimination order; feed it to the oracle
+        pos, lev, nl = s.ordering()
+        assert sorted(pos.tolist()) == list(range(nb))
+        # ILU0 factors
+        s.ilu0_factor()
+        lu = s.ilu0_get(col.size)
+        st, luo = oracle.ilu0(rowptr, col, val, position=pos, single=single)
+        assert st == 0
+        assert rel_err(lu, luo) < (5e-6 if single else 1e-13), name
+        # ILU0 apply (relaxation 0.9 folded into the forward sweep)
+        v, vo = s.ilu0_apply(x), oracle.ilu0_apply(rowptr, col, luo, x, position=pos, relax=0.9, single=single)
+        assert rel_err(v, vo) < (5e-6 if single else 1e-13), name
+        s.close()
+
+
+def test_spmv_linearity_and_edge_sizes(gpu_lib, oracle):
+    for nb in (1, 2, 63, 64, 65):
+        rowptr = np.arange(nb + 1, dtype=np.int32) if nb < 3 else None
+        if rowptr is None:
+            rows = [[j for j in (i - 1, i, i + 1) if 0 <= j < nb] for i in range(nb)]
+            rowptr = np.cumsum([0] + [len(r) for r in rows]).astype(np.int32)
+            col = np.concatenate(rows).astype(np.int32)
+        else:
+            col = np.arange(nb, dtype=np.int32)
+        val = random_block_matrix(rowptr, col, seed=nb)
+        s = GpuNewtonIteration()
+        s.load(rowptr, col, val)
+        rng = np.random.default_rng(nb)
+        x, z = rng.standard_normal(3 * nb), rng.standard_normal(3 * nb)
+        assert rel_err(s.spmv(2.0 * x - 3.0 * z), 2.0 * s.spmv(x) - 3.0 * s.spmv(z)) < 1e-13
+        assert rel_err(s.spmv(x), bsr_to_scipy(rowptr, col, val) @ x) < 1e-14
+        s.close()
+
+
+@pytest.mark.parametrize("ordering", [capi.ORDER_NATURAL, capi.ORDER_MULTICOLOR])
+@pytest.mark.parametrize("single", [False, True])
+def test_bicgstab_parity(gpu_lib, oracle, ordering, single):
+    """computeNewtonIncrement on an assembled black-oil Jacobian: same stopping rule as the oracle,
+    solution within the solver tolerance of the exact solve, iteration count within +-2."""
+    grid = decks.cartesian_grid(12, 10, 8, lognormal_sigma=1.0)
+    tab = decks.satfunc_standard_tables()
+    st = decks.initial_state(grid, tab, perturb=0.01)
+    prm = capi.default_params(ilu_ordering=ordering)
+    rowptr, col = oracle.pattern(grid)
+    r, val, _, _ = oracle.assemble(grid, tab, 10 * decks.DAY, st, rowptr, col, scale=tuple(prm.matbalscale))
+    nc = grid.nc
+    b = np.ascontiguousarray((r * np.repeat(np.asarray(prm.matbalscale[:]), nc)).reshape(3, nc).T).ravel()
+    A = bsr_to_scipy(rowptr, col, val)
+    xe = spla.spsolve(A.tocsc(), b)
+    s = GpuNewtonIteration(prm)
+    x = s.computeNewtonIncrement(rowptr, col, val, b, single)
+    pos, _, _ = s.ordering()
+    sto, xo, ito, redo, _ = oracle.bicgstab(rowptr, col, val, b, prm, position=pos, single=single)
+    assert sto == 0
+    assert abs(s.iterations() - ito) <= 2, (s.iterations(), ito)
+    res = np.linalg.norm(A @ x - b) / np.linalg.norm(b)
+    assert res < 1.5e-2 and s.reduction < 1e-2, (res, s.reduction)          # linear_solver_reduction = 1e-2
+    # tight tolerance: both converge to the direct solution
+    prm2 = capi.default_params(ilu_ordering=ordering, linear_solver_reduction=1e-5 if single else 1e-10, linear_solver_maxiter=300)
+    s2 = GpuNewtonIteration(prm2)
+    x2 = s2.computeNewtonIncrement(rowptr, col, val, b, single)
+    assert np.linalg.norm(x2 - xe) / np.linalg.norm(xe) < (5e-3 if single else 1e-7)
+    s.close(); s2.close()
+
+
+def test_solver_error_contract(gpu_lib, oracle):
+    grid = decks.cartesian_grid(6, 5, 4)
+    rowptr, col = oracle.pattern(grid)
+    val = random_block_matrix(rowptr, col, seed=2, dominance=0.31)       # weakly dominant: needs iterations
+    b = np.random.default_rng(0).standard_normal(3 * grid.nc)
+    s = GpuNewtonIteration(capi.default_params(linear_solver_maxiter=1, linear_solver_reduction=1e-12))
+    with pytest.raises(LinearSolverProblem):                             # ISTLSolver.hpp:358-368
+        s.computeNewtonIncrement(rowptr, col, val, b, False)
+    s.close()
+    s = GpuNewtonIteration(capi.default_params(linear_solver_maxiter=1, linear_solver_reduction=1e-12, ignore_convergence_failure=1))
+    s.computeNewtonIncrement(rowptr, col, val, b, False)                 # ignoreConvergenceFailure_
+    s.close()
+    val2 = val.copy()
+    val2[np.flatnonzero(col == 0)[0]] = 0.0                              # singular pivot block in row 0
+    s = GpuNewtonIteration()
+    with pytest.raises(ISTLError):
+        s.computeNewtonIncrement(rowptr, col, val2, b, False)
+    with pytest.raises(ValueError):                                      # pattern without a diagonal
+        s.computeNewtonIncrement(np.array([0, 1, 2], np.int32), np.array([1, 0], np.int32), np.ones((2, 9)), np.ones(6), False)
+    s.close()
+
+
+def test_pattern_cache_and_replan(gpu_lib, oracle):
+    s = GpuNewtonIteration()
+    for dims in ((5, 4, 3), (5, 4, 3), (6, 4, 3)):
+        grid = decks.cartesian_grid(*dims)
+        rowptr, col = oracle.pattern(grid)
+        val = random_block_matrix(rowptr, col, seed=sum(dims))
+        b = np.random.default_rng(1).standard_normal(3 * grid.nc)
+        x = s.computeNewtonIncrement(rowptr, col, val, b, False)
+        A = bsr_to_scipy(rowptr, col, val)
+        assert np.linalg.norm(A @ x - b) / np.linalg.norm(b) < 1e-2
+    s.close()
