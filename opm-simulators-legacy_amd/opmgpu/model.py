@@ -77,7 +77,7 @@ class GpuNewtonIteration:
         return None         # empty boost::any <=> serial
 
     def computeNewtonIncrement(self, rowptr, col, val9, rhs3, single_precision):
-        nb = rowptr.size - 1
+        nb = self.nb = rowptr.size - 1
         x = np.zeros(3 * nb)
         it, red = C.c_int(0), C.c_double(0)
         st = self.lib.opmgpu_solve_bsr(self.ctx, nb, capi.iptr(rowptr), capi.iptr(col), capi.dptr(capi.f64(val9)),

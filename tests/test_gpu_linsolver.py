@@ -94,7 +94,12 @@ def test_bicgstab_parity(gpu_lib, oracle, ordering, single):
     prm2 = capi.default_params(ilu_ordering=ordering, linear_solver_reduction=1e-5 if single else 1e-10, linear_solver_maxiter=300)
     s2 = GpuNewtonIteration(prm2)
     x2 = s2.computeNewtonIncrement(rowptr, col, val, b, single)
-    assert np.linalg.norm(x2 - xe) / np.linalg.norm(xe) < (5e-3 if single else 1e-7)
+    if single:      # f32: as accurate as the oracle's f32 solve of the same system (cond(A) * eps_f32 limits both)
+        _, xo2, _, _, _ = oracle.bicgstab(rowptr, col, val, b, prm2, position=pos, single=True)
+        err_o = np.linalg.norm(xo2 - xe) / np.linalg.norm(xe)
+        assert np.linalg.norm(x2 - xe) / np.linalg.norm(xe) < 3.0 * err_o + 1e-6
+    else:
+        assert np.linalg.norm(x2 - xe) / np.linalg.norm(xe) < 1e-7
     s.close(); s2.close()
 
 
