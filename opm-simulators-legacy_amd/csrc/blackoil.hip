@@ -287,11 +287,22 @@ __global__ __launch_bounds__(kBlock) void k_flux(int nb, int nbp, const int32_t*
                                                  const int32_t* __restrict__ conn_code, const double* __restrict__ trans,
                                                  const double* __restrict__ gdz, const double* __restrict__ thpres,
                                                  const double* __restrict__ pstate, const double* __restrict__ props,
-                                                 double s0, double s1, double s2, double* __restrict__ R, double* __restrict__ A)
+                                                 double s0, double s1, double s2, const int8_t* __restrict__ mask,
+                                                 double* __restrict__ R, double* __restrict__ A)
 {
     const int row = blockIdx.x * kBlock + threadIdx.x;
     if (row >= nb) return;
     const int base = slice_ptr[row >> 6], lane = row & 63, nl = nlower[row], len = rowlen[row];
+    if (mask && !mask[row]) {
+        // ghost row (multi-GPU): identity block, zero residual -- the owner rank assembles the real equation
+        for (int k = 0; k < len; ++k) {
+            double* bptr = A + long(base + k) * 576 + lane;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) bptr[q * 64] = (k == nl && (q == 0 || q == 4 || q == 8)) ? 1.0 : 0.0;
+        }
+        R[row] = 0.0; R[nbp + row] = 0.0; R[2 * long(nbp) + row] = 0.0;
+        return;
+    }
     const double scale[3] = { s0, s1, s2 };
     double Rl[3] = { R[row], R[nbp + row], R[2 * long(nbp) + row] };
     double D[9];
@@ -373,9 +384,11 @@ __global__ __launch_bounds__(kBlock) void k_flux(int nb, int nbp, const int32_t*
     R[row] = Rl[0]; R[nbp + row] = Rl[1]; R[2 * long(nbp) + row] = Rl[2];
 }
 
-// convergenceReduction (BlackoilModelBase_impl.hpp:1633-1714): per phase sum(1/b), max|R|/pv, sum R, max|R|, non-finite flag
+// convergenceReduction (BlackoilModelBase_impl.hpp:1633-1714): per phase sum(1/b), sum R, non-finite flag (sums: slots 0..6),
+// max|R|/pv, max|R| (maxima: slots 7..12); owned rows only (multi-GPU: followed by an all-reduce of each group)
+__device__ __forceinline__ bool conv_is_max(int q) { return q >= 7; }
 __global__ __launch_bounds__(kBlock) void k_conv_partial(int nb, int nbp, const double* __restrict__ R, const double* __restrict__ binv,
-                                                         const double* __restrict__ pv, double* __restrict__ part)
+                                                         const double* __restrict__ pv, const int8_t* __restrict__ mask, double* __restrict__ part)
 {
     __shared__ double sm[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -383,20 +396,21 @@ __global__ __launch_bounds__(kBlock) void k_conv_partial(int nb, int nbp, const 
 #pragma unroll
     for (int q = 0; q < 13; ++q) vals[q] = 0.0;
     for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < nb; i += long(gridDim.x) * kBlock) {
+        if (mask && !mask[i]) continue;
         const double ipv = 1.0 / pv[i];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const double r = R[long(a) * nbp + i];
             vals[a] += binv[long(a) * nbp + i];
-            vals[3 + a] = fmax(vals[3 + a], fabs(r) * ipv);
-            vals[6 + a] += r;
-            vals[9 + a] = fmax(vals[9 + a], fabs(r));
-            if (!(fabs(r) <= 1.79e308)) vals[12] = 1.0;
+            vals[3 + a] += r;
+            vals[7 + a] = fmax(vals[7 + a], fabs(r) * ipv);
+            vals[10 + a] = fmax(vals[10 + a], fabs(r));
+            if (!(fabs(r) <= 1.79e308)) vals[6] = 1.0;
         }
     }
 #pragma unroll
     for (int q = 0; q < 13; ++q) {
-        const bool is_max = (q >= 3 && q < 6) || q >= 9;
+        const bool is_max = conv_is_max(q);
         const double s = is_max ? wave_max(vals[q]) : wave_sum(vals[q]);
         __syncthreads();
         if (lane == 0) sm[w] = s;
@@ -409,7 +423,7 @@ __global__ __launch_bounds__(kBlock) void k_conv_final(int nblocks, const double
     __shared__ double sm[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int q = 0; q < 13; ++q) {
-        const bool is_max = (q >= 3 && q < 6) || q >= 9;
+        const bool is_max = conv_is_max(q);
         double v = 0.0;
         for (int i = threadIdx.x; i < nblocks; i += kBlock) { const double x = part[long(q) * nblocks + i]; v = is_max ? fmax(v, x) : v + x; }
         const double s = is_max ? wave_max(v) : wave_sum(v);
@@ -702,7 +716,7 @@ void BlackoilDevice::assemble(double dt, bool initial)
                        ls.dp.slice_ptr.p, ls.dp.nlower.p, d_props.p, d_accum0.p, d_R.p, d_binv.p, ls.matrix_d());
     hipLaunchKernelGGL(k_flux, dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, P.nbp, ls.dp.slice_ptr.p, ls.dp.col.p, ls.dp.rowlen.p,
                        ls.dp.nlower.p, d_conn_code.p, d_trans.p, d_gdz.p, use_thpres ? d_thpres.p : (const double*)nullptr,
-                       d_p.p, d_props.p, sc[0], sc[1], sc[2], d_R.p, ls.matrix_d());
+                       d_p.p, d_props.p, sc[0], sc[1], sc[2], ls.comm ? ls.comm->owner_mask() : (const int8_t*)nullptr, d_R.p, ls.matrix_d());
 }
 
 double BlackoilDevice::time_assemble(int reps, int props_only)
@@ -734,22 +748,40 @@ int BlackoilDevice::convergence(double dt, double* B3, double* CNV3, double* MB3
 {
     const Plan& P = ls.plan;
     const int g = std::min(grid_for(nc), kMaxRedBlocks);
-    hipLaunchKernelGGL(k_conv_partial, dim3(g), dim3(kBlock), 0, stream, nc, P.nbp, d_R.p, d_binv.p, d_pv.p, d_red.p + 16);
+    const int8_t* mask = ls.comm ? ls.comm->owner_mask() : nullptr;
+    hipLaunchKernelGGL(k_conv_partial, dim3(g), dim3(kBlock), 0, stream, nc, P.nbp, d_R.p, d_binv.p, d_pv.p, mask, d_red.p + 16);
     hipLaunchKernelGGL(k_conv_final, dim3(1), dim3(kBlock), 0, stream, g, d_red.p + 16, d_red.p);
+    if (ls.comm) { ls.comm->allreduce_sum(d_red.p, 7, stream); ls.comm->allreduce_max(d_red.p + 7, 6, stream); }
     OPMGPU_HIP(hipMemcpyAsync(h_red, d_red.p, 13 * sizeof(double), hipMemcpyDeviceToHost, stream));
     OPMGPU_HIP(hipStreamSynchronize(stream));
     bool conv = true; int status = OPMGPU_OK;
-    if (h_red[12] != 0.0) status = OPMGPU_ENUMERICAL;                                   // non-finite residual, :1562-1566
+    const double ncg = ls.comm ? double(ls.comm->n_owned_global) : double(nc);
+    const double pvs = ls.comm ? pvsum_global : pvsum;
+    if (h_red[6] != 0.0) status = OPMGPU_ENUMERICAL;                                    // non-finite residual, :1562-1566
     for (int a = 0; a < 3; ++a) {
-        const double B = h_red[a] / nc;
-        const double cnv = B * dt * h_red[3 + a], mb = std::fabs(B * h_red[6 + a]) * dt / pvsum;
-        if (B3) B3[a] = B; if (CNV3) CNV3[a] = cnv; if (MB3) MB3[a] = mb; if (linf3) linf3[a] = h_red[9 + a];
+        const double B = h_red[a] / ncg;
+        const double cnv = B * dt * h_red[7 + a], mb = std::fabs(B * h_red[3 + a]) * dt / pvs;
+        if (B3) B3[a] = B; if (CNV3) CNV3[a] = cnv; if (MB3) MB3[a] = mb; if (linf3) linf3[a] = h_red[10 + a];
         conv = conv && (mb < prm.tolerance_mb) && (cnv < prm.tolerance_cnv);
         if (std::isnan(mb) || std::isnan(cnv)) status = OPMGPU_ENUMERICAL;              // :1828-1836
         if (mb > prm.max_residual_allowed || cnv > prm.max_residual_allowed) status = OPMGPU_ENUMERICAL;   // :1837-1845
     }
     if (converged) *converged = conv ? 1 : 0;
     return status;
+}
+
+// multi-GPU: the communicator knows rank-local caller numbering; (re)derive internal rows + global sums
+void BlackoilDevice::attach_comm(CommBase* c, int n_owned)
+{
+    ls.comm = c;
+    double loc[2] = { 0.0, double(n_owned) };
+    for (int i = 0; i < n_owned; ++i) loc[0] += h_pv[i];
+    OPMGPU_HIP(hipMemcpyAsync(d_red.p, loc, 2 * sizeof(double), hipMemcpyHostToDevice, stream));
+    c->allreduce_sum(d_red.p, 2, stream);
+    OPMGPU_HIP(hipMemcpyAsync(h_red, d_red.p, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
+    OPMGPU_HIP(hipStreamSynchronize(stream));
+    pvsum_global = h_red[0];
+    c->n_owned_global = int(h_red[1] + 0.5);
 }
 
 void BlackoilDevice::perf_props(double* out)

@@ -40,6 +40,8 @@ public:
     void update_state(const double* dx_host, double relax);
     void get_residual(double* r);
     double time_assemble(int reps, int props_only);
+    void attach_comm(CommBase* c, int n_owned);
+    const Plan& plan() const { return ls.plan; }
 
     int nc = 0, nconn = 0;
     opmgpu_params prm;
@@ -56,7 +58,7 @@ private:
     // host copies of the static inputs (caller numbering)
     std::vector<int32_t> h_conn, h_pvtnum, h_satnum, h_well_connpos, h_well_cells;
     std::vector<double> h_trans, h_pv, h_z, h_thpres;
-    double gravity = 0.0, pvsum = 0.0;
+    double gravity = 0.0, pvsum = 0.0, pvsum_global = 0.0;
     bool use_thpres = false;
     // device: tables
     opmgpu_tables dt_;                       // same struct, device pointers

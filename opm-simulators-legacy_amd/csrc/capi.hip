@@ -9,6 +9,7 @@
 #include <string>
 
 #include "blackoil.hpp"
+#include "dist.hpp"
 #include "linsolver.hpp"
 
 using namespace opmgpu;
@@ -25,8 +26,7 @@ struct opmgpu_ctx {
     bool factored = false;
     double t_assemble = 0, t_solve = 0, t_update = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // RCCL halo description (multi-GPU), see dist.hip
-    void* comm = nullptr;
+    std::unique_ptr<RcclComm> comm;   // multi-GPU (dist.hip); empty = single GPU
 };
 
 namespace {
@@ -123,7 +123,7 @@ void opmgpu_destroy(opmgpu_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    c->model.reset(); c->ls.reset();
+    c->model.reset(); c->ls.reset(); c->comm.reset();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -135,7 +135,11 @@ const char* opmgpu_last_error(const opmgpu_ctx* c) { return c ? c->err.c_str() :
 int opmgpu_set_wells(opmgpu_ctx* c, int nw, const int32_t* well_connpos, const int32_t* well_cells)
 {
     if (!c || !c->model) return OPMGPU_EINVAL;
-    return guarded(c, [&]() { c->matrix_loaded = false; return c->model->set_wells(nw, well_connpos, well_cells); });
+    return guarded(c, [&]() {
+        c->matrix_loaded = false;
+        if (c->comm && nw > 0) return fail(c, OPMGPU_EINVAL, "wells are not supported in multi-GPU mode yet");
+        return c->model->set_wells(nw, well_connpos, well_cells);
+    });
 }
 
 int opmgpu_set_state(opmgpu_ctx* c, const double* p, const double* sat, const double* rs, const double* rv, const int8_t* hc)
@@ -294,8 +298,8 @@ int opmgpu_ilu0_apply(opmgpu_ctx* c, const double* d3, double* v3)
     if (!c->factored) return fail(c, OPMGPU_EINVAL, "call opmgpu_ilu0_factor first");
     return guarded(c, [&]() {
         LinSolver& ls = *c->ls;
-        if (c->cur_single) { auto& w = ls.work<float>(); ls.vec_from_host<float>(d3, VEC_BLOCK_INTERLEAVED, w.p.p); ls.ilu_apply<float>(w.p.p, w.y.p, c->prm.ilu_relaxation); ls.vec_to_host<float>(w.y.p, VEC_BLOCK_INTERLEAVED, v3); }
-        else { auto& w = ls.work<double>(); ls.vec_from_host<double>(d3, VEC_BLOCK_INTERLEAVED, w.p.p); ls.ilu_apply<double>(w.p.p, w.y.p, c->prm.ilu_relaxation); ls.vec_to_host<double>(w.y.p, VEC_BLOCK_INTERLEAVED, v3); }
+        if (c->cur_single) { auto& w = ls.work<float>(); ls.vec_from_host<float>(d3, VEC_BLOCK_INTERLEAVED, w.p.p); ls.ilu_apply<float>(w.p.p, w.y.p, c->prm.ilu_relaxation, nullptr); ls.vec_to_host<float>(w.y.p, VEC_BLOCK_INTERLEAVED, v3); }
+        else { auto& w = ls.work<double>(); ls.vec_from_host<double>(d3, VEC_BLOCK_INTERLEAVED, w.p.p); ls.ilu_apply<double>(w.p.p, w.y.p, c->prm.ilu_relaxation, nullptr); ls.vec_to_host<double>(w.y.p, VEC_BLOCK_INTERLEAVED, v3); }
         return int(OPMGPU_OK);
     });
 }
@@ -364,6 +368,31 @@ int opmgpu_last_timings(opmgpu_ctx* c, double* assemble_ms, double* solve_ms, do
     if (solve_ms) *solve_ms = c->t_solve;
     if (update_ms) *update_ms = c->t_update;
     return OPMGPU_OK;
+}
+
+int opmgpu_comm_unique_id(uint8_t* id)
+{
+    if (!id) return OPMGPU_EINVAL;
+    try { return RcclComm::unique_id(id); } catch (...) { return OPMGPU_ECOMM; }
+}
+
+int opmgpu_comm_init(opmgpu_ctx* c, int rank, int nranks, const uint8_t* id, int32_t n_owned, int n_neigh, const int32_t* neigh_rank,
+                     const int32_t* send_ptr, const int32_t* send_cells, const int32_t* recv_ptr, const int32_t* recv_cells)
+{
+    if (!c || !c->model || !id || nranks < 1 || rank < 0 || rank >= nranks || n_owned <= 0 || n_owned > c->model->nc || n_neigh < 0) return OPMGPU_EINVAL;
+    if (n_neigh > 0 && (!neigh_rank || !send_ptr || !send_cells || !recv_ptr || !recv_cells)) return OPMGPU_EINVAL;
+    return guarded(c, [&]() {
+        std::unique_ptr<RcclComm> cm(new RcclComm());
+        static const int32_t zero2[2] = { 0, 0 };
+        const int st = cm->init(rank, nranks, id, n_owned, c->model->nc, n_neigh, neigh_rank, n_neigh ? send_ptr : zero2, send_cells,
+                                n_neigh ? recv_ptr : zero2, recv_cells);
+        if (st != OPMGPU_OK) return fail(c, st, "RCCL communicator initialisation failed");
+        cm->rebuild(c->model->plan(), c->stream);
+        c->comm = std::move(cm);
+        c->model->attach_comm(c->comm.get(), n_owned);
+        c->matrix_loaded = false;
+        return int(OPMGPU_OK);
+    });
 }
 
 // host-only planning entry (no device needed): used by the CPU unit tests of the ordering logic

@@ -3,8 +3,12 @@
 // All kernels are HBM-bandwidth bound (<= 0.25 flop/byte): no MFMA.  One thread owns one block row;
 // the SELL-64 layout makes every matrix / index load of a wavefront one contiguous segment, the
 // vectors are component-major planes so x[col] gathers of neighbouring rows coalesce as well.
-// Reductions are two-stage and order-deterministic (per-workgroup partials, single-workgroup
-// finalise that also updates the BiCGStab scalars on the device).
+//
+// Reductions are order-deterministic and need no extra launches: a producer kernel writes one
+// partial per workgroup, every workgroup of the consumer kernel re-reduces the (<= 1024-entry)
+// partial array in the same fixed order and derives the BiCGStab scalars itself.  A device-resident
+// `done` flag lets the host enqueue iterations ahead of the convergence result (no per-iteration
+// host synchronisation); the host polls a host-mapped control block after an event.
 #include "linsolver.hpp"
 
 #include <algorithm>
@@ -13,57 +17,88 @@
 
 namespace opmgpu {
 
+constexpr int kMaxPart = 1024;      // workgroups (= partials) of every reducing kernel
+
 // ------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ long vidx(int base_slot, int lane) { return long(base_slot) * 576 + lane; }
 
+// fixed-order sum of NV partial arrays of n entries; result broadcast to all threads of the block
+template <int NV>
+__device__ __forceinline__ void reduce_partials(const double* const (&arr)[NV], int n, double (&out)[NV], double* sm /* >= 4*NV + NV */)
+{
+    double acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        acc[k] = 0.0;
+        for (int i = threadIdx.x; i < n; i += kBlock) acc[k] += arr[k][i];
+    }
+    block_sum<NV>(acc, sm);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) sm[4 * NV + k] = acc[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) out[k] = sm[4 * NV + k];
+    __syncthreads();
+}
+
 // y = A x  (+ fused dot products: NDOT==1: <w1,y>; NDOT==2: <y,w1>, <y,y>)
-// MatrixAdapter::apply + the scalar products of BiCGSTABSolver::apply.
+// MatrixAdapter::apply + the scalar products of BiCGSTABSolver::apply.  Grid-stride over 256-row
+// chunks so that a reducing launch has at most kMaxPart workgroups.  mask (multi-GPU): rows that are
+// not owned produce 0.
 template <class S, int NDOT>
 __global__ __launch_bounds__(kBlock) void k_spmv(int nb, int nbp, const int32_t* __restrict__ slice_ptr,
                                                  const int32_t* __restrict__ col, const S* __restrict__ val,
                                                  const S* __restrict__ x, S* __restrict__ y,
-                                                 const S* __restrict__ w1, double* __restrict__ partials)
+                                                 const S* __restrict__ w1, const int8_t* __restrict__ mask,
+                                                 const SolveCtl* __restrict__ ctl, double* __restrict__ p0, double* __restrict__ p1)
 {
     __shared__ double sm[8];
-    const int row = blockIdx.x * kBlock + threadIdx.x;
+    if (ctl && ctl->done) return;
     double acc[2] = { 0.0, 0.0 };
-    if (row < nb) {
+    for (int row = blockIdx.x * kBlock + threadIdx.x; row < nb; row += gridDim.x * kBlock) {
         const int sl = row >> 6, lane = row & 63;
         const int base = slice_ptr[sl], width = slice_ptr[sl + 1] - base;
         const S* __restrict__ v = val + vidx(base, lane);
         const int32_t* __restrict__ c = col + long(base) * 64 + lane;
         S y0 = 0, y1 = 0, y2 = 0;
-        for (int k = 0; k < width; ++k) {
-            const int cc = c[k * 64];
-            const S x0 = x[cc], x1 = x[nbp + cc], x2 = x[2 * nbp + cc];
-            const S* __restrict__ b = v + k * 576;
-            y0 += b[0] * x0 + b[64] * x1 + b[128] * x2;
-            y1 += b[192] * x0 + b[256] * x1 + b[320] * x2;
-            y2 += b[384] * x0 + b[448] * x1 + b[512] * x2;
+        if (!mask || mask[row]) {
+            for (int k = 0; k < width; ++k) {
+                const int cc = c[k * 64];
+                const S x0 = x[cc], x1 = x[nbp + cc], x2 = x[2 * nbp + cc];
+                const S* __restrict__ b = v + k * 576;
+                y0 += b[0] * x0 + b[64] * x1 + b[128] * x2;
+                y1 += b[192] * x0 + b[256] * x1 + b[320] * x2;
+                y2 += b[384] * x0 + b[448] * x1 + b[512] * x2;
+            }
         }
         y[row] = y0; y[nbp + row] = y1; y[2 * nbp + row] = y2;
-        if (NDOT >= 1) acc[0] = double(w1[row]) * double(y0) + double(w1[nbp + row]) * double(y1) + double(w1[2 * nbp + row]) * double(y2);
-        if (NDOT == 2) acc[1] = double(y0) * double(y0) + double(y1) * double(y1) + double(y2) * double(y2);
+        if (NDOT >= 1) acc[0] += double(w1[row]) * double(y0) + double(w1[nbp + row]) * double(y1) + double(w1[2 * nbp + row]) * double(y2);
+        if (NDOT == 2) acc[1] += double(y0) * double(y0) + double(y1) * double(y1) + double(y2) * double(y2);
     }
     if (NDOT >= 1) {
         block_sum<2>(acc, sm);
         if (threadIdx.x == 0) {
-            partials[blockIdx.x] = acc[0];
-            if (NDOT == 2) partials[gridDim.x + blockIdx.x] = acc[1];
+            p0[blockIdx.x] = acc[0];
+            if (NDOT == 2) p1[blockIdx.x] = acc[1];
         }
     }
 }
 
-// forward sweep of one level: v_i = w d_i - sum_{j lower} L_ij v_j ; for the top level the pivot
-// inverse is applied at once (no upper entries there).  ParallelOverlappingILU0::apply, lower part;
-// the relaxation factor is folded in here (the sweeps are linear in d).
+// forward sweep of one level l >= 1: v_i = w d_i - sum_{j lower} L_ij y_j with y_j = w d_j for level-0
+// rows (their forward sweep is the identity, so it is never launched) and y_j = v_j otherwise.  For the
+// top level the pivot inverse is applied at once (no upper entries there).
+// ParallelOverlappingILU0::apply, lower part; the relaxation factor w is folded in (the sweeps are linear).
 template <class S>
-__global__ __launch_bounds__(kBlock) void k_ilu_lower(int lo, int hi, int nbp, int top, S w, const int32_t* __restrict__ slice_ptr,
+__global__ __launch_bounds__(kBlock) void k_ilu_lower(int lo, int hi, int n0, int nbp, int top, S w, const int32_t* __restrict__ slice_ptr,
                                                       const int32_t* __restrict__ col, const int16_t* __restrict__ nlower,
-                                                      const S* __restrict__ lu, const S* __restrict__ d, S* __restrict__ v)
+                                                      const S* __restrict__ lu, const S* __restrict__ d, S* __restrict__ v,
+                                                      const SolveCtl* __restrict__ ctl)
 {
+    if (ctl && ctl->done) return;
     const int row = lo + blockIdx.x * kBlock + threadIdx.x;
     if (row >= hi) return;
     const int base = slice_ptr[row >> 6], lane = row & 63, nl = nlower[row];
@@ -72,7 +107,9 @@ __global__ __launch_bounds__(kBlock) void k_ilu_lower(int lo, int hi, int nbp, i
     S r0 = w * d[row], r1 = w * d[nbp + row], r2 = w * d[2 * nbp + row];
     for (int k = 0; k < nl; ++k) {
         const int cc = c[k * 64];
-        const S x0 = v[cc], x1 = v[nbp + cc], x2 = v[2 * nbp + cc];
+        S x0, x1, x2;
+        if (cc < n0) { x0 = w * d[cc]; x1 = w * d[nbp + cc]; x2 = w * d[2 * nbp + cc]; }
+        else { x0 = v[cc]; x1 = v[nbp + cc]; x2 = v[2 * nbp + cc]; }
         const S* __restrict__ b = m + k * 576;
         r0 -= b[0] * x0 + b[64] * x1 + b[128] * x2;
         r1 -= b[192] * x0 + b[256] * x1 + b[320] * x2;
@@ -88,18 +125,22 @@ __global__ __launch_bounds__(kBlock) void k_ilu_lower(int lo, int hi, int nbp, i
     v[row] = r0; v[nbp + row] = r1; v[2 * nbp + row] = r2;
 }
 
-// backward sweep of one level: v_i = Dinv_i (v_i - sum_{j upper} U_ij v_j)
+// backward sweep of one level: v_i = Dinv_i (y_i - sum_{j upper} U_ij v_j), y_i = w d_i on level 0
 template <class S>
-__global__ __launch_bounds__(kBlock) void k_ilu_upper(int lo, int hi, int nbp, const int32_t* __restrict__ slice_ptr,
+__global__ __launch_bounds__(kBlock) void k_ilu_upper(int lo, int hi, int n0, int nbp, S w, const int32_t* __restrict__ slice_ptr,
                                                       const int32_t* __restrict__ col, const int16_t* __restrict__ nlower,
-                                                      const int16_t* __restrict__ rowlen, const S* __restrict__ lu, S* __restrict__ v)
+                                                      const int16_t* __restrict__ rowlen, const S* __restrict__ lu,
+                                                      const S* __restrict__ d, S* __restrict__ v, const SolveCtl* __restrict__ ctl)
 {
+    if (ctl && ctl->done) return;
     const int row = lo + blockIdx.x * kBlock + threadIdx.x;
     if (row >= hi) return;
     const int base = slice_ptr[row >> 6], lane = row & 63, nl = nlower[row], len = rowlen[row];
     const S* __restrict__ m = lu + vidx(base, lane);
     const int32_t* __restrict__ c = col + long(base) * 64 + lane;
-    S r0 = v[row], r1 = v[nbp + row], r2 = v[2 * nbp + row];
+    S r0, r1, r2;
+    if (row < n0) { r0 = w * d[row]; r1 = w * d[nbp + row]; r2 = w * d[2 * nbp + row]; }
+    else { r0 = v[row]; r1 = v[nbp + row]; r2 = v[2 * nbp + row]; }
     for (int k = nl + 1; k < len; ++k) {
         const int cc = c[k * 64];
         const S x0 = v[cc], x1 = v[nbp + cc], x2 = v[2 * nbp + cc];
@@ -178,35 +219,157 @@ __global__ __launch_bounds__(kBlock) void k_ilu_factor(int lo, int hi, const int
     st9(lu, ed, o);
 }
 
-// ---- BiCGStab vector updates (grid-stride over the 3*nbp plane elements) ----
-// p = r + beta (p - omega v)   (first half-step: p = r)
+// copy the status fields to the host-mapped block (one thread; only when the solve stops / at the final check)
+__device__ __forceinline__ void publish(const SolveCtl* ctl, SolveCtl* hst)
+{
+    hst->norm0_2 = ctl->norm0_2; hst->norm2 = ctl->norm2; hst->flag = ctl->flag; hst->iters = ctl->iters; hst->decided = ctl->decided;
+    __threadfence_system();
+    hst->done = ctl->done;
+}
+
+// ---- BiCGStab (Dune::BiCGSTABSolver::apply) ------------------------------------------------
+// iteration j = 1, 2, ...:
+//   k_update_p (j)  : [test ||r||^2 of iteration j-1]  rho_new = <rt,r>; beta; p = r + beta (p - omega v)
+//   ILU, k_spmv<1>  : y = M^-1 p ; v = A y ; partials h = <rt,v>
+//   k_update_xr1(j) : alpha = rho_new / h ; x += alpha y ; r -= alpha v ; partials ||r||^2
+//   ILU, k_spmv<2>  : y = M^-1 r ; t = A y ; partials <t,r>, <t,t>
+//   k_update_xr2(j) : [test ||r||^2 of the first half step]  omega ; x += omega y ; r -= omega t ; partials ||r||^2, <rt,r>
+// Every workgroup derives the scalars from the partial arrays itself; workgroup 0 records them.
 template <class S>
-__global__ __launch_bounds__(kBlock) void k_update_p(long n, int first, const double* __restrict__ sc, const S* __restrict__ r,
+__global__ __launch_bounds__(kBlock) void k_update_p(long n, int j, double eps, SolveCtl* __restrict__ ctl, SolveCtl* __restrict__ hst, const double* __restrict__ p_n2,
+                                                     const double* __restrict__ p_rho, int np, const S* __restrict__ r,
                                                      const S* __restrict__ v, S* __restrict__ p)
 {
-    const S beta = S(sc[SC_BETA]), omega = S(sc[SC_OMEGA]);
-    for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock)
-        p[i] = first ? r[i] : (p[i] - omega * v[i]) * beta + r[i];
+    __shared__ double sm[12];
+    if (ctl->done) return;
+    const double* const arr[2] = { p_n2, p_rho };
+    double s[2];
+    reduce_partials<2>(arr, np, s, sm);
+    const double norm2 = s[0], rho_new = s[1];
+    const bool first = (j == 1);
+    if (first) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->norm0_2 = norm2; ctl->norm2 = norm2; ctl->rho[1] = rho_new; }
+        if (!(norm2 == norm2)) { if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->flag = 2; ctl->decided = j; ctl->done = 1; publish(ctl, hst); } return; }
+        if (norm2 < 1e-60) { if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->iters = 0; ctl->decided = j; ctl->done = 1; publish(ctl, hst); } return; }
+        for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) p[i] = r[i];
+        return;
+    }
+    // convergence test after the second half of iteration j-1:  norm < reduction * norm0  ||  norm < 1e-30
+    if (norm2 < ctl->thresh2 || norm2 < 1e-60) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->norm2 = norm2; ctl->iters = j - 1; ctl->decided = j; ctl->done = 1; publish(ctl, hst); }
+        return;
+    }
+    const double rho_old = ctl->rho[(j - 1) & 1], omega = ctl->omega, alpha = ctl->alpha;
+    if (fabs(rho_old) <= eps || fabs(omega) <= eps || !(rho_old == rho_old) || !(omega == omega) || !(norm2 == norm2)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->norm2 = norm2; ctl->flag = 2; ctl->iters = j - 1; ctl->decided = j; ctl->done = 1; publish(ctl, hst); }
+        return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->rho[j & 1] = rho_new; ctl->norm2 = norm2; }
+    const S beta = S((rho_new / rho_old) * (alpha / omega)), om = S(omega);
+    for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) p[i] = (p[i] - om * v[i]) * beta + r[i];
 }
-// x += a y ; r -= a q ; partials: <r,r> [, <rt,r>]      (a = alpha or omega, read from the device scalars)
-template <class S, int NDOT>
-__global__ __launch_bounds__(kBlock) void k_update_xr(long n, int which, const double* __restrict__ sc, const S* __restrict__ y,
-                                                      const S* __restrict__ q, const S* __restrict__ rt, S* __restrict__ x,
-                                                      S* __restrict__ r, double* __restrict__ partials)
+
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_update_xr1(long n, int j, double eps, SolveCtl* __restrict__ ctl, SolveCtl* __restrict__ hst, const double* __restrict__ p_h, int np,
+                                                       const S* __restrict__ y, const S* __restrict__ q, S* __restrict__ x, S* __restrict__ r,
+                                                       double* __restrict__ p_n1)
 {
-    __shared__ double sm[8];
-    const S a = S(sc[which]);
+    __shared__ double sm[12];
+    if (ctl->done) return;
+    const double* const arr[1] = { p_h };
+    double s[1];
+    reduce_partials<1>(arr, np, s, sm);
+    const double h = s[0];
+    if (fabs(h) < eps || !(h == h)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->flag = 1; ctl->iters = j; ctl->decided = j; ctl->done = 1; publish(ctl, hst); }
+        return;
+    }
+    const double alpha = ctl->rho[j & 1] / h;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->alpha = alpha;
+    const S a = S(alpha);
+    double acc[1] = { 0.0 };
+    for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) {
+        x[i] += a * y[i];
+        const S rn = r[i] - a * q[i];
+        r[i] = rn;
+        acc[0] += double(rn) * double(rn);
+    }
+    block_sum<1>(acc, sm);
+    if (threadIdx.x == 0) p_n1[blockIdx.x] = acc[0];
+}
+
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_update_xr2(long n, int j, SolveCtl* __restrict__ ctl, SolveCtl* __restrict__ hst, const double* __restrict__ p_n1,
+                                                       const double* __restrict__ p_tr, const double* __restrict__ p_tt, int np_v, int np_s,
+                                                       const S* __restrict__ y, const S* __restrict__ q, const S* __restrict__ rt,
+                                                       S* __restrict__ x, S* __restrict__ r, double* __restrict__ p_n2, double* __restrict__ p_rho)
+{
+    __shared__ double sm[12];
+    if (ctl->done) return;
+    double s1[1], s2[2];
+    { const double* const arr[1] = { p_n1 }; reduce_partials<1>(arr, np_v, s1, sm); }
+    if (s1[0] < ctl->thresh2) {          // converged after the first half step of iteration j: x is final
+        if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->norm2 = s1[0]; ctl->iters = j; ctl->decided = j; ctl->done = 1; publish(ctl, hst); }
+        return;
+    }
+    { const double* const arr[2] = { p_tr, p_tt }; reduce_partials<2>(arr, np_s, s2, sm); }
+    const double omega = s2[0] / s2[1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->omega = omega;
+    const S a = S(omega);
     double acc[2] = { 0.0, 0.0 };
     for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) {
         x[i] += a * y[i];
         const S rn = r[i] - a * q[i];
         r[i] = rn;
         acc[0] += double(rn) * double(rn);
-        if (NDOT == 2) acc[1] += double(rt[i]) * double(rn);
+        acc[1] += double(rt[i]) * double(rn);
     }
     block_sum<2>(acc, sm);
-    if (threadIdx.x == 0) { partials[blockIdx.x] = acc[0]; if (NDOT == 2) partials[gridDim.x + blockIdx.x] = acc[1]; }
+    if (threadIdx.x == 0) { p_n2[blockIdx.x] = acc[0]; p_rho[blockIdx.x] = acc[1]; }
 }
+
+// convergence test after the last enqueued iteration (what k_update_p(j+1) would have done)
+__global__ __launch_bounds__(kBlock) void k_final_check(int j, SolveCtl* __restrict__ ctl, SolveCtl* __restrict__ hst, const double* __restrict__ p_n2, int np)
+{
+    __shared__ double sm[12];
+    if (ctl->done) { if (threadIdx.x == 0) publish(ctl, hst); return; }
+    const double* const arr[1] = { p_n2 };
+    double s[1];
+    reduce_partials<1>(arr, np, s, sm);
+    if (threadIdx.x == 0) {
+        ctl->norm2 = s[0];
+        ctl->iters = j;
+        if (s[0] < ctl->thresh2 || s[0] < 1e-60) ctl->done = 1;
+        publish(ctl, hst);
+    }
+}
+__global__ void k_ctl_init(SolveCtl* ctl, SolveCtl* hst, double red)
+{
+    hst->done = 0; hst->flag = 0; hst->iters = 0; hst->decided = 0; hst->norm2 = 0.0; hst->norm0_2 = 0.0;
+    ctl->rho[0] = 1.0; ctl->rho[1] = 1.0; ctl->alpha = 1.0; ctl->omega = 1.0;
+    ctl->norm0_2 = 0.0; ctl->norm2 = 0.0; ctl->thresh2 = 0.0; ctl->done = 0; ctl->flag = 0; ctl->iters = 0; ctl->decided = 0;
+    (void)red;
+}
+// thresh2 = (reduction * ||r0||)^2 needs ||r0||^2: one workgroup, right after the initial dot
+__global__ __launch_bounds__(kBlock) void k_ctl_thresh(SolveCtl* __restrict__ ctl, double red, const double* __restrict__ p_n2, int np)
+{
+    __shared__ double sm[12];
+    const double* const arr[1] = { p_n2 };
+    double s[1];
+    reduce_partials<1>(arr, np, s, sm);
+    if (threadIdx.x == 0) { ctl->norm0_2 = s[0]; ctl->norm2 = s[0]; ctl->thresh2 = red * red * s[0]; }
+}
+// multi-GPU bridge: collapse partial arrays to their sums (fixed order) so they can be all-reduced
+template <int NV>
+__global__ __launch_bounds__(kBlock) void k_sum_partials(const double* __restrict__ a0, const double* __restrict__ a1, int np, double* __restrict__ out)
+{
+    __shared__ double sm[12];
+    const double* const arr[2] = { a0, a1 ? a1 : a0 };
+    double s[2];
+    reduce_partials<2>(arr, np, s, sm);
+    if (threadIdx.x == 0) { out[0] = s[0]; if (NV == 2) out[1] = s[1]; }
+}
+
 template <class S>
 __global__ __launch_bounds__(kBlock) void k_dot(long n, const S* __restrict__ a, const S* __restrict__ b, double* __restrict__ partials)
 {
@@ -229,47 +392,6 @@ __global__ __launch_bounds__(kBlock) void k_convert(long n, const A* __restrict_
 __global__ __launch_bounds__(kBlock) void k_copy16(long n16, const double2* __restrict__ a, double2* __restrict__ b)
 {
     for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n16; i += long(gridDim.x) * kBlock) b[i] = a[i];
-}
-
-// single-workgroup finalise: fixed-order sum of the per-workgroup partials + scalar recurrences of
-// Dune::BiCGSTABSolver::apply.
-enum { FIN_INIT = 0, FIN_H, FIN_NORM1, FIN_OMEGA, FIN_NORM2, FIN_PLAIN };
-__global__ __launch_bounds__(kBlock) void k_finalize(int op, int nblocks, double eps, const double* __restrict__ partials, double* __restrict__ sc)
-{
-    __shared__ double sm[8];
-    double acc[2] = { 0.0, 0.0 };
-    for (int i = threadIdx.x; i < nblocks; i += kBlock) { acc[0] += partials[i]; acc[1] += partials[nblocks + i]; }
-    block_sum<2>(acc, sm);
-    if (threadIdx.x != 0) return;
-    switch (op) {
-    case FIN_INIT:      // r = rt = b
-        sc[SC_NORM0_2] = acc[0]; sc[SC_NORM2] = acc[0]; sc[SC_RHONEW] = acc[0];
-        sc[SC_RHO] = 1.0; sc[SC_ALPHA] = 1.0; sc[SC_OMEGA] = 1.0; sc[SC_BETA] = 0.0; sc[SC_FLAG] = 0.0;
-        break;
-    case FIN_H:         // h = <rt,v>; alpha = rho_new / h
-        sc[SC_H] = acc[0];
-        if (fabs(acc[0]) < eps || !(acc[0] == acc[0])) sc[SC_FLAG] = 1.0;
-        sc[SC_ALPHA] = sc[SC_RHONEW] / acc[0];
-        break;
-    case FIN_NORM1:
-        sc[SC_NORM2] = acc[0];
-        break;
-    case FIN_OMEGA:     // omega = <t,r> / <t,t>
-        sc[SC_TR] = acc[0]; sc[SC_TT] = acc[1];
-        sc[SC_OMEGA] = acc[0] / acc[1];
-        break;
-    case FIN_NORM2: {   // rho = rho_new; rho_new = <rt,r>; beta for the next half step
-        sc[SC_NORM2] = acc[0];
-        const double rho = sc[SC_RHONEW], omega = sc[SC_OMEGA];
-        sc[SC_RHO] = rho; sc[SC_RHONEW] = acc[1];
-        if (fabs(rho) <= eps || fabs(omega) <= eps || !(rho == rho) || !(omega == omega)) sc[SC_FLAG] = 2.0;
-        sc[SC_BETA] = (acc[1] / rho) * (sc[SC_ALPHA] / omega);
-        break;
-    }
-    default:
-        sc[SC_NORM2] = acc[0];
-        break;
-    }
 }
 
 // ---- layout conversion kernels ----
@@ -323,8 +445,7 @@ void DevPlan::upload(const Plan& P, hipStream_t s)
     slice_ptr.upload(P.slice_ptr, s); col.upload(P.sell_col, s); src.upload(P.sell_src, s);
     entry_of_block.upload(P.entry_of_block, s); nat.upload(P.nat, s); pos.upload(P.pos, s);
     trip_ptr.upload(P.trip_ptr, s);
-    // hipMalloc(0) is avoided: keep at least one element
-    std::vector<int32_t> one(1, 0);
+    std::vector<int32_t> one(1, 0);      // hipMalloc(0) is avoided: keep at least one element
     trip_l.upload(P.trip_l.empty() ? one : P.trip_l, s); trip_u.upload(P.trip_u.empty() ? one : P.trip_u, s);
     trip_t.upload(P.trip_t.empty() ? one : P.trip_t, s);
     rowlen.upload(P.rowlen, s); nlower.upload(P.nlower, s);
@@ -334,17 +455,24 @@ void DevPlan::upload(const Plan& P, hipStream_t s)
 
 LinSolver::LinSolver(hipStream_t s) : stream(s)
 {
-    partials.alloc(2 * kMaxRedBlocks);
-    scalars.alloc(SC_COUNT);
+    npart = kMaxPart;
+    partials.alloc(size_t(6) * npart + 16);
     flags.alloc(4);
-    partials.zero(stream); scalars.zero(stream); flags.zero(stream);
-    OPMGPU_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_scalars), SC_COUNT * sizeof(double)));
+    partials.zero(stream); flags.zero(stream);
+    OPMGPU_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_ctl), sizeof(SolveCtl), hipHostMallocMapped));
+    std::memset(h_ctl, 0, sizeof(SolveCtl));
+    OPMGPU_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h_ctl_dev), h_ctl, 0));
+    ctl.alloc(1); ctl.zero(stream);
     OPMGPU_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_flags), 4 * sizeof(int32_t)));
+    OPMGPU_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+    OPMGPU_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
 }
 LinSolver::~LinSolver()
 {
-    if (h_scalars) (void)hipHostFree(h_scalars);
+    if (h_ctl) (void)hipHostFree(h_ctl);
     if (h_flags) (void)hipHostFree(h_flags);
+    if (ev[0]) (void)hipEventDestroy(ev[0]);
+    if (ev[1]) (void)hipEventDestroy(ev[1]);
 }
 
 template <> SolverWork<double>& LinSolver::work<double>() { return wd; }
@@ -365,8 +493,6 @@ int LinSolver::set_pattern(int nb, const int32_t* rowptr, const int32_t* col, in
     dp.upload(plan, stream);
     Ad.alloc(size_t(plan.nentries) * 9);
     Ad.zero(stream);
-    partials.alloc(size_t(2) * std::max(grid_for(plan.nb), kMaxRedBlocks));
-    partials.zero(stream);
     wd.allocated = false; wf.allocated = false;
     return OPMGPU_OK;
 }
@@ -418,92 +544,118 @@ template <class S> int LinSolver::factor()
     return (h_flags[0] & 1) ? OPMGPU_ESINGULAR : OPMGPU_OK;
 }
 
-template <class S> void LinSolver::ilu_apply(const S* d, S* v, double relax)
+template <class S> void LinSolver::ilu_apply(const S* d, S* v, double relax, const SolveCtl* ctl)
 {
     SolverWork<S>& w = work<S>();
     const int L = plan.nlevels;
-    for (int l = 0; l < L; ++l) {
+    const int n0 = plan.level_ptr[1];
+    if (L == 1) {
+        hipLaunchKernelGGL((k_ilu_lower<S>), dim3(grid_for(n0)), dim3(kBlock), 0, stream, 0, n0, 0, plan.nbp, 1, S(relax),
+                           dp.slice_ptr.p, dp.col.p, dp.nlower.p, w.LU.p, d, v, ctl);
+        return;
+    }
+    for (int l = 1; l < L; ++l) {
         const int lo = plan.level_ptr[l], hi = plan.level_ptr[l + 1];
         if (hi == lo) continue;
-        hipLaunchKernelGGL((k_ilu_lower<S>), dim3(grid_for(hi - lo)), dim3(kBlock), 0, stream, lo, hi, plan.nbp, int(l == L - 1), S(relax),
-                           dp.slice_ptr.p, dp.col.p, dp.nlower.p, w.LU.p, d, v);
+        hipLaunchKernelGGL((k_ilu_lower<S>), dim3(grid_for(hi - lo)), dim3(kBlock), 0, stream, lo, hi, n0, plan.nbp, int(l == L - 1), S(relax),
+                           dp.slice_ptr.p, dp.col.p, dp.nlower.p, w.LU.p, d, v, ctl);
     }
     for (int l = L - 2; l >= 0; --l) {
         const int lo = plan.level_ptr[l], hi = plan.level_ptr[l + 1];
         if (hi == lo) continue;
-        hipLaunchKernelGGL((k_ilu_upper<S>), dim3(grid_for(hi - lo)), dim3(kBlock), 0, stream, lo, hi, plan.nbp, dp.slice_ptr.p, dp.col.p,
-                           dp.nlower.p, dp.rowlen.p, w.LU.p, v);
+        hipLaunchKernelGGL((k_ilu_upper<S>), dim3(grid_for(hi - lo)), dim3(kBlock), 0, stream, lo, hi, n0, plan.nbp, S(relax), dp.slice_ptr.p, dp.col.p,
+                           dp.nlower.p, dp.rowlen.p, w.LU.p, d, v, ctl);
     }
 }
 
 template <class S> void LinSolver::spmv(const S* x, S* y)
 {
-    hipLaunchKernelGGL((k_spmv<S, 0>), dim3(grid_for(plan.nb)), dim3(kBlock), 0, stream, plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p,
-                       matrix<S>(), x, y, (const S*)nullptr, partials.p);
+    const int g = std::min(grid_for(plan.nb), 4 * kMaxPart);
+    hipLaunchKernelGGL((k_spmv<S, 0>), dim3(g), dim3(kBlock), 0, stream, plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p,
+                       matrix<S>(), x, y, (const S*)nullptr, comm ? comm->owner_mask() : (const int8_t*)nullptr, (const SolveCtl*)nullptr,
+                       (double*)nullptr, (double*)nullptr);
 }
+
+template <class S> static void halo(CommBase* c, S* v, hipStream_t s);
+template <> void halo<float>(CommBase* c, float* v, hipStream_t s) { c->halo_exchange_f(v, s); }
+template <> void halo<double>(CommBase* c, double* v, hipStream_t s) { c->halo_exchange_d(v, s); }
 
 template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
 {
     SolverWork<S>& w = work<S>();
     SolveResult res;
     const long n = long(3) * plan.nbp;
-    const int gv = std::min(grid_for(n), kMaxRedBlocks);
-    const int gs = grid_for(plan.nb);
-    const double eps = sizeof(S) == 8 ? 1e-80 : 0.0;      // dune: real_type EPSILON = 1e-80 (0 in float)
-    const double red = prm.linear_solver_reduction;
+    const int gv = std::min(grid_for(n), kMaxPart);            // vector kernels (also the number of their partials)
+    const int gs = std::min(grid_for(plan.nb), kMaxPart);      // reducing SpMV launches
+    const double eps = sizeof(S) == 8 ? 1e-80 : 0.0;           // dune: real_type EPSILON = 1e-80 (0 in float)
     const int maxit = prm.linear_solver_maxiter;
-    auto finalize = [&](int op, int nblocks) {
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), 0, stream, op, nblocks, eps, partials.p, scalars.p);
-    };
-    auto fetch = [&]() {
-        OPMGPU_HIP(hipMemcpyAsync(h_scalars, scalars.p, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, stream));
-        OPMGPU_HIP(hipStreamSynchronize(stream));
+    const int8_t* mask = comm ? comm->owner_mask() : nullptr;
+    double* P_h = partials.p, *P_n1 = P_h + npart, *P_tr = P_n1 + npart, *P_tt = P_tr + npart, *P_n2 = P_tt + npart, *P_rho = P_n2 + npart;
+    double* red = P_rho + npart;                               // 8 all-reduced scalars (multi-GPU)
+    // (multi-GPU) collapse partial arrays of np entries into red[slot..] and all-reduce them; consumers then read 1 entry
+    auto bridge = [&](double*& a0, double*& a1, int& np, int slot) {
+        if (!comm) return;
+        if (a1) hipLaunchKernelGGL((k_sum_partials<2>), dim3(1), dim3(kBlock), 0, stream, a0, a1, np, red + slot);
+        else hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(kBlock), 0, stream, a0, (const double*)nullptr, np, red + slot);
+        comm->allreduce_sum(red + slot, a1 ? 2 : 1, stream);
+        a0 = red + slot; if (a1) a1 = red + slot + 1; np = 1;
     };
     // x = 0, r = rt = b, p = v = 0
-    w.x.zero(stream); w.p.zero(stream); w.v.zero(stream);
+    w.x.zero(stream);
     OPMGPU_HIP(hipMemcpyAsync(w.r.p, w.b.p, n * sizeof(S), hipMemcpyDeviceToDevice, stream));
     OPMGPU_HIP(hipMemcpyAsync(w.rt.p, w.b.p, n * sizeof(S), hipMemcpyDeviceToDevice, stream));
-    partials.zero(stream);
-    hipLaunchKernelGGL((k_dot<S>), dim3(gv), dim3(kBlock), 0, stream, n, w.r.p, w.r.p, partials.p);
-    finalize(FIN_INIT, gv);
-    fetch();
-    const double norm0 = std::sqrt(h_scalars[SC_NORM0_2]);
-    double norm = norm0;
-    if (!(norm0 == norm0)) { res.status = OPMGPU_EBREAKDOWN; return res; }
-    double it = 0.0;
-    if (norm < red * norm0 || norm < 1e-30) { res.converged = true; }
-    else {
-        for (it = 0.5; it < maxit; it += 0.5) {
-            hipLaunchKernelGGL((k_update_p<S>), dim3(gv), dim3(kBlock), 0, stream, n, int(it < 1), scalars.p, w.r.p, w.v.p, w.p.p);
-            ilu_apply<S>(w.p.p, w.y.p, prm.ilu_relaxation);
-            hipLaunchKernelGGL((k_spmv<S, 1>), dim3(gs), dim3(kBlock), 0, stream, plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p, matrix<S>(),
-                               w.y.p, w.v.p, w.rt.p, partials.p);
-            finalize(FIN_H, gs);
-            hipLaunchKernelGGL((k_update_xr<S, 1>), dim3(gv), dim3(kBlock), 0, stream, n, int(SC_ALPHA), scalars.p, w.y.p, w.v.p, w.rt.p,
-                               w.x.p, w.r.p, partials.p);
-            finalize(FIN_NORM1, gv);
-            fetch();
-            if (h_scalars[SC_FLAG] != 0.0) { res.status = OPMGPU_EBREAKDOWN; break; }
-            norm = std::sqrt(h_scalars[SC_NORM2]);
-            if (norm < red * norm0) { res.converged = true; break; }
-            it += 0.5;
-            ilu_apply<S>(w.r.p, w.y.p, prm.ilu_relaxation);
-            hipLaunchKernelGGL((k_spmv<S, 2>), dim3(gs), dim3(kBlock), 0, stream, plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p, matrix<S>(),
-                               w.y.p, w.t.p, w.r.p, partials.p);
-            finalize(FIN_OMEGA, gs);
-            hipLaunchKernelGGL((k_update_xr<S, 2>), dim3(gv), dim3(kBlock), 0, stream, n, int(SC_OMEGA), scalars.p, w.y.p, w.t.p, w.rt.p,
-                               w.x.p, w.r.p, partials.p);
-            finalize(FIN_NORM2, gv);
-            fetch();
-            norm = std::sqrt(h_scalars[SC_NORM2]);
-            if (norm < red * norm0 || norm < 1e-30) { res.converged = true; break; }
-            if (h_scalars[SC_FLAG] != 0.0 || !(norm == norm)) { res.status = OPMGPU_EBREAKDOWN; break; }
+    SolveCtl* d_ctl = ctl.p;
+    hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(1), 0, stream, d_ctl, h_ctl_dev, prm.linear_solver_reduction);
+    hipLaunchKernelGGL((k_dot<S>), dim3(gv), dim3(kBlock), 0, stream, n, w.r.p, w.r.p, P_n2);
+    double* a_n2 = P_n2; double* a_rho = P_n2; double* none = nullptr; int np_n2 = gv;
+    bridge(a_n2, none, np_n2, 0); a_rho = a_n2;
+    hipLaunchKernelGGL(k_ctl_thresh, dim3(1), dim3(kBlock), 0, stream, d_ctl, prm.linear_solver_reduction, (const double*)a_n2, np_n2);
+    int j = 1, last = 0, target = 0;
+    bool stop = false;
+    for (; j <= maxit && !stop; ++j) {
+        hipLaunchKernelGGL((k_update_p<S>), dim3(gv), dim3(kBlock), 0, stream, n, j, eps, d_ctl, h_ctl_dev, (const double*)a_n2, (const double*)a_rho, np_n2,
+                           w.r.p, w.v.p, w.p.p);
+        ilu_apply<S>(w.p.p, w.y.p, prm.ilu_relaxation, d_ctl);
+        if (comm) halo<S>(comm, w.y.p, stream);
+        hipLaunchKernelGGL((k_spmv<S, 1>), dim3(gs), dim3(kBlock), 0, stream, plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p, matrix<S>(),
+                           w.y.p, w.v.p, w.rt.p, mask, (const SolveCtl*)d_ctl, P_h, (double*)nullptr);
+        double* a_h = P_h; int np_h = gs; none = nullptr;
+        bridge(a_h, none, np_h, 1);
+        hipLaunchKernelGGL((k_update_xr1<S>), dim3(gv), dim3(kBlock), 0, stream, n, j, eps, d_ctl, h_ctl_dev, (const double*)a_h, np_h, w.y.p, w.v.p,
+                           w.x.p, w.r.p, P_n1);
+        double* a_n1 = P_n1; int np_n1 = gv; none = nullptr;
+        bridge(a_n1, none, np_n1, 2);
+        ilu_apply<S>(w.r.p, w.y.p, prm.ilu_relaxation, d_ctl);
+        if (comm) halo<S>(comm, w.y.p, stream);
+        hipLaunchKernelGGL((k_spmv<S, 2>), dim3(gs), dim3(kBlock), 0, stream, plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p, matrix<S>(),
+                           w.y.p, w.t.p, w.r.p, mask, (const SolveCtl*)d_ctl, P_tr, P_tt);
+        double* a_tr = P_tr; double* a_tt = P_tt; int np_t = gs;
+        bridge(a_tr, a_tt, np_t, 3);
+        hipLaunchKernelGGL((k_update_xr2<S>), dim3(gv), dim3(kBlock), 0, stream, n, j, d_ctl, h_ctl_dev, (const double*)a_n1, (const double*)a_tr,
+                           (const double*)a_tt, np_n1, np_t, w.y.p, w.t.p, w.rt.p, w.x.p, w.r.p, P_n2, P_rho);
+        a_n2 = P_n2; a_rho = P_rho; np_n2 = gv;
+        bridge(a_n2, a_rho, np_n2, 5);
+        OPMGPU_HIP(hipEventRecord(ev[j & 1], stream));
+        last = j;
+        if (j >= 2 && target == 0) {       // iteration j-1 is complete once its event has fired; iteration j is already queued
+            OPMGPU_HIP(hipEventSynchronize(ev[(j - 1) & 1]));
+            if (h_ctl->done) {
+                // single GPU: stop now.  Multi GPU: every rank must enqueue the SAME number of iterations (their
+                // collectives pair up); `decided` is identical on all ranks, when a rank notices it is not.
+                if (!comm) stop = true;
+                else target = std::min(maxit, h_ctl->decided + 1);
+            }
         }
+        if (target != 0 && j >= target) stop = true;
     }
-    it = std::min(double(maxit), it);
-    res.iterations = int(std::ceil(it));
+    hipLaunchKernelGGL(k_final_check, dim3(1), dim3(kBlock), 0, stream, last, d_ctl, h_ctl_dev, (const double*)a_n2, np_n2);
+    OPMGPU_HIP(hipStreamSynchronize(stream));
+    const double norm0 = std::sqrt(h_ctl->norm0_2), norm = std::sqrt(h_ctl->norm2);
+    res.converged = h_ctl->done && h_ctl->flag == 0;
+    res.iterations = h_ctl->done ? h_ctl->iters : maxit;
     res.reduction = norm0 > 0 ? norm / norm0 : 0.0;
-    if (res.status == OPMGPU_OK && !res.converged && !prm.ignore_convergence_failure) res.status = OPMGPU_ELINSOLVE;   // ISTLSolver.hpp:358-368
+    if (h_ctl->flag != 0 || !(norm0 == norm0)) res.status = OPMGPU_EBREAKDOWN;
+    else if (!res.converged && !prm.ignore_convergence_failure) res.status = OPMGPU_ELINSOLVE;      // ISTLSolver.hpp:358-368
     return res;
 }
 
@@ -549,13 +701,13 @@ template <class S> static double time_kernel_t(LinSolver& ls, int kernel, int re
     SolverWork<S>& w = ls.work<S>();
     const Plan& P = ls.plan;
     const long n = long(3) * P.nbp;
-    const int gv = std::min(grid_for(n), kMaxRedBlocks);
+    const int gv = std::min(grid_for(n), kMaxPart);
     hipEvent_t e0, e1;
     OPMGPU_HIP(hipEventCreate(&e0)); OPMGPU_HIP(hipEventCreate(&e1));
     auto launch = [&]() {
         switch (kernel) {
         case OPMGPU_K_SPMV: ls.spmv<S>(w.p.p, w.v.p); break;
-        case OPMGPU_K_ILU_APPLY: ls.ilu_apply<S>(w.p.p, w.y.p, relax); break;
+        case OPMGPU_K_ILU_APPLY: ls.ilu_apply<S>(w.p.p, w.y.p, relax, nullptr); break;
         case OPMGPU_K_DOT: hipLaunchKernelGGL((k_dot<S>), dim3(gv), dim3(kBlock), 0, ls.stream, n, w.p.p, w.v.p, ls.partials.p); break;
         case OPMGPU_K_AXPY: hipLaunchKernelGGL((k_axpy<S>), dim3(gv), dim3(kBlock), 0, ls.stream, n, S(1e-3), w.p.p, w.t.p); break;
         case OPMGPU_K_STREAM_COPY: {
@@ -597,16 +749,16 @@ double LinSolver::time_kernel(int kernel, int reps, int single_precision)
 }
 
 // explicit instantiations
-#define OPMGPU_INST(S)                                                        \
-    template void LinSolver::ensure_work<S>();                                 \
-    template int LinSolver::factor<S>();                                       \
-    template void LinSolver::ilu_apply<S>(const S*, S*, double);               \
-    template void LinSolver::spmv<S>(const S*, S*);                            \
-    template SolveResult LinSolver::bicgstab<S>(const opmgpu_params&);         \
-    template void LinSolver::vec_from_host<S>(const double*, int, S*);         \
-    template void LinSolver::vec_to_host<S>(const S*, int, double*);           \
-    template void LinSolver::vec_in<S>(const double*, int, S*);                \
-    template void LinSolver::vec_out<S>(const S*, int, double*);               \
+#define OPMGPU_INST(S)                                                                  \
+    template void LinSolver::ensure_work<S>();                                           \
+    template int LinSolver::factor<S>();                                                 \
+    template void LinSolver::ilu_apply<S>(const S*, S*, double, const SolveCtl*);        \
+    template void LinSolver::spmv<S>(const S*, S*);                                      \
+    template SolveResult LinSolver::bicgstab<S>(const opmgpu_params&);                   \
+    template void LinSolver::vec_from_host<S>(const double*, int, S*);                   \
+    template void LinSolver::vec_to_host<S>(const S*, int, double*);                     \
+    template void LinSolver::vec_in<S>(const double*, int, S*);                          \
+    template void LinSolver::vec_out<S>(const S*, int, double*);                         \
     template void LinSolver::get_lu_bsr<S>(double*);
 OPMGPU_INST(float)
 OPMGPU_INST(double)

@@ -19,8 +19,32 @@ struct DevPlan {
     void upload(const Plan& P, hipStream_t s);
 };
 
-enum { SC_RHO = 0, SC_RHONEW, SC_ALPHA, SC_OMEGA, SC_BETA, SC_H, SC_NORM2, SC_NORM0_2, SC_FLAG, SC_TR, SC_TT, SC_COUNT = 16 };
 enum { VEC_BLOCK_INTERLEAVED = 0, VEC_EQUATION_MAJOR = 1 };
+
+// Device-resident control block of one BiCGStab solve.  Every kernel of the iteration starts with
+// `if (ctl->done) return;` so the host can enqueue iterations ahead of the convergence result.
+struct SolveCtl {
+    double rho[2];        // <rt,r> of the previous / current iteration (double-buffered by parity)
+    double alpha, omega;
+    double norm0_2;       // ||r0||^2
+    double norm2;         // ||r||^2 at the last convergence test
+    double thresh2;       // (reduction * ||r0||)^2
+    int done;             // 1 = stop (converged or breakdown)
+    int flag;             // 0 ok, 1 = |h| < eps, 2 = |rho| or |omega| <= eps
+    int iters;            // dune's ceil(it) at convergence
+    int decided;          // iteration whose kernel set `done` (identical on all ranks)
+};
+
+// Multi-GPU hooks (dist.hip): owner mask, halo exchange of a plane vector, all-reduce of a few doubles.
+struct CommBase {
+    virtual ~CommBase() {}
+    virtual void halo_exchange_f(float* v, hipStream_t s) = 0;
+    virtual void halo_exchange_d(double* v, hipStream_t s) = 0;
+    virtual void allreduce_sum(double* dbuf, int n, hipStream_t s) = 0;
+    virtual void allreduce_max(double* dbuf, int n, hipStream_t s) = 0;
+    virtual const int8_t* owner_mask() const = 0;     // [nbp] internal numbering, 1 = owned
+    int n_owned_global = 0;
+};
 
 template <class S>
 struct SolverWork {
@@ -50,7 +74,7 @@ public:
     template <class S> const S* matrix();
 
     template <class S> int factor();                                // ILU0 numeric factorisation
-    template <class S> void ilu_apply(const S* d, S* v, double relax);
+    template <class S> void ilu_apply(const S* d, S* v, double relax, const SolveCtl* ctl = nullptr);
     template <class S> void spmv(const S* x, S* y);
     // x0 = 0; rhs in work<S>().b; solution in work<S>().x
     template <class S> SolveResult bicgstab(const opmgpu_params& prm);
@@ -76,12 +100,16 @@ public:
     hipStream_t stream;
     DevArray<double> Ad;
     DevArray<double> stage;        // host-BSR staging / vector staging
-    DevArray<double> partials;
-    DevArray<double> scalars;
+    DevArray<double> partials;     // 6 partial arrays of npart doubles + 8 all-reduced scalars
     DevArray<int32_t> flags;
-    double* h_scalars = nullptr;   // pinned
+    SolveCtl* h_ctl = nullptr;     // host-mapped status copy (device publishes, host polls after an event)
+    SolveCtl* h_ctl_dev = nullptr; // device alias of h_ctl
+    DevArray<SolveCtl> ctl;        // device-resident control block read by every kernel
     int32_t* h_flags = nullptr;    // pinned
     int cur_ordering = -1;
+    int npart = 0;                 // entries per partial array
+    CommBase* comm = nullptr;      // not owned; nullptr = single GPU
+    hipEvent_t ev[2] = { nullptr, nullptr };
 
 private:
     SolverWork<double> wd;

@@ -1,0 +1,112 @@
+"""Domain decomposition for multi-GPU runs: owned cells + one ghost layer per rank.
+
+Role of the reference's `Dune::CpGrid::loadBalance` + `ParallelISTLInformation` index sets
+(RedistributeDataHandles.hpp:540-628, ISTLSolver.hpp:286-298).  Rank-local numbering is
+[owned (ascending global id) | ghosts (by owner rank, then global id)]; the send list towards a
+neighbour and that neighbour's receive list name the same cells in the same (global id) order, so a
+halo exchange is a plain pack / send / recv / unpack.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .decks import GridData, State
+
+
+def slab_partition(grid, nranks):
+    """Contiguous slabs of whole layers along the slowest (k) axis when the Cartesian dims are known,
+    else contiguous index ranges.  Returns part[cell] = owner rank."""
+    n = grid.nc
+    if grid.dims is not None and grid.dims[0] * grid.dims[1] * grid.dims[2] == n:
+        nx, ny, nz = grid.dims
+        layer_owner = (np.arange(nz) * nranks) // nz
+        return np.repeat(layer_owner, nx * ny).astype(np.int32)
+    return ((np.arange(n, dtype=np.int64) * nranks) // n).astype(np.int32)
+
+
+class LocalDomain:
+    """One rank's share of a partitioned grid."""
+
+    def __init__(self, grid, part, rank):
+        part = np.asarray(part)
+        conn = grid.conn_cells
+        p1, p2 = part[conn[:, 0]], part[conn[:, 1]]
+        keep = (p1 == rank) | (p2 == rank)
+        lc = conn[keep]
+        owned = np.flatnonzero(part == rank)
+        cells = np.unique(lc)
+        ghosts = cells[part[cells] != rank]
+        ghosts = ghosts[np.lexsort((ghosts, part[ghosts]))]           # by owner, then global id
+        self.rank, self.n_owned, self.n_ghost = rank, owned.size, ghosts.size
+        self.global_of_local = np.concatenate([owned, ghosts]).astype(np.int64)
+        g2l = -np.ones(grid.nc, dtype=np.int64)
+        g2l[self.global_of_local] = np.arange(self.global_of_local.size)
+        self.conn_index = np.flatnonzero(keep)
+        self.grid = GridData(self.global_of_local.size, g2l[lc], grid.trans[keep], grid.pv[self.global_of_local],
+                             grid.z[self.global_of_local], gravity=grid.gravity,
+                             thpres=None if grid.thpres is None else grid.thpres[keep],
+                             pvtnum=None if grid.pvtnum is None else grid.pvtnum[self.global_of_local],
+                             satnum=None if grid.satnum is None else grid.satnum[self.global_of_local])
+        # halo lists
+        gown = part[ghosts]
+        self.neigh_rank = np.unique(gown).astype(np.int32)
+        recv_ptr, send_ptr, send_cells = [0], [0], []
+        cut = p1 != p2
+        mine_a = cut & (p1 == rank)
+        mine_b = cut & (p2 == rank)
+        for q in self.neigh_rank:
+            recv_ptr.append(recv_ptr[-1] + int((gown == q).sum()))
+            a = conn[mine_a & (p2 == q), 0]
+            b = conn[mine_b & (p1 == q), 1]
+            s = np.unique(np.concatenate([a, b]))
+            send_cells.append(g2l[s])
+            send_ptr.append(send_ptr[-1] + s.size)
+        self.recv_ptr, self.send_ptr = capi.i32(recv_ptr), capi.i32(send_ptr)
+        self.recv_cells = capi.i32(self.n_owned + np.arange(ghosts.size))          # ghosts are already grouped by owner
+        self.send_cells = capi.i32(np.concatenate(send_cells) if send_cells else np.zeros(0, np.int64))
+
+    def local_state(self, st):
+        g = self.global_of_local
+        return State(st.p[g], st.sat[g], st.rs[g], st.rv[g], st.hc[g])
+
+
+def attach_comm(model, dom, rank, world, unique_id):
+    """opmgpu_comm_init for a model created on dom.grid."""
+    lib = capi.load()
+    idb = (C.c_uint8 * capi.UNIQUE_ID_BYTES).from_buffer_copy(bytes(unique_id))
+    st = lib.opmgpu_comm_init(model.ctx, rank, world, idb, dom.n_owned, int(dom.neigh_rank.size), capi.iptr(dom.neigh_rank),
+                              capi.iptr(dom.send_ptr), capi.iptr(dom.send_cells), capi.iptr(dom.recv_ptr), capi.iptr(dom.recv_cells))
+    if st != capi.OK:
+        raise RuntimeError("opmgpu_comm_init failed with status %d: %s" % (st, lib.opmgpu_last_error(model.ctx)))
+
+
+def make_unique_id():
+    lib = capi.load()
+    buf = (C.c_uint8 * capi.UNIQUE_ID_BYTES)()
+    st = lib.opmgpu_comm_unique_id(buf)
+    if st != capi.OK:
+        raise RuntimeError("opmgpu_comm_unique_id failed with status %d" % st)
+    return bytes(buf)
+
+
+def build_distributed_model(nx, ny, nz, tables, params, rank, world, local_rank, lognormal_sigma=0.5, seed=12345, perturb=0.002):
+    """Every rank builds the same global synthetic deck, keeps its slab (+ghosts) and joins the RCCL communicator.
+    The unique id travels through torch.distributed (backend nccl = RCCL)."""
+    import torch
+    import torch.distributed as dist
+    from . import decks
+    from .model import GpuBlackoilModel
+    grid = decks.cartesian_grid(nx, ny, nz, lognormal_sigma=lognormal_sigma, seed=seed)
+    st = decks.initial_state(grid, tables, perturb=perturb, seed=seed)
+    part = slab_partition(grid, world)
+    dom = LocalDomain(grid, part, rank)
+    model = GpuBlackoilModel(dom.grid, tables, params, device=local_rank)
+    dev = torch.device("cuda", local_rank)
+    idt = torch.zeros(capi.UNIQUE_ID_BYTES, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        idt.copy_(torch.frombuffer(bytearray(make_unique_id()), dtype=torch.uint8))
+    dist.broadcast(idt, src=0)
+    attach_comm(model, dom, rank, world, bytes(idt.cpu().numpy().tobytes()))
+    info = {"n_owned": dom.n_owned, "n_global": grid.nc, "n_ghost": dom.n_ghost, "neighbours": dom.neigh_rank.tolist()}
+    return model, dom.grid, dom.local_state(st), info

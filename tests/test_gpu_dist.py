@@ -1,0 +1,95 @@
+"""Multi-GPU code path exercised on ONE GPU: a z-periodic deck solved (A) as a plain grid whose
+wrap-around faces are ordinary connections and (B) as a one-rank RCCL "decomposition" whose wrap-around
+neighbours are ghost copies refreshed by a halo exchange with itself (grouped ncclSend/ncclRecv to
+self).  B runs every multi-GPU mechanism -- owner mask, identity ghost rows, halo pack/exchange/unpack
+before each SpMV, partial-sum bridge + all-reduce, deterministic stop rule, block-Jacobi ILU0 -- and
+must reproduce A."""
+import numpy as np
+import pytest
+
+from opmgpu import capi, decks, partition
+from opmgpu.model import GpuBlackoilModel
+from util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _periodic_pair(nx=6, ny=5, nz=4):
+    base = decks.cartesian_grid(nx, ny, nz, lognormal_sigma=0.4)
+    n, L = base.nc, nx * ny
+    bottom, top = np.arange(L), np.arange(n - L, n)           # k = 0 layer and k = nz-1 layer
+    twrap = np.full(L, np.median(base.trans))
+    # A: wrap faces as extra connections (top cell is c1)
+    connA = np.concatenate([base.conn_cells, np.stack([top, bottom], 1)])
+    gridA = decks.GridData(n, connA, np.concatenate([base.trans, twrap]), base.pv, base.z)
+    # B: owned cells + ghost copies [bottom copies | top copies]
+    gb, gt = n + np.arange(L), n + L + np.arange(L)
+    connB = np.concatenate([base.conn_cells, np.stack([top, gb], 1), np.stack([gt, bottom], 1)])
+    pv = np.concatenate([base.pv, base.pv[bottom], base.pv[top]])
+    z = np.concatenate([base.z, base.z[bottom], base.z[top]])
+    gridB = decks.GridData(n + 2 * L, connB, np.concatenate([base.trans, twrap, twrap]), pv, z)
+    src = np.concatenate([np.arange(n), bottom, top])          # original cell of every local cell
+    halo = dict(n_owned=n, neigh_rank=capi.i32([0]), send_ptr=capi.i32([0, 2 * L]), send_cells=capi.i32(np.concatenate([bottom, top])),
+                recv_ptr=capi.i32([0, 2 * L]), recv_cells=capi.i32(n + np.arange(2 * L)))
+    return gridA, gridB, src, halo
+
+
+class _Dom:
+    pass
+
+
+@pytest.mark.parametrize("single", [False, True])
+def test_self_halo_reproduces_plain_grid(gpu_lib, oracle, single):
+    gridA, gridB, src, halo = _periodic_pair()
+    tab = decks.satfunc_standard_tables()
+    stA = decks.initial_state(gridA, tab, perturb=0.01)
+    stB = decks.State(stA.p[src], stA.sat[src], stA.rs[src], stA.rv[src], stA.hc[src])
+    red = 1e-4 if single else 1e-11
+    prm = capi.default_params(linear_solver_reduction=red, linear_solver_maxiter=400)
+    dt = 5 * decks.DAY
+    n = gridA.nc
+    A = GpuBlackoilModel(gridA, tab, prm)
+    B = GpuBlackoilModel(gridB, tab, prm)
+    dom = _Dom()
+    for k, v in halo.items():
+        setattr(dom, k, v)
+    partition.attach_comm(B, dom, 0, 1, partition.make_unique_id())
+    A.prepareStep(dt, stA)
+    B.prepareStep(dt, stB)
+    for it in range(3):
+        A.assemble(it == 0); B.assemble(it == 0)
+        # owned rows of B == rows of A (ghost column g <-> its original cell), ghost rows = identity, zero residual
+        rA, rB = A.residual(), B.residual()
+        nB = gridB.nc
+        for a in range(3):
+            assert rel_err(rB[a * nB:a * nB + n], rA[a * n:(a + 1) * n]) < 1e-12
+            assert np.all(rB[a * nB + n:(a + 1) * nB] == 0.0)
+        rpA, clA, vA = A.jacobian(); rpB, clB, vB = B.jacobian()
+        for i in range(n):
+            ca = {int(c): vA[k] for k, c in zip(range(rpA[i], rpA[i + 1]), clA[rpA[i]:rpA[i + 1]])}
+            cb = {int(src[c]): vB[k] for k, c in zip(range(rpB[i], rpB[i + 1]), clB[rpB[i]:rpB[i + 1]])}
+            assert ca.keys() == cb.keys()
+            for c in ca:
+                assert np.allclose(ca[c], cb[c], rtol=1e-12, atol=1e-14 * np.abs(vA).max())
+        for i in range(n, nB):
+            blk = {int(c): vB[k] for k, c in zip(range(rpB[i], rpB[i + 1]), clB[rpB[i]:rpB[i + 1]])}
+            assert np.array_equal(blk.pop(i), np.eye(3).ravel()) and all(np.all(b == 0) for b in blk.values())
+        cA, cB = A.getConvergence(), B.getConvergence()
+        assert cA == cB and np.allclose(A.CNV, B.CNV, rtol=1e-10) and np.allclose(A.MB, B.MB, rtol=1e-7, atol=1e-18) and np.allclose(A.B_avg, B.B_avg, rtol=1e-12)
+        dxA = A.solveJacobianSystem(want_dx=True, single_precision=single)
+        dxB = B.solveJacobianSystem(want_dx=True, single_precision=single)
+        assert B.linear_iterations >= 1 and B.linear_reduction < red
+        if not single:
+            for a in range(3):
+                blkA, blkB = dxA[a * n:(a + 1) * n], dxB[a * nB:a * nB + n]
+                assert np.abs(blkA - blkB).max() <= 1e-6 * np.abs(blkA).max() + 1e-300, (it, a)
+                # ghosts carry their owner's increment bit for bit (halo-exchanged search directions)
+                assert np.array_equal(dxB[a * nB + n:(a + 1) * nB], dxB[a * nB:a * nB + n][src[n:]])
+        A.updateState(); B.updateState()
+        sa, sb = A.getState(), B.getState()
+        if not single:
+            assert np.array_equal(sa.hc, sb.hc[:n])
+            assert np.abs(sa.p - sb.p[:n]).max() <= 1e-6 * np.abs(sa.p).max() and np.abs(sa.sat - sb.sat[:n]).max() <= 1e-6
+            # ghost state stays a copy of the owner's state without any state exchange
+            assert np.array_equal(sb.p[n:], sb.p[src[n:]]) and np.array_equal(sb.sat[n:], sb.sat[src[n:]]) and np.array_equal(sb.hc[n:], sb.hc[src[n:]])
+    A.close(); B.close()
