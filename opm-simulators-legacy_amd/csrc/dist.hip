@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 
 #include <cstring>
+#include <string>
 
 #include "dist.hpp"
 
@@ -39,8 +40,21 @@ struct Rccl {
     bool load()
     {
         if (h) return true;
-        const char* names[] = { "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so", "/opt/rocm/lib/librccl.so.1" };
-        for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+        // Load the RCCL that sits next to the HIP runtime this process actually uses (PyTorch wheels bundle their own
+        // libamdhip64 / libhsa-runtime64 / librccl; mixing one tree's RCCL with the other's HSA runtime opens a second
+        // HSA instance that cannot see the GPU).
+        std::string dir;
+        Dl_info info;
+        if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+            dir = info.dli_fname;
+            const size_t k = dir.rfind('/');
+            dir = (k == std::string::npos) ? std::string() : dir.substr(0, k + 1);
+        }
+        std::vector<std::string> names;
+        if (!dir.empty()) { names.push_back(dir + "librccl.so"); names.push_back(dir + "librccl.so.1"); }
+        names.push_back("librccl.so"); names.push_back("librccl.so.1");
+        names.push_back("/opt/rocm/lib/librccl.so"); names.push_back("/opt/rocm/lib/librccl.so.1");
+        for (const std::string& n : names) { h = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL); if (h) break; }
         if (!h) return false;
 #define L(sym) *reinterpret_cast<void**>(&sym) = dlsym(h, "nccl" #sym); if (!sym) return false;
         L(GetUniqueId) L(CommInitRank) L(CommDestroy) L(AllReduce) L(Send) L(Recv) L(GroupStart) L(GroupEnd)

@@ -135,6 +135,12 @@ def load(path=None):
     if _lib is not None and path is None:
         return _lib
     path = path or LIB_PATH
+    try:
+        # PyTorch wheels bundle their own HIP/HSA/RCCL.  Importing torch FIRST makes libopmgpu.so bind to the same
+        # runtime instance, so device pointers, streams and RCCL communicators are shared instead of duplicated.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(path):
         raise RuntimeError(
             "libopmgpu.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
