@@ -1,0 +1,168 @@
+// opmgpu.hpp -- C++ host-side mirror of the reference's plug-in interfaces over the C ABI (include/opmgpu.h).
+//
+// Header-only, no OPM / Eigen / Dune dependency: these are the classes a flow_legacy maintainer derives
+// the real adaptors from (INTEGRATION.md shows the OPM-side glue).  Names, call order and error
+// behaviour follow the reference:
+//   opmgpu::NewtonIterationBlackoilGpu   <->  Opm::NewtonIterationBlackoilInterface
+//                                             (opm/autodiff/NewtonIterationBlackoilInterface.hpp:31-52)
+//   opmgpu::BlackoilModelGpu             <->  Opm::BlackoilModelBase hooks
+//                                             (opm/autodiff/BlackoilModelBase_impl.hpp:222-326)
+//   opmgpu::NonlinearSolverGpu::step     <->  Opm::NonlinearSolver::step (NonlinearSolver_impl.hpp:119-174)
+// Status codes of the C ABI become the exception types the reference's AdaptiveTimeStepping catches
+// (AdaptiveTimeStepping_impl.hpp:244-281).
+#ifndef OPMGPU_HOST_HPP
+#define OPMGPU_HOST_HPP
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/opmgpu.h"
+
+namespace opmgpu {
+
+struct NumericalIssue : std::runtime_error { using std::runtime_error::runtime_error; };        // Opm::NumericalIssue
+struct LinearSolverProblem : std::runtime_error { using std::runtime_error::runtime_error; };   // Opm::LinearSolverProblem
+struct ISTLError : std::runtime_error { using std::runtime_error::runtime_error; };             // Dune::ISTLError / MatrixBlockError
+struct TooManyIterations : std::runtime_error { using std::runtime_error::runtime_error; };     // Opm::TooManyIterations
+
+inline void throw_on_status(const opmgpu_ctx* ctx, int st)
+{
+    if (st == OPMGPU_OK) return;
+    const std::string msg = ctx ? opmgpu_last_error(ctx) : "";
+    switch (st) {
+    case OPMGPU_ENUMERICAL: throw NumericalIssue(msg);
+    case OPMGPU_ELINSOLVE:  throw LinearSolverProblem(msg);
+    case OPMGPU_EBREAKDOWN:
+    case OPMGPU_ESINGULAR:  throw ISTLError(msg);
+    case OPMGPU_EINVAL:     throw std::logic_error("opmgpu: invalid argument: " + msg);
+    default:                throw std::runtime_error("opmgpu status " + std::to_string(st) + ": " + msg);
+    }
+}
+
+/// BCRSMatrix<MatrixBlock<Scalar,3,3>> + BlockVector handed over as plain arrays
+/// (what formInterleavedSystem produces, NewtonIterationBlackoilInterleaved.cpp:110-194, 263-269).
+struct BsrSystem {
+    int nb = 0;
+    std::vector<int32_t> rowptr, col;      // columns ascending per row, diagonal present
+    std::vector<double> val9;              // nnzb * 9, row-major blocks  A[row][col][eq][var]
+    std::vector<double> rhs3;              // nb * 3, block-interleaved
+    bool singlePrecision = false;          // LinearisedBlackoilResidual::singlePrecision
+};
+
+/// B1: drop-in for NewtonIterationBlackoilInterleaved's solve stage.
+class NewtonIterationBlackoilGpu {
+public:
+    explicit NewtonIterationBlackoilGpu(const opmgpu_params* prm = nullptr, int device = 0)
+    {
+        const int st = opmgpu_create_solver(&ctx_, device, prm);
+        if (st != OPMGPU_OK) throw std::runtime_error("opmgpu_create_solver failed (no GPU? there is no CPU fallback), status " + std::to_string(st));
+    }
+    ~NewtonIterationBlackoilGpu() { opmgpu_destroy(ctx_); }
+    NewtonIterationBlackoilGpu(const NewtonIterationBlackoilGpu&) = delete;
+    NewtonIterationBlackoilGpu& operator=(const NewtonIterationBlackoilGpu&) = delete;
+
+    /// x (nb*3, block-interleaved) with J x = rhs; const like the reference's (mutable internals, :75-79)
+    std::vector<double> computeNewtonIncrement(const BsrSystem& sys) const
+    {
+        std::vector<double> x(size_t(3) * sys.nb, 0.0);
+        const int st = opmgpu_solve_bsr(ctx_, sys.nb, sys.rowptr.data(), sys.col.data(), sys.val9.data(), sys.rhs3.data(),
+                                        sys.singlePrecision ? 1 : 0, x.data(), &iterations_, &reduction_);
+        throw_on_status(ctx_, st);
+        return x;
+    }
+    int iterations() const { return iterations_; }                   // NewtonIterationBlackoilInterface::iterations
+    double reduction() const { return reduction_; }
+    opmgpu_ctx* handle() const { return ctx_; }
+
+private:
+    mutable opmgpu_ctx* ctx_ = nullptr;
+    mutable int iterations_ = 0;
+    mutable double reduction_ = 0.0;
+};
+
+/// ReservoirState view (opm/core/simulator/BlackoilState.hpp:40-90)
+struct ReservoirStateView {
+    double* pressure; double* saturation; double* gasoilratio; double* rv; int8_t* hydroCarbonState;
+};
+
+struct ConvergenceReport { double B_avg[3], CNV[3], MB[3], linf[3]; bool converged; };
+
+/// B2: the BlackoilModel hooks on the device.  The context outlives the model object like the reference's
+/// linear solver outlives BlackoilModel (FlowMain.hpp:237 vs SimulatorBase_impl.hpp:201-203).
+class BlackoilModelGpu {
+public:
+    BlackoilModelGpu(const opmgpu_grid& grid, const opmgpu_tables& tables, const opmgpu_params* prm = nullptr, int device = 0)
+    {
+        nc_ = grid.nc;
+        const int st = opmgpu_create(&ctx_, device, &grid, &tables, prm);
+        if (st != OPMGPU_OK) throw std::runtime_error("opmgpu_create failed (no GPU? there is no CPU fallback), status " + std::to_string(st));
+    }
+    ~BlackoilModelGpu() { opmgpu_destroy(ctx_); }
+    BlackoilModelGpu(const BlackoilModelGpu&) = delete;
+    BlackoilModelGpu& operator=(const BlackoilModelGpu&) = delete;
+
+    int numPhases() const { return 3; }
+    void setWells(int nw, const int32_t* well_connpos, const int32_t* well_cells) { throw_on_status(ctx_, opmgpu_set_wells(ctx_, nw, well_connpos, well_cells)); }
+
+    /// prepareStep (:222-232): remembers dt (pvdt = pv/dt is applied in assemble) and uploads the state
+    void prepareStep(double dt, const ReservoirStateView& s)
+    {
+        dt_ = dt;
+        throw_on_status(ctx_, opmgpu_set_state(ctx_, s.pressure, s.saturation, s.gasoilratio, s.rv, s.hydroCarbonState));
+    }
+    void assemble(bool initial_assembly) { throw_on_status(ctx_, opmgpu_assemble(ctx_, dt_, initial_assembly ? 1 : 0, nullptr, nullptr, nullptr, nullptr, nullptr)); }
+    ConvergenceReport getConvergence()
+    {
+        ConvergenceReport r; int conv = 0;
+        const int st = opmgpu_convergence(ctx_, dt_, r.B_avg, r.CNV, r.MB, r.linf, &conv);
+        r.converged = conv != 0;
+        throw_on_status(ctx_, st);         // NumericalIssue on NaN / too large residual
+        return r;
+    }
+    /// solveJacobianSystem (:1139-1145); residual_.singlePrecision = dt < maxSinglePrecisionTimeStep (:284)
+    void solveJacobianSystem()
+    {
+        const int single = dt_ < max_single_precision_days_ * 86400.0 ? 1 : 0;
+        throw_on_status(ctx_, opmgpu_solve(ctx_, single, nullptr, &linear_iterations_, &linear_reduction_));
+    }
+    void updateState(double relax = 1.0) { throw_on_status(ctx_, opmgpu_update_state(ctx_, nullptr, relax)); }
+    void downloadState(const ReservoirStateView& s) { throw_on_status(ctx_, opmgpu_get_state(ctx_, s.pressure, s.saturation, s.gasoilratio, s.rv, s.hydroCarbonState)); }
+
+    /// nonlinearIteration (:239-326): assemble -> getConvergence -> [solve -> update]
+    bool nonlinearIteration(int iteration, int min_iter = 1)
+    {
+        assemble(iteration == 0);
+        const ConvergenceReport r = getConvergence();
+        const bool must_solve = (iteration < min_iter) || !r.converged;
+        if (must_solve) { solveJacobianSystem(); updateState(); }
+        return r.converged;
+    }
+    int linearIterationsLastSolve() const { return linear_iterations_; }
+    opmgpu_ctx* handle() const { return ctx_; }
+
+private:
+    opmgpu_ctx* ctx_ = nullptr;
+    int nc_ = 0;
+    double dt_ = 0.0, max_single_precision_days_ = 20.0, linear_reduction_ = 0.0;
+    int linear_iterations_ = 0;
+};
+
+/// NonlinearSolver::step (NonlinearSolver_impl.hpp:119-174) without the oscillation / relaxation logic
+struct NonlinearSolverGpu {
+    int max_iter = 10, min_iter = 1;
+    int step(BlackoilModelGpu& model) const
+    {
+        int iteration = 0; bool converged = false;
+        do {
+            converged = model.nonlinearIteration(iteration, min_iter);
+            ++iteration;
+        } while ((!converged && iteration <= max_iter) || iteration <= min_iter);
+        if (!converged) throw TooManyIterations("Failed to complete a time step within " + std::to_string(max_iter) + " iterations.");
+        return iteration;
+    }
+};
+
+} // namespace opmgpu
+#endif
