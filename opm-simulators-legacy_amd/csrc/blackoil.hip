@@ -290,7 +290,10 @@ __global__ __launch_bounds__(kBlock) void k_flux(int nb, int nbp, const int32_t*
                                                  double s0, double s1, double s2, const int8_t* __restrict__ mask,
                                                  double* __restrict__ R, double* __restrict__ A)
 {
-    const int row = blockIdx.x * kBlock + threadIdx.x;
+    const int nchunks = (nb + kBlock - 1) / kBlock;
+    const int ch = xcd_first(nchunks);
+    if (ch >= xcd_end(nchunks)) return;
+    const int row = ch * kBlock + threadIdx.x;
     if (row >= nb) return;
     const int base = slice_ptr[row >> 6], lane = row & 63, nl = nlower[row], len = rowlen[row];
     if (mask && !mask[row]) {
@@ -714,7 +717,7 @@ void BlackoilDevice::assemble(double dt, bool initial)
     hipLaunchKernelGGL(k_cell_props, dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_pv.p,
                        d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, 1.0 / dt, int(initial), sc[0], sc[1], sc[2],
                        ls.dp.slice_ptr.p, ls.dp.nlower.p, d_props.p, d_accum0.p, d_R.p, d_binv.p, ls.matrix_d());
-    hipLaunchKernelGGL(k_flux, dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, P.nbp, ls.dp.slice_ptr.p, ls.dp.col.p, ls.dp.rowlen.p,
+    hipLaunchKernelGGL(k_flux, dim3(grid8_for(nc)), dim3(kBlock), 0, stream, nc, P.nbp, ls.dp.slice_ptr.p, ls.dp.col.p, ls.dp.rowlen.p,
                        ls.dp.nlower.p, d_conn_code.p, d_trans.p, d_gdz.p, use_thpres ? d_thpres.p : (const double*)nullptr,
                        d_p.p, d_props.p, sc[0], sc[1], sc[2], ls.comm ? ls.comm->owner_mask() : (const int8_t*)nullptr, d_R.p, ls.matrix_d());
 }

@@ -59,7 +59,10 @@ __global__ __launch_bounds__(kBlock) void k_spmv(int nb, int nbp, const int32_t*
     __shared__ double sm[8];
     if (ctl && ctl->done) return;
     double acc[2] = { 0.0, 0.0 };
-    for (int row = blockIdx.x * kBlock + threadIdx.x; row < nb; row += gridDim.x * kBlock) {
+    const int nchunks = (nb + kBlock - 1) / kBlock;
+    for (int ch = xcd_first(nchunks); ch < xcd_end(nchunks); ch += gridDim.x >> 3) {
+        const int row = ch * kBlock + threadIdx.x;
+        if (row >= nb) continue;
         const int sl = row >> 6, lane = row & 63;
         const int base = slice_ptr[sl], width = slice_ptr[sl + 1] - base;
         const S* __restrict__ v = val + vidx(base, lane);
@@ -99,7 +102,10 @@ __global__ __launch_bounds__(kBlock) void k_ilu_lower(int lo, int hi, int n0, in
                                                       const SolveCtl* __restrict__ ctl)
 {
     if (ctl && ctl->done) return;
-    const int row = lo + blockIdx.x * kBlock + threadIdx.x;
+    const int nchunks = (hi - lo + kBlock - 1) / kBlock;
+    const int ch = xcd_first(nchunks);
+    if (ch >= xcd_end(nchunks)) return;
+    const int row = lo + ch * kBlock + threadIdx.x;
     if (row >= hi) return;
     const int base = slice_ptr[row >> 6], lane = row & 63, nl = nlower[row];
     const S* __restrict__ m = lu + vidx(base, lane);
@@ -133,7 +139,10 @@ __global__ __launch_bounds__(kBlock) void k_ilu_upper(int lo, int hi, int n0, in
                                                       const S* __restrict__ d, S* __restrict__ v, const SolveCtl* __restrict__ ctl)
 {
     if (ctl && ctl->done) return;
-    const int row = lo + blockIdx.x * kBlock + threadIdx.x;
+    const int nchunks = (hi - lo + kBlock - 1) / kBlock;
+    const int ch = xcd_first(nchunks);
+    if (ch >= xcd_end(nchunks)) return;
+    const int row = lo + ch * kBlock + threadIdx.x;
     if (row >= hi) return;
     const int base = slice_ptr[row >> 6], lane = row & 63, nl = nlower[row], len = rowlen[row];
     const S* __restrict__ m = lu + vidx(base, lane);
@@ -550,27 +559,27 @@ template <class S> void LinSolver::ilu_apply(const S* d, S* v, double relax, con
     const int L = plan.nlevels;
     const int n0 = plan.level_ptr[1];
     if (L == 1) {
-        hipLaunchKernelGGL((k_ilu_lower<S>), dim3(grid_for(n0)), dim3(kBlock), 0, stream, 0, n0, 0, plan.nbp, 1, S(relax),
+        hipLaunchKernelGGL((k_ilu_lower<S>), dim3(grid8_for(n0)), dim3(kBlock), 0, stream, 0, n0, 0, plan.nbp, 1, S(relax),
                            dp.slice_ptr.p, dp.col.p, dp.nlower.p, w.LU.p, d, v, ctl);
         return;
     }
     for (int l = 1; l < L; ++l) {
         const int lo = plan.level_ptr[l], hi = plan.level_ptr[l + 1];
         if (hi == lo) continue;
-        hipLaunchKernelGGL((k_ilu_lower<S>), dim3(grid_for(hi - lo)), dim3(kBlock), 0, stream, lo, hi, n0, plan.nbp, int(l == L - 1), S(relax),
+        hipLaunchKernelGGL((k_ilu_lower<S>), dim3(grid8_for(hi - lo)), dim3(kBlock), 0, stream, lo, hi, n0, plan.nbp, int(l == L - 1), S(relax),
                            dp.slice_ptr.p, dp.col.p, dp.nlower.p, w.LU.p, d, v, ctl);
     }
     for (int l = L - 2; l >= 0; --l) {
         const int lo = plan.level_ptr[l], hi = plan.level_ptr[l + 1];
         if (hi == lo) continue;
-        hipLaunchKernelGGL((k_ilu_upper<S>), dim3(grid_for(hi - lo)), dim3(kBlock), 0, stream, lo, hi, n0, plan.nbp, S(relax), dp.slice_ptr.p, dp.col.p,
+        hipLaunchKernelGGL((k_ilu_upper<S>), dim3(grid8_for(hi - lo)), dim3(kBlock), 0, stream, lo, hi, n0, plan.nbp, S(relax), dp.slice_ptr.p, dp.col.p,
                            dp.nlower.p, dp.rowlen.p, w.LU.p, d, v, ctl);
     }
 }
 
 template <class S> void LinSolver::spmv(const S* x, S* y)
 {
-    const int g = std::min(grid_for(plan.nb), 4 * kMaxPart);
+    const int g = std::min(grid8_for(plan.nb), 4 * kMaxPart);
     hipLaunchKernelGGL((k_spmv<S, 0>), dim3(g), dim3(kBlock), 0, stream, plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p,
                        matrix<S>(), x, y, (const S*)nullptr, comm ? comm->owner_mask() : (const int8_t*)nullptr, (const SolveCtl*)nullptr,
                        (double*)nullptr, (double*)nullptr);
@@ -586,7 +595,7 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
     SolveResult res;
     const long n = long(3) * plan.nbp;
     const int gv = std::min(grid_for(n), kMaxPart);            // vector kernels (also the number of their partials)
-    const int gs = std::min(grid_for(plan.nb), kMaxPart);      // reducing SpMV launches
+    const int gs = std::min(grid8_for(plan.nb), kMaxPart);     // reducing SpMV launches (multiple of 8: XCD-aware chunking)
     const double eps = sizeof(S) == 8 ? 1e-80 : 0.0;           // dune: real_type EPSILON = 1e-80 (0 in float)
     const int maxit = prm.linear_solver_maxiter;
     const int8_t* mask = comm ? comm->owner_mask() : nullptr;

@@ -86,7 +86,9 @@ int build_plan(int nb, const int32_t* rowptr, const int32_t* col, int ordering, 
         for (int s = rowptr[i]; s < rowptr[i + 1]; ++s) { const int j = col[s]; if (j != i && before(j, i)) l = std::max(l, lev[j] + 1); }
         lev[i] = l; nlev = std::max(nlev, l + 1);
     }
-    // --- internal numbering: sort by (level, caller index)
+    // --- internal numbering: sort by (level, caller index).  (A/B on MI355X, 100^3: re-grouping the rows of a level
+    // into compact BFS clusters of 512 / 4096 rows made SpMV 5-12 % and the assembly 30-45 % SLOWER than keeping the
+    // caller's order inside a level -- the banded Cartesian order already keeps gathers within a few cache lines.)
     P.nat.resize(nb); std::iota(P.nat.begin(), P.nat.end(), 0);
     std::stable_sort(P.nat.begin(), P.nat.end(), [&](int a, int b) { return lev[a] < lev[b]; });
     P.pos.resize(nb);
