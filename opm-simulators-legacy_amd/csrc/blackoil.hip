@@ -282,7 +282,7 @@ __device__ __forceinline__ V4 load4(const double* __restrict__ props, int plane,
 // TPFA flux residual + 3x3 Jacobian blocks, one thread per row
 // (computeMassFlux :1484-1512, applyThresholdPressures :1518-1545, UpwindSelector AutoDiffHelpers.hpp:204-221,
 //  rs/rv cross terms :889-906, div = ngrad^T)
-__global__ __launch_bounds__(kBlock) void k_flux(int nb, int nbp, const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
+__global__ __launch_bounds__(kBlock) void k_flux(int xm, int nb, int nbp, const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
                                                  const int16_t* __restrict__ rowlen, const int16_t* __restrict__ nlower,
                                                  const int32_t* __restrict__ conn_code, const double* __restrict__ trans,
                                                  const double* __restrict__ gdz, const double* __restrict__ thpres,
@@ -291,8 +291,8 @@ __global__ __launch_bounds__(kBlock) void k_flux(int nb, int nbp, const int32_t*
                                                  double* __restrict__ R, double* __restrict__ A)
 {
     const int nchunks = (nb + kBlock - 1) / kBlock;
-    const int ch = xcd_first(nchunks);
-    if (ch >= xcd_end(nchunks)) return;
+    const int ch = xcd_first(nchunks, xm);
+    if (ch >= xcd_end(nchunks, xm)) return;
     const int row = ch * kBlock + threadIdx.x;
     if (row >= nb) return;
     const int base = slice_ptr[row >> 6], lane = row & 63, nl = nlower[row], len = rowlen[row];
@@ -717,7 +717,7 @@ void BlackoilDevice::assemble(double dt, bool initial)
     hipLaunchKernelGGL(k_cell_props, dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_pv.p,
                        d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, 1.0 / dt, int(initial), sc[0], sc[1], sc[2],
                        ls.dp.slice_ptr.p, ls.dp.nlower.p, d_props.p, d_accum0.p, d_R.p, d_binv.p, ls.matrix_d());
-    hipLaunchKernelGGL(k_flux, dim3(grid8_for(nc)), dim3(kBlock), 0, stream, nc, P.nbp, ls.dp.slice_ptr.p, ls.dp.col.p, ls.dp.rowlen.p,
+    hipLaunchKernelGGL(k_flux, dim3(grid8_for(nc)), dim3(kBlock), 0, stream, xcd_mode(), nc, P.nbp, ls.dp.slice_ptr.p, ls.dp.col.p, ls.dp.rowlen.p,
                        ls.dp.nlower.p, d_conn_code.p, d_trans.p, d_gdz.p, use_thpres ? d_thpres.p : (const double*)nullptr,
                        d_p.p, d_props.p, sc[0], sc[1], sc[2], ls.comm ? ls.comm->owner_mask() : (const int8_t*)nullptr, d_R.p, ls.matrix_d());
 }

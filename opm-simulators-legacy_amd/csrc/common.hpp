@@ -67,9 +67,12 @@ inline int grid8_for(long n, int block = kBlock) { return (grid_for(n, block) + 
 // has its own L2): give every XCD one CONTIGUOUS range of 256-row chunks so that the x / property lines its rows
 // gather are fetched into one L2 instead of up to eight.  Speed only, never correctness (any mapping covers all chunks).
 // Iterate:  for (int c = xcd_first(...); c < xcd_end(...); c += gridDim.x >> 3)
+// mode is a kernel argument (0 = plain round-robin chunks, 1 = XCD-contiguous ranges) so both can be A/B-timed.
 __device__ __forceinline__ int xcd_per(int nchunks) { return (nchunks + 7) >> 3; }
-__device__ __forceinline__ int xcd_first(int nchunks) { return int(blockIdx.x & 7) * xcd_per(nchunks) + int(blockIdx.x >> 3); }
-__device__ __forceinline__ int xcd_end(int nchunks) { const int e = (int(blockIdx.x & 7) + 1) * xcd_per(nchunks); return e < nchunks ? e : nchunks; }
+__device__ __forceinline__ int xcd_first(int nchunks, int mode) { return mode ? int(blockIdx.x & 7) * xcd_per(nchunks) + int(blockIdx.x >> 3) : int(blockIdx.x); }
+__device__ __forceinline__ int xcd_end(int nchunks, int mode) { if (!mode) return nchunks; const int e = (int(blockIdx.x & 7) + 1) * xcd_per(nchunks); return e < nchunks ? e : nchunks; }
+__device__ __forceinline__ int xcd_stride(int mode) { return mode ? int(gridDim.x >> 3) : int(gridDim.x); }
+int xcd_mode();     // host: OPMGPU_XCD env (default chosen by measurement)
 
 // ---- wave64 / workgroup reductions (double accumulators; deterministic order) ----
 __device__ __forceinline__ double wave_sum(double v)

@@ -13,9 +13,16 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace opmgpu {
+
+int xcd_mode()
+{
+    static const int m = [] { const char* e = std::getenv("OPMGPU_XCD"); return e ? std::atoi(e) : 1; }();
+    return m;
+}
 
 constexpr int kMaxPart = 1024;      // workgroups (= partials) of every reducing kernel
 
@@ -50,7 +57,7 @@ __device__ __forceinline__ void reduce_partials(const double* const (&arr)[NV], 
 // chunks so that a reducing launch has at most kMaxPart workgroups.  mask (multi-GPU): rows that are
 // not owned produce 0.
 template <class S, int NDOT>
-__global__ __launch_bounds__(kBlock) void k_spmv(int nb, int nbp, const int32_t* __restrict__ slice_ptr,
+__global__ __launch_bounds__(kBlock) void k_spmv(int xm, int nb, int nbp, const int32_t* __restrict__ slice_ptr,
                                                  const int32_t* __restrict__ col, const S* __restrict__ val,
                                                  const S* __restrict__ x, S* __restrict__ y,
                                                  const S* __restrict__ w1, const int8_t* __restrict__ mask,
@@ -60,7 +67,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(int nb, int nbp, const int32_t*
     if (ctl && ctl->done) return;
     double acc[2] = { 0.0, 0.0 };
     const int nchunks = (nb + kBlock - 1) / kBlock;
-    for (int ch = xcd_first(nchunks); ch < xcd_end(nchunks); ch += gridDim.x >> 3) {
+    for (int ch = xcd_first(nchunks, xm); ch < xcd_end(nchunks, xm); ch += xcd_stride(xm)) {
         const int row = ch * kBlock + threadIdx.x;
         if (row >= nb) continue;
         const int sl = row >> 6, lane = row & 63;
@@ -96,15 +103,15 @@ __global__ __launch_bounds__(kBlock) void k_spmv(int nb, int nbp, const int32_t*
 // top level the pivot inverse is applied at once (no upper entries there).
 // ParallelOverlappingILU0::apply, lower part; the relaxation factor w is folded in (the sweeps are linear).
 template <class S>
-__global__ __launch_bounds__(kBlock) void k_ilu_lower(int lo, int hi, int n0, int nbp, int top, S w, const int32_t* __restrict__ slice_ptr,
+__global__ __launch_bounds__(kBlock) void k_ilu_lower(int xm, int lo, int hi, int n0, int nbp, int top, S w, const int32_t* __restrict__ slice_ptr,
                                                       const int32_t* __restrict__ col, const int16_t* __restrict__ nlower,
                                                       const S* __restrict__ lu, const S* __restrict__ d, S* __restrict__ v,
                                                       const SolveCtl* __restrict__ ctl)
 {
     if (ctl && ctl->done) return;
     const int nchunks = (hi - lo + kBlock - 1) / kBlock;
-    const int ch = xcd_first(nchunks);
-    if (ch >= xcd_end(nchunks)) return;
+    const int ch = xcd_first(nchunks, xm);
+    if (ch >= xcd_end(nchunks, xm)) return;
     const int row = lo + ch * kBlock + threadIdx.x;
     if (row >= hi) return;
     const int base = slice_ptr[row >> 6], lane = row & 63, nl = nlower[row];
@@ -133,15 +140,15 @@ __global__ __launch_bounds__(kBlock) void k_ilu_lower(int lo, int hi, int n0, in
 
 // backward sweep of one level: v_i = Dinv_i (y_i - sum_{j upper} U_ij v_j), y_i = w d_i on level 0
 template <class S>
-__global__ __launch_bounds__(kBlock) void k_ilu_upper(int lo, int hi, int n0, int nbp, S w, const int32_t* __restrict__ slice_ptr,
+__global__ __launch_bounds__(kBlock) void k_ilu_upper(int xm, int lo, int hi, int n0, int nbp, S w, const int32_t* __restrict__ slice_ptr,
                                                       const int32_t* __restrict__ col, const int16_t* __restrict__ nlower,
                                                       const int16_t* __restrict__ rowlen, const S* __restrict__ lu,
                                                       const S* __restrict__ d, S* __restrict__ v, const SolveCtl* __restrict__ ctl)
 {
     if (ctl && ctl->done) return;
     const int nchunks = (hi - lo + kBlock - 1) / kBlock;
-    const int ch = xcd_first(nchunks);
-    if (ch >= xcd_end(nchunks)) return;
+    const int ch = xcd_first(nchunks, xm);
+    if (ch >= xcd_end(nchunks, xm)) return;
     const int row = lo + ch * kBlock + threadIdx.x;
     if (row >= hi) return;
     const int base = slice_ptr[row >> 6], lane = row & 63, nl = nlower[row], len = rowlen[row];
@@ -559,20 +566,20 @@ template <class S> void LinSolver::ilu_apply(const S* d, S* v, double relax, con
     const int L = plan.nlevels;
     const int n0 = plan.level_ptr[1];
     if (L == 1) {
-        hipLaunchKernelGGL((k_ilu_lower<S>), dim3(grid8_for(n0)), dim3(kBlock), 0, stream, 0, n0, 0, plan.nbp, 1, S(relax),
+        hipLaunchKernelGGL((k_ilu_lower<S>), dim3(grid8_for(n0)), dim3(kBlock), 0, stream, xcd_mode(), 0, n0, 0, plan.nbp, 1, S(relax),
                            dp.slice_ptr.p, dp.col.p, dp.nlower.p, w.LU.p, d, v, ctl);
         return;
     }
     for (int l = 1; l < L; ++l) {
         const int lo = plan.level_ptr[l], hi = plan.level_ptr[l + 1];
         if (hi == lo) continue;
-        hipLaunchKernelGGL((k_ilu_lower<S>), dim3(grid8_for(hi - lo)), dim3(kBlock), 0, stream, lo, hi, n0, plan.nbp, int(l == L - 1), S(relax),
+        hipLaunchKernelGGL((k_ilu_lower<S>), dim3(grid8_for(hi - lo)), dim3(kBlock), 0, stream, xcd_mode(), lo, hi, n0, plan.nbp, int(l == L - 1), S(relax),
                            dp.slice_ptr.p, dp.col.p, dp.nlower.p, w.LU.p, d, v, ctl);
     }
     for (int l = L - 2; l >= 0; --l) {
         const int lo = plan.level_ptr[l], hi = plan.level_ptr[l + 1];
         if (hi == lo) continue;
-        hipLaunchKernelGGL((k_ilu_upper<S>), dim3(grid8_for(hi - lo)), dim3(kBlock), 0, stream, lo, hi, n0, plan.nbp, S(relax), dp.slice_ptr.p, dp.col.p,
+        hipLaunchKernelGGL((k_ilu_upper<S>), dim3(grid8_for(hi - lo)), dim3(kBlock), 0, stream, xcd_mode(), lo, hi, n0, plan.nbp, S(relax), dp.slice_ptr.p, dp.col.p,
                            dp.nlower.p, dp.rowlen.p, w.LU.p, d, v, ctl);
     }
 }
@@ -580,7 +587,7 @@ template <class S> void LinSolver::ilu_apply(const S* d, S* v, double relax, con
 template <class S> void LinSolver::spmv(const S* x, S* y)
 {
     const int g = std::min(grid8_for(plan.nb), 4 * kMaxPart);
-    hipLaunchKernelGGL((k_spmv<S, 0>), dim3(g), dim3(kBlock), 0, stream, plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p,
+    hipLaunchKernelGGL((k_spmv<S, 0>), dim3(g), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p,
                        matrix<S>(), x, y, (const S*)nullptr, comm ? comm->owner_mask() : (const int8_t*)nullptr, (const SolveCtl*)nullptr,
                        (double*)nullptr, (double*)nullptr);
 }
@@ -626,7 +633,7 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
                            w.r.p, w.v.p, w.p.p);
         ilu_apply<S>(w.p.p, w.y.p, prm.ilu_relaxation, d_ctl);
         if (comm) halo<S>(comm, w.y.p, stream);
-        hipLaunchKernelGGL((k_spmv<S, 1>), dim3(gs), dim3(kBlock), 0, stream, plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p, matrix<S>(),
+        hipLaunchKernelGGL((k_spmv<S, 1>), dim3(gs), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p, matrix<S>(),
                            w.y.p, w.v.p, w.rt.p, mask, (const SolveCtl*)d_ctl, P_h, (double*)nullptr);
         double* a_h = P_h; int np_h = gs; none = nullptr;
         bridge(a_h, none, np_h, 1);
@@ -636,7 +643,7 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
         bridge(a_n1, none, np_n1, 2);
         ilu_apply<S>(w.r.p, w.y.p, prm.ilu_relaxation, d_ctl);
         if (comm) halo<S>(comm, w.y.p, stream);
-        hipLaunchKernelGGL((k_spmv<S, 2>), dim3(gs), dim3(kBlock), 0, stream, plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p, matrix<S>(),
+        hipLaunchKernelGGL((k_spmv<S, 2>), dim3(gs), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p, matrix<S>(),
                            w.y.p, w.t.p, w.r.p, mask, (const SolveCtl*)d_ctl, P_tr, P_tt);
         double* a_tr = P_tr; double* a_tt = P_tt; int np_t = gs;
         bridge(a_tr, a_tt, np_t, 3);
