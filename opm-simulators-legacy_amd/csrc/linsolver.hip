@@ -56,19 +56,38 @@ __device__ __forceinline__ void reduce_partials(const double* const (&arr)[NV], 
 // MatrixAdapter::apply + the scalar products of BiCGSTABSolver::apply.  Grid-stride over 256-row
 // chunks so that a reducing launch has at most kMaxPart workgroups.  mask (multi-GPU): rows that are
 // not owned produce 0.
+//
+// pin != nullptr (single GPU, x = M^-1 pin with the ILU0 of THIS matrix): for the n0 level-0 rows the
+// product is known in closed form.  Such a row has no lower entries, so U_ij = A_ij and Dinv_i = A_ii^-1, and
+//   x_i = A_ii^-1 (w pin_i - sum_j A_ij x_j)   =>   (A x)_i = A_ii x_i + sum_j A_ij x_j = w pin_i .
+// Those rows (half of all rows with the 2-colour ordering) need no matrix traffic.  Light and heavy rows
+// are chunked separately so that every XCD gets the same share of both.
 template <class S, int NDOT>
 __global__ __launch_bounds__(kBlock) void k_spmv(int xm, int nb, int nbp, const int32_t* __restrict__ slice_ptr,
                                                  const int32_t* __restrict__ col, const S* __restrict__ val,
                                                  const S* __restrict__ x, S* __restrict__ y,
                                                  const S* __restrict__ w1, const int8_t* __restrict__ mask,
-                                                 const SolveCtl* __restrict__ ctl, double* __restrict__ p0, double* __restrict__ p1)
+                                                 const SolveCtl* __restrict__ ctl, double* __restrict__ p0, double* __restrict__ p1,
+                                                 const S* __restrict__ pin, int n0, S w)
 {
     __shared__ double sm[8];
     if (ctl && ctl->done) return;
     double acc[2] = { 0.0, 0.0 };
-    const int nchunks = (nb + kBlock - 1) / kBlock;
+    const int nlight = pin ? n0 : 0;
+    {
+        const int nchunks = (nlight + kBlock - 1) / kBlock;
+        for (int ch = xcd_first(nchunks, xm); ch < xcd_end(nchunks, xm); ch += xcd_stride(xm)) {
+            const int row = ch * kBlock + threadIdx.x;
+            if (row >= nlight) continue;
+            const S y0 = w * pin[row], y1 = w * pin[nbp + row], y2 = w * pin[2 * nbp + row];
+            y[row] = y0; y[nbp + row] = y1; y[2 * nbp + row] = y2;
+            if (NDOT >= 1) acc[0] += double(w1[row]) * double(y0) + double(w1[nbp + row]) * double(y1) + double(w1[2 * nbp + row]) * double(y2);
+            if (NDOT == 2) acc[1] += double(y0) * double(y0) + double(y1) * double(y1) + double(y2) * double(y2);
+        }
+    }
+    const int nchunks = (nb - nlight + kBlock - 1) / kBlock;
     for (int ch = xcd_first(nchunks, xm); ch < xcd_end(nchunks, xm); ch += xcd_stride(xm)) {
-        const int row = ch * kBlock + threadIdx.x;
+        const int row = nlight + ch * kBlock + threadIdx.x;
         if (row >= nb) continue;
         const int sl = row >> 6, lane = row & 63;
         const int base = slice_ptr[sl], width = slice_ptr[sl + 1] - base;
@@ -482,6 +501,7 @@ LinSolver::LinSolver(hipStream_t s) : stream(s)
     OPMGPU_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_flags), 4 * sizeof(int32_t)));
     OPMGPU_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
     OPMGPU_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    if (const char* e = std::getenv("OPMGPU_CLOSED")) closed_form_level0 = std::atoi(e) != 0;
 }
 LinSolver::~LinSolver()
 {
@@ -589,7 +609,7 @@ template <class S> void LinSolver::spmv(const S* x, S* y)
     const int g = std::min(grid8_for(plan.nb), 4 * kMaxPart);
     hipLaunchKernelGGL((k_spmv<S, 0>), dim3(g), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p,
                        matrix<S>(), x, y, (const S*)nullptr, comm ? comm->owner_mask() : (const int8_t*)nullptr, (const SolveCtl*)nullptr,
-                       (double*)nullptr, (double*)nullptr);
+                       (double*)nullptr, (double*)nullptr, (const S*)nullptr, 0, S(0));
 }
 
 template <class S> static void halo(CommBase* c, S* v, hipStream_t s);
@@ -606,6 +626,11 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
     const double eps = sizeof(S) == 8 ? 1e-80 : 0.0;           // dune: real_type EPSILON = 1e-80 (0 in float)
     const int maxit = prm.linear_solver_maxiter;
     const int8_t* mask = comm ? comm->owner_mask() : nullptr;
+    // closed form of (A M^-1 p) on the level-0 rows -- valid when M is the ILU0 of exactly this matrix and the ghost
+    // entries of M^-1 p are not overwritten by a halo exchange, i.e. single GPU
+    const bool closed = !comm && closed_form_level0;
+    const S* pin_p = closed ? w.p.p : nullptr; const S* pin_r = closed ? w.r.p : nullptr;
+    const int n0 = plan.level_ptr[1];
     double* P_h = partials.p, *P_n1 = P_h + npart, *P_tr = P_n1 + npart, *P_tt = P_tr + npart, *P_n2 = P_tt + npart, *P_rho = P_n2 + npart;
     double* red = P_rho + npart;                               // 8 all-reduced scalars (multi-GPU)
     // (multi-GPU) collapse partial arrays of np entries into red[slot..] and all-reduce them; consumers then read 1 entry
@@ -634,7 +659,7 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
         ilu_apply<S>(w.p.p, w.y.p, prm.ilu_relaxation, d_ctl);
         if (comm) halo<S>(comm, w.y.p, stream);
         hipLaunchKernelGGL((k_spmv<S, 1>), dim3(gs), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p, matrix<S>(),
-                           w.y.p, w.v.p, w.rt.p, mask, (const SolveCtl*)d_ctl, P_h, (double*)nullptr);
+                           w.y.p, w.v.p, w.rt.p, mask, (const SolveCtl*)d_ctl, P_h, (double*)nullptr, pin_p, n0, S(prm.ilu_relaxation));
         double* a_h = P_h; int np_h = gs; none = nullptr;
         bridge(a_h, none, np_h, 1);
         hipLaunchKernelGGL((k_update_xr1<S>), dim3(gv), dim3(kBlock), 0, stream, n, j, eps, d_ctl, h_ctl_dev, (const double*)a_h, np_h, w.y.p, w.v.p,
@@ -644,7 +669,7 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
         ilu_apply<S>(w.r.p, w.y.p, prm.ilu_relaxation, d_ctl);
         if (comm) halo<S>(comm, w.y.p, stream);
         hipLaunchKernelGGL((k_spmv<S, 2>), dim3(gs), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p, matrix<S>(),
-                           w.y.p, w.t.p, w.r.p, mask, (const SolveCtl*)d_ctl, P_tr, P_tt);
+                           w.y.p, w.t.p, w.r.p, mask, (const SolveCtl*)d_ctl, P_tr, P_tt, pin_r, n0, S(prm.ilu_relaxation));
         double* a_tr = P_tr; double* a_tt = P_tt; int np_t = gs;
         bridge(a_tr, a_tt, np_t, 3);
         hipLaunchKernelGGL((k_update_xr2<S>), dim3(gv), dim3(kBlock), 0, stream, n, j, d_ctl, h_ctl_dev, (const double*)a_n1, (const double*)a_tr,

@@ -109,6 +109,7 @@ public:
     int cur_ordering = -1;
     int npart = 0;                 // entries per partial array
     CommBase* comm = nullptr;      // not owned; nullptr = single GPU
+    bool closed_form_level0 = true; // k_spmv shortcut on level-0 rows (A/B switch: OPMGPU_CLOSED=0)
     hipEvent_t ev[2] = { nullptr, nullptr };
 
 private:
