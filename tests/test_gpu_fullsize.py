@@ -1,0 +1,122 @@
+"""BASELINE.json configurations at FULL size on the GPU, checked through size-independent properties
+(the oracle is too slow to be the checker at 1 M cells), plus the SPE9-like case against the oracle."""
+import numpy as np
+import pytest
+
+from opmgpu import capi, decks
+from opmgpu.model import GpuBlackoilModel, GpuNewtonIteration
+from util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cart100_full_size_properties(gpu_lib):
+    """configs[2]: synthetic 100x100x100, 1 M cells, 6.94 M blocks."""
+    grid = decks.cartesian_grid(100, 100, 100, lognormal_sigma=0.5, seed=12345)
+    tab = decks.satfunc_standard_tables()
+    st = decks.initial_state(grid, tab, perturb=0.002, seed=12345)
+    prm = capi.default_params()
+    nc = grid.nc
+    m = GpuBlackoilModel(grid, tab, prm)
+    pos, lev, nlev = m.ordering()
+    assert nlev == 2 and np.bincount(lev).tolist() == [500000, 500000]          # red-black on the 7-point grid
+    dt = 5 * decks.DAY
+    m.prepareStep(dt, st)
+    m.assemble(True)
+    r = m.residual()
+    # mass conservation of the flux part: with accum1 == accum0 every interior flux enters two rows with opposite signs
+    for a in range(3):
+        ra = r[a * nc:(a + 1) * nc]
+        assert abs(ra.sum()) <= 1e-9 * np.abs(ra).sum()
+    conv = m.getConvergence()
+    assert not conv and np.all(np.isfinite(m.CNV)) and np.all(m.MB < 1e-12)
+    # solve, then verify the TRUE residual of the returned increment with an independent SpMV on the same matrix
+    rowptr, col, val = m.jacobian()
+    assert col.size == 6940000
+    scale = np.asarray(prm.matbalscale[:])
+    for single in (True, False):
+        dx = m.solveJacobianSystem(want_dx=True, single_precision=single)
+        assert 1 <= m.linear_iterations <= 150 and m.linear_reduction < 1e-2
+        s = GpuNewtonIteration(prm)
+        s.load(rowptr, col, val, False)
+        x3 = np.ascontiguousarray(dx.reshape(3, nc).T).ravel()
+        b3 = np.ascontiguousarray((r * np.repeat(scale, nc)).reshape(3, nc).T).ravel()
+        ax = s.spmv(x3)
+        assert np.linalg.norm(ax - b3) <= 1.5e-2 * np.linalg.norm(b3)              # linear_solver_reduction = 1e-2
+        if not single:
+            # linearity of the SpMV at full size and determinism of the whole solve (bitwise repeatable)
+            rng = np.random.default_rng(0)
+            z3 = rng.standard_normal(3 * nc)
+            assert rel_err(s.spmv(2.0 * x3 - 0.5 * z3), 2.0 * ax - 0.5 * s.spmv(z3)) < 1e-12
+            dx2 = m.solveJacobianSystem(want_dx=True, single_precision=False)
+            assert np.array_equal(dx, dx2)
+        s.close()
+    # update with a zero increment is the identity on pressures/saturations; a real update keeps the invariants
+    before = m.getState()
+    m.updateState(np.zeros(3 * nc))
+    same = m.getState()
+    assert np.array_equal(before.p, same.p) and np.array_equal(before.sat, same.sat)
+    m.updateState(dx)
+    after = m.getState()
+    assert np.all(after.p > 0) and np.all(after.sat >= 0) and np.all(after.sat <= 1 + 1e-12)
+    assert np.abs(after.sat.sum(1) - 1).max() < 1e-12 or np.all(after.sat.sum(1) <= 1 + 1e-9)
+    assert np.all(np.abs(after.p - before.p) <= 0.3 * np.abs(before.p) * (1 + 1e-12))
+    m.close()
+
+
+def test_spe9_like_with_well_cliques(gpu_lib, oracle):
+    """configs[1]-like: 24x25x15 = 9000 cells, 26 wells (pattern = stencil U per-well cliques), vs the oracle."""
+    grid = decks.cartesian_grid(24, 25, 15, dx=91.44, dy=91.44, dz=6.0, tops=2743.0, lognormal_sigma=1.0, seed=9)
+    tab = decks.satfunc_standard_tables()
+    st = decks.initial_state(grid, tab, p_ref=248.0 * decks.BAR, z_ref=2743.0, perturb=0.005, seed=9)
+    rng = np.random.default_rng(9)
+    cols = rng.choice(24 * 25, 26, replace=False)
+    connpos, cells = [0], []
+    for w, c in enumerate(cols):
+        layers = range(10, 15) if w == 0 else range(1, 4)            # injector completed low, producers in layers 2-4
+        cells += [int(c + 600 * k) for k in layers]
+        connpos.append(len(cells))
+    wells = (np.asarray(connpos, np.int32), np.asarray(cells, np.int32))
+    prm = capi.default_params(linear_solver_reduction=1e-10, linear_solver_maxiter=500)
+    m = GpuBlackoilModel(grid, tab, prm, wells=wells)
+    dt = 10 * decks.DAY
+    m.prepareStep(dt, st)
+    m.assemble(True)
+    rowptr, col = oracle.pattern(grid, *wells)
+    scale = tuple(prm.matbalscale)
+    r0, v0, _, _ = oracle.assemble(grid, tab, dt, st, rowptr, col, scale=scale)
+    gr, gc, gv = m.jacobian()
+    assert np.array_equal(gr, rowptr) and np.array_equal(gc, col)
+    assert col.size > 9000 + 2 * grid.nconn                         # clique fill is part of the pattern
+    assert rel_err(gv, v0) < 1e-11 and rel_err(m.residual(), r0) < 1e-11
+    # a synthetic Schur complement on the cliques, then the solve against the oracle on the modified system
+    rc, blocks = [], []
+    for w in range(26):
+        cw = cells[connpos[w]:connpos[w + 1]]
+        for a in cw:
+            for b in cw:
+                rc.append((a, b)); blocks.append(np.eye(3).ravel() * (1e-9 if a == b else -1e-10) * np.array([1, 1e5, 1e5, 1, 1e5, 1e5, 1, 1e5, 1e5]))
+    rc, blocks = np.asarray(rc, np.int32), np.asarray(blocks)
+    delta = rng.standard_normal((len(cells), 3)) * 1e-6
+    m.addWellTerms(delta, rc, blocks)
+    nc = grid.nc
+    r1 = r0.copy()
+    for i, c in enumerate(cells):
+        for a in range(3):
+            r1[a * nc + c] += delta[i, a]
+    v1 = v0.copy()
+    sc = np.repeat(np.asarray(scale), 3)
+    for k, (a, b) in enumerate(rc):
+        s = rowptr[a] + np.searchsorted(col[rowptr[a]:rowptr[a + 1]], b)
+        v1[s] += blocks[k] * sc
+    assert rel_err(m.jacobian()[2], v1) < 1e-11 and rel_err(m.residual(), r1) < 1e-11
+    dx = m.solveJacobianSystem(want_dx=True, single_precision=False)
+    pos = m.ordering()[0]
+    b3 = np.ascontiguousarray((r1 * np.repeat(np.asarray(scale), nc)).reshape(3, nc).T).ravel()
+    sto, x, ito, redo, _ = oracle.bicgstab(rowptr, col, v1, b3, prm, position=pos)
+    assert sto == 0 and abs(ito - m.linear_iterations) <= 2
+    dxo = np.ascontiguousarray(x.reshape(nc, 3).T).ravel()
+    for a in range(3):
+        blk = slice(a * nc, (a + 1) * nc)
+        assert np.abs(dx[blk] - dxo[blk]).max() <= 1e-6 * np.abs(dxo[blk]).max()
+    m.close()
