@@ -161,6 +161,15 @@ int opmgpu_perf_props(opmgpu_ctx* ctx, double* out);
 int opmgpu_add_well_terms(opmgpu_ctx* ctx, const double* resid_delta, int nblk,
                           const int32_t* schur_rc, const double* schur_blocks);
 
+/* Right-hand-side part of the Schur elimination: -B D^-1 r_well per perforation (UNSCALED, phase fastest).  Unlike
+ * resid_delta above it must NOT enter the convergence check (the reference eliminates on a copy inside the linear
+ * solver, NewtonIterationBlackoilInterleaved.cpp:221-231), so it is kept apart and only added when the RHS is built.
+ * Cleared by every opmgpu_assemble. */
+int opmgpu_add_well_rhs(opmgpu_ctx* ctx, const double* rhs_delta /*nperf*3*/);
+/* Newton increment of the perforated cells after opmgpu_solve (for recoverVariable, NewtonIterationUtilities.cpp:134-184):
+ * out[nperf*3] = dP, dSw, dXvar per perforation. */
+int opmgpu_perf_dx(opmgpu_ctx* ctx, double* out);
+
 /* getConvergence / convergenceReduction (BlackoilModelBase_impl.hpp:1633-1857) for the reservoir
  * equations: B_avg, CNV, MB per phase plus the L-inf residual norms of computeResidualNorms
  * (:1551-1589).  *converged = all MB < tol_mb && all CNV < tol_cnv.  Returns OPMGPU_ENUMERICAL

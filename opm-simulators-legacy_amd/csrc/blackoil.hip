@@ -503,11 +503,22 @@ __global__ __launch_bounds__(kBlock) void k_update_state(int nb, int nbp, opmgpu
 
 // b = matbalscale * R in the solver's precision (NewtonIterationBlackoilInterleaved.cpp:234-236, 263-269)
 template <class S>
-__global__ __launch_bounds__(kBlock) void k_build_rhs(int nb, int nbp, double s0, double s1, double s2, const double* __restrict__ R, S* __restrict__ b)
+__global__ __launch_bounds__(kBlock) void k_build_rhs(int nb, int nbp, double s0, double s1, double s2, const double* __restrict__ R,
+                                                      const double* __restrict__ extra, S* __restrict__ b)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= nb) return;
-    b[i] = S(s0 * R[i]); b[nbp + i] = S(s1 * R[nbp + i]); b[2 * long(nbp) + i] = S(s2 * R[2 * long(nbp) + i]);
+    const long i1 = nbp + i, i2 = 2 * long(nbp) + i;
+    double r0 = R[i], r1 = R[i1], r2 = R[i2];
+    if (extra) { r0 += extra[i]; r1 += extra[i1]; r2 += extra[i2]; }
+    b[i] = S(s0 * r0); b[i1] = S(s1 * r1); b[i2] = S(s2 * r2);
+}
+__global__ __launch_bounds__(kBlock) void k_gather_perf3(int nperf, int nbp, const int32_t* __restrict__ cells, const double* __restrict__ v, double* __restrict__ out)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nperf) return;
+    const int c = cells[i];
+    out[3 * long(i)] = v[c]; out[3 * long(i) + 1] = v[nbp + c]; out[3 * long(i) + 2] = v[2 * long(nbp) + c];
 }
 
 // per-perforation properties for the host well model (extractWellPerfProperties)
@@ -713,6 +724,7 @@ void BlackoilDevice::assemble(double dt, bool initial)
 {
     const Plan& P = ls.plan;
     last_dt = dt;
+    has_rhs_extra = false;
     const double* sc = prm.matbalscale;
     hipLaunchKernelGGL(k_cell_props, dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_pv.p,
                        d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, 1.0 / dt, int(initial), sc[0], sc[1], sc[2],
@@ -832,11 +844,32 @@ void launch_convert_f2d(long n, const float* a, double* b, hipStream_t s)
     hipLaunchKernelGGL(k_f2d, dim3(std::min(grid_for(n), kMaxRedBlocks)), dim3(kBlock), 0, s, n, a, b);
 }
 
+void BlackoilDevice::add_well_rhs(const double* rhs_delta)
+{
+    if (nperf == 0) return;
+    const Plan& P = ls.plan;
+    d_rhs_extra.alloc(3 * size_t(P.nbp));
+    d_rhs_extra.zero(stream);
+    DevArray<double> dd; dd.upload(rhs_delta, 3 * size_t(nperf), stream);
+    hipLaunchKernelGGL(k_add_well_resid, dim3(grid_for(nperf)), dim3(kBlock), 0, stream, nperf, P.nbp, d_perf_cells.p, dd.p, d_rhs_extra.p);
+    OPMGPU_HIP(hipStreamSynchronize(stream));
+    has_rhs_extra = true;
+}
+
+void BlackoilDevice::perf_dx(double* out)
+{
+    if (nperf == 0) return;
+    hipLaunchKernelGGL(k_gather_perf3, dim3(grid_for(nperf)), dim3(kBlock), 0, stream, nperf, ls.plan.nbp, d_perf_cells.p, d_dx.p, d_perf.p);
+    OPMGPU_HIP(hipMemcpyAsync(out, d_perf.p, size_t(nperf) * 3 * sizeof(double), hipMemcpyDeviceToHost, stream));
+    OPMGPU_HIP(hipStreamSynchronize(stream));
+}
+
 template <class S> void BlackoilDevice::build_rhs()
 {
     const Plan& P = ls.plan;
     const double* sc = prm.matbalscale;
-    hipLaunchKernelGGL((k_build_rhs<S>), dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, P.nbp, sc[0], sc[1], sc[2], d_R.p, ls.work<S>().b.p);
+    hipLaunchKernelGGL((k_build_rhs<S>), dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, P.nbp, sc[0], sc[1], sc[2], d_R.p,
+                       has_rhs_extra ? d_rhs_extra.p : (const double*)nullptr, ls.work<S>().b.p);
 }
 template <class S> void BlackoilDevice::store_dx()
 {

@@ -33,6 +33,8 @@ public:
     int convergence(double dt, double* B3, double* CNV3, double* MB3, double* linf3, int* converged);
     void perf_props(double* out);
     int add_well_terms(const double* resid_delta, int nblk, const int32_t* rc, const double* blocks);
+    void add_well_rhs(const double* rhs_delta);
+    void perf_dx(double* out);
     // right-hand side of the scaled system into the solver's b vector (precision S)
     template <class S> void build_rhs();
     template <class S> void store_dx();                 // solver x -> resident dx (double, internal planes)
@@ -46,7 +48,7 @@ public:
     int nc = 0, nconn = 0;
     opmgpu_params prm;
     double last_dt = 0.0;
-    bool has_state = false, has_dx = false;
+    bool has_state = false, has_dx = false, has_rhs_extra = false;
     int nperf = 0;
 
 private:
@@ -71,7 +73,7 @@ private:
     DevArray<double> d_p, d_sw, d_so, d_sg, d_rs, d_rv;
     DevArray<int8_t> d_hc;
     // device: work
-    DevArray<double> d_props, d_accum0, d_R, d_binv, d_dx, d_red, d_perf;
+    DevArray<double> d_props, d_accum0, d_R, d_binv, d_dx, d_red, d_perf, d_rhs_extra;
     double* h_red = nullptr;
     std::vector<double> hbuf;
     std::vector<int8_t> hbuf8;

@@ -183,6 +183,17 @@ int opmgpu_add_well_terms(opmgpu_ctx* c, const double* resid_delta, int nblk, co
     return guarded(c, [&]() { c->factored = false; c->cur_single = -1; return c->model->add_well_terms(resid_delta, nblk, schur_rc, schur_blocks); });
 }
 
+int opmgpu_add_well_rhs(opmgpu_ctx* c, const double* rhs_delta)
+{
+    if (!c || !c->model || !rhs_delta) return OPMGPU_EINVAL;
+    return guarded(c, [&]() { c->model->add_well_rhs(rhs_delta); return OPMGPU_OK; });
+}
+int opmgpu_perf_dx(opmgpu_ctx* c, double* out)
+{
+    if (!c || !c->model || !out || !c->model->has_dx) return OPMGPU_EINVAL;
+    return guarded(c, [&]() { c->model->perf_dx(out); return OPMGPU_OK; });
+}
+
 int opmgpu_convergence(opmgpu_ctx* c, double dt, double* B_avg3, double* CNV3, double* MB3, double* linf3, int* converged)
 {
     if (!c || !c->model || !c->matrix_loaded) return OPMGPU_EINVAL;

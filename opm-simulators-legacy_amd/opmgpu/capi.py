@@ -103,6 +103,8 @@ SIGNATURES = {
     "opmgpu_assemble": (C.c_int, [C.c_void_p, C.c_double, C.c_int, _dp, _dp, _dp, _dp, _bp]),
     "opmgpu_perf_props": (C.c_int, [C.c_void_p, _dp]),
     "opmgpu_add_well_terms": (C.c_int, [C.c_void_p, _dp, C.c_int, _ip, _dp]),
+    "opmgpu_add_well_rhs": (C.c_int, [C.c_void_p, _dp]),
+    "opmgpu_perf_dx": (C.c_int, [C.c_void_p, _dp]),
     "opmgpu_convergence": (C.c_int, [C.c_void_p, C.c_double, _dp, _dp, _dp, _dp, C.POINTER(C.c_int)]),
     "opmgpu_solve": (C.c_int, [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int), _dp]),
     "opmgpu_update_state": (C.c_int, [C.c_void_p, _dp, C.c_double]),

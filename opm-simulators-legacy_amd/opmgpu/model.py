@@ -233,6 +233,14 @@ class GpuBlackoilModel:
         nblk = rc.size // 2
         self._chk(self.lib.opmgpu_add_well_terms(self.ctx, capi.dptr(capi.f64(resid_delta)), nblk, capi.iptr(rc), capi.dptr(capi.f64(blocks))))
 
+    def addWellRhs(self, rhs_delta):
+        self._chk(self.lib.opmgpu_add_well_rhs(self.ctx, capi.dptr(capi.f64(rhs_delta))))
+
+    def perfDx(self, nperf):
+        out = np.zeros((nperf, 3))
+        self._chk(self.lib.opmgpu_perf_dx(self.ctx, capi.dptr(out)))
+        return out
+
     def timings(self):
         a, s, u = C.c_double(0), C.c_double(0), C.c_double(0)
         self.lib.opmgpu_last_timings(self.ctx, C.byref(a), C.byref(s), C.byref(u))

@@ -1,0 +1,113 @@
+"""Host-side standard well model: the reference's known answer for the segmented wellbore density, a
+finite-difference check of the well Jacobians, and a well-driven Newton loop on the SPE1-like deck
+(BASELINE configs[0]: 10x10x3 = 300 cells, 2 wells) entirely on the CPU through the oracle backend."""
+import json
+import os
+
+import numpy as np
+
+from opmgpu import capi, decks, wells as W
+from util import OracleBackend
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_welldensitysegmented_known_answer():
+    g = json.load(open(os.path.join(GOLD, "welldensitysegmented.json")))
+    wells = W.Wells()
+    wells.add_well("INJ", W.INJECTOR, g["ref_depth"], g["cells"], 1.0, g["comp_frac_inj"], (W.BHP, 0.0))
+    wells.add_well("PROD", W.PRODUCER, g["ref_depth"], g["cells"], 1.0, g["comp_frac_prod"], (W.BHP, 0.0))
+    n = 10
+    rates = np.asarray(g["perf_rates"]).reshape(n, 3)
+    b = np.asarray(g["b_perf"]).reshape(n, 3)
+    cd = W.connection_densities(wells, rates, b, np.asarray(g["rsmax_perf"]), np.asarray(g["rvmax_perf"]), np.asarray(g["surf_dens"]).reshape(n, 3))
+    dp = W.connection_pressure_delta(wells, np.asarray(g["z_perf"]), cd, g["gravity"])
+    ans = np.asarray(g["answer_over_gravity"]) * g["gravity"]
+    assert np.allclose(dp, ans, rtol=1e-10)            # BOOST_CHECK_CLOSE(..., 1e-8) percent
+
+
+def _setup(nx=10, ny=10, nz=3):
+    grid = decks.cartesian_grid(nx, ny, nz, dx=300.0, dy=300.0, dz=10.0, tops=2500.0, poro=0.3, permx_md=200.0, lognormal_sigma=0.3)
+    tab = decks.satfunc_standard_tables()
+    st = decks.initial_state(grid, tab, p_ref=250 * decks.BAR, z_ref=2500.0, gas_cap_fraction=0.0, gas_only_fraction=0.0)
+    col = lambda i, j: [i + nx * j + nx * ny * k for k in range(nz)]
+    wl = W.Wells()
+    WI = 5.0 * float(np.median(grid.trans))
+    wl.add_well("INJ", W.INJECTOR, grid.z[col(0, 0)[0]], col(0, 0), WI, (1.0, 0.0, 0.0), (W.SURFACE_RATE, 2000.0 / 86400.0, (1.0, 0.0, 0.0)))
+    wl.add_well("PROD", W.PRODUCER, grid.z[col(nx - 1, ny - 1)[0]], col(nx - 1, ny - 1)[:2], WI, (0.0, 1.0, 0.0), (W.BHP, 200 * decks.BAR))
+    return grid, tab, st, wl
+
+
+def test_well_jacobian_finite_differences(oracle):
+    grid, tab, st, wl = _setup()
+    prm = capi.default_params()
+    be = OracleBackend(oracle, grid, tab, prm, wells=wl.arrays())
+    be.prepareStep(decks.DAY, st); be.assemble(True)
+    pp = be.perfProps(wl.nperf).reshape(wl.nperf, 9, 4)
+    wh = W.StandardWellsHost(wl, grid.z, tab.surface_density[0])
+    ws = W.WellState(wl, st.p)
+    ws.qs[0] = [2000.0 / 86400.0, 0.0, 0.0]; ws.bhp[0] = 300 * decks.BAR          # injecting
+    wh.compute_connection_pressures(pp, ws)
+    rd, rc, blocks, rhs = wh.assemble(pp, ws.copy())
+    sys0 = [tuple(np.array(a) for a in s) for s in wh._sys]
+    E0 = np.concatenate([wh.flux_eq, wh.ctrl_eq[:, None]], 1)
+    # d E / d (q_s, bhp): perturb the well unknowns
+    for w in range(wl.nw):
+        D = np.linalg.inv(sys0[w][0])
+        for k in range(4):
+            h = 1e-7 * (abs(ws.qs[w, k]) + 1e-3) if k < 3 else 1.0
+            wp = ws.copy()
+            if k < 3:
+                wp.qs[w, k] += h
+            else:
+                wp.bhp[w] += h
+            wh.assemble(pp, wp)
+            E1 = np.concatenate([wh.flux_eq, wh.ctrl_eq[:, None]], 1)
+            fd = (E1[w] - E0[w]) / h
+            assert np.allclose(fd, D[:, k], rtol=2e-5, atol=1e-9 * np.abs(D).max()), (w, k, fd, D[:, k])
+    # d E / d cell variables: move perforation i's properties along their own d/dP, d/dSw, d/dXvar directions
+    for w in range(wl.nw):
+        lo = wl.connpos[w]
+        C = sys0[w][1]
+        for i in range(wl.connpos[w + 1] - lo):
+            for d in range(3):
+                t = [1e2, 1e-6, 1e-6][d]
+                pp1 = pp.copy()
+                pp1[lo + i, :, 0] += t * pp[lo + i, :, 1 + d]
+                wh.assemble(pp1, ws.copy())
+                E1 = np.concatenate([wh.flux_eq, wh.ctrl_eq[:, None]], 1)
+                fd = (E1[w] - E0[w]) / t
+                assert np.allclose(fd, C[:, 3 * i + d], rtol=5e-4, atol=1e-7 * np.abs(C[:, 3 * i + d]).max() + 1e-30), (w, i, d)
+
+
+def test_spe1_like_well_driven_newton_on_cpu(oracle):
+    """configs[0] plumbing: the 300-cell, 2-well case through the reference-shaped Newton loop on the CPU."""
+    grid, tab, st, wl = _setup()
+    prm = capi.default_params(ilu_ordering=capi.ORDER_NATURAL)
+    be = OracleBackend(oracle, grid, tab, prm, wells=wl.arrays())
+    wh = W.StandardWellsHost(wl, grid.z, tab.surface_density[0])
+    ws = W.WellState(wl, st.p)
+    model = W.WellCoupledModel(be, wh, ws)
+    dt = 2 * decks.DAY
+    water0 = None
+    model.prepareStep(dt, st)
+    for step in range(2):
+        it = 0
+        while True:
+            conv, lin = model.nonlinearIteration(it, single_precision=False)
+            it += 1
+            if conv and it >= 1:
+                break
+            assert it <= 12, "Newton did not converge"
+        # surface water volume in place, from the accumulation terms of the converged state
+        props = oracle.cell_props(grid, tab, be.st)
+        water = float((props[:, oracle.PROP_NAMES.index("accum_w"), 0] * grid.pv).sum())
+        if water0 is not None:
+            # implicit Euler mass balance of the water component: d(water in place) = dt * sum of the wells' water rates
+            inj = ws.qs[0, 0] * dt
+            net = ws.qs[:, 0].sum() * dt
+            assert abs((water - water0) - net) <= 1e-4 * inj, (water - water0, net)
+        water0 = water
+        assert abs(ws.qs[0, 0] - 2000.0 / 86400.0) <= 1e-9 and ws.qs[1, 1] < 0          # injects water at target, produces oil
+        assert abs(ws.bhp[1] - 200 * decks.BAR) < 1e-3
+        model.prepareStep(dt)

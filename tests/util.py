@@ -30,3 +30,77 @@ def random_block_matrix(rowptr, col, seed=1, dominance=6.0):
 
 def rel_err(a, b):
     return np.abs(np.asarray(a) - np.asarray(b)).max() / (np.abs(np.asarray(b)).max() + 1e-300)
+
+
+class OracleBackend:
+    """The GpuBlackoilModel interface on top of the CPU oracle (checker side of the well-coupled parity tests)."""
+
+    def __init__(self, orc, grid, tables, params, wells=None):
+        from opmgpu import capi
+        self.orc, self.grid, self.tab, self.prm = orc, grid, tables, params
+        self.scale = np.asarray(params.matbalscale[:])
+        self.wells = wells
+        self.rowptr, self.col = orc.pattern(grid, *(wells or (None, None)))
+        self.nc = grid.nc
+        self.position = None
+        self.linear_iterations = 0
+        self.capi = capi
+
+    def prepareStep(self, dt, state=None):
+        self.dt = float(dt)
+        if state is not None:
+            self.st = state.copy()
+        self.acc0 = None
+
+    def assemble(self, initial):
+        if initial:
+            self.acc0 = None
+        self.r, self.val, self.acc0, self.binv = self.orc.assemble(self.grid, self.tab, self.dt, self.st, self.rowptr, self.col,
+                                                                   scale=tuple(self.scale), accum0=self.acc0)
+        self.rhs_extra = np.zeros(3 * self.nc)
+
+    def perfProps(self, nperf):
+        props = self.orc.cell_props(self.grid, self.tab, self.st)[self.wells[1]]
+        names = self.orc.PROP_NAMES
+        idx = [names.index(n) for n in ["p_o", "rs", "rv", "b_w", "b_o", "b_g", "mob_w", "mob_o", "mob_g"]]
+        return props[:, idx, :].reshape(nperf, 36)
+
+    def addWellTerms(self, resid_delta, rc, blocks):
+        nc = self.nc
+        for i, c in enumerate(self.wells[1]):
+            for a in range(3):
+                self.r[a * nc + c] += resid_delta[i, a]
+        sc = np.repeat(self.scale, 3)
+        for k, (a, b) in enumerate(np.asarray(rc).reshape(-1, 2)):
+            s = self.rowptr[a] + np.searchsorted(self.col[self.rowptr[a]:self.rowptr[a + 1]], b)
+            self.val[s] += np.asarray(blocks[k]) * sc
+
+    def addWellRhs(self, rhs_delta):
+        nc = self.nc
+        for i, c in enumerate(self.wells[1]):
+            for a in range(3):
+                self.rhs_extra[a * nc + c] += rhs_delta[i, a]
+
+    def getConvergence(self):
+        st, self.B_avg, self.CNV, self.MB, self.linf, conv = self.orc.convergence(self.grid, self.prm, self.dt, self.r, self.binv)
+        assert st == 0
+        return conv
+
+    def solveJacobianSystem(self, want_dx=False, single_precision=False):
+        nc = self.nc
+        b = np.ascontiguousarray(((self.r + self.rhs_extra) * np.repeat(self.scale, nc)).reshape(3, nc).T).ravel()
+        sto, x, it, red, _ = self.orc.bicgstab(self.rowptr, self.col, self.val, b, self.prm, position=self.position, single=bool(single_precision))
+        assert sto == 0, sto
+        self.linear_iterations = it
+        self.dx = np.ascontiguousarray(x.reshape(nc, 3).T).ravel()
+        return self.dx
+
+    def perfDx(self, nperf):
+        nc = self.nc
+        return np.stack([self.dx[a * nc + self.wells[1]] for a in range(3)], 1)
+
+    def updateState(self):
+        self.st = self.orc.update_state(self.grid, self.tab, self.prm, self.dx, self.st)
+
+    def getState(self):
+        return self.st
