@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--nz", type=int, default=100)
     ap.add_argument("--dt-days", type=float, default=5.0)
     ap.add_argument("--ordering", choices=["multicolor", "natural"], default="multicolor")
+    ap.add_argument("--solver", choices=["cpr", "ilu0"], default="cpr",
+                    help="cpr: AMG pressure stage + ILU0 (reference solver_approach=cpr); ilu0: reference default solver_approach=interleaved")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=1)
     args = ap.parse_args()
@@ -62,7 +64,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     ordering = capi.ORDER_MULTICOLOR if args.ordering == "multicolor" else capi.ORDER_NATURAL
-    prm = capi.default_params(ilu_ordering=ordering)
+    prm = capi.default_params(ilu_ordering=ordering, use_cpr=int(args.solver == "cpr" and world == 1))
     tab = decks.satfunc_standard_tables()
     dt = args.dt_days * decks.DAY
     single = dt < 20 * decks.DAY            # BlackoilModelBase_impl.hpp:284
@@ -157,7 +159,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64 assembly + %s linear solve" % ("f32" if single else "f64"), "data": "synthetic",
             "config": {"workload": "cart%dx%dx%d_3phase_blackoil" % (args.nx, args.ny, args.nz), "cells": nc_global, "nnzb": nnzb,
-                       "dt_days": args.dt_days, "ilu0_ordering": args.ordering, "linear_iterations_per_newton": lin_total / args.steps,
+                       "dt_days": args.dt_days, "linear_solver": ("cpr(amg V-cycle + ilu0)" if prm.use_cpr else "ilu0") + " + bicgstab", "ilu0_ordering": args.ordering, "linear_iterations_per_newton": lin_total / args.steps,
                        "time_steps_completed": steps_done, "tables": "tests/satfuncStandard.DATA PROPS (reference's own test deck)",
                        "parallelism": "1 GPU" if world == 1 else "domain decomposition x%d, RCCL halo" % world},
             "breakdown_ms_per_step": {"assemble": t_asm / args.steps, "linear_solve": t_sol / args.steps, "update": t_upd / args.steps},

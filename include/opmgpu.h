@@ -108,6 +108,9 @@ typedef struct opmgpu_params {
     double ilu_relaxation;          /* 0.9    */
     int32_t ilu_ordering;           /* OPMGPU_ORDER_*                                           */
     int32_t ignore_convergence_failure; /* 0  */
+    int32_t use_cpr;                /* 0 = block-ILU0 (solver_approach=interleaved, the default, FlowMain.hpp:806-830);
+                                       1 = CPR: AMG V-cycle on the pressure system + block-ILU0
+                                           (solver_approach=cpr, NewtonIterationBlackoilCPR.cpp:79-185)     */
 } opmgpu_params;
 
 void opmgpu_default_params(opmgpu_params* p);

@@ -1,0 +1,388 @@
+// amg.hip -- plain-aggregation AMG for the CPR pressure stage (see amg.hpp).
+#include "amg.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+#include "linsolver.hpp"
+
+namespace opmgpu {
+
+namespace {
+
+// ---------------------------------------------------------------- host: hierarchy setup
+struct HostCsr {
+    int n = 0;
+    std::vector<int32_t> rowptr, col, dev;   // dev = device entry id of every csr entry
+    std::vector<double> val;
+};
+
+// greedy strength-based aggregation (Vanek-style, as in dune-istl's aggregation AMG): a node whose strong
+// neighbours are all free seeds an aggregate with them; leftovers join their strongest aggregated neighbour.
+int aggregate(const HostCsr& A, double theta, std::vector<int32_t>& agg)
+{
+    const int n = A.n;
+    agg.assign(n, -1);
+    std::vector<double> maxoff(n, 0.0);
+    for (int i = 0; i < n; ++i)
+        for (int s = A.rowptr[i]; s < A.rowptr[i + 1]; ++s)
+            if (A.col[s] != i) maxoff[i] = std::max(maxoff[i], std::fabs(A.val[s]));
+    auto strong = [&](int i, int s) { return A.col[s] != i && std::fabs(A.val[s]) >= theta * maxoff[i] && maxoff[i] > 0.0; };
+    int na = 0;
+    for (int i = 0; i < n; ++i) {
+        if (agg[i] >= 0) continue;
+        bool free_nb = true;
+        for (int s = A.rowptr[i]; s < A.rowptr[i + 1] && free_nb; ++s) if (strong(i, s) && agg[A.col[s]] >= 0) free_nb = false;
+        if (!free_nb) continue;
+        agg[i] = na;
+        for (int s = A.rowptr[i]; s < A.rowptr[i + 1]; ++s) if (strong(i, s)) agg[A.col[s]] = na;
+        ++na;
+    }
+    for (int i = 0; i < n; ++i) {
+        if (agg[i] >= 0) continue;
+        double best = -1.0; int bj = -1;
+        for (int s = A.rowptr[i]; s < A.rowptr[i + 1]; ++s)
+            if (strong(i, s) && agg[A.col[s]] >= 0 && std::fabs(A.val[s]) > best) { best = std::fabs(A.val[s]); bj = A.col[s]; }
+        agg[i] = bj >= 0 ? agg[bj] : na++;
+    }
+    return na;
+}
+
+// Galerkin product with piecewise-constant prolongation: Ac(I,J) = sum_{i in I, j in J} A(i,j).
+// Also returns, for every fine csr entry, the coarse csr entry it is added to.
+void coarsen(const HostCsr& A, const std::vector<int32_t>& agg, int na, HostCsr& C, std::vector<int32_t>& coarse_of_fine,
+             std::vector<int32_t>& agg_ptr, std::vector<int32_t>& agg_rows)
+{
+    agg_ptr.assign(na + 1, 0);
+    for (int i = 0; i < A.n; ++i) agg_ptr[agg[i] + 1]++;
+    for (int I = 0; I < na; ++I) agg_ptr[I + 1] += agg_ptr[I];
+    agg_rows.resize(A.n);
+    { std::vector<int32_t> fill(agg_ptr.begin(), agg_ptr.end() - 1); for (int i = 0; i < A.n; ++i) agg_rows[fill[agg[i]]++] = i; }
+    C.n = na; C.rowptr.assign(na + 1, 0); C.col.clear(); C.val.clear();
+    coarse_of_fine.assign(A.col.size(), -1);
+    std::vector<int32_t> marker(na, -1);
+    for (int I = 0; I < na; ++I) {
+        const int start = int(C.col.size());
+        // diagonal first
+        marker[I] = start; C.col.push_back(I); C.val.push_back(0.0);
+        for (int q = agg_ptr[I]; q < agg_ptr[I + 1]; ++q) {
+            const int i = agg_rows[q];
+            for (int s = A.rowptr[i]; s < A.rowptr[i + 1]; ++s) {
+                const int J = agg[A.col[s]];
+                if (marker[J] < start) { marker[J] = int(C.col.size()); C.col.push_back(J); C.val.push_back(0.0); }
+                C.val[marker[J]] += A.val[s];
+                coarse_of_fine[s] = marker[J];
+            }
+        }
+        C.rowptr[I + 1] = int(C.col.size());
+    }
+}
+
+// scalar SELL-64 layout of a csr matrix; fills C.dev
+void to_sell(HostCsr& C, std::vector<int32_t>& slice_ptr, std::vector<int32_t>& sell_col, std::vector<int32_t>& diag_entry, int& nentries)
+{
+    const int n = C.n, ns = (n + 63) / 64;
+    slice_ptr.assign(ns + 1, 0);
+    for (int s = 0; s < ns; ++s) {
+        int w = 0;
+        for (int r = s * 64; r < std::min(n, s * 64 + 64); ++r) w = std::max(w, C.rowptr[r + 1] - C.rowptr[r]);
+        slice_ptr[s + 1] = slice_ptr[s] + w;
+    }
+    nentries = slice_ptr[ns] * 64;
+    sell_col.assign(nentries, 0);
+    diag_entry.assign(n, 0);
+    C.dev.assign(C.col.size(), -1);
+    for (int r = 0; r < ns * 64; ++r) {
+        const int base = slice_ptr[r >> 6], w = slice_ptr[(r >> 6) + 1] - base;
+        int len = 0;
+        if (r < n) {
+            len = C.rowptr[r + 1] - C.rowptr[r];
+            for (int k = 0; k < len; ++k) {
+                const int e = (base + k) * 64 + (r & 63);
+                sell_col[e] = C.col[C.rowptr[r] + k]; C.dev[C.rowptr[r] + k] = e;
+                if (C.col[C.rowptr[r] + k] == r) diag_entry[r] = e;
+            }
+        }
+        for (int k = len; k < w; ++k) sell_col[(base + k) * 64 + (r & 63)] = std::min(r, n - 1);
+    }
+}
+
+} // namespace
+
+// ---------------------------------------------------------------- device kernels
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_amg_galerkin(int nce, const int32_t* __restrict__ cptr, const int32_t* __restrict__ cidx,
+                                                         const int32_t* __restrict__ cdev, const S* __restrict__ fine, S* __restrict__ coarse)
+{
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= nce) return;
+    double s = 0.0;
+    for (int q = cptr[e]; q < cptr[e + 1]; ++q) s += double(fine[cidx[q]]);
+    coarse[cdev[e]] = S(s);
+}
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_amg_dinv(int n, const int32_t* __restrict__ diag_entry, const S* __restrict__ val, S* __restrict__ dinv)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const S d = val[diag_entry[i]];
+    dinv[i] = d != S(0) ? S(1) / d : S(0);
+}
+// first pre-smoothing sweep from a zero guess: x = omega D^-1 b
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_amg_smooth0(int n, S omega, const S* __restrict__ dinv, const S* __restrict__ b, S* __restrict__ x,
+                                                        const SolveCtl* __restrict__ ctl)
+{
+    if (ctl && ctl->done) return;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    x[i] = omega * dinv[i] * b[i];
+}
+// acc -= sum_k val[k] * xfun(col[k]) over one SELL row.  The slots are walked in predicated batches of 8 so that all
+// index loads, then all gathers of a batch are in flight together: with 4-byte scalars a row is only ~7 x 12 bytes and a
+// plain dependent loop (col -> x -> fma) is latency bound at a fraction of the HBM rate.
+template <class S, class XF>
+__device__ __forceinline__ S sell_row_dot(const S* __restrict__ v, const int32_t* __restrict__ c, int width, XF xfun)
+{
+    S acc = 0;
+    for (int k0 = 0; k0 < width; k0 += 8) {
+        int cc[8]; S vv[8], xx[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const bool ok = k0 + u < width; cc[u] = ok ? c[(k0 + u) * 64] : -1; vv[u] = ok ? v[(k0 + u) * 64] : S(0); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xx[u] = cc[u] >= 0 ? xfun(cc[u]) : S(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += vv[u] * xx[u];
+    }
+    return acc;
+}
+
+// pre-smoothing from a zero guess fused with the residual (small, launch-bound levels): x = omega D^-1 b ; r = b - A x
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_amg_smooth0_residual(int n, const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
+                                                                 const S* __restrict__ val, const S* __restrict__ b, S omega, const S* __restrict__ dinv,
+                                                                 S* __restrict__ x, S* __restrict__ r, const SolveCtl* __restrict__ ctl)
+{
+    if (ctl && ctl->done) return;
+    const int row = blockIdx.x * kBlock + threadIdx.x;
+    if (row >= n) return;
+    const int base = slice_ptr[row >> 6], width = slice_ptr[(row >> 6) + 1] - base, lane = row & 63;
+    const S ax = sell_row_dot<S>(val + long(base) * 64 + lane, col + long(base) * 64 + lane, width, [&](int j) { return omega * dinv[j] * b[j]; });
+    x[row] = omega * dinv[row] * b[row];
+    r[row] = b[row] - ax;
+}
+// MODE 0: r = b - A x ;  MODE 1: xout = x + omega D^-1 (b - A x)   (damped Jacobi sweep)
+template <class S, int MODE>
+__global__ __launch_bounds__(kBlock) void k_amg_residual(int n, const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
+                                                         const S* __restrict__ val, const S* __restrict__ b, const S* __restrict__ x,
+                                                         S omega, const S* __restrict__ dinv, S* __restrict__ out, const SolveCtl* __restrict__ ctl)
+{
+    if (ctl && ctl->done) return;
+    const int row = blockIdx.x * kBlock + threadIdx.x;
+    if (row >= n) return;
+    const int base = slice_ptr[row >> 6], width = slice_ptr[(row >> 6) + 1] - base, lane = row & 63;
+    const S acc = b[row] - sell_row_dot<S>(val + long(base) * 64 + lane, col + long(base) * 64 + lane, width, [&](int j) { return x[j]; });
+    out[row] = MODE == 0 ? acc : x[row] + omega * dinv[row] * acc;
+}
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_amg_restrict(int nc, const int32_t* __restrict__ aptr, const int32_t* __restrict__ arows,
+                                                         const S* __restrict__ r, S* __restrict__ bc, const SolveCtl* __restrict__ ctl)
+{
+    if (ctl && ctl->done) return;
+    const int I = blockIdx.x * kBlock + threadIdx.x;
+    if (I >= nc) return;
+    const int q0 = aptr[I], q1 = aptr[I + 1];
+    S s = 0;
+    for (int q = q0; q < q1; q += 8) {          // fixed order, batched gathers
+        int rr[8]; S vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rr[u] = q + u < q1 ? arows[q + u] : -1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) vv[u] = rr[u] >= 0 ? r[rr[u]] : S(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += vv[u];
+    }
+    bc[I] = s;
+}
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_amg_prolong(int n, const int32_t* __restrict__ agg, const S* __restrict__ xc, S* __restrict__ x,
+                                                        const SolveCtl* __restrict__ ctl)
+{
+    if (ctl && ctl->done) return;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    x[i] += xc[agg[i]];
+}
+// coarsest level: dense [A | I] -> Gauss-Jordan (no pivoting: the pressure operators are diagonally dominant M-matrix-like)
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_dense_fill(int n, const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
+                                                       const S* __restrict__ val, double* __restrict__ aug)
+{
+    const int row = blockIdx.x * kBlock + threadIdx.x;
+    if (row >= n) return;
+    double* a = aug + long(row) * 2 * n;
+    for (int j = 0; j < 2 * n; ++j) a[j] = (j == n + row) ? 1.0 : 0.0;
+    const int base = slice_ptr[row >> 6], width = slice_ptr[(row >> 6) + 1] - base, lane = row & 63;
+    for (int k = 0; k < width; ++k) { const long e = long(base + k) * 64 + lane; a[col[e]] += double(val[e]); }
+}
+__global__ __launch_bounds__(1024) void k_dense_invert(int n, double* __restrict__ aug, double* __restrict__ inv)
+{
+    __shared__ double f[256];
+    const int n2 = 2 * n;
+    for (int p = 0; p < n; ++p) {
+        const double piv = aug[long(p) * n2 + p];
+        __syncthreads();
+        for (int j = threadIdx.x; j < n2; j += blockDim.x) aug[long(p) * n2 + j] /= piv;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) f[i] = (i == p) ? 0.0 : aug[long(i) * n2 + p];
+        __syncthreads();
+        for (long t = threadIdx.x; t < long(n) * n2; t += blockDim.x) {
+            const int i = int(t / n2), j = int(t % n2);
+            if (i != p) aug[t] -= f[i] * aug[long(p) * n2 + j];
+        }
+        __syncthreads();
+    }
+    // stored TRANSPOSED (inv[j*n + i] = Ainv(i,j)) so that k_dense_apply's loads are contiguous across threads
+    for (long t = threadIdx.x; t < long(n) * n; t += blockDim.x) inv[(t % n) * n + (t / n)] = aug[(t / n) * n2 + n + (t % n)];
+}
+// x = Ainv b on the coarsest level: one wavefront per row (inv is stored transposed, so row i is read with stride n by
+// its wave -- n <= 256 keeps that inside a few cache lines per step; what matters is 64-way parallelism per row)
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_dense_apply(int n, const double* __restrict__ inv, const S* __restrict__ b, S* __restrict__ x,
+                                                        const SolveCtl* __restrict__ ctl)
+{
+    if (ctl && ctl->done) return;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int j = lane; j < n; j += 64) s += inv[long(j) * n + i] * double(b[j]);
+    s = wave_sum(s);
+    if (lane == 0) x[i] = S(s);
+}
+
+// ---------------------------------------------------------------- host driver
+template <class S>
+void AmgHierarchy<S>::setup(const Plan& P, const int32_t* d_slice_ptr, const int32_t* d_col, const std::vector<double>& ap_host)
+{
+    levels.clear(); level_sizes.clear(); coarse_dev.clear();
+    HostCsr A;
+    A.n = P.nb; A.rowptr.assign(P.nb + 1, 0);
+    for (int r = 0; r < P.nb; ++r) A.rowptr[r + 1] = A.rowptr[r] + P.rowlen[r];
+    A.col.resize(A.rowptr[P.nb]); A.val.resize(A.col.size()); A.dev.resize(A.col.size());
+    std::vector<int32_t> diag0(P.nb, 0);
+    for (int r = 0; r < P.nb; ++r)
+        for (int k = 0; k < P.rowlen[r]; ++k) {
+            const int e = P.entry(r, k), s = A.rowptr[r] + k;
+            A.col[s] = P.sell_col[e]; A.val[s] = ap_host[e]; A.dev[s] = e;
+            if (A.col[s] == r) diag0[r] = e;
+        }
+    // level 0 borrows the block plan's SELL structure
+    std::unique_ptr<AmgLevel<S>> L(new AmgLevel<S>());
+    L->n = P.nb; L->nslices = P.nslices; L->nentries = P.nentries; L->slice_ptr = d_slice_ptr; L->col = d_col;
+    L->diag_entry.upload(diag0, stream);
+    const int kMaxDense = 200, kMaxLevels = 12;
+    while (true) {
+        const int n = A.n;
+        L->val.alloc(L->nentries); L->dinv.alloc(n); L->x.alloc(n); L->b.alloc(n); L->r.alloc(n); L->x2.alloc(n);
+        if (!levels.empty()) L->val.zero(stream);
+        level_sizes.push_back(n);
+        std::vector<int32_t> agg;
+        int na = 0;
+        const bool stop = n <= kMaxDense || int(levels.size()) + 1 >= kMaxLevels;
+        if (!stop) na = aggregate(A, 0.25, agg);
+        if (stop || na * 10 > n * 8 || na < 1) {           // coarsest level (or coarsening stalled)
+            levels.push_back(std::move(L));
+            break;
+        }
+        HostCsr C; std::vector<int32_t> cof, aptr, arows;
+        coarsen(A, agg, na, C, cof, aptr, arows);
+        std::vector<int32_t> sp, scol, dent; int nent = 0;
+        to_sell(C, sp, scol, dent, nent);
+        // contribution lists per coarse csr entry, in fine DEVICE entry ids
+        const int nce = int(C.col.size());
+        std::vector<int32_t> cptr(nce + 1, 0), cidx(A.col.size());
+        for (size_t s = 0; s < A.col.size(); ++s) cptr[cof[s] + 1]++;
+        for (int e = 0; e < nce; ++e) cptr[e + 1] += cptr[e];
+        { std::vector<int32_t> fill(cptr.begin(), cptr.end() - 1); for (size_t s = 0; s < A.col.size(); ++s) cidx[fill[cof[s]]++] = A.dev[s]; }
+        L->agg.upload(agg, stream); L->agg_ptr.upload(aptr, stream); L->agg_rows.upload(arows, stream);
+        L->contrib_ptr.upload(cptr, stream); L->contrib_idx.upload(cidx, stream);
+        L->n_coarse = na; L->nentries_coarse = nce;
+        std::unique_ptr<AmgLevel<S>> Lc(new AmgLevel<S>());
+        Lc->n = na; Lc->nslices = (na + 63) / 64; Lc->nentries = nent;
+        Lc->own_slice_ptr.upload(sp, stream); Lc->own_col.upload(scol, stream);
+        Lc->slice_ptr = Lc->own_slice_ptr.p; Lc->col = Lc->own_col.p;
+        Lc->diag_entry.upload(dent, stream);
+        // stash coarse device-entry ids on the FINE level (used by k_amg_galerkin)
+        {
+            DevArray<int32_t>* cdev = new DevArray<int32_t>();
+            cdev->upload(C.dev, stream);
+            coarse_dev.emplace_back(cdev);
+        }
+        levels.push_back(std::move(L));
+        L = std::move(Lc);
+        A = std::move(C);
+    }
+    n_coarsest = levels.back()->n;
+    if (n_coarsest <= 256) {
+        dense_inv.alloc(size_t(n_coarsest) * n_coarsest);
+        dense_work.alloc(size_t(n_coarsest) * 2 * n_coarsest);
+    }
+    OPMGPU_HIP(hipStreamSynchronize(stream));
+}
+
+template <class S>
+void AmgHierarchy<S>::galerkin()
+{
+    for (size_t l = 0; l + 1 < levels.size(); ++l) {
+        AmgLevel<S>& F = *levels[l]; AmgLevel<S>& C = *levels[l + 1];
+        hipLaunchKernelGGL((k_amg_dinv<S>), dim3(grid_for(F.n)), dim3(kBlock), 0, stream, F.n, F.diag_entry.p, F.val.p, F.dinv.p);
+        hipLaunchKernelGGL((k_amg_galerkin<S>), dim3(grid_for(F.nentries_coarse)), dim3(kBlock), 0, stream, F.nentries_coarse,
+                           F.contrib_ptr.p, F.contrib_idx.p, coarse_dev[l]->p, F.val.p, C.val.p);
+    }
+    AmgLevel<S>& B = *levels.back();
+    hipLaunchKernelGGL((k_amg_dinv<S>), dim3(grid_for(B.n)), dim3(kBlock), 0, stream, B.n, B.diag_entry.p, B.val.p, B.dinv.p);
+    if (n_coarsest <= 256) {
+        hipLaunchKernelGGL((k_dense_fill<S>), dim3(grid_for(B.n)), dim3(kBlock), 0, stream, B.n, B.slice_ptr, B.col, B.val.p, dense_work.p);
+        hipLaunchKernelGGL(k_dense_invert, dim3(1), dim3(1024), 0, stream, B.n, dense_work.p, dense_inv.p);
+    }
+}
+
+template <class S>
+void AmgHierarchy<S>::vcycle(const SolveCtl* ctl)
+{
+    const S om = S(omega);
+    const int nl = int(levels.size());
+    for (int l = 0; l < nl - 1; ++l) {
+        AmgLevel<S>& F = *levels[l]; AmgLevel<S>& C = *levels[l + 1];
+        const int g = grid_for(F.n);
+        if (F.n > 50000) {
+            hipLaunchKernelGGL((k_amg_smooth0<S>), dim3(g), dim3(kBlock), 0, stream, F.n, om, F.dinv.p, F.b.p, F.x.p, ctl);
+            hipLaunchKernelGGL((k_amg_residual<S, 0>), dim3(g), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, F.x.p, om, F.dinv.p, F.r.p, ctl);
+        } else {
+            hipLaunchKernelGGL((k_amg_smooth0_residual<S>), dim3(g), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, om, F.dinv.p, F.x.p, F.r.p, ctl);
+        }
+        hipLaunchKernelGGL((k_amg_restrict<S>), dim3(grid_for(C.n)), dim3(kBlock), 0, stream, C.n, F.agg_ptr.p, F.agg_rows.p, F.r.p, C.b.p, ctl);
+    }
+    AmgLevel<S>& B = *levels.back();
+    if (n_coarsest <= 256) {
+        hipLaunchKernelGGL((k_dense_apply<S>), dim3((B.n + 3) / 4), dim3(kBlock), 0, stream, B.n, dense_inv.p, B.b.p, B.x.p, ctl);
+    } else {        // coarsening stalled above the dense limit: a few Jacobi sweeps stand in for the coarse solve
+        hipLaunchKernelGGL((k_amg_smooth0<S>), dim3(grid_for(B.n)), dim3(kBlock), 0, stream, B.n, om, B.dinv.p, B.b.p, B.x.p, ctl);
+        for (int s = 0; s < 4; ++s) {
+            hipLaunchKernelGGL((k_amg_residual<S, 1>), dim3(grid_for(B.n)), dim3(kBlock), 0, stream, B.n, B.slice_ptr, B.col, B.val.p, B.b.p, B.x.p, om, B.dinv.p, B.x2.p, ctl);
+            hipLaunchKernelGGL((k_amg_residual<S, 1>), dim3(grid_for(B.n)), dim3(kBlock), 0, stream, B.n, B.slice_ptr, B.col, B.val.p, B.b.p, B.x2.p, om, B.dinv.p, B.x.p, ctl);
+        }
+    }
+    for (int l = nl - 2; l >= 0; --l) {
+        AmgLevel<S>& F = *levels[l]; AmgLevel<S>& C = *levels[l + 1];
+        const int g = grid_for(F.n);
+        hipLaunchKernelGGL((k_amg_prolong<S>), dim3(g), dim3(kBlock), 0, stream, F.n, F.agg.p, C.x.p, F.x.p, ctl);
+        hipLaunchKernelGGL((k_amg_residual<S, 1>), dim3(g), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, F.x.p, om, F.dinv.p, F.x2.p, ctl);
+        std::swap(F.x.p, F.x2.p);       // post-smoothed iterate becomes x (buffers are the same size)
+    }
+}
+
+template class AmgHierarchy<float>;
+template class AmgHierarchy<double>;
+
+} // namespace opmgpu

@@ -102,7 +102,7 @@ void opmgpu_default_params(opmgpu_params* p)
     p->max_residual_allowed = 1e7; p->tolerance_mb = 1e-5; p->tolerance_cnv = 1e-2;
     p->matbalscale[0] = 1.1169; p->matbalscale[1] = 1.0031; p->matbalscale[2] = 0.0031;   // BlackoilModelBase_impl.hpp:139
     p->linear_solver_reduction = 1e-2; p->linear_solver_maxiter = 150;                    // FlowLinearSolverParameters
-    p->ilu_relaxation = 0.9; p->ilu_ordering = OPMGPU_ORDER_MULTICOLOR; p->ignore_convergence_failure = 0;
+    p->ilu_relaxation = 0.9; p->ilu_ordering = OPMGPU_ORDER_MULTICOLOR; p->ignore_convergence_failure = 0; p->use_cpr = 0;
 }
 
 int opmgpu_create_solver(opmgpu_ctx** ctx, int device, const opmgpu_params* params) { return make_ctx(ctx, device, params); }

@@ -429,6 +429,57 @@ __global__ __launch_bounds__(kBlock) void k_copy16(long n16, const double2* __re
     for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n16; i += long(gridDim.x) * kBlock) b[i] = a[i];
 }
 
+// ---- CPR (NewtonIterationBlackoilCPR.cpp:79-185) ----
+// elliptic system of formEllipticSystem (NewtonIterationUtilities.cpp:197-287, default L): A_p(i,j) = sum_eq A_ij[eq][pressure]
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_extract_pressure(long nentries, const S* __restrict__ A, S* __restrict__ Ap)
+{
+    const long e = blockIdx.x * long(kBlock) + threadIdx.x;
+    if (e >= nentries) return;
+    const S* b = A + (e >> 6) * 576 + (e & 63);
+    Ap[e] = b[0] + b[192] + b[384];
+}
+// r_p = sum of the three (scaled) phase residuals
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_cpr_sum_eqs(int nb, int nbp, const S* __restrict__ d, S* __restrict__ bp, const SolveCtl* __restrict__ ctl)
+{
+    if (ctl && ctl->done) return;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nb) return;
+    bp[i] = d[i] + d[nbp + i] + d[2 * long(nbp) + i];
+}
+// z = d - A [x_p; 0; 0]   (only the pressure column of every block is read: 1/3 of the matrix)
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_cpr_presidual(int xm, int nb, int nbp, const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
+                                                          const S* __restrict__ val, const S* __restrict__ d, const S* __restrict__ xp,
+                                                          S* __restrict__ z, const SolveCtl* __restrict__ ctl)
+{
+    if (ctl && ctl->done) return;
+    const int nchunks = (nb + kBlock - 1) / kBlock;
+    const int ch = xcd_first(nchunks, xm);
+    if (ch >= xcd_end(nchunks, xm)) return;
+    const int row = ch * kBlock + threadIdx.x;
+    if (row >= nb) return;
+    const int base = slice_ptr[row >> 6], width = slice_ptr[(row >> 6) + 1] - base, lane = row & 63;
+    const S* __restrict__ v = val + vidx(base, lane);
+    const int32_t* __restrict__ c = col + long(base) * 64 + lane;
+    S z0 = d[row], z1 = d[nbp + row], z2 = d[2 * long(nbp) + row];
+    for (int k = 0; k < width; ++k) {
+        const S x0 = xp[c[k * 64]];
+        const S* __restrict__ b = v + k * 576;
+        z0 -= b[0] * x0; z1 -= b[192] * x0; z2 -= b[384] * x0;
+    }
+    z[row] = z0; z[nbp + row] = z1; z[2 * long(nbp) + row] = z2;
+}
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_cpr_add_p(int nb, const S* __restrict__ xp, S* __restrict__ v, const SolveCtl* __restrict__ ctl)
+{
+    if (ctl && ctl->done) return;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nb) return;
+    v[i] += xp[i];
+}
+
 // ---- layout conversion kernels ----
 __global__ __launch_bounds__(kBlock) void k_bsr_to_sell(int nentries, const int32_t* __restrict__ src, const double* __restrict__ bsr, double* __restrict__ sell)
 {
@@ -540,8 +591,9 @@ template <class S> void LinSolver::ensure_work()
     const size_t nv = size_t(3) * plan.nbp, nm = size_t(plan.nentries) * 9;
     if (sizeof(S) == 4) { w.A.alloc(nm); w.A.zero(stream); }
     w.LU.alloc(nm); w.LU.zero(stream);
-    DevArray<S>* vs[] = { &w.r, &w.rt, &w.p, &w.v, &w.t, &w.y, &w.x, &w.b };
+    DevArray<S>* vs[] = { &w.r, &w.rt, &w.p, &w.v, &w.t, &w.y, &w.x, &w.b, &w.z };
     for (DevArray<S>* a : vs) { a->alloc(nv); a->zero(stream); }
+    w.amg.reset();
     w.allocated = true;
 }
 
@@ -612,6 +664,39 @@ template <class S> void LinSolver::spmv(const S* x, S* y)
                        (double*)nullptr, (double*)nullptr, (const S*)nullptr, 0, S(0));
 }
 
+template <class S> void LinSolver::cpr_prepare()
+{
+    SolverWork<S>& w = work<S>();
+    const long ne = plan.nentries;
+    if (!w.amg) w.amg.reset(new AmgHierarchy<S>(stream));
+    if (!w.amg->ready()) {
+        // first matrix with this pattern: pressure values to the host, aggregation hierarchy (structure only) built there
+        DevArray<S> tmp; tmp.alloc(ne);
+        hipLaunchKernelGGL((k_extract_pressure<S>), dim3(grid_for(ne)), dim3(kBlock), 0, stream, ne, matrix<S>(), tmp.p);
+        std::vector<S> h(ne);
+        tmp.download(h.data(), ne, stream);
+        OPMGPU_HIP(hipStreamSynchronize(stream));
+        std::vector<double> hd(h.begin(), h.end());
+        w.amg->setup(plan, dp.slice_ptr.p, dp.col.p, hd);
+    }
+    hipLaunchKernelGGL((k_extract_pressure<S>), dim3(grid_for(ne)), dim3(kBlock), 0, stream, ne, matrix<S>(), w.amg->levels[0]->val.p);
+    w.amg->galerkin();
+}
+
+// M^-1 d = [x_p;0;0] + ILU0^-1 (d - A [x_p;0;0]),  x_p = Vcycle(sum of the equations of d)
+template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, const SolveCtl* ctl)
+{
+    SolverWork<S>& w = work<S>();
+    AmgLevel<S>& L0 = *w.amg->levels[0];
+    const int g = grid_for(plan.nb);
+    hipLaunchKernelGGL((k_cpr_sum_eqs<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, plan.nbp, d, L0.b.p, ctl);
+    w.amg->vcycle(ctl);
+    hipLaunchKernelGGL((k_cpr_presidual<S>), dim3(grid8_for(plan.nb)), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p,
+                       matrix<S>(), d, (const S*)L0.x.p, w.z.p, ctl);
+    ilu_apply<S>(w.z.p, v, relax, ctl);
+    hipLaunchKernelGGL((k_cpr_add_p<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, (const S*)L0.x.p, v, ctl);
+}
+
 template <class S> static void halo(CommBase* c, S* v, hipStream_t s);
 template <> void halo<float>(CommBase* c, float* v, hipStream_t s) { c->halo_exchange_f(v, s); }
 template <> void halo<double>(CommBase* c, double* v, hipStream_t s) { c->halo_exchange_d(v, s); }
@@ -628,7 +713,9 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
     const int8_t* mask = comm ? comm->owner_mask() : nullptr;
     // closed form of (A M^-1 p) on the level-0 rows -- valid when M is the ILU0 of exactly this matrix and the ghost
     // entries of M^-1 p are not overwritten by a halo exchange, i.e. single GPU
-    const bool closed = !comm && closed_form_level0;
+    const bool cpr = prm.use_cpr != 0 && !comm;          // CPR is single-GPU for now; multi-GPU falls back to block-Jacobi ILU0
+    if (cpr) cpr_prepare<S>();
+    const bool closed = !comm && closed_form_level0 && !cpr;
     const S* pin_p = closed ? w.p.p : nullptr; const S* pin_r = closed ? w.r.p : nullptr;
     const int n0 = plan.level_ptr[1];
     double* P_h = partials.p, *P_n1 = P_h + npart, *P_tr = P_n1 + npart, *P_tt = P_tr + npart, *P_n2 = P_tt + npart, *P_rho = P_n2 + npart;
@@ -656,7 +743,7 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
     for (; j <= maxit && !stop; ++j) {
         hipLaunchKernelGGL((k_update_p<S>), dim3(gv), dim3(kBlock), 0, stream, n, j, eps, d_ctl, h_ctl_dev, (const double*)a_n2, (const double*)a_rho, np_n2,
                            w.r.p, w.v.p, w.p.p);
-        ilu_apply<S>(w.p.p, w.y.p, prm.ilu_relaxation, d_ctl);
+        if (cpr) cpr_apply<S>(w.p.p, w.y.p, prm.ilu_relaxation, d_ctl); else ilu_apply<S>(w.p.p, w.y.p, prm.ilu_relaxation, d_ctl);
         if (comm) halo<S>(comm, w.y.p, stream);
         hipLaunchKernelGGL((k_spmv<S, 1>), dim3(gs), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p, matrix<S>(),
                            w.y.p, w.v.p, w.rt.p, mask, (const SolveCtl*)d_ctl, P_h, (double*)nullptr, pin_p, n0, S(prm.ilu_relaxation));
@@ -666,7 +753,7 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
                            w.x.p, w.r.p, P_n1);
         double* a_n1 = P_n1; int np_n1 = gv; none = nullptr;
         bridge(a_n1, none, np_n1, 2);
-        ilu_apply<S>(w.r.p, w.y.p, prm.ilu_relaxation, d_ctl);
+        if (cpr) cpr_apply<S>(w.r.p, w.y.p, prm.ilu_relaxation, d_ctl); else ilu_apply<S>(w.r.p, w.y.p, prm.ilu_relaxation, d_ctl);
         if (comm) halo<S>(comm, w.y.p, stream);
         hipLaunchKernelGGL((k_spmv<S, 2>), dim3(gs), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p, matrix<S>(),
                            w.y.p, w.t.p, w.r.p, mask, (const SolveCtl*)d_ctl, P_tr, P_tt, pin_r, n0, S(prm.ilu_relaxation));
@@ -676,8 +763,16 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
                            (const double*)a_tt, np_n1, np_t, w.y.p, w.t.p, w.rt.p, w.x.p, w.r.p, P_n2, P_rho);
         a_n2 = P_n2; a_rho = P_rho; np_n2 = gv;
         bridge(a_n2, a_rho, np_n2, 5);
-        OPMGPU_HIP(hipEventRecord(ev[j & 1], stream));
         last = j;
+        if (cpr) {
+            // CPR iterations are long (~0.6 ms of kernels) and few (~5): a speculative extra iteration of ~50 no-op
+            // launches costs more than one host round trip, so test convergence at the END of the iteration and wait.
+            hipLaunchKernelGGL(k_final_check, dim3(1), dim3(kBlock), 0, stream, j, d_ctl, h_ctl_dev, (const double*)a_n2, np_n2);
+            OPMGPU_HIP(hipStreamSynchronize(stream));
+            if (h_ctl->done) stop = true;
+            continue;
+        }
+        OPMGPU_HIP(hipEventRecord(ev[j & 1], stream));
         if (j >= 2 && target == 0) {       // iteration j-1 is complete once its event has fired; iteration j is already queued
             OPMGPU_HIP(hipEventSynchronize(ev[(j - 1) & 1]));
             if (h_ctl->done) {
@@ -795,6 +890,8 @@ double LinSolver::time_kernel(int kernel, int reps, int single_precision)
     template int LinSolver::factor<S>();                                                 \
     template void LinSolver::ilu_apply<S>(const S*, S*, double, const SolveCtl*);        \
     template void LinSolver::spmv<S>(const S*, S*);                                      \
+    template void LinSolver::cpr_prepare<S>();                                           \
+    template void LinSolver::cpr_apply<S>(const S*, S*, double, const SolveCtl*);        \
     template SolveResult LinSolver::bicgstab<S>(const opmgpu_params&);                   \
     template void LinSolver::vec_from_host<S>(const double*, int, S*);                   \
     template void LinSolver::vec_to_host<S>(const S*, int, double*);                     \

@@ -6,6 +6,7 @@
 #ifndef OPMGPU_LINSOLVER_HPP
 #define OPMGPU_LINSOLVER_HPP
 
+#include "amg.hpp"
 #include "common.hpp"
 #include "plan.hpp"
 
@@ -50,7 +51,8 @@ template <class S>
 struct SolverWork {
     DevArray<S> A;      // float copy of the matrix (unused for double: the double matrix is used in place)
     DevArray<S> LU;
-    DevArray<S> r, rt, p, v, t, y, x, b;
+    DevArray<S> r, rt, p, v, t, y, x, b, z;      // z: scratch of the CPR second stage
+    std::unique_ptr<AmgHierarchy<S>> amg;         // CPR pressure stage (built on first use)
     bool allocated = false;
 };
 
@@ -76,6 +78,9 @@ public:
     template <class S> int factor();                                // ILU0 numeric factorisation
     template <class S> void ilu_apply(const S* d, S* v, double relax, const SolveCtl* ctl = nullptr);
     template <class S> void spmv(const S* x, S* y);
+    // CPR (solver_approach=cpr): build / refresh the pressure AMG for the current matrix; two-stage apply
+    template <class S> void cpr_prepare();
+    template <class S> void cpr_apply(const S* d, S* v, double relax, const SolveCtl* ctl);
     // x0 = 0; rhs in work<S>().b; solution in work<S>().x
     template <class S> SolveResult bicgstab(const opmgpu_params& prm);
 

@@ -52,7 +52,7 @@ class Params(C.Structure):
                 ("tolerance_cnv", C.c_double), ("matbalscale", C.c_double * 3),
                 ("linear_solver_reduction", C.c_double), ("linear_solver_maxiter", C.c_int32),
                 ("ilu_relaxation", C.c_double), ("ilu_ordering", C.c_int32),
-                ("ignore_convergence_failure", C.c_int32)]
+                ("ignore_convergence_failure", C.c_int32), ("use_cpr", C.c_int32)]
 
 
 def default_params(**over):
@@ -62,7 +62,7 @@ def default_params(**over):
     p.max_residual_allowed, p.tolerance_mb, p.tolerance_cnv = 1e7, 1e-5, 1e-2
     p.matbalscale[:] = [1.1169, 1.0031, 0.0031]
     p.linear_solver_reduction, p.linear_solver_maxiter = 1e-2, 150
-    p.ilu_relaxation, p.ilu_ordering, p.ignore_convergence_failure = 0.9, ORDER_MULTICOLOR, 0
+    p.ilu_relaxation, p.ilu_ordering, p.ignore_convergence_failure, p.use_cpr = 0.9, ORDER_MULTICOLOR, 0, 0
     for k, v in over.items():
         if k == "matbalscale":
             p.matbalscale[:] = list(v)

@@ -136,3 +136,46 @@ def test_pattern_cache_and_replan(gpu_lib, oracle):
         A = bsr_to_scipy(rowptr, col, val)
         assert np.linalg.norm(A @ x - b) / np.linalg.norm(b) < 1e-2
     s.close()
+
+
+@pytest.mark.parametrize("single", [False, True])
+def test_cpr_amg_solve(gpu_lib, oracle, single):
+    """solver_approach=cpr: AMG V-cycle on the pressure system + ILU0.  Contract: same stopping rule,
+    dx solves the system to the linear tolerance; and it must need far fewer iterations than ILU0 alone on a
+    Newton iteration with a hard pressure part."""
+    grid = decks.cartesian_grid(20, 18, 16, lognormal_sigma=0.8)
+    tab = decks.satfunc_standard_tables()
+    st = decks.initial_state(grid, tab, perturb=0.004)
+    prm0 = capi.default_params()
+    scale = np.asarray(prm0.matbalscale[:])
+    rowptr, col = oracle.pattern(grid)
+    nc = grid.nc
+    dt = 5 * decks.DAY
+    # second Newton iteration of the step: the first one is easy for any preconditioner
+    r, val, acc0, _ = oracle.assemble(grid, tab, dt, st, rowptr, col, scale=tuple(scale))
+    b = np.ascontiguousarray((r * np.repeat(scale, nc)).reshape(3, nc).T).ravel()
+    _, x, _, _, _ = oracle.bicgstab(rowptr, col, val, b, prm0)
+    st1 = oracle.update_state(grid, tab, prm0, np.ascontiguousarray(x.reshape(nc, 3).T).ravel(), st)
+    r, val, _, _ = oracle.assemble(grid, tab, dt, st1, rowptr, col, scale=tuple(scale), accum0=acc0)
+    b = np.ascontiguousarray((r * np.repeat(scale, nc)).reshape(3, nc).T).ravel()
+    A = bsr_to_scipy(rowptr, col, val)
+    xe = spla.spsolve(A.tocsc(), b)
+    its = {}
+    for cpr in (0, 1):
+        s = GpuNewtonIteration(capi.default_params(use_cpr=cpr))
+        xs = s.computeNewtonIncrement(rowptr, col, val, b, single)
+        its[cpr] = s.iterations()
+        assert np.linalg.norm(A @ xs - b) <= 1.5e-2 * np.linalg.norm(b) and s.reduction < 1e-2
+        s.close()
+    assert its[1] * 3 <= its[0], its                      # CPR: at least 3x fewer iterations here
+    red = 1e-5 if single else 1e-10
+    s = GpuNewtonIteration(capi.default_params(use_cpr=1, linear_solver_reduction=red, linear_solver_maxiter=200))
+    xs = s.computeNewtonIncrement(rowptr, col, val, b, single)
+    if single:
+        assert np.linalg.norm(A @ xs - b) <= 30 * red * np.linalg.norm(b)
+    else:
+        assert np.linalg.norm(xs - xe) <= 1e-6 * np.linalg.norm(xe)
+    # the same matrix again (hierarchy reused, numeric Galerkin repeated): bitwise identical result
+    xs2 = s.computeNewtonIncrement(rowptr, col, val, b, single)
+    assert np.array_equal(xs, xs2)
+    s.close()
