@@ -64,7 +64,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     ordering = capi.ORDER_MULTICOLOR if args.ordering == "multicolor" else capi.ORDER_NATURAL
-    prm = capi.default_params(ilu_ordering=ordering, use_cpr=int(args.solver == "cpr" and world == 1))
+    prm = capi.default_params(ilu_ordering=ordering, use_cpr=int(args.solver == "cpr"))
     tab = decks.satfunc_standard_tables()
     dt = args.dt_days * decks.DAY
     single = dt < 20 * decks.DAY            # BlackoilModelBase_impl.hpp:284

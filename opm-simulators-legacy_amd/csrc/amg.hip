@@ -3,6 +3,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <numeric>
 
 #include "linsolver.hpp"
@@ -122,6 +124,17 @@ __global__ __launch_bounds__(kBlock) void k_amg_galerkin(int nce, const int32_t*
     coarse[cdev[e]] = S(s);
 }
 template <class S>
+__global__ __launch_bounds__(kBlock) void k_amg_galerkin_wave(int nce, const int32_t* __restrict__ cptr, const int32_t* __restrict__ cidx,
+                                                              const int32_t* __restrict__ cdev, const S* __restrict__ fine, S* __restrict__ coarse)
+{
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+    if (e >= nce) return;
+    double s = 0.0;
+    for (int q = cptr[e] + l; q < cptr[e + 1]; q += 64) s += double(fine[cidx[q]]);
+    s = wave_sum(s);                       // fixed lane order: deterministic
+    if (l == 0) coarse[cdev[e]] = S(s);
+}
+template <class S>
 __global__ __launch_bounds__(kBlock) void k_amg_dinv(int n, const int32_t* __restrict__ diag_entry, const S* __restrict__ val, S* __restrict__ dinv)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -185,6 +198,33 @@ __global__ __launch_bounds__(kBlock) void k_amg_residual(int n, const int32_t* _
     const S acc = b[row] - sell_row_dot<S>(val + long(base) * 64 + lane, col + long(base) * 64 + lane, width, [&](int j) { return x[j]; });
     out[row] = MODE == 0 ? acc : x[row] + omega * dinv[row] * acc;
 }
+// small levels: one wavefront per row (aggregated stencils are 30-100 entries wide there; a single thread walking them
+// is latency bound).  MODE 0: r = b - A x ; MODE 1: out = x + omega D^-1 (b - A x) ; MODE 2: x = omega D^-1 b, r = b - A x fused
+template <class S, int MODE>
+__global__ __launch_bounds__(kBlock) void k_amg_row_wave(int n, const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
+                                                         const S* __restrict__ val, const S* __restrict__ b, const S* __restrict__ x,
+                                                         S omega, const S* __restrict__ dinv, S* __restrict__ out, S* __restrict__ xout,
+                                                         const SolveCtl* __restrict__ ctl)
+{
+    if (ctl && ctl->done) return;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+    if (row >= n) return;
+    const int base = slice_ptr[row >> 6], width = slice_ptr[(row >> 6) + 1] - base, lane = row & 63;
+    double acc = 0.0;
+    for (int k = l; k < width; k += 64) {
+        const long e = long(base + k) * 64 + lane;
+        const int j = col[e];
+        const S xj = MODE == 2 ? omega * dinv[j] * b[j] : x[j];
+        acc += double(val[e]) * double(xj);
+    }
+    acc = wave_sum(acc);
+    if (l == 0) {
+        const S res = b[row] - S(acc);
+        if (MODE == 0) out[row] = res;
+        else if (MODE == 1) out[row] = x[row] + omega * dinv[row] * res;
+        else { out[row] = res; xout[row] = omega * dinv[row] * b[row]; }
+    }
+}
 template <class S>
 __global__ __launch_bounds__(kBlock) void k_amg_restrict(int nc, const int32_t* __restrict__ aptr, const int32_t* __restrict__ arows,
                                                          const S* __restrict__ r, S* __restrict__ bc, const SolveCtl* __restrict__ ctl)
@@ -226,24 +266,31 @@ __global__ __launch_bounds__(kBlock) void k_dense_fill(int n, const int32_t* __r
     const int base = slice_ptr[row >> 6], width = slice_ptr[(row >> 6) + 1] - base, lane = row & 63;
     for (int k = 0; k < width; ++k) { const long e = long(base + k) * 64 + lane; a[col[e]] += double(val[e]); }
 }
-__global__ __launch_bounds__(1024) void k_dense_invert(int n, double* __restrict__ aug, double* __restrict__ inv)
+// Gauss-Jordan on the augmented matrix held entirely in LDS (n <= kDenseMax = 96: 96 x 192 doubles = 144 KiB of the
+// 160 KiB per CU); one workgroup, no pivoting (the pressure operators are diagonally dominant M-matrix-like).
+constexpr int kDenseMax = 96;
+__global__ __launch_bounds__(512) void k_dense_invert(int n, const double* __restrict__ aug_in, double* __restrict__ inv)
 {
-    __shared__ double f[256];
+    extern __shared__ double lds[];
+    double* a = lds;                 // [n][2n]
+    __shared__ double f[kDenseMax];
     const int n2 = 2 * n;
+    for (int t = threadIdx.x; t < n * n2; t += blockDim.x) a[t] = aug_in[t];
+    __syncthreads();
     for (int p = 0; p < n; ++p) {
-        const double piv = aug[long(p) * n2 + p];
+        const double ipiv = 1.0 / a[p * n2 + p];
         __syncthreads();
-        for (int j = threadIdx.x; j < n2; j += blockDim.x) aug[long(p) * n2 + j] /= piv;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) f[i] = (i == p) ? 0.0 : aug[long(i) * n2 + p];
+        for (int j = threadIdx.x; j < n2; j += blockDim.x) a[p * n2 + j] *= ipiv;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) f[i] = (i == p) ? 0.0 : a[i * n2 + p];
         __syncthreads();
-        for (long t = threadIdx.x; t < long(n) * n2; t += blockDim.x) {
-            const int i = int(t / n2), j = int(t % n2);
-            if (i != p) aug[t] -= f[i] * aug[long(p) * n2 + j];
+        for (int t = threadIdx.x; t < n * n2; t += blockDim.x) {
+            const int i = t / n2, j = t - i * n2;
+            a[t] -= f[i] * a[p * n2 + j];
         }
         __syncthreads();
     }
-    // stored TRANSPOSED (inv[j*n + i] = Ainv(i,j)) so that k_dense_apply's loads are contiguous across threads
-    for (long t = threadIdx.x; t < long(n) * n; t += blockDim.x) inv[(t % n) * n + (t / n)] = aug[(t / n) * n2 + n + (t % n)];
+    // stored TRANSPOSED (inv[j*n + i] = Ainv(i,j)) so that k_dense_apply's loads are contiguous across lanes
+    for (int t = threadIdx.x; t < n * n; t += blockDim.x) { const int i = t / n, j = t - i * n; inv[j * n + i] = a[i * n2 + n + j]; }
 }
 // x = Ainv b on the coarsest level: one wavefront per row (inv is stored transposed, so row i is read with stride n by
 // its wave -- n <= 256 keeps that inside a few cache lines per step; what matters is 64-way parallelism per row)
@@ -280,7 +327,7 @@ void AmgHierarchy<S>::setup(const Plan& P, const int32_t* d_slice_ptr, const int
     std::unique_ptr<AmgLevel<S>> L(new AmgLevel<S>());
     L->n = P.nb; L->nslices = P.nslices; L->nentries = P.nentries; L->slice_ptr = d_slice_ptr; L->col = d_col;
     L->diag_entry.upload(diag0, stream);
-    const int kMaxDense = 200, kMaxLevels = 12;
+    const int kMaxDense = kDenseMax, kMaxLevels = 12;
     while (true) {
         const int n = A.n;
         L->val.alloc(L->nentries); L->dinv.alloc(n); L->x.alloc(n); L->b.alloc(n); L->r.alloc(n); L->x2.alloc(n);
@@ -323,7 +370,10 @@ void AmgHierarchy<S>::setup(const Plan& P, const int32_t* d_slice_ptr, const int
         A = std::move(C);
     }
     n_coarsest = levels.back()->n;
-    if (n_coarsest <= 256) {
+    if (n_coarsest <= kDenseMax)        // > 64 KiB of dynamic LDS must be requested explicitly
+        OPMGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_invert), hipFuncAttributeMaxDynamicSharedMemorySize, kDenseMax * 2 * kDenseMax * int(sizeof(double))));
+    if (std::getenv("OPMGPU_VERBOSE")) { std::fprintf(stderr, "[opmgpu] AMG levels:"); for (int n : level_sizes) std::fprintf(stderr, " %d", n); std::fprintf(stderr, "\n"); }
+    if (n_coarsest <= kDenseMax) {
         dense_inv.alloc(size_t(n_coarsest) * n_coarsest);
         dense_work.alloc(size_t(n_coarsest) * 2 * n_coarsest);
     }
@@ -336,14 +386,19 @@ void AmgHierarchy<S>::galerkin()
     for (size_t l = 0; l + 1 < levels.size(); ++l) {
         AmgLevel<S>& F = *levels[l]; AmgLevel<S>& C = *levels[l + 1];
         hipLaunchKernelGGL((k_amg_dinv<S>), dim3(grid_for(F.n)), dim3(kBlock), 0, stream, F.n, F.diag_entry.p, F.val.p, F.dinv.p);
-        hipLaunchKernelGGL((k_amg_galerkin<S>), dim3(grid_for(F.nentries_coarse)), dim3(kBlock), 0, stream, F.nentries_coarse,
-                           F.contrib_ptr.p, F.contrib_idx.p, coarse_dev[l]->p, F.val.p, C.val.p);
+        if (F.nentries_coarse > 400000)
+            hipLaunchKernelGGL((k_amg_galerkin<S>), dim3(grid_for(F.nentries_coarse)), dim3(kBlock), 0, stream, F.nentries_coarse,
+                               F.contrib_ptr.p, F.contrib_idx.p, coarse_dev[l]->p, F.val.p, C.val.p);
+        else
+            hipLaunchKernelGGL((k_amg_galerkin_wave<S>), dim3((F.nentries_coarse + 3) / 4), dim3(kBlock), 0, stream, F.nentries_coarse,
+                               F.contrib_ptr.p, F.contrib_idx.p, coarse_dev[l]->p, F.val.p, C.val.p);
     }
     AmgLevel<S>& B = *levels.back();
     hipLaunchKernelGGL((k_amg_dinv<S>), dim3(grid_for(B.n)), dim3(kBlock), 0, stream, B.n, B.diag_entry.p, B.val.p, B.dinv.p);
-    if (n_coarsest <= 256) {
+    if (n_coarsest <= kDenseMax) {
         hipLaunchKernelGGL((k_dense_fill<S>), dim3(grid_for(B.n)), dim3(kBlock), 0, stream, B.n, B.slice_ptr, B.col, B.val.p, dense_work.p);
-        hipLaunchKernelGGL(k_dense_invert, dim3(1), dim3(1024), 0, stream, B.n, dense_work.p, dense_inv.p);
+        hipLaunchKernelGGL(k_dense_invert, dim3(1), dim3(512), size_t(B.n) * 2 * B.n * sizeof(double), stream, B.n, (const double*)dense_work.p, dense_inv.p);
+        OPMGPU_HIP(hipGetLastError());
     }
 }
 
@@ -358,13 +413,15 @@ void AmgHierarchy<S>::vcycle(const SolveCtl* ctl)
         if (F.n > 50000) {
             hipLaunchKernelGGL((k_amg_smooth0<S>), dim3(g), dim3(kBlock), 0, stream, F.n, om, F.dinv.p, F.b.p, F.x.p, ctl);
             hipLaunchKernelGGL((k_amg_residual<S, 0>), dim3(g), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, F.x.p, om, F.dinv.p, F.r.p, ctl);
-        } else {
+        } else if (F.n > 20000) {
             hipLaunchKernelGGL((k_amg_smooth0_residual<S>), dim3(g), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, om, F.dinv.p, F.x.p, F.r.p, ctl);
+        } else {
+            hipLaunchKernelGGL((k_amg_row_wave<S, 2>), dim3((F.n + 3) / 4), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, (const S*)F.x.p, om, F.dinv.p, F.r.p, F.x.p, ctl);
         }
         hipLaunchKernelGGL((k_amg_restrict<S>), dim3(grid_for(C.n)), dim3(kBlock), 0, stream, C.n, F.agg_ptr.p, F.agg_rows.p, F.r.p, C.b.p, ctl);
     }
     AmgLevel<S>& B = *levels.back();
-    if (n_coarsest <= 256) {
+    if (n_coarsest <= kDenseMax) {
         hipLaunchKernelGGL((k_dense_apply<S>), dim3((B.n + 3) / 4), dim3(kBlock), 0, stream, B.n, dense_inv.p, B.b.p, B.x.p, ctl);
     } else {        // coarsening stalled above the dense limit: a few Jacobi sweeps stand in for the coarse solve
         hipLaunchKernelGGL((k_amg_smooth0<S>), dim3(grid_for(B.n)), dim3(kBlock), 0, stream, B.n, om, B.dinv.p, B.b.p, B.x.p, ctl);
@@ -377,7 +434,10 @@ void AmgHierarchy<S>::vcycle(const SolveCtl* ctl)
         AmgLevel<S>& F = *levels[l]; AmgLevel<S>& C = *levels[l + 1];
         const int g = grid_for(F.n);
         hipLaunchKernelGGL((k_amg_prolong<S>), dim3(g), dim3(kBlock), 0, stream, F.n, F.agg.p, C.x.p, F.x.p, ctl);
-        hipLaunchKernelGGL((k_amg_residual<S, 1>), dim3(g), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, F.x.p, om, F.dinv.p, F.x2.p, ctl);
+        if (F.n > 20000)
+            hipLaunchKernelGGL((k_amg_residual<S, 1>), dim3(g), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, F.x.p, om, F.dinv.p, F.x2.p, ctl);
+        else
+            hipLaunchKernelGGL((k_amg_row_wave<S, 1>), dim3((F.n + 3) / 4), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, (const S*)F.x.p, om, F.dinv.p, F.x2.p, (S*)nullptr, ctl);
         std::swap(F.x.p, F.x2.p);       // post-smoothed iterate becomes x (buffers are the same size)
     }
 }

@@ -57,9 +57,11 @@ __device__ __forceinline__ void reduce_partials(const double* const (&arr)[NV], 
 // chunks so that a reducing launch has at most kMaxPart workgroups.  mask (multi-GPU): rows that are
 // not owned produce 0.
 //
-// pin != nullptr (single GPU, x = M^-1 pin with the ILU0 of THIS matrix): for the n0 level-0 rows the
-// product is known in closed form.  Such a row has no lower entries, so U_ij = A_ij and Dinv_i = A_ii^-1, and
-//   x_i = A_ii^-1 (w pin_i - sum_j A_ij x_j)   =>   (A x)_i = A_ii x_i + sum_j A_ij x_j = w pin_i .
+// pin != nullptr (single GPU, x = M^-1 pin where the last stage of M^-1 is the ILU0 of THIS matrix): for the n0
+// level-0 rows the product is known in closed form.  Such a row has no lower entries, so U_ij = A_ij and
+// Dinv_i = A_ii^-1; with x = c + ILU0^-1 z  (ILU0 alone: c = 0, z = pin;  CPR: c = [x_p;0;0], z = pin - A c)
+//   (ILU0^-1 z)_i = A_ii^-1 (w z_i - sum_j A_ij (ILU0^-1 z)_j)  =>  (A ILU0^-1 z)_i = w z_i
+//   (A x)_i = (A c)_i + w z_i = (pin_i - z_i) + w z_i = pin_i - (1 - w) z_i .
 // Those rows (half of all rows with the 2-colour ordering) need no matrix traffic.  Light and heavy rows
 // are chunked separately so that every XCD gets the same share of both.
 template <class S, int NDOT>
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(int xm, int nb, int nbp, const 
                                                  const S* __restrict__ x, S* __restrict__ y,
                                                  const S* __restrict__ w1, const int8_t* __restrict__ mask,
                                                  const SolveCtl* __restrict__ ctl, double* __restrict__ p0, double* __restrict__ p1,
-                                                 const S* __restrict__ pin, int n0, S w)
+                                                 const S* __restrict__ pin, const S* __restrict__ zin, int n0, S w)
 {
     __shared__ double sm[8];
     if (ctl && ctl->done) return;
@@ -79,7 +81,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv(int xm, int nb, int nbp, const 
         for (int ch = xcd_first(nchunks, xm); ch < xcd_end(nchunks, xm); ch += xcd_stride(xm)) {
             const int row = ch * kBlock + threadIdx.x;
             if (row >= nlight) continue;
-            const S y0 = w * pin[row], y1 = w * pin[nbp + row], y2 = w * pin[2 * nbp + row];
+            const S om = S(1) - w;
+            const S y0 = pin[row] - om * zin[row], y1 = pin[nbp + row] - om * zin[nbp + row], y2 = pin[2 * nbp + row] - om * zin[2 * nbp + row];
             y[row] = y0; y[nbp + row] = y1; y[2 * nbp + row] = y2;
             if (NDOT >= 1) acc[0] += double(w1[row]) * double(y0) + double(w1[nbp + row]) * double(y1) + double(w1[2 * nbp + row]) * double(y2);
             if (NDOT == 2) acc[1] += double(y0) * double(y0) + double(y1) * double(y1) + double(y2) * double(y2);
@@ -216,11 +219,17 @@ template <class S>
 __global__ __launch_bounds__(kBlock) void k_ilu_factor(int lo, int hi, const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
                                                        const int16_t* __restrict__ nlower, const int32_t* __restrict__ trip_ptr,
                                                        const int32_t* __restrict__ trip_l, const int32_t* __restrict__ trip_u,
-                                                       const int32_t* __restrict__ trip_t, S* __restrict__ lu, int32_t* __restrict__ flags)
+                                                       const int32_t* __restrict__ trip_t, const S* __restrict__ A, const int16_t* __restrict__ rowlen,
+                                                       S* __restrict__ lu, int32_t* __restrict__ flags)
 {
     const int row = lo + blockIdx.x * kBlock + threadIdx.x;
     if (row >= hi) return;
     const int base = slice_ptr[row >> 6], lane = row & 63, nl = nlower[row];
+    // this row of LU starts as a copy of the row of A (fused here instead of a separate 2 x matrix-size device copy)
+    for (int k = 0, len = rowlen[row]; k < len; ++k) {
+        const int32_t e = (base + k) * 64 + lane;
+        S t[9]; ld9(A, e, t); st9(lu, e, t);
+    }
     int tp = trip_ptr[row];
     const int te = trip_ptr[row + 1];
     for (int k = 0; k < nl; ++k) {
@@ -452,7 +461,7 @@ __global__ __launch_bounds__(kBlock) void k_cpr_sum_eqs(int nb, int nbp, const S
 template <class S>
 __global__ __launch_bounds__(kBlock) void k_cpr_presidual(int xm, int nb, int nbp, const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
                                                           const S* __restrict__ val, const S* __restrict__ d, const S* __restrict__ xp,
-                                                          S* __restrict__ z, const SolveCtl* __restrict__ ctl)
+                                                          S* __restrict__ z, const int8_t* __restrict__ mask, const SolveCtl* __restrict__ ctl)
 {
     if (ctl && ctl->done) return;
     const int nchunks = (nb + kBlock - 1) / kBlock;
@@ -463,6 +472,7 @@ __global__ __launch_bounds__(kBlock) void k_cpr_presidual(int xm, int nb, int nb
     const int base = slice_ptr[row >> 6], width = slice_ptr[(row >> 6) + 1] - base, lane = row & 63;
     const S* __restrict__ v = val + vidx(base, lane);
     const int32_t* __restrict__ c = col + long(base) * 64 + lane;
+    if (mask && !mask[row]) { z[row] = 0; z[nbp + row] = 0; z[2 * long(nbp) + row] = 0; return; }     // ghost rows stay zero (block-Jacobi second stage)
     S z0 = d[row], z1 = d[nbp + row], z2 = d[2 * long(nbp) + row];
     for (int k = 0; k < width; ++k) {
         const S x0 = xp[c[k * 64]];
@@ -591,7 +601,7 @@ template <class S> void LinSolver::ensure_work()
     const size_t nv = size_t(3) * plan.nbp, nm = size_t(plan.nentries) * 9;
     if (sizeof(S) == 4) { w.A.alloc(nm); w.A.zero(stream); }
     w.LU.alloc(nm); w.LU.zero(stream);
-    DevArray<S>* vs[] = { &w.r, &w.rt, &w.p, &w.v, &w.t, &w.y, &w.x, &w.b, &w.z };
+    DevArray<S>* vs[] = { &w.r, &w.rt, &w.p, &w.v, &w.t, &w.y, &w.x, &w.b, &w.z, &w.hx };
     for (DevArray<S>* a : vs) { a->alloc(nv); a->zero(stream); }
     w.amg.reset();
     w.allocated = true;
@@ -618,14 +628,12 @@ template <> const float* LinSolver::matrix<float>() { return wf.A.p; }
 template <class S> int LinSolver::factor()
 {
     SolverWork<S>& w = work<S>();
-    const size_t bytes = size_t(plan.nentries) * 9 * sizeof(S);
-    OPMGPU_HIP(hipMemcpyAsync(w.LU.p, matrix<S>(), bytes, hipMemcpyDeviceToDevice, stream));
     flags.zero(stream);
     for (int l = 0; l < plan.nlevels; ++l) {
         const int lo = plan.level_ptr[l], hi = plan.level_ptr[l + 1];
         if (hi == lo) continue;
         hipLaunchKernelGGL((k_ilu_factor<S>), dim3(grid_for(hi - lo)), dim3(kBlock), 0, stream, lo, hi, dp.slice_ptr.p, dp.col.p,
-                           dp.nlower.p, dp.trip_ptr.p, dp.trip_l.p, dp.trip_u.p, dp.trip_t.p, w.LU.p, flags.p);
+                           dp.nlower.p, dp.trip_ptr.p, dp.trip_l.p, dp.trip_u.p, dp.trip_t.p, matrix<S>(), dp.rowlen.p, w.LU.p, flags.p);
     }
     OPMGPU_HIP(hipMemcpyAsync(h_flags, flags.p, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     OPMGPU_HIP(hipStreamSynchronize(stream));
@@ -661,8 +669,11 @@ template <class S> void LinSolver::spmv(const S* x, S* y)
     const int g = std::min(grid8_for(plan.nb), 4 * kMaxPart);
     hipLaunchKernelGGL((k_spmv<S, 0>), dim3(g), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p,
                        matrix<S>(), x, y, (const S*)nullptr, comm ? comm->owner_mask() : (const int8_t*)nullptr, (const SolveCtl*)nullptr,
-                       (double*)nullptr, (double*)nullptr, (const S*)nullptr, 0, S(0));
+                       (double*)nullptr, (double*)nullptr, (const S*)nullptr, (const S*)nullptr, 0, S(0));
 }
+
+static void halo_dispatch(CommBase* c, float* v, hipStream_t s) { c->halo_exchange_f(v, s); }
+static void halo_dispatch(CommBase* c, double* v, hipStream_t s) { c->halo_exchange_d(v, s); }
 
 template <class S> void LinSolver::cpr_prepare()
 {
@@ -691,10 +702,18 @@ template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, con
     const int g = grid_for(plan.nb);
     hipLaunchKernelGGL((k_cpr_sum_eqs<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, plan.nbp, d, L0.b.p, ctl);
     w.amg->vcycle(ctl);
+    const S* xp = L0.x.p;
+    if (comm) {
+        // multi-GPU: the AMG is rank-local (additive Schwarz: ghost rows are identity rows); the owners' x_p is copied
+        // to the ghosts before the full-system residual so that stage 2 sees a consistent pressure correction
+        OPMGPU_HIP(hipMemcpyAsync(w.hx.p, L0.x.p, size_t(plan.nb) * sizeof(S), hipMemcpyDeviceToDevice, stream));
+        halo_dispatch(comm, w.hx.p, stream);
+        xp = w.hx.p;
+    }
     hipLaunchKernelGGL((k_cpr_presidual<S>), dim3(grid8_for(plan.nb)), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p,
-                       matrix<S>(), d, (const S*)L0.x.p, w.z.p, ctl);
+                       matrix<S>(), d, xp, w.z.p, comm ? comm->owner_mask() : (const int8_t*)nullptr, ctl);
     ilu_apply<S>(w.z.p, v, relax, ctl);
-    hipLaunchKernelGGL((k_cpr_add_p<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, (const S*)L0.x.p, v, ctl);
+    hipLaunchKernelGGL((k_cpr_add_p<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, xp, v, ctl);
 }
 
 template <class S> static void halo(CommBase* c, S* v, hipStream_t s);
@@ -713,10 +732,11 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
     const int8_t* mask = comm ? comm->owner_mask() : nullptr;
     // closed form of (A M^-1 p) on the level-0 rows -- valid when M is the ILU0 of exactly this matrix and the ghost
     // entries of M^-1 p are not overwritten by a halo exchange, i.e. single GPU
-    const bool cpr = prm.use_cpr != 0 && !comm;          // CPR is single-GPU for now; multi-GPU falls back to block-Jacobi ILU0
+    const bool cpr = prm.use_cpr != 0;                   // multi-GPU: rank-local (additive Schwarz) AMG + block-Jacobi ILU0
     if (cpr) cpr_prepare<S>();
-    const bool closed = !comm && closed_form_level0 && !cpr;
+    const bool closed = !comm && closed_form_level0;
     const S* pin_p = closed ? w.p.p : nullptr; const S* pin_r = closed ? w.r.p : nullptr;
+    const S* zin_p = cpr ? w.z.p : pin_p; const S* zin_r = cpr ? w.z.p : pin_r;     // second-stage input of the last M^-1
     const int n0 = plan.level_ptr[1];
     double* P_h = partials.p, *P_n1 = P_h + npart, *P_tr = P_n1 + npart, *P_tt = P_tr + npart, *P_n2 = P_tt + npart, *P_rho = P_n2 + npart;
     double* red = P_rho + npart;                               // 8 all-reduced scalars (multi-GPU)
@@ -746,7 +766,7 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
         if (cpr) cpr_apply<S>(w.p.p, w.y.p, prm.ilu_relaxation, d_ctl); else ilu_apply<S>(w.p.p, w.y.p, prm.ilu_relaxation, d_ctl);
         if (comm) halo<S>(comm, w.y.p, stream);
         hipLaunchKernelGGL((k_spmv<S, 1>), dim3(gs), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p, matrix<S>(),
-                           w.y.p, w.v.p, w.rt.p, mask, (const SolveCtl*)d_ctl, P_h, (double*)nullptr, pin_p, n0, S(prm.ilu_relaxation));
+                           w.y.p, w.v.p, w.rt.p, mask, (const SolveCtl*)d_ctl, P_h, (double*)nullptr, pin_p, zin_p, n0, S(prm.ilu_relaxation));
         double* a_h = P_h; int np_h = gs; none = nullptr;
         bridge(a_h, none, np_h, 1);
         hipLaunchKernelGGL((k_update_xr1<S>), dim3(gv), dim3(kBlock), 0, stream, n, j, eps, d_ctl, h_ctl_dev, (const double*)a_h, np_h, w.y.p, w.v.p,
@@ -756,7 +776,7 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
         if (cpr) cpr_apply<S>(w.r.p, w.y.p, prm.ilu_relaxation, d_ctl); else ilu_apply<S>(w.r.p, w.y.p, prm.ilu_relaxation, d_ctl);
         if (comm) halo<S>(comm, w.y.p, stream);
         hipLaunchKernelGGL((k_spmv<S, 2>), dim3(gs), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p, matrix<S>(),
-                           w.y.p, w.t.p, w.r.p, mask, (const SolveCtl*)d_ctl, P_tr, P_tt, pin_r, n0, S(prm.ilu_relaxation));
+                           w.y.p, w.t.p, w.r.p, mask, (const SolveCtl*)d_ctl, P_tr, P_tt, pin_r, zin_r, n0, S(prm.ilu_relaxation));
         double* a_tr = P_tr; double* a_tt = P_tt; int np_t = gs;
         bridge(a_tr, a_tt, np_t, 3);
         hipLaunchKernelGGL((k_update_xr2<S>), dim3(gv), dim3(kBlock), 0, stream, n, j, d_ctl, h_ctl_dev, (const double*)a_n1, (const double*)a_tr,

@@ -51,7 +51,7 @@ template <class S>
 struct SolverWork {
     DevArray<S> A;      // float copy of the matrix (unused for double: the double matrix is used in place)
     DevArray<S> LU;
-    DevArray<S> r, rt, p, v, t, y, x, b, z;      // z: scratch of the CPR second stage
+    DevArray<S> r, rt, p, v, t, y, x, b, z, hx;  // z: scratch of the CPR second stage; hx: halo staging of x_p (multi-GPU)
     std::unique_ptr<AmgHierarchy<S>> amg;         // CPR pressure stage (built on first use)
     bool allocated = false;
 };

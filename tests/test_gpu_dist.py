@@ -38,14 +38,15 @@ class _Dom:
     pass
 
 
+@pytest.mark.parametrize("cpr", [0, 1])
 @pytest.mark.parametrize("single", [False, True])
-def test_self_halo_reproduces_plain_grid(gpu_lib, oracle, single):
+def test_self_halo_reproduces_plain_grid(gpu_lib, oracle, single, cpr):
     gridA, gridB, src, halo = _periodic_pair()
     tab = decks.satfunc_standard_tables()
     stA = decks.initial_state(gridA, tab, perturb=0.01)
     stB = decks.State(stA.p[src], stA.sat[src], stA.rs[src], stA.rv[src], stA.hc[src])
     red = 1e-4 if single else 1e-11
-    prm = capi.default_params(linear_solver_reduction=red, linear_solver_maxiter=400)
+    prm = capi.default_params(linear_solver_reduction=red, linear_solver_maxiter=400, use_cpr=cpr)
     dt = 5 * decks.DAY
     n = gridA.nc
     A = GpuBlackoilModel(gridA, tab, prm)
