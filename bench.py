@@ -79,41 +79,56 @@ def main():
         info = {"n_owned": grid.nc, "n_global": grid.nc}
     nc_global = info["n_global"]
 
-    # ---- timed region: exactly K Newton iterations ----
-    model.prepareStep(dt, st)
-    it = 0
-    newton_total, lin_total, steps_done = 0, 0, 0
-    t_asm = t_sol = t_upd = 0.0
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    t0 = None
-    for step in range(args.warmup + args.steps):
-        if step == args.warmup:
-            barrier()
-            t0 = time.perf_counter()
-            lin_total = 0
-            t_asm = t_sol = t_upd = 0.0
-        converged, lin = model.nonlinearIteration(it)
-        a, s, u = model.timings()
-        t_asm += a; t_sol += s; t_upd += u
-        lin_total += lin
-        it += 1
-        if (converged and it >= 1) or it > 10:
-            model.prepareStep(dt)           # next time step from the resident state
-            it = 0
-            steps_done += 1
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    def timed_run(model):
+        """exactly K timed Newton iterations after W warm-up ones; time steps follow each other like in the simulator"""
+        model.prepareStep(dt, st)
+        it, lin_total, steps_done = 0, 0, 0
+        t_asm = t_sol = t_upd = 0.0
+        t0 = None
+        for step in range(args.warmup + args.steps):
+            if step == args.warmup:
+                barrier()
+                t0 = time.perf_counter()
+                lin_total = 0
+                t_asm = t_sol = t_upd = 0.0
+            converged, lin = model.nonlinearIteration(it)
+            a, s, u = model.timings()
+            t_asm += a; t_sol += s; t_upd += u
+            lin_total += lin
+            it += 1
+            if (converged and it >= 1) or it > 10:
+                model.prepareStep(dt)           # next time step from the resident state
+                it = 0
+                steps_done += 1
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        return {"elapsed": elapsed, "lin": lin_total / args.steps, "steps_done": steps_done,
+                "breakdown": {"assemble": t_asm / args.steps, "linear_solve": t_sol / args.steps, "update": t_upd / args.steps}}
+
+    # ---- timed region: exactly K Newton iterations ----
+    res = timed_run(model)
+    elapsed, steps_done = res["elapsed"], res["steps_done"]
     ms_per_step = 1e3 * elapsed / args.steps
     value = nc_global / (elapsed / args.steps) / 1e6
+    # the same K iterations with the reference's DEFAULT linear solver (solver_approach=interleaved: ILU0 + BiCGStab),
+    # which is also what the CPU baseline runs
+    ilu0 = None
+    if world == 1 and prm.use_cpr:
+        prm0 = capi.default_params(ilu_ordering=ordering, use_cpr=0)
+        m0 = GpuBlackoilModel(grid, tab, prm0, device=local_rank)
+        r0 = timed_run(m0)
+        m0.close()
+        ilu0 = {"value": nc_global / (r0["elapsed"] / args.steps) / 1e6, "ms_per_step": 1e3 * r0["elapsed"] / args.steps,
+                "linear_iterations_per_newton": r0["lin"], "breakdown_ms_per_step": r0["breakdown"]}
 
     out = None
     if rank == 0:
@@ -144,7 +159,9 @@ def main():
             try:
                 d = json.load(open(pmc))
                 for name in roof:
-                    roof[name]["traffic"] = d.get(name)
+                    if name in d:      # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE), profiles/r01_pmc_spmv.json
+                        roof[name]["traffic"] = d[name]["hbm_bytes_per_launch"]
+                        roof[name]["traffic_over_algorithmic"] = d[name]["traffic_over_algorithmic"]
             except Exception:
                 pass
         main_roof = roof["f32" if single else "f64"]
@@ -159,10 +176,11 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64 assembly + %s linear solve" % ("f32" if single else "f64"), "data": "synthetic",
             "config": {"workload": "cart%dx%dx%d_3phase_blackoil" % (args.nx, args.ny, args.nz), "cells": nc_global, "nnzb": nnzb,
-                       "dt_days": args.dt_days, "linear_solver": ("cpr(amg V-cycle + ilu0)" if prm.use_cpr else "ilu0") + " + bicgstab", "ilu0_ordering": args.ordering, "linear_iterations_per_newton": lin_total / args.steps,
+                       "dt_days": args.dt_days, "linear_solver": ("cpr(amg V-cycle + ilu0)" if prm.use_cpr else "ilu0") + " + bicgstab", "ilu0_ordering": args.ordering, "linear_iterations_per_newton": res["lin"],
                        "time_steps_completed": steps_done, "tables": "tests/satfuncStandard.DATA PROPS (reference's own test deck)",
                        "parallelism": "1 GPU" if world == 1 else "domain decomposition x%d, RCCL halo" % world},
-            "breakdown_ms_per_step": {"assemble": t_asm / args.steps, "linear_solve": t_sol / args.steps, "update": t_upd / args.steps},
+            "breakdown_ms_per_step": res["breakdown"],
+            "same_run_with_reference_default_solver_ilu0": ilu0,
             "roofline": main_roof, "roofline_f64_spmv": roof["f64"], "roofline_f32_spmv": roof["f32"],
             "cpu_baseline": cpu,
         }

@@ -162,6 +162,7 @@ int opmgpu_assemble(opmgpu_ctx* c, double dt, int initial, const double* p, cons
             c->model->set_state(p, sat, rs, rv, hc);
         }
         if (!c->model->has_state) return fail(c, OPMGPU_EINVAL, "no reservoir state on the device");
+        c->t_solve = 0.0; c->t_update = 0.0;       // a Newton iteration that converges here runs no solve / update
         {
             Timed t(c, &c->t_assemble);
             c->model->assemble(dt, initial != 0);
