@@ -64,6 +64,10 @@ typedef struct opmgpu_grid {
     const double*  thpres;      /* [nconn] threshold pressures by connection, or NULL           */
     const int32_t* pvtnum;      /* [nc] 0-based PVT region (cellPvtRegionIdx_), or NULL (=0)    */
     const int32_t* satnum;      /* [nc] 0-based saturation region, or NULL (=0)                 */
+    /* ENDSCALE (two-point saturation scaling, SCALECRS NO): per-cell scaled end points as opm-material's
+     * EclEpsScalingPointsInfo holds them (materialLawParams(cell), SaturationPropsFromDeck.cpp:91-92).  Either all
+     * eight are given or all are NULL (no end-point scaling).  Order: SWL SWCR SWU SOWCR SGL SGCR SGU SOGCR. */
+    const double*  eps[8];
 } opmgpu_grid;
 
 /* Fluid tables, already converted to SI and pre-processed the way opm-material stores

@@ -92,13 +92,40 @@ __device__ __forceinline__ void rv_sat_d(const opmgpu_tables& T, int reg, double
     pvt1(T.gas_pg + a, T.gas_rvsat + a, T.gas_node_ptr[reg + 1] - a, p, f, df);
 }
 
+// ENDSCALE (two-point): per curve S_unscaled = u0 + (S - s0) * k with k = (u2 - u0) / (s2 - s0) precomputed on the host
+// (BlackoilDevice::rebuild_structure).  Curve order: krw, krow, pcow, krg, krog (in oil saturation), pcgo.
+enum { EC_KRW = 0, EC_KROW, EC_PCOW, EC_KRG, EC_KROG, EC_PCGO, EC_COUNT };
+struct EpsD {
+    bool on;
+    double u0[EC_COUNT], s0[EC_COUNT], k[EC_COUNT];
+};
+// eps: 12 planes [s0 x6 | k x6] of stride nbp (nullptr = no ENDSCALE); u0: [n_sat_regions][6]
+__device__ __forceinline__ void eps_load(const double* __restrict__ eps, const double* __restrict__ u0, long nbp, int row, int sreg, EpsD& e)
+{
+    e.on = eps != nullptr;
+    if (!e.on) return;
+#pragma unroll
+    for (int c = 0; c < EC_COUNT; ++c) {
+        e.u0[c] = u0[EC_COUNT * sreg + c];
+        e.s0[c] = eps[long(c) * nbp + row];
+        e.k[c] = eps[long(EC_COUNT + c) * nbp + row];
+    }
+}
+template <bool RIGHT>
+__device__ __forceinline__ void sat_curve(const double* __restrict__ x, const double* __restrict__ y, int n, double sv, const EpsD& e, int c, double& f, double& df)
+{
+    if (!e.on) { sat_eval<RIGHT>(x, y, n, sv, f, df); return; }
+    sat_eval<RIGHT>(x, y, n, e.u0[c] + (sv - e.s0[c]) * e.k[c], f, df);
+    df *= e.k[c];
+}
+
 struct CellEval {
     V4 pw, pg, rs, rv, sw, so, sg;
     V4 b[3], mob[3], rho[3], accum[3];
 };
 
 // SolutionState + ReservoirResidualQuant of one cell (BlackoilModelBase_impl.hpp:614-751, 1484-1497, 2009-2027)
-__device__ void eval_cell(const opmgpu_tables& T, int preg, int sreg, double p, double sw_, double sg_, double rs_, double rv_, int hc, CellEval& q)
+__device__ void eval_cell(const opmgpu_tables& T, const EpsD& E, int preg, int sreg, double p, double sw_, double sg_, double rs_, double rv_, int hc, CellEval& q)
 {
     const bool isSg = hc == OPMGPU_HC_GAS_AND_OIL, isRs = hc == OPMGPU_HC_OIL_ONLY, isRv = hc == OPMGPU_HC_GAS_ONLY;
     const bool freeOil = isSg || isRs, freeGas = isSg || isRv;
@@ -115,23 +142,27 @@ __device__ void eval_cell(const opmgpu_tables& T, int preg, int sreg, double p, 
     const int ga = T.sgof_ptr[sreg], ng = T.sgof_ptr[sreg + 1] - ga;
     const double* xsw = T.swof_sw + wa; const double* xsg = T.sgof_sg + ga;
     double f, df;
-    sat_eval<false>(xsw, T.swof_pcow + wa, nw, sw_, f, df);
+    sat_curve<false>(xsw, T.swof_pcow + wa, nw, sw_, E, EC_PCOW, f, df);
     q.pw = mk(p - f, 1, -df, 0);
-    sat_eval<true>(xsg, T.sgof_pcgo + ga, ng, sg.v, f, df);
+    sat_curve<true>(xsg, T.sgof_pcgo + ga, ng, sg.v, E, EC_PCGO, f, df);
     q.pg = mk(p + f, 1, df * sg.w, df * sg.x);
-    sat_eval<false>(xsw, T.swof_krw + wa, nw, sw_, f, df);
+    sat_curve<false>(xsw, T.swof_krw + wa, nw, sw_, E, EC_KRW, f, df);
     const V4 krw = mk(f, 0, df, 0);
-    sat_eval<true>(xsg, T.sgof_krg + ga, ng, sg.v, f, df);
+    sat_curve<true>(xsg, T.sgof_krg + ga, ng, sg.v, E, EC_KRG, f, df);
     const V4 krg = vchain(f, df, sg);
     V4 kro;
     {   // EclDefaultMaterial::krn
-        const double swco = xsw[0];
+        const double swco = E.on ? E.s0[EC_PCOW] : xsw[0];      // (scaled) connate water
         const V4 swp = (sw_ > swco) ? W : mk(swco, 0, 0, 0);
         const V4 swow = vadd(sg, swp);
-        sat_eval<false>(xsw, T.swof_krow + wa, nw, swow.v, f, df);
+        sat_curve<false>(xsw, T.swof_krow + wa, nw, swow.v, E, EC_KROW, f, df);
         const V4 kow = vchain(f, df, swow);
         const V4 sgeq = mk(swow.v - swco, swow.p, swow.w, swow.x);
-        sat_eval<true>(xsg, T.sgof_krog + ga, ng, sgeq.v, f, df);
+        if (E.on) {     // krog is tabulated against the oil saturation 1 - Swco_table - Sg; the scaling acts on that axis
+            const double so_u = E.u0[EC_KROG] + ((1.0 - swow.v) - E.s0[EC_KROG]) * E.k[EC_KROG];
+            sat_eval<true>(xsg, T.sgof_krog + ga, ng, 1.0 - xsw[0] - so_u, f, df);
+            df *= E.k[EC_KROG];
+        } else sat_eval<true>(xsg, T.sgof_krog + ga, ng, sgeq.v, f, df);
         const V4 kgo = vchain(f, df, sgeq);
         const double eps = 1e-5;
         const V4 den = sgeq;                                    // Sw_ow - Swco
@@ -230,13 +261,16 @@ __global__ __launch_bounds__(kBlock) void k_cell_props(int nb, int nbp, opmgpu_t
                                                        const double* __restrict__ rs, const double* __restrict__ rv, const int8_t* __restrict__ hc,
                                                        double inv_dt, int initial, double s0, double s1, double s2,
                                                        const int32_t* __restrict__ slice_ptr, const int16_t* __restrict__ nlower,
+                                                       const double* __restrict__ eps, const double* __restrict__ eps_u0,
                                                        double* __restrict__ props, double* __restrict__ accum0, double* __restrict__ R,
                                                        double* __restrict__ binv, double* __restrict__ A)
 {
     const int row = blockIdx.x * kBlock + threadIdx.x;
     if (row >= nb) return;
     CellEval q;
-    eval_cell(T, pvtnum[row], satnum[row], p[row], sw[row], sg[row], rs[row], rv[row], hc[row], q);
+    EpsD E;
+    eps_load(eps, eps_u0, nbp, row, satnum[row], E);
+    eval_cell(T, E, pvtnum[row], satnum[row], p[row], sw[row], sg[row], rs[row], rv[row], hc[row], q);
     props[long(PL_PW) * nbp + row] = q.pw.v; props[long(PL_PG) * nbp + row] = q.pg.v;
     props[long(PL_DPW_W) * nbp + row] = q.pw.w; props[long(PL_DPG_W) * nbp + row] = q.pg.w; props[long(PL_DPG_X) * nbp + row] = q.pg.x;
 #pragma unroll
@@ -442,7 +476,8 @@ __global__ __launch_bounds__(kBlock) void k_update_state(int nb, int nbp, opmgpu
                                                          const int32_t* __restrict__ satnum, const double* __restrict__ dx, double relax,
                                                          double dp_max_rel, double ds_max, double dr_max_rel,
                                                          double* __restrict__ p, double* __restrict__ sw, double* __restrict__ so,
-                                                         double* __restrict__ sg, double* __restrict__ rs, double* __restrict__ rv, int8_t* __restrict__ hc)
+                                                         double* __restrict__ sg, double* __restrict__ rs, double* __restrict__ rv, int8_t* __restrict__ hc,
+                                                         const double* __restrict__ eps_planes, const double* __restrict__ eps_u0)
 {
     const int c = blockIdx.x * kBlock + threadIdx.x;
     if (c >= nb) return;
@@ -486,8 +521,10 @@ __global__ __launch_bounds__(kBlock) void k_update_state(int nb, int nbp, opmgpu
     }
     if (T.has_vapoil) {
         const int ga = T.sgof_ptr[sreg], ng = T.sgof_ptr[sreg + 1] - ga;
-        sat_eval<true>(T.sgof_sg + ga, T.sgof_pcgo + ga, ng, sg_old, f, df); const double pg_old = p_old + f;
-        sat_eval<true>(T.sgof_sg + ga, T.sgof_pcgo + ga, ng, g_, f, df); const double pg_new = pn + f;
+        EpsD E;
+        eps_load(eps_planes, eps_u0, nbp, c, sreg, E);
+        sat_curve<true>(T.sgof_sg + ga, T.sgof_pcgo + ga, ng, sg_old, E, EC_PCGO, f, df); const double pg_old = p_old + f;
+        sat_curve<true>(T.sgof_sg + ga, T.sgof_pcgo + ga, ng, g_, E, EC_PCGO, f, df); const double pg_new = pn + f;
         rv_sat_d(T, preg, pg_old, f, df); const double rvSat0 = f;
         rv_sat_d(T, preg, pg_new, f, df); const double rvSat = f;
         const bool hasOil = (o_ > 0 && !isRv);
@@ -525,13 +562,16 @@ __global__ __launch_bounds__(kBlock) void k_gather_perf3(int nperf, int nbp, con
 __global__ __launch_bounds__(kBlock) void k_perf_props(int nperf, opmgpu_tables T, const int32_t* __restrict__ cells, const int32_t* __restrict__ pvtnum,
                                                        const int32_t* __restrict__ satnum, const double* __restrict__ p, const double* __restrict__ sw,
                                                        const double* __restrict__ sg, const double* __restrict__ rs, const double* __restrict__ rv,
-                                                       const int8_t* __restrict__ hc, double* __restrict__ out)
+                                                       const int8_t* __restrict__ hc, const double* __restrict__ eps,
+                                                       const double* __restrict__ eps_u0, long nbp, double* __restrict__ out)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= nperf) return;
     const int c = cells[i];
     CellEval q;
-    eval_cell(T, pvtnum[c], satnum[c], p[c], sw[c], sg[c], rs[c], rv[c], hc[c], q);
+    EpsD E;
+    eps_load(eps, eps_u0, nbp, c, satnum[c], E);
+    eval_cell(T, E, pvtnum[c], satnum[c], p[c], sw[c], sg[c], rs[c], rv[c], hc[c], q);
     const V4 list[9] = { mk(p[c], 1, 0, 0), q.rs, q.rv, q.b[0], q.b[1], q.b[2], q.mob[0], q.mob[1], q.mob[2] };
     double* o = out + long(i) * OPMGPU_PERF_K;
 #pragma unroll
@@ -579,6 +619,12 @@ BlackoilDevice::BlackoilDevice(hipStream_t s, LinSolver& ls_, const opmgpu_grid*
     h_pvtnum.assign(nc, 0); h_satnum.assign(nc, 0);
     if (g->pvtnum) h_pvtnum.assign(g->pvtnum, g->pvtnum + nc);
     if (g->satnum) h_satnum.assign(g->satnum, g->satnum + nc);
+    use_eps = g->eps[0] != nullptr;
+    if (use_eps)
+        for (int k = 0; k < 8; ++k) {
+            if (!g->eps[k]) throw HipError(OPMGPU_EINVAL, "ENDSCALE needs all eight end-point arrays (SWL SWCR SWU SOWCR SGL SGCR SGU SOGCR)");
+            h_eps[k].assign(g->eps[k], g->eps[k] + nc);
+        }
     pvsum = 0.0;
     for (int c = 0; c < nc; ++c) pvsum += h_pv[c];
     upload_tables(t);
@@ -624,6 +670,19 @@ void BlackoilDevice::upload_tables(const opmgpu_tables* t)
     dt_.swof_sw = upd(t->swof_sw, nsw); dt_.swof_krw = upd(t->swof_krw, nsw); dt_.swof_krow = upd(t->swof_krow, nsw); dt_.swof_pcow = upd(t->swof_pcow, nsw);
     dt_.sgof_ptr = upi(t->sgof_ptr, ns + 1);
     dt_.sgof_sg = upd(t->sgof_sg, nsg); dt_.sgof_krg = upd(t->sgof_krg, nsg); dt_.sgof_krog = upd(t->sgof_krog, nsg); dt_.sgof_pcgo = upd(t->sgof_pcgo, nsg);
+    // unscaled end points of every saturation region (what opm-material's EclEpsScalingPointsInfo::extractUnscaled reads off the
+    // tables): Swl Swcr Swu Sowcr Sgl Sgcr Sgu Sogcr
+    h_unscaled.assign(8 * size_t(ns), 0.0);
+    for (int r = 0; r < ns; ++r) {
+        const int a = t->swof_ptr[r], nw = t->swof_ptr[r + 1] - a, b = t->sgof_ptr[r], ng = t->sgof_ptr[r + 1] - b;
+        auto last_zero = [](const double* x, const double* y, int n) { int i = 0; while (i + 1 < n && y[i + 1] == 0.0) ++i; return x[i]; };
+        auto first_zero = [](const double* x, const double* y, int n) { int i = 0; while (i < n - 1 && y[i] != 0.0) ++i; return x[i]; };
+        double* u = &h_unscaled[8 * size_t(r)];
+        u[0] = t->swof_sw[a]; u[1] = last_zero(t->swof_sw + a, t->swof_krw + a, nw); u[2] = t->swof_sw[a + nw - 1];
+        u[3] = 1.0 - first_zero(t->swof_sw + a, t->swof_krow + a, nw);
+        u[4] = t->sgof_sg[b]; u[5] = last_zero(t->sgof_sg + b, t->sgof_krg + b, ng); u[6] = t->sgof_sg[b + ng - 1];
+        u[7] = 1.0 - first_zero(t->sgof_sg + b, t->sgof_krog + b, ng);
+    }
     OPMGPU_HIP(hipStreamSynchronize(stream));
 }
 
@@ -647,6 +706,33 @@ void BlackoilDevice::rebuild_structure()
     std::vector<double> pvi(nbp, 1.0); std::vector<int32_t> pn(nbp, 0), sn(nbp, 0);
     for (int r = 0; r < nc; ++r) { pvi[r] = h_pv[P.nat[r]]; pn[r] = h_pvtnum[P.nat[r]]; sn[r] = h_satnum[P.nat[r]]; }
     d_pv.upload(pvi, stream); d_pvtnum.upload(pn, stream); d_satnum.upload(sn, stream);
+    if (use_eps) {
+        // two-point scaling maps per cell and curve: (scaled s0, slope k); the unscaled u0 is per region
+        const int ns = dt_.n_sat_regions;
+        std::vector<double> u0(size_t(EC_COUNT) * ns), ep(size_t(2 * EC_COUNT) * nbp, 0.0);
+        for (int r = 0; r < ns; ++r) {
+            const double* u = &h_unscaled[8 * size_t(r)];
+            double* o = &u0[size_t(EC_COUNT) * r];
+            o[EC_KRW] = u[1]; o[EC_KROW] = u[0] + u[4]; o[EC_PCOW] = u[0]; o[EC_KRG] = u[5]; o[EC_KROG] = u[7]; o[EC_PCGO] = u[4];
+        }
+        for (int r = 0; r < nbp; ++r) {
+            const int c = r < nc ? P.nat[r] : -1;
+            const double* u = &h_unscaled[8 * size_t(c < 0 ? 0 : h_satnum[c])];
+            double e[8];
+            for (int k = 0; k < 8; ++k) e[k] = c < 0 ? u[k] : h_eps[k][c];
+            const double SWL = e[0], SWCR = e[1], SWU = e[2], SOWCR = e[3], SGL = e[4], SGCR = e[5], SGU = e[6], SOGCR = e[7];
+            const double s0[EC_COUNT] = { SWCR, SWL + SGL, SWL, SGCR, SOGCR, SGL };
+            const double s2[EC_COUNT] = { SWU, 1.0 - SOWCR - SGL, SWU, SGU, 1.0 - SWL - SGL, SGU };
+            const double u0c[EC_COUNT] = { u[1], u[0] + u[4], u[0], u[5], u[7], u[4] };
+            const double u2c[EC_COUNT] = { u[2], 1.0 - u[3] - u[4], u[2], u[6], 1.0 - u[0] - u[4], u[6] };
+            for (int k = 0; k < EC_COUNT; ++k) {
+                if (c >= 0 && !(s2[k] > s0[k])) throw HipError(OPMGPU_EINVAL, "ENDSCALE end points of a cell are not increasing");
+                ep[size_t(k) * nbp + r] = s0[k];
+                ep[size_t(EC_COUNT + k) * nbp + r] = (u2c[k] - u0c[k]) / (s2[k] - s0[k]);
+            }
+        }
+        d_eps.upload(ep, stream); d_eps_u0.upload(u0, stream);
+    }
     std::vector<double> gdz(std::max(nconn, 1), 0.0);
     for (int f = 0; f < nconn; ++f) gdz[f] = gravity * (h_z[h_conn[2 * f]] - h_z[h_conn[2 * f + 1]]);
     d_gdz.upload(gdz, stream);
@@ -728,7 +814,7 @@ void BlackoilDevice::assemble(double dt, bool initial)
     const double* sc = prm.matbalscale;
     hipLaunchKernelGGL(k_cell_props, dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_pv.p,
                        d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, 1.0 / dt, int(initial), sc[0], sc[1], sc[2],
-                       ls.dp.slice_ptr.p, ls.dp.nlower.p, d_props.p, d_accum0.p, d_R.p, d_binv.p, ls.matrix_d());
+                       ls.dp.slice_ptr.p, ls.dp.nlower.p, eps_planes(), d_eps_u0.p, d_props.p, d_accum0.p, d_R.p, d_binv.p, ls.matrix_d());
     hipLaunchKernelGGL(k_flux, dim3(grid8_for(nc)), dim3(kBlock), 0, stream, xcd_mode(), nc, P.nbp, ls.dp.slice_ptr.p, ls.dp.col.p, ls.dp.rowlen.p,
                        ls.dp.nlower.p, d_conn_code.p, d_trans.p, d_gdz.p, use_thpres ? d_thpres.p : (const double*)nullptr,
                        d_p.p, d_props.p, sc[0], sc[1], sc[2], ls.comm ? ls.comm->owner_mask() : (const int8_t*)nullptr, d_R.p, ls.matrix_d());
@@ -745,7 +831,7 @@ double BlackoilDevice::time_assemble(int reps, int props_only)
         if (props_only)
             hipLaunchKernelGGL(k_cell_props, dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_pv.p,
                                d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, 1.0 / dt, 0, sc[0], sc[1], sc[2],
-                               ls.dp.slice_ptr.p, ls.dp.nlower.p, d_props.p, d_accum0.p, d_R.p, d_binv.p, ls.matrix_d());
+                               ls.dp.slice_ptr.p, ls.dp.nlower.p, eps_planes(), d_eps_u0.p, d_props.p, d_accum0.p, d_R.p, d_binv.p, ls.matrix_d());
         else assemble(dt, false);
     };
     launch();
@@ -803,7 +889,7 @@ void BlackoilDevice::perf_props(double* out)
 {
     if (nperf == 0) return;
     hipLaunchKernelGGL(k_perf_props, dim3(grid_for(nperf)), dim3(kBlock), 0, stream, nperf, dt_, d_perf_cells.p, d_pvtnum.p, d_satnum.p,
-                       d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, d_perf.p);
+                       d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, eps_planes(), d_eps_u0.p, long(ls.plan.nbp), d_perf.p);
     OPMGPU_HIP(hipMemcpyAsync(out, d_perf.p, size_t(nperf) * OPMGPU_PERF_K * sizeof(double), hipMemcpyDeviceToHost, stream));
     OPMGPU_HIP(hipStreamSynchronize(stream));
 }
@@ -896,7 +982,7 @@ void BlackoilDevice::update_state(const double* dx_host, double relax)
     const Plan& P = ls.plan;
     if (dx_host) { ls.vec_from_host<double>(dx_host, VEC_EQUATION_MAJOR, d_dx.p); has_dx = true; }
     hipLaunchKernelGGL(k_update_state, dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_dx.p, relax,
-                       prm.dp_max_rel, prm.ds_max, prm.dr_max_rel, d_p.p, d_sw.p, d_so.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p);
+                       prm.dp_max_rel, prm.ds_max, prm.dr_max_rel, d_p.p, d_sw.p, d_so.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, eps_planes(), d_eps_u0.p);
 }
 
 void BlackoilDevice::get_residual(double* r)

@@ -62,6 +62,11 @@ private:
     std::vector<double> h_trans, h_pv, h_z, h_thpres;
     double gravity = 0.0, pvsum = 0.0, pvsum_global = 0.0;
     bool use_thpres = false;
+    // ENDSCALE: per-cell scaled end points (caller numbering), unscaled points per saturation region
+    bool use_eps = false;
+    std::vector<double> h_eps[8], h_unscaled;
+    DevArray<double> d_eps, d_eps_u0;
+    const double* eps_planes() const { return use_eps ? d_eps.p : nullptr; }
     // device: tables
     opmgpu_tables dt_;                       // same struct, device pointers
     std::vector<DevArray<double>*> tab_d;

@@ -26,7 +26,7 @@ _bp = C.POINTER(C.c_int8)
 class Grid(C.Structure):
     _fields_ = [("nc", C.c_int32), ("nconn", C.c_int32), ("conn_cells", _ip), ("trans", _dp),
                 ("pv", _dp), ("z", _dp), ("gravity", C.c_double), ("thpres", _dp),
-                ("pvtnum", _ip), ("satnum", _ip)]
+                ("pvtnum", _ip), ("satnum", _ip), ("eps", _dp * 8)]
 
 
 class Tables(C.Structure):

@@ -172,7 +172,9 @@ def fluid_data_tables():
 class GridData:
     """Static grid data matching `opmgpu_grid`."""
 
-    def __init__(self, nc, conn_cells, trans, pv, z, gravity=GRAVITY, thpres=None, pvtnum=None, satnum=None, dims=None):
+    EPS_NAMES = ("SWL", "SWCR", "SWU", "SOWCR", "SGL", "SGCR", "SGU", "SOGCR")
+
+    def __init__(self, nc, conn_cells, trans, pv, z, gravity=GRAVITY, thpres=None, pvtnum=None, satnum=None, dims=None, eps=None):
         self.nc = int(nc)
         self.conn_cells = capi.i32(conn_cells).reshape(-1, 2)
         self.nconn = self.conn_cells.shape[0]
@@ -182,6 +184,8 @@ class GridData:
         self.pvtnum = None if pvtnum is None else capi.i32(pvtnum)
         self.satnum = None if satnum is None else capi.i32(satnum)
         self.dims = dims
+        # ENDSCALE: dict name -> per-cell array for the eight scaled end points (all or none)
+        self.eps = None if eps is None else [capi.f64(np.broadcast_to(eps[k], (self.nc,))) for k in self.EPS_NAMES]
         self._struct = None
 
     def struct(self):
@@ -191,8 +195,26 @@ class GridData:
             g.conn_cells, g.trans, g.pv, g.z = capi.iptr(self.conn_cells), capi.dptr(self.trans), capi.dptr(self.pv), capi.dptr(self.z)
             g.gravity = self.gravity
             g.thpres, g.pvtnum, g.satnum = capi.dptr(self.thpres), capi.iptr(self.pvtnum), capi.iptr(self.satnum)
+            for k in range(8):
+                g.eps[k] = capi.dptr(None if self.eps is None else self.eps[k])
             self._struct = g
         return self._struct
+
+
+def with_endpoints(grid, eps):
+    """Copy of `grid` carrying ENDSCALE end points (dict name -> scalar / per-cell array, all eight names)."""
+    return GridData(grid.nc, grid.conn_cells, grid.trans, grid.pv, grid.z, gravity=grid.gravity, thpres=grid.thpres,
+                    pvtnum=grid.pvtnum, satnum=grid.satnum, dims=grid.dims, eps=eps)
+
+
+def random_endpoints(grid, seed=0, base=None, jitter=0.06):
+    """Synthetic per-cell scaled end points scattered around `base` (default: the satfuncStandard tables' own points)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    base = base or {"SWL": 0.1, "SWCR": 0.2, "SWU": 0.9, "SOWCR": 0.2, "SGL": 0.0, "SGCR": 0.1, "SGU": 0.9, "SOGCR": 0.2}
+    eps = {k: np.clip(v + jitter * (rng.random(grid.nc) - 0.5), 0.0, 1.0) for k, v in base.items()}
+    eps["SGL"] = np.zeros(grid.nc)
+    eps["SWCR"] = np.maximum(eps["SWCR"], eps["SWL"])
+    return eps
 
 
 def cartesian_grid(nx, ny, nz, dx=10.0, dy=10.0, dz=2.0, tops=2000.0, poro=0.2, permx_md=100.0, permz_ratio=0.1,

@@ -47,7 +47,8 @@ class LocalDomain:
                              grid.z[self.global_of_local], gravity=grid.gravity,
                              thpres=None if grid.thpres is None else grid.thpres[keep],
                              pvtnum=None if grid.pvtnum is None else grid.pvtnum[self.global_of_local],
-                             satnum=None if grid.satnum is None else grid.satnum[self.global_of_local])
+                             satnum=None if grid.satnum is None else grid.satnum[self.global_of_local],
+                             eps=None if grid.eps is None else {k: grid.eps[i][self.global_of_local] for i, k in enumerate(GridData.EPS_NAMES)})
         # halo lists
         gown = part[ghosts]
         self.neigh_rank = np.unique(gown).astype(np.int32)

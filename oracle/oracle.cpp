@@ -103,20 +103,74 @@ SatTab sat_tab(const opmgpu_tables* t, int reg)
     return s;
 }
 
+// ENDSCALE, two-point scaling (opm-material EclEpsTwoPhaseLaw / EclEpsScalingPoints, SCALECRS NO):
+//   S_unscaled = u0 + (S - s0) * ((u2 - u0) / (s2 - s0))
+// Unscaled points of a table (EclEpsScalingPointsInfo::extractUnscaled): Swl = first Sw, Swu = last Sw, Swcr = last Sw with
+// krw == 0, Sowcr = 1 - (first Sw with krow == 0); Sgl, Sgu, Sgcr alike, Sogcr = 1 - (first Sg with krog == 0)  [no Swl
+// subtracted: pinned by tests/test_boprops_ad.cpp:197-208 (0.13) and the EPS_A derivatives of tests/test_satfunc.cpp:299-307].
+// Pairs of (scaled, unscaled) points per curve: krw [Swcr, Swu]; krow [Swl+Sgl, 1-Sowcr-Sgl]; pcow [Swl, Swu];
+// krg [Sgcr, Sgu]; krog in oil saturation [Sogcr, 1-Swl-Sgl]; pcgo [Sgl, Sgu].  Pinned by tests/test_satfunc.cpp:140-379.
+struct Lin { double u0, s0, k; };
+inline double lin_map(const Lin& m, double s) { return m.u0 + (s - m.s0) * m.k; }
+struct Eps {
+    bool on;
+    Lin krw, krow, pcow, krg, krog, pcgo;
+    double swl;        // scaled connate water used by the three-phase law (params.Swl())
+    double swl_t;      // unscaled Swco of the table (the SGOF oil-saturation abscissa is 1 - swl_t - Sg)
+};
+Eps eps_for_cell(const opmgpu_grid* g, const SatTab& s, int c)
+{
+    Eps e; e.on = g && g->eps[0] != nullptr; e.swl = s.swco; e.swl_t = s.swco;
+    if (!e.on) return e;
+    auto last_zero = [](const double* x, const double* y, int n) { int i = 0; while (i + 1 < n && y[i + 1] == 0.0) ++i; return x[i]; };
+    auto first_zero = [](const double* x, const double* y, int n) { int i = 0; while (i < n - 1 && y[i] != 0.0) ++i; return x[i]; };
+    const double Swl = s.sw[0], Swu = s.sw[s.nw - 1], Swcr = last_zero(s.sw, s.krw, s.nw), Sowcr = 1.0 - first_zero(s.sw, s.krow, s.nw);
+    const double Sgl = s.sg[0], Sgu = s.sg[s.ng - 1], Sgcr = last_zero(s.sg, s.krg, s.ng), Sogcr = 1.0 - first_zero(s.sg, s.krog, s.ng);
+    const double SWL = g->eps[0][c], SWCR = g->eps[1][c], SWU = g->eps[2][c], SOWCR = g->eps[3][c];
+    const double SGL = g->eps[4][c], SGCR = g->eps[5][c], SGU = g->eps[6][c], SOGCR = g->eps[7][c];
+    auto mk = [](double u0, double u2, double s0, double s2) { Lin m; m.u0 = u0; m.s0 = s0; m.k = (u2 - u0) / (s2 - s0); return m; };
+    e.krw = mk(Swcr, Swu, SWCR, SWU);
+    e.krow = mk(Swl + Sgl, 1.0 - Sowcr - Sgl, SWL + SGL, 1.0 - SOWCR - SGL);
+    e.pcow = mk(Swl, Swu, SWL, SWU);
+    e.krg = mk(Sgcr, Sgu, SGCR, SGU);
+    e.krog = mk(Sogcr, 1.0 - Swl - Sgl, SOGCR, 1.0 - SWL - SGL);
+    e.pcgo = mk(Sgl, Sgu, SGL, SGU);
+    e.swl = SWL;
+    return e;
+}
+// table value at the (possibly scaled) saturation S; RIGHT selects the SGOF segment rule
+template <int N, bool RIGHT>
+Dual<N> sat_curve(const double* x, const double* y, int n, const Dual<N>& S, bool on, const Lin& m)
+{
+    double f, df;
+    if (!on) { if (RIGHT) sat_right(x, y, n, S.v, f, df); else sat_left(x, y, n, S.v, f, df); return chain(f, df, S); }
+    const double su = lin_map(m, S.v);
+    if (RIGHT) sat_right(x, y, n, su, f, df); else sat_left(x, y, n, su, f, df);
+    return chain(f, df * m.k, S);
+}
+
 // EclDefaultMaterial::{krw,krg,krn} (opm-material; reached from SaturationPropsFromDeck.cpp:91-92).
 // Generic in the AD width so the same code serves oracle_relperm (independent sw,so,sg) and the model.
 template <int N>
-void relperm3(const SatTab& s, const Dual<N>& Sw, const Dual<N>& Sg, Dual<N>& krw, Dual<N>& kro, Dual<N>& krg)
+void relperm3(const SatTab& s, const Eps& e, const Dual<N>& Sw, const Dual<N>& Sg, Dual<N>& krw, Dual<N>& kro, Dual<N>& krg)
 {
-    double f, df;
-    sat_left(s.sw, s.krw, s.nw, Sw.v, f, df);  krw = chain(f, df, Sw);
-    sat_right(s.sg, s.krg, s.ng, Sg.v, f, df); krg = chain(f, df, Sg);
-    const double Swco = s.swco;
+    krw = sat_curve<N, false>(s.sw, s.krw, s.nw, Sw, e.on, e.krw);
+    krg = sat_curve<N, true>(s.sg, s.krg, s.ng, Sg, e.on, e.krg);
+    const double Swco = e.swl;
     Dual<N> Swp = (Sw.v > Swco) ? Sw : Dual<N>(Swco);       // max(Swco, Sw)
     Dual<N> Sw_ow = Sg + Swp;
-    sat_left(s.sw, s.krow, s.nw, Sw_ow.v, f, df);  Dual<N> kro_ow = chain(f, df, Sw_ow);
-    Dual<N> Sg_eq = Sw_ow - Swco;                          // So_go = 1 - Sw_ow on So-samples 1 - Swco - Sg_i
-    sat_right(s.sg, s.krog, s.ng, Sg_eq.v, f, df); Dual<N> kro_go = chain(f, df, Sg_eq);
+    Dual<N> kro_ow = sat_curve<N, false>(s.sw, s.krow, s.nw, Sw_ow, e.on, e.krow);
+    // krog is tabulated against the oil saturation So = 1 - swl_t - Sg of the gas-oil system; left-in-So == right-in-Sg
+    Dual<N> So_go = 1.0 - Sw_ow;
+    Dual<N> kro_go;
+    {
+        const double k = e.on ? e.krog.k : 1.0;
+        const double so_u = e.on ? lin_map(e.krog, So_go.v) : So_go.v + (Swco - e.swl_t);   // unscaled: Sg_eq = Sw_ow - Swco
+        const double sg_eq = 1.0 - e.swl_t - so_u;
+        double f, df;
+        sat_right(s.sg, s.krog, s.ng, e.on ? sg_eq : Sw_ow.v - Swco, f, df);
+        kro_go = chain(f, -df * k, So_go);
+    }
     const double eps = 1e-5;
     if (Sw_ow.v - Swco < eps) {
         Dual<N> kro2 = (kro_ow + kro_go) / 2.0;
@@ -134,11 +188,10 @@ void relperm3(const SatTab& s, const Dual<N>& Sw, const Dual<N>& Sg, Dual<N>& kr
 // EclDefaultMaterial::capillaryPressures + the sign / reference-phase shift of
 // SaturationPropsFromDeck.cpp:163-174: pc[w] = pcow(Sw), pc[o] = 0, pc[g] = pcgo(Sg).
 template <int N>
-void cappress3(const SatTab& s, const Dual<N>& Sw, const Dual<N>& Sg, Dual<N>& pcow, Dual<N>& pcgo)
+void cappress3(const SatTab& s, const Eps& e, const Dual<N>& Sw, const Dual<N>& Sg, Dual<N>& pcow, Dual<N>& pcgo)
 {
-    double f, df;
-    sat_left(s.sw, s.pcow, s.nw, Sw.v, f, df);  pcow = chain(f, df, Sw);
-    sat_right(s.sg, s.pcgo, s.ng, Sg.v, f, df); pcgo = chain(f, df, Sg);
+    pcow = sat_curve<N, false>(s.sw, s.pcow, s.nw, Sw, e.on, e.pcow);
+    pcgo = sat_curve<N, true>(s.sg, s.pcgo, s.ng, Sg, e.on, e.pcgo);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -278,6 +331,7 @@ CellQ cell_eval(const opmgpu_grid* g, const opmgpu_tables* t, int c, double p, d
     const int preg = g->pvtnum ? g->pvtnum[c] : 0;
     const int sreg = g->satnum ? g->satnum[c] : 0;
     const SatTab st = sat_tab(t, sreg);
+    const Eps ep = eps_for_cell(g, st, c);
     // updatePhaseCondFromPrimalVariable, BlackoilModelBase_impl.hpp:2207-2241
     const bool isSg = (hc == OPMGPU_HC_GAS_AND_OIL), isRs = (hc == OPMGPU_HC_OIL_ONLY), isRv = (hc == OPMGPU_HC_GAS_ONLY);
     const bool freeOil = isSg || isRs, freeGas = isSg || isRv;
@@ -293,7 +347,7 @@ CellQ cell_eval(const opmgpu_grid* g, const opmgpu_tables* t, int c, double p, d
     q.sw = W; q.so = so; q.sg = sg;
     // computePressures, :1425-1460
     D3 pcow, pcgo;
-    cappress3(st, W, sg, pcow, pcgo);
+    cappress3(st, ep, W, sg, pcow, pcgo);
     q.po = P; q.pw = P - pcow; q.pg = P + pcgo;
     // rsSat / rvSat (T = 293.15 ignored by the isothermal tables), :662-674
     {
@@ -312,7 +366,7 @@ CellQ cell_eval(const opmgpu_grid* g, const opmgpu_tables* t, int c, double p, d
     { const PvtOut o = b_gas(t, preg, q.pg.v, q.rv.v, freeOil);  q.b[2]  = chain2(o.v, o.dp, q.pg, o.dr, q.rv); }
     { const PvtOut o = mu_gas(t, preg, q.pg.v, q.rv.v, freeOil); q.mu[2] = chain2(o.v, o.dp, q.pg, o.dr, q.rv); }
     // computeRelPerm, :1395-1419
-    relperm3(st, W, sg, q.kr[0], q.kr[1], q.kr[2]);
+    relperm3(st, ep, W, sg, q.kr[0], q.kr[1], q.kr[2]);
     // poroMult / transMult, :2089-2145 ; RockCompressibility.cpp:86-125
     D3 pvm(1.0);
     if (t->rock_comp != 0.0) {
@@ -578,12 +632,29 @@ extern "C" {
 void oracle_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
 int oracle_get_threads(void) { return g_threads; }
 
-void oracle_relperm(const opmgpu_tables* t, int n, const double* s, const int32_t* satnum, double* kr, double* dkrds)
+void oracle_relperm_eps(const opmgpu_tables* t, const opmgpu_grid* g, int n, const double* s, const int32_t* cells, double* kr, double* dkrds)
 {
     for (int i = 0; i < n; ++i) {
-        const SatTab st = sat_tab(t, satnum ? satnum[i] : 0);
+        const int c = cells ? cells[i] : 0;
+        const SatTab st = sat_tab(t, (g && g->satnum) ? g->satnum[c] : 0);
+        const Eps ep = eps_for_cell(g, st, c);
         D3 Sw = D3::var(s[3 * i], 0), Sg = D3::var(s[3 * i + 2], 2), k[3];
-        relperm3(st, Sw, Sg, k[0], k[1], k[2]);
+        relperm3(st, ep, Sw, Sg, k[0], k[1], k[2]);
+        for (int a = 0; a < 3; ++a) {
+            kr[3 * i + a] = k[a].v;
+            if (dkrds) for (int b = 0; b < 3; ++b) dkrds[9 * i + 3 * b + a] = k[a].d[b];
+        }
+    }
+}
+
+void oracle_relperm(const opmgpu_tables* t, int n, const double* s, const int32_t* satnum, double* kr, double* dkrds)
+{
+    const Eps ep = Eps();
+    for (int i = 0; i < n; ++i) {
+        const SatTab st = sat_tab(t, satnum ? satnum[i] : 0);
+        Eps e0 = ep; e0.on = false; e0.swl = st.swco; e0.swl_t = st.swco;
+        D3 Sw = D3::var(s[3 * i], 0), Sg = D3::var(s[3 * i + 2], 2), k[3];
+        relperm3(st, e0, Sw, Sg, k[0], k[1], k[2]);
         for (int a = 0; a < 3; ++a) {
             kr[3 * i + a] = k[a].v;
             if (dkrds) for (int b = 0; b < 3; ++b) dkrds[9 * i + 3 * b + a] = k[a].d[b];
@@ -595,8 +666,9 @@ void oracle_cappress(const opmgpu_tables* t, int n, const double* s, const int32
 {
     for (int i = 0; i < n; ++i) {
         const SatTab st = sat_tab(t, satnum ? satnum[i] : 0);
+        Eps e0; e0.on = false; e0.swl = st.swco; e0.swl_t = st.swco;
         D3 Sw = D3::var(s[3 * i], 0), Sg = D3::var(s[3 * i + 2], 2), pcow, pcgo;
-        cappress3(st, Sw, Sg, pcow, pcgo);
+        cappress3(st, e0, Sw, Sg, pcow, pcgo);
         const D3 k[3] = { pcow, D3(0.0), pcgo };
         for (int a = 0; a < 3; ++a) {
             pc[3 * i + a] = k[a].v;
@@ -819,9 +891,10 @@ void oracle_update_state(const opmgpu_grid* g, const opmgpu_tables* t, const opm
         if (t->has_vapoil) {
             // computeGasPressure, :1466-1480 (old saturations for the old pressure, new for the new)
             D3 a, b;
-            cappress3(st, D3(sw_old), D3(sg_old), a, b);
+            const Eps ep = eps_for_cell(g, st, c);
+            cappress3(st, ep, D3(sw_old), D3(sg_old), a, b);
             const double pg_old = p_old + b.v;
-            cappress3(st, D3(sw), D3(sg), a, b);
+            cappress3(st, ep, D3(sw), D3(sg), a, b);
             const double pg_new = pn + b.v;
             const double rvSat0 = rv_sat(t, preg, pg_old).v;
             const double rvSat = rv_sat(t, preg, pg_new).v;

@@ -8,7 +8,8 @@
  *
  * Parity pinning (see DESIGN.md "Oracle"): the relperm path is pinned by the
  * reference's own known answers (tests/test_satfunc.cpp:93-108 with
- * tests/satfuncStandard.DATA; tests/test_boprops_ad.cpp:109-208 with tests/fluid.data),
+ * tests/satfuncStandard.DATA; :140-379, :480-660 with the satfuncEPS{Base,_A,_C,_D}.DATA
+ * end-point-scaling decks; tests/test_boprops_ad.cpp:109-208 with tests/fluid.data),
  * transcribed under tests/golden/.  PVT table interpolation (opm-material), ILU0
  * (opm-simulators ParallelOverlappingILU0) and BiCGStab (dune-istl) are third-party
  * code absent from the reference tree with no numeric pins in it: for those the
@@ -28,6 +29,9 @@ extern "C" {
  * s[n*3] (w,o,g), kr[n*3], dkrds[n*9] Fortran order dkrds[9*i + 3*sat + kr]. */
 void oracle_relperm(const opmgpu_tables* t, int n, const double* s, const int32_t* satnum,
                     double* kr, double* dkrds);
+/* same with ENDSCALE: cells[i] indexes the per-cell end points / satnum of the grid (tests/test_satfunc.cpp:227-379) */
+void oracle_relperm_eps(const opmgpu_tables* t, const opmgpu_grid* g, int n, const double* s, const int32_t* cells,
+                        double* kr, double* dkrds);
 void oracle_cappress(const opmgpu_tables* t, int n, const double* s, const int32_t* satnum,
                      double* pc, double* dpcds);
 

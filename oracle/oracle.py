@@ -36,6 +36,7 @@ def lib():
             build()
         L = C.CDLL(LIB)
         L.oracle_relperm.argtypes = [_T, C.c_int, _dp, _ip, _dp, _dp]
+        L.oracle_relperm_eps.argtypes = [_T, _G, C.c_int, _dp, _ip, _dp, _dp]
         L.oracle_cappress.argtypes = [_T, C.c_int, _dp, _ip, _dp, _dp]
         L.oracle_pvt.argtypes = [_T, C.c_int, C.c_int, _dp, _dp, _bp, _ip, _dp]
         L.oracle_cell_props.argtypes = [_G, _T, _dp, _dp, _dp, _dp, _bp, _dp]
@@ -66,6 +67,15 @@ def relperm(tables, s, satnum=None):
     n = s.shape[0]
     kr, dkr = np.zeros((n, 3)), np.zeros((n, 9))
     lib().oracle_relperm(C.byref(tables.struct()), n, capi.dptr(s), capi.iptr(satnum), capi.dptr(kr), capi.dptr(dkr))
+    return kr, dkr
+
+
+def relperm_eps(tables, grid, s, cells):
+    s = capi.f64(s).reshape(-1, 3)
+    n = s.shape[0]
+    kr, dkr = np.zeros((n, 3)), np.zeros((n, 9))
+    cells = capi.i32(cells)
+    lib().oracle_relperm_eps(C.byref(tables.struct()), C.byref(grid.struct()), n, capi.dptr(s), capi.iptr(cells), capi.dptr(kr), capi.dptr(dkr))
     return kr, dkr
 
 

@@ -238,3 +238,78 @@ def test_dead_oil_dry_gas_tables(gpu_lib, oracle):
     r0, v0, _, _ = oracle.assemble(grid, tab, decks.DAY, st, rowptr, col, scale=tuple(prm.matbalscale))
     assert rel_err(m.jacobian()[2], v0) < RTOL_JAC and rel_err(m.residual(), r0) < RTOL_JAC
     m.close()
+
+
+def test_endscale_assembly_and_update_parity(gpu_lib, oracle):
+    """ENDSCALE (two-point end-point scaling, per-cell SWL..SOGCR): Jacobian / residual / updateState vs the oracle, whose
+    scaled curves are pinned by the reference's GwsegEPS* known answers (tests/test_oracle_golden.py)."""
+    tab = decks.satfunc_standard_tables(pc_scale=1.0)
+    base = decks.cartesian_grid(7, 6, 5, lognormal_sigma=0.5)
+    grid = decks.with_endpoints(base, decks.random_endpoints(base, seed=3))
+    prm = capi.default_params()
+    scale = tuple(prm.matbalscale)
+    rowptr, col = oracle.pattern(grid)
+    rng = np.random.default_rng(8)
+    nc = grid.nc
+    for seed in (1, 2):
+        st = decks.random_state(grid, tab, seed=seed)
+        m = GpuBlackoilModel(grid, tab, prm)
+        m.prepareStep(2 * decks.DAY, st)
+        m.assemble(True)
+        r0, v0, _, _ = oracle.assemble(grid, tab, 2 * decks.DAY, st, rowptr, col, scale=scale)
+        # the scaling must matter for this to be a test of it
+        r_plain, v_plain, _, _ = oracle.assemble(base, tab, 2 * decks.DAY, st, rowptr, col, scale=scale)
+        assert rel_err(v_plain, v0) > 1e-3
+        assert rel_err(m.jacobian()[2], v0) < RTOL_JAC, rel_err(m.jacobian()[2], v0)
+        assert rel_err(m.residual(), r0) < RTOL_JAC
+        dx = np.concatenate([rng.standard_normal(nc) * 30 * decks.BAR, rng.standard_normal(nc) * 0.25,
+                             rng.standard_normal(nc) * np.where(st.hc == capi.HC_OIL_ONLY, 30.0, np.where(st.hc == capi.HC_GAS_ONLY, 1e-4, 0.25))])
+        m.updateState(dx)
+        g, o = m.getState(), oracle.update_state(grid, tab, prm, dx, st)
+        assert np.array_equal(g.hc, o.hc)
+        assert np.allclose(g.p, o.p, rtol=1e-14, atol=0) and np.allclose(g.sat, o.sat, rtol=0, atol=1e-14)
+        assert np.allclose(g.rs, o.rs, rtol=1e-13, atol=1e-13) and np.allclose(g.rv, o.rv, rtol=1e-13, atol=1e-18)
+        m.close()
+
+
+def test_endscale_known_answers_on_device(gpu_lib):
+    """The reference's GwsegEPS_A known answers (tests/test_satfunc.cpp:227-307) checked on the DEVICE path directly, without
+    the oracle: kr = mobility * mu from opmgpu_perf_props.  mu_w, mu_o are constant here (no capillary pressure, one pressure,
+    one undersaturated rs) and are read off an unscaled twin model where kr is a plain table value (GwsegEPSBase)."""
+    import json
+    import os
+    G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "satfunc_eps.json")))["cases"]
+    A, B = G["GwsegEPS_A"], G["GwsegEPSBase"]
+    tab = decks.satfunc_standard_tables(pc_scale=0.0)
+    g0 = decks.cartesian_grid(1, 1, 8)
+    eps = {"SWL": 0.1, "SWCR": 0.2, "SWU": 0.9, "SOWCR": 0.2, "SGL": 0.0, "SGCR": 0.1, "SGU": 0.9, "SOGCR": 0.2}
+    eps.update({k: np.asarray(v, float)[:8] for k, v in A["endpoints"].items()})
+    wells = (np.array([0, 8], np.int32), np.arange(8, dtype=np.int32))
+    prm = capi.default_params()
+
+    def state(sw):
+        return decks.State(np.full(8, 200 * decks.BAR), np.tile([sw, 1.0 - sw, 0.0], (8, 1)), np.full(8, 10.0), np.zeros(8),
+                           np.full(8, capi.HC_OIL_ONLY, np.int8))
+
+    def perf(m, sw):
+        m.prepareStep(decks.DAY, state(sw))
+        return m.perfProps(8).reshape(8, 9, 4)        # p rs rv b_w b_o b_g mob_w mob_o mob_g, each (v, d/dP, d/dSw, d/dX)
+
+    plain = GpuBlackoilModel(g0, tab, prm, wells=wells)
+    mu_w = B["krw"][10] / perf(plain, 1.0)[0, 6, 0]
+    mu_o = B["kro"][1] / perf(plain, 0.1)[0, 7, 0]
+    plain.close()
+    m = GpuBlackoilModel(decks.with_endpoints(g0, eps), tab, prm, wells=wells)
+    tol = A["reltol_percent"] / 100.0
+
+    def close(a, b):
+        return abs(a - b) <= tol * max(abs(a), abs(b)) or (abs(a) < 1e-14 and abs(b) < 1e-14)
+
+    for i in range(11):
+        pp = perf(m, 0.1 * i)
+        for c in range(8):
+            assert close(pp[c, 6, 0] * mu_w, A["krw"][c][i]), (c, i, "krw", pp[c, 6, 0] * mu_w, A["krw"][c][i])
+            assert close(pp[c, 7, 0] * mu_o, A["kro"][c][i]), (c, i, "kro", pp[c, 7, 0] * mu_o, A["kro"][c][i])
+            assert close(pp[c, 6, 2] * mu_w, A["DkrwDsw"][c][i]), (c, i, "DkrwDsw", pp[c, 6, 2] * mu_w, A["DkrwDsw"][c][i])
+            assert close(pp[c, 7, 2] * mu_o, A["DkroDsw"][c][i]), (c, i, "DkroDsw", pp[c, 7, 2] * mu_o, A["DkroDsw"][c][i])
+    m.close()

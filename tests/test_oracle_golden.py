@@ -50,3 +50,39 @@ def test_boprops_fluid_data(oracle):
     sgcr = sg[np.flatnonzero(krg > 0)[0] - 1]
     sogcr = 1.0 - sg[np.flatnonzero(krog == 0)[0]]
     assert abs(sgcr - g["sgcr"]) < 1e-15 and abs(sogcr - g["sogcr"]) < 1e-15
+
+
+def _eps_grid(endpoints, n=10):
+    """1x1xn column with per-cell scaled end points; everything not given defaults to the table's own points
+    (SWOF/SGOF of satfuncStandard.DATA: Swl .1, Swcr .2, Swu .9, Sowcr .2, Sgl 0, Sgcr .1, Sgu .9, Sogcr .2)."""
+    g = decks.cartesian_grid(1, 1, n)
+    eps = {"SWL": 0.1, "SWCR": 0.2, "SWU": 0.9, "SOWCR": 0.2, "SGL": 0.0, "SGCR": 0.1, "SGU": 0.9, "SOGCR": 0.2}
+    eps.update({k: np.asarray(v, float) for k, v in (endpoints or {}).items()})
+    return decks.GridData(g.nc, g.conn_cells, g.trans, g.pv, g.z, eps=eps, dims=(1, 1, n))
+
+
+def test_satfunc_endscale_known_answers(oracle):
+    """GwsegEPSBase, GwsegEPS_A, GwsegEPS_C, GwsegEPS_D of the reference's tests/test_satfunc.cpp (two-point ENDSCALE;
+    EPS_D = hysteresis enabled but no saturation history, i.e. the drainage curves).  GwsegEPS_B's deck is not in the
+    reference tree, its arrays are transcribed but cannot be reproduced without the deck."""
+    G = json.load(open(os.path.join(GOLD, "satfunc_eps.json")))["cases"]
+    t = decks.satfunc_standard_tables()
+    n = 11
+    for name in ("GwsegEPSBase", "GwsegEPS_D", "GwsegEPS_A", "GwsegEPS_C"):
+        g = G[name]
+        grid = _eps_grid(g.get("endpoints"))
+        ncell = 8 if isinstance(g["krw"][0], list) else 1
+        tol = g["reltol_percent"]
+        for icell in range(ncell):
+            s = np.zeros((n, 3))
+            s[:, 0] = np.arange(n) * 0.1
+            s[:, 1] = 1.0 - s[:, 0]
+            kr, dkr = oracle.relperm_eps(t, grid, s, np.full(n, icell))
+            row = (lambda a: a[icell]) if ncell > 1 else (lambda a: a)
+            for i in range(n):
+                where = (name, icell, i)
+                assert _close(kr[i, 0], row(g["krw"])[i], tol), where + ("krw", kr[i, 0])
+                assert _close(kr[i, 1], row(g["kro"])[i], tol), where + ("kro", kr[i, 1])
+                assert _close(dkr[i, 0], row(g["DkrwDsw"])[i], tol), where + ("DkrwDsw", dkr[i, 0])
+                assert _close(dkr[i, 1], row(g["DkroDsw"])[i], tol), where + ("DkroDsw", dkr[i, 1])
+                assert _close(dkr[i, 3 * 2 + 1], row(g["DkroDsg"])[i], tol), where + ("DkroDsg", dkr[i, 7])
