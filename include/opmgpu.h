@@ -95,6 +95,15 @@ typedef struct opmgpu_tables {
     const double  *sgof_sg, *sgof_krg, *sgof_krog, *sgof_pcgo;
     /* ROCK (RockCompressibility.cpp:86-125, quadratic form)                                    */
     double rock_pref, rock_comp;
+    /* VAPPARS (BlackoilPropsAdFromDeck.cpp:168-172, applyVap :1052-1078): rvSat *= (so/soMax)^vap1,
+     * rsSat *= (so/soMax)^vap2 where soMax > 0.01 and so < soMax; 0 = off.  soMax per cell: see
+     * opmgpu_set_sat_oil_max / opmgpu_update_sat_oil_max.                                       */
+    double vap1, vap2;
+    /* ROCKTAB (RockCompressibility.cpp:50-62, :86-125), single region: pore-volume and
+     * transmissibility multipliers tabulated against pressure, piecewise linear with linear
+     * extrapolation; rocktab_n == 0 = use the quadratic ROCK form above (trans multiplier 1).    */
+    int32_t rocktab_n;
+    const double *rocktab_p, *rocktab_pvmult, *rocktab_transmult;
 } opmgpu_tables;
 
 /* Newton + linear-solver knobs: BlackoilModelParameters.cpp:76-102, BlackoilModelBase_impl.hpp:139,
@@ -195,6 +204,23 @@ int opmgpu_solve(opmgpu_ctx* ctx, int single_precision, double* dx, int* iters, 
  * renormalisation, rs/rv limits, phase-state switching.  dx NULL = use the resident increment
  * of the last opmgpu_solve.  relax multiplies dx first (NonlinearSolver_impl.hpp:283-301, dampen). */
 int opmgpu_update_state(opmgpu_ctx* ctx, const double* dx, double relax);
+
+/* Maximum historical oil saturation per cell (BlackoilPropsAdFromDeck::satOilMax_, used by VAPPARS).
+ * set: explicit values (nc, caller order; restart).  update: soMax = max(soMax, so of the resident state) --
+ * what SimulatorBase_impl.hpp:192 does at the start of every report step (updateSatOilMax, :933-945).
+ * Starts at zero like the reference's (BlackoilPropsAdFromDeck.cpp:175). */
+int opmgpu_set_sat_oil_max(opmgpu_ctx* ctx, const double* so_max);
+int opmgpu_update_sat_oil_max(opmgpu_ctx* ctx);
+int opmgpu_get_sat_oil_max(opmgpu_ctx* ctx, double* so_max);
+
+/* NonlinearSolver::stabilizeNonlinearUpdate (NonlinearSolver_impl.hpp:260-301) on the resident
+ * increment: dx_old <- dx, then DAMPEN: dx *= omega, SOR: dx = omega*dx + (1-omega)*dx_old(previous).
+ * dx_old is zeroed by opmgpu_assemble(initial_assembly = 1) (BlackoilModelBase_impl.hpp:254-260).
+ * The oscillation detection itself (detectOscillations, :221-257) works on the three L-inf norms
+ * that opmgpu_convergence returns and stays with the caller (host/opmgpu.hpp, opmgpu/model.py). */
+#define OPMGPU_RELAX_DAMPEN 0
+#define OPMGPU_RELAX_SOR 1
+int opmgpu_stabilize_update(opmgpu_ctx* ctx, int relax_type, double omega);
 
 /* ------------------------------------------------------------------------------------------
  * B1 boundary: NewtonIterationBlackoilInterface::computeNewtonIncrement

@@ -119,13 +119,33 @@ __device__ __forceinline__ void sat_curve(const double* __restrict__ x, const do
     df *= e.k[c];
 }
 
+// VAPPARS (applyVap, BlackoilPropsAdFromDeck.cpp:1052-1078): factor (so/soMax)^vap and its so-derivative
+__device__ __forceinline__ void vap_factor(double vap, double so, double so_max, double& f, double& df)
+{
+    f = 1.0; df = 0.0;
+    if (vap > 0.0 && so_max > 0.01 && so < so_max) {
+        const double so_i = fmax(so, 1.4901161193847656e-08);
+        f = pow(so_i / so_max, vap);
+        df = vap * pow(so_i / so_max, vap - 1.0) / so_max;
+    }
+}
+// ROCKTAB (RockCompressibility.cpp:86-125 -> Opm::linearInterpolation): left segment at a breakpoint, linear extrapolation
+__device__ __forceinline__ void rocktab_eval(const double* __restrict__ x, const double* __restrict__ y, int n, double xv, double& f, double& df)
+{
+    int i = 0;
+    for (int k = 1; k <= n - 2; ++k) i += (x[k] < xv) ? 1 : 0;
+    df = (y[i + 1] - y[i]) / (x[i + 1] - x[i]);
+    f = y[i] + df * (xv - x[i]);
+}
+
 struct CellEval {
     V4 pw, pg, rs, rv, sw, so, sg;
     V4 b[3], mob[3], rho[3], accum[3];
 };
 
 // SolutionState + ReservoirResidualQuant of one cell (BlackoilModelBase_impl.hpp:614-751, 1484-1497, 2009-2027)
-__device__ void eval_cell(const opmgpu_tables& T, const EpsD& E, int preg, int sreg, double p, double sw_, double sg_, double rs_, double rv_, int hc, CellEval& q)
+__device__ void eval_cell(const opmgpu_tables& T, const EpsD& E, double so_max, int preg, int sreg, double p, double sw_, double sg_, double rs_, double rv_, int hc,
+                          CellEval& q)
 {
     const bool isSg = hc == OPMGPU_HC_GAS_AND_OIL, isRs = hc == OPMGPU_HC_OIL_ONLY, isRv = hc == OPMGPU_HC_GAS_ONLY;
     const bool freeOil = isSg || isRs, freeGas = isSg || isRv;
@@ -179,9 +199,13 @@ __device__ void eval_cell(const opmgpu_tables& T, const EpsD& E, int preg, int s
     }
     // rs / rv
     rs_sat_d(T, preg, p, f, df);
-    q.rs = (T.has_disgas && isRs) ? X : mk(f, df, 0, 0);
+    V4 rsSat = mk(f, df, 0, 0);
+    if (T.vap2 > 0.0) { vap_factor(T.vap2, so.v, so_max, f, df); rsSat = vmul(vchain(f, df, so), rsSat); }
+    q.rs = (T.has_disgas && isRs) ? X : rsSat;
     rv_sat_d(T, preg, q.pg.v, f, df);
-    q.rv = (T.has_vapoil && isRv) ? X : vchain(f, df, q.pg);
+    V4 rvSat = vchain(f, df, q.pg);
+    if (T.vap1 > 0.0) { vap_factor(T.vap1, so.v, so_max, f, df); rvSat = vmul(vchain(f, df, so), rvSat); }
+    q.rv = (T.has_vapoil && isRv) ? X : rvSat;
     // water PVT (ConstantCompressibilityWaterPvt)
     V4 mu[3];
     {
@@ -231,10 +255,17 @@ __device__ void eval_cell(const opmgpu_tables& T, const EpsD& E, int preg, int s
     q.rho[0] = vscale(rhos[0], q.b[0]);
     q.rho[1] = vadd(vscale(rhos[1], q.b[1]), vscale(rhos[2], vmul(q.rs, q.b[1])));
     q.rho[2] = vadd(vscale(rhos[2], q.b[2]), vscale(rhos[1], vmul(q.rv, q.b[2])));
-    q.mob[0] = vdiv(krw, mu[0]); q.mob[1] = vdiv(kro, mu[1]); q.mob[2] = vdiv(krg, mu[2]);
-    // accumulation with rock compressibility (RockCompressibility.cpp:86-125)
+    // accumulation with rock compressibility, transmissibility multiplier (RockCompressibility.cpp:86-125)
     V4 pvm = mk(1, 0, 0, 0);
-    if (T.rock_comp != 0.0) {
+    if (T.rocktab_n > 0) {
+        rocktab_eval(T.rocktab_p, T.rocktab_pvmult, T.rocktab_n, p, f, df); pvm = mk(f, df, 0, 0);
+        rocktab_eval(T.rocktab_p, T.rocktab_transmult, T.rocktab_n, p, f, df);
+        const V4 trm = mk(f, df, 0, 0);
+        q.mob[0] = vdiv(vmul(trm, krw), mu[0]); q.mob[1] = vdiv(vmul(trm, kro), mu[1]); q.mob[2] = vdiv(vmul(trm, krg), mu[2]);
+    } else {
+        q.mob[0] = vdiv(krw, mu[0]); q.mob[1] = vdiv(kro, mu[1]); q.mob[2] = vdiv(krg, mu[2]);
+    }
+    if (T.rocktab_n == 0 && T.rock_comp != 0.0) {
         const double cp = T.rock_comp * (p - T.rock_pref);
         pvm = mk(1.0 + cp + 0.5 * cp * cp, T.rock_comp + cp * T.rock_comp, 0, 0);
     }
@@ -262,6 +293,7 @@ __global__ __launch_bounds__(kBlock) void k_cell_props(int nb, int nbp, opmgpu_t
                                                        double inv_dt, int initial, double s0, double s1, double s2,
                                                        const int32_t* __restrict__ slice_ptr, const int16_t* __restrict__ nlower,
                                                        const double* __restrict__ eps, const double* __restrict__ eps_u0,
+                                                       const double* __restrict__ somax,
                                                        double* __restrict__ props, double* __restrict__ accum0, double* __restrict__ R,
                                                        double* __restrict__ binv, double* __restrict__ A)
 {
@@ -270,7 +302,7 @@ __global__ __launch_bounds__(kBlock) void k_cell_props(int nb, int nbp, opmgpu_t
     CellEval q;
     EpsD E;
     eps_load(eps, eps_u0, nbp, row, satnum[row], E);
-    eval_cell(T, E, pvtnum[row], satnum[row], p[row], sw[row], sg[row], rs[row], rv[row], hc[row], q);
+    eval_cell(T, E, somax[row], pvtnum[row], satnum[row], p[row], sw[row], sg[row], rs[row], rv[row], hc[row], q);
     props[long(PL_PW) * nbp + row] = q.pw.v; props[long(PL_PG) * nbp + row] = q.pg.v;
     props[long(PL_DPW_W) * nbp + row] = q.pw.w; props[long(PL_DPG_W) * nbp + row] = q.pg.w; props[long(PL_DPG_X) * nbp + row] = q.pg.x;
 #pragma unroll
@@ -477,7 +509,8 @@ __global__ __launch_bounds__(kBlock) void k_update_state(int nb, int nbp, opmgpu
                                                          double dp_max_rel, double ds_max, double dr_max_rel,
                                                          double* __restrict__ p, double* __restrict__ sw, double* __restrict__ so,
                                                          double* __restrict__ sg, double* __restrict__ rs, double* __restrict__ rv, int8_t* __restrict__ hc,
-                                                         const double* __restrict__ eps_planes, const double* __restrict__ eps_u0)
+                                                         const double* __restrict__ eps_planes, const double* __restrict__ eps_u0,
+                                                         const double* __restrict__ somax)
 {
     const int c = blockIdx.x * kBlock + threadIdx.x;
     if (c >= nb) return;
@@ -512,8 +545,11 @@ __global__ __launch_bounds__(kBlock) void k_update_state(int nb, int nbp, opmgpu
     int hn = OPMGPU_HC_GAS_AND_OIL;
     double f, df;
     if (T.has_disgas) {
-        rs_sat_d(T, preg, p_old, f, df); const double rsSat0 = f;
-        rs_sat_d(T, preg, pn, f, df); const double rsSat = f;
+        double v0, v1;
+        vap_factor(T.vap2, so_old, somax[c], v0, df);
+        vap_factor(T.vap2, o_, somax[c], v1, df);
+        rs_sat_d(T, preg, p_old, f, df); const double rsSat0 = v0 * f;
+        rs_sat_d(T, preg, pn, f, df); const double rsSat = v1 * f;
         const bool hasGas = (g_ > 0 && !isRs);
         const bool gasVaporized = ((rsn > rsSat * (1 + eps) && isRs) && (rs_old > rsSat0 * (1 - eps)));
         if (watOnly || hasGas || gasVaporized) { rsn = rsSat; if (watOnly) { o_ = 0; g_ = 0; rsn = 0; } }
@@ -525,8 +561,11 @@ __global__ __launch_bounds__(kBlock) void k_update_state(int nb, int nbp, opmgpu
         eps_load(eps_planes, eps_u0, nbp, c, sreg, E);
         sat_curve<true>(T.sgof_sg + ga, T.sgof_pcgo + ga, ng, sg_old, E, EC_PCGO, f, df); const double pg_old = p_old + f;
         sat_curve<true>(T.sgof_sg + ga, T.sgof_pcgo + ga, ng, g_, E, EC_PCGO, f, df); const double pg_new = pn + f;
-        rv_sat_d(T, preg, pg_old, f, df); const double rvSat0 = f;
-        rv_sat_d(T, preg, pg_new, f, df); const double rvSat = f;
+        double v0, v1;
+        vap_factor(T.vap1, so_old, somax[c], v0, df);
+        vap_factor(T.vap1, o_, somax[c], v1, df);
+        rv_sat_d(T, preg, pg_old, f, df); const double rvSat0 = v0 * f;
+        rv_sat_d(T, preg, pg_new, f, df); const double rvSat = v1 * f;
         const bool hasOil = (o_ > 0 && !isRv);
         const bool oilCondensed = ((rvn > rvSat * (1 + eps) && isRv) && (rv_old > rvSat0 * (1 - eps)));
         if (watOnly || hasOil || oilCondensed) { rvn = rvSat; if (watOnly) { o_ = 0; g_ = 0; rvn = 0; } }
@@ -563,7 +602,8 @@ __global__ __launch_bounds__(kBlock) void k_perf_props(int nperf, opmgpu_tables 
                                                        const int32_t* __restrict__ satnum, const double* __restrict__ p, const double* __restrict__ sw,
                                                        const double* __restrict__ sg, const double* __restrict__ rs, const double* __restrict__ rv,
                                                        const int8_t* __restrict__ hc, const double* __restrict__ eps,
-                                                       const double* __restrict__ eps_u0, long nbp, double* __restrict__ out)
+                                                       const double* __restrict__ eps_u0, const double* __restrict__ somax, long nbp,
+                                                       double* __restrict__ out)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= nperf) return;
@@ -571,7 +611,7 @@ __global__ __launch_bounds__(kBlock) void k_perf_props(int nperf, opmgpu_tables 
     CellEval q;
     EpsD E;
     eps_load(eps, eps_u0, nbp, c, satnum[c], E);
-    eval_cell(T, E, pvtnum[c], satnum[c], p[c], sw[c], sg[c], rs[c], rv[c], hc[c], q);
+    eval_cell(T, E, somax[c], pvtnum[c], satnum[c], p[c], sw[c], sg[c], rs[c], rv[c], hc[c], q);
     const V4 list[9] = { mk(p[c], 1, 0, 0), q.rs, q.rv, q.b[0], q.b[1], q.b[2], q.mob[0], q.mob[1], q.mob[2] };
     double* o = out + long(i) * OPMGPU_PERF_K;
 #pragma unroll
@@ -593,6 +633,17 @@ __global__ __launch_bounds__(kBlock) void k_add_well_blocks(int nblk, const int3
     const double scale[3] = { s0, s1, s2 };
     double* o = A + long(e >> 6) * 576 + (e & 63);
     for (int a = 0; a < 3; ++a) for (int v = 0; v < 3; ++v) atomicAdd(&o[(3 * a + v) * 64], scale[a] * blocks[9 * long(i) + 3 * a + v]);
+}
+
+// stabilizeNonlinearUpdate: dx_old <- dx; dx <- omega*dx (+ (1-omega)*previous dx_old for SOR)
+__global__ __launch_bounds__(kBlock) void k_stabilize(long n, int sor, double omega, double* __restrict__ dx, double* __restrict__ dx_old)
+{
+    const long i = long(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const double d = dx[i], o = dx_old[i];
+    dx_old[i] = d;
+    if (omega == 1.0) return;
+    dx[i] = sor ? omega * d + (1.0 - omega) * o : omega * d;
 }
 
 template <class T_>
@@ -670,6 +721,11 @@ void BlackoilDevice::upload_tables(const opmgpu_tables* t)
     dt_.swof_sw = upd(t->swof_sw, nsw); dt_.swof_krw = upd(t->swof_krw, nsw); dt_.swof_krow = upd(t->swof_krow, nsw); dt_.swof_pcow = upd(t->swof_pcow, nsw);
     dt_.sgof_ptr = upi(t->sgof_ptr, ns + 1);
     dt_.sgof_sg = upd(t->sgof_sg, nsg); dt_.sgof_krg = upd(t->sgof_krg, nsg); dt_.sgof_krog = upd(t->sgof_krog, nsg); dt_.sgof_pcgo = upd(t->sgof_pcgo, nsg);
+    if (t->rocktab_n > 0) {
+        if (t->rocktab_n < 2) throw HipError(OPMGPU_EINVAL, "ROCKTAB needs at least two rows");
+        dt_.rocktab_p = upd(t->rocktab_p, t->rocktab_n); dt_.rocktab_pvmult = upd(t->rocktab_pvmult, t->rocktab_n);
+        dt_.rocktab_transmult = upd(t->rocktab_transmult, t->rocktab_n);
+    }
     // unscaled end points of every saturation region (what opm-material's EclEpsScalingPointsInfo::extractUnscaled reads off the
     // tables): Swl Swcr Swu Sowcr Sgl Sgcr Sgu Sogcr
     h_unscaled.assign(8 * size_t(ns), 0.0);
@@ -695,6 +751,8 @@ void BlackoilDevice::rebuild_structure()
     if (st != OPMGPU_OK) throw HipError(st, "invalid grid connections / wells (out of range or duplicate cell pair)");
     // keep the state across a re-plan (wells change between report steps)
     std::vector<double> sp, ssat, srs, srv; std::vector<int8_t> shc;
+    std::vector<double> smax;
+    if (d_somax.p) { smax.resize(nc); get_sat_oil_max(smax.data()); }
     if (has_state) { sp.resize(nc); ssat.resize(3 * size_t(nc)); srs.resize(nc); srv.resize(nc); shc.resize(nc); get_state(sp.data(), ssat.data(), srs.data(), srv.data(), shc.data()); }
     const int st2 = ls.set_pattern(nc, rowptr.data(), col.data(), prm.ilu_ordering);
     if (st2 != OPMGPU_OK) throw HipError(st2, "sparsity plan failed");
@@ -752,9 +810,13 @@ void BlackoilDevice::rebuild_structure()
     d_R.alloc(3 * size_t(nbp)); d_R.zero(stream);
     d_binv.alloc(3 * size_t(nbp)); d_binv.zero(stream);
     d_dx.alloc(3 * size_t(nbp)); d_dx.zero(stream);
+    d_dx_old.alloc(3 * size_t(nbp)); d_dx_old.zero(stream);
     d_red.alloc(13 * size_t(kMaxRedBlocks) + 16);
     OPMGPU_HIP(hipStreamSynchronize(stream));
     has_dx = false;
+    d_somax.alloc(nbp); d_somax.zero(stream);
+    OPMGPU_HIP(hipStreamSynchronize(stream));
+    if (!smax.empty()) set_sat_oil_max(smax.data());
     if (has_state) set_state(sp.data(), ssat.data(), srs.data(), srv.data(), shc.data());
 }
 
@@ -811,10 +873,11 @@ void BlackoilDevice::assemble(double dt, bool initial)
     const Plan& P = ls.plan;
     last_dt = dt;
     has_rhs_extra = false;
+    if (initial) d_dx_old.zero(stream);
     const double* sc = prm.matbalscale;
     hipLaunchKernelGGL(k_cell_props, dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_pv.p,
                        d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, 1.0 / dt, int(initial), sc[0], sc[1], sc[2],
-                       ls.dp.slice_ptr.p, ls.dp.nlower.p, eps_planes(), d_eps_u0.p, d_props.p, d_accum0.p, d_R.p, d_binv.p, ls.matrix_d());
+                       ls.dp.slice_ptr.p, ls.dp.nlower.p, eps_planes(), d_eps_u0.p, d_somax.p, d_props.p, d_accum0.p, d_R.p, d_binv.p, ls.matrix_d());
     hipLaunchKernelGGL(k_flux, dim3(grid8_for(nc)), dim3(kBlock), 0, stream, xcd_mode(), nc, P.nbp, ls.dp.slice_ptr.p, ls.dp.col.p, ls.dp.rowlen.p,
                        ls.dp.nlower.p, d_conn_code.p, d_trans.p, d_gdz.p, use_thpres ? d_thpres.p : (const double*)nullptr,
                        d_p.p, d_props.p, sc[0], sc[1], sc[2], ls.comm ? ls.comm->owner_mask() : (const int8_t*)nullptr, d_R.p, ls.matrix_d());
@@ -831,7 +894,7 @@ double BlackoilDevice::time_assemble(int reps, int props_only)
         if (props_only)
             hipLaunchKernelGGL(k_cell_props, dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_pv.p,
                                d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, 1.0 / dt, 0, sc[0], sc[1], sc[2],
-                               ls.dp.slice_ptr.p, ls.dp.nlower.p, eps_planes(), d_eps_u0.p, d_props.p, d_accum0.p, d_R.p, d_binv.p, ls.matrix_d());
+                               ls.dp.slice_ptr.p, ls.dp.nlower.p, eps_planes(), d_eps_u0.p, d_somax.p, d_props.p, d_accum0.p, d_R.p, d_binv.p, ls.matrix_d());
         else assemble(dt, false);
     };
     launch();
@@ -889,7 +952,7 @@ void BlackoilDevice::perf_props(double* out)
 {
     if (nperf == 0) return;
     hipLaunchKernelGGL(k_perf_props, dim3(grid_for(nperf)), dim3(kBlock), 0, stream, nperf, dt_, d_perf_cells.p, d_pvtnum.p, d_satnum.p,
-                       d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, eps_planes(), d_eps_u0.p, long(ls.plan.nbp), d_perf.p);
+                       d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, eps_planes(), d_eps_u0.p, d_somax.p, long(ls.plan.nbp), d_perf.p);
     OPMGPU_HIP(hipMemcpyAsync(out, d_perf.p, size_t(nperf) * OPMGPU_PERF_K * sizeof(double), hipMemcpyDeviceToHost, stream));
     OPMGPU_HIP(hipStreamSynchronize(stream));
 }
@@ -982,7 +1045,41 @@ void BlackoilDevice::update_state(const double* dx_host, double relax)
     const Plan& P = ls.plan;
     if (dx_host) { ls.vec_from_host<double>(dx_host, VEC_EQUATION_MAJOR, d_dx.p); has_dx = true; }
     hipLaunchKernelGGL(k_update_state, dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_dx.p, relax,
-                       prm.dp_max_rel, prm.ds_max, prm.dr_max_rel, d_p.p, d_sw.p, d_so.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, eps_planes(), d_eps_u0.p);
+                       prm.dp_max_rel, prm.ds_max, prm.dr_max_rel, d_p.p, d_sw.p, d_so.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, eps_planes(), d_eps_u0.p, d_somax.p);
+}
+
+__global__ __launch_bounds__(kBlock) void k_somax_update(int nb, const double* __restrict__ so, double* __restrict__ somax)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < nb) somax[i] = fmax(somax[i], so[i]);
+}
+
+void BlackoilDevice::update_sat_oil_max()
+{
+    hipLaunchKernelGGL(k_somax_update, dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, d_so.p, d_somax.p);
+}
+void BlackoilDevice::set_sat_oil_max(const double* v)
+{
+    const Plan& P = ls.plan;
+    std::vector<double> h(P.nbp, 0.0);
+    for (int r = 0; r < nc; ++r) h[r] = v[P.nat[r]];
+    d_somax.upload(h, stream);
+    OPMGPU_HIP(hipStreamSynchronize(stream));
+}
+void BlackoilDevice::get_sat_oil_max(double* v)
+{
+    const Plan& P = ls.plan;
+    std::vector<double> h(P.nbp);
+    OPMGPU_HIP(hipMemcpyAsync(h.data(), d_somax.p, size_t(P.nbp) * sizeof(double), hipMemcpyDeviceToHost, stream));
+    OPMGPU_HIP(hipStreamSynchronize(stream));
+    for (int r = 0; r < nc; ++r) v[P.nat[r]] = h[r];
+}
+
+void BlackoilDevice::stabilize_update(int relax_type, double omega)
+{
+    const long n = 3 * long(ls.plan.nbp);
+    hipLaunchKernelGGL(k_stabilize, dim3(unsigned((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, n, relax_type == OPMGPU_RELAX_SOR ? 1 : 0, omega,
+                       d_dx.p, d_dx_old.p);
 }
 
 void BlackoilDevice::get_residual(double* r)

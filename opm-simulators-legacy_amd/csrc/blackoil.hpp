@@ -40,6 +40,10 @@ public:
     template <class S> void store_dx();                 // solver x -> resident dx (double, internal planes)
     void dx_to_host(double* dx);                        // resident dx -> host, equation-major caller order
     void update_state(const double* dx_host, double relax);
+    void stabilize_update(int relax_type, double omega);
+    void update_sat_oil_max();
+    void set_sat_oil_max(const double* v);
+    void get_sat_oil_max(double* v);
     void get_residual(double* r);
     double time_assemble(int reps, int props_only);
     void attach_comm(CommBase* c, int n_owned);
@@ -65,7 +69,7 @@ private:
     // ENDSCALE: per-cell scaled end points (caller numbering), unscaled points per saturation region
     bool use_eps = false;
     std::vector<double> h_eps[8], h_unscaled;
-    DevArray<double> d_eps, d_eps_u0;
+    DevArray<double> d_eps, d_eps_u0, d_somax;
     const double* eps_planes() const { return use_eps ? d_eps.p : nullptr; }
     // device: tables
     opmgpu_tables dt_;                       // same struct, device pointers
@@ -78,7 +82,7 @@ private:
     DevArray<double> d_p, d_sw, d_so, d_sg, d_rs, d_rv;
     DevArray<int8_t> d_hc;
     // device: work
-    DevArray<double> d_props, d_accum0, d_R, d_binv, d_dx, d_red, d_perf, d_rhs_extra;
+    DevArray<double> d_props, d_accum0, d_R, d_binv, d_dx, d_dx_old, d_red, d_perf, d_rhs_extra;
     double* h_red = nullptr;
     std::vector<double> hbuf;
     std::vector<int8_t> hbuf8;

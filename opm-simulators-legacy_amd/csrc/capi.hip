@@ -235,6 +235,32 @@ int opmgpu_update_state(opmgpu_ctx* c, const double* dx, double relax)
     });
 }
 
+int opmgpu_set_sat_oil_max(opmgpu_ctx* c, const double* so_max)
+{
+    if (!c || !c->model || !so_max) return OPMGPU_EINVAL;
+    return guarded(c, [&]() { c->model->set_sat_oil_max(so_max); return OPMGPU_OK; });
+}
+int opmgpu_update_sat_oil_max(opmgpu_ctx* c)
+{
+    if (!c || !c->model || !c->model->has_state) return OPMGPU_EINVAL;
+    return guarded(c, [&]() { c->model->update_sat_oil_max(); return OPMGPU_OK; });
+}
+int opmgpu_get_sat_oil_max(opmgpu_ctx* c, double* so_max)
+{
+    if (!c || !c->model || !so_max) return OPMGPU_EINVAL;
+    return guarded(c, [&]() { c->model->get_sat_oil_max(so_max); return OPMGPU_OK; });
+}
+
+int opmgpu_stabilize_update(opmgpu_ctx* c, int relax_type, double omega)
+{
+    if (!c || !c->model || (relax_type != OPMGPU_RELAX_DAMPEN && relax_type != OPMGPU_RELAX_SOR)) return OPMGPU_EINVAL;
+    if (!c->model->has_dx) return fail(c, OPMGPU_EINVAL, "no resident Newton increment");
+    return guarded(c, [&]() {
+        c->model->stabilize_update(relax_type, omega);
+        return OPMGPU_OK;
+    });
+}
+
 int opmgpu_load_bsr(opmgpu_ctx* c, int nb, const int32_t* rowptr, const int32_t* col, const double* val9, int single_precision)
 {
     if (!c || nb <= 0 || !rowptr || !col || !val9) return OPMGPU_EINVAL;

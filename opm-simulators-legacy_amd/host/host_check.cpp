@@ -1,14 +1,110 @@
-// Compile/link check of the C++ host mirror against libopmgpu.so; also exercises the "no GPU" error path.
+// host_check -- the C++ host mirror (opmgpu.hpp) driven the way flow_legacy drives BlackoilModel / NonlinearSolver:
+// a hand-authored dead-oil / dry-gas 6x6x3 deck, one time step through NonlinearSolverGpu::step (assemble ->
+// getConvergence -> solveJacobianSystem -> stabilise -> updateState on the device), state downloaded at the end.
+// Without a GPU it only exercises the "no device, no CPU fallback" error path (exit code 0 either way when behaving).
+#include <cmath>
 #include <cstdio>
+#include <vector>
+
 #include "opmgpu.hpp"
+
+namespace {
+
+struct Deck {
+    // fluids, SI
+    std::vector<double> dens{ 1000.0, 850.0, 1.0 }, pvtw{ 200e5, 1.02, 4.5e-10, 0.5e-3, 0.0 };
+    std::vector<int32_t> oil_node_ptr{ 0, 2 }, oil_col_ptr{ 0, 1, 2 }, gas_node_ptr{ 0, 2 }, gas_col_ptr{ 0, 1, 2 };
+    std::vector<double> oil_rs{ 0.0, 0.0 }, oil_p{ 1e5, 400e5 }, oil_invb{ 1.0, 1.05 }, oil_invbmu{ 1.0 / 1e-3, 1.05 / 1e-3 };
+    std::vector<double> gas_p{ 1e5, 400e5 }, gas_rv{ 0.0, 0.0 }, gas_invb{ 1.0, 300.0 }, gas_invbmu{ 1.0 / 2e-5, 300.0 / 2e-5 };
+    std::vector<int32_t> swof_ptr{ 0, 4 }, sgof_ptr{ 0, 4 };
+    std::vector<double> sw{ 0.2, 0.5, 0.8, 1.0 }, krw{ 0, 0.2, 0.6, 1.0 }, krow{ 1.0, 0.3, 0.0, 0.0 }, pcow{ 0, 0, 0, 0 };
+    std::vector<double> sg{ 0.0, 0.1, 0.5, 0.8 }, krg{ 0, 0, 0.4, 0.9 }, krog{ 1.0, 0.7, 0.1, 0.0 }, pcgo{ 0, 0, 0, 0 };
+    // grid
+    int nx = 6, ny = 6, nz = 3;
+    std::vector<int32_t> conn;
+    std::vector<double> trans, pv, z;
+
+    Deck()
+    {
+        const double dx = 10, dy = 10, dz = 2, perm = 1e-13, poro = 0.2;
+        auto id = [&](int i, int j, int k) { return (k * ny + j) * nx + i; };
+        for (int k = 0; k < nz; ++k) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
+            pv.push_back(poro * dx * dy * dz); z.push_back(2000.0 + (k + 0.5) * dz);
+        }
+        for (int k = 0; k < nz; ++k) for (int j = 0; j < ny; ++j) for (int i = 0; i + 1 < nx; ++i) { conn.push_back(id(i, j, k)); conn.push_back(id(i + 1, j, k)); trans.push_back(perm * dy * dz / dx); }
+        for (int k = 0; k < nz; ++k) for (int j = 0; j + 1 < ny; ++j) for (int i = 0; i < nx; ++i) { conn.push_back(id(i, j, k)); conn.push_back(id(i, j + 1, k)); trans.push_back(perm * dx * dz / dy); }
+        for (int k = 0; k + 1 < nz; ++k) for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) { conn.push_back(id(i, j, k)); conn.push_back(id(i, j, k + 1)); trans.push_back(0.1 * perm * dx * dy / dz); }
+    }
+    opmgpu_grid grid() const
+    {
+        opmgpu_grid g{};
+        g.nc = nx * ny * nz; g.nconn = int32_t(trans.size()); g.conn_cells = conn.data(); g.trans = trans.data(); g.pv = pv.data(); g.z = z.data();
+        g.gravity = 9.80665;
+        return g;
+    }
+    opmgpu_tables tables() const
+    {
+        opmgpu_tables t{};
+        t.n_pvt_regions = 1; t.n_sat_regions = 1; t.has_disgas = 0; t.has_vapoil = 0;
+        t.surface_density = dens.data(); t.pvtw = pvtw.data();
+        t.oil_node_ptr = oil_node_ptr.data(); t.oil_rs = oil_rs.data(); t.oil_psat = oil_p.data(); t.oil_invb_sat = oil_invb.data(); t.oil_invbmu_sat = oil_invbmu.data();
+        t.oil_col_ptr = oil_col_ptr.data(); t.oil_col_p = oil_p.data(); t.oil_col_invb = oil_invb.data(); t.oil_col_invbmu = oil_invbmu.data();
+        t.gas_node_ptr = gas_node_ptr.data(); t.gas_pg = gas_p.data(); t.gas_rvsat = gas_rv.data(); t.gas_invb_sat = gas_invb.data(); t.gas_invbmu_sat = gas_invbmu.data();
+        t.gas_col_ptr = gas_col_ptr.data(); t.gas_col_rv = gas_rv.data(); t.gas_col_invb = gas_invb.data(); t.gas_col_invbmu = gas_invbmu.data();
+        t.swof_ptr = swof_ptr.data(); t.swof_sw = sw.data(); t.swof_krw = krw.data(); t.swof_krow = krow.data(); t.swof_pcow = pcow.data();
+        t.sgof_ptr = sgof_ptr.data(); t.sgof_sg = sg.data(); t.sgof_krg = krg.data(); t.sgof_krog = krog.data(); t.sgof_pcgo = pcgo.data();
+        t.rock_pref = 200e5; t.rock_comp = 4e-10;
+        return t;
+    }
+};
+
+} // namespace
+
 int main()
 {
     std::printf("%s, devices: %d\n", opmgpu_version(), opmgpu_device_count());
+    const Deck deck;
+    const opmgpu_grid grid = deck.grid();
+    const opmgpu_tables tables = deck.tables();
+    if (opmgpu_device_count() <= 0) {
+        try {
+            opmgpu::BlackoilModelGpu model(grid, tables);
+            std::printf("host_check: FAILED, a model was created without a device\n");
+            return 1;
+        } catch (const std::exception& e) {
+            std::printf("expected without a GPU: %s\n", e.what());
+        }
+        return 0;
+    }
+    const int nc = grid.nc;
+    std::vector<double> p(nc), sat(3 * size_t(nc)), rs(nc, 0.0), rv(nc, 0.0);
+    std::vector<int8_t> hc(nc, int8_t(OPMGPU_HC_GAS_AND_OIL));
+    for (int c = 0; c < nc; ++c) {
+        p[c] = 200e5 + 2e5 * std::sin(0.7 * c);                      // out of equilibrium: the step has something to do
+        sat[3 * c] = 0.3; sat[3 * c + 2] = (c % 5 == 0) ? 0.1 : 0.0; sat[3 * c + 1] = 1.0 - sat[3 * c] - sat[3 * c + 2];
+    }
+    opmgpu::ReservoirStateView state{ p.data(), sat.data(), rs.data(), rv.data(), hc.data() };
     try {
-        opmgpu::NewtonIterationBlackoilGpu solver;
-        std::printf("solver context created\n");
+        opmgpu::BlackoilModelGpu model(grid, tables);
+        opmgpu::NonlinearSolverGpu solver;
+        const double p_before = p[0];
+        model.prepareStep(86400.0, state);
+        const int its = solver.step(model);
+        model.downloadState(state);
+        double smin = 1.0, ssum_err = 0.0;
+        for (int c = 0; c < nc; ++c) {
+            for (int a = 0; a < 3; ++a) smin = std::min(smin, sat[3 * c + a]);
+            ssum_err = std::max(ssum_err, std::abs(sat[3 * c] + sat[3 * c + 1] + sat[3 * c + 2] - 1.0));
+        }
+        if (!(smin >= 0.0) || !(ssum_err < 1e-12) || !(p[0] != p_before)) {
+            std::printf("host_check: FAILED, implausible state after the step (smin %g, sum error %g)\n", smin, ssum_err);
+            return 1;
+        }
+        std::printf("host_check: converged in %d Newton iterations, last linear solve %d iterations, relaxation %.2f\n", its,
+                    model.linearIterationsLastSolve(), model.relaxation());
     } catch (const std::exception& e) {
-        std::printf("expected without a GPU: %s\n", e.what());
+        std::printf("host_check: FAILED with exception: %s\n", e.what());
+        return 1;
     }
     return 0;
 }

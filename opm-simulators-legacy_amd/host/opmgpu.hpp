@@ -13,6 +13,9 @@
 #ifndef OPMGPU_HOST_HPP
 #define OPMGPU_HOST_HPP
 
+#include <algorithm>
+#include <array>
+#include <cmath>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -130,15 +133,30 @@ public:
     void updateState(double relax = 1.0) { throw_on_status(ctx_, opmgpu_update_state(ctx_, nullptr, relax)); }
     void downloadState(const ReservoirStateView& s) { throw_on_status(ctx_, opmgpu_get_state(ctx_, s.pressure, s.saturation, s.gasoilratio, s.rv, s.hydroCarbonState)); }
 
-    /// nonlinearIteration (:239-326): assemble -> getConvergence -> [solve -> update]
-    bool nonlinearIteration(int iteration, int min_iter = 1)
+    /// nonlinearIteration (:239-326): assemble -> getConvergence -> [solve -> stabilise -> update].
+    /// NonlinearSolverType supplies minIter / detectOscillations / relaxIncrement / relaxMax / relaxType like the reference's.
+    template <class NonlinearSolverType>
+    bool nonlinearIteration(int iteration, const NonlinearSolverType& nonlinear_solver)
     {
+        if (iteration == 0) { residual_norms_history_.clear(); current_relaxation_ = 1.0; }    // dx_old is zeroed by the initial assembly
         assemble(iteration == 0);
         const ConvergenceReport r = getConvergence();
-        const bool must_solve = (iteration < min_iter) || !r.converged;
-        if (must_solve) { solveJacobianSystem(); updateState(); }
+        residual_norms_history_.push_back({ r.linf[0], r.linf[1], r.linf[2] });               // computeResidualNorms (:1551-1589)
+        const bool must_solve = (iteration < nonlinear_solver.minIter()) || !r.converged;
+        if (must_solve) {
+            solveJacobianSystem();
+            if (use_update_stabilization_) {
+                bool isOscillate = false, isStagnate = false;
+                nonlinear_solver.detectOscillations(residual_norms_history_, iteration, isOscillate, isStagnate);
+                if (isOscillate) current_relaxation_ = std::max(current_relaxation_ - nonlinear_solver.relaxIncrement(), nonlinear_solver.relaxMax());
+                throw_on_status(ctx_, opmgpu_stabilize_update(ctx_, nonlinear_solver.relaxType(), current_relaxation_));
+            }
+            updateState();
+        }
         return r.converged;
     }
+    double relaxation() const { return current_relaxation_; }
+    void setUseUpdateStabilization(bool on) { use_update_stabilization_ = on; }
     int linearIterationsLastSolve() const { return linear_iterations_; }
     opmgpu_ctx* handle() const { return ctx_; }
 
@@ -147,16 +165,44 @@ private:
     int nc_ = 0;
     double dt_ = 0.0, max_single_precision_days_ = 20.0, linear_reduction_ = 0.0;
     int linear_iterations_ = 0;
+    bool use_update_stabilization_ = true;              // BlackoilModelParameters.cpp:98
+    double current_relaxation_ = 1.0;
+    std::vector<std::array<double, 3>> residual_norms_history_;
 };
 
-/// NonlinearSolver::step (NonlinearSolver_impl.hpp:119-174) without the oscillation / relaxation logic
+/// NonlinearSolver (NonlinearSolver_impl.hpp:119-301): step loop, oscillation detection, relaxation parameters
 struct NonlinearSolverGpu {
-    int max_iter = 10, min_iter = 1;
+    int max_iter = 10, min_iter = 1;                                          // SolverParameters::reset (:183-192)
+    int relax_type = OPMGPU_RELAX_DAMPEN;
+    double relax_max = 0.5, relax_increment = 0.1, relax_rel_tol = 0.2;
+    int minIter() const { return min_iter; }
+    int maxIter() const { return max_iter; }
+    int relaxType() const { return relax_type; }
+    double relaxMax() const { return relax_max; }
+    double relaxIncrement() const { return relax_increment; }
+    double relaxRelTol() const { return relax_rel_tol; }
+
+    /// detectOscillations (:221-257): two of the three phase residual norms return to their value of two iterations ago
+    void detectOscillations(const std::vector<std::array<double, 3>>& residual_history, int it, bool& oscillate, bool& stagnate) const
+    {
+        if (it < 2) { oscillate = false; stagnate = false; return; }
+        stagnate = true;
+        int oscillatePhase = 0;
+        const auto &F0 = residual_history[it], &F1 = residual_history[it - 1], &F2 = residual_history[it - 2];
+        for (int p = 0; p < 3; ++p) {
+            const double d1 = std::abs((F0[p] - F2[p]) / F0[p]);
+            const double d2 = std::abs((F0[p] - F1[p]) / F0[p]);
+            oscillatePhase += (d1 < relax_rel_tol) && (relax_rel_tol < d2);
+            stagnate = stagnate && !(std::abs((F1[p] - F2[p]) / F2[p]) > 1.0e-3);
+        }
+        oscillate = oscillatePhase > 1;
+    }
+
     int step(BlackoilModelGpu& model) const
     {
         int iteration = 0; bool converged = false;
         do {
-            converged = model.nonlinearIteration(iteration, min_iter);
+            converged = model.nonlinearIteration(iteration, *this);
             ++iteration;
         } while ((!converged && iteration <= max_iter) || iteration <= min_iter);
         if (!converged) throw TooManyIterations("Failed to complete a time step within " + std::to_string(max_iter) + " iterations.");

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libopmgpu.so")
 
 OK, EINVAL, ENODEVICE, ENUMERICAL, ELINSOLVE, EBREAKDOWN, ESINGULAR, ENOMEM, ECOMM = range(9)
 HC_GAS_ONLY, HC_GAS_AND_OIL, HC_OIL_ONLY = 0, 1, 2
+RELAX_DAMPEN, RELAX_SOR = 0, 1
 ORDER_NATURAL, ORDER_MULTICOLOR = 0, 1
 K_SPMV, K_ILU_APPLY, K_ILU_FACTOR, K_ASSEMBLE, K_DOT, K_AXPY, K_PROPS, K_STREAM_COPY = range(8)
 PERF_K = 36
@@ -43,7 +44,9 @@ class Tables(C.Structure):
                 ("swof_pcow", _dp),
                 ("sgof_ptr", _ip), ("sgof_sg", _dp), ("sgof_krg", _dp), ("sgof_krog", _dp),
                 ("sgof_pcgo", _dp),
-                ("rock_pref", C.c_double), ("rock_comp", C.c_double)]
+                ("rock_pref", C.c_double), ("rock_comp", C.c_double),
+                ("vap1", C.c_double), ("vap2", C.c_double),
+                ("rocktab_n", C.c_int32), ("rocktab_p", _dp), ("rocktab_pvmult", _dp), ("rocktab_transmult", _dp)]
 
 
 class Params(C.Structure):
@@ -108,6 +111,10 @@ SIGNATURES = {
     "opmgpu_convergence": (C.c_int, [C.c_void_p, C.c_double, _dp, _dp, _dp, _dp, C.POINTER(C.c_int)]),
     "opmgpu_solve": (C.c_int, [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int), _dp]),
     "opmgpu_update_state": (C.c_int, [C.c_void_p, _dp, C.c_double]),
+    "opmgpu_stabilize_update": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
+    "opmgpu_set_sat_oil_max": (C.c_int, [C.c_void_p, _dp]),
+    "opmgpu_update_sat_oil_max": (C.c_int, [C.c_void_p]),
+    "opmgpu_get_sat_oil_max": (C.c_int, [C.c_void_p, _dp]),
     "opmgpu_create_solver": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(Params)]),
     "opmgpu_solve_bsr": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _dp, _dp, C.c_int, _dp, C.POINTER(C.c_int), _dp]),
     "opmgpu_load_bsr": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _dp, C.c_int]),

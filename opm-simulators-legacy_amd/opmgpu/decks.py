@@ -27,12 +27,13 @@ GRAVITY = 9.80665
 class FluidTables:
     """Flat table arrays matching `opmgpu_tables` (include/opmgpu.h)."""
 
-    def __init__(self, density_wog, pvtw, pvto, pvtg, swof, sgof, rock, disgas=True, vapoil=True):
+    def __init__(self, density_wog, pvtw, pvto, pvtg, swof, sgof, rock, disgas=True, vapoil=True, vappars=(0.0, 0.0), rocktab=None):
         """All inputs in deck units (METRIC): lists per region.
 
         pvto: per region, list of (rs, [(p, Bo, muo), ...]) saturated rows with undersaturated
         branches; pvtg: per region, list of (pg, [(rv, Bg, mug), ...]) (first = saturated).
         pvdo / pvdg style dead tables: pass rows with a single column entry and disgas/vapoil False.
+        vappars = (vap1, vap2) of VAPPARS; rocktab = rows (p [bar], pv_mult, trans_mult) of ROCKTAB (replaces `rock`).
         """
         self.n_pvt = len(pvtw)
         self.n_sat = len(swof)
@@ -45,6 +46,12 @@ class FluidTables:
         self._build_gas(pvtg)
         self._build_sat(swof, sgof)
         self.rock_pref, self.rock_comp = rock[0] * BAR, rock[1] / BAR
+        self.vap1, self.vap2 = float(vappars[0]), float(vappars[1])
+        self.rocktab_n = 0
+        if rocktab is not None:
+            rt = capi.f64(rocktab).reshape(-1, 3)
+            self.rocktab_n = rt.shape[0]
+            self.rocktab_p, self.rocktab_pvmult, self.rocktab_transmult = capi.f64(rt[:, 0] * BAR), capi.f64(rt[:, 1]), capi.f64(rt[:, 2])
         self._struct = None
 
     # opm-material LiveOilPvt::initFromDeck + extendPvtoTable_ (restated): rows without
@@ -131,12 +138,13 @@ class FluidTables:
                     a = getattr(self, name)
                     setattr(t, name, capi.iptr(a) if a.dtype == np.int32 else capi.dptr(a))
             t.rock_pref, t.rock_comp = self.rock_pref, self.rock_comp
+            t.vap1, t.vap2, t.rocktab_n = self.vap1, self.vap2, self.rocktab_n
             self._struct = t
         return self._struct
 
 
-def satfunc_standard_tables(pc_scale=1.0):
-    """PROPS of the reference's tests/satfuncStandard.DATA (METRIC)."""
+def satfunc_standard_tables(pc_scale=1.0, **extra):
+    """PROPS of the reference's tests/satfuncStandard.DATA (METRIC); extra = vappars= / rocktab= passed on to FluidTables."""
     pvto = [[(0, [(1., 1.0000, 1.20)]), (20, [(40., 1.0120, 1.17)]), (40, [(80., 1.0255, 1.14)]),
              (60, [(120., 1.0380, 1.11)]), (80, [(160., 1.0510, 1.08)]), (100, [(200., 1.0630, 1.06)]),
              (120, [(240., 1.0750, 1.03)]), (140, [(280., 1.0870, 1.00)]), (160, [(320., 1.0985, .98)]),
@@ -151,7 +159,7 @@ def satfunc_standard_tables(pc_scale=1.0):
     sgof = [[(a, b, c, d * pc_scale) for a, b, c, d in sgof[0]]]
     # DENSITY 700 1000 1 is (oil, water, gas); ours is (water, oil, gas)
     return FluidTables(density_wog=[[1000.0, 700.0, 1.0]], pvtw=[[1.0, 1.0, 4.0e-5, 0.96, 0.0]],
-                       pvto=pvto, pvtg=pvtg, swof=swof, sgof=sgof, rock=(1.0, 5.0e-5))
+                       pvto=pvto, pvtg=pvtg, swof=swof, sgof=sgof, rock=(1.0, 5.0e-5), **extra)
 
 
 def fluid_data_tables():

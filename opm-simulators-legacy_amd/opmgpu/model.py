@@ -137,6 +137,8 @@ class GpuBlackoilModel:
         self.max_single_precision_days = 20.0       # BlackoilModelParameters.cpp:95
         self.linear_iterations = 0
         self.dt = None
+        self.use_update_stabilization = True        # BlackoilModelParameters.cpp:98
+        self.residual_norms_history, self.current_relaxation = [], 1.0
         if wells is not None:
             self.setWells(*wells)
 
@@ -199,14 +201,39 @@ class GpuBlackoilModel:
     def updateState(self, dx=None, relax=1.0):
         self._chk(self.lib.opmgpu_update_state(self.ctx, capi.dptr(None if dx is None else capi.f64(dx)), float(relax)))
 
-    def nonlinearIteration(self, iteration, single_precision=None):
-        """nonlinearIteration (:239-326). Returns (converged, linear_iterations)."""
+    # satOilMax_ of BlackoilPropsAdFromDeck (VAPPARS); updateSatOilMax is called once per report step (SimulatorBase_impl.hpp:192)
+    def setSatOilMax(self, so_max):
+        self._chk(self.lib.opmgpu_set_sat_oil_max(self.ctx, capi.dptr(capi.f64(so_max))))
+
+    def updateSatOilMax(self):
+        self._chk(self.lib.opmgpu_update_sat_oil_max(self.ctx))
+
+    def satOilMax(self):
+        out = np.zeros(self.nc)
+        self._chk(self.lib.opmgpu_get_sat_oil_max(self.ctx, capi.dptr(out)))
+        return out
+
+    def stabilizeUpdate(self, relax_type, omega):
+        self._chk(self.lib.opmgpu_stabilize_update(self.ctx, int(relax_type), float(omega)))
+
+    def nonlinearIteration(self, iteration, single_precision=None, nonlinear_solver=None):
+        """nonlinearIteration (BlackoilModelBase_impl.hpp:239-326). Returns (converged, linear_iterations).
+        With a `NonlinearSolver` the update is stabilised exactly like the reference's use_update_stabilization path."""
+        ns = nonlinear_solver
+        if iteration == 0:
+            self.residual_norms_history, self.current_relaxation = [], 1.0
         self.assemble(iteration == 0)
         converged = self.getConvergence()
+        self.residual_norms_history.append(list(self.linf))          # computeResidualNorms (:1551-1589)
         lin = 0
-        if not converged or iteration < 1:         # min_iter = 1 (NonlinearSolver_impl.hpp:179-219)
+        if not converged or iteration < (ns.min_iter if ns else 1):
             self.solveJacobianSystem(single_precision=single_precision)
             lin = self.linear_iterations
+            if ns is not None and self.use_update_stabilization:
+                oscillate, _ = ns.detectOscillations(self.residual_norms_history, iteration)
+                if oscillate:
+                    self.current_relaxation = max(self.current_relaxation - ns.relax_increment, ns.relax_max)
+                self.stabilizeUpdate(ns.relax_type, self.current_relaxation)
             self.updateState()
         return converged, lin
 
@@ -258,8 +285,43 @@ class GpuBlackoilModel:
         return pos, lev, nl.value
 
 
+class NonlinearSolver:
+    """NonlinearSolver (NonlinearSolver_impl.hpp:119-301): step loop, oscillation detection, relaxation parameters."""
+
+    def __init__(self, max_iter=10, min_iter=1, relax_type=capi.RELAX_DAMPEN, relax_max=0.5, relax_increment=0.1, relax_rel_tol=0.2):
+        self.max_iter, self.min_iter = max_iter, min_iter               # SolverParameters::reset (:183-192)
+        self.relax_type, self.relax_max, self.relax_increment, self.relax_rel_tol = relax_type, relax_max, relax_increment, relax_rel_tol
+
+    def detectOscillations(self, residual_history, it):
+        """(:221-257) -> (oscillate, stagnate); only the three mass-balance norms take part."""
+        if it < 2:
+            return False, False
+        F0, F1, F2 = residual_history[it], residual_history[it - 1], residual_history[it - 2]
+        stagnate, n_osc = True, 0
+        with np.errstate(divide="ignore", invalid="ignore"):
+            for p in range(3):
+                d1 = abs(np.float64(F0[p] - F2[p]) / F0[p])
+                d2 = abs(np.float64(F0[p] - F1[p]) / F0[p])
+                n_osc += int((d1 < self.relax_rel_tol) and (self.relax_rel_tol < d2))
+                stagnate = stagnate and not (abs(np.float64(F1[p] - F2[p]) / F2[p]) > 1.0e-3)
+        return n_osc > 1, stagnate
+
+    def step(self, model, single_precision=None):
+        """(:119-174). Returns (newton_iterations, linear_iterations); raises TooManyIterations."""
+        it, lin_total = 0, 0
+        while True:
+            converged, lin = model.nonlinearIteration(it, single_precision=single_precision, nonlinear_solver=self)
+            lin_total += lin
+            it += 1
+            if not ((not converged and it <= self.max_iter) or it <= self.min_iter):
+                break
+        if not converged:
+            raise TooManyIterations("Solver convergence failure - Failed to complete a time step within %d iterations." % self.max_iter)
+        return it, lin_total
+
+
 def newton_step(model, max_iter=10, min_iter=1):
-    """NonlinearSolver::step (NonlinearSolver_impl.hpp:119-174) without the relaxation logic.
+    """NonlinearSolver::step (NonlinearSolver_impl.hpp:119-174) with use_update_stabilization=false (plain Newton).
     Returns (newton_iterations, linear_iterations)."""
     it, lin_total = 0, 0
     while True:

@@ -316,6 +316,28 @@ PvtOut rv_sat(const opmgpu_tables* t, int reg, double p)
     return r;
 }
 
+// VAPPARS, BlackoilPropsAdFromDeck::applyVap (BlackoilPropsAdFromDeck.cpp:1027-1078): factor and d(factor)/d(so)
+const double* g_so_max = nullptr;      // satOilMax_ per cell (oracle_set_sat_oil_max); NULL = all zero (:175)
+inline void vap_factor(double vap, double so, double so_max, double& f, double& df)
+{
+    f = 1.0; df = 0.0;
+    if (vap > 0.0 && so_max > 0.01 /* vap_satmax_guard_, :187 */ && so < so_max) {
+        const double so_i = std::max(so, std::sqrt(std::numeric_limits<double>::epsilon()));
+        f = std::pow(so_i / so_max, vap);
+        df = vap * std::pow(so_i / so_max, vap - 1.0) / so_max;
+    }
+}
+// ROCKTAB, Opm::linearInterpolation / linearInterpolationDerivative (opm-common, restated: tableIndex = lower_bound - 1
+// clamped to [0, n-2], i.e. the LEFT segment at a breakpoint and linear extrapolation outside)
+inline void rocktab_eval(const double* x, const double* y, int n, double xv, double& f, double& df)
+{
+    int i = int(std::lower_bound(x, x + n, xv) - x);
+    i = (i >= n) ? n - 2 : (i > 0 ? i - 1 : 0);
+    if (i > n - 2) i = n - 2;
+    df = (y[i + 1] - y[i]) / (x[i + 1] - x[i]);
+    f = y[i] + df * (xv - x[i]);
+}
+
 // ----------------------------------------------------------------------------------------
 // per-cell SolutionState + ReservoirResidualQuant
 // ----------------------------------------------------------------------------------------
@@ -351,11 +373,17 @@ CellQ cell_eval(const opmgpu_grid* g, const opmgpu_tables* t, int c, double p, d
     q.po = P; q.pw = P - pcow; q.pg = P + pcgo;
     // rsSat / rvSat (T = 293.15 ignored by the isothermal tables), :662-674
     {
+        const double so_max = g_so_max ? g_so_max[c] : 0.0;
+        double vf, dvf;
         const PvtOut r = rs_sat(t, preg, q.po.v);
         D3 rsSat = chain(r.v, r.dp, q.po);
+        vap_factor(t->vap2, so.v, so_max, vf, dvf);                  // :679
+        if (t->vap2 > 0.0) rsSat = chain(vf, dvf, so) * rsSat;
         q.rs = t->has_disgas ? ((isRs ? 0.0 : 1.0) * rsSat + (isRs ? 1.0 : 0.0) * X) : rsSat;
         const PvtOut v = rv_sat(t, preg, q.pg.v);
         D3 rvSat = chain(v.v, v.dp, q.pg);
+        vap_factor(t->vap1, so.v, so_max, vf, dvf);                  // :736
+        if (t->vap1 > 0.0) rvSat = chain(vf, dvf, so) * rvSat;
         q.rv = t->has_vapoil ? ((isRv ? 0.0 : 1.0) * rvSat + (isRv ? 1.0 : 0.0) * X) : rvSat;
     }
     // fluidReciprocFVF / fluidViscosity, BlackoilPropsAdFromDeck.cpp:264-622
@@ -368,12 +396,15 @@ CellQ cell_eval(const opmgpu_grid* g, const opmgpu_tables* t, int c, double p, d
     // computeRelPerm, :1395-1419
     relperm3(st, ep, W, sg, q.kr[0], q.kr[1], q.kr[2]);
     // poroMult / transMult, :2089-2145 ; RockCompressibility.cpp:86-125
-    D3 pvm(1.0);
-    if (t->rock_comp != 0.0) {
+    D3 pvm(1.0), trm(1.0);
+    if (t->rocktab_n > 0) {
+        double f, df;
+        rocktab_eval(t->rocktab_p, t->rocktab_pvmult, t->rocktab_n, p, f, df); pvm = chain(f, df, P);
+        rocktab_eval(t->rocktab_p, t->rocktab_transmult, t->rocktab_n, p, f, df); trm = chain(f, df, P);
+    } else if (t->rock_comp != 0.0) {
         const double cp = t->rock_comp * (p - t->rock_pref);
         pvm = chain(1.0 + cp + 0.5 * cp * cp, t->rock_comp + cp * t->rock_comp, P);
     }
-    const D3 trm(1.0);
     // fluidDensity, :2009-2027
     const double* rhos = t->surface_density + 3 * preg;
     q.rho[0] = rhos[0] * q.b[0];
@@ -877,11 +908,15 @@ void oracle_update_state(const opmgpu_grid* g, const opmgpu_tables* t, const opm
             rvn = std::max(rv_old - lim, 0.0);
         }
         // phase-state switching, :1292-1356
+        const double so_max = g_so_max ? g_so_max[c] : 0.0;
         const bool watOnly = sw > (1 - eps);
         int hcn = OPMGPU_HC_GAS_AND_OIL;
         if (t->has_disgas) {
-            const double rsSat0 = rs_sat(t, preg, p_old).v;
-            const double rsSat = rs_sat(t, preg, pn).v;
+            double f0, f1, df;
+            vap_factor(t->vap2, so_old, so_max, f0, df);
+            vap_factor(t->vap2, so, so_max, f1, df);
+            const double rsSat0 = f0 * rs_sat(t, preg, p_old).v;          // fluidRsSat(p_old, so_old), :1301
+            const double rsSat = f1 * rs_sat(t, preg, pn).v;              // fluidRsSat(p, so), :1302
             const bool hasGas = (sg > 0 && !isRs);
             const bool gasVaporized = ((rsn > rsSat * (1 + eps) && isRs) && (rs_old > rsSat0 * (1 - eps)));
             const bool useSg = watOnly || hasGas || gasVaporized;
@@ -896,8 +931,11 @@ void oracle_update_state(const opmgpu_grid* g, const opmgpu_tables* t, const opm
             const double pg_old = p_old + b.v;
             cappress3(st, ep, D3(sw), D3(sg), a, b);
             const double pg_new = pn + b.v;
-            const double rvSat0 = rv_sat(t, preg, pg_old).v;
-            const double rvSat = rv_sat(t, preg, pg_new).v;
+            double f0, f1, df;
+            vap_factor(t->vap1, so_old, so_max, f0, df);
+            vap_factor(t->vap1, so, so_max, f1, df);
+            const double rvSat0 = f0 * rv_sat(t, preg, pg_old).v;         // :1332
+            const double rvSat = f1 * rv_sat(t, preg, pg_new).v;          // :1333 (so possibly zeroed by the rs block above)
             const bool hasOil = (so > 0 && !isRv);
             const bool oilCondensed = ((rvn > rvSat * (1 + eps) && isRv) && (rv_old > rvSat0 * (1 - eps)));
             const bool useSg = watOnly || hasOil || oilCondensed;
@@ -910,6 +948,8 @@ void oracle_update_state(const opmgpu_grid* g, const opmgpu_tables* t, const opm
         hc[c] = int8_t(hcn);
     }
 }
+
+void oracle_set_sat_oil_max(const double* so_max) { g_so_max = so_max; }
 
 void oracle_spmv(int nb, const int32_t* rowptr, const int32_t* col, const double* val9, const double* x3, double* y3, int sp)
 {

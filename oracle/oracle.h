@@ -79,6 +79,9 @@ void oracle_update_state(const opmgpu_grid* g, const opmgpu_tables* t, const opm
                          const double* dx, double* p, double* sat, double* rs, double* rv,
                          int8_t* hc);
 
+/* VAPPARS: satOilMax_ per cell used by every later call (BlackoilPropsAdFromDeck.cpp:933-955); the pointer is kept, NULL = zeros */
+void oracle_set_sat_oil_max(const double* so_max);
+
 /* MatrixAdapter::apply: y = A x on BSR, x/y block-interleaved. */
 void oracle_spmv(int nb, const int32_t* rowptr, const int32_t* col, const double* val9,
                  const double* x3, double* y3, int single_precision);

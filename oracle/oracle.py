@@ -52,6 +52,7 @@ def lib():
         L.oracle_ilu0_apply.argtypes = [C.c_int, _ip, _ip, _dp, _ip, C.c_double, C.c_int, _dp, _dp]
         L.oracle_bicgstab_ilu0.argtypes = [C.c_int, _ip, _ip, _dp, _dp, _ip, _P, C.c_int, _dp, C.POINTER(C.c_int), _dp, _dp, C.c_int, C.POINTER(C.c_int)]
         L.oracle_bicgstab_ilu0.restype = C.c_int
+        L.oracle_set_sat_oil_max.argtypes = [_dp]
         L.oracle_set_threads.argtypes = [C.c_int]
         L.oracle_get_threads.restype = C.c_int
         _lib = L
@@ -60,6 +61,16 @@ def lib():
 
 def set_threads(n):
     lib().oracle_set_threads(int(n))
+
+
+_so_max_keepalive = None
+
+
+def set_sat_oil_max(so_max):
+    """satOilMax_ for every later cell_props / assemble / update_state call (None = zeros, the reference's initial value)."""
+    global _so_max_keepalive
+    _so_max_keepalive = None if so_max is None else capi.f64(so_max).copy()
+    lib().oracle_set_sat_oil_max(capi.dptr(_so_max_keepalive))
 
 
 def relperm(tables, s, satnum=None):

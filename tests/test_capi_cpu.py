@@ -95,3 +95,32 @@ def test_plan_rejects_bad_patterns(lib):
     rowptr = np.array([0, 2, 3], np.int32)
     assert _plan(lib, rowptr, np.array([1, 0, 1], np.int32), 0)[0] == capi.EINVAL   # unsorted columns
     assert _plan(lib, np.array([0, 1, 2], np.int32), np.array([0, 1], np.int32), 7)[0] == capi.EINVAL
+
+
+def test_cpp_host_mirror_builds_and_fails_loudly_without_gpu():
+    """host/opmgpu.hpp (the C++ mirror of BlackoilModel / NonlinearSolver) compiles with plain g++ against the C ABI;
+    without a device the model constructor throws instead of falling back to a CPU path."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(capi.LIB_PATH), "host_check")
+    assert os.path.exists(exe), "run `make -C opm-simulators-legacy_amd/csrc` (or __graft_entry__.build())"
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("covered by the gpu test")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "expected without a GPU" in out.stdout and "no CPU fallback" in out.stdout
+
+
+def test_detect_oscillations_rule():
+    """NonlinearSolver::detectOscillations (NonlinearSolver_impl.hpp:221-257): at least two phases whose residual norm returns
+    to its value of two iterations ago (within relax_rel_tol) while differing from the previous one."""
+    from opmgpu.model import NonlinearSolver
+    ns = NonlinearSolver()
+    assert ns.detectOscillations([[1, 1, 1]], 0) == (False, False)
+    assert ns.detectOscillations([[1, 1, 1], [2, 2, 2]], 1) == (False, False)
+    hist = [[1.0, 1.0, 1.0], [2.0, 2.0, 1.0], [1.05, 0.95, 1.0]]          # phases 0 and 1 flip back, phase 2 is flat
+    assert ns.detectOscillations(hist, 2) == (True, False)
+    hist = [[1.0, 1.0, 1.0], [2.0, 1.0, 1.0], [1.05, 1.0, 1.0]]           # only one phase oscillates
+    assert ns.detectOscillations(hist, 2) == (False, False)
+    hist = [[1.0, 1.0, 1.0], [1.0, 1.0, 1.0 + 5e-4], [0.5, 0.4, 0.3]]     # nothing moved between it-2 and it-1: stagnation
+    assert ns.detectOscillations(hist, 2) == (False, True)

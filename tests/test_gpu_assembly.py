@@ -313,3 +313,96 @@ def test_endscale_known_answers_on_device(gpu_lib):
             assert close(pp[c, 6, 2] * mu_w, A["DkrwDsw"][c][i]), (c, i, "DkrwDsw", pp[c, 6, 2] * mu_w, A["DkrwDsw"][c][i])
             assert close(pp[c, 7, 2] * mu_o, A["DkroDsw"][c][i]), (c, i, "DkroDsw", pp[c, 7, 2] * mu_o, A["DkroDsw"][c][i])
     m.close()
+
+
+def test_stabilize_update_dampen_and_sor(gpu_lib, oracle):
+    """stabilizeNonlinearUpdate (NonlinearSolver_impl.hpp:260-301) on the resident increment, observed through updateState."""
+    tab = decks.satfunc_standard_tables()
+    grid = decks.cartesian_grid(6, 5, 4)
+    prm = capi.default_params()
+    rng = np.random.default_rng(11)
+    nc = grid.nc
+    st = decks.random_state(grid, tab, seed=3)
+
+    def rand_dx():
+        return np.concatenate([rng.standard_normal(nc) * 5 * decks.BAR, rng.standard_normal(nc) * 0.05,
+                               rng.standard_normal(nc) * np.where(st.hc == capi.HC_OIL_ONLY, 5.0, np.where(st.hc == capi.HC_GAS_ONLY, 1e-5, 0.05))])
+
+    def check(m, dx_expected):
+        m.setState(st)
+        m.updateState()
+        g, o = m.getState(), oracle.update_state(grid, tab, prm, dx_expected, st)
+        assert np.array_equal(g.hc, o.hc)
+        assert np.allclose(g.p, o.p, rtol=1e-13, atol=0) and np.allclose(g.sat, o.sat, rtol=0, atol=1e-13)
+
+    for rtype in (capi.RELAX_DAMPEN, capi.RELAX_SOR):
+        m = GpuBlackoilModel(grid, tab, prm)
+        m.prepareStep(decks.DAY, st)
+        m.assemble(True)                                   # iteration 0 zeroes dx_old
+        dx1, dx2 = rand_dx(), rand_dx()
+        m.updateState(dx1)
+        m.stabilizeUpdate(rtype, 1.0)                      # omega == 1: dx untouched, dx_old <- dx1
+        check(m, dx1)
+        m.updateState(dx2)
+        m.stabilizeUpdate(rtype, 0.6)
+        check(m, 0.6 * dx2 if rtype == capi.RELAX_DAMPEN else 0.6 * dx2 + 0.4 * dx1)
+        m.close()
+
+
+def test_cpp_host_mirror_runs_a_time_step(gpu_lib):
+    """The C++ mirror (host/opmgpu.hpp: BlackoilModelGpu + NonlinearSolverGpu) drives one time step of a hand-authored
+    dead-oil deck through the C ABI -- the binding a flow_legacy maintainer would compile."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(capi.LIB_PATH), "host_check")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "host_check: converged in" in out.stdout, out.stdout
+
+
+def test_vappars_rocktab_parity(gpu_lib, oracle):
+    """VAPPARS (applyVap, BlackoilPropsAdFromDeck.cpp:1052-1078) and ROCKTAB (RockCompressibility.cpp:86-125): assembly and
+    updateState vs the oracle, soMax handling (updateSatOilMax, :933-945) included."""
+    rocktab = [(100.0, 0.98, 0.95), (200.0, 1.0, 1.0), (300.0, 1.03, 1.08), (500.0, 1.05, 1.12)]
+    plain = decks.satfunc_standard_tables()
+    tab = decks.satfunc_standard_tables(vappars=(0.7, 1.3), rocktab=rocktab)
+    grid = decks.cartesian_grid(7, 6, 5, lognormal_sigma=0.5)
+    prm = capi.default_params()
+    scale = tuple(prm.matbalscale)
+    rowptr, col = oracle.pattern(grid)
+    rng = np.random.default_rng(21)
+    nc = grid.nc
+    try:
+        for seed in (1, 2):
+            st = decks.random_state(grid, tab, seed=seed)
+            m = GpuBlackoilModel(grid, tab, prm)
+            m.prepareStep(2 * decks.DAY, st)
+            assert np.all(m.satOilMax() == 0.0)                       # starts at zero like the reference's
+            m.updateSatOilMax()
+            assert np.array_equal(m.satOilMax(), st.sat[:, 1])        # first report step: soMax = so
+            so_max = np.maximum(st.sat[:, 1], rng.uniform(0.2, 0.9, nc))
+            m.setSatOilMax(so_max)
+            m.updateSatOilMax()
+            assert np.array_equal(m.satOilMax(), so_max)
+            oracle.set_sat_oil_max(so_max)
+            m.assemble(True)
+            r0, v0, _, _ = oracle.assemble(grid, tab, 2 * decks.DAY, st, rowptr, col, scale=scale)
+            oracle.set_sat_oil_max(None)
+            r_plain, v_plain, _, _ = oracle.assemble(grid, plain, 2 * decks.DAY, st, rowptr, col, scale=scale)
+            oracle.set_sat_oil_max(so_max)
+            assert rel_err(v_plain, v0) > 1e-3                        # the keywords matter for this state
+            assert rel_err(m.jacobian()[2], v0) < RTOL_JAC, rel_err(m.jacobian()[2], v0)
+            assert rel_err(m.residual(), r0) < RTOL_JAC
+            dx = np.concatenate([rng.standard_normal(nc) * 30 * decks.BAR, rng.standard_normal(nc) * 0.25,
+                                 rng.standard_normal(nc) * np.where(st.hc == capi.HC_OIL_ONLY, 30.0, np.where(st.hc == capi.HC_GAS_ONLY, 1e-4, 0.25))])
+            m.updateState(dx)
+            g, o = m.getState(), oracle.update_state(grid, tab, prm, dx, st)
+            assert np.array_equal(g.hc, o.hc)
+            assert np.allclose(g.p, o.p, rtol=1e-14, atol=0) and np.allclose(g.sat, o.sat, rtol=0, atol=1e-14)
+            assert np.allclose(g.rs, o.rs, rtol=1e-12, atol=1e-12) and np.allclose(g.rv, o.rv, rtol=1e-12, atol=1e-17)
+            # wells re-plan keeps soMax
+            m.setWells(np.array([0, 3], np.int32), np.array([2, 44, 86], np.int32))
+            assert np.array_equal(m.satOilMax(), so_max)
+            m.close()
+    finally:
+        oracle.set_sat_oil_max(None)

@@ -1,5 +1,6 @@
 """Independent checks of the CPU oracle itself (finite differences, exact solves)."""
 import numpy as np
+import pytest
 import scipy.sparse as sp
 import scipy.sparse.linalg as spla
 
@@ -15,10 +16,27 @@ def _eqmajor_to_interleaved(v, nc):
     return np.ascontiguousarray(v.reshape(3, nc).T).ravel()
 
 
-def test_fd_jacobian(oracle):
+ROCKTAB = [(100.0, 0.98, 0.95), (200.0, 1.0, 1.0), (300.0, 1.03, 1.08), (500.0, 1.05, 1.12)]
+
+
+@pytest.mark.parametrize("variant", ["plain", "endscale", "vappars+rocktab"])
+def test_fd_jacobian(oracle, variant):
     """Analytic (forward-AD) Jacobian vs central differences of the residual."""
     grid = decks.cartesian_grid(4, 3, 3, lognormal_sigma=0.5)
     tab = decks.satfunc_standard_tables()
+    nc = grid.nc
+    if variant == "endscale":
+        grid = decks.with_endpoints(grid, decks.random_endpoints(grid, seed=5))
+    if variant == "vappars+rocktab":
+        tab = decks.satfunc_standard_tables(vappars=(0.7, 1.3), rocktab=ROCKTAB)
+        oracle.set_sat_oil_max(np.random.default_rng(2).uniform(0.3, 0.9, nc))
+    try:
+        _fd_jacobian(oracle, grid, tab)
+    finally:
+        oracle.set_sat_oil_max(None)
+
+
+def _fd_jacobian(oracle, grid, tab):
     st = decks.random_state(grid, tab, seed=3, breakpoints=False)
     nc = grid.nc
     dt = 5 * decks.DAY
