@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N > 1: weak = every GPU keeps an nx x ny x nz slab (global deck nx x ny x nz*N, sized for 288 GB/GPU); strong = the fixed nx x ny x nz deck is cut into N slabs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="take the domain-decomposition code path (torch.distributed + RCCL communicator) even with one rank")
     ap.add_argument("--cpu-threads", type=int, default=1)
     args = ap.parse_args()
 
@@ -62,8 +63,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     ordering = capi.ORDER_MULTICOLOR if args.ordering == "multicolor" else capi.ORDER_NATURAL
     prm = capi.default_params(ilu_ordering=ordering, use_cpr=int(args.solver == "cpr"))
@@ -71,7 +74,7 @@ def main():
     dt = args.dt_days * decks.DAY
     single = dt < 20 * decks.DAY            # BlackoilModelBase_impl.hpp:284
 
-    if world > 1:
+    if use_dist:
         from opmgpu import partition
         nz_global = args.nz * world if args.scaling == "weak" else args.nz
         model, grid, st, info = partition.build_distributed_model(args.nx, args.ny, nz_global, tab, prm, rank, world, local_rank)
@@ -83,7 +86,7 @@ def main():
     nc_global = info["n_global"]
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -110,7 +113,7 @@ def main():
                 steps_done += 1
         barrier()
         elapsed = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
@@ -125,7 +128,7 @@ def main():
     # the same K iterations with the reference's DEFAULT linear solver (solver_approach=interleaved: ILU0 + BiCGStab),
     # which is also what the CPU baseline runs
     ilu0 = None
-    if world == 1 and prm.use_cpr:
+    if not use_dist and prm.use_cpr:
         prm0 = capi.default_params(ilu_ordering=ordering, use_cpr=0)
         m0 = GpuBlackoilModel(grid, tab, prm0, device=local_rank)
         r0 = timed_run(m0)
@@ -170,7 +173,7 @@ def main():
         main_roof = roof["f32" if single else "f64"]
 
         cpu = None
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and not use_dist:
             cpu = cpu_baseline(args, grid, tab, st, prm, dt, single)
 
         out = {
@@ -189,7 +192,7 @@ def main():
             "cpu_baseline": cpu,
         }
     model.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

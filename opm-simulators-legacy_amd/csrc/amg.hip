@@ -246,51 +246,47 @@ __global__ __launch_bounds__(kBlock) void k_amg_restrict(int nc, const int32_t* 
     bc[I] = s;
 }
 template <class S>
-__global__ __launch_bounds__(kBlock) void k_amg_prolong(int n, const int32_t* __restrict__ agg, const S* __restrict__ xc, S* __restrict__ x,
+__global__ __launch_bounds__(kBlock) void k_amg_prolong(int n, const int32_t* __restrict__ agg, const S* __restrict__ xc, S* __restrict__ x, S pdamp,
                                                         const SolveCtl* __restrict__ ctl)
 {
     if (ctl && ctl->done) return;
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    x[i] += xc[agg[i]];
+    x[i] += pdamp * xc[agg[i]];
 }
-// coarsest level: dense [A | I] -> Gauss-Jordan (no pivoting: the pressure operators are diagonally dominant M-matrix-like)
-template <class S>
-__global__ __launch_bounds__(kBlock) void k_dense_fill(int n, const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
-                                                       const S* __restrict__ val, double* __restrict__ aug)
-{
-    const int row = blockIdx.x * kBlock + threadIdx.x;
-    if (row >= n) return;
-    double* a = aug + long(row) * 2 * n;
-    for (int j = 0; j < 2 * n; ++j) a[j] = (j == n + row) ? 1.0 : 0.0;
-    const int base = slice_ptr[row >> 6], width = slice_ptr[(row >> 6) + 1] - base, lane = row & 63;
-    for (int k = 0; k < width; ++k) { const long e = long(base + k) * 64 + lane; a[col[e]] += double(val[e]); }
-}
-// Gauss-Jordan on the augmented matrix held entirely in LDS (n <= kDenseMax = 96: 96 x 192 doubles = 144 KiB of the
-// 160 KiB per CU); one workgroup, no pivoting (the pressure operators are diagonally dominant M-matrix-like).
+// coarsest level: the sparse operator is scattered into LDS and inverted IN PLACE by Gauss-Jordan (n <= kDenseMax = 96:
+// 72 KiB of the 160 KiB per CU); one workgroup of 1024 threads, no pivoting (the pressure operators are diagonally
+// dominant M-matrix-like).  Thread (i0, j) owns column j of rows i0, i0 + rows_per_pass, ...: no integer division in the loop.
 constexpr int kDenseMax = 96;
-__global__ __launch_bounds__(512) void k_dense_invert(int n, const double* __restrict__ aug_in, double* __restrict__ inv)
+template <class S>
+__global__ __launch_bounds__(1024) void k_dense_invert(int n, int log2_np, const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
+                                                       const S* __restrict__ val, double* __restrict__ inv)
 {
-    extern __shared__ double lds[];
-    double* a = lds;                 // [n][2n]
+    extern __shared__ double a[];    // [n][n]
     __shared__ double f[kDenseMax];
-    const int n2 = 2 * n;
-    for (int t = threadIdx.x; t < n * n2; t += blockDim.x) a[t] = aug_in[t];
+    for (int t = threadIdx.x; t < n * n; t += blockDim.x) a[t] = 0.0;
     __syncthreads();
+    for (int row = threadIdx.x; row < n; row += blockDim.x) {
+        const int base = slice_ptr[row >> 6], width = slice_ptr[(row >> 6) + 1] - base, lane = row & 63;
+        for (int k = 0; k < width; ++k) { const long e = long(base + k) * 64 + lane; a[row * n + col[e]] += double(val[e]); }   // padding entries carry 0
+    }
+    __syncthreads();
+    const int np = 1 << log2_np, j = threadIdx.x & (np - 1), i0 = threadIdx.x >> log2_np, istep = blockDim.x >> log2_np;
     for (int p = 0; p < n; ++p) {
-        const double ipiv = 1.0 / a[p * n2 + p];
+        const double d = 1.0 / a[p * n + p];
+        if (j < n && i0 == 0) f[j] = (j == p) ? 0.0 : a[j * n + p];      // column p (multipliers), before it is overwritten
         __syncthreads();
-        for (int j = threadIdx.x; j < n2; j += blockDim.x) a[p * n2 + j] *= ipiv;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) f[i] = (i == p) ? 0.0 : a[i * n2 + p];
+        if (i0 == 0 && j < n) a[p * n + j] = (j == p) ? d : a[p * n + j] * d;
+        if (j == p) for (int i = i0; i < n; i += istep) if (i != p) a[i * n + p] = 0.0;
         __syncthreads();
-        for (int t = threadIdx.x; t < n * n2; t += blockDim.x) {
-            const int i = t / n2, j = t - i * n2;
-            a[t] -= f[i] * a[p * n2 + j];
+        if (j < n) {
+            const double apj = a[p * n + j];
+            for (int i = i0; i < n; i += istep) if (i != p) a[i * n + j] -= f[i] * apj;
         }
         __syncthreads();
     }
     // stored TRANSPOSED (inv[j*n + i] = Ainv(i,j)) so that k_dense_apply's loads are contiguous across lanes
-    for (int t = threadIdx.x; t < n * n; t += blockDim.x) { const int i = t / n, j = t - i * n; inv[j * n + i] = a[i * n2 + n + j]; }
+    if (j < n) for (int i = i0; i < n; i += istep) inv[j * n + i] = a[i * n + j];
 }
 // x = Ainv b on the coarsest level: one wavefront per row (inv is stored transposed, so row i is read with stride n by
 // its wave -- n <= 256 keeps that inside a few cache lines per step; what matters is 64-way parallelism per row)
@@ -312,6 +308,10 @@ template <class S>
 void AmgHierarchy<S>::setup(const Plan& P, const int32_t* d_slice_ptr, const int32_t* d_col, const std::vector<double>& ap_host)
 {
     levels.clear(); level_sizes.clear(); coarse_dev.clear();
+    if (const char* e = std::getenv("OPMGPU_AMG_OMEGA")) omega = std::atof(e);
+    if (const char* e = std::getenv("OPMGPU_AMG_PDAMP")) pdamp = std::atof(e);
+    if (const char* e = std::getenv("OPMGPU_AMG_NPRE")) npre = std::atoi(e);
+    if (const char* e = std::getenv("OPMGPU_AMG_NPOST")) npost = std::atoi(e);
     HostCsr A;
     A.n = P.nb; A.rowptr.assign(P.nb + 1, 0);
     for (int r = 0; r < P.nb; ++r) A.rowptr[r + 1] = A.rowptr[r] + P.rowlen[r];
@@ -371,11 +371,10 @@ void AmgHierarchy<S>::setup(const Plan& P, const int32_t* d_slice_ptr, const int
     }
     n_coarsest = levels.back()->n;
     if (n_coarsest <= kDenseMax)        // > 64 KiB of dynamic LDS must be requested explicitly
-        OPMGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_invert), hipFuncAttributeMaxDynamicSharedMemorySize, kDenseMax * 2 * kDenseMax * int(sizeof(double))));
+        OPMGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_invert<S>), hipFuncAttributeMaxDynamicSharedMemorySize, kDenseMax * kDenseMax * int(sizeof(double))));
     if (std::getenv("OPMGPU_VERBOSE")) { std::fprintf(stderr, "[opmgpu] AMG levels:"); for (int n : level_sizes) std::fprintf(stderr, " %d", n); std::fprintf(stderr, "\n"); }
     if (n_coarsest <= kDenseMax) {
         dense_inv.alloc(size_t(n_coarsest) * n_coarsest);
-        dense_work.alloc(size_t(n_coarsest) * 2 * n_coarsest);
     }
     OPMGPU_HIP(hipStreamSynchronize(stream));
 }
@@ -396,8 +395,8 @@ void AmgHierarchy<S>::galerkin()
     AmgLevel<S>& B = *levels.back();
     hipLaunchKernelGGL((k_amg_dinv<S>), dim3(grid_for(B.n)), dim3(kBlock), 0, stream, B.n, B.diag_entry.p, B.val.p, B.dinv.p);
     if (n_coarsest <= kDenseMax) {
-        hipLaunchKernelGGL((k_dense_fill<S>), dim3(grid_for(B.n)), dim3(kBlock), 0, stream, B.n, B.slice_ptr, B.col, B.val.p, dense_work.p);
-        hipLaunchKernelGGL(k_dense_invert, dim3(1), dim3(512), size_t(B.n) * 2 * B.n * sizeof(double), stream, B.n, (const double*)dense_work.p, dense_inv.p);
+        int lg = 0; while ((1 << lg) < B.n) ++lg;
+        hipLaunchKernelGGL((k_dense_invert<S>), dim3(1), dim3(1024), size_t(B.n) * B.n * sizeof(double), stream, B.n, lg, B.slice_ptr, B.col, B.val.p, dense_inv.p);
         OPMGPU_HIP(hipGetLastError());
     }
 }
@@ -418,6 +417,13 @@ void AmgHierarchy<S>::vcycle(const SolveCtl* ctl)
         } else {
             hipLaunchKernelGGL((k_amg_row_wave<S, 2>), dim3((F.n + 3) / 4), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, (const S*)F.x.p, om, F.dinv.p, F.r.p, F.x.p, ctl);
         }
+        for (int sw = 1; sw < npre; ++sw) {      // further pre-smoothing sweeps, then the residual again
+            sweep(F, ctl);
+            if (F.n > 20000)
+                hipLaunchKernelGGL((k_amg_residual<S, 0>), dim3(g), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, F.x.p, om, F.dinv.p, F.r.p, ctl);
+            else
+                hipLaunchKernelGGL((k_amg_row_wave<S, 0>), dim3((F.n + 3) / 4), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, (const S*)F.x.p, om, F.dinv.p, F.r.p, (S*)nullptr, ctl);
+        }
         hipLaunchKernelGGL((k_amg_restrict<S>), dim3(grid_for(C.n)), dim3(kBlock), 0, stream, C.n, F.agg_ptr.p, F.agg_rows.p, F.r.p, C.b.p, ctl);
     }
     AmgLevel<S>& B = *levels.back();
@@ -433,13 +439,21 @@ void AmgHierarchy<S>::vcycle(const SolveCtl* ctl)
     for (int l = nl - 2; l >= 0; --l) {
         AmgLevel<S>& F = *levels[l]; AmgLevel<S>& C = *levels[l + 1];
         const int g = grid_for(F.n);
-        hipLaunchKernelGGL((k_amg_prolong<S>), dim3(g), dim3(kBlock), 0, stream, F.n, F.agg.p, C.x.p, F.x.p, ctl);
-        if (F.n > 20000)
-            hipLaunchKernelGGL((k_amg_residual<S, 1>), dim3(g), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, F.x.p, om, F.dinv.p, F.x2.p, ctl);
-        else
-            hipLaunchKernelGGL((k_amg_row_wave<S, 1>), dim3((F.n + 3) / 4), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, (const S*)F.x.p, om, F.dinv.p, F.x2.p, (S*)nullptr, ctl);
-        std::swap(F.x.p, F.x2.p);       // post-smoothed iterate becomes x (buffers are the same size)
+        hipLaunchKernelGGL((k_amg_prolong<S>), dim3(g), dim3(kBlock), 0, stream, F.n, F.agg.p, C.x.p, F.x.p, S(pdamp), ctl);
+        for (int sw = 0; sw < npost; ++sw) sweep(F, ctl);
     }
+}
+
+// one damped-Jacobi sweep x <- x + omega D^-1 (b - A x) (ping-pong between x and x2)
+template <class S>
+void AmgHierarchy<S>::sweep(AmgLevel<S>& F, const SolveCtl* ctl)
+{
+    const S om = S(omega);
+    if (F.n > 20000)
+        hipLaunchKernelGGL((k_amg_residual<S, 1>), dim3(grid_for(F.n)), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, F.x.p, om, F.dinv.p, F.x2.p, ctl);
+    else
+        hipLaunchKernelGGL((k_amg_row_wave<S, 1>), dim3((F.n + 3) / 4), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, (const S*)F.x.p, om, F.dinv.p, F.x2.p, (S*)nullptr, ctl);
+    std::swap(F.x.p, F.x2.p);       // the swept iterate becomes x (buffers are the same size)
 }
 
 template class AmgHierarchy<float>;

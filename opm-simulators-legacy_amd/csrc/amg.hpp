@@ -53,11 +53,16 @@ public:
     std::vector<std::unique_ptr<AmgLevel<S>>> levels;
     std::vector<std::unique_ptr<DevArray<int32_t>>> coarse_dev;   // per fine level: device entry id of every coarse csr entry
     DevArray<double> dense_inv;      // coarsest: explicit inverse (double), n_c x n_c
-    DevArray<double> dense_work;
     int n_coarsest = 0;
     std::vector<int> level_sizes;
     hipStream_t stream;
-    double omega = 0.67;
+    // Measured on MI355X over omega x pdamp x npre x npost (tools/amg_sweep.py, 100^3 decks with sigma_lnK = 0.5 and 2.0): the
+    // plain-aggregation correction is too small by a factor ~2 (dune-istl scales it by 1.6 for the same reason); 1.9 / 0.9 / 1+2
+    // sweeps was the best setting that helped on both decks (-19 % and -7 % time per Newton iteration).  Env OPMGPU_AMG_* override.
+    double omega = 0.9;           // damped-Jacobi weight
+    double pdamp = 1.9;           // coarse-grid correction scaling (dune-istl's prolongation damping factor)
+    int npre = 1, npost = 2;      // smoothing sweeps before / after the coarse-grid correction
+    void sweep(AmgLevel<S>& F, const SolveCtl* ctl);
 };
 
 } // namespace opmgpu
