@@ -205,6 +205,14 @@ int opmgpu_solve(opmgpu_ctx* ctx, int single_precision, double* dx, int* iters, 
  * of the last opmgpu_solve.  relax multiplies dx first (NonlinearSolver_impl.hpp:283-301, dampen). */
 int opmgpu_update_state(opmgpu_ctx* ctx, const double* dx, double relax);
 
+/* Device-side last_state of AdaptiveTimeStepping (AdaptiveTimeStepping_impl.hpp:211-212, :318-319, :346-347): save = copy
+ * the resident reservoir state aside, restore = copy it back after a failed sub-step (the state never leaves the device),
+ * relative_change = BlackoilModelBase::relativeChange(previous = saved, current = resident)
+ * (BlackoilModelBase_impl.hpp:1595-1631): (|p0-p|^2 + |s0-s|^2) / (|p|^2 + |s|^2), what the PID controllers consume. */
+int opmgpu_save_state(opmgpu_ctx* ctx);
+int opmgpu_restore_state(opmgpu_ctx* ctx);
+int opmgpu_relative_change(opmgpu_ctx* ctx, double* value);
+
 /* Maximum historical oil saturation per cell (BlackoilPropsAdFromDeck::satOilMax_, used by VAPPARS).
  * set: explicit values (nc, caller order; restart).  update: soMax = max(soMax, so of the resident state) --
  * what SimulatorBase_impl.hpp:192 does at the start of every report step (updateSatOilMax, :933-945).

@@ -813,7 +813,7 @@ void BlackoilDevice::rebuild_structure()
     d_dx_old.alloc(3 * size_t(nbp)); d_dx_old.zero(stream);
     d_red.alloc(13 * size_t(kMaxRedBlocks) + 16);
     OPMGPU_HIP(hipStreamSynchronize(stream));
-    has_dx = false;
+    has_dx = false; has_saved = false;
     d_somax.alloc(nbp); d_somax.zero(stream);
     OPMGPU_HIP(hipStreamSynchronize(stream));
     if (!smax.empty()) set_sat_oil_max(smax.data());
@@ -932,6 +932,78 @@ int BlackoilDevice::convergence(double dt, double* B3, double* CNV3, double* MB3
     }
     if (converged) *converged = conv ? 1 : 0;
     return status;
+}
+
+// relativeChange (BlackoilModelBase_impl.hpp:1595-1631): partial sums of |p0-p|^2 + |s0-s|^2 and |p|^2 + |s|^2, owned rows
+__global__ __launch_bounds__(kBlock) void k_relchange_partial(int nb, const double* __restrict__ p, const double* __restrict__ sw,
+                                                              const double* __restrict__ so, const double* __restrict__ sg,
+                                                              const double* __restrict__ p0, const double* __restrict__ sw0,
+                                                              const double* __restrict__ so0, const double* __restrict__ sg0,
+                                                              const int8_t* __restrict__ mask, double* __restrict__ part)
+{
+    __shared__ double sm[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double vals[2] = { 0.0, 0.0 };
+    for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < nb; i += long(gridDim.x) * kBlock) {
+        if (mask && !mask[i]) continue;
+        const double a = p[i], b = sw[i], c = so[i], d = sg[i];
+        const double da = p0[i] - a, db = sw0[i] - b, dc = so0[i] - c, dd = sg0[i] - d;
+        vals[0] += da * da + (db * db + dc * dc + dd * dd);
+        vals[1] += a * a + (b * b + c * c + d * d);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const double s = wave_sum(vals[q]);
+        __syncthreads();
+        if (lane == 0) sm[w] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) part[long(q) * gridDim.x + blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_sum2_final(int nblocks, const double* __restrict__ part, double* __restrict__ out)
+{
+    __shared__ double sm[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int q = 0; q < 2; ++q) {
+        double v = 0.0;
+        for (int i = threadIdx.x; i < nblocks; i += kBlock) v += part[long(q) * nblocks + i];
+        const double s = wave_sum(v);
+        __syncthreads();
+        if (lane == 0) sm[w] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) out[q] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    }
+}
+
+// device-side copy of the reservoir state: what AdaptiveTimeStepping keeps as last_state (AdaptiveTimeStepping_impl.hpp:211-212)
+void BlackoilDevice::save_state()
+{
+    const size_t nbp = size_t(ls.plan.nbp);
+    d_saved.alloc(6 * nbp); d_saved_hc.alloc(nbp);
+    DevArray<double>* planes[] = { &d_p, &d_sw, &d_so, &d_sg, &d_rs, &d_rv };
+    for (int k = 0; k < 6; ++k) OPMGPU_HIP(hipMemcpyAsync(d_saved.p + size_t(k) * nbp, planes[k]->p, nbp * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    OPMGPU_HIP(hipMemcpyAsync(d_saved_hc.p, d_hc.p, nbp, hipMemcpyDeviceToDevice, stream));
+    has_saved = true;
+}
+void BlackoilDevice::restore_state()
+{
+    const size_t nbp = size_t(ls.plan.nbp);
+    DevArray<double>* planes[] = { &d_p, &d_sw, &d_so, &d_sg, &d_rs, &d_rv };
+    for (int k = 0; k < 6; ++k) OPMGPU_HIP(hipMemcpyAsync(planes[k]->p, d_saved.p + size_t(k) * nbp, nbp * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    OPMGPU_HIP(hipMemcpyAsync(d_hc.p, d_saved_hc.p, nbp, hipMemcpyDeviceToDevice, stream));
+}
+double BlackoilDevice::relative_change()
+{
+    const size_t nbp = size_t(ls.plan.nbp);
+    const int g = std::min(grid_for(nc), kMaxRedBlocks);
+    const int8_t* mask = ls.comm ? ls.comm->owner_mask() : nullptr;
+    hipLaunchKernelGGL(k_relchange_partial, dim3(g), dim3(kBlock), 0, stream, nc, d_p.p, d_sw.p, d_so.p, d_sg.p, d_saved.p, d_saved.p + nbp,
+                       d_saved.p + 2 * nbp, d_saved.p + 3 * nbp, mask, d_red.p + 16);
+    hipLaunchKernelGGL(k_sum2_final, dim3(1), dim3(kBlock), 0, stream, g, d_red.p + 16, d_red.p);
+    if (ls.comm) ls.comm->allreduce_sum(d_red.p, 2, stream);
+    OPMGPU_HIP(hipMemcpyAsync(h_red, d_red.p, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
+    OPMGPU_HIP(hipStreamSynchronize(stream));
+    return h_red[1] > 0.0 ? h_red[0] / h_red[1] : 0.0;
 }
 
 // multi-GPU: the communicator knows rank-local caller numbering; (re)derive internal rows + global sums

@@ -41,6 +41,9 @@ public:
     void dx_to_host(double* dx);                        // resident dx -> host, equation-major caller order
     void update_state(const double* dx_host, double relax);
     void stabilize_update(int relax_type, double omega);
+    void save_state();
+    void restore_state();
+    double relative_change();
     void update_sat_oil_max();
     void set_sat_oil_max(const double* v);
     void get_sat_oil_max(double* v);
@@ -52,7 +55,7 @@ public:
     int nc = 0, nconn = 0;
     opmgpu_params prm;
     double last_dt = 0.0;
-    bool has_state = false, has_dx = false, has_rhs_extra = false;
+    bool has_state = false, has_dx = false, has_rhs_extra = false, has_saved = false;
     int nperf = 0;
 
 private:
@@ -69,7 +72,8 @@ private:
     // ENDSCALE: per-cell scaled end points (caller numbering), unscaled points per saturation region
     bool use_eps = false;
     std::vector<double> h_eps[8], h_unscaled;
-    DevArray<double> d_eps, d_eps_u0, d_somax;
+    DevArray<double> d_eps, d_eps_u0, d_somax, d_saved;
+    DevArray<int8_t> d_saved_hc;
     const double* eps_planes() const { return use_eps ? d_eps.p : nullptr; }
     // device: tables
     opmgpu_tables dt_;                       // same struct, device pointers

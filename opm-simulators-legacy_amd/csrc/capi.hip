@@ -235,6 +235,24 @@ int opmgpu_update_state(opmgpu_ctx* c, const double* dx, double relax)
     });
 }
 
+int opmgpu_save_state(opmgpu_ctx* c)
+{
+    if (!c || !c->model || !c->model->has_state) return OPMGPU_EINVAL;
+    return guarded(c, [&]() { c->model->save_state(); return OPMGPU_OK; });
+}
+int opmgpu_restore_state(opmgpu_ctx* c)
+{
+    if (!c || !c->model) return OPMGPU_EINVAL;
+    if (!c->model->has_saved) return fail(c, OPMGPU_EINVAL, "no saved state (opmgpu_save_state; a well re-plan discards it)");
+    return guarded(c, [&]() { c->model->restore_state(); return OPMGPU_OK; });
+}
+int opmgpu_relative_change(opmgpu_ctx* c, double* value)
+{
+    if (!c || !c->model || !value) return OPMGPU_EINVAL;
+    if (!c->model->has_saved) return fail(c, OPMGPU_EINVAL, "no saved state (opmgpu_save_state; a well re-plan discards it)");
+    return guarded(c, [&]() { *value = c->model->relative_change(); return OPMGPU_OK; });
+}
+
 int opmgpu_set_sat_oil_max(opmgpu_ctx* c, const double* so_max)
 {
     if (!c || !c->model || !so_max) return OPMGPU_EINVAL;

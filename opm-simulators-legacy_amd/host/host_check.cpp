@@ -102,6 +102,18 @@ int main()
         }
         std::printf("host_check: converged in %d Newton iterations, last linear solve %d iterations, relaxation %.2f\n", its,
                     model.linearIterationsLastSolve(), model.relaxation());
+        // a 20-day report step through the adaptive sub-stepping loop (AdaptiveTimeStepping::stepImpl), state resident on the device
+        opmgpu::AdaptiveTimeSteppingGpu ats;
+        ats.step(20 * 86400.0, solver, model);
+        double total = 0.0;
+        for (double d : ats.substeps) total += d;
+        if (ats.substeps.size() < 2 || std::abs(total - 20 * 86400.0) > 1e-6 || !(ats.substeps[1] > ats.substeps[0])) {
+            std::printf("host_check: FAILED, adaptive stepping took %zu sub-steps summing to %g s\n", ats.substeps.size(), total);
+            return 1;
+        }
+        std::printf("host_check: report step of 20 d in %zu sub-steps (first %.2f d, last %.2f d), %d failed, next suggestion %.2f d\n",
+                    ats.substeps.size(), ats.substeps.front() / 86400.0, ats.substeps.back() / 86400.0, ats.failed_substeps,
+                    ats.suggested_next_timestep / 86400.0);
     } catch (const std::exception& e) {
         std::printf("host_check: FAILED with exception: %s\n", e.what());
         return 1;

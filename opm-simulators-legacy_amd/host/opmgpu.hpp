@@ -155,6 +155,11 @@ public:
         }
         return r.converged;
     }
+    /// last_state of AdaptiveTimeStepping kept on the device, and BlackoilModelBase::relativeChange (:1595-1631) against it
+    void saveState() { throw_on_status(ctx_, opmgpu_save_state(ctx_)); }
+    void restoreState() { throw_on_status(ctx_, opmgpu_restore_state(ctx_)); }
+    double relativeChange() { double v = 0.0; throw_on_status(ctx_, opmgpu_relative_change(ctx_, &v)); return v; }
+    void setStepLength(double dt) { dt_ = dt; }
     double relaxation() const { return current_relaxation_; }
     void setUseUpdateStabilization(bool on) { use_update_stabilization_ = on; }
     int linearIterationsLastSolve() const { return linear_iterations_; }
@@ -207,6 +212,78 @@ struct NonlinearSolverGpu {
         } while ((!converged && iteration <= max_iter) || iteration <= min_iter);
         if (!converged) throw TooManyIterations("Failed to complete a time step within " + std::to_string(max_iter) + " iterations.");
         return iteration;
+    }
+};
+
+/// PIDTimeStepControl / AdaptiveSimulatorTimer (opm-core, not in the reference tree: restated) and
+/// AdaptiveTimeStepping::stepImpl (AdaptiveTimeStepping_impl.hpp:183-372) around the device-resident Newton loop.
+struct PIDTimeStepControl {
+    double tol = 1e-1, errors[3] = { 1e-1, 1e-1, 1e-1 };
+    int target_iterations = 0;                         // > 0: the "pid+iteration" variant
+    double computeTimeStepSize(double dt, int iterations, double relative_change)
+    {
+        errors[0] = errors[1]; errors[1] = errors[2]; errors[2] = relative_change;
+        for (double e : errors) if (!std::isfinite(e)) throw NumericalIssue("non-finite relative change in the time step control");
+        double est;
+        if (errors[2] > tol) est = dt * tol / errors[2];
+        else est = dt * std::pow(errors[1] / errors[2], 0.075) * std::pow(tol / errors[2], 0.175) * std::pow(errors[0] * errors[0] / errors[1] / errors[2], 0.01);
+        if (target_iterations > 0 && iterations > target_iterations) est *= double(target_iterations) / double(iterations);
+        return est;
+    }
+};
+
+struct AdaptiveTimeSteppingGpu {
+    double restart_factor = 0.33, growth_factor = 2.0, max_growth = 3.0, max_time_step = 365.0 * 86400.0;     // :101-112
+    int solver_restart_max = 10;
+    double suggested_next_timestep = 86400.0;
+    PIDTimeStepControl control;
+    std::vector<double> substeps;                      // of the last report step
+    int failed_substeps = 0;
+
+    static double clip(double est, double remaining, double max_step)        // AdaptiveSimulatorTimer::provideTimeStepEstimate
+    {
+        double dt = std::min(est, max_step);
+        if (remaining > 0) {
+            if (1.05 * dt > remaining) { dt = remaining; if (dt > max_step) dt = 0.5 * remaining; return dt; }
+            if (1.5 * dt > remaining) dt = 0.5 * remaining;
+        }
+        return dt;
+    }
+    /// one report step of length `timestep` [s] from the model's resident state
+    void step(double timestep, const NonlinearSolverGpu& solver, BlackoilModelGpu& model)
+    {
+        if (suggested_next_timestep < 0) suggested_next_timestep = restart_factor * timestep;
+        double done = 0.0, dt = clip(suggested_next_timestep, timestep, max_time_step);
+        model.saveState();
+        substeps.clear();
+        int restarts = 0;
+        while (timestep - done > 1e-9 * std::max(1.0, timestep)) {
+            bool converged = false; int linear = 0;
+            try {
+                model.setStepLength(dt);
+                solver.step(model);
+                linear = model.linearIterationsLastSolve();
+                converged = true;
+            }
+            catch (const TooManyIterations&) {}
+            catch (const LinearSolverProblem&) {}
+            catch (const NumericalIssue&) {}
+            catch (const std::runtime_error&) {}
+            if (converged) {
+                done += dt; substeps.push_back(dt);
+                double est = std::min(control.computeTimeStepSize(dt, linear, model.relativeChange()), max_growth * dt);
+                if (restarts > 0) { est = std::min(growth_factor * dt, est); restarts = 0; }
+                dt = clip(est, timestep - done, max_time_step);
+                model.saveState();
+            } else {
+                ++failed_substeps;
+                if (restarts >= solver_restart_max) throw NumericalIssue("Solver failed to converge after cutting timestep " + std::to_string(restarts) + " times.");
+                dt = clip(restart_factor * dt, timestep - done, max_time_step);
+                model.restoreState();
+                ++restarts;
+            }
+        }
+        suggested_next_timestep = std::isfinite(dt) ? dt : timestep;
     }
 };
 

@@ -112,6 +112,9 @@ SIGNATURES = {
     "opmgpu_solve": (C.c_int, [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int), _dp]),
     "opmgpu_update_state": (C.c_int, [C.c_void_p, _dp, C.c_double]),
     "opmgpu_stabilize_update": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
+    "opmgpu_save_state": (C.c_int, [C.c_void_p]),
+    "opmgpu_restore_state": (C.c_int, [C.c_void_p]),
+    "opmgpu_relative_change": (C.c_int, [C.c_void_p, _dp]),
     "opmgpu_set_sat_oil_max": (C.c_int, [C.c_void_p, _dp]),
     "opmgpu_update_sat_oil_max": (C.c_int, [C.c_void_p]),
     "opmgpu_get_sat_oil_max": (C.c_int, [C.c_void_p, _dp]),

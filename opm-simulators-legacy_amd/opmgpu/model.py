@@ -201,6 +201,19 @@ class GpuBlackoilModel:
     def updateState(self, dx=None, relax=1.0):
         self._chk(self.lib.opmgpu_update_state(self.ctx, capi.dptr(None if dx is None else capi.f64(dx)), float(relax)))
 
+    # last_state of AdaptiveTimeStepping, kept on the device
+    def saveState(self):
+        self._chk(self.lib.opmgpu_save_state(self.ctx))
+
+    def restoreState(self):
+        self._chk(self.lib.opmgpu_restore_state(self.ctx))
+
+    def relativeChange(self):
+        """BlackoilModelBase::relativeChange(saved, resident) (BlackoilModelBase_impl.hpp:1595-1631)."""
+        v = C.c_double(0.0)
+        self._chk(self.lib.opmgpu_relative_change(self.ctx, C.byref(v)))
+        return v.value
+
     # satOilMax_ of BlackoilPropsAdFromDeck (VAPPARS); updateSatOilMax is called once per report step (SimulatorBase_impl.hpp:192)
     def setSatOilMax(self, so_max):
         self._chk(self.lib.opmgpu_set_sat_oil_max(self.ctx, capi.dptr(capi.f64(so_max))))

@@ -122,6 +122,10 @@ class WellState:
         import copy
         return copy.deepcopy(self)
 
+    def assign(self, other):
+        """state = last_state (AdaptiveTimeStepping_impl.hpp:346-347), in place so that holders of this object see it"""
+        self.bhp[:], self.qs[:], self.perf_press[:], self.perf_rates[:] = other.bhp, other.qs, other.perf_press, other.perf_rates
+
 
 def connection_densities(wells, perf_rates, b_perf, rsmax_perf, rvmax_perf, surf_dens_perf):
     """WellDensitySegmented::computeConnectionDensities (WellDensitySegmented.cpp:66-135); components w, o, g."""
@@ -296,7 +300,16 @@ class WellCoupledModel:
     def prepareStep(self, dt, state=None):
         self.m.prepareStep(dt, state)
 
-    def nonlinearIteration(self, iteration, single_precision=None):
+    def saveState(self):
+        self.m.saveState()
+
+    def restoreState(self):
+        self.m.restoreState()
+
+    def relativeChange(self):
+        return self.m.relativeChange()
+
+    def nonlinearIteration(self, iteration, single_precision=None, nonlinear_solver=None):
         m, wh, ws = self.m, self.wh, self.ws
         m.assemble(iteration == 0)
         pp = m.perfProps(self.nperf).reshape(self.nperf, 9, 4)

@@ -1,0 +1,64 @@
+"""GPU: adaptive sub-stepping around the device-resident Newton loop -- opmgpu_save_state / restore_state /
+relative_change through the C ABI, driven by opmgpu/timestepping.py (mirror of AdaptiveTimeStepping::stepImpl)."""
+import numpy as np
+import pytest
+
+from opmgpu import capi, decks
+from opmgpu import timestepping as ts
+from opmgpu.model import GpuBlackoilModel, NonlinearSolver
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup():
+    tab = decks.satfunc_standard_tables()
+    grid = decks.cartesian_grid(8, 7, 5, lognormal_sigma=0.6)
+    st = decks.initial_state(grid, tab, perturb=0.03)
+    return tab, grid, st
+
+
+def test_relative_change_and_restore(gpu_lib):
+    tab, grid, st = _setup()
+    m = GpuBlackoilModel(grid, tab, capi.default_params())
+    m.prepareStep(5 * decks.DAY, st)
+    m.saveState()
+    assert m.relativeChange() == 0.0
+    NonlinearSolver().step(m)
+    new = m.getState()
+    expect = (((st.p - new.p) ** 2).sum() + ((st.sat - new.sat) ** 2).sum()) / ((new.p ** 2).sum() + (new.sat ** 2).sum())
+    assert expect > 0 and m.relativeChange() == pytest.approx(expect, rel=1e-12)
+    m.restoreState()
+    back = m.getState()
+    assert np.array_equal(back.p, st.p) and np.array_equal(back.sat, st.sat) and np.array_equal(back.rs, st.rs)
+    assert np.array_equal(back.rv, st.rv) and np.array_equal(back.hc, st.hc)
+    m.close()
+
+
+@pytest.mark.parametrize("force_failures", [False, True])
+def test_report_step_equals_replay_of_its_substeps(gpu_lib, force_failures):
+    """The adaptive loop must end exactly where a replay of its successful sub-steps ends: failed sub-steps leave no trace
+    (the state is restored on the device), and the whole loop is deterministic."""
+    tab, grid, st = _setup()
+    prm = capi.default_params()
+    solver = NonlinearSolver(max_iter=2 if force_failures else 10)        # max_iter 2: long sub-steps run out of iterations
+    m = GpuBlackoilModel(grid, tab, prm)
+    m.setState(st)
+    ats = ts.AdaptiveTimeStepping(initial_timestep_days=30.0 if force_failures else 1.0)
+    rep = ats.step(0.0, 30 * decks.DAY, solver, m)
+    assert rep["converged"] and sum(rep["substeps"]) == pytest.approx(30 * decks.DAY, rel=1e-12)
+    if force_failures:
+        assert rep["failed"] and rep["failed"][0][0] == 30 * decks.DAY
+        assert rep["substeps"][0] < 30 * decks.DAY
+    else:
+        assert rep["substeps"][0] == decks.DAY and len(rep["substeps"]) > 2        # a long sub-step may still fail and be chopped
+    end = m.getState()
+    assert np.all(np.isfinite(end.p)) and np.abs(end.sat.sum(axis=1) - 1).max() < 1e-12
+    m.close()
+    m2 = GpuBlackoilModel(grid, tab, prm)
+    m2.setState(st)
+    for dt in rep["substeps"]:
+        m2.prepareStep(dt)
+        solver.step(m2)
+    replay = m2.getState()
+    assert np.array_equal(replay.p, end.p) and np.array_equal(replay.sat, end.sat) and np.array_equal(replay.hc, end.hc)
+    m2.close()

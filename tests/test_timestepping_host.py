@@ -1,0 +1,104 @@
+"""Host logic of the adaptive sub-stepping (opmgpu/timestepping.py) on a fake model: controllers, sub-step timer,
+restart-on-failure contract of AdaptiveTimeStepping::stepImpl (AdaptiveTimeStepping_impl.hpp:183-372).  No GPU."""
+import math
+
+import pytest
+
+from opmgpu import timestepping as ts
+from opmgpu.model import NumericalIssue, TooManyIterations
+
+DAY = ts.DAY
+
+
+class FakeModel:
+    """Scalar 'state' x that relaxes towards 1; a sub-step longer than dt_fail does not converge."""
+
+    def __init__(self, dt_fail=float("inf")):
+        self.x, self.saved, self.dt, self.dt_fail = 0.0, None, None, dt_fail
+        self.log = []
+
+    def prepareStep(self, dt):
+        self.dt = dt
+
+    def saveState(self):
+        self.saved = self.x
+
+    def restoreState(self):
+        self.x = self.saved
+        self.log.append("restore")
+
+    def relativeChange(self):
+        return (self.x - self.saved) ** 2 / max(self.x ** 2, 1e-300)
+
+
+class FakeSolver:
+    def step(self, model):
+        if model.dt > model.dt_fail:
+            model.x = float("nan")          # a failed solve leaves garbage behind
+            raise TooManyIterations("too many")
+        model.x += (1.0 - model.x) * (1.0 - math.exp(-model.dt / (30 * DAY)))
+        return 3, 12
+
+
+def test_pid_controller_arithmetic():
+    c = ts.PIDTimeStepControl(tol=0.1)
+    assert c.computeTimeStepSize(10.0, 5, lambda: 0.4) == pytest.approx(10.0 * 0.1 / 0.4)           # too large an error: proportional cut
+    e0, e1, e2 = 0.1, 0.4, 0.05
+    exp = 10.0 * (e1 / e2) ** 0.075 * (0.1 / e2) ** 0.175 * (e0 * e0 / e1 / e2) ** 0.01
+    assert c.computeTimeStepSize(10.0, 5, lambda: 0.05) == pytest.approx(exp)
+    c2 = ts.PIDAndIterationCountTimeStepControl(target_iterations=8, tol=0.1)
+    base = ts.PIDTimeStepControl(tol=0.1).computeTimeStepSize(10.0, 16, lambda: 0.05)
+    assert c2.computeTimeStepSize(10.0, 16, lambda: 0.05) == pytest.approx(base * 8 / 16)
+    c3 = ts.SimpleIterationCountTimeStepControl(target_iterations=10, decayrate=0.75, growthrate=1.25)
+    assert c3.computeTimeStepSize(4.0, 11, None) == 3.0 and c3.computeTimeStepSize(4.0, 8, None) == 5.0 and c3.computeTimeStepSize(4.0, 9, None) == 4.0
+
+
+def test_substep_timer_clipping():
+    t = ts.AdaptiveSimulatorTimer(0.0, 10.0, 4.0, max_time_step=100.0)
+    assert t.currentStepLength() == 4.0
+    t.advance(); t.provideTimeStepEstimate(4.1)             # remaining 6: 1.5*4.1 > 6 -> two halves instead of 4.1 + 1.9
+    assert t.currentStepLength() == 3.0
+    t.advance(); t.provideTimeStepEstimate(2.9)             # remaining 3: 1.05*2.9 > 3 -> take it all
+    assert t.currentStepLength() == 3.0
+    t.advance()
+    assert t.done() and t.steps == [4.0, 3.0, 3.0]
+    t2 = ts.AdaptiveSimulatorTimer(0.0, 10.0, 50.0, max_time_step=6.0)   # estimate clipped to the max step
+    assert t2.currentStepLength() == 6.0
+    t3 = ts.AdaptiveSimulatorTimer(0.0, 6.2, 50.0, max_time_step=6.0)    # remainder just above the max step -> two halves
+    assert t3.currentStepLength() == pytest.approx(3.1)
+
+
+def test_report_step_growth_and_suggestion():
+    m, a = FakeModel(), ts.AdaptiveTimeStepping(initial_timestep_days=1.0)
+    rep = a.step(0.0, 30 * DAY, FakeSolver(), m)
+    assert rep["converged"] and sum(rep["substeps"]) == pytest.approx(30 * DAY)
+    assert rep["substeps"][0] == DAY
+    for prev, cur in zip(rep["substeps"], rep["substeps"][1:]):
+        assert cur <= 3.0 * prev * (1 + 1e-12)               # max_growth
+    assert rep["newton_iterations"] == 3 * len(rep["substeps"]) and not rep["failed"]
+    assert a.suggested_next_timestep > DAY                    # carried to the next report step
+    rep2 = a.step(30 * DAY, 30 * DAY, FakeSolver(), m)
+    assert rep2["substeps"][0] == pytest.approx(min(a.max_time_step, rep2["substeps"][0]))
+    assert len(rep2["substeps"]) <= len(rep["substeps"])
+
+
+def test_restart_on_failure_restores_state_and_limits_growth():
+    m = FakeModel(dt_fail=2.5 * DAY)
+    a = ts.AdaptiveTimeStepping(initial_timestep_days=6.0)
+    rep = a.step(0.0, 12 * DAY, FakeSolver(), m)
+    assert rep["converged"] and math.isfinite(m.x)
+    assert [round(d / DAY, 6) for d, _ in rep["failed"][:1]] == [6.0]
+    assert rep["failed"][0][1].startswith("Solver convergence failure - Iteration limit")
+    assert "restore" in m.log
+    first_ok = rep["substeps"][0]
+    assert first_ok == pytest.approx(6.0 * DAY * 0.33)       # chopped by restart_factor
+    assert all(d <= 2.5 * DAY * (1 + 1e-12) for d in rep["substeps"])
+    assert sum(rep["substeps"]) == pytest.approx(12 * DAY)
+
+
+def test_gives_up_after_solver_restart_max():
+    m = FakeModel(dt_fail=0.0)                                # nothing ever converges
+    a = ts.AdaptiveTimeStepping(initial_timestep_days=1.0, solver_restart_max=4)
+    with pytest.raises(NumericalIssue, match="cutting timestep 4 times"):
+        a.step(0.0, 10 * DAY, FakeSolver(), m)
+    assert a.failed_substeps == 5
