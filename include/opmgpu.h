@@ -205,6 +205,37 @@ int opmgpu_solve(opmgpu_ctx* ctx, int single_precision, double* dx, int* iters, 
  * of the last opmgpu_solve.  relax multiplies dx first (NonlinearSolver_impl.hpp:283-301, dampen). */
 int opmgpu_update_state(opmgpu_ctx* ctx, const double* dx, double relax);
 
+/* ------------------------------------------------------------------------------------------
+ * Wells on the device: the standard well model of StandardWells_impl.hpp:396-998 evaluated per well on
+ * the GPU, the well unknowns (q_s[3], bhp) Schur-eliminated like NewtonIterationUtilities.cpp:45-128 -- but kept in
+ * factored form (diagonal-block updates + a rank-7 operator per well applied inside the SpMV) instead of filling the
+ * matrix with a clique per well.  Alternative to the host-well path (opmgpu_set_wells / perf_props / add_well_terms):
+ * after opmgpu_set_device_wells, opmgpu_assemble adds the well terms itself, opmgpu_solve uses the coupled operator,
+ * opmgpu_update_state also recovers and updates the well unknowns (updateWellState, :611-650), and
+ * opmgpu_save_state / restore_state carry the well state along.  Fields mirror opm-core's `Wells` struct.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct opmgpu_wells {
+    int32_t        nw;
+    const int32_t* well_connpos;   /* [nw+1]                                                   */
+    const int32_t* well_cells;     /* [nperf] (a cell may be perforated by one well only)      */
+    const double*  WI;             /* [nperf] well index (connection transmissibility factor)  */
+    const int32_t* type;           /* [nw] 0 = INJECTOR, 1 = PRODUCER                          */
+    const int32_t* allow_cf;       /* [nw] allow cross flow; NULL = all 1                      */
+    const double*  depth_ref;      /* [nw] bhp reference depth                                 */
+    const double*  comp_frac;      /* [nw*3] injection stream composition (w, o, g)            */
+    const int32_t* ctrl_type;      /* [nw] 0 = BHP, 1 = SURFACE_RATE                           */
+    const double*  ctrl_target;    /* [nw]                                                     */
+    const double*  ctrl_distr;     /* [nw*3] rate-control phase weights; NULL = 0              */
+} opmgpu_wells;
+
+int opmgpu_set_device_wells(opmgpu_ctx* ctx, const opmgpu_wells* wells);   /* nw == 0 removes them */
+/* WellStateFullyImplicitBlackoil fields: bhp[nw], wellRates qs[nw*3]; perf_rates[nperf*3] may be NULL (keep) */
+int opmgpu_well_state_set(opmgpu_ctx* ctx, const double* bhp, const double* qs, const double* perf_rates);
+int opmgpu_well_state_get(opmgpu_ctx* ctx, double* bhp, double* qs, double* perf_press, double* perf_rates);
+/* well part of getConvergence (BlackoilModelBase_impl.hpp:1769-1779) after opmgpu_assemble: max |flux equation| per
+ * phase (to be multiplied by B_avg and compared with tolerance_wells) and max |control equation|. */
+int opmgpu_well_convergence(opmgpu_ctx* ctx, double* flux_residual3, double* control_residual);
+
 /* Device-side last_state of AdaptiveTimeStepping (AdaptiveTimeStepping_impl.hpp:211-212, :318-319, :346-347): save = copy
  * the resident reservoir state aside, restore = copy it back after a failed sub-step (the state never leaves the device),
  * relative_change = BlackoilModelBase::relativeChange(previous = saved, current = resident)

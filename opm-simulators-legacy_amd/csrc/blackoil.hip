@@ -686,6 +686,7 @@ BlackoilDevice::BlackoilDevice(hipStream_t s, LinSolver& ls_, const opmgpu_grid*
 
 BlackoilDevice::~BlackoilDevice()
 {
+    wells_free();
     for (DevArray<double>* a : tab_d) delete a;
     for (DevArray<int32_t>* a : tab_i) delete a;
     if (h_red) (void)hipHostFree(h_red);
@@ -706,6 +707,7 @@ void BlackoilDevice::upload_tables(const opmgpu_tables* t)
     const int non = t->oil_node_ptr[np], ngn = t->gas_node_ptr[np];
     const int noc = t->oil_col_ptr[non], ngc = t->gas_col_ptr[ngn];
     const int nsw = t->swof_ptr[ns], nsg = t->sgof_ptr[ns];
+    h_surface_density.assign(t->surface_density, t->surface_density + 3 * size_t(np));
     dt_.surface_density = upd(t->surface_density, 3 * np); dt_.pvtw = upd(t->pvtw, 5 * np);
     dt_.oil_node_ptr = upi(t->oil_node_ptr, np + 1);
     dt_.oil_rs = upd(t->oil_rs, non); dt_.oil_psat = upd(t->oil_psat, non);
@@ -746,7 +748,7 @@ void BlackoilDevice::upload_tables(const opmgpu_tables* t)
 void BlackoilDevice::rebuild_structure()
 {
     std::vector<int32_t> rowptr, col, code;
-    const int nw = int(h_well_connpos.size()) - 1;
+    const int nw = device_wells ? 0 : int(h_well_connpos.size()) - 1;     // device wells: factored operator, no clique fill
     const int st = build_reservoir_pattern(nc, nconn, h_conn.data(), nw, h_well_connpos.data(), h_well_cells.data(), rowptr, col, code);
     if (st != OPMGPU_OK) throw HipError(st, "invalid grid connections / wells (out of range or duplicate cell pair)");
     // keep the state across a re-plan (wells change between report steps)
@@ -817,6 +819,7 @@ void BlackoilDevice::rebuild_structure()
     d_somax.alloc(nbp); d_somax.zero(stream);
     OPMGPU_HIP(hipStreamSynchronize(stream));
     if (!smax.empty()) set_sat_oil_max(smax.data());
+    wells_rebind();
     if (has_state) set_state(sp.data(), ssat.data(), srs.data(), srv.data(), shc.data());
 }
 
@@ -881,6 +884,7 @@ void BlackoilDevice::assemble(double dt, bool initial)
     hipLaunchKernelGGL(k_flux, dim3(grid8_for(nc)), dim3(kBlock), 0, stream, xcd_mode(), nc, P.nbp, ls.dp.slice_ptr.p, ls.dp.col.p, ls.dp.rowlen.p,
                        ls.dp.nlower.p, d_conn_code.p, d_trans.p, d_gdz.p, use_thpres ? d_thpres.p : (const double*)nullptr,
                        d_p.p, d_props.p, sc[0], sc[1], sc[2], ls.comm ? ls.comm->owner_mask() : (const int8_t*)nullptr, d_R.p, ls.matrix_d());
+    wells_assemble(initial);
 }
 
 double BlackoilDevice::time_assemble(int reps, int props_only)
@@ -983,6 +987,7 @@ void BlackoilDevice::save_state()
     DevArray<double>* planes[] = { &d_p, &d_sw, &d_so, &d_sg, &d_rs, &d_rv };
     for (int k = 0; k < 6; ++k) OPMGPU_HIP(hipMemcpyAsync(d_saved.p + size_t(k) * nbp, planes[k]->p, nbp * sizeof(double), hipMemcpyDeviceToDevice, stream));
     OPMGPU_HIP(hipMemcpyAsync(d_saved_hc.p, d_hc.p, nbp, hipMemcpyDeviceToDevice, stream));
+    wells_save();
     has_saved = true;
 }
 void BlackoilDevice::restore_state()
@@ -991,6 +996,7 @@ void BlackoilDevice::restore_state()
     DevArray<double>* planes[] = { &d_p, &d_sw, &d_so, &d_sg, &d_rs, &d_rv };
     for (int k = 0; k < 6; ++k) OPMGPU_HIP(hipMemcpyAsync(planes[k]->p, d_saved.p + size_t(k) * nbp, nbp * sizeof(double), hipMemcpyDeviceToDevice, stream));
     OPMGPU_HIP(hipMemcpyAsync(d_hc.p, d_saved_hc.p, nbp, hipMemcpyDeviceToDevice, stream));
+    wells_restore();
 }
 double BlackoilDevice::relative_change()
 {
@@ -1018,6 +1024,13 @@ void BlackoilDevice::attach_comm(CommBase* c, int n_owned)
     OPMGPU_HIP(hipStreamSynchronize(stream));
     pvsum_global = h_red[0];
     c->n_owned_global = int(h_red[1] + 0.5);
+}
+
+void BlackoilDevice::perf_props_device()
+{
+    if (nperf == 0) return;
+    hipLaunchKernelGGL(k_perf_props, dim3(grid_for(nperf)), dim3(kBlock), 0, stream, nperf, dt_, d_perf_cells.p, d_pvtnum.p, d_satnum.p,
+                       d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, eps_planes(), d_eps_u0.p, d_somax.p, long(ls.plan.nbp), d_perf.p);
 }
 
 void BlackoilDevice::perf_props(double* out)
@@ -1116,6 +1129,7 @@ void BlackoilDevice::update_state(const double* dx_host, double relax)
 {
     const Plan& P = ls.plan;
     if (dx_host) { ls.vec_from_host<double>(dx_host, VEC_EQUATION_MAJOR, d_dx.p); has_dx = true; }
+    if (device_wells) wells_update(relax);          // recoverVariable + updateWellState from the same increment
     hipLaunchKernelGGL(k_update_state, dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_dx.p, relax,
                        prm.dp_max_rel, prm.ds_max, prm.dr_max_rel, d_p.p, d_sw.p, d_so.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, eps_planes(), d_eps_u0.p, d_somax.p);
 }

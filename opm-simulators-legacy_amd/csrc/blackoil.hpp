@@ -48,6 +48,14 @@ public:
     void set_sat_oil_max(const double* v);
     void get_sat_oil_max(double* v);
     void get_residual(double* r);
+    // wells on the device (wells.hip)
+    struct WellsDev;
+    int set_device_wells(const opmgpu_wells* spec);
+    int well_state_set(const double* bhp, const double* qs, const double* perf_rates);
+    int well_state_get(double* bhp, double* qs, double* perf_press, double* perf_rates);
+    int well_convergence(double* flux3, double* ctrl);
+    void set_dbhp_max_rel(double v);
+    bool device_wells = false;
     double time_assemble(int reps, int props_only);
     void attach_comm(CommBase* c, int n_owned);
     const Plan& plan() const { return ls.plan; }
@@ -60,6 +68,15 @@ public:
 
 private:
     void upload_tables(const opmgpu_tables* t);
+    void perf_props_device();
+    void wells_assemble(bool initial);
+    void wells_update(double relax);
+    void wells_save();
+    void wells_restore();
+    void wells_rebind();
+    void wells_free();
+    WellsDev* wd = nullptr;
+    std::vector<double> h_surface_density;
     void rebuild_structure();
 
     hipStream_t stream;

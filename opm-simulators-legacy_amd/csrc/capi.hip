@@ -235,6 +235,33 @@ int opmgpu_update_state(opmgpu_ctx* c, const double* dx, double relax)
     });
 }
 
+int opmgpu_set_device_wells(opmgpu_ctx* c, const opmgpu_wells* wells)
+{
+    if (!c || !c->model || !wells) return OPMGPU_EINVAL;
+    return guarded(c, [&]() {
+        c->matrix_loaded = false;
+        if (c->comm && wells->nw > 0) return fail(c, OPMGPU_EINVAL, "wells are not supported in multi-GPU mode yet");
+        const int st = c->model->set_device_wells(wells);
+        if (st != OPMGPU_OK) return fail(c, st, "invalid well specification (missing array, cell out of range or perforated twice)");
+        return st;
+    });
+}
+int opmgpu_well_state_set(opmgpu_ctx* c, const double* bhp, const double* qs, const double* perf_rates)
+{
+    if (!c || !c->model) return OPMGPU_EINVAL;
+    return guarded(c, [&]() { return c->model->well_state_set(bhp, qs, perf_rates); });
+}
+int opmgpu_well_state_get(opmgpu_ctx* c, double* bhp, double* qs, double* perf_press, double* perf_rates)
+{
+    if (!c || !c->model) return OPMGPU_EINVAL;
+    return guarded(c, [&]() { return c->model->well_state_get(bhp, qs, perf_press, perf_rates); });
+}
+int opmgpu_well_convergence(opmgpu_ctx* c, double* flux3, double* ctrl)
+{
+    if (!c || !c->model) return OPMGPU_EINVAL;
+    return guarded(c, [&]() { return c->model->well_convergence(flux3, ctrl); });
+}
+
 int opmgpu_save_state(opmgpu_ctx* c)
 {
     if (!c || !c->model || !c->model->has_state) return OPMGPU_EINVAL;

@@ -64,13 +64,48 @@ __device__ __forceinline__ void reduce_partials(const double* const (&arr)[NV], 
 //   (A x)_i = (A c)_i + w z_i = (pin_i - z_i) + w z_i = pin_i - (1 - w) z_i .
 // Those rows (half of all rows with the 2-colour ordering) need no matrix traffic.  Light and heavy rows
 // are chunked separately so that every XCD gets the same share of both.
+// y_i += P_i t_w on a perforated row (t_w = Q_w x from k_lowrank_reduce)
+template <class S>
+__device__ __forceinline__ void lowrank_add(const LowRankOp& lr, int row, S& y0, S& y1, S& y2)
+{
+    const int pf = lr.perf_of_row[row];
+    if (pf < 0) return;
+    const double* __restrict__ P = lr.P + 21 * long(pf);
+    const double* __restrict__ t = lr.t + 7 * lr.perf_well[pf];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) { a0 += P[k] * t[k]; a1 += P[7 + k] * t[k]; a2 += P[14 + k] * t[k]; }
+    y0 += S(a0); y1 += S(a1); y2 += S(a2);
+}
+// t_w = Q_w x: one workgroup per well, fixed reduction order
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_lowrank_reduce(LowRankOp lr, int nbp, const S* __restrict__ x, const SolveCtl* __restrict__ ctl)
+{
+    __shared__ double sm[28];
+    if (ctl && ctl->done) return;
+    const int w = blockIdx.x;
+    double acc[7] = { 0, 0, 0, 0, 0, 0, 0 };
+    for (int j = lr.connpos[w] + threadIdx.x; j < lr.connpos[w + 1]; j += kBlock) {
+        const int row = lr.perf_row[j];
+        const double x0 = double(x[row]), x1 = double(x[nbp + row]), x2 = double(x[2 * long(nbp) + row]);
+        const double* __restrict__ Q = lr.Q + 21 * long(j);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) acc[k] += Q[3 * k] * x0 + Q[3 * k + 1] * x1 + Q[3 * k + 2] * x2;
+    }
+    block_sum<7>(acc, sm);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) lr.t[7 * w + k] = acc[k];
+    }
+}
+
 template <class S, int NDOT>
 __global__ __launch_bounds__(kBlock) void k_spmv(int xm, int nb, int nbp, const int32_t* __restrict__ slice_ptr,
                                                  const int32_t* __restrict__ col, const S* __restrict__ val,
                                                  const S* __restrict__ x, S* __restrict__ y,
                                                  const S* __restrict__ w1, const int8_t* __restrict__ mask,
                                                  const SolveCtl* __restrict__ ctl, double* __restrict__ p0, double* __restrict__ p1,
-                                                 const S* __restrict__ pin, const S* __restrict__ zin, int n0, S w)
+                                                 const S* __restrict__ pin, const S* __restrict__ zin, int n0, S w, LowRankOp lr)
 {
     __shared__ double sm[8];
     if (ctl && ctl->done) return;
@@ -82,7 +117,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv(int xm, int nb, int nbp, const 
             const int row = ch * kBlock + threadIdx.x;
             if (row >= nlight) continue;
             const S om = S(1) - w;
-            const S y0 = pin[row] - om * zin[row], y1 = pin[nbp + row] - om * zin[nbp + row], y2 = pin[2 * nbp + row] - om * zin[2 * nbp + row];
+            S y0 = pin[row] - om * zin[row], y1 = pin[nbp + row] - om * zin[nbp + row], y2 = pin[2 * nbp + row] - om * zin[2 * nbp + row];
+            if (lr.perf_of_row) lowrank_add(lr, row, y0, y1, y2);
             y[row] = y0; y[nbp + row] = y1; y[2 * nbp + row] = y2;
             if (NDOT >= 1) acc[0] += double(w1[row]) * double(y0) + double(w1[nbp + row]) * double(y1) + double(w1[2 * nbp + row]) * double(y2);
             if (NDOT == 2) acc[1] += double(y0) * double(y0) + double(y1) * double(y1) + double(y2) * double(y2);
@@ -107,6 +143,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(int xm, int nb, int nbp, const 
                 y2 += b[384] * x0 + b[448] * x1 + b[512] * x2;
             }
         }
+        if (lr.perf_of_row) lowrank_add(lr, row, y0, y1, y2);
         y[row] = y0; y[nbp + row] = y1; y[2 * nbp + row] = y2;
         if (NDOT >= 1) acc[0] += double(w1[row]) * double(y0) + double(w1[nbp + row]) * double(y1) + double(w1[2 * nbp + row]) * double(y2);
         if (NDOT == 2) acc[1] += double(y0) * double(y0) + double(y1) * double(y1) + double(y2) * double(y2);
@@ -667,9 +704,15 @@ template <class S> void LinSolver::ilu_apply(const S* d, S* v, double relax, con
 template <class S> void LinSolver::spmv(const S* x, S* y)
 {
     const int g = std::min(grid8_for(plan.nb), 4 * kMaxPart);
+    lowrank_reduce<S>(x, nullptr);
     hipLaunchKernelGGL((k_spmv<S, 0>), dim3(g), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p,
                        matrix<S>(), x, y, (const S*)nullptr, comm ? comm->owner_mask() : (const int8_t*)nullptr, (const SolveCtl*)nullptr,
-                       (double*)nullptr, (double*)nullptr, (const S*)nullptr, (const S*)nullptr, 0, S(0));
+                       (double*)nullptr, (double*)nullptr, (const S*)nullptr, (const S*)nullptr, 0, S(0), lowrank);
+}
+
+template <class S> void LinSolver::lowrank_reduce(const S* x, const SolveCtl* ctl)
+{
+    if (lowrank.nw > 0) hipLaunchKernelGGL((k_lowrank_reduce<S>), dim3(lowrank.nw), dim3(kBlock), 0, stream, lowrank, plan.nbp, x, ctl);
 }
 
 static void halo_dispatch(CommBase* c, float* v, hipStream_t s) { c->halo_exchange_f(v, s); }
@@ -765,8 +808,9 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
                            w.r.p, w.v.p, w.p.p);
         if (cpr) cpr_apply<S>(w.p.p, w.y.p, prm.ilu_relaxation, d_ctl); else ilu_apply<S>(w.p.p, w.y.p, prm.ilu_relaxation, d_ctl);
         if (comm) halo<S>(comm, w.y.p, stream);
+        lowrank_reduce<S>(w.y.p, d_ctl);
         hipLaunchKernelGGL((k_spmv<S, 1>), dim3(gs), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p, matrix<S>(),
-                           w.y.p, w.v.p, w.rt.p, mask, (const SolveCtl*)d_ctl, P_h, (double*)nullptr, pin_p, zin_p, n0, S(prm.ilu_relaxation));
+                           w.y.p, w.v.p, w.rt.p, mask, (const SolveCtl*)d_ctl, P_h, (double*)nullptr, pin_p, zin_p, n0, S(prm.ilu_relaxation), lowrank);
         double* a_h = P_h; int np_h = gs; none = nullptr;
         bridge(a_h, none, np_h, 1);
         hipLaunchKernelGGL((k_update_xr1<S>), dim3(gv), dim3(kBlock), 0, stream, n, j, eps, d_ctl, h_ctl_dev, (const double*)a_h, np_h, w.y.p, w.v.p,
@@ -775,8 +819,9 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
         bridge(a_n1, none, np_n1, 2);
         if (cpr) cpr_apply<S>(w.r.p, w.y.p, prm.ilu_relaxation, d_ctl); else ilu_apply<S>(w.r.p, w.y.p, prm.ilu_relaxation, d_ctl);
         if (comm) halo<S>(comm, w.y.p, stream);
+        lowrank_reduce<S>(w.y.p, d_ctl);
         hipLaunchKernelGGL((k_spmv<S, 2>), dim3(gs), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p, matrix<S>(),
-                           w.y.p, w.t.p, w.r.p, mask, (const SolveCtl*)d_ctl, P_tr, P_tt, pin_r, zin_r, n0, S(prm.ilu_relaxation));
+                           w.y.p, w.t.p, w.r.p, mask, (const SolveCtl*)d_ctl, P_tr, P_tt, pin_r, zin_r, n0, S(prm.ilu_relaxation), lowrank);
         double* a_tr = P_tr; double* a_tt = P_tt; int np_t = gs;
         bridge(a_tr, a_tt, np_t, 3);
         hipLaunchKernelGGL((k_update_xr2<S>), dim3(gv), dim3(kBlock), 0, stream, n, j, d_ctl, h_ctl_dev, (const double*)a_n1, (const double*)a_tr,

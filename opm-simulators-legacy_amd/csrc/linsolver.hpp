@@ -47,6 +47,20 @@ struct CommBase {
     int n_owned_global = 0;
 };
 
+// Low-rank part of the operator: A_total = A + sum over wells of P_w Q_w (rank 7 per well: the Schur complement of the
+// well equations plus the mixture coupling of the perforations, wells.hip).  Applied matrix-free inside k_spmv after
+// k_lowrank_reduce has formed t_w = Q_w x; ILU0 and the AMG see A only.
+struct LowRankOp {
+    int nw = 0, nperf = 0;
+    const int32_t* connpos = nullptr;      // [nw+1]
+    const int32_t* perf_row = nullptr;     // [nperf] internal row of every perforation
+    const int32_t* perf_well = nullptr;    // [nperf]
+    const int32_t* perf_of_row = nullptr;  // [nbp] perforation of a row or -1
+    const double* P = nullptr;             // [nperf][3][7], rows already matbal-scaled
+    const double* Q = nullptr;             // [nperf][7][3]
+    double* t = nullptr;                   // [nw][7] scratch
+};
+
 template <class S>
 struct SolverWork {
     DevArray<S> A;      // float copy of the matrix (unused for double: the double matrix is used in place)
@@ -114,6 +128,8 @@ public:
     int cur_ordering = -1;
     int npart = 0;                 // entries per partial array
     CommBase* comm = nullptr;      // not owned; nullptr = single GPU
+    LowRankOp lowrank;             // nw == 0: none
+    template <class S> void lowrank_reduce(const S* x, const SolveCtl* ctl);
     bool closed_form_level0 = true; // k_spmv shortcut on level-0 rows (A/B switch: OPMGPU_CLOSED=0)
     hipEvent_t ev[2] = { nullptr, nullptr };
 

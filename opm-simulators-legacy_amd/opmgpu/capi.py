@@ -49,6 +49,11 @@ class Tables(C.Structure):
                 ("rocktab_n", C.c_int32), ("rocktab_p", _dp), ("rocktab_pvmult", _dp), ("rocktab_transmult", _dp)]
 
 
+class WellsSpec(C.Structure):
+    _fields_ = [("nw", C.c_int32), ("well_connpos", _ip), ("well_cells", _ip), ("WI", _dp), ("type", _ip), ("allow_cf", _ip),
+                ("depth_ref", _dp), ("comp_frac", _dp), ("ctrl_type", _ip), ("ctrl_target", _dp), ("ctrl_distr", _dp)]
+
+
 class Params(C.Structure):
     _fields_ = [("dp_max_rel", C.c_double), ("ds_max", C.c_double), ("dr_max_rel", C.c_double),
                 ("max_residual_allowed", C.c_double), ("tolerance_mb", C.c_double),
@@ -112,6 +117,10 @@ SIGNATURES = {
     "opmgpu_solve": (C.c_int, [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int), _dp]),
     "opmgpu_update_state": (C.c_int, [C.c_void_p, _dp, C.c_double]),
     "opmgpu_stabilize_update": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
+    "opmgpu_set_device_wells": (C.c_int, [C.c_void_p, C.POINTER(WellsSpec)]),
+    "opmgpu_well_state_set": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
+    "opmgpu_well_state_get": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp]),
+    "opmgpu_well_convergence": (C.c_int, [C.c_void_p, _dp, _dp]),
     "opmgpu_save_state": (C.c_int, [C.c_void_p]),
     "opmgpu_restore_state": (C.c_int, [C.c_void_p]),
     "opmgpu_relative_change": (C.c_int, [C.c_void_p, _dp]),

@@ -329,6 +329,78 @@ class WellCoupledModel:
         return converged, lin
 
 
+class DeviceWellModel:
+    """The same nonlinear iteration with the well model ON THE DEVICE (csrc/wells.hip): no per-iteration
+    read-back of perforation properties, no clique fill -- opmgpu_set_device_wells / well_state_set / well_convergence.
+    Interface of WellCoupledModel, so NonlinearSolver / AdaptiveTimeStepping drive either."""
+
+    def __init__(self, backend, wells, well_state, tolerance_wells=1e-4, tolerance_well_control=1e-7):
+        import ctypes as C
+        from . import capi
+        self.m, self.w, self.ws = backend, wells, well_state
+        self.tol_wells, self.tol_ctrl = tolerance_wells, tolerance_well_control
+        self.linear_iterations = 0
+        nw = wells.nw
+        spec = capi.WellsSpec()
+        self._keep = [np.asarray(wells.connpos, np.int32), np.asarray(wells.cells, np.int32), capi.f64(wells.WI),
+                      np.asarray(wells.type, np.int32), np.asarray([int(a) for a in wells.allow_cf], np.int32), capi.f64(wells.depth_ref),
+                      capi.f64(np.asarray(wells.comp_frac, float).reshape(nw, 3)), np.asarray(wells.ctrl_type, np.int32),
+                      capi.f64(wells.ctrl_target), capi.f64(np.asarray(wells.ctrl_distr, float).reshape(nw, 3))]
+        k = self._keep
+        spec.nw = nw
+        spec.well_connpos, spec.well_cells, spec.WI, spec.type, spec.allow_cf = capi.iptr(k[0]), capi.iptr(k[1]), capi.dptr(k[2]), capi.iptr(k[3]), capi.iptr(k[4])
+        spec.depth_ref, spec.comp_frac, spec.ctrl_type, spec.ctrl_target, spec.ctrl_distr = capi.dptr(k[5]), capi.dptr(k[6]), capi.iptr(k[7]), capi.dptr(k[8]), capi.dptr(k[9])
+        backend._chk(backend.lib.opmgpu_set_device_wells(backend.ctx, C.byref(spec)))
+        self.push_well_state()
+
+    def push_well_state(self):
+        from . import capi
+        m, ws = self.m, self.ws
+        m._chk(m.lib.opmgpu_well_state_set(m.ctx, capi.dptr(capi.f64(ws.bhp)), capi.dptr(capi.f64(ws.qs)), capi.dptr(capi.f64(ws.perf_rates))))
+
+    def pull_well_state(self):
+        """device well state -> the WellState object (bhp, wellRates, perfPress, perfPhaseRates)"""
+        from . import capi
+        m, ws = self.m, self.ws
+        bhp, qs = np.zeros(self.w.nw), np.zeros((self.w.nw, 3))
+        pp, pr = np.zeros(self.w.nperf), np.zeros((self.w.nperf, 3))
+        m._chk(m.lib.opmgpu_well_state_get(m.ctx, capi.dptr(bhp), capi.dptr(qs), capi.dptr(pp), capi.dptr(pr)))
+        ws.bhp[:], ws.qs[:], ws.perf_press[:], ws.perf_rates[:] = bhp, qs, pp, pr
+        return ws
+
+    def prepareStep(self, dt, state=None):
+        self.m.prepareStep(dt, state)
+
+    def saveState(self):
+        self.m.saveState()
+
+    def restoreState(self):
+        self.m.restoreState()
+
+    def relativeChange(self):
+        return self.m.relativeChange()
+
+    def wellConvergence(self):
+        from . import capi
+        m = self.m
+        flux, ctrl = np.zeros(3), np.zeros(1)
+        m._chk(m.lib.opmgpu_well_convergence(m.ctx, capi.dptr(flux), capi.dptr(ctrl)))
+        self.well_flux_residual, self.well_ctrl_residual = np.asarray(m.B_avg) * flux, float(ctrl[0])
+        return bool(np.all(self.well_flux_residual < self.tol_wells) and self.well_ctrl_residual < self.tol_ctrl)
+
+    def nonlinearIteration(self, iteration, single_precision=None, nonlinear_solver=None):
+        m = self.m
+        m.assemble(iteration == 0)                      # reservoir + wells, connection pressures at iteration 0
+        converged = m.getConvergence()
+        converged = self.wellConvergence() and converged
+        lin = 0
+        if not converged or iteration < 1:
+            m.solveJacobianSystem(single_precision=single_precision)
+            lin = self.linear_iterations = m.linear_iterations
+            m.updateState()                              # also recovers and updates (q_s, bhp) on the device
+        return converged, lin
+
+
 def five_spot(grid, rate_m3_per_day=500.0, bhp_prod_bar=150.0, wi=None):
     """SURVEY 8d synthetic wells: one water injector (rate controlled, full column) in the centre and four
     BHP-controlled producers in the corners of a Cartesian grid.  Peaceman-like WI from the cell transmissibility scale."""

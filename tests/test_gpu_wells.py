@@ -40,3 +40,82 @@ def test_well_coupled_newton_parity(gpu_lib, oracle):
         mg.prepareStep(dt); mo.prepareStep(dt)
     assert mg.ws.qs[0, 0] > 0 and mg.ws.qs[1, 1] < 0
     gm.close()
+
+
+@pytest.mark.parametrize("cpr", [0, 1])
+def test_device_wells_match_host_wells_on_the_oracle(gpu_lib, oracle, cpr):
+    """Wells ON THE DEVICE (csrc/wells.hip: factored Schur complement, rank-7 operator per well inside the SpMV) vs the CPU
+    oracle driven by the host well model with the explicit Schur complement: same Newton path, same well state."""
+    grid, tab, st, wl = _setup()
+    prm = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=500, use_cpr=cpr)
+    prm_o = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=500)
+    dt = 2 * decks.DAY
+    gm = GpuBlackoilModel(grid, tab, prm)
+    ob = OracleBackend(oracle, grid, tab, prm_o, wells=wl.arrays())
+    md = W.DeviceWellModel(gm, wl, W.WellState(wl, st.p))
+    mo = W.WellCoupledModel(ob, W.StandardWellsHost(wl, grid.z, tab.surface_density[0]), W.WellState(wl, st.p))
+    md.prepareStep(dt, st); mo.prepareStep(dt, st)
+    for step in range(2):
+        it = 0
+        while True:
+            cd, ld = md.nonlinearIteration(it, single_precision=False)
+            co, lo = mo.nonlinearIteration(it, single_precision=False)
+            assert cd == co, (step, it)
+            assert np.allclose(md.well_flux_residual, mo.wh.well_flux_residual, rtol=1e-5, atol=1e-12), (step, it)
+            assert md.well_ctrl_residual == pytest.approx(mo.wh.well_ctrl_residual, rel=1e-5, abs=1e-12)
+            it += 1
+            a, b = gm.getState(), ob.getState()
+            ws = md.pull_well_state()
+            assert np.array_equal(a.hc, b.hc), (step, it)
+            assert np.abs(a.p - b.p).max() <= 1e-6 * np.abs(b.p).max(), (step, it)
+            assert np.abs(a.sat - b.sat).max() <= 1e-6, (step, it)
+            assert np.allclose(ws.bhp, mo.ws.bhp, rtol=1e-7), (step, it, ws.bhp, mo.ws.bhp)
+            assert np.allclose(ws.qs, mo.ws.qs, rtol=1e-6, atol=1e-9 * np.abs(mo.ws.qs).max()), (step, it)
+            assert np.allclose(ws.perf_rates, mo.ws.perf_rates, rtol=1e-6, atol=1e-9 * np.abs(mo.ws.perf_rates).max())
+            assert np.allclose(gm.CNV, ob.CNV, rtol=1e-5, atol=1e-9)
+            if cd and it >= 1:
+                break
+            assert it <= 12
+        md.prepareStep(dt); mo.prepareStep(dt)
+    assert ws.qs[0, 0] > 0 and ws.qs[1, 1] < 0
+    gm.close()
+
+
+@pytest.mark.parametrize("single", [False, True])
+def test_device_wells_five_spot_vs_host_wells(gpu_lib, single):
+    """5-spot with full-column wells (SURVEY 8d synthetic wells) on a deck with all three hydrocarbon states: the device well
+    model against the host well model (explicit cliques), both on the GPU reservoir path, tight linear tolerance."""
+    tab = decks.satfunc_standard_tables()
+    grid = decks.cartesian_grid(9, 9, 12, lognormal_sigma=0.5)
+    st = decks.initial_state(grid, tab, perturb=0.002)
+    wl = W.five_spot(grid, rate_m3_per_day=40.0, bhp_prod_bar=150.0)
+    red = 1e-6 if single else 1e-11
+    prm = capi.default_params(linear_solver_reduction=red, linear_solver_maxiter=500)
+    dt = 1 * decks.DAY
+    gh = GpuBlackoilModel(grid, tab, prm, wells=wl.arrays())
+    gd = GpuBlackoilModel(grid, tab, prm)
+    mh = W.WellCoupledModel(gh, W.StandardWellsHost(wl, grid.z, tab.surface_density[0]), W.WellState(wl, st.p))
+    md = W.DeviceWellModel(gd, wl, W.WellState(wl, st.p))
+    mh.prepareStep(dt, st); md.prepareStep(dt, st)
+    tol_p, tol_s = (2e-5, 2e-5) if single else (1e-6, 1e-6)
+    for step in range(2):
+        it = 0
+        while True:
+            ch, _ = mh.nonlinearIteration(it, single_precision=single)
+            cd, _ = md.nonlinearIteration(it, single_precision=single)
+            it += 1
+            a, b = gd.getState(), gh.getState()
+            ws = md.pull_well_state()
+            assert np.array_equal(a.hc, b.hc), (step, it)
+            assert np.abs(a.p - b.p).max() <= tol_p * np.abs(b.p).max(), (step, it, np.abs(a.p - b.p).max() / np.abs(b.p).max())
+            assert np.abs(a.sat - b.sat).max() <= tol_s, (step, it)
+            assert np.allclose(ws.bhp, mh.ws.bhp, rtol=10 * tol_p), (step, it)
+            assert np.allclose(ws.qs, mh.ws.qs, rtol=0, atol=50 * tol_p * np.abs(mh.ws.qs).max()), (step, it)
+            if not single:
+                assert ch == cd, (step, it)
+            if (ch and cd and it >= 1) or it > 12:
+                break
+        assert it <= 12
+        mh.prepareStep(dt); md.prepareStep(dt)
+    assert ws.qs[0, 0] > 0 and (ws.qs[1:, 1] < 0).all()
+    gh.close(); gd.close()
