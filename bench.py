@@ -44,6 +44,8 @@ def main():
                     help="cpr: AMG pressure stage + ILU0 (reference solver_approach=cpr); ilu0: reference default solver_approach=interleaved")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N > 1: weak = every GPU keeps an nx x ny x nz slab (global deck nx x ny x nz*N, sized for 288 GB/GPU); strong = the fixed nx x ny x nz deck is cut into N slabs")
+    ap.add_argument("--wells", choices=["none", "fivespot"], default="none",
+                    help="fivespot: SURVEY 8d synthetic wells (1 rate-controlled water injector + 4 BHP producers, full columns) with the device well model; single GPU only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="take the domain-decomposition code path (torch.distributed + RCCL communicator) even with one rank")
     ap.add_argument("--cpu-threads", type=int, default=1)
@@ -90,8 +92,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_run(model):
+    def with_wells(model, which):
+        if which == "none" or use_dist:
+            return model
+        from opmgpu import wells as W
+        wl = W.five_spot(grid, rate_m3_per_day=5000.0, bhp_prod_bar=150.0)
+        return W.DeviceWellModel(model, wl, W.WellState(wl, st.p))
+
+    def timed_run(model, wells=None):
         """exactly K timed Newton iterations after W warm-up ones; time steps follow each other like in the simulator"""
+        core = model
+        model = with_wells(model, wells if wells is not None else args.wells)
         model.prepareStep(dt, st)
         it, lin_total, steps_done = 0, 0, 0
         t_asm = t_sol = t_upd = 0.0
@@ -103,7 +114,7 @@ def main():
                 lin_total = 0
                 t_asm = t_sol = t_upd = 0.0
             converged, lin = model.nonlinearIteration(it)
-            a, s, u = model.timings()
+            a, s, u = core.timings()
             t_asm += a; t_sol += s; t_upd += u
             lin_total += lin
             it += 1
@@ -135,6 +146,16 @@ def main():
         m0.close()
         ilu0 = {"value": nc_global / (r0["elapsed"] / args.steps) / 1e6, "ms_per_step": 1e3 * r0["elapsed"] / args.steps,
                 "linear_iterations_per_newton": r0["lin"], "breakdown_ms_per_step": r0["breakdown"]}
+
+    # ... and with the SURVEY 8d 5-spot (device well model), unless that already is the main run
+    fivespot = None
+    if not use_dist and args.wells == "none":
+        m1 = GpuBlackoilModel(grid, tab, prm, device=local_rank)
+        r1 = timed_run(m1, wells="fivespot")
+        m1.close()
+        fivespot = {"value": nc_global / (r1["elapsed"] / args.steps) / 1e6, "ms_per_step": 1e3 * r1["elapsed"] / args.steps,
+                    "linear_iterations_per_newton": r1["lin"], "breakdown_ms_per_step": r1["breakdown"],
+                    "wells": "1 rate-controlled water injector + 4 BHP producers, %d perforations each, device well model" % args.nz}
 
     out = None
     if rank == 0:
@@ -185,9 +206,11 @@ def main():
                        "cells": nc_global, "cells_per_gpu": info["n_owned"], "nnzb_rank0": nnzb,
                        "dt_days": args.dt_days, "linear_solver": ("cpr(amg V-cycle + ilu0)" if prm.use_cpr else "ilu0") + " + bicgstab", "ilu0_ordering": args.ordering, "linear_iterations_per_newton": res["lin"],
                        "time_steps_completed": steps_done, "tables": "tests/satfuncStandard.DATA PROPS (reference's own test deck)",
+                       "wells": "none" if (args.wells == "none" or use_dist) else "5-spot, 5 wells x %d perforations, device well model (rank-7 operator per well)" % args.nz,
                        "parallelism": "1 GPU" if world == 1 else "domain decomposition x%d, RCCL halo" % world},
             "breakdown_ms_per_step": res["breakdown"],
             "same_run_with_reference_default_solver_ilu0": ilu0,
+            "same_run_with_fivespot_wells": fivespot,
             "roofline": main_roof, "roofline_f64_spmv": roof["f64"], "roofline_f32_spmv": roof["f32"],
             "cpu_baseline": cpu,
         }

@@ -102,6 +102,21 @@ int main()
         }
         std::printf("host_check: converged in %d Newton iterations, last linear solve %d iterations, relaxation %.2f\n", its,
                     model.linearIterationsLastSolve(), model.relaxation());
+        // two wells with the device well model: a rate-controlled water injector (full column) and a BHP-controlled producer
+        {
+            const int32_t connpos[3] = { 0, 3, 6 };
+            const int32_t cells[6] = { 0, 36, 72, 35, 71, 107 };
+            const double WI[6] = { 2e-12, 2e-12, 2e-12, 2e-12, 2e-12, 2e-12 };
+            const int32_t type[2] = { 0, 1 }, ctrl_type[2] = { 1, 0 };
+            const double depth_ref[2] = { 2001.0, 2001.0 }, comp_frac[6] = { 1, 0, 0, 0, 1, 0 };
+            const double ctrl_target[2] = { 5.0 / 86400.0, 150e5 }, ctrl_distr[6] = { 1, 0, 0, 0, 0, 0 };
+            opmgpu_wells wells{};
+            wells.nw = 2; wells.well_connpos = connpos; wells.well_cells = cells; wells.WI = WI; wells.type = type; wells.depth_ref = depth_ref;
+            wells.comp_frac = comp_frac; wells.ctrl_type = ctrl_type; wells.ctrl_target = ctrl_target; wells.ctrl_distr = ctrl_distr;
+            model.setDeviceWells(wells);
+            const double bhp0[2] = { 1.01 * p[0], 150e5 }, qs0[6] = { 5.0 / 86400.0, 0, 0, 0, 0, 0 };
+            model.setWellState(bhp0, qs0);
+        }
         // a 20-day report step through the adaptive sub-stepping loop (AdaptiveTimeStepping::stepImpl), state resident on the device
         opmgpu::AdaptiveTimeSteppingGpu ats;
         ats.step(20 * 86400.0, solver, model);
@@ -111,6 +126,14 @@ int main()
             std::printf("host_check: FAILED, adaptive stepping took %zu sub-steps summing to %g s\n", ats.substeps.size(), total);
             return 1;
         }
+        double bhp[2], qs[6];
+        model.getWellState(bhp, qs);
+        if (!(std::abs(qs[0] - 5.0 / 86400.0) < 1e-9) || !(qs[4] < 0.0) || !(std::abs(bhp[1] - 150e5) < 1.0) || !(bhp[0] > 150e5)) {
+            std::printf("host_check: FAILED, well state after the report step: inj rate %g bhp %g, prod oil rate %g bhp %g\n", qs[0], bhp[0], qs[4], bhp[1]);
+            return 1;
+        }
+        std::printf("host_check: wells: injector bhp %.1f bar at %.2f m3/d water, producer %.2f m3/d oil at %.1f bar\n", bhp[0] / 1e5, qs[0] * 86400.0,
+                    -qs[4] * 86400.0, bhp[1] / 1e5);
         std::printf("host_check: report step of 20 d in %zu sub-steps (first %.2f d, last %.2f d), %d failed, next suggestion %.2f d\n",
                     ats.substeps.size(), ats.substeps.front() / 86400.0, ats.substeps.back() / 86400.0, ats.failed_substeps,
                     ats.suggested_next_timestep / 86400.0);

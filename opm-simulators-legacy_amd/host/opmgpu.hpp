@@ -109,6 +109,21 @@ public:
     int numPhases() const { return 3; }
     void setWells(int nw, const int32_t* well_connpos, const int32_t* well_cells) { throw_on_status(ctx_, opmgpu_set_wells(ctx_, nw, well_connpos, well_cells)); }
 
+    /// wells on the device (StandardWells restated in csrc/wells.hip): topology + controls, then the WellState fields
+    void setDeviceWells(const opmgpu_wells& wells) { throw_on_status(ctx_, opmgpu_set_device_wells(ctx_, &wells)); device_wells_ = wells.nw > 0; }
+    void setWellState(const double* bhp, const double* well_rates, const double* perf_rates = nullptr) { throw_on_status(ctx_, opmgpu_well_state_set(ctx_, bhp, well_rates, perf_rates)); }
+    void getWellState(double* bhp, double* well_rates, double* perf_press = nullptr, double* perf_rates = nullptr) { throw_on_status(ctx_, opmgpu_well_state_get(ctx_, bhp, well_rates, perf_press, perf_rates)); }
+    /// well part of getConvergence (:1769-1779)
+    bool wellsConverged(const ConvergenceReport& r)
+    {
+        if (!device_wells_) return true;
+        double flux[3], ctrl = 0.0;
+        throw_on_status(ctx_, opmgpu_well_convergence(ctx_, flux, &ctrl));
+        bool ok = ctrl < tolerance_well_control_;
+        for (int a = 0; a < 3; ++a) ok = ok && (r.B_avg[a] * flux[a] < tolerance_wells_);
+        return ok;
+    }
+
     /// prepareStep (:222-232): remembers dt (pvdt = pv/dt is applied in assemble) and uploads the state
     void prepareStep(double dt, const ReservoirStateView& s)
     {
@@ -140,7 +155,8 @@ public:
     {
         if (iteration == 0) { residual_norms_history_.clear(); current_relaxation_ = 1.0; }    // dx_old is zeroed by the initial assembly
         assemble(iteration == 0);
-        const ConvergenceReport r = getConvergence();
+        ConvergenceReport r = getConvergence();
+        r.converged = wellsConverged(r) && r.converged;
         residual_norms_history_.push_back({ r.linf[0], r.linf[1], r.linf[2] });               // computeResidualNorms (:1551-1589)
         const bool must_solve = (iteration < nonlinear_solver.minIter()) || !r.converged;
         if (must_solve) {
@@ -171,6 +187,8 @@ private:
     double dt_ = 0.0, max_single_precision_days_ = 20.0, linear_reduction_ = 0.0;
     int linear_iterations_ = 0;
     bool use_update_stabilization_ = true;              // BlackoilModelParameters.cpp:98
+    bool device_wells_ = false;
+    double tolerance_wells_ = 1e-4, tolerance_well_control_ = 1e-7;    // BlackoilModelParameters.cpp:88-89
     double current_relaxation_ = 1.0;
     std::vector<std::array<double, 3>> residual_norms_history_;
 };

@@ -147,7 +147,9 @@ def test_newton_iterations_parity(gpu_lib, oracle, single):
             res_o = np.linalg.norm(A @ x - b) / np.linalg.norm(b)
             # dx solves the system to the linear tolerance -- or, where f32 rounding of the recurrence
             # residual is the limit, at least as well as the CPU f32 implementation does
-            assert res_g <= max(3.0 * red, 1.5 * res_o), (it, res_g, res_o)
+            # (the f32 attainable accuracy cond(A)*eps_f32 ~ 1e-3..1e-4 here depends on the rounding path: same order of magnitude, not equal)
+            assert m.linear_reduction <= red, (it, m.linear_reduction)
+            assert res_g <= max(3.0 * red, 10.0 * res_o), (it, res_g, res_o)
             so = g.copy()               # restart the oracle from the device state
     m.close()
 
