@@ -1,0 +1,354 @@
+"""Minimal ECLIPSE deck ingest for the hot path's static inputs.
+
+What `flow_legacy` gets from opm-parser + `DerivedGeology` (opm/autodiff/GeoProps.hpp:84-195) + `BlackoilPropsAdFromDeck`
+(opm/autodiff/BlackoilPropsAdFromDeck.cpp:60-240), restricted to what the device path consumes:
+
+  RUNSPEC   DIMENS TABDIMS OIL WATER GAS DISGAS VAPOIL METRIC ENDSCALE
+  GRID      DX DY DZ / DXV DYV DZV, TOPS (+BOX for the top layer) or DEPTHZ (flat), PORO PERMX PERMY PERMZ NTG ACTNUM
+            MULTX MULTY MULTZ MULTPV NNC
+  PROPS     SWOF SGOF PVTO PVDO PVCDO PVTG PVDG PVTW DENSITY ROCK ROCKTAB VAPPARS SCALECRS
+            SWL SWCR SWU SOWCR SGL SGCR SGU SOGCR
+  REGIONS   PVTNUM SATNUM
+  SOLUTION  PRESSURE SWAT SGAS RS RV (explicit initial state; EQUIL is outside the hot path)
+
+Block-centred Cartesian geometry only (corner-point COORD/ZCORN needs opm-grid's processing, out of scope).  TPFA
+transmissibilities as `tpfa_htrans_compute` / `tpfa_trans_compute` do for such cells: half-transmissibility
+K A / (d/2) per side (horizontal ones times NTG, DerivedGeology :135-160), harmonic sum, times the MULT? of the face.
+Everything else (SCHEDULE, SUMMARY, report keywords) is skipped.  METRIC units only.
+"""
+import re
+
+import numpy as np
+
+from . import decks
+from .decks import BAR, DAY, FluidTables, GridData, MD, State
+
+FLAG_KEYWORDS = {"RUNSPEC", "GRID", "EDIT", "PROPS", "REGIONS", "SOLUTION", "SUMMARY", "SCHEDULE", "END", "NOECHO", "ECHO", "OIL", "WATER",
+                 "GAS", "DISGAS", "VAPOIL", "METRIC", "FIELD", "LAB", "FMTOUT", "FMTIN", "UNIFOUT", "UNIFIN", "RUNSUM", "SEPARATE", "ALL",
+                 "INIT", "NOSIM", "ENDBOX", "EXCEL", "NOGGF", "NEWTRAN", "OLDTRAN"}
+_KW = re.compile(r"^[A-Z][A-Z0-9_+\-]{0,7}$")
+EPS_NAMES = GridData.EPS_NAMES
+
+
+def _tokens(text):
+    """comment-stripped tokens; quoted strings stay single tokens; '/' is its own token"""
+    out = []
+    for line in text.splitlines():
+        # cut '--' comments outside quotes
+        q, cut = False, len(line)
+        for i, ch in enumerate(line):
+            if ch == "'":
+                q = not q
+            elif not q and line.startswith("--", i):
+                cut = i
+                break
+        line = line[:cut]
+        toks = re.findall(r"'[^']*'|/|[^\s/']+", line)
+        out.append(toks)
+    return out
+
+
+def _expand(tok):
+    """'3*0.2' -> [0.2]*3 ; '2*' -> [None]*2 ; number / string otherwise"""
+    m = re.match(r"^(\d+)\*(.*)$", tok)
+    if m:
+        n, v = int(m.group(1)), m.group(2)
+        return [(_value(v) if v != "" else None)] * n
+    return [_value(tok)]
+
+
+def _value(tok):
+    if tok.startswith("'"):
+        return tok.strip("'")
+    try:
+        return float(tok.replace("D", "E").replace("d", "e"))
+    except ValueError:
+        return tok
+
+
+class Deck:
+    def __init__(self, keywords):
+        self.kw = keywords              # name -> list of records (each a list of values), last occurrence wins; BOX-scoped ones keep their box
+
+    def has(self, name):
+        return name in self.kw
+
+    def records(self, name):
+        return self.kw[name]["records"]
+
+    def array(self, name, n=None, default=None):
+        if name not in self.kw:
+            return default
+        v = [x for x in self.kw[name]["records"][0]]
+        a = np.asarray([np.nan if x is None else x for x in v], dtype=float)
+        if n is not None and a.size != n:
+            raise ValueError("%s holds %d values, expected %d" % (name, a.size, n))
+        return a
+
+    # ---------------------------------------------------------------- RUNSPEC
+    @property
+    def dims(self):
+        r = self.records("DIMENS")[0]
+        return int(r[0]), int(r[1]), int(r[2])
+
+    def tabdims(self):
+        r = self.records("TABDIMS")[0] if self.has("TABDIMS") else []
+        get = lambda i, d: int(r[i]) if len(r) > i and r[i] is not None else d
+        return get(0, 1), get(1, 1)          # NTSFUN, NTPVT
+
+    # ---------------------------------------------------------------- PROPS
+    def tables(self):
+        if self.has("FIELD") or self.has("LAB"):
+            raise ValueError("only METRIC decks are supported")
+        ntsfun, ntpvt = self.tabdims()
+        dens = [[r[1], r[0], r[2]] for r in self.records("DENSITY")[:ntpvt]]            # deck order oil water gas -> (w, o, g)
+        pvtw = [[r[0], r[1], r[2], r[3], r[4] if len(r) > 4 and r[4] is not None else 0.0] for r in self.records("PVTW")[:ntpvt]]
+        disgas, vapoil = self.has("DISGAS"), self.has("VAPOIL")
+        # oil
+        if self.has("PVTO"):
+            pvto = []
+            for tab in _split_tables(self.records("PVTO")):
+                rows = []
+                for rec in tab:
+                    rs, rest = rec[0], rec[1:]
+                    rows.append((rs, [tuple(rest[i:i + 3]) for i in range(0, len(rest), 3)]))
+                pvto.append(rows)
+        elif self.has("PVDO"):
+            pvto = [[(0.0, [tuple(rec[i:i + 3])]) for i in range(0, len(rec), 3)] for rec in self.records("PVDO")[:ntpvt]]
+            disgas = False
+        elif self.has("PVCDO"):
+            # constant compressibility dead oil: two nodes far apart reproduce it when Co = Cv = 0 (the reference's tests/fluid.data)
+            pvto = []
+            for r in self.records("PVCDO")[:ntpvt]:
+                pref, bo, co, mu = r[0], r[1], r[2], r[3]
+                cv = r[4] if len(r) > 4 and r[4] is not None else 0.0
+                if co != 0.0 or cv != 0.0:
+                    raise ValueError("PVCDO with non-zero compressibility / viscosibility is not supported")
+                pvto.append([(0.0, [(pref, bo, mu)]), (0.0, [(pref + 800.0, bo, mu)])])
+            disgas = False
+        else:
+            raise ValueError("no oil PVT keyword (PVTO / PVDO / PVCDO)")
+        # gas
+        if self.has("PVTG"):
+            pvtg = []
+            for tab in _split_tables(self.records("PVTG")):
+                rows = []
+                for rec in tab:
+                    pg, rest = rec[0], rec[1:]
+                    rows.append((pg, [tuple(rest[i:i + 3]) for i in range(0, len(rest), 3)]))
+                pvtg.append(rows)
+        elif self.has("PVDG"):
+            pvtg = [[(rec[i], [(0.0, rec[i + 1], rec[i + 2])]) for i in range(0, len(rec), 3)] for rec in self.records("PVDG")[:ntpvt]]
+            vapoil = False
+        else:
+            raise ValueError("no gas PVT keyword (PVTG / PVDG)")
+        swof = [[tuple(rec[i:i + 4]) for i in range(0, len(rec), 4)] for rec in self.records("SWOF")[:ntsfun]]
+        sgof = [[tuple(rec[i:i + 4]) for i in range(0, len(rec), 4)] for rec in self.records("SGOF")[:ntsfun]]
+        rock = (1.0, 0.0)
+        if self.has("ROCK"):
+            r = self.records("ROCK")[0]
+            rock = (r[0], r[1])
+        rocktab = None
+        if self.has("ROCKTAB"):
+            rec = self.records("ROCKTAB")[0]
+            ncol = 5 if len(rec) % 5 == 0 and len(rec) % 3 != 0 else 3
+            rocktab = [(rec[i], rec[i + 1], rec[i + 2]) for i in range(0, len(rec), ncol)]
+        vappars = (0.0, 0.0)
+        if self.has("VAPPARS"):
+            r = self.records("VAPPARS")[0]
+            vappars = (r[0], r[1])
+        return FluidTables(density_wog=dens, pvtw=pvtw, pvto=pvto, pvtg=pvtg, swof=swof, sgof=sgof, rock=rock, disgas=disgas, vapoil=vapoil,
+                           vappars=vappars, rocktab=rocktab)
+
+    # ---------------------------------------------------------------- GRID
+    def _cell_sizes(self):
+        nx, ny, nz = self.dims
+        n = nx * ny * nz
+
+        def axis(full, vec, count, shape):
+            if self.has(full):
+                return self.array(full, n).reshape(nz, ny, nx)
+            v = self.array(vec, count)
+            return np.broadcast_to(v.reshape(shape), (nz, ny, nx)).copy()
+        dx = axis("DX", "DXV", nx, (1, 1, nx)); dy = axis("DY", "DYV", ny, (1, ny, 1)); dz = axis("DZ", "DZV", nz, (nz, 1, 1))
+        return dx, dy, dz
+
+    def grid(self, gravity=decks.GRAVITY):
+        """GridData of the active cells: connections x- then y- then z-normal faces (grid face order), then the NNCs."""
+        nx, ny, nz = self.dims
+        n = nx * ny * nz
+        dx, dy, dz = self._cell_sizes()
+        if self.has("TOPS"):
+            t = self.array("TOPS")
+            top = t[:nx * ny].reshape(ny, nx) if t.size >= nx * ny else np.full((ny, nx), t[0])
+        elif self.has("DEPTHZ"):
+            top = np.full((ny, nx), self.array("DEPTHZ")[0])
+        else:
+            top = np.zeros((ny, nx))
+        ztop = top[None, :, :] + np.concatenate([np.zeros((1, ny, nx)), np.cumsum(dz, axis=0)[:-1]], axis=0)
+        zc = (ztop + 0.5 * dz).ravel()
+        poro = self.array("PORO", n, np.full(n, 0.0))
+        ntg = self.array("NTG", n, np.ones(n))
+        kx = self.array("PERMX", n, np.zeros(n)) * MD
+        ky = self.array("PERMY", n, kx / MD) * MD
+        kz = self.array("PERMZ", n, kx / MD) * MD
+        multpv = self.array("MULTPV", n, np.ones(n))
+        act = self.array("ACTNUM", n, np.ones(n)) > 0
+        vol = (dx * dy * dz).ravel()
+        pv = poro * ntg * multpv * vol
+        act &= pv > 0.0                                            # MINPV-free: cells without pore volume are inactive
+        idx = np.arange(n).reshape(nz, ny, nx)
+        dxr, dyr, dzr = dx.ravel(), dy.ravel(), dz.ravel()
+
+        def faces(a, b, kperm, area_a, area_b, da, db, horiz, mult):
+            a, b = a.ravel(), b.ravel()
+            h1 = kperm[a] * area_a[a] / (da[a] / 2.0); h2 = kperm[b] * area_b[b] / (db[b] / 2.0)
+            if horiz:
+                h1, h2 = h1 * ntg[a], h2 * ntg[b]
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t = 1.0 / (1.0 / h1 + 1.0 / h2)
+            t = np.where(np.isfinite(t), t, 0.0)
+            if mult is not None:
+                t = t * mult[a]                                    # MULTX applies to the face towards +x of the cell it is given for
+            return np.stack([a, b], 1), t
+        ayz, axz, axy = dyr * dzr, dxr * dzr, dxr * dyr
+        cx, tx = faces(idx[:, :, :-1], idx[:, :, 1:], kx, ayz, ayz, dxr, dxr, True, self.array("MULTX", n))
+        cy, ty = faces(idx[:, :-1, :], idx[:, 1:, :], ky, axz, axz, dyr, dyr, True, self.array("MULTY", n))
+        cz, tz = faces(idx[:-1, :, :], idx[1:, :, :], kz, axy, axy, dzr, dzr, False, self.array("MULTZ", n))
+        conn = np.concatenate([cx, cy, cz]); trans = np.concatenate([tx, ty, tz])
+        if self.has("NNC"):
+            for r in self.records("NNC"):
+                if not r:
+                    continue
+                c1 = int(r[0]) - 1 + nx * (int(r[1]) - 1) + nx * ny * (int(r[2]) - 1)
+                c2 = int(r[3]) - 1 + nx * (int(r[4]) - 1) + nx * ny * (int(r[5]) - 1)
+                conn = np.concatenate([conn, [[c1, c2]]]); trans = np.concatenate([trans, [r[6] * decks.CP * 1.0 / (DAY * BAR)]])
+        newid = -np.ones(n, dtype=np.int64); newid[act] = np.arange(int(act.sum()))
+        keep = act[conn[:, 0]] & act[conn[:, 1]] & (trans > 0.0)
+        conn = newid[conn[keep]]; trans = trans[keep]
+        self.active = np.flatnonzero(act)
+        reg = lambda name: None if not self.has(name) else (self.array(name, n)[act].astype(np.int32) - 1)
+        eps = self.endpoints()
+        if eps is not None:
+            eps = {k: v[act] for k, v in eps.items()}
+        return GridData(int(act.sum()), conn, trans, pv[act], zc[act], gravity=gravity, pvtnum=reg("PVTNUM"), satnum=reg("SATNUM"),
+                        dims=(nx, ny, nz) if act.all() else None, eps=eps)
+
+    def endpoints(self):
+        """ENDSCALE: per-cell scaled end points; the ones the deck does not give default to the cell's table values
+        (EclEpsScalingPointsInfo::extractScaled falls back to the unscaled points)."""
+        if not self.has("ENDSCALE"):
+            return None
+        if self.has("SCALECRS") and str(self.records("SCALECRS")[0][0]).upper().startswith("Y"):
+            raise ValueError("three-point end-point scaling (SCALECRS YES) is not supported")
+        nx, ny, nz = self.dims
+        n = nx * ny * nz
+        t = self.tables()
+        sat = (self.array("SATNUM", n).astype(int) - 1) if self.has("SATNUM") else np.zeros(n, int)
+        un = np.zeros((t.n_sat, 8))
+        for r in range(t.n_sat):
+            a, b = t.swof_ptr[r], t.swof_ptr[r + 1]
+            sw, krw, krow = t.swof_sw[a:b], t.swof_krw[a:b], t.swof_krow[a:b]
+            a, b = t.sgof_ptr[r], t.sgof_ptr[r + 1]
+            sg, krg, krog = t.sgof_sg[a:b], t.sgof_krg[a:b], t.sgof_krog[a:b]
+            un[r] = [sw[0], last_zero(sw, krw), sw[-1], 1.0 - first_zero(sw, krow), sg[0], last_zero(sg, krg), sg[-1], 1.0 - first_zero(sg, krog)]
+        out = {}
+        for k, name in enumerate(EPS_NAMES):
+            a = self.array(name, n, None)
+            dflt = un[sat, k]
+            out[name] = dflt if a is None else np.where(np.isnan(a), dflt, a)
+        return out
+
+    # ---------------------------------------------------------------- SOLUTION
+    def initial_state(self, tables):
+        """explicit PRESSURE / SWAT / SGAS / RS / RV arrays (active cells); hydrocarbon state from the saturations"""
+        nx, ny, nz = self.dims
+        n = nx * ny * nz
+        act = self.active
+        p = self.array("PRESSURE", n)[act] * BAR
+        sw = self.array("SWAT", n, np.zeros(n))[act]; sg = self.array("SGAS", n, np.zeros(n))[act]
+        rs = self.array("RS", n, np.zeros(n))[act]; rv = self.array("RV", n, np.zeros(n))[act]
+        sat = np.stack([sw, 1.0 - sw - sg, sg], 1)
+        from . import capi
+        hc = np.where(sg > 0, np.where(sat[:, 1] > 0, capi.HC_GAS_AND_OIL, capi.HC_GAS_ONLY), capi.HC_OIL_ONLY).astype(np.int8)
+        if not tables.has_disgas:
+            hc[hc == capi.HC_OIL_ONLY] = capi.HC_GAS_AND_OIL
+        return State(p, sat, rs, rv, hc)
+
+
+def last_zero(x, y):
+    """abscissa of the last leading zero of y (critical saturation: the curve leaves zero after it)"""
+    i = 0
+    while i + 1 < len(y) and y[i + 1] == 0.0:
+        i += 1
+    return x[i]
+
+
+def first_zero(x, y):
+    i = 0
+    while i < len(y) - 1 and y[i] != 0.0:
+        i += 1
+    return x[i]
+
+
+def _split_tables(records):
+    """PVTO / PVTG: records of one table are closed by an empty record"""
+    tabs, cur = [], []
+    for r in records:
+        if len(r) == 0:
+            if cur:
+                tabs.append(cur)
+            cur = []
+        else:
+            cur.append(r)
+    if cur:
+        tabs.append(cur)
+    return tabs
+
+
+def read_deck(path):
+    text = open(path).read()
+    lines = _tokens(text)
+    kws, cur, open_record = {}, None, False
+    box = None
+    skip_line = False
+    for toks in lines:
+        if not toks:
+            continue
+        if skip_line:                 # TITLE: the next line is free text without a terminating slash
+            skip_line = False
+            continue
+        first = toks[0]
+        expects_data = cur is not None and not cur["closed"] and not cur["records"] and not cur["pending"]   # e.g. SCALECRS \n NO /
+        if not open_record and not expects_data and _KW.match(first) and not _is_data(first):
+            name = first
+            cur = {"records": [], "pending": [], "closed": False, "box": box}
+            if name == "ENDBOX":
+                box = None
+            kws[name] = cur
+            toks = toks[1:]
+            if name == "TITLE":
+                cur["closed"] = True
+                skip_line = True
+                continue
+            if name in FLAG_KEYWORDS:
+                cur["closed"] = True
+                continue
+        if cur is None:
+            continue
+        for t in toks:
+            if t == "/":
+                cur["records"].append(cur["pending"]); cur["pending"] = []
+                open_record = False
+            else:
+                cur["pending"].extend(_expand(t))
+                open_record = True
+    return Deck(kws)
+
+
+def _is_data(tok):
+    try:
+        float(tok.replace("D", "E"))
+        return True
+    except ValueError:
+        return False

@@ -282,10 +282,16 @@ def test_endscale_known_answers_on_device(gpu_lib):
     import os
     G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "satfunc_eps.json")))["cases"]
     A, B = G["GwsegEPS_A"], G["GwsegEPSBase"]
-    tab = decks.satfunc_standard_tables(pc_scale=0.0)
+    # tables, column grid and per-cell end points straight from the reference's deck file (fixture copy), capillary pressure zeroed
+    from opmgpu import deck
+    d = deck.read_deck(os.path.join(os.path.dirname(__file__), "golden", "decks", "satfuncEPS_A.DATA"))
+    tab = d.tables()
+    tab.swof_pcow[:] = 0.0; tab.sgof_pcgo[:] = 0.0
+    full = d.grid()
     g0 = decks.cartesian_grid(1, 1, 8)
-    eps = {"SWL": 0.1, "SWCR": 0.2, "SWU": 0.9, "SOWCR": 0.2, "SGL": 0.0, "SGCR": 0.1, "SGU": 0.9, "SOGCR": 0.2}
-    eps.update({k: np.asarray(v, float)[:8] for k, v in A["endpoints"].items()})
+    eps = {k: full.eps[i][:8] for i, k in enumerate(decks.GridData.EPS_NAMES)}
+    for k, v in A["endpoints"].items():
+        assert np.array_equal(eps[k], np.asarray(v, float)[:8]), k
     wells = (np.array([0, 8], np.int32), np.arange(8, dtype=np.int32))
     prm = capi.default_params()
 
