@@ -46,6 +46,7 @@ def main():
                     help="N > 1: weak = every GPU keeps an nx x ny x nz slab (global deck nx x ny x nz*N, sized for 288 GB/GPU); strong = the fixed nx x ny x nz deck is cut into N slabs")
     ap.add_argument("--wells", choices=["none", "fivespot"], default="none",
                     help="fivespot: SURVEY 8d synthetic wells (1 rate-controlled water injector + 4 BHP producers, full columns) with the device well model; single GPU only")
+    ap.add_argument("--only-main", action="store_true", help="skip the same-run ILU0 / 5-spot variants and the roofline micro-runs (profiling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="take the domain-decomposition code path (torch.distributed + RCCL communicator) even with one rank")
     ap.add_argument("--cpu-threads", type=int, default=1)
@@ -139,7 +140,7 @@ def main():
     # the same K iterations with the reference's DEFAULT linear solver (solver_approach=interleaved: ILU0 + BiCGStab),
     # which is also what the CPU baseline runs
     ilu0 = None
-    if not use_dist and prm.use_cpr:
+    if not use_dist and prm.use_cpr and not args.only_main:
         prm0 = capi.default_params(ilu_ordering=ordering, use_cpr=0)
         m0 = GpuBlackoilModel(grid, tab, prm0, device=local_rank)
         r0 = timed_run(m0)
@@ -149,7 +150,7 @@ def main():
 
     # ... and with the SURVEY 8d 5-spot (device well model), unless that already is the main run
     fivespot = None
-    if not use_dist and args.wells == "none":
+    if not use_dist and args.wells == "none" and not args.only_main:
         m1 = GpuBlackoilModel(grid, tab, prm, device=local_rank)
         r1 = timed_run(m1, wells="fivespot")
         m1.close()

@@ -186,6 +186,12 @@ int opmgpu_add_well_rhs(opmgpu_ctx* ctx, const double* rhs_delta /*nperf*3*/);
  * out[nperf*3] = dP, dSw, dXvar per perforation. */
 int opmgpu_perf_dx(opmgpu_ctx* ctx, double* out);
 
+/* Precision of the coming opmgpu_solve, known before the assembly like the reference's residual_.singlePrecision = dt <
+ * maxSinglePrecisionTimeStep (BlackoilModelBase_impl.hpp:284).  With single_precision != 0 the next opmgpu_assemble writes
+ * the Jacobian as float directly (no f64 copy, no conversion pass; opmgpu_get_jacobian_bsr then returns the float values
+ * widened, and a double solve after such an assembly works on the widened values).  Default 0 = double. */
+int opmgpu_set_solve_precision(opmgpu_ctx* ctx, int single_precision);
+
 /* getConvergence / convergenceReduction (BlackoilModelBase_impl.hpp:1633-1857) for the reservoir
  * equations: B_avg, CNV, MB per phase plus the L-inf residual norms of computeResidualNorms
  * (:1551-1589).  *converged = all MB < tol_mb && all CNV < tol_cnv.  Returns OPMGPU_ENUMERICAL

@@ -286,6 +286,7 @@ __device__ __forceinline__ void st4(double* __restrict__ props, int plane, long 
     props[long(plane + 2) * nbp + row] = a.w; props[long(plane + 3) * nbp + row] = a.x;
 }
 
+template <class MS>
 __global__ __launch_bounds__(kBlock) void k_cell_props(int nb, int nbp, opmgpu_tables T, const int32_t* __restrict__ pvtnum,
                                                        const int32_t* __restrict__ satnum, const double* __restrict__ pv,
                                                        const double* __restrict__ p, const double* __restrict__ sw, const double* __restrict__ sg,
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(kBlock) void k_cell_props(int nb, int nbp, opmgpu_t
                                                        const double* __restrict__ eps, const double* __restrict__ eps_u0,
                                                        const double* __restrict__ somax,
                                                        double* __restrict__ props, double* __restrict__ accum0, double* __restrict__ R,
-                                                       double* __restrict__ binv, double* __restrict__ A)
+                                                       double* __restrict__ binv, MS* __restrict__ A)
 {
     const int row = blockIdx.x * kBlock + threadIdx.x;
     if (row >= nb) return;
@@ -315,15 +316,15 @@ __global__ __launch_bounds__(kBlock) void k_cell_props(int nb, int nbp, opmgpu_t
     // accumulation term pvdt * (accum1 - accum0) and its diagonal-block contribution
     const double pvdt = pv[row] * inv_dt;
     const double scale[3] = { s0, s1, s2 };
-    double* d = A + long(slice_ptr[row >> 6] + nlower[row]) * 576 + (row & 63);
+    MS* d = A + long(slice_ptr[row >> 6] + nlower[row]) * 576 + (row & 63);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         if (initial) accum0[long(a) * nbp + row] = q.accum[a].v;
         const double a0 = initial ? q.accum[a].v : accum0[long(a) * nbp + row];
         R[long(a) * nbp + row] = pvdt * (q.accum[a].v - a0);
-        d[(3 * a) * 64] = scale[a] * pvdt * q.accum[a].p;
-        d[(3 * a + 1) * 64] = scale[a] * pvdt * q.accum[a].w;
-        d[(3 * a + 2) * 64] = scale[a] * pvdt * q.accum[a].x;
+        d[(3 * a) * 64] = MS(scale[a] * pvdt * q.accum[a].p);
+        d[(3 * a + 1) * 64] = MS(scale[a] * pvdt * q.accum[a].w);
+        d[(3 * a + 2) * 64] = MS(scale[a] * pvdt * q.accum[a].x);
     }
 }
 
@@ -348,13 +349,14 @@ __device__ __forceinline__ V4 load4(const double* __restrict__ props, int plane,
 // TPFA flux residual + 3x3 Jacobian blocks, one thread per row
 // (computeMassFlux :1484-1512, applyThresholdPressures :1518-1545, UpwindSelector AutoDiffHelpers.hpp:204-221,
 //  rs/rv cross terms :889-906, div = ngrad^T)
+template <class MS>
 __global__ __launch_bounds__(kBlock) void k_flux(int xm, int nb, int nbp, const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
                                                  const int16_t* __restrict__ rowlen, const int16_t* __restrict__ nlower,
                                                  const int32_t* __restrict__ conn_code, const double* __restrict__ trans,
                                                  const double* __restrict__ gdz, const double* __restrict__ thpres,
                                                  const double* __restrict__ pstate, const double* __restrict__ props,
                                                  double s0, double s1, double s2, const int8_t* __restrict__ mask,
-                                                 double* __restrict__ R, double* __restrict__ A)
+                                                 double* __restrict__ R, MS* __restrict__ A)
 {
     const int nchunks = (nb + kBlock - 1) / kBlock;
     const int ch = xcd_first(nchunks, xm);
@@ -365,9 +367,9 @@ __global__ __launch_bounds__(kBlock) void k_flux(int xm, int nb, int nbp, const 
     if (mask && !mask[row]) {
         // ghost row (multi-GPU): identity block, zero residual -- the owner rank assembles the real equation
         for (int k = 0; k < len; ++k) {
-            double* bptr = A + long(base + k) * 576 + lane;
+            MS* bptr = A + long(base + k) * 576 + lane;
 #pragma unroll
-            for (int q = 0; q < 9; ++q) bptr[q * 64] = (k == nl && (q == 0 || q == 4 || q == 8)) ? 1.0 : 0.0;
+            for (int q = 0; q < 9; ++q) bptr[q * 64] = (k == nl && (q == 0 || q == 4 || q == 8)) ? MS(1) : MS(0);
         }
         R[row] = 0.0; R[nbp + row] = 0.0; R[2 * long(nbp) + row] = 0.0;
         return;
@@ -375,17 +377,17 @@ __global__ __launch_bounds__(kBlock) void k_flux(int xm, int nb, int nbp, const 
     const double scale[3] = { s0, s1, s2 };
     double Rl[3] = { R[row], R[nbp + row], R[2 * long(nbp) + row] };
     double D[9];
-    double* dptr = A + long(base + nl) * 576 + lane;
+    MS* dptr = A + long(base + nl) * 576 + lane;
 #pragma unroll
-    for (int q = 0; q < 9; ++q) D[q] = dptr[q * 64];
+    for (int q = 0; q < 9; ++q) D[q] = double(dptr[q * 64]);
     for (int k = 0; k < len; ++k) {
         if (k == nl) continue;
         const long e = long(base + k) * 64 + lane;
         const int code = conn_code[e];
-        double* bptr = A + long(base + k) * 576 + lane;
+        MS* bptr = A + long(base + k) * 576 + lane;
         if (code < 0) {          // pure well fill: the host adds the Schur block later
 #pragma unroll
-            for (int q = 0; q < 9; ++q) bptr[q * 64] = 0.0;
+            for (int q = 0; q < 9; ++q) bptr[q * 64] = MS(0);
             continue;
         }
         const int nbr = col[e];
@@ -444,12 +446,12 @@ __global__ __launch_bounds__(kBlock) void k_flux(int xm, int nb, int nbp, const 
                 const double own = side ? dG2[a][v] : dG1[a][v];
                 const double oth = side ? dG1[a][v] : dG2[a][v];
                 D[3 * a + v] += s * scale[a] * own;
-                bptr[(3 * a + v) * 64] = s * scale[a] * oth;
+                bptr[(3 * a + v) * 64] = MS(s * scale[a] * oth);
             }
         }
     }
 #pragma unroll
-    for (int q = 0; q < 9; ++q) dptr[q * 64] = D[q];
+    for (int q = 0; q < 9; ++q) dptr[q * 64] = MS(D[q]);
     R[row] = Rl[0]; R[nbp + row] = Rl[1]; R[2 * long(nbp) + row] = Rl[2];
 }
 
@@ -489,18 +491,17 @@ __global__ __launch_bounds__(kBlock) void k_conv_partial(int nb, int nbp, const 
 }
 __global__ __launch_bounds__(kBlock) void k_conv_final(int nblocks, const double* __restrict__ part, double* __restrict__ out)
 {
+    // one workgroup per scalar (13 of them), fixed order within each
     __shared__ double sm[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int q = 0; q < 13; ++q) {
-        const bool is_max = conv_is_max(q);
-        double v = 0.0;
-        for (int i = threadIdx.x; i < nblocks; i += kBlock) { const double x = part[long(q) * nblocks + i]; v = is_max ? fmax(v, x) : v + x; }
-        const double s = is_max ? wave_max(v) : wave_sum(v);
-        __syncthreads();
-        if (lane == 0) sm[w] = s;
-        __syncthreads();
-        if (threadIdx.x == 0) out[q] = is_max ? fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3])) : (sm[0] + sm[1]) + (sm[2] + sm[3]);
-    }
+    const int q = blockIdx.x;
+    const bool is_max = conv_is_max(q);
+    double v = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += kBlock) { const double x = part[long(q) * nblocks + i]; v = is_max ? fmax(v, x) : v + x; }
+    const double s_ = is_max ? wave_max(v) : wave_sum(v);
+    if (lane == 0) sm[w] = s_;
+    __syncthreads();
+    if (threadIdx.x == 0) out[q] = is_max ? fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3])) : (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 
 // updateState (BlackoilModelBase_impl.hpp:1147-1389), one thread per cell
@@ -871,19 +872,29 @@ void BlackoilDevice::get_state(double* p, double* sat, double* rs, double* rv, i
     }
 }
 
-void BlackoilDevice::assemble(double dt, bool initial)
+template <class MS> void BlackoilDevice::assemble_kernels(double dt, bool initial, MS* A)
 {
     const Plan& P = ls.plan;
+    const double* sc = prm.matbalscale;
+    hipLaunchKernelGGL((k_cell_props<MS>), dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_pv.p,
+                       d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, 1.0 / dt, int(initial), sc[0], sc[1], sc[2],
+                       ls.dp.slice_ptr.p, ls.dp.nlower.p, eps_planes(), d_eps_u0.p, d_somax.p, d_props.p, d_accum0.p, d_R.p, d_binv.p, A);
+    hipLaunchKernelGGL((k_flux<MS>), dim3(grid8_for(nc)), dim3(kBlock), 0, stream, xcd_mode(), nc, P.nbp, ls.dp.slice_ptr.p, ls.dp.col.p, ls.dp.rowlen.p,
+                       ls.dp.nlower.p, d_conn_code.p, d_trans.p, d_gdz.p, use_thpres ? d_thpres.p : (const double*)nullptr,
+                       d_p.p, d_props.p, sc[0], sc[1], sc[2], ls.comm ? ls.comm->owner_mask() : (const int8_t*)nullptr, d_R.p, A);
+}
+
+// The Jacobian is written in the precision of the coming solve (opmgpu_set_solve_precision): float saves the f64 -> f32 copy
+// of the whole matrix and half of the assembly's write traffic.  The host-well path adds f64 blocks, so it keeps the double matrix.
+void BlackoilDevice::assemble(double dt, bool initial)
+{
     last_dt = dt;
     has_rhs_extra = false;
     if (initial) d_dx_old.zero(stream);
-    const double* sc = prm.matbalscale;
-    hipLaunchKernelGGL(k_cell_props, dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_pv.p,
-                       d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, 1.0 / dt, int(initial), sc[0], sc[1], sc[2],
-                       ls.dp.slice_ptr.p, ls.dp.nlower.p, eps_planes(), d_eps_u0.p, d_somax.p, d_props.p, d_accum0.p, d_R.p, d_binv.p, ls.matrix_d());
-    hipLaunchKernelGGL(k_flux, dim3(grid8_for(nc)), dim3(kBlock), 0, stream, xcd_mode(), nc, P.nbp, ls.dp.slice_ptr.p, ls.dp.col.p, ls.dp.rowlen.p,
-                       ls.dp.nlower.p, d_conn_code.p, d_trans.p, d_gdz.p, use_thpres ? d_thpres.p : (const double*)nullptr,
-                       d_p.p, d_props.p, sc[0], sc[1], sc[2], ls.comm ? ls.comm->owner_mask() : (const int8_t*)nullptr, d_R.p, ls.matrix_d());
+    const bool host_wells = nperf > 0 && !device_wells;
+    ls.matrix_is_float = assemble_single && !host_wells;
+    if (ls.matrix_is_float) assemble_kernels<float>(dt, initial, ls.matrix_f());
+    else assemble_kernels<double>(dt, initial, ls.matrix_d());
     wells_assemble(initial);
 }
 
@@ -896,7 +907,7 @@ double BlackoilDevice::time_assemble(int reps, int props_only)
     OPMGPU_HIP(hipEventCreate(&e0)); OPMGPU_HIP(hipEventCreate(&e1));
     auto launch = [&]() {
         if (props_only)
-            hipLaunchKernelGGL(k_cell_props, dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_pv.p,
+            hipLaunchKernelGGL((k_cell_props<double>), dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_pv.p,
                                d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, 1.0 / dt, 0, sc[0], sc[1], sc[2],
                                ls.dp.slice_ptr.p, ls.dp.nlower.p, eps_planes(), d_eps_u0.p, d_somax.p, d_props.p, d_accum0.p, d_R.p, d_binv.p, ls.matrix_d());
         else assemble(dt, false);
@@ -918,7 +929,7 @@ int BlackoilDevice::convergence(double dt, double* B3, double* CNV3, double* MB3
     const int g = std::min(grid_for(nc), kMaxRedBlocks);
     const int8_t* mask = ls.comm ? ls.comm->owner_mask() : nullptr;
     hipLaunchKernelGGL(k_conv_partial, dim3(g), dim3(kBlock), 0, stream, nc, P.nbp, d_R.p, d_binv.p, d_pv.p, mask, d_red.p + 16);
-    hipLaunchKernelGGL(k_conv_final, dim3(1), dim3(kBlock), 0, stream, g, d_red.p + 16, d_red.p);
+    hipLaunchKernelGGL(k_conv_final, dim3(13), dim3(kBlock), 0, stream, g, d_red.p + 16, d_red.p);
     if (ls.comm) { ls.comm->allreduce_sum(d_red.p, 7, stream); ls.comm->allreduce_max(d_red.p + 7, 6, stream); }
     OPMGPU_HIP(hipMemcpyAsync(h_red, d_red.p, 13 * sizeof(double), hipMemcpyDeviceToHost, stream));
     OPMGPU_HIP(hipStreamSynchronize(stream));

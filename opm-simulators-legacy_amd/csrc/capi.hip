@@ -172,6 +172,13 @@ int opmgpu_assemble(opmgpu_ctx* c, double dt, int initial, const double* p, cons
     });
 }
 
+int opmgpu_set_solve_precision(opmgpu_ctx* c, int single_precision)
+{
+    if (!c || !c->model) return OPMGPU_EINVAL;
+    c->model->assemble_single = single_precision != 0;
+    return OPMGPU_OK;
+}
+
 int opmgpu_perf_props(opmgpu_ctx* c, double* out)
 {
     if (!c || !c->model || !out) return OPMGPU_EINVAL;
@@ -421,7 +428,7 @@ int opmgpu_get_jacobian_bsr(opmgpu_ctx* c, int32_t* rowptr, int32_t* col, double
         const Plan& P = c->ls->plan;
         if (rowptr) std::memcpy(rowptr, P.rowptr.data(), sizeof(int32_t) * (P.nb + 1));
         if (col) std::memcpy(col, P.col.data(), sizeof(int32_t) * P.nnzb);
-        if (val9) c->ls->get_matrix_bsr(c->ls->matrix_d(), val9);
+        if (val9) { c->ls->widen_matrix(); c->ls->get_matrix_bsr(c->ls->matrix_d(), val9); }
         return OPMGPU_OK;
     });
 }

@@ -600,6 +600,7 @@ LinSolver::LinSolver(hipStream_t s) : stream(s)
     OPMGPU_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
     OPMGPU_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
     if (const char* e = std::getenv("OPMGPU_CLOSED")) closed_form_level0 = std::atoi(e) != 0;
+    if (const char* e = std::getenv("OPMGPU_CPR_SPECULATE")) cpr_speculate = std::atoi(e) != 0;
 }
 LinSolver::~LinSolver()
 {
@@ -646,16 +647,25 @@ template <class S> void LinSolver::ensure_work()
 
 void LinSolver::load_host_bsr(const double* val9)
 {
+    matrix_is_float = false;
     stage.ensure(std::max(size_t(plan.nnzb) * 9, size_t(3) * plan.nbp));
     OPMGPU_HIP(hipMemcpyAsync(stage.p, val9, size_t(plan.nnzb) * 9 * sizeof(double), hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(k_bsr_to_sell, dim3(grid_for(plan.nentries)), dim3(kBlock), 0, stream, plan.nentries, dp.src.p, stage.p, Ad.p);
 }
 
-template <> void LinSolver::prepare<double>(bool) { ensure_work<double>(); }
+float* LinSolver::matrix_f() { ensure_work<float>(); return wf.A.p; }
+void LinSolver::widen_matrix()
+{
+    if (!matrix_is_float) return;
+    const long n = long(plan.nentries) * 9;
+    hipLaunchKernelGGL((k_convert<float, double>), dim3(std::min(grid_for(n), kMaxRedBlocks)), dim3(kBlock), 0, stream, n, (const float*)wf.A.p, Ad.p);
+    matrix_is_float = false;
+}
+template <> void LinSolver::prepare<double>(bool) { ensure_work<double>(); widen_matrix(); }
 template <> void LinSolver::prepare<float>(bool matrix_changed)
 {
     ensure_work<float>();
-    if (!matrix_changed) return;
+    if (!matrix_changed || matrix_is_float) return;
     const long n = long(plan.nentries) * 9;
     hipLaunchKernelGGL((k_convert<double, float>), dim3(std::min(grid_for(n), kMaxRedBlocks)), dim3(kBlock), 0, stream, n, Ad.p, wf.A.p);
 }
@@ -829,7 +839,7 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
         a_n2 = P_n2; a_rho = P_rho; np_n2 = gv;
         bridge(a_n2, a_rho, np_n2, 5);
         last = j;
-        if (cpr) {
+        if (cpr && !cpr_speculate) {
             // CPR iterations are long (~0.6 ms of kernels) and few (~5): a speculative extra iteration of ~50 no-op
             // launches costs more than one host round trip, so test convergence at the END of the iteration and wait.
             hipLaunchKernelGGL(k_final_check, dim3(1), dim3(kBlock), 0, stream, j, d_ctl, h_ctl_dev, (const double*)a_n2, np_n2);

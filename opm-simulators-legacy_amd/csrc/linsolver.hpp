@@ -84,6 +84,9 @@ public:
     // matrix values: from a host BSR (B1) -- the assembly kernels write Ad directly (B2)
     void load_host_bsr(const double* val9);
     double* matrix_d() { return Ad.p; }
+    float* matrix_f();                 // float matrix buffer (allocates the float work set on first use)
+    bool matrix_is_float = false;      // the current matrix values live in the float buffer only (assembled for a float solve)
+    void widen_matrix();               // float buffer -> double buffer (getters, or a double solve after a float assembly)
     void zero_matrix() { Ad.zero(stream); }
     // make the matrix available in precision S (float: converts Ad -> wf.A)
     template <class S> void prepare(bool matrix_changed = true);
@@ -131,6 +134,7 @@ public:
     LowRankOp lowrank;             // nw == 0: none
     template <class S> void lowrank_reduce(const S* x, const SolveCtl* ctl);
     bool closed_form_level0 = true; // k_spmv shortcut on level-0 rows (A/B switch: OPMGPU_CLOSED=0)
+    bool cpr_speculate = false;     // CPR: enqueue the next iteration before the convergence result is known (A/B: OPMGPU_CPR_SPECULATE=1)
     hipEvent_t ev[2] = { nullptr, nullptr };
 
 private:

@@ -127,8 +127,9 @@ __device__ bool inv4(const double* m, double* out)
 }
 
 // well equations + reduced (Schur) contributions of one well per workgroup
+template <class MS>
 __global__ __launch_bounds__(kBlock) void k_well_assemble(WellArgs A, const int32_t* __restrict__ slice_ptr, const int16_t* __restrict__ nlower,
-                                                          double s0, double s1, double s2, double* __restrict__ R, double* __restrict__ Amat,
+                                                          double s0, double s1, double s2, double* __restrict__ R, MS* __restrict__ Amat,
                                                           double* __restrict__ rhs_extra, int32_t* __restrict__ flags)
 {
     __shared__ double sm[64];
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void k_well_assemble(WellArgs A, const int3
         Du<7> cq_s[3];
         for (int a = 0; a < 3; ++a) cq_s[a] = f.cq_ps[a] + cm[a] * cqt_is;                                          // :553-560
         const int row = A.perf_row[j];
-        double* dptr = Amat + long(slice_ptr[row >> 6] + nlower[row]) * 576 + (row & 63);
+        MS* dptr = Amat + long(slice_ptr[row >> 6] + nlower[row]) * 576 + (row & 63);
         double* Pj = A.P + 21 * long(j); double* Qj = A.Q + 21 * long(j); double* Fs = A.Fsave + 21 * long(j);
         // H = d cq_ps / d cell, G = d cmix / d cell = (-H + cmix (1^T H)) / wbqt
         for (int v = 0; v < 3; ++v) {
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(kBlock) void k_well_assemble(WellArgs A, const int3
             acc2[12 + a] += cq_s[a].d[3];
             Fs[18 + a] = cq_s[a].d[3];
             for (int v = 0; v < 3; ++v) {
-                dptr[(3 * a + v) * 64] -= scale[a] * cq_s[a].d[v];                    // own-cell part of -d cq_s / d cell
+                dptr[(3 * a + v) * 64] = MS(double(dptr[(3 * a + v) * 64]) - scale[a] * cq_s[a].d[v]);    // own-cell part of -d cq_s / d cell
                 Fs[3 * a + v] = cq_s[a].d[v];
                 Fs[9 + 3 * a + v] = cq_s[a].d[4 + v];
                 acc2[3 + 3 * a + v] += cq_s[a].d[4 + v];
@@ -453,8 +454,12 @@ void BlackoilDevice::wells_assemble(bool initial)
         hipLaunchKernelGGL(k_well_cdp, dim3((W.nw + 63) / 64), dim3(64), 0, stream, W.nw, A, gravity);
     d_rhs_extra.zero(stream);
     const double* sc = prm.matbalscale;
-    hipLaunchKernelGGL(k_well_assemble, dim3(W.nw), dim3(kBlock), 0, stream, A, ls.dp.slice_ptr.p, ls.dp.nlower.p, sc[0], sc[1], sc[2], d_R.p,
-                       ls.matrix_d(), d_rhs_extra.p, W.flags.p);
+    if (ls.matrix_is_float)
+        hipLaunchKernelGGL((k_well_assemble<float>), dim3(W.nw), dim3(kBlock), 0, stream, A, ls.dp.slice_ptr.p, ls.dp.nlower.p, sc[0], sc[1], sc[2], d_R.p,
+                           ls.matrix_f(), d_rhs_extra.p, W.flags.p);
+    else
+        hipLaunchKernelGGL((k_well_assemble<double>), dim3(W.nw), dim3(kBlock), 0, stream, A, ls.dp.slice_ptr.p, ls.dp.nlower.p, sc[0], sc[1], sc[2], d_R.p,
+                           ls.matrix_d(), d_rhs_extra.p, W.flags.p);
     has_rhs_extra = true;
 }
 

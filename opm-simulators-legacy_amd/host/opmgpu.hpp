@@ -154,6 +154,7 @@ public:
     bool nonlinearIteration(int iteration, const NonlinearSolverType& nonlinear_solver)
     {
         if (iteration == 0) { residual_norms_history_.clear(); current_relaxation_ = 1.0; }    // dx_old is zeroed by the initial assembly
+        throw_on_status(ctx_, opmgpu_set_solve_precision(ctx_, dt_ < max_single_precision_days_ * 86400.0 ? 1 : 0));   // :284, before the assembly
         assemble(iteration == 0);
         ConvergenceReport r = getConvergence();
         r.converged = wellsConverged(r) && r.converged;

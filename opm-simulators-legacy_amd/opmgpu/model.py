@@ -226,6 +226,13 @@ class GpuBlackoilModel:
         self._chk(self.lib.opmgpu_get_sat_oil_max(self.ctx, capi.dptr(out)))
         return out
 
+    def setSolvePrecision(self, single_precision=None):
+        """residual_.singlePrecision = dt < maxSinglePrecisionTimeStep (:284), told to the device BEFORE the assembly so that
+        the Jacobian is written in the solve's precision."""
+        if single_precision is None:
+            single_precision = self.dt < self.max_single_precision_days * 86400.0
+        self._chk(self.lib.opmgpu_set_solve_precision(self.ctx, int(bool(single_precision))))
+
     def stabilizeUpdate(self, relax_type, omega):
         self._chk(self.lib.opmgpu_stabilize_update(self.ctx, int(relax_type), float(omega)))
 
@@ -235,6 +242,7 @@ class GpuBlackoilModel:
         ns = nonlinear_solver
         if iteration == 0:
             self.residual_norms_history, self.current_relaxation = [], 1.0
+        self.setSolvePrecision(single_precision)
         self.assemble(iteration == 0)
         converged = self.getConvergence()
         self.residual_norms_history.append(list(self.linf))          # computeResidualNorms (:1551-1589)

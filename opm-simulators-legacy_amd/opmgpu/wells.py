@@ -390,6 +390,7 @@ class DeviceWellModel:
 
     def nonlinearIteration(self, iteration, single_precision=None, nonlinear_solver=None):
         m = self.m
+        m.setSolvePrecision(single_precision)
         m.assemble(iteration == 0)                      # reservoir + wells, connection pressures at iteration 0
         converged = m.getConvergence()
         converged = self.wellConvergence() and converged

@@ -414,3 +414,46 @@ def test_vappars_rocktab_parity(gpu_lib, oracle):
             m.close()
     finally:
         oracle.set_sat_oil_max(None)
+
+
+def test_float_assembly_for_a_float_solve(gpu_lib, oracle):
+    """opmgpu_set_solve_precision(1): the Jacobian is written as float by the assembly kernels themselves (no f64 copy, no
+    conversion pass).  Values = the f64 Jacobian rounded to float; the residual stays f64; a Newton iteration through this
+    path lands where the f64-assembly + conversion path lands (same f32 system up to the rounding of the diagonal seed)."""
+    tab = decks.satfunc_standard_tables()
+    grid = decks.cartesian_grid(8, 7, 5, lognormal_sigma=0.6)
+    st = decks.initial_state(grid, tab, perturb=0.01)
+    prm = capi.default_params(linear_solver_reduction=1e-5, linear_solver_maxiter=300)
+    rowptr, col = oracle.pattern(grid)
+    dt = 5 * decks.DAY
+    r0, v0, _, _ = oracle.assemble(grid, tab, dt, st, rowptr, col, scale=tuple(prm.matbalscale))
+    a = GpuBlackoilModel(grid, tab, prm)
+    a.prepareStep(dt, st)
+    a.setSolvePrecision(True)
+    a.assemble(True)
+    _, _, va = a.jacobian()
+    assert rel_err(va, v0) < 2e-7 and np.abs(va - v0.astype(np.float32)).max() <= 2e-7 * np.abs(v0).max()
+    assert rel_err(a.residual(), r0) < RTOL_JAC
+    b = GpuBlackoilModel(grid, tab, prm)
+    b.prepareStep(dt, st)
+    b.setSolvePrecision(False)
+    b.assemble(True)
+    for m in (a, b):
+        m.getConvergence()
+        m.solveJacobianSystem(single_precision=True)
+        m.updateState()
+    sa, sb = a.getState(), b.getState()
+    assert np.array_equal(sa.hc, sb.hc)
+    # two f32 systems that differ by one rounding of the entries: the solutions differ by cond(A) * eps_f32 (the pressure level of
+    # a closed, nearly incompressible system is the badly conditioned mode) -- the same size as either one's distance to the f64 solve
+    c = GpuBlackoilModel(grid, tab, prm)
+    c.prepareStep(dt, st); c.assemble(True); c.getConvergence(); c.solveJacobianSystem(single_precision=False); c.updateState()
+    sc_ = c.getState()
+    c.close()
+    ea, eb = np.abs(sa.p - sc_.p).max(), np.abs(sb.p - sc_.p).max()
+    assert ea <= 5e-4 * np.abs(sc_.p).max() and ea <= 5.0 * max(eb, 1e-6 * np.abs(sc_.p).max()), (ea, eb)
+    assert np.abs(sa.sat - sc_.sat).max() <= 1e-4 and np.abs(sa.sat - sb.sat).max() <= 1e-4
+    # a double solve after a float assembly works on the widened values
+    a.setState(st); a.setSolvePrecision(True); a.assemble(True); a.getConvergence()
+    a.solveJacobianSystem(single_precision=False)
+    a.close(); b.close()

@@ -97,7 +97,7 @@ def test_device_wells_five_spot_vs_host_wells(gpu_lib, single):
     mh = W.WellCoupledModel(gh, W.StandardWellsHost(wl, grid.z, tab.surface_density[0]), W.WellState(wl, st.p))
     md = W.DeviceWellModel(gd, wl, W.WellState(wl, st.p))
     mh.prepareStep(dt, st); md.prepareStep(dt, st)
-    tol_p, tol_s = (2e-5, 2e-5) if single else (1e-6, 1e-6)
+    tol_p, tol_s = (1e-4, 1e-4) if single else (1e-6, 1e-6)        # f32: two different f32 systems (explicit clique vs factored operator, float assembly)
     for step in range(2):
         it = 0
         while True:
