@@ -2,11 +2,15 @@
 #include "plan.hpp"
 
 #include <algorithm>
+#include <cstdlib>
+#include <map>
 #include <numeric>
 
 #include "../../include/opmgpu.h"
 
 namespace opmgpu {
+
+constexpr int kDefaultZBlock = 1;      // plane-interleaving block of the intra-level row order (see build_plan)
 
 int build_reservoir_pattern(int nc, int nconn, const int32_t* conn_cells, int nw, const int32_t* well_connpos,
                             const int32_t* well_cells, std::vector<int32_t>& rowptr, std::vector<int32_t>& col,
@@ -46,6 +50,20 @@ int build_reservoir_pattern(int nc, int nconn, const int32_t* conn_cells, int nw
         rowptr[c + 1] = int32_t(col.size());
     }
     return OPMGPU_OK;
+}
+
+// Is the pattern the 7-point stencil of a full nx x ny x nz Cartesian box in natural (i fastest) order?  (all offsets in
+// {+-1, +-nx, +-nx*ny} with exactly the face counts of the box)
+static bool infer_cartesian_dims(int nb, const int32_t* rowptr, const int32_t* col, int& nx, int& ny, int& nz)
+{
+    std::map<int32_t, int64_t> cnt;
+    for (int i = 0; i < nb; ++i)
+        for (int s = rowptr[i]; s < rowptr[i + 1]; ++s) { const int d = col[s] - i; if (d > 0) { if (cnt.size() > 3 && !cnt.count(d)) return false; cnt[d]++; } }
+    if (cnt.size() != 3 || cnt.begin()->first != 1) return false;
+    auto it = cnt.begin(); ++it; const int a = it->first; ++it; const int b = it->first;
+    if (a <= 1 || b <= a || b % a != 0 || nb % b != 0) return false;
+    nx = a; ny = b / a; nz = nb / b;
+    return cnt[1] == int64_t(nx - 1) * ny * nz && cnt[a] == int64_t(nx) * (ny - 1) * nz && cnt[b] == int64_t(nx) * ny * (nz - 1);
 }
 
 int build_plan(int nb, const int32_t* rowptr, const int32_t* col, int ordering, Plan& P)
@@ -89,8 +107,25 @@ int build_plan(int nb, const int32_t* rowptr, const int32_t* col, int ordering, 
     // --- internal numbering: sort by (level, caller index).  (A/B on MI355X, 100^3: re-grouping the rows of a level
     // into compact BFS clusters of 512 / 4096 rows made SpMV 5-12 % and the assembly 30-45 % SLOWER than keeping the
     // caller's order inside a level -- the banded Cartesian order already keeps gathers within a few cache lines.)
+    // Rows of one level are mutually independent, so their order inside the level is free (speed only).  For a full Cartesian
+    // box the k-planes are interleaved line by line in blocks of B planes -- key ((k / B), j, (k % B), i) -- so that both the y- and
+    // (B - 1 of B) z-neighbours of a row sit a few lines away instead of a whole plane away: every per-wave gather stays a
+    // contiguous run, but its reuse distance shrinks from nx*ny to B*nx rows and fits the L2.  OPMGPU_ZBLOCK overrides B (1 = off).
     P.nat.resize(nb); std::iota(P.nat.begin(), P.nat.end(), 0);
-    std::stable_sort(P.nat.begin(), P.nat.end(), [&](int a, int b) { return lev[a] < lev[b]; });
+    std::vector<int64_t> lkey;
+    {
+        int B = kDefaultZBlock, nx = 0, ny = 0, nz = 0;
+        if (const char* e = std::getenv("OPMGPU_ZBLOCK")) B = std::atoi(e);
+        if (B > 1 && ordering == OPMGPU_ORDER_MULTICOLOR && infer_cartesian_dims(nb, rowptr, col, nx, ny, nz)) {
+            lkey.resize(nb);
+            for (int c = 0; c < nb; ++c) {
+                const int64_t i = c % nx, j = (c / nx) % ny, k = c / (int64_t(nx) * ny);
+                lkey[c] = (((k / B) * ny + j) * B + (k % B)) * nx + i;
+            }
+        }
+    }
+    if (lkey.empty()) std::stable_sort(P.nat.begin(), P.nat.end(), [&](int a, int b) { return lev[a] < lev[b]; });
+    else std::sort(P.nat.begin(), P.nat.end(), [&](int a, int b) { return lev[a] != lev[b] ? lev[a] < lev[b] : lkey[a] < lkey[b]; });
     P.pos.resize(nb);
     for (int r = 0; r < nb; ++r) P.pos[P.nat[r]] = r;
     P.level.resize(nb); P.nlevels = nlev; P.level_ptr.assign(nlev + 1, 0);

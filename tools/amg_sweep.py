@@ -22,18 +22,18 @@ def child(n, steps, warmup, sigma=0.5):
     dt = 5 * decks.DAY
     m = GpuBlackoilModel(grid, tab, capi.default_params(use_cpr=1))
     m.prepareStep(dt, st)
-    it, lin_total, t_sol, t0, nsteps = 0, 0, 0.0, None, 0
+    it, lin_total, t_sol, t_asm, t0, nsteps = 0, 0, 0.0, 0.0, None, 0
     for step in range(warmup + steps):
         if step == warmup:
-            torch.cuda.synchronize(); t0 = time.perf_counter(); lin_total = 0; t_sol = 0.0
+            torch.cuda.synchronize(); t0 = time.perf_counter(); lin_total = 0; t_sol = 0.0; t_asm = 0.0
         conv, lin = m.nonlinearIteration(it)
-        lin_total += lin; t_sol += m.timings()[1]
+        lin_total += lin; t_sol += m.timings()[1]; t_asm += m.timings()[0]
         it += 1
         if conv or it > 10:
             m.prepareStep(dt); it = 0; nsteps += 1
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    print(json.dumps({"ms_per_newton": 1e3 * el / steps, "solve_ms": t_sol / steps, "lin_per_newton": lin_total / steps, "time_steps": nsteps}))
+    print(json.dumps({"ms_per_newton": 1e3 * el / steps, "solve_ms": t_sol / steps, "assemble_ms": t_asm / steps, "lin_per_newton": lin_total / steps, "time_steps": nsteps}))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Tiny driver for PMC passes over the assembly kernels: a few assemblies of the bench deck, nothing else.
+   rocprofv3 --pmc <counters> --kernel-trace -d out -- python3 tools/pmc_assembly.py [n]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "opm-simulators-legacy_amd")); sys.path.insert(0, ROOT)
+import torch  # noqa: F401
+from opmgpu import capi, decks
+from opmgpu.model import GpuBlackoilModel
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+grid = decks.cartesian_grid(n, n, n, lognormal_sigma=0.5, seed=12345)
+tab = decks.satfunc_standard_tables()
+st = decks.initial_state(grid, tab, perturb=0.002, seed=12345)
+m = GpuBlackoilModel(grid, tab, capi.default_params())
+m.prepareStep(5 * decks.DAY, st)
+m.setSolvePrecision(True)
+for i in range(4):
+    m.assemble(i == 0)
+m.getConvergence()
+m.close()
