@@ -305,7 +305,9 @@ int opmgpu_get_jacobian_bsr(opmgpu_ctx* ctx, int32_t* rowptr, int32_t* col, doub
 /* timing of device work: runs `reps` launches of one kernel on the context's stream between two
  * hipEvents and returns the average milliseconds per launch (HIP events on the launch stream). */
 enum { OPMGPU_K_SPMV = 0, OPMGPU_K_ILU_APPLY = 1, OPMGPU_K_ILU_FACTOR = 2, OPMGPU_K_ASSEMBLE = 3,
-       OPMGPU_K_DOT = 4, OPMGPU_K_AXPY = 5, OPMGPU_K_PROPS = 6, OPMGPU_K_STREAM_COPY = 7 };
+       OPMGPU_K_DOT = 4, OPMGPU_K_AXPY = 5, OPMGPU_K_PROPS = 6, OPMGPU_K_STREAM_COPY = 7,
+       OPMGPU_K_CPR_APPLY = 8 /* whole two-stage preconditioner application */, OPMGPU_K_VCYCLE = 9 /* its AMG V-cycle alone */,
+       OPMGPU_K_CPR_SETUP = 10 /* pressure extraction + Galerkin + coarsest inverse */ };
 int opmgpu_time_kernel(opmgpu_ctx* ctx, int kernel, int reps, double* ms_per_launch);
 /* elapsed device milliseconds of the last assemble / solve / update_state call. */
 int opmgpu_last_timings(opmgpu_ctx* ctx, double* assemble_ms, double* solve_ms, double* update_ms);

@@ -120,7 +120,16 @@ __global__ __launch_bounds__(kBlock) void k_amg_galerkin(int nce, const int32_t*
     const int e = blockIdx.x * kBlock + threadIdx.x;
     if (e >= nce) return;
     double s = 0.0;
-    for (int q = cptr[e]; q < cptr[e + 1]; ++q) s += double(fine[cidx[q]]);
+    const int q0 = cptr[e], q1 = cptr[e + 1];
+    for (int q = q0; q < q1; q += 8) {          // fixed order; index loads, then gathers, of a batch in flight together
+        int id[8]; S v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) id[u] = q + u < q1 ? cidx[q + u] : -1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = id[u] >= 0 ? fine[id[u]] : S(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += double(v[u]);
+    }
     coarse[cdev[e]] = S(s);
 }
 template <class S>
@@ -186,15 +195,22 @@ __global__ __launch_bounds__(kBlock) void k_amg_smooth0_residual(int n, const in
     r[row] = b[row] - ax;
 }
 // MODE 0: r = b - A x ;  MODE 1: xout = x + omega D^-1 (b - A x)   (damped Jacobi sweep)
+// MODE 3: the same sweep on the prolongated iterate x + pdamp P xc, gathered on the fly (saves the prolongation launch)
 template <class S, int MODE>
 __global__ __launch_bounds__(kBlock) void k_amg_residual(int n, const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
                                                          const S* __restrict__ val, const S* __restrict__ b, const S* __restrict__ x,
-                                                         S omega, const S* __restrict__ dinv, S* __restrict__ out, const SolveCtl* __restrict__ ctl)
+                                                         S omega, const S* __restrict__ dinv, S* __restrict__ out, const SolveCtl* __restrict__ ctl,
+                                                         const int32_t* __restrict__ agg = nullptr, const S* __restrict__ xc = nullptr, S pdamp = S(0))
 {
     if (ctl && ctl->done) return;
     const int row = blockIdx.x * kBlock + threadIdx.x;
     if (row >= n) return;
     const int base = slice_ptr[row >> 6], width = slice_ptr[(row >> 6) + 1] - base, lane = row & 63;
+    if (MODE == 3) {
+        const S acc = b[row] - sell_row_dot<S>(val + long(base) * 64 + lane, col + long(base) * 64 + lane, width, [&](int j) { return x[j] + pdamp * xc[agg[j]]; });
+        out[row] = (x[row] + pdamp * xc[agg[row]]) + omega * dinv[row] * acc;
+        return;
+    }
     const S acc = b[row] - sell_row_dot<S>(val + long(base) * 64 + lane, col + long(base) * 64 + lane, width, [&](int j) { return x[j]; });
     out[row] = MODE == 0 ? acc : x[row] + omega * dinv[row] * acc;
 }
@@ -204,7 +220,8 @@ template <class S, int MODE>
 __global__ __launch_bounds__(kBlock) void k_amg_row_wave(int n, const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
                                                          const S* __restrict__ val, const S* __restrict__ b, const S* __restrict__ x,
                                                          S omega, const S* __restrict__ dinv, S* __restrict__ out, S* __restrict__ xout,
-                                                         const SolveCtl* __restrict__ ctl)
+                                                         const SolveCtl* __restrict__ ctl,
+                                                         const int32_t* __restrict__ agg = nullptr, const S* __restrict__ xc = nullptr, S pdamp = S(0))
 {
     if (ctl && ctl->done) return;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
@@ -214,7 +231,7 @@ __global__ __launch_bounds__(kBlock) void k_amg_row_wave(int n, const int32_t* _
     for (int k = l; k < width; k += 64) {
         const long e = long(base + k) * 64 + lane;
         const int j = col[e];
-        const S xj = MODE == 2 ? omega * dinv[j] * b[j] : x[j];
+        const S xj = MODE == 2 ? omega * dinv[j] * b[j] : (MODE == 3 ? x[j] + pdamp * xc[agg[j]] : x[j]);
         acc += double(val[e]) * double(xj);
     }
     acc = wave_sum(acc);
@@ -222,12 +239,14 @@ __global__ __launch_bounds__(kBlock) void k_amg_row_wave(int n, const int32_t* _
         const S res = b[row] - S(acc);
         if (MODE == 0) out[row] = res;
         else if (MODE == 1) out[row] = x[row] + omega * dinv[row] * res;
+        else if (MODE == 3) out[row] = (x[row] + pdamp * xc[agg[row]]) + omega * dinv[row] * res;
         else { out[row] = res; xout[row] = omega * dinv[row] * b[row]; }
     }
 }
 template <class S>
 __global__ __launch_bounds__(kBlock) void k_amg_restrict(int nc, const int32_t* __restrict__ aptr, const int32_t* __restrict__ arows,
-                                                         const S* __restrict__ r, S* __restrict__ bc, const SolveCtl* __restrict__ ctl)
+                                                         const S* __restrict__ r, S* __restrict__ bc, S omega, const S* __restrict__ dinv_c,
+                                                         S* __restrict__ xc, const SolveCtl* __restrict__ ctl)
 {
     if (ctl && ctl->done) return;
     const int I = blockIdx.x * kBlock + threadIdx.x;
@@ -244,6 +263,7 @@ __global__ __launch_bounds__(kBlock) void k_amg_restrict(int nc, const int32_t* 
         for (int u = 0; u < 8; ++u) s += vv[u];
     }
     bc[I] = s;
+    if (xc) xc[I] = omega * dinv_c[I] * s;      // the coarse level's first pre-smoothing sweep from a zero guess, fused
 }
 template <class S>
 __global__ __launch_bounds__(kBlock) void k_amg_prolong(int n, const int32_t* __restrict__ agg, const S* __restrict__ xc, S* __restrict__ x, S pdamp,
@@ -312,6 +332,7 @@ void AmgHierarchy<S>::setup(const Plan& P, const int32_t* d_slice_ptr, const int
     if (const char* e = std::getenv("OPMGPU_AMG_PDAMP")) pdamp = std::atof(e);
     if (const char* e = std::getenv("OPMGPU_AMG_NPRE")) npre = std::atoi(e);
     if (const char* e = std::getenv("OPMGPU_AMG_NPOST")) npost = std::atoi(e);
+    if (const char* e = std::getenv("OPMGPU_AMG_FUSE")) fuse = std::atoi(e) != 0;
     HostCsr A;
     A.n = P.nb; A.rowptr.assign(P.nb + 1, 0);
     for (int r = 0; r < P.nb; ++r) A.rowptr[r + 1] = A.rowptr[r] + P.rowlen[r];
@@ -402,15 +423,16 @@ void AmgHierarchy<S>::galerkin()
 }
 
 template <class S>
-void AmgHierarchy<S>::vcycle(const SolveCtl* ctl)
+void AmgHierarchy<S>::vcycle(const SolveCtl* ctl, bool level0_presmoothed)
 {
     const S om = S(omega);
     const int nl = int(levels.size());
+    bool presmoothed = level0_presmoothed && fuse;  // F.x already holds omega D^-1 b (fused into the kernel that produced b)
     for (int l = 0; l < nl - 1; ++l) {
         AmgLevel<S>& F = *levels[l]; AmgLevel<S>& C = *levels[l + 1];
         const int g = grid_for(F.n);
         if (F.n > 50000) {
-            hipLaunchKernelGGL((k_amg_smooth0<S>), dim3(g), dim3(kBlock), 0, stream, F.n, om, F.dinv.p, F.b.p, F.x.p, ctl);
+            if (!presmoothed) hipLaunchKernelGGL((k_amg_smooth0<S>), dim3(g), dim3(kBlock), 0, stream, F.n, om, F.dinv.p, F.b.p, F.x.p, ctl);
             hipLaunchKernelGGL((k_amg_residual<S, 0>), dim3(g), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, F.x.p, om, F.dinv.p, F.r.p, ctl);
         } else if (F.n > 20000) {
             hipLaunchKernelGGL((k_amg_smooth0_residual<S>), dim3(g), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, om, F.dinv.p, F.x.p, F.r.p, ctl);
@@ -424,7 +446,10 @@ void AmgHierarchy<S>::vcycle(const SolveCtl* ctl)
             else
                 hipLaunchKernelGGL((k_amg_row_wave<S, 0>), dim3((F.n + 3) / 4), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, (const S*)F.x.p, om, F.dinv.p, F.r.p, (S*)nullptr, ctl);
         }
-        hipLaunchKernelGGL((k_amg_restrict<S>), dim3(grid_for(C.n)), dim3(kBlock), 0, stream, C.n, F.agg_ptr.p, F.agg_rows.p, F.r.p, C.b.p, ctl);
+        // the restriction also performs the coarse level's first sweep when that level would launch a separate kernel for it
+        presmoothed = fuse && (l + 1 < nl - 1) && C.n > 50000;
+        hipLaunchKernelGGL((k_amg_restrict<S>), dim3(grid_for(C.n)), dim3(kBlock), 0, stream, C.n, F.agg_ptr.p, F.agg_rows.p, F.r.p, C.b.p, om,
+                           presmoothed ? (const S*)C.dinv.p : (const S*)nullptr, presmoothed ? C.x.p : (S*)nullptr, ctl);
     }
     AmgLevel<S>& B = *levels.back();
     if (n_coarsest <= kDenseMax) {
@@ -439,8 +464,21 @@ void AmgHierarchy<S>::vcycle(const SolveCtl* ctl)
     for (int l = nl - 2; l >= 0; --l) {
         AmgLevel<S>& F = *levels[l]; AmgLevel<S>& C = *levels[l + 1];
         const int g = grid_for(F.n);
-        hipLaunchKernelGGL((k_amg_prolong<S>), dim3(g), dim3(kBlock), 0, stream, F.n, F.agg.p, C.x.p, F.x.p, S(pdamp), ctl);
-        for (int sw = 0; sw < npost; ++sw) sweep(F, ctl);
+        int done_sweeps = 0;
+        if (fuse && npost >= 1 && F.n <= 200000) {
+            // small and medium levels: the prolongation is gathered inside the first post-smoothing sweep (one launch less)
+            if (F.n > 20000)
+                hipLaunchKernelGGL((k_amg_residual<S, 3>), dim3(g), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, (const S*)F.x.p, om, F.dinv.p, F.x2.p, ctl,
+                                   (const int32_t*)F.agg.p, (const S*)C.x.p, S(pdamp));
+            else
+                hipLaunchKernelGGL((k_amg_row_wave<S, 3>), dim3((F.n + 3) / 4), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, (const S*)F.x.p, om, F.dinv.p, F.x2.p,
+                                   (S*)nullptr, ctl, (const int32_t*)F.agg.p, (const S*)C.x.p, S(pdamp));
+            std::swap(F.x.p, F.x2.p);
+            done_sweeps = 1;
+        } else {
+            hipLaunchKernelGGL((k_amg_prolong<S>), dim3(g), dim3(kBlock), 0, stream, F.n, F.agg.p, C.x.p, F.x.p, S(pdamp), ctl);
+        }
+        for (int sw = done_sweeps; sw < npost; ++sw) sweep(F, ctl);
     }
 }
 

@@ -49,7 +49,8 @@ public:
     // numeric phase for a new matrix: level-0 values are already in levels[0].val
     void galerkin();
     // x0 = Vcycle(b0) with b0 in levels[0].b; result in levels[0].x
-    void vcycle(const SolveCtl* ctl);
+    // level0_presmoothed: levels[0].x already holds omega D^-1 b (the caller's kernel did the first sweep)
+    void vcycle(const SolveCtl* ctl, bool level0_presmoothed = false);
     std::vector<std::unique_ptr<AmgLevel<S>>> levels;
     std::vector<std::unique_ptr<DevArray<int32_t>>> coarse_dev;   // per fine level: device entry id of every coarse csr entry
     DevArray<double> dense_inv;      // coarsest: explicit inverse (double), n_c x n_c
@@ -62,6 +63,7 @@ public:
     double omega = 0.9;           // damped-Jacobi weight
     double pdamp = 1.9;           // coarse-grid correction scaling (dune-istl's prolongation damping factor)
     int npre = 1, npost = 2;      // smoothing sweeps before / after the coarse-grid correction
+    bool fuse = true;             // launch fusions of the V-cycle (A/B: OPMGPU_AMG_FUSE=0)
     void sweep(AmgLevel<S>& F, const SolveCtl* ctl);
 };
 

@@ -262,34 +262,65 @@ __global__ __launch_bounds__(kBlock) void k_ilu_factor(int lo, int hi, const int
     const int row = lo + blockIdx.x * kBlock + threadIdx.x;
     if (row >= hi) return;
     const int base = slice_ptr[row >> 6], lane = row & 63, nl = nlower[row];
-    // this row of LU starts as a copy of the row of A (fused here instead of a separate 2 x matrix-size device copy)
-    for (int k = 0, len = rowlen[row]; k < len; ++k) {
-        const int32_t e = (base + k) * 64 + lane;
-        S t[9]; ld9(A, e, t); st9(lu, e, t);
-    }
+    const int len = rowlen[row];
+    const int32_t ed = (base + nl) * 64 + lane;
     int tp = trip_ptr[row];
     const int te = trip_ptr[row + 1];
-    for (int k = 0; k < nl; ++k) {
-        const int32_t e = (base + k) * 64 + lane;
-        const int j = col[e];
-        const int32_t ej = (slice_ptr[j >> 6] + nlower[j]) * 64 + (j & 63);
-        S a[9], dj[9], L[9];
-        ld9(lu, e, a); ld9(lu, ej, dj);
-        mm9(a, dj, L);
-        st9(lu, e, L);
-        while (tp < te && trip_l[tp] == e) {
-            S u[9], t[9], bb[9];
-            ld9(lu, trip_u[tp], u); ld9(lu, trip_t[tp], t);
-            mm9(L, u, bb);
-#pragma unroll
-            for (int q = 0; q < 9; ++q) t[q] -= bb[q];
-            st9(lu, trip_t[tp], t);
-            ++tp;
-        }
-    }
-    const int32_t ed = (base + nl) * 64 + lane;
+    // Fast path (every row of a multicolour ordering on a grid stencil): all updates of this row hit its diagonal block, so the
+    // diagonal is accumulated in registers and every entry of A is read once and every entry of LU written once -- the generic
+    // path below goes through memory for each update (copy, re-load, store; measured 2.6x the traffic of this one).
+    bool simple = true;
+    for (int q = tp; q < te; ++q) simple = simple && (trip_t[q] == ed);
     S m[9], o[9];
-    ld9(lu, ed, m);
+    if (simple) {
+        ld9(A, ed, m);
+        for (int k = 0; k < nl; ++k) {
+            const int32_t e = (base + k) * 64 + lane;
+            const int j = col[e];
+            const int32_t ej = (slice_ptr[j >> 6] + nlower[j]) * 64 + (j & 63);
+            S a[9], dj[9], L[9];
+            ld9(A, e, a); ld9(lu, ej, dj);
+            mm9(a, dj, L);
+            st9(lu, e, L);
+            while (tp < te && trip_l[tp] == e) {
+                S u[9], bb[9];
+                ld9(lu, trip_u[tp], u);
+                mm9(L, u, bb);
+#pragma unroll
+                for (int q = 0; q < 9; ++q) m[q] -= bb[q];
+                ++tp;
+            }
+        }
+        for (int k = nl + 1; k < len; ++k) {           // upper part: unchanged copy of A
+            const int32_t e = (base + k) * 64 + lane;
+            S t[9]; ld9(A, e, t); st9(lu, e, t);
+        }
+    } else {
+        // generic IKJ: this row of LU starts as a copy of the row of A, updates go through memory
+        for (int k = 0; k < len; ++k) {
+            const int32_t e = (base + k) * 64 + lane;
+            S t[9]; ld9(A, e, t); st9(lu, e, t);
+        }
+        for (int k = 0; k < nl; ++k) {
+            const int32_t e = (base + k) * 64 + lane;
+            const int j = col[e];
+            const int32_t ej = (slice_ptr[j >> 6] + nlower[j]) * 64 + (j & 63);
+            S a[9], dj[9], L[9];
+            ld9(lu, e, a); ld9(lu, ej, dj);
+            mm9(a, dj, L);
+            st9(lu, e, L);
+            while (tp < te && trip_l[tp] == e) {
+                S u[9], t[9], bb[9];
+                ld9(lu, trip_u[tp], u); ld9(lu, trip_t[tp], t);
+                mm9(L, u, bb);
+#pragma unroll
+                for (int q = 0; q < 9; ++q) t[q] -= bb[q];
+                st9(lu, trip_t[tp], t);
+                ++tp;
+            }
+        }
+        ld9(lu, ed, m);
+    }
     const S c0 = m[4] * m[8] - m[5] * m[7], c1 = m[5] * m[6] - m[3] * m[8], c2 = m[3] * m[7] - m[4] * m[6];
     const S det = m[0] * c0 + m[1] * c1 + m[2] * c2;
     if (det == S(0) || !(det == det)) { atomicOr(flags, 1); return; }
@@ -487,12 +518,15 @@ __global__ __launch_bounds__(kBlock) void k_extract_pressure(long nentries, cons
 }
 // r_p = sum of the three (scaled) phase residuals
 template <class S>
-__global__ __launch_bounds__(kBlock) void k_cpr_sum_eqs(int nb, int nbp, const S* __restrict__ d, S* __restrict__ bp, const SolveCtl* __restrict__ ctl)
+__global__ __launch_bounds__(kBlock) void k_cpr_sum_eqs(int nb, int nbp, const S* __restrict__ d, S* __restrict__ bp, S omega, const S* __restrict__ dinv,
+                                                        S* __restrict__ x0, const SolveCtl* __restrict__ ctl)
 {
     if (ctl && ctl->done) return;
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= nb) return;
-    bp[i] = d[i] + d[nbp + i] + d[2 * long(nbp) + i];
+    const S b = d[i] + d[nbp + i] + d[2 * long(nbp) + i];
+    bp[i] = b;
+    x0[i] = omega * dinv[i] * b;          // first pre-smoothing sweep of the V-cycle from a zero guess, fused (one launch less)
 }
 // z = d - A [x_p; 0; 0]   (only the pressure column of every block is read: 1/3 of the matrix)
 template <class S>
@@ -753,8 +787,8 @@ template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, con
     SolverWork<S>& w = work<S>();
     AmgLevel<S>& L0 = *w.amg->levels[0];
     const int g = grid_for(plan.nb);
-    hipLaunchKernelGGL((k_cpr_sum_eqs<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, plan.nbp, d, L0.b.p, ctl);
-    w.amg->vcycle(ctl);
+    hipLaunchKernelGGL((k_cpr_sum_eqs<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, plan.nbp, d, L0.b.p, S(w.amg->omega), (const S*)L0.dinv.p, L0.x.p, ctl);
+    w.amg->vcycle(ctl, true);
     const S* xp = L0.x.p;
     if (comm) {
         // multi-GPU: the AMG is rank-local (additive Schwarz: ghost rows are identity rows); the owners' x_p is copied
@@ -910,6 +944,7 @@ template <class S> void LinSolver::get_lu_bsr(double* val9)
 template <class S> static double time_kernel_t(LinSolver& ls, int kernel, int reps, double relax)
 {
     SolverWork<S>& w = ls.work<S>();
+    if ((kernel == OPMGPU_K_CPR_APPLY || kernel == OPMGPU_K_VCYCLE) && (!w.amg || !w.amg->ready())) throw HipError(OPMGPU_EINVAL, "no CPR hierarchy yet (solve once with use_cpr)");
     const Plan& P = ls.plan;
     const long n = long(3) * P.nbp;
     const int gv = std::min(grid_for(n), kMaxPart);
@@ -919,6 +954,9 @@ template <class S> static double time_kernel_t(LinSolver& ls, int kernel, int re
         switch (kernel) {
         case OPMGPU_K_SPMV: ls.spmv<S>(w.p.p, w.v.p); break;
         case OPMGPU_K_ILU_APPLY: ls.ilu_apply<S>(w.p.p, w.y.p, relax, nullptr); break;
+        case OPMGPU_K_CPR_APPLY: ls.cpr_apply<S>(w.p.p, w.y.p, relax, nullptr); break;
+        case OPMGPU_K_VCYCLE: w.amg->vcycle(nullptr, false); break;
+        case OPMGPU_K_CPR_SETUP: ls.cpr_prepare<S>(); break;
         case OPMGPU_K_DOT: hipLaunchKernelGGL((k_dot<S>), dim3(gv), dim3(kBlock), 0, ls.stream, n, w.p.p, w.v.p, ls.partials.p); break;
         case OPMGPU_K_AXPY: hipLaunchKernelGGL((k_axpy<S>), dim3(gv), dim3(kBlock), 0, ls.stream, n, S(1e-3), w.p.p, w.t.p); break;
         case OPMGPU_K_STREAM_COPY: {

@@ -15,7 +15,7 @@ OK, EINVAL, ENODEVICE, ENUMERICAL, ELINSOLVE, EBREAKDOWN, ESINGULAR, ENOMEM, ECO
 HC_GAS_ONLY, HC_GAS_AND_OIL, HC_OIL_ONLY = 0, 1, 2
 RELAX_DAMPEN, RELAX_SOR = 0, 1
 ORDER_NATURAL, ORDER_MULTICOLOR = 0, 1
-K_SPMV, K_ILU_APPLY, K_ILU_FACTOR, K_ASSEMBLE, K_DOT, K_AXPY, K_PROPS, K_STREAM_COPY = range(8)
+K_SPMV, K_ILU_APPLY, K_ILU_FACTOR, K_ASSEMBLE, K_DOT, K_AXPY, K_PROPS, K_STREAM_COPY, K_CPR_APPLY, K_VCYCLE, K_CPR_SETUP = range(11)
 PERF_K = 36
 UNIQUE_ID_BYTES = 128
 
