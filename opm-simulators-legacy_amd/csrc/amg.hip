@@ -1,6 +1,9 @@
 // amg.hip -- plain-aggregation AMG for the CPR pressure stage (see amg.hpp).
 #include "amg.hpp"
 
+#include <string>
+#include <utility>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -333,6 +336,8 @@ void AmgHierarchy<S>::setup(const Plan& P, const int32_t* d_slice_ptr, const int
     if (const char* e = std::getenv("OPMGPU_AMG_NPRE")) npre = std::atoi(e);
     if (const char* e = std::getenv("OPMGPU_AMG_NPOST")) npost = std::atoi(e);
     if (const char* e = std::getenv("OPMGPU_AMG_FUSE")) fuse = std::atoi(e) != 0;
+    npost0 = npost;
+    if (const char* e = std::getenv("OPMGPU_AMG_NPOST0")) npost0 = std::atoi(e);
     HostCsr A;
     A.n = P.nb; A.rowptr.assign(P.nb + 1, 0);
     for (int r = 0; r < P.nb; ++r) A.rowptr[r + 1] = A.rowptr[r] + P.rowlen[r];
@@ -427,6 +432,14 @@ void AmgHierarchy<S>::vcycle(const SolveCtl* ctl, bool level0_presmoothed)
 {
     const S om = S(omega);
     const int nl = int(levels.size());
+    // OPMGPU_AMG_TIME=1: HIP events between the launches of ONE cycle, printed to stderr (diagnostic; no profiler distortion)
+    static const bool timing = std::getenv("OPMGPU_AMG_TIME") != nullptr;
+    std::vector<std::pair<std::string, hipEvent_t>> marks;
+    auto mark = [&](const std::string& name) {
+        if (!timing) return;
+        hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, stream); marks.emplace_back(name, e);
+    };
+    mark("start");
     bool presmoothed = level0_presmoothed && fuse;  // F.x already holds omega D^-1 b (fused into the kernel that produced b)
     for (int l = 0; l < nl - 1; ++l) {
         AmgLevel<S>& F = *levels[l]; AmgLevel<S>& C = *levels[l + 1];
@@ -450,6 +463,7 @@ void AmgHierarchy<S>::vcycle(const SolveCtl* ctl, bool level0_presmoothed)
         presmoothed = fuse && (l + 1 < nl - 1) && C.n > 50000;
         hipLaunchKernelGGL((k_amg_restrict<S>), dim3(grid_for(C.n)), dim3(kBlock), 0, stream, C.n, F.agg_ptr.p, F.agg_rows.p, F.r.p, C.b.p, om,
                            presmoothed ? (const S*)C.dinv.p : (const S*)nullptr, presmoothed ? C.x.p : (S*)nullptr, ctl);
+        mark("down L" + std::to_string(l));
     }
     AmgLevel<S>& B = *levels.back();
     if (n_coarsest <= kDenseMax) {
@@ -461,10 +475,12 @@ void AmgHierarchy<S>::vcycle(const SolveCtl* ctl, bool level0_presmoothed)
             hipLaunchKernelGGL((k_amg_residual<S, 1>), dim3(grid_for(B.n)), dim3(kBlock), 0, stream, B.n, B.slice_ptr, B.col, B.val.p, B.b.p, B.x2.p, om, B.dinv.p, B.x.p, ctl);
         }
     }
+    mark("coarsest");
     for (int l = nl - 2; l >= 0; --l) {
         AmgLevel<S>& F = *levels[l]; AmgLevel<S>& C = *levels[l + 1];
         const int g = grid_for(F.n);
         int done_sweeps = 0;
+        const int npost = l == 0 ? this->npost0 : this->npost;
         if (fuse && npost >= 1 && F.n <= 200000) {
             // small and medium levels: the prolongation is gathered inside the first post-smoothing sweep (one launch less)
             if (F.n > 20000)
@@ -479,6 +495,15 @@ void AmgHierarchy<S>::vcycle(const SolveCtl* ctl, bool level0_presmoothed)
             hipLaunchKernelGGL((k_amg_prolong<S>), dim3(g), dim3(kBlock), 0, stream, F.n, F.agg.p, C.x.p, F.x.p, S(pdamp), ctl);
         }
         for (int sw = done_sweeps; sw < npost; ++sw) sweep(F, ctl);
+        mark("up L" + std::to_string(l));
+    }
+    if (timing && !marks.empty()) {
+        (void)hipStreamSynchronize(stream);
+        static int printed = 0;
+        if (printed++ == 40) {           // one cycle deep inside a solve
+            for (size_t i = 1; i < marks.size(); ++i) { float ms = 0; (void)hipEventElapsedTime(&ms, marks[i - 1].second, marks[i].second); std::fprintf(stderr, "[amg] %-10s %7.1f us\n", marks[i].first.c_str(), 1e3 * ms); }
+        }
+        for (auto& m : marks) (void)hipEventDestroy(m.second);
     }
 }
 

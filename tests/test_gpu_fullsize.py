@@ -120,3 +120,58 @@ def test_spe9_like_with_well_cliques(gpu_lib, oracle):
         blk = slice(a * nc, (a + 1) * nc)
         assert np.abs(dx[blk] - dxo[blk]).max() <= 1e-6 * np.abs(dxo[blk]).max()
     m.close()
+
+
+def _newton_parity(gpu_lib, oracle, grid, tab, st, dt, prm, wells=None, niter=3):
+    """free-running Newton iterations GPU vs oracle (f64 solve, tight linear tolerance)"""
+    from util import bsr_to_scipy  # noqa: F401
+    m = GpuBlackoilModel(grid, tab, prm)
+    m.prepareStep(dt, st)
+    rowptr, col = oracle.pattern(grid)
+    scale = np.asarray(prm.matbalscale[:])
+    nc = grid.nc
+    so, acc0, pos = st.copy(), None, None
+    for it in range(niter):
+        m.assemble(it == 0)
+        m.getConvergence()
+        m.solveJacobianSystem(single_precision=False)
+        m.updateState()
+        if pos is None:
+            pos = m.ordering()[0]
+        r, val, acc0, binv = oracle.assemble(grid, tab, dt, so, rowptr, col, scale=tuple(scale), accum0=acc0)
+        b = np.ascontiguousarray((r * np.repeat(scale, nc)).reshape(3, nc).T).ravel()
+        sto, x, _, _, _ = oracle.bicgstab(rowptr, col, val, b, prm, position=pos, single=False)
+        assert sto == 0
+        so = oracle.update_state(grid, tab, prm, np.ascontiguousarray(x.reshape(nc, 3).T).ravel(), so)
+        g = m.getState()
+        assert np.array_equal(g.hc, so.hc), it
+        assert np.abs(g.p - so.p).max() / np.abs(so.p).max() < 1e-6, it
+        assert np.abs(g.sat - so.sat).max() < 1e-6, it
+    m.close()
+
+
+def test_spe10_like_heterogeneity(gpu_lib, oracle):
+    """configs[3]-like at an oracle-checkable size: channelised lognormal permeability with sigma_lnK = 2.5 (four orders of
+    magnitude of transmissibility contrast), thin cells, CPR and ILU0."""
+    grid = decks.cartesian_grid(12, 22, 17, dx=6.096, dy=3.048, dz=0.6096, tops=3657.6, lognormal_sigma=2.5, seed=10)
+    assert np.log10(grid.trans.max() / grid.trans.min()) > 4
+    tab = decks.satfunc_standard_tables()
+    st = decks.initial_state(grid, tab, p_ref=413.0 * decks.BAR, z_ref=3657.6, perturb=0.005, seed=10)
+    for cpr in (0, 1):
+        prm = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=1500, use_cpr=cpr)
+        _newton_parity(gpu_lib, oracle, grid, tab, st, 2 * decks.DAY, prm)
+
+
+def test_norne_like_unstructured(gpu_lib, oracle):
+    """configs[4]-like: 60 % of the cells inactive, fault-style non-neighbour connections (5 % extra), threshold pressures:
+    arbitrary BSR rows (1-25 blocks), several ILU colours, isolated cells."""
+    rng = np.random.default_rng(44)
+    act = rng.random(23 * 28 * 11) > 0.6
+    grid = decks.cartesian_grid(23, 28, 11, actnum=act, nnc_fraction=0.05, lognormal_sigma=1.0, thpres=0.02 * decks.BAR, seed=44)
+    tab = decks.satfunc_standard_tables()
+    st = decks.initial_state(grid, tab, perturb=0.01, seed=44)
+    rowptr, _ = oracle.pattern(grid)
+    assert np.diff(rowptr).min() >= 1 and np.diff(rowptr).max() >= 8
+    for cpr in (0, 1):
+        prm = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=1500, use_cpr=cpr)
+        _newton_parity(gpu_lib, oracle, grid, tab, st, 3 * decks.DAY, prm)
