@@ -199,7 +199,11 @@ def main():
             cpu = cpu_baseline(args, grid, tab, st, prm, dt, single, threads=args.cpu_threads)
             # the same port with its OpenMP-able loops (assembly, SpMV, vector updates; the ILU sweeps stay sequential like the
             # reference's) on all host cores of this box -- the reference itself caps OpenMP at 4 threads (FlowMain.hpp:269-271)
-            ncores = os.cpu_count() or 1
+            try:
+                ncores = len(os.sched_getaffinity(0))
+            except AttributeError:
+                ncores = os.cpu_count() or 1
+            ncores = min(ncores, 16)             # a one-GPU box shares its host: 16 cores is this job's share (more threads only oversubscribe)
             if ncores > args.cpu_threads:
                 cpu_all = cpu_baseline(args, grid, tab, st, prm, dt, single, threads=ncores, budget_s=8.0, max_newton=2)
 
