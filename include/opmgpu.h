@@ -297,6 +297,9 @@ int opmgpu_ilu0_apply(opmgpu_ctx* ctx, const double* d3, double* v3);
 int opmgpu_ilu0_get(opmgpu_ctx* ctx, double* val9);
 /* elimination position of every caller row (perm[row] = position) and its level. */
 int opmgpu_get_ordering(opmgpu_ctx* ctx, int32_t* position, int32_t* level, int32_t* nlevels);
+/* per-cell 0/1 weights of the CPR pressure equation after a solve with use_cpr (formEllipticSystem's dominance test,
+ * NewtonIterationUtilities.cpp:212-252): w[3*nb], equation-major (water, oil, gas), caller row order. */
+int opmgpu_get_cpr_weights(opmgpu_ctx* ctx, double* w);
 /* assembled reservoir system back to the host in caller numbering: residual (unscaled,
  * equation-major 3*nc), and the matbal-scaled Jacobian in BSR. */
 int opmgpu_get_residual(opmgpu_ctx* ctx, double* r);

@@ -410,6 +410,17 @@ int opmgpu_get_ordering(opmgpu_ctx* c, int32_t* position, int32_t* level, int32_
     return OPMGPU_OK;
 }
 
+int opmgpu_get_cpr_weights(opmgpu_ctx* c, double* w)
+{
+    if (!c || !w || !c->ls->has_pattern()) return OPMGPU_EINVAL;
+    return guarded(c, [&]() {
+        LinSolver& ls = *c->ls;
+        if (c->cur_single == 1) { if (!ls.work<float>().cprw.p) return fail(c, OPMGPU_EINVAL, "no CPR solve yet"); ls.vec_to_host<float>(ls.work<float>().cprw.p, VEC_EQUATION_MAJOR, w); }
+        else { if (!ls.work<double>().cprw.p) return fail(c, OPMGPU_EINVAL, "no CPR solve yet"); ls.vec_to_host<double>(ls.work<double>().cprw.p, VEC_EQUATION_MAJOR, w); }
+        return int(OPMGPU_OK);
+    });
+}
+
 int opmgpu_get_residual(opmgpu_ctx* c, double* r)
 {
     if (!c || !c->model || !r) return OPMGPU_EINVAL;

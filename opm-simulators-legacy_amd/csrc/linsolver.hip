@@ -507,24 +507,61 @@ __global__ __launch_bounds__(kBlock) void k_copy16(long n16, const double2* __re
 }
 
 // ---- CPR (NewtonIterationBlackoilCPR.cpp:79-185) ----
-// elliptic system of formEllipticSystem (NewtonIterationUtilities.cpp:197-287, default L): A_p(i,j) = sum_eq A_ij[eq][pressure]
+// formEllipticSystem (NewtonIterationUtilities.cpp:197-287): the pressure equation of a cell is the sum of those (matbal-scaled)
+// phase equations whose pressure derivative is strong on the diagonal -- |J_ii| / (column sum of |J_ji|, j != i) > 0.01 --
+// with the reference's fix-up for a weak oil equation (:233-252): if no equation is strong the oil equation alone is used.
+// Equations here are ordered water, oil, gas (the reference swaps oil first: "a concession to MRST").  Weights are 0 / 1.
 template <class S>
-__global__ __launch_bounds__(kBlock) void k_extract_pressure(long nentries, const S* __restrict__ A, S* __restrict__ Ap)
+__global__ __launch_bounds__(kBlock) void k_cpr_weights(int nb, int nbp, const int32_t* __restrict__ slice_ptr, const int16_t* __restrict__ rowlen,
+                                                        const int16_t* __restrict__ nlower, const int32_t* __restrict__ tpos, const S* __restrict__ A,
+                                                        S* __restrict__ w)
 {
-    const long e = blockIdx.x * long(kBlock) + threadIdx.x;
-    if (e >= nentries) return;
-    const S* b = A + (e >> 6) * 576 + (e & 63);
-    Ap[e] = b[0] + b[192] + b[384];
+    const int row = blockIdx.x * kBlock + threadIdx.x;
+    if (row >= nb) return;
+    const int base = slice_ptr[row >> 6], lane = row & 63, len = rowlen[row], nl = nlower[row];
+    double sod[3] = { 0.0, 0.0, 0.0 }, dj[3];
+    for (int k = 0; k < len; ++k) {
+        const long e = long(base + k) * 64 + lane;
+        if (k == nl) {
+            const S* b = A + (e >> 6) * 576 + (e & 63);
+            dj[0] = fabs(double(b[0])); dj[1] = fabs(double(b[192])); dj[2] = fabs(double(b[384]));
+        } else {
+            const int t = tpos[e];
+            if (t < 0) continue;
+            const S* b = A + long(t >> 6) * 576 + (t & 63);
+            sod[0] += fabs(double(b[0])); sod[1] += fabs(double(b[192])); sod[2] += fabs(double(b[384]));
+        }
+    }
+    const bool sw = dj[0] / sod[0] > 0.01, sg = dj[2] / sod[2] > 0.01;       // NaN (0/0) compares false like the reference's Eigen cast
+    bool so = dj[1] / sod[1] > 0.01;
+    if (!so && !sw && !sg) so = true;
+    w[row] = sw ? S(1) : S(0); w[nbp + row] = so ? S(1) : S(0); w[2 * long(nbp) + row] = sg ? S(1) : S(0);
 }
-// r_p = sum of the three (scaled) phase residuals
+// A_p(i,j) = sum over the selected equations of A_ij[eq][pressure]; one thread per row (padding slots included: value 0)
 template <class S>
-__global__ __launch_bounds__(kBlock) void k_cpr_sum_eqs(int nb, int nbp, const S* __restrict__ d, S* __restrict__ bp, S omega, const S* __restrict__ dinv,
-                                                        S* __restrict__ x0, const SolveCtl* __restrict__ ctl)
+__global__ __launch_bounds__(kBlock) void k_extract_pressure(int nb, int nbp, const int32_t* __restrict__ slice_ptr, const S* __restrict__ w,
+                                                             const S* __restrict__ A, S* __restrict__ Ap)
+{
+    const int row = blockIdx.x * kBlock + threadIdx.x;
+    if (row >= nbp) return;
+    const int base = slice_ptr[row >> 6], width = slice_ptr[(row >> 6) + 1] - base, lane = row & 63;
+    const bool real = row < nb;
+    const S w0 = real ? w[row] : S(0), w1 = real ? w[nbp + row] : S(0), w2 = real ? w[2 * long(nbp) + row] : S(0);
+    for (int k = 0; k < width; ++k) {
+        const long e = long(base + k) * 64 + lane;
+        const S* b = A + (e >> 6) * 576 + (e & 63);
+        Ap[e] = w0 * b[0] + w1 * b[192] + w2 * b[384];
+    }
+}
+// r_p = the same combination of the three (scaled) phase residuals
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_cpr_sum_eqs(int nb, int nbp, const S* __restrict__ d, const S* __restrict__ w, S* __restrict__ bp, S omega,
+                                                        const S* __restrict__ dinv, S* __restrict__ x0, const SolveCtl* __restrict__ ctl)
 {
     if (ctl && ctl->done) return;
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= nb) return;
-    const S b = d[i] + d[nbp + i] + d[2 * long(nbp) + i];
+    const S b = w[i] * d[i] + w[nbp + i] * d[nbp + i] + w[2 * long(nbp) + i] * d[2 * long(nbp) + i];
     bp[i] = b;
     x0[i] = omega * dinv[i] * b;          // first pre-smoothing sweep of the V-cycle from a zero guess, fused (one launch less)
 }
@@ -615,7 +652,7 @@ void DevPlan::upload(const Plan& P, hipStream_t s)
     std::vector<int32_t> one(1, 0);      // hipMalloc(0) is avoided: keep at least one element
     trip_l.upload(P.trip_l.empty() ? one : P.trip_l, s); trip_u.upload(P.trip_u.empty() ? one : P.trip_u, s);
     trip_t.upload(P.trip_t.empty() ? one : P.trip_t, s);
-    rowlen.upload(P.rowlen, s); nlower.upload(P.nlower, s);
+    rowlen.upload(P.rowlen, s); nlower.upload(P.nlower, s); tpos.upload(P.tpos, s);
     level_ptr = P.level_ptr;
     OPMGPU_HIP(hipStreamSynchronize(s));      // the host vectors may go away
 }
@@ -767,17 +804,21 @@ template <class S> void LinSolver::cpr_prepare()
     SolverWork<S>& w = work<S>();
     const long ne = plan.nentries;
     if (!w.amg) w.amg.reset(new AmgHierarchy<S>(stream));
+    w.cprw.alloc(3 * size_t(plan.nbp));
+    hipLaunchKernelGGL((k_cpr_weights<S>), dim3(grid_for(plan.nb)), dim3(kBlock), 0, stream, plan.nb, plan.nbp, dp.slice_ptr.p, dp.rowlen.p, dp.nlower.p,
+                       dp.tpos.p, matrix<S>(), w.cprw.p);
     if (!w.amg->ready()) {
         // first matrix with this pattern: pressure values to the host, aggregation hierarchy (structure only) built there
         DevArray<S> tmp; tmp.alloc(ne);
-        hipLaunchKernelGGL((k_extract_pressure<S>), dim3(grid_for(ne)), dim3(kBlock), 0, stream, ne, matrix<S>(), tmp.p);
+        hipLaunchKernelGGL((k_extract_pressure<S>), dim3(grid_for(plan.nbp)), dim3(kBlock), 0, stream, plan.nb, plan.nbp, dp.slice_ptr.p, (const S*)w.cprw.p, matrix<S>(), tmp.p);
         std::vector<S> h(ne);
         tmp.download(h.data(), ne, stream);
         OPMGPU_HIP(hipStreamSynchronize(stream));
         std::vector<double> hd(h.begin(), h.end());
         w.amg->setup(plan, dp.slice_ptr.p, dp.col.p, hd);
     }
-    hipLaunchKernelGGL((k_extract_pressure<S>), dim3(grid_for(ne)), dim3(kBlock), 0, stream, ne, matrix<S>(), w.amg->levels[0]->val.p);
+    hipLaunchKernelGGL((k_extract_pressure<S>), dim3(grid_for(plan.nbp)), dim3(kBlock), 0, stream, plan.nb, plan.nbp, dp.slice_ptr.p, (const S*)w.cprw.p, matrix<S>(),
+                       w.amg->levels[0]->val.p);
     w.amg->galerkin();
 }
 
@@ -787,7 +828,7 @@ template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, con
     SolverWork<S>& w = work<S>();
     AmgLevel<S>& L0 = *w.amg->levels[0];
     const int g = grid_for(plan.nb);
-    hipLaunchKernelGGL((k_cpr_sum_eqs<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, plan.nbp, d, L0.b.p, S(w.amg->omega), (const S*)L0.dinv.p, L0.x.p, ctl);
+    hipLaunchKernelGGL((k_cpr_sum_eqs<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, plan.nbp, d, (const S*)w.cprw.p, L0.b.p, S(w.amg->omega), (const S*)L0.dinv.p, L0.x.p, ctl);
     w.amg->vcycle(ctl, true);
     const S* xp = L0.x.p;
     if (comm) {

@@ -14,7 +14,7 @@ namespace opmgpu {
 
 struct DevPlan {
     int nb = 0, nbp = 0, nslices = 0, nentries = 0, nlevels = 0, nnzb = 0;
-    DevArray<int32_t> slice_ptr, col, src, entry_of_block, nat, pos, trip_ptr, trip_l, trip_u, trip_t;
+    DevArray<int32_t> slice_ptr, col, src, entry_of_block, nat, pos, trip_ptr, trip_l, trip_u, trip_t, tpos;
     DevArray<int16_t> rowlen, nlower;
     std::vector<int32_t> level_ptr;
     void upload(const Plan& P, hipStream_t s);
@@ -66,6 +66,7 @@ struct SolverWork {
     DevArray<S> A;      // float copy of the matrix (unused for double: the double matrix is used in place)
     DevArray<S> LU;
     DevArray<S> r, rt, p, v, t, y, x, b, z, hx;  // z: scratch of the CPR second stage; hx: halo staging of x_p (multi-GPU)
+    DevArray<S> cprw;                            // [3][nbp] per-cell weights of the pressure equation (formEllipticSystem)
     std::unique_ptr<AmgHierarchy<S>> amg;         // CPR pressure stage (built on first use)
     bool allocated = false;
 };

@@ -161,6 +161,15 @@ int build_plan(int nb, const int32_t* rowptr, const int32_t* col, int ordering, 
         }
         for (int k = len; k < w; ++k) P.sell_col[(base + k) * 64 + (r & 63)] = std::min(r, nb - 1);   // padding: value 0, safe gather
     }
+    // --- transposed entries (column sums of formEllipticSystem's dominance test are taken over rows)
+    P.tpos.assign(P.nentries, -1);
+    for (int r = 0; r < nb; ++r)
+        for (int k = 0; k < P.rowlen[r]; ++k) {
+            const int e = P.entry(r, k), j = P.sell_col[e];
+            int lo = 0, hi = P.rowlen[j];                   // columns of row j ascend over its real slots
+            while (lo < hi) { const int mid = (lo + hi) / 2; if (P.sell_col[P.entry(j, mid)] < r) lo = mid + 1; else hi = mid; }
+            if (lo < P.rowlen[j] && P.sell_col[P.entry(j, lo)] == r) P.tpos[e] = P.entry(j, lo);
+        }
     // --- ILU0 update triples
     P.trip_ptr.assign(nb + 1, 0);
     std::vector<int32_t> slot_of(nb, -1);

@@ -117,6 +117,7 @@ SIGNATURES = {
     "opmgpu_solve": (C.c_int, [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int), _dp]),
     "opmgpu_update_state": (C.c_int, [C.c_void_p, _dp, C.c_double]),
     "opmgpu_stabilize_update": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
+    "opmgpu_get_cpr_weights": (C.c_int, [C.c_void_p, _dp]),
     "opmgpu_set_solve_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "opmgpu_set_device_wells": (C.c_int, [C.c_void_p, C.POINTER(WellsSpec)]),
     "opmgpu_well_state_set": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),

@@ -179,3 +179,50 @@ def test_cpr_amg_solve(gpu_lib, oracle, single):
     xs2 = s.computeNewtonIncrement(rowptr, col, val, b, single)
     assert np.array_equal(xs, xs2)
     s.close()
+
+
+def test_cpr_pressure_equation_weights(gpu_lib, oracle):
+    """formEllipticSystem's dominance test (NewtonIterationUtilities.cpp:212-252) restated here in numpy from the reference
+    text: per cell and phase, strong <=> |J_ii| / (column sum of |J_ji|, j != i) > 0.01 on the pressure derivative of the
+    scaled equations; a weak oil equation with nothing else strong falls back to the oil equation alone."""
+    import ctypes as C
+    grid = decks.cartesian_grid(9, 8, 7, nnc_fraction=0.03, lognormal_sigma=0.8)
+    rowptr, col = oracle.pattern(grid)
+    nb = rowptr.size - 1
+    val = random_block_matrix(rowptr, col, seed=5).reshape(-1, 3, 3)
+    rng = np.random.default_rng(6)
+    rows = np.repeat(np.arange(nb), np.diff(rowptr))
+    diag = rows == col
+    # manufacture weak pressure diagonals: gas equation in a third of the cells, all three in a few, oil only in some
+    weak_g, weak_all, weak_o = rng.random(nb) < 0.3, rng.random(nb) < 0.05, rng.random(nb) < 0.1
+    for c in range(nb):
+        d = np.flatnonzero(diag & (rows == c))[0]
+        if weak_g[c] or weak_all[c]:
+            val[d, 2, 0] *= 1e-4
+        if weak_all[c] or weak_o[c]:
+            val[d, 1, 0] *= 1e-4
+        if weak_all[c]:
+            val[d, 0, 0] *= 1e-4
+    val = val.reshape(-1, 9)
+    # reference rule in numpy
+    expect = np.zeros((3, nb))
+    v3 = val.reshape(-1, 3, 3)
+    for eq in range(3):
+        dj = np.abs(v3[diag, eq, 0])[np.argsort(rows[diag])]
+        colsum = np.zeros(nb)
+        np.add.at(colsum, col, np.abs(v3[:, eq, 0]))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            expect[eq] = (dj / (colsum - dj) > 0.01)
+    none = (expect.sum(0) == 0)
+    expect[1, none] = 1.0
+    assert none.any() and (expect[2] == 0).any() and ((expect[1] == 0) & (expect[0] == 1)).any()
+    b = rng.standard_normal(3 * nb)
+    s = GpuNewtonIteration(capi.default_params(use_cpr=1, linear_solver_maxiter=400))
+    try:
+        s.computeNewtonIncrement(rowptr, col, val, b, False)
+    except LinearSolverProblem:
+        pass                                             # the random matrix is not the point here
+    w = np.zeros(3 * nb)
+    assert s.lib.opmgpu_get_cpr_weights(s.ctx, capi.dptr(w)) == capi.OK
+    assert np.array_equal(w.reshape(3, nb), expect)
+    s.close()
