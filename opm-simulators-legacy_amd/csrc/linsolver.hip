@@ -99,13 +99,26 @@ __global__ __launch_bounds__(kBlock) void k_lowrank_reduce(LowRankOp lr, int nbp
     }
 }
 
+// multi-GPU: rows whose closed form survives the halo exchange = owned rows with only owned neighbours
+__global__ __launch_bounds__(kBlock) void k_light_mask(int nb, const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
+                                                       const int16_t* __restrict__ rowlen, const int8_t* __restrict__ owner, int8_t* __restrict__ ok)
+{
+    const int row = blockIdx.x * kBlock + threadIdx.x;
+    if (row >= nb) return;
+    const int base = slice_ptr[row >> 6], lane = row & 63;
+    bool good = owner[row] != 0;
+    for (int k = 0, len = rowlen[row]; k < len; ++k) good = good && owner[col[long(base + k) * 64 + lane]] != 0;
+    ok[row] = good ? 1 : 0;
+}
+
 template <class S, int NDOT>
 __global__ __launch_bounds__(kBlock) void k_spmv(int xm, int nb, int nbp, const int32_t* __restrict__ slice_ptr,
                                                  const int32_t* __restrict__ col, const S* __restrict__ val,
                                                  const S* __restrict__ x, S* __restrict__ y,
                                                  const S* __restrict__ w1, const int8_t* __restrict__ mask,
                                                  const SolveCtl* __restrict__ ctl, double* __restrict__ p0, double* __restrict__ p1,
-                                                 const S* __restrict__ pin, const S* __restrict__ zin, int n0, S w, LowRankOp lr)
+                                                 const S* __restrict__ pin, const S* __restrict__ zin, int n0, S w, LowRankOp lr,
+                                                 const int8_t* __restrict__ lightmask)
 {
     __shared__ double sm[8];
     if (ctl && ctl->done) return;
@@ -116,8 +129,28 @@ __global__ __launch_bounds__(kBlock) void k_spmv(int xm, int nb, int nbp, const 
         for (int ch = xcd_first(nchunks, xm); ch < xcd_end(nchunks, xm); ch += xcd_stride(xm)) {
             const int row = ch * kBlock + threadIdx.x;
             if (row >= nlight) continue;
-            const S om = S(1) - w;
-            S y0 = pin[row] - om * zin[row], y1 = pin[nbp + row] - om * zin[nbp + row], y2 = pin[2 * nbp + row] - om * zin[2 * nbp + row];
+            S y0, y1, y2;
+            if (!lightmask || lightmask[row]) {
+                const S om = S(1) - w;
+                y0 = pin[row] - om * zin[row]; y1 = pin[nbp + row] - om * zin[nbp + row]; y2 = pin[2 * nbp + row] - om * zin[2 * nbp + row];
+            } else {
+                // multi-GPU: a level-0 row next to a ghost cell (its x was replaced by the owner's value) or a ghost row itself
+                y0 = 0; y1 = 0; y2 = 0;
+                if (!mask || mask[row]) {
+                    const int sl = row >> 6, lane = row & 63;
+                    const int base = slice_ptr[sl], width = slice_ptr[sl + 1] - base;
+                    const S* __restrict__ v = val + vidx(base, lane);
+                    const int32_t* __restrict__ c = col + long(base) * 64 + lane;
+                    for (int k = 0; k < width; ++k) {
+                        const int cc = c[k * 64];
+                        const S x0 = x[cc], x1 = x[nbp + cc], x2 = x[2 * nbp + cc];
+                        const S* __restrict__ b = v + k * 576;
+                        y0 += b[0] * x0 + b[64] * x1 + b[128] * x2;
+                        y1 += b[192] * x0 + b[256] * x1 + b[320] * x2;
+                        y2 += b[384] * x0 + b[448] * x1 + b[512] * x2;
+                    }
+                }
+            }
             if (lr.perf_of_row) lowrank_add(lr, row, y0, y1, y2);
             y[row] = y0; y[nbp + row] = y1; y[2 * nbp + row] = y2;
             if (NDOT >= 1) acc[0] += double(w1[row]) * double(y0) + double(w1[nbp + row]) * double(y1) + double(w1[2 * nbp + row]) * double(y2);
@@ -690,6 +723,7 @@ int LinSolver::set_pattern(int nb, const int32_t* rowptr, const int32_t* col, in
         std::memcmp(plan.rowptr.data(), rowptr, sizeof(int32_t) * (nb + 1)) == 0 &&
         std::memcmp(plan.col.data(), col, sizeof(int32_t) * plan.nnzb) == 0)
         return OPMGPU_OK;
+    light_ok_for = nullptr;
     Plan P;
     const int st = build_plan(nb, rowptr, col, ordering, P);
     if (st != OPMGPU_OK) return st;
@@ -788,7 +822,7 @@ template <class S> void LinSolver::spmv(const S* x, S* y)
     lowrank_reduce<S>(x, nullptr);
     hipLaunchKernelGGL((k_spmv<S, 0>), dim3(g), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p,
                        matrix<S>(), x, y, (const S*)nullptr, comm ? comm->owner_mask() : (const int8_t*)nullptr, (const SolveCtl*)nullptr,
-                       (double*)nullptr, (double*)nullptr, (const S*)nullptr, (const S*)nullptr, 0, S(0), lowrank);
+                       (double*)nullptr, (double*)nullptr, (const S*)nullptr, (const S*)nullptr, 0, S(0), lowrank, (const int8_t*)nullptr);
 }
 
 template <class S> void LinSolver::lowrank_reduce(const S* x, const SolveCtl* ctl)
@@ -858,11 +892,20 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
     const double eps = sizeof(S) == 8 ? 1e-80 : 0.0;           // dune: real_type EPSILON = 1e-80 (0 in float)
     const int maxit = prm.linear_solver_maxiter;
     const int8_t* mask = comm ? comm->owner_mask() : nullptr;
-    // closed form of (A M^-1 p) on the level-0 rows -- valid when M is the ILU0 of exactly this matrix and the ghost
-    // entries of M^-1 p are not overwritten by a halo exchange, i.e. single GPU
+    // closed form of (A M^-1 p) on the level-0 rows -- valid when M is the ILU0 of exactly this matrix and none of the row's
+    // neighbours is a ghost whose entry of M^-1 p is overwritten by the halo exchange (multi-GPU: light_ok masks those rows out)
     const bool cpr = prm.use_cpr != 0;                   // multi-GPU: rank-local (additive Schwarz) AMG + block-Jacobi ILU0
     if (cpr) cpr_prepare<S>();
-    const bool closed = !comm && closed_form_level0;
+    const bool closed = closed_form_level0;
+    const int8_t* lightmask = nullptr;
+    if (comm && closed) {
+        if (light_ok_for != comm || light_ok.n != size_t(plan.nbp)) {
+            light_ok.alloc(plan.nbp); light_ok.zero(stream);
+            hipLaunchKernelGGL(k_light_mask, dim3(grid_for(plan.nb)), dim3(kBlock), 0, stream, plan.nb, dp.slice_ptr.p, dp.col.p, dp.rowlen.p, comm->owner_mask(), light_ok.p);
+            light_ok_for = comm;
+        }
+        lightmask = light_ok.p;
+    }
     const S* pin_p = closed ? w.p.p : nullptr; const S* pin_r = closed ? w.r.p : nullptr;
     const S* zin_p = cpr ? w.z.p : pin_p; const S* zin_r = cpr ? w.z.p : pin_r;     // second-stage input of the last M^-1
     const int n0 = plan.level_ptr[1];
@@ -895,7 +938,7 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
         if (comm) halo<S>(comm, w.y.p, stream);
         lowrank_reduce<S>(w.y.p, d_ctl);
         hipLaunchKernelGGL((k_spmv<S, 1>), dim3(gs), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p, matrix<S>(),
-                           w.y.p, w.v.p, w.rt.p, mask, (const SolveCtl*)d_ctl, P_h, (double*)nullptr, pin_p, zin_p, n0, S(prm.ilu_relaxation), lowrank);
+                           w.y.p, w.v.p, w.rt.p, mask, (const SolveCtl*)d_ctl, P_h, (double*)nullptr, pin_p, zin_p, n0, S(prm.ilu_relaxation), lowrank, lightmask);
         double* a_h = P_h; int np_h = gs; none = nullptr;
         bridge(a_h, none, np_h, 1);
         hipLaunchKernelGGL((k_update_xr1<S>), dim3(gv), dim3(kBlock), 0, stream, n, j, eps, d_ctl, h_ctl_dev, (const double*)a_h, np_h, w.y.p, w.v.p,
@@ -906,7 +949,7 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
         if (comm) halo<S>(comm, w.y.p, stream);
         lowrank_reduce<S>(w.y.p, d_ctl);
         hipLaunchKernelGGL((k_spmv<S, 2>), dim3(gs), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p, matrix<S>(),
-                           w.y.p, w.t.p, w.r.p, mask, (const SolveCtl*)d_ctl, P_tr, P_tt, pin_r, zin_r, n0, S(prm.ilu_relaxation), lowrank);
+                           w.y.p, w.t.p, w.r.p, mask, (const SolveCtl*)d_ctl, P_tr, P_tt, pin_r, zin_r, n0, S(prm.ilu_relaxation), lowrank, lightmask);
         double* a_tr = P_tr; double* a_tt = P_tt; int np_t = gs;
         bridge(a_tr, a_tt, np_t, 3);
         hipLaunchKernelGGL((k_update_xr2<S>), dim3(gv), dim3(kBlock), 0, stream, n, j, d_ctl, h_ctl_dev, (const double*)a_n1, (const double*)a_tr,

@@ -133,6 +133,8 @@ public:
     int npart = 0;                 // entries per partial array
     CommBase* comm = nullptr;      // not owned; nullptr = single GPU
     LowRankOp lowrank;             // nw == 0: none
+    DevArray<int8_t> light_ok;     // multi-GPU: rows that keep the closed form (owned, no ghost neighbour)
+    const CommBase* light_ok_for = nullptr;
     template <class S> void lowrank_reduce(const S* x, const SolveCtl* ctl);
     bool closed_form_level0 = true; // k_spmv shortcut on level-0 rows (A/B switch: OPMGPU_CLOSED=0)
     bool cpr_speculate = false;     // CPR: enqueue the next iteration before the convergence result is known (A/B: OPMGPU_CPR_SPECULATE=1)
