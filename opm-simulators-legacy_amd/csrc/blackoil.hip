@@ -672,6 +672,7 @@ BlackoilDevice::BlackoilDevice(hipStream_t s, LinSolver& ls_, const opmgpu_grid*
     : prm(*prm_), stream(s), ls(ls_)
 {
     nc = g->nc; nconn = g->nconn; gravity = g->gravity;
+    n_owned_cells = nc;
     h_conn.assign(g->conn_cells, g->conn_cells + 2 * size_t(nconn));
     h_trans.assign(g->trans, g->trans + nconn);
     h_pv.assign(g->pv, g->pv + nc);
@@ -1037,6 +1038,8 @@ double BlackoilDevice::relative_change()
 void BlackoilDevice::attach_comm(CommBase* c, int n_owned)
 {
     ls.comm = c;
+    n_owned_cells = n_owned;
+    for (int32_t pc : h_well_cells) if (device_wells && pc >= n_owned) throw HipError(OPMGPU_EINVAL, "multi-GPU: a well perforates a ghost cell; keep every well on one rank");
     double loc[2] = { 0.0, double(n_owned) };
     for (int i = 0; i < n_owned; ++i) loc[0] += h_pv[i];
     OPMGPU_HIP(hipMemcpyAsync(d_red.p, loc, 2 * sizeof(double), hipMemcpyHostToDevice, stream));

@@ -58,6 +58,7 @@ public:
     int well_convergence(double* flux3, double* ctrl);
     void set_dbhp_max_rel(double v);
     bool device_wells = false;
+    int n_owned_cells = 0;            // multi-GPU: caller cells [0, n_owned) are owned (set by attach_comm), else nc
     double time_assemble(int reps, int props_only);
     void attach_comm(CommBase* c, int n_owned);
     const Plan& plan() const { return ls.plan; }

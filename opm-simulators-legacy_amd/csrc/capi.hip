@@ -247,7 +247,11 @@ int opmgpu_set_device_wells(opmgpu_ctx* c, const opmgpu_wells* wells)
     if (!c || !c->model || !wells) return OPMGPU_EINVAL;
     return guarded(c, [&]() {
         c->matrix_loaded = false;
-        if (c->comm && wells->nw > 0) return fail(c, OPMGPU_EINVAL, "wells are not supported in multi-GPU mode yet");
+        // multi-GPU: a well lives on ONE rank (the reference hands the wells to loadBalance for the same reason,
+        // RedistributeDataHandles.hpp:559-560): every perforated cell must be an owned cell of this rank
+        if (c->comm && wells->nw > 0 && wells->well_connpos && wells->well_cells)
+            for (int j = 0; j < wells->well_connpos[wells->nw]; ++j)
+                if (wells->well_cells[j] >= c->model->n_owned_cells) return fail(c, OPMGPU_EINVAL, "multi-GPU: a well perforates a ghost cell; keep every well on one rank");
         const int st = c->model->set_device_wells(wells);
         if (st != OPMGPU_OK) return fail(c, st, "invalid well specification (missing array, cell out of range or perforated twice)");
         return st;

@@ -466,21 +466,33 @@ void BlackoilDevice::wells_assemble(bool initial)
 // well part of getConvergence (BlackoilModelBase_impl.hpp:1769-1779): max |flux equation| per phase, max |control equation|
 int BlackoilDevice::well_convergence(double* flux3, double* ctrl)
 {
-    if (!wd) return OPMGPU_EINVAL;
-    WellsDev& W = *wd;
-    OPMGPU_HIP(hipMemcpyAsync(W.h_pinned, W.wellE.p, 4 * size_t(W.nw) * sizeof(double), hipMemcpyDeviceToHost, stream));
-    int32_t fl = 0;
-    OPMGPU_HIP(hipMemcpyAsync(&fl, W.flags.p, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-    OPMGPU_HIP(hipStreamSynchronize(stream));
+    if (!wd && !ls.comm) return OPMGPU_EINVAL;
     double f[3] = { 0, 0, 0 }, c = 0.0;
-    bool bad = false;
-    for (int w = 0; w < W.nw; ++w) {
-        for (int a = 0; a < 3; ++a) { const double e = std::fabs(W.h_pinned[4 * w + a]); if (!(e == e)) bad = true; f[a] = std::max(f[a], e); }
-        const double e = std::fabs(W.h_pinned[4 * w + 3]); if (!(e == e)) bad = true; c = std::max(c, e);
+    bool bad = false, singular = false;
+    if (wd) {
+        WellsDev& W = *wd;
+        OPMGPU_HIP(hipMemcpyAsync(W.h_pinned, W.wellE.p, 4 * size_t(W.nw) * sizeof(double), hipMemcpyDeviceToHost, stream));
+        int32_t fl = 0;
+        OPMGPU_HIP(hipMemcpyAsync(&fl, W.flags.p, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        OPMGPU_HIP(hipStreamSynchronize(stream));
+        for (int w = 0; w < W.nw; ++w) {
+            for (int a = 0; a < 3; ++a) { const double e = std::fabs(W.h_pinned[4 * w + a]); if (!(e == e)) bad = true; f[a] = std::max(f[a], e); }
+            const double e = std::fabs(W.h_pinned[4 * w + 3]); if (!(e == e)) bad = true; c = std::max(c, e);
+        }
+        if (fl & 2) { W.flags.zero(stream); singular = true; }
+    }
+    if (ls.comm) {      // collective: every rank calls it, also the ones without wells
+        double loc[6] = { f[0], f[1], f[2], c, bad ? 1.0 : 0.0, singular ? 1.0 : 0.0 };
+        OPMGPU_HIP(hipMemcpyAsync(d_red.p, loc, sizeof(loc), hipMemcpyHostToDevice, stream));
+        ls.comm->allreduce_max(d_red.p, 6, stream);
+        OPMGPU_HIP(hipMemcpyAsync(h_red, d_red.p, sizeof(loc), hipMemcpyDeviceToHost, stream));
+        OPMGPU_HIP(hipStreamSynchronize(stream));
+        for (int a = 0; a < 3; ++a) f[a] = h_red[a];
+        c = h_red[3]; bad = h_red[4] != 0.0; singular = h_red[5] != 0.0;
     }
     if (flux3) for (int a = 0; a < 3; ++a) flux3[a] = f[a];
     if (ctrl) *ctrl = c;
-    if (fl & 2) { W.flags.zero(stream); return OPMGPU_ESINGULAR; }
+    if (singular) return OPMGPU_ESINGULAR;
     return bad ? OPMGPU_ENUMERICAL : OPMGPU_OK;
 }
 

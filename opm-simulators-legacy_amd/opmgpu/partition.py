@@ -14,14 +14,16 @@ from . import capi
 from .decks import GridData, State
 
 
-def slab_partition(grid, nranks):
-    """Contiguous slabs of whole layers along the slowest (k) axis when the Cartesian dims are known,
-    else contiguous index ranges.  Returns part[cell] = owner rank."""
+def slab_partition(grid, nranks, axis=2):
+    """Contiguous slabs of whole layers along `axis` (default: the slowest, k) when the Cartesian dims are known, else
+    contiguous index ranges.  axis = 1 (slabs of whole j-rows) keeps vertical wells on one rank -- the reference hands the
+    wells to loadBalance for the same reason (RedistributeDataHandles.hpp:559-560).  Returns part[cell] = owner rank."""
     n = grid.nc
     if grid.dims is not None and grid.dims[0] * grid.dims[1] * grid.dims[2] == n:
         nx, ny, nz = grid.dims
-        layer_owner = (np.arange(nz) * nranks) // nz
-        return np.repeat(layer_owner, nx * ny).astype(np.int32)
+        i, j, k = np.arange(n) % nx, (np.arange(n) // nx) % ny, np.arange(n) // (nx * ny)
+        coord, extent = ((i, nx), (j, ny), (k, nz))[axis]
+        return ((coord.astype(np.int64) * nranks) // extent).astype(np.int32)
     return ((np.arange(n, dtype=np.int64) * nranks) // n).astype(np.int32)
 
 
@@ -66,6 +68,27 @@ class LocalDomain:
         self.recv_ptr, self.send_ptr = capi.i32(recv_ptr), capi.i32(send_ptr)
         self.recv_cells = capi.i32(self.n_owned + np.arange(ghosts.size))          # ghosts are already grouped by owner
         self.send_cells = capi.i32(np.concatenate(send_cells) if send_cells else np.zeros(0, np.int64))
+
+    def local_wells(self, wells, part):
+        """The wells of this rank in rank-local cell numbering: a well belongs to the rank that owns ALL of its perforated
+        cells (ValueError if a well straddles ranks: choose a partition that keeps wells intact)."""
+        from .wells import Wells
+        g2l = -np.ones(part.size, dtype=np.int64)
+        g2l[self.global_of_local] = np.arange(self.global_of_local.size)
+        out = Wells()
+        self.well_index = []
+        for w in range(wells.nw):
+            cells = np.asarray(wells.cells[wells.connpos[w]:wells.connpos[w + 1]])
+            owners = np.unique(part[cells])
+            if owners.size != 1:
+                raise ValueError("well %s straddles ranks %s" % (wells.name[w], owners.tolist()))
+            if owners[0] != self.rank:
+                continue
+            ctrl = (wells.ctrl_type[w], wells.ctrl_target[w], wells.ctrl_distr[w])
+            out.add_well(wells.name[w], wells.type[w], wells.depth_ref[w], g2l[cells], wells.WI[wells.connpos[w]:wells.connpos[w + 1]],
+                         wells.comp_frac[w], ctrl, allow_cf=wells.allow_cf[w])
+            self.well_index.append(w)
+        return out
 
     def local_state(self, st):
         g = self.global_of_local

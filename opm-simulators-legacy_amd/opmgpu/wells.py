@@ -356,12 +356,16 @@ class DeviceWellModel:
     def push_well_state(self):
         from . import capi
         m, ws = self.m, self.ws
+        if self.w.nw == 0:          # a rank without wells (multi-GPU): nothing to upload, the convergence call stays collective
+            return
         m._chk(m.lib.opmgpu_well_state_set(m.ctx, capi.dptr(capi.f64(ws.bhp)), capi.dptr(capi.f64(ws.qs)), capi.dptr(capi.f64(ws.perf_rates))))
 
     def pull_well_state(self):
         """device well state -> the WellState object (bhp, wellRates, perfPress, perfPhaseRates)"""
         from . import capi
         m, ws = self.m, self.ws
+        if self.w.nw == 0:
+            return ws
         bhp, qs = np.zeros(self.w.nw), np.zeros((self.w.nw, 3))
         pp, pr = np.zeros(self.w.nperf), np.zeros((self.w.nperf, 3))
         m._chk(m.lib.opmgpu_well_state_get(m.ctx, capi.dptr(bhp), capi.dptr(qs), capi.dptr(pp), capi.dptr(pr)))

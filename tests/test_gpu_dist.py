@@ -97,3 +97,49 @@ def test_self_halo_reproduces_plain_grid(gpu_lib, oracle, single, cpr):
             # ghost state stays a copy of the owner's state without any state exchange
             assert np.array_equal(sb.p[n:], sb.p[src[n:]]) and np.array_equal(sb.sat[n:], sb.sat[src[n:]]) and np.array_equal(sb.hc[n:], sb.hc[src[n:]])
     A.close(); B.close()
+
+
+@pytest.mark.parametrize("cpr", [0, 1])
+def test_self_halo_with_device_wells(gpu_lib, cpr):
+    """Wells in multi-GPU mode live on one rank (all perforated cells owned): the one-rank decomposition with ghost copies and
+    device wells must walk the same Newton path as the plain periodic grid with the same wells."""
+    from opmgpu import wells as W
+    gridA, gridB, src, halo = _periodic_pair(nx=6, ny=5, nz=5)
+    tab = decks.satfunc_standard_tables()
+    stA = decks.initial_state(gridA, tab, perturb=0.005)
+    stB = decks.State(stA.p[src], stA.sat[src], stA.rs[src], stA.rv[src], stA.hc[src])
+    n, L = gridA.nc, 30
+    wl = W.Wells()
+    WI = 5.0 * float(np.median(gridA.trans))
+    inj = [7 + L * k for k in range(0, 3)]            # includes the k = 0 layer: rows next to ghost cells
+    prod = [22 + L * k for k in range(2, 5)]          # includes the top layer
+    wl.add_well("INJ", W.INJECTOR, gridA.z[inj[0]], inj, WI, (1.0, 0.0, 0.0), (W.SURFACE_RATE, 20.0 / 86400.0, (1.0, 0.0, 0.0)))
+    wl.add_well("PROD", W.PRODUCER, gridA.z[prod[0]], prod, WI, (0.0, 1.0, 0.0), (W.BHP, 150 * decks.BAR))
+    prm = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=500, use_cpr=cpr)
+    A = GpuBlackoilModel(gridA, tab, prm)
+    B = GpuBlackoilModel(gridB, tab, prm)
+    dom = _Dom()
+    for k, v in halo.items():
+        setattr(dom, k, v)
+    partition.attach_comm(B, dom, 0, 1, partition.make_unique_id())
+    mA = W.DeviceWellModel(A, wl, W.WellState(wl, stA.p))
+    mB = W.DeviceWellModel(B, wl, W.WellState(wl, stB.p))       # local ids == global ids for owned cells here
+    dt = 2 * decks.DAY
+    mA.prepareStep(dt, stA); mB.prepareStep(dt, stB)
+    for it in range(4):
+        cA, _ = mA.nonlinearIteration(it, single_precision=False)
+        cB, _ = mB.nonlinearIteration(it, single_precision=False)
+        assert cA == cB, it
+        assert np.allclose(mA.well_flux_residual, mB.well_flux_residual, rtol=1e-5, atol=1e-12)
+        sa, sb = A.getState(), B.getState()
+        wa, wb = mA.pull_well_state(), mB.pull_well_state()
+        assert np.array_equal(sa.hc, sb.hc[:n]), it
+        assert np.abs(sa.p - sb.p[:n]).max() <= 1e-6 * np.abs(sa.p).max() and np.abs(sa.sat - sb.sat[:n]).max() <= 1e-6, it
+        assert np.allclose(wa.bhp, wb.bhp, rtol=1e-7) and np.allclose(wa.qs, wb.qs, rtol=1e-6, atol=1e-9 * np.abs(wa.qs).max()), it
+        assert np.array_equal(sb.p[n:], sb.p[src[n:]])            # ghost state still a copy of its owner's
+    # a well that perforates a ghost cell is refused
+    bad = W.Wells()
+    bad.add_well("BAD", W.PRODUCER, gridB.z[0], [0, n + 1], WI, (0.0, 1.0, 0.0), (W.BHP, 150 * decks.BAR))
+    with pytest.raises(ValueError, match="ghost"):
+        W.DeviceWellModel(B, bad, W.WellState(bad, stB.p))
+    A.close(); B.close()

@@ -111,3 +111,28 @@ def test_spe1_like_well_driven_newton_on_cpu(oracle):
         assert abs(ws.qs[0, 0] - 2000.0 / 86400.0) <= 1e-9 and ws.qs[1, 1] < 0          # injects water at target, produces oil
         assert abs(ws.bhp[1] - 200 * decks.BAR) < 1e-3
         model.prepareStep(dt)
+
+
+def test_partition_keeps_wells_on_one_rank():
+    """slab_partition(axis=1) + LocalDomain.local_wells: vertical wells of a 5-spot stay intact with slabs of j-rows, each well
+    belongs to exactly one rank in that rank's local numbering; slabs of k-layers would cut them (refused)."""
+    import pytest
+    from opmgpu import partition
+    grid = decks.cartesian_grid(10, 12, 4)
+    wl = W.five_spot(grid)
+    part = partition.slab_partition(grid, 3, axis=1)
+    assert np.array_equal(np.unique(part), [0, 1, 2])
+    seen = []
+    for r in range(3):
+        dom = partition.LocalDomain(grid, part, r)
+        lw = dom.local_wells(wl, part)
+        for k, w in enumerate(dom.well_index):
+            loc = np.asarray(lw.cells[lw.connpos[k]:lw.connpos[k + 1]])
+            assert np.all(loc < dom.n_owned)
+            assert np.array_equal(dom.global_of_local[loc], wl.cells[wl.connpos[w]:wl.connpos[w + 1]])
+            assert lw.ctrl_type[k] == wl.ctrl_type[w] and lw.ctrl_target[k] == wl.ctrl_target[w]
+        seen += dom.well_index
+    assert sorted(seen) == list(range(wl.nw))
+    part_k = partition.slab_partition(grid, 2, axis=2)
+    with pytest.raises(ValueError, match="straddles"):
+        partition.LocalDomain(grid, part_k, 0).local_wells(wl, part_k)
