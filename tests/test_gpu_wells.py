@@ -119,3 +119,45 @@ def test_device_wells_five_spot_vs_host_wells(gpu_lib, single):
         mh.prepareStep(dt); md.prepareStep(dt)
     assert ws.qs[0, 0] > 0 and (ws.qs[1:, 1] < 0).all()
     gh.close(); gd.close()
+
+
+def test_waterflood_material_balance_through_adaptive_stepping(gpu_lib, oracle):
+    """End to end on the device: SPE1-like deck, device wells, NonlinearSolver with update stabilisation, AdaptiveTimeStepping over
+    a 30-day report step.  Physics check that needs no reference solver: for every converged sub-step the change of each
+    component's surface volume in place equals dt times the wells' surface rates (implicit Euler), to the Newton tolerance."""
+    from opmgpu import timestepping as ts
+    from opmgpu.model import NonlinearSolver
+    grid, tab, st, wl = _setup()
+    # tight tolerances: the default ones (MB 1e-5 of the pore volume, wells 1e-4 m3/s) allow hundreds of m3 of imbalance per step
+    prm = capi.default_params(use_cpr=1, tolerance_mb=1e-10, tolerance_cnv=1e-6, linear_solver_reduction=1e-8, linear_solver_maxiter=300)
+    gm = GpuBlackoilModel(grid, tab, prm)
+    model = W.DeviceWellModel(gm, wl, W.WellState(wl, st.p), tolerance_wells=1e-9, tolerance_well_control=1e-9)
+    gm.setState(st)
+    names = oracle.PROP_NAMES
+
+    def in_place():
+        props = oracle.cell_props(grid, tab, gm.getState())
+        return np.array([(props[:, names.index("accum_" + c), 0] * grid.pv).sum() for c in "wog"])
+
+    class Recorder:                      # wraps the solver: records (dt, volumes before/after, well rates) of every converged sub-step
+        def __init__(self):
+            self.inner, self.steps = NonlinearSolver(), []
+
+        def step(self, m):
+            before = in_place()
+            out = self.inner.step(m, single_precision=False)
+            ws = model.pull_well_state()
+            self.steps.append((m.m.dt, before, in_place(), ws.qs.copy()))
+            return out
+
+    rec = Recorder()
+    ats = ts.AdaptiveTimeStepping(initial_timestep_days=1.0)
+    rep = ats.step(0.0, 30 * decks.DAY, rec, model)
+    assert rep["converged"] and len(rep["substeps"]) >= 3 and sum(rep["substeps"]) == pytest.approx(30 * decks.DAY)
+    inj_rate = 2000.0 / 86400.0
+    for dt, before, after, qs in rec.steps[-len(rep["substeps"]):]:
+        net = qs.sum(axis=0) * dt                                        # surface volumes added by all wells, per component
+        scale = inj_rate * dt
+        assert np.all(np.abs((after - before) - net) <= 1e-5 * np.array([scale, scale, 200 * scale])), (dt / decks.DAY, after - before, net)
+        assert abs(qs[0, 0] - inj_rate) <= 1e-9 and qs[1, 1] < 0
+    gm.close()
