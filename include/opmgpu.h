@@ -124,6 +124,9 @@ typedef struct opmgpu_params {
     int32_t use_cpr;                /* 0 = block-ILU0 (solver_approach=interleaved, the default, FlowMain.hpp:806-830);
                                        1 = CPR: AMG V-cycle on the pressure system + block-ILU0
                                            (solver_approach=cpr, NewtonIterationBlackoilCPR.cpp:79-185)     */
+    int32_t newton_use_gmres;       /* 0 = BiCGStab; 1 = Dune::RestartedGMResSolver (ISTLSolver.hpp:257-264): left-preconditioned
+                                       restarted GMRES, modified Gram-Schmidt; single GPU                    */
+    int32_t linear_solver_restart;  /* 40     */
 } opmgpu_params;
 
 void opmgpu_default_params(opmgpu_params* p);

@@ -76,7 +76,7 @@ template <class S> int solve_loaded(opmgpu_ctx* c, bool matrix_changed, SolveRes
     const int st = ls.factor<S>();
     if (st != OPMGPU_OK) return fail(c, st, "singular diagonal block in ILU0");
     c->factored = true;
-    res = ls.bicgstab<S>(c->prm);
+    res = c->prm.newton_use_gmres ? ls.gmres<S>(c->prm) : ls.bicgstab<S>(c->prm);
     if (res.status == OPMGPU_ELINSOLVE) c->err = "Convergence failure for linear solver.";
     if (res.status == OPMGPU_EBREAKDOWN) c->err = "breakdown in BiCGSTAB";
     return res.status;
@@ -103,6 +103,7 @@ void opmgpu_default_params(opmgpu_params* p)
     p->matbalscale[0] = 1.1169; p->matbalscale[1] = 1.0031; p->matbalscale[2] = 0.0031;   // BlackoilModelBase_impl.hpp:139
     p->linear_solver_reduction = 1e-2; p->linear_solver_maxiter = 150;                    // FlowLinearSolverParameters
     p->ilu_relaxation = 0.9; p->ilu_ordering = OPMGPU_ORDER_MULTICOLOR; p->ignore_convergence_failure = 0; p->use_cpr = 0;
+    p->newton_use_gmres = 0; p->linear_solver_restart = 40;                                // NewtonIterationBlackoilCPR.cpp:61-64
 }
 
 int opmgpu_create_solver(opmgpu_ctx** ctx, int device, const opmgpu_params* params) { return make_ctx(ctx, device, params); }

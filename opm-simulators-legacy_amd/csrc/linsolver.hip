@@ -988,6 +988,179 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
     return res;
 }
 
+// ---- restarted GMRES (Dune::RestartedGMResSolver::apply, reached from ISTLSolver.hpp:257-264 with newton_use_gmres) ----
+// LEFT-preconditioned: the residual it measures is M^-1 (b - A x).  Arnoldi with modified Gram-Schmidt: every projection is a
+// k_dot launch whose partials the following k_gm_axpy re-reduces (no reduction launches, deterministic); the Hessenberg
+// column, the Givens rotations and the convergence test live on the device (k_gm_givens, one thread), the host only reads the
+// mapped status block once per iteration like the CPR path does.
+struct GmState { double* H; double* s; double* cs; double* sn; double* y; };      // H[(m+1) x m] row-major, all double
+
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_gm_axpy(long n, int slot, const double* __restrict__ parts, int np, double* __restrict__ H,
+                                                    const S* __restrict__ vk, S* __restrict__ w, const SolveCtl* __restrict__ ctl)
+{
+    __shared__ double sm[12];
+    if (ctl->done) return;
+    const double* const arr[1] = { parts };
+    double s[1];
+    reduce_partials<1>(arr, np, s, sm);
+    if (blockIdx.x == 0 && threadIdx.x == 0) H[slot] = s[0];
+    const S h = S(s[0]);
+    for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) w[i] -= h * vk[i];
+}
+// vout = w / ||w|| with ||w||^2 in parts; slot >= 0: H[slot] = ||w|| (breakdown flag if ~0); slot < 0: the restart normalisation,
+// s[0] = ||w|| and, at the very first one (first != 0), the convergence threshold
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_gm_normalize(long n, int slot, int first, double red, const double* __restrict__ parts, int np,
+                                                         double* __restrict__ H, double* __restrict__ s0, const S* __restrict__ w, S* __restrict__ vout,
+                                                         SolveCtl* __restrict__ ctl, SolveCtl* __restrict__ hst)
+{
+    __shared__ double sm[12];
+    if (ctl->done) return;
+    const double* const arr[1] = { parts };
+    double s[1];
+    reduce_partials<1>(arr, np, s, sm);
+    const double nrm = sqrt(s[0]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (slot >= 0) H[slot] = nrm; else { s0[0] = nrm; ctl->norm2 = s[0]; }
+        if (first) { ctl->norm0_2 = s[0]; ctl->norm2 = s[0]; ctl->thresh2 = red * red * s[0]; }
+    }
+    if (!(nrm == nrm) || nrm < 1e-80) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (first && nrm == nrm) { ctl->iters = 0; ctl->done = 1; }            // zero right-hand side: converged at once
+            else { ctl->flag = 2; ctl->done = 1; }                                   // breakdown in GMRes - |w| == 0
+            publish(ctl, hst);
+        }
+        return;
+    }
+    const S inv = S(1.0 / nrm);
+    for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) vout[i] = w[i] * inv;
+}
+// column i of the Hessenberg matrix: previous rotations, new rotation (dune generatePlaneRotation / applyPlaneRotation), |s[i+1]|
+__global__ void k_gm_givens(int i, int m, int j, GmState g, SolveCtl* __restrict__ ctl, SolveCtl* __restrict__ hst)
+{
+    if (ctl->done) return;
+    double* H = g.H;
+    auto rot = [](double& dx, double& dy, double c, double sN) { const double t = c * dx + sN * dy; dy = -sN * dx + c * dy; dx = t; };
+    for (int k = 0; k < i; ++k) rot(H[k * m + i], H[(k + 1) * m + i], g.cs[k], g.sn[k]);
+    const double dx = H[i * m + i], dy = H[(i + 1) * m + i];
+    const double ndx = fabs(dx), ndy = fabs(dy);
+    double c, sN;
+    if (ndy < 1e-15) { c = 1.0; sN = 0.0; }
+    else if (ndx < 1e-15) { c = 0.0; sN = 1.0; }
+    else if (ndy > ndx) { const double t = ndx / ndy; c = 1.0 / sqrt(1.0 + t * t); sN = c; c *= t; sN *= dx / ndx; sN *= dy / ndy; }
+    else { const double t = ndy / ndx; c = 1.0 / sqrt(1.0 + t * t); sN = c * (dy / dx); }
+    g.cs[i] = c; g.sn[i] = sN;
+    rot(H[i * m + i], H[(i + 1) * m + i], c, sN);
+    rot(g.s[i], g.s[i + 1], c, sN);
+    const double nrm = fabs(g.s[i + 1]);
+    ctl->norm2 = nrm * nrm;
+    ctl->iters = j;
+    if (nrm * nrm < ctl->thresh2) { ctl->done = 1; ctl->decided = j; }
+    publish(ctl, hst);
+}
+// y = R^-1 s (back-substitution over the first cnt columns)
+__global__ void k_gm_solve_y(int cnt, int m, GmState g)
+{
+    for (int a = cnt - 1; a >= 0; --a) {
+        double rhs = g.s[a];
+        for (int b = a + 1; b < cnt; ++b) rhs -= g.H[a * m + b] * g.y[b];
+        g.y[a] = rhs / g.H[a * m + a];
+    }
+}
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_gm_update_x(long n, int cnt, const double* __restrict__ y, const S* __restrict__ kry, S* __restrict__ x)
+{
+    for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) {
+        S acc = 0;
+        for (int a = cnt - 1; a >= 0; --a) acc += S(y[a]) * kry[long(a) * n + i];       // the order of dune's update(): a = i-1 .. 0
+        x[i] += acc;
+    }
+}
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_gm_defect(long n, const S* __restrict__ b, const S* __restrict__ ax, S* __restrict__ out)
+{
+    for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) out[i] = b[i] - ax[i];
+}
+__global__ void k_gm_reset_s(int m, GmState g) { for (int i = 1; i < m + 1; ++i) g.s[i] = 0.0; }
+
+template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
+{
+    SolveResult res;
+    if (comm) { res.status = OPMGPU_EINVAL; return res; }            // single GPU (the projections would need one all-reduce each)
+    SolverWork<S>& w = work<S>();
+    const long n = long(3) * plan.nbp;
+    const int gv = std::min(grid_for(n), kMaxPart);
+    const int m = std::max(1, int(prm.linear_solver_restart));
+    const int maxit = prm.linear_solver_maxiter;
+    const bool cpr = prm.use_cpr != 0;
+    if (cpr) cpr_prepare<S>();
+    w.kry.alloc(size_t(m + 1) * n);
+    gmbuf.alloc(size_t(m + 1) * m + (m + 1) + 3 * m + 8);
+    gmbuf.zero(stream);
+    GmState g; g.H = gmbuf.p; g.s = g.H + size_t(m + 1) * m; g.cs = g.s + (m + 1); g.sn = g.cs + m; g.y = g.sn + m;
+    double* parts = partials.p;
+    SolveCtl* d_ctl = ctl.p;
+    auto V = [&](int k) { return w.kry.p + size_t(k) * n; };
+    auto precond = [&](const S* d, S* out) { if (cpr) cpr_apply<S>(d, out, prm.ilu_relaxation, d_ctl); else ilu_apply<S>(d, out, prm.ilu_relaxation, d_ctl); };
+    auto normalize_start = [&](int first) {          // v0 = M^-1 defect (in w.t), then v0 /= ||v0||, s[0] = ||v0||
+        hipLaunchKernelGGL((k_dot<S>), dim3(gv), dim3(kBlock), 0, stream, n, w.t.p, w.t.p, parts);
+        hipLaunchKernelGGL((k_gm_normalize<S>), dim3(gv), dim3(kBlock), 0, stream, n, -1, first, prm.linear_solver_reduction, (const double*)parts, gv,
+                           g.H, g.s, (const S*)w.t.p, V(0), d_ctl, h_ctl_dev);
+        hipLaunchKernelGGL(k_gm_reset_s, dim3(1), dim3(1), 0, stream, m, g);
+    };
+    // x0 = 0: defect = b
+    w.x.zero(stream);
+    hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(1), 0, stream, d_ctl, h_ctl_dev, prm.linear_solver_reduction);
+    precond(w.b.p, w.t.p);
+    normalize_start(1);
+    OPMGPU_HIP(hipStreamSynchronize(stream));
+    int j = 1;
+    bool stop = h_ctl->done != 0;
+    while (j <= maxit && !stop) {
+        int i = 0;
+        for (; i < m && j <= maxit && !stop; ++i, ++j) {
+            lowrank_reduce<S>(V(i), d_ctl);
+            hipLaunchKernelGGL((k_spmv<S, 0>), dim3(std::min(grid8_for(plan.nb), 4 * kMaxPart)), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp,
+                               dp.slice_ptr.p, dp.col.p, matrix<S>(), (const S*)V(i), w.v.p, (const S*)nullptr, (const int8_t*)nullptr, (const SolveCtl*)d_ctl,
+                               (double*)nullptr, (double*)nullptr, (const S*)nullptr, (const S*)nullptr, 0, S(0), lowrank, (const int8_t*)nullptr);
+            precond(w.v.p, w.t.p);                                     // w = M^-1 A v_i
+            for (int k = 0; k <= i; ++k) {
+                hipLaunchKernelGGL((k_dot<S>), dim3(gv), dim3(kBlock), 0, stream, n, (const S*)V(k), (const S*)w.t.p, parts);
+                hipLaunchKernelGGL((k_gm_axpy<S>), dim3(gv), dim3(kBlock), 0, stream, n, k * m + i, (const double*)parts, gv, g.H, (const S*)V(k), w.t.p,
+                                   (const SolveCtl*)d_ctl);
+            }
+            hipLaunchKernelGGL((k_dot<S>), dim3(gv), dim3(kBlock), 0, stream, n, w.t.p, w.t.p, parts);
+            hipLaunchKernelGGL((k_gm_normalize<S>), dim3(gv), dim3(kBlock), 0, stream, n, (i + 1) * m + i, 0, 0.0, (const double*)parts, gv, g.H, g.s,
+                               (const S*)w.t.p, V(i + 1), d_ctl, h_ctl_dev);
+            hipLaunchKernelGGL(k_gm_givens, dim3(1), dim3(1), 0, stream, i, m, j, g, d_ctl, h_ctl_dev);
+            OPMGPU_HIP(hipStreamSynchronize(stream));
+            if (h_ctl->done) stop = true;
+        }
+        if (h_ctl->flag != 0) break;                                   // breakdown: dune throws, no update
+        // x += sum_a y_a v_a with R y = s   (i columns were completed)
+        hipLaunchKernelGGL(k_gm_solve_y, dim3(1), dim3(1), 0, stream, i, m, g);
+        hipLaunchKernelGGL((k_gm_update_x<S>), dim3(gv), dim3(kBlock), 0, stream, n, i, (const double*)g.y, (const S*)w.kry.p, w.x.p);
+        if (!stop && j <= maxit) {                                     // restart from the true defect
+            lowrank_reduce<S>(w.x.p, nullptr);
+            hipLaunchKernelGGL((k_spmv<S, 0>), dim3(std::min(grid8_for(plan.nb), 4 * kMaxPart)), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp,
+                               dp.slice_ptr.p, dp.col.p, matrix<S>(), (const S*)w.x.p, w.v.p, (const S*)nullptr, (const int8_t*)nullptr, (const SolveCtl*)nullptr,
+                               (double*)nullptr, (double*)nullptr, (const S*)nullptr, (const S*)nullptr, 0, S(0), lowrank, (const int8_t*)nullptr);
+            hipLaunchKernelGGL((k_gm_defect<S>), dim3(gv), dim3(kBlock), 0, stream, n, (const S*)w.b.p, (const S*)w.v.p, w.r.p);
+            precond(w.r.p, w.t.p);
+            normalize_start(0);
+        }
+    }
+    OPMGPU_HIP(hipStreamSynchronize(stream));
+    const double norm0 = std::sqrt(h_ctl->norm0_2), norm = std::sqrt(h_ctl->norm2);
+    res.converged = h_ctl->done && h_ctl->flag == 0;
+    res.iterations = j - 1;
+    res.reduction = norm0 > 0 ? norm / norm0 : 0.0;
+    if (h_ctl->flag != 0 || !(norm0 == norm0)) res.status = OPMGPU_EBREAKDOWN;
+    else if (!res.converged && !prm.ignore_convergence_failure) res.status = OPMGPU_ELINSOLVE;
+    return res;
+}
+
 template <class S> void LinSolver::vec_in(const double* dsrc, int layout, S* d)
 {
     hipLaunchKernelGGL((k_vec_in<S>), dim3(grid_for(plan.nb)), dim3(kBlock), 0, stream, plan.nb, plan.nbp, layout, dp.nat.p, dsrc, d);
@@ -1090,6 +1263,7 @@ double LinSolver::time_kernel(int kernel, int reps, int single_precision)
     template void LinSolver::cpr_prepare<S>();                                           \
     template void LinSolver::cpr_apply<S>(const S*, S*, double, const SolveCtl*);        \
     template SolveResult LinSolver::bicgstab<S>(const opmgpu_params&);                   \
+    template SolveResult LinSolver::gmres<S>(const opmgpu_params&);                      \
     template void LinSolver::vec_from_host<S>(const double*, int, S*);                   \
     template void LinSolver::vec_to_host<S>(const S*, int, double*);                     \
     template void LinSolver::vec_in<S>(const double*, int, S*);                          \

@@ -66,6 +66,7 @@ struct SolverWork {
     DevArray<S> A;      // float copy of the matrix (unused for double: the double matrix is used in place)
     DevArray<S> LU;
     DevArray<S> r, rt, p, v, t, y, x, b, z, hx;  // z: scratch of the CPR second stage; hx: halo staging of x_p (multi-GPU)
+    DevArray<S> kry;                             // GMRES: Krylov basis, (restart + 1) vectors
     DevArray<S> cprw;                            // [3][nbp] per-cell weights of the pressure equation (formEllipticSystem)
     std::unique_ptr<AmgHierarchy<S>> amg;         // CPR pressure stage (built on first use)
     bool allocated = false;
@@ -101,6 +102,7 @@ public:
     template <class S> void cpr_apply(const S* d, S* v, double relax, const SolveCtl* ctl);
     // x0 = 0; rhs in work<S>().b; solution in work<S>().x
     template <class S> SolveResult bicgstab(const opmgpu_params& prm);
+    template <class S> SolveResult gmres(const opmgpu_params& prm);      // newton_use_gmres: restarted, left-preconditioned (single GPU)
 
     // host <-> device vector staging (caller numbering <-> internal, component-major planes)
     template <class S> void vec_from_host(const double* h, int layout, S* d);
@@ -125,6 +127,7 @@ public:
     DevArray<double> stage;        // host-BSR staging / vector staging
     DevArray<double> partials;     // 6 partial arrays of npart doubles + 8 all-reduced scalars
     DevArray<int32_t> flags;
+    DevArray<double> gmbuf;        // GMRES: Hessenberg matrix, s, cs, sn, y
     SolveCtl* h_ctl = nullptr;     // host-mapped status copy (device publishes, host polls after an event)
     SolveCtl* h_ctl_dev = nullptr; // device alias of h_ctl
     DevArray<SolveCtl> ctl;        // device-resident control block read by every kernel

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(kBlock) void k_well_assemble(WellArgs A, const int3
         for (int a = 0; a < 3; ++a) cq_s[a] = f.cq_ps[a] + cm[a] * cqt_is;                                          // :553-560
         const int row = A.perf_row[j];
         MS* dptr = Amat + long(slice_ptr[row >> 6] + nlower[row]) * 576 + (row & 63);
-        double* Pj = A.P + 21 * long(j); double* Qj = A.Q + 21 * long(j); double* Fs = A.Fsave + 21 * long(j);
+        double* Qj = A.Q + 21 * long(j); double* Fs = A.Fsave + 21 * long(j);
         // H = d cq_ps / d cell, G = d cmix / d cell = (-H + cmix (1^T H)) / wbqt
         for (int v = 0; v < 3; ++v) {
             const double hs = f.cq_ps[0].d[v] + f.cq_ps[1].d[v] + f.cq_ps[2].d[v];
@@ -222,7 +222,6 @@ __global__ __launch_bounds__(kBlock) void k_well_assemble(WellArgs A, const int3
             }
         }
         A.perf_press[j] = bhp + A.cdp[j];
-        (void)Pj;
     }
     __syncthreads();
     block_sum<15>(acc2, sm);

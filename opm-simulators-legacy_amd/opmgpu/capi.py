@@ -60,7 +60,8 @@ class Params(C.Structure):
                 ("tolerance_cnv", C.c_double), ("matbalscale", C.c_double * 3),
                 ("linear_solver_reduction", C.c_double), ("linear_solver_maxiter", C.c_int32),
                 ("ilu_relaxation", C.c_double), ("ilu_ordering", C.c_int32),
-                ("ignore_convergence_failure", C.c_int32), ("use_cpr", C.c_int32)]
+                ("ignore_convergence_failure", C.c_int32), ("use_cpr", C.c_int32),
+                ("newton_use_gmres", C.c_int32), ("linear_solver_restart", C.c_int32)]
 
 
 def default_params(**over):
@@ -71,6 +72,7 @@ def default_params(**over):
     p.matbalscale[:] = [1.1169, 1.0031, 0.0031]
     p.linear_solver_reduction, p.linear_solver_maxiter = 1e-2, 150
     p.ilu_relaxation, p.ilu_ordering, p.ignore_convergence_failure, p.use_cpr = 0.9, ORDER_MULTICOLOR, 0, 0
+    p.newton_use_gmres, p.linear_solver_restart = 0, 40
     for k, v in over.items():
         if k == "matbalscale":
             p.matbalscale[:] = list(v)

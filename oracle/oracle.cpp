@@ -631,6 +631,92 @@ int bicgstab_t(int nb, const int32_t* rowptr, const int32_t* col, const double* 
     return OPMGPU_OK;
 }
 
+// Dune::RestartedGMResSolver::apply (dune-istl, external; restated from the published algorithm): LEFT-preconditioned restarted
+// GMRES -- the residual it measures is the preconditioned one, W^-1 (b - A x) --, Arnoldi with modified Gram-Schmidt, Givens
+// rotations (generatePlaneRotation / applyPlaneRotation), update by back-substitution.  Reached from ISTLSolver.hpp:257-264.
+template <class S>
+int gmres_t(int nb, const int32_t* rowptr, const int32_t* col, const double* val9, const double* rhs3,
+            const int32_t* position, const opmgpu_params* prm, double* x3, int* iters, double* reduction)
+{
+    const int n = 3 * nb;
+    IluData<S> D;
+    const int st = ilu0_setup<S>(nb, rowptr, col, val9, position, D);
+    if (st != OPMGPU_OK) return st;
+    std::vector<S> A(size_t(rowptr[nb]) * 9);
+    for (size_t k = 0; k < A.size(); ++k) A[k] = S(val9[k]);
+    const int m = std::max(1, int(prm->linear_solver_restart));
+    const S relax = S(prm->ilu_relaxation), red = S(prm->linear_solver_reduction);
+    const int maxit = prm->linear_solver_maxiter;
+    const S EPS = S(1e-80);
+    std::vector<S> x(n, S(0)), b(n), b2(n), w(n), tmp(n);
+    for (int i = 0; i < n; ++i) b[i] = S(rhs3[i]);
+    b2 = b;
+    std::vector<std::vector<S> > v(m + 1, std::vector<S>(n, S(0))), H(m + 1, std::vector<S>(m, S(0)));
+    std::vector<S> s(m + 1), cs(m), sn(m);
+    auto precond = [&](const std::vector<S>& d, std::vector<S>& out) { std::fill(out.begin(), out.end(), S(0)); ilu0_apply(D, col, relax, d.data(), out.data()); };
+    auto gen = [](S dx, S dy, S& c, S& sN) {
+        const S ndx = std::fabs(dx), ndy = std::fabs(dy);
+        if (ndy < S(1e-15)) { c = 1; sN = 0; }
+        else if (ndx < S(1e-15)) { c = 0; sN = 1; }
+        else if (ndy > ndx) { const S t = ndx / ndy; c = S(1) / std::sqrt(S(1) + t * t); sN = c; c *= t; sN *= dx / ndx; sN *= dy / ndy; }
+        else { const S t = ndy / ndx; c = S(1) / std::sqrt(S(1) + t * t); sN = c * (dy / dx); }
+    };
+    auto rot = [](S& dx, S& dy, S c, S sN) { const S t = c * dx + sN * dy; dy = -sN * dx + c * dy; dx = t; };
+    // x0 = 0: defect = b; preconditioned defect
+    precond(b, v[0]);
+    S norm = std::sqrt(dot_t(n, v[0].data(), v[0].data()));
+    const S norm0 = norm;
+    bool converged = false;
+    int j = 1, status = OPMGPU_OK;
+    if (norm0 < EPS) converged = true;
+    while (j <= maxit && !converged && status == OPMGPU_OK) {
+        int i = 0;
+        for (int q = 0; q < n; ++q) v[0][q] *= S(1) / norm;
+        s[0] = norm;
+        for (i = 1; i < m + 1; ++i) s[i] = 0;
+        for (i = 0; i < m && j <= maxit && !converged; ++i, ++j) {
+            spmv_t(nb, rowptr, col, A.data(), v[i].data(), tmp.data());
+            precond(tmp, w);
+            for (int k = 0; k < i + 1; ++k) {
+                H[k][i] = dot_t(n, v[k].data(), w.data());
+                axpy_t(n, -H[k][i], v[k].data(), w.data());
+            }
+            H[i + 1][i] = std::sqrt(dot_t(n, w.data(), w.data()));
+            if (std::fabs(H[i + 1][i]) < EPS) { status = OPMGPU_EBREAKDOWN; break; }
+            for (int q = 0; q < n; ++q) v[i + 1][q] = w[q] * (S(1) / H[i + 1][i]);
+            for (int k = 0; k < i; ++k) rot(H[k][i], H[k + 1][i], cs[k], sn[k]);
+            gen(H[i][i], H[i + 1][i], cs[i], sn[i]);
+            rot(H[i][i], H[i + 1][i], cs[i], sn[i]);
+            rot(s[i], s[i + 1], cs[i], sn[i]);
+            norm = std::fabs(s[i + 1]);
+            if (norm < red * norm0) converged = true;
+        }
+        if (status != OPMGPU_OK) break;
+        // update(w, i, H, s, v): back-substitution, then x += w
+        std::vector<S> y(s.begin(), s.begin() + i);
+        std::fill(w.begin(), w.end(), S(0));
+        for (int a = i - 1; a >= 0; --a) {
+            S rhs = s[a];
+            for (int bq = a + 1; bq < i; ++bq) rhs -= H[a][bq] * y[bq];
+            y[a] = rhs / H[a][a];
+            axpy_t(n, y[a], v[a].data(), w.data());
+        }
+        axpy_t(n, S(1), w.data(), x.data());
+        if (!converged && j <= maxit) {         // restart from the true defect
+            spmv_t(nb, rowptr, col, A.data(), x.data(), tmp.data());
+            for (int q = 0; q < n; ++q) b[q] = b2[q] - tmp[q];
+            precond(b, v[0]);
+            norm = std::sqrt(dot_t(n, v[0].data(), v[0].data()));
+        }
+    }
+    for (int i = 0; i < n; ++i) x3[i] = double(x[i]);
+    if (iters) *iters = j - 1;
+    if (reduction) *reduction = norm0 > 0 ? double(norm / norm0) : 0.0;
+    if (status != OPMGPU_OK) return status;
+    if (!converged && !prm->ignore_convergence_failure) return OPMGPU_ELINSOLVE;
+    return OPMGPU_OK;
+}
+
 } // namespace
 
 namespace {
@@ -991,6 +1077,11 @@ int oracle_bicgstab_ilu0(int nb, const int32_t* rowptr, const int32_t* col, cons
                          const int32_t* position, const opmgpu_params* prm, int sp, double* x3, int* iters,
                          double* reduction, double* hist, int nhist, int* nhist_out)
 {
+    if (prm->newton_use_gmres) {        // ISTLSolver.hpp:257-264
+        if (nhist_out) *nhist_out = 0;
+        return sp ? gmres_t<float>(nb, rowptr, col, val9, rhs3, position, prm, x3, iters, reduction)
+                  : gmres_t<double>(nb, rowptr, col, val9, rhs3, position, prm, x3, iters, reduction);
+    }
     if (sp) return bicgstab_t<float>(nb, rowptr, col, val9, rhs3, position, prm, x3, iters, reduction, hist, nhist, nhist_out);
     return bicgstab_t<double>(nb, rowptr, col, val9, rhs3, position, prm, x3, iters, reduction, hist, nhist, nhist_out);
 }

@@ -226,3 +226,48 @@ def test_cpr_pressure_equation_weights(gpu_lib, oracle):
     assert s.lib.opmgpu_get_cpr_weights(s.ctx, capi.dptr(w)) == capi.OK
     assert np.array_equal(w.reshape(3, nb), expect)
     s.close()
+
+
+@pytest.mark.parametrize("single", [False, True])
+def test_gmres_option(gpu_lib, oracle, single):
+    """newton_use_gmres (ISTLSolver.hpp:257-264): restarted, left-preconditioned GMRES as Dune::RestartedGMResSolver does it, vs
+    the oracle's restatement with the ILU0 in the same elimination order -- same iteration count (+-1: rounding at the
+    threshold), same solution; restart shorter than the iteration count; CPR as the preconditioner; failure contract."""
+    grid = decks.cartesian_grid(12, 10, 8, lognormal_sigma=0.8)
+    tab = decks.satfunc_standard_tables()
+    st = decks.initial_state(grid, tab, perturb=0.01)
+    red = 1e-4 if single else 1e-6
+    # natural-order ILU0 (the stronger one): GMRES(m) stagnates more easily than BiCGStab behind the 2-colour ILU0
+    prm = capi.default_params(newton_use_gmres=1, linear_solver_reduction=red, linear_solver_maxiter=400, ilu_ordering=capi.ORDER_NATURAL)
+    scale = np.asarray(prm.matbalscale[:])
+    rowptr, col = oracle.pattern(grid)
+    nc = grid.nc
+    r, val, _, _ = oracle.assemble(grid, tab, 5 * decks.DAY, st, rowptr, col, scale=tuple(scale))
+    b = np.ascontiguousarray((r * np.repeat(scale, nc)).reshape(3, nc).T).ravel()
+    A = bsr_to_scipy(rowptr, col, val)
+    xe = spla.spsolve(A.tocsc(), b)
+    for restart in (40, 12):
+        prm.linear_solver_restart = restart
+        sto, xo, ito, redo, _ = oracle.bicgstab(rowptr, col, val, b, prm, position=None, single=single)
+        assert sto == 0, (restart, ito, redo)
+        s = GpuNewtonIteration(prm)
+        xg = s.computeNewtonIncrement(rowptr, col, val, b, single)
+        assert abs(s.iterations() - ito) <= (3 if single else 1), (restart, s.iterations(), ito)
+        assert s.reduction < red
+        # left-preconditioned: the PRECONDITIONED residual is controlled; the two implementations must agree with each other
+        assert np.linalg.norm(xg - xo) <= (50 * red if single else 1e-6) * np.linalg.norm(xo), restart
+        if restart == 12:
+            assert s.iterations() > 12                        # the restart path ran
+        s.close()
+    # CPR as the preconditioner of GMRES (NewtonIterationBlackoilCPR.hpp:116-119)
+    red_c = 1e-5 if single else 1e-10
+    prm_c = capi.default_params(newton_use_gmres=1, use_cpr=1, linear_solver_reduction=red_c, linear_solver_maxiter=200)
+    s = GpuNewtonIteration(prm_c)
+    xg = s.computeNewtonIncrement(rowptr, col, val, b, single)
+    assert np.linalg.norm(xg - xe) <= (3e-3 if single else 1e-6) * np.linalg.norm(xe) and s.iterations() < 40
+    s.close()
+    # iteration limit: LinearSolverProblem like ISTLSolver.hpp:358-368
+    s = GpuNewtonIteration(capi.default_params(newton_use_gmres=1, linear_solver_reduction=1e-12, linear_solver_maxiter=3))
+    with pytest.raises(LinearSolverProblem):
+        s.computeNewtonIncrement(rowptr, col, val, b, single)
+    s.close()
