@@ -119,6 +119,26 @@ __device__ __forceinline__ void sat_curve(const double* __restrict__ x, const do
     df *= e.k[c];
 }
 
+// Tables in LDS: every table function is two dependent memory round trips (find the segment, read its end points) and a cell
+// evaluates ~14 of them; from L1/L2 that chain is ~10 us of pure latency per wave, from LDS a tenth of it.  The whole blob is
+// copied by the workgroup (words > 0; the host passes 0 when it does not fit) and the struct's pointers are rebased onto it.
+__device__ __forceinline__ void stage_tables(opmgpu_tables& T, const double* __restrict__ blob, int words, double* lds)
+{
+    if (words <= 0) return;
+    for (int i = threadIdx.x; i < words; i += blockDim.x) lds[i] = blob[i];
+    __syncthreads();
+    auto rd = [&](const double*& p) { if (p) p = lds + (p - blob); };
+    auto ri = [&](const int32_t*& p) { if (p) p = reinterpret_cast<const int32_t*>(lds + (reinterpret_cast<const double*>(p) - blob)); };
+    rd(T.surface_density); rd(T.pvtw);
+    ri(T.oil_node_ptr); rd(T.oil_rs); rd(T.oil_psat); rd(T.oil_invb_sat); rd(T.oil_invbmu_sat);
+    ri(T.oil_col_ptr); rd(T.oil_col_p); rd(T.oil_col_invb); rd(T.oil_col_invbmu);
+    ri(T.gas_node_ptr); rd(T.gas_pg); rd(T.gas_rvsat); rd(T.gas_invb_sat); rd(T.gas_invbmu_sat);
+    ri(T.gas_col_ptr); rd(T.gas_col_rv); rd(T.gas_col_invb); rd(T.gas_col_invbmu);
+    ri(T.swof_ptr); rd(T.swof_sw); rd(T.swof_krw); rd(T.swof_krow); rd(T.swof_pcow);
+    ri(T.sgof_ptr); rd(T.sgof_sg); rd(T.sgof_krg); rd(T.sgof_krog); rd(T.sgof_pcgo);
+    rd(T.rocktab_p); rd(T.rocktab_pvmult); rd(T.rocktab_transmult);
+}
+
 // VAPPARS (applyVap, BlackoilPropsAdFromDeck.cpp:1052-1078): factor (so/soMax)^vap and its so-derivative
 __device__ __forceinline__ void vap_factor(double vap, double so, double so_max, double& f, double& df)
 {
@@ -296,8 +316,10 @@ __global__ __launch_bounds__(kBlock) void k_cell_props(int nb, int nbp, opmgpu_t
                                                        const double* __restrict__ eps, const double* __restrict__ eps_u0,
                                                        const double* __restrict__ somax,
                                                        double* __restrict__ props, double* __restrict__ accum0, double* __restrict__ R,
-                                                       double* __restrict__ binv, MS* __restrict__ A)
+                                                       double* __restrict__ binv, MS* __restrict__ A, const double* __restrict__ tab_blob, int tab_words)
 {
+    extern __shared__ double tab_lds[];
+    stage_tables(T, tab_blob, tab_words, tab_lds);
     const int row = blockIdx.x * kBlock + threadIdx.x;
     if (row >= nb) return;
     CellEval q;
@@ -521,8 +543,10 @@ __global__ __launch_bounds__(kBlock) void k_update_state(int nb, int nbp, opmgpu
                                                          double* __restrict__ p, double* __restrict__ sw, double* __restrict__ so,
                                                          double* __restrict__ sg, double* __restrict__ rs, double* __restrict__ rv, int8_t* __restrict__ hc,
                                                          const double* __restrict__ eps_planes, const double* __restrict__ eps_u0,
-                                                         const double* __restrict__ somax)
+                                                         const double* __restrict__ somax, const double* __restrict__ tab_blob, int tab_words)
 {
+    extern __shared__ double tab_lds[];
+    stage_tables(T, tab_blob, tab_words, tab_lds);
     const int c = blockIdx.x * kBlock + threadIdx.x;
     if (c >= nb) return;
     const double eps = 1.4901161193847656e-08;      // sqrt(DBL_EPSILON)
@@ -699,21 +723,25 @@ BlackoilDevice::BlackoilDevice(hipStream_t s, LinSolver& ls_, const opmgpu_grid*
 BlackoilDevice::~BlackoilDevice()
 {
     wells_free();
-    for (DevArray<double>* a : tab_d) delete a;
-    for (DevArray<int32_t>* a : tab_i) delete a;
     if (h_red) (void)hipHostFree(h_red);
 }
 
 void BlackoilDevice::upload_tables(const opmgpu_tables* t)
 {
     dt_ = *t;
+    // all table arrays live in ONE device blob (8-byte words) so that a kernel can stage them in LDS with one cooperative copy
+    std::vector<double> blob;
     auto upd = [&](const double* src, size_t n) -> const double* {
-        DevArray<double>* a = new DevArray<double>(); tab_d.push_back(a);
-        a->upload(src, std::max<size_t>(n, 1), stream); return a->p;
+        const size_t off = blob.size();
+        blob.insert(blob.end(), src, src + n);
+        if (n == 0) blob.push_back(0.0);
+        return reinterpret_cast<const double*>(off + 1);         // encoded offset (+1: never null), resolved below
     };
     auto upi = [&](const int32_t* src, size_t n) -> const int32_t* {
-        DevArray<int32_t>* a = new DevArray<int32_t>(); tab_i.push_back(a);
-        a->upload(src, n, stream); return a->p;
+        const size_t off = blob.size();
+        blob.resize(off + (n + 1) / 2 + 1, 0.0);
+        std::memcpy(&blob[off], src, n * sizeof(int32_t));
+        return reinterpret_cast<const int32_t*>(off + 1);
     };
     const int np = t->n_pvt_regions, ns = t->n_sat_regions;
     const int non = t->oil_node_ptr[np], ngn = t->gas_node_ptr[np];
@@ -739,6 +767,21 @@ void BlackoilDevice::upload_tables(const opmgpu_tables* t)
         if (t->rocktab_n < 2) throw HipError(OPMGPU_EINVAL, "ROCKTAB needs at least two rows");
         dt_.rocktab_p = upd(t->rocktab_p, t->rocktab_n); dt_.rocktab_pvmult = upd(t->rocktab_pvmult, t->rocktab_n);
         dt_.rocktab_transmult = upd(t->rocktab_transmult, t->rocktab_n);
+    }
+    d_tab.upload(blob, stream);
+    tab_words = int(blob.size());
+    {
+        auto fixd = [&](const double*& p) { if (p) p = d_tab.p + (reinterpret_cast<size_t>(p) - 1); };
+        auto fixi = [&](const int32_t*& p) { if (p) p = reinterpret_cast<const int32_t*>(d_tab.p + (reinterpret_cast<size_t>(p) - 1)); };
+        fixd(dt_.surface_density); fixd(dt_.pvtw);
+        fixi(dt_.oil_node_ptr); fixd(dt_.oil_rs); fixd(dt_.oil_psat); fixd(dt_.oil_invb_sat); fixd(dt_.oil_invbmu_sat);
+        fixi(dt_.oil_col_ptr); fixd(dt_.oil_col_p); fixd(dt_.oil_col_invb); fixd(dt_.oil_col_invbmu);
+        fixi(dt_.gas_node_ptr); fixd(dt_.gas_pg); fixd(dt_.gas_rvsat); fixd(dt_.gas_invb_sat); fixd(dt_.gas_invbmu_sat);
+        fixi(dt_.gas_col_ptr); fixd(dt_.gas_col_rv); fixd(dt_.gas_col_invb); fixd(dt_.gas_col_invbmu);
+        fixi(dt_.swof_ptr); fixd(dt_.swof_sw); fixd(dt_.swof_krw); fixd(dt_.swof_krow); fixd(dt_.swof_pcow);
+        fixi(dt_.sgof_ptr); fixd(dt_.sgof_sg); fixd(dt_.sgof_krg); fixd(dt_.sgof_krog); fixd(dt_.sgof_pcgo);
+        if (t->rocktab_n > 0) { fixd(dt_.rocktab_p); fixd(dt_.rocktab_pvmult); fixd(dt_.rocktab_transmult); }
+        else { dt_.rocktab_p = nullptr; dt_.rocktab_pvmult = nullptr; dt_.rocktab_transmult = nullptr; }
     }
     // unscaled end points of every saturation region (what opm-material's EclEpsScalingPointsInfo::extractUnscaled reads off the
     // tables): Swl Swcr Swu Sowcr Sgl Sgcr Sgu Sogcr
@@ -887,9 +930,10 @@ template <class MS> void BlackoilDevice::assemble_kernels(double dt, bool initia
 {
     const Plan& P = ls.plan;
     const double* sc = prm.matbalscale;
-    hipLaunchKernelGGL((k_cell_props<MS>), dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_pv.p,
+    hipLaunchKernelGGL((k_cell_props<MS>), dim3(grid_for(nc)), dim3(kBlock), tab_lds_bytes(), stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_pv.p,
                        d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, 1.0 / dt, int(initial), sc[0], sc[1], sc[2],
-                       ls.dp.slice_ptr.p, ls.dp.nlower.p, eps_planes(), d_eps_u0.p, d_somax.p, d_props.p, d_accum0.p, d_R.p, d_binv.p, A);
+                       ls.dp.slice_ptr.p, ls.dp.nlower.p, eps_planes(), d_eps_u0.p, d_somax.p, d_props.p, d_accum0.p, d_R.p, d_binv.p, A,
+                       (const double*)d_tab.p, tab_lds_words());
     hipLaunchKernelGGL((k_flux<MS>), dim3(grid8_for(nc)), dim3(kBlock), 0, stream, xcd_mode(), nc, P.nbp, ls.dp.slice_ptr.p, ls.dp.col.p, ls.dp.rowlen.p,
                        ls.dp.nlower.p, d_conn_code.p, d_trans.p, d_gdz.p, use_thpres ? d_thpres.p : (const double*)nullptr,
                        d_p.p, d_props.p, sc[0], sc[1], sc[2], ls.comm ? ls.comm->owner_mask() : (const int8_t*)nullptr, d_R.p, A);
@@ -918,9 +962,10 @@ double BlackoilDevice::time_assemble(int reps, int props_only)
     OPMGPU_HIP(hipEventCreate(&e0)); OPMGPU_HIP(hipEventCreate(&e1));
     auto launch = [&]() {
         if (props_only)
-            hipLaunchKernelGGL((k_cell_props<double>), dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_pv.p,
+            hipLaunchKernelGGL((k_cell_props<double>), dim3(grid_for(nc)), dim3(kBlock), tab_lds_bytes(), stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_pv.p,
                                d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, 1.0 / dt, 0, sc[0], sc[1], sc[2],
-                               ls.dp.slice_ptr.p, ls.dp.nlower.p, eps_planes(), d_eps_u0.p, d_somax.p, d_props.p, d_accum0.p, d_R.p, d_binv.p, ls.matrix_d());
+                               ls.dp.slice_ptr.p, ls.dp.nlower.p, eps_planes(), d_eps_u0.p, d_somax.p, d_props.p, d_accum0.p, d_R.p, d_binv.p, ls.matrix_d(),
+                               (const double*)d_tab.p, tab_lds_words());
         else assemble(dt, false);
     };
     launch();
@@ -1154,8 +1199,9 @@ void BlackoilDevice::update_state(const double* dx_host, double relax)
     const Plan& P = ls.plan;
     if (dx_host) { ls.vec_from_host<double>(dx_host, VEC_EQUATION_MAJOR, d_dx.p); has_dx = true; }
     if (device_wells) wells_update(relax);          // recoverVariable + updateWellState from the same increment
-    hipLaunchKernelGGL(k_update_state, dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_dx.p, relax,
-                       prm.dp_max_rel, prm.ds_max, prm.dr_max_rel, d_p.p, d_sw.p, d_so.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, eps_planes(), d_eps_u0.p, d_somax.p);
+    hipLaunchKernelGGL(k_update_state, dim3(grid_for(nc)), dim3(kBlock), tab_lds_bytes(), stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_dx.p, relax,
+                       prm.dp_max_rel, prm.ds_max, prm.dr_max_rel, d_p.p, d_sw.p, d_so.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, eps_planes(), d_eps_u0.p, d_somax.p,
+                       (const double*)d_tab.p, tab_lds_words());
 }
 
 __global__ __launch_bounds__(kBlock) void k_somax_update(int nb, const double* __restrict__ so, double* __restrict__ somax)

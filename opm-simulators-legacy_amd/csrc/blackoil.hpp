@@ -97,8 +97,11 @@ private:
     const double* eps_planes() const { return use_eps ? d_eps.p : nullptr; }
     // device: tables
     opmgpu_tables dt_;                       // same struct, device pointers
-    std::vector<DevArray<double>*> tab_d;
-    std::vector<DevArray<int32_t>*> tab_i;
+    DevArray<double> d_tab;                  // all table arrays in one blob of 8-byte words (staged in LDS by the property kernels)
+    int tab_words = 0;
+    static constexpr int kTabLdsMaxBytes = 24 * 1024;     // 6 workgroups x 24 KiB fit the 160 KiB LDS of a CU: no occupancy lost
+    int tab_lds_words() const { return tab_words * 8 <= kTabLdsMaxBytes ? tab_words : 0; }
+    size_t tab_lds_bytes() const { return size_t(tab_lds_words()) * 8; }
     // device: static per-cell / per-connection (internal numbering for cells)
     DevArray<double> d_pv, d_trans, d_gdz, d_thpres;
     DevArray<int32_t> d_pvtnum, d_satnum, d_conn_code, d_perf_cells;
