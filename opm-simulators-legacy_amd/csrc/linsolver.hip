@@ -547,11 +547,26 @@ __global__ __launch_bounds__(kBlock) void k_copy16(long n16, const double2* __re
 template <class S>
 __global__ __launch_bounds__(kBlock) void k_cpr_weights(int nb, int nbp, const int32_t* __restrict__ slice_ptr, const int16_t* __restrict__ rowlen,
                                                         const int16_t* __restrict__ nlower, const int32_t* __restrict__ tpos, const S* __restrict__ A,
-                                                        S* __restrict__ w)
+                                                        S* __restrict__ w, int mode)
 {
     const int row = blockIdx.x * kBlock + threadIdx.x;
     if (row >= nb) return;
     const int base = slice_ptr[row >> 6], lane = row & 63, len = rowlen[row], nl = nlower[row];
+    if (mode == 1) {
+        // quasi-IMPES: w = first row of A_ii^-1, i.e. the combination of the cell's equations that eliminates its own saturation /
+        // composition unknowns from the diagonal block (w . A_ii = [1 0 0]); not what the reference does (experiment knob)
+        const long e = long(base + nl) * 64 + lane;
+        const S* b = A + (e >> 6) * 576 + (e & 63);
+        double m[9];
+        for (int q = 0; q < 9; ++q) m[q] = double(b[q * 64]);
+        const double c0 = m[4] * m[8] - m[5] * m[7], c1 = m[5] * m[6] - m[3] * m[8], c2 = m[3] * m[7] - m[4] * m[6];
+        const double det = m[0] * c0 + m[1] * c1 + m[2] * c2;
+        const double id = (det != 0.0 && det == det) ? 1.0 / det : 0.0;
+        double w0 = c0 * id, w1 = (m[2] * m[7] - m[1] * m[8]) * id, w2 = (m[1] * m[5] - m[2] * m[4]) * id;
+        if (id == 0.0) { w0 = 1.0; w1 = 1.0; w2 = 1.0; }
+        w[row] = S(w0); w[nbp + row] = S(w1); w[2 * long(nbp) + row] = S(w2);
+        return;
+    }
     double sod[3] = { 0.0, 0.0, 0.0 }, dj[3];
     for (int k = 0; k < len; ++k) {
         const long e = long(base + k) * 64 + lane;
@@ -705,6 +720,7 @@ LinSolver::LinSolver(hipStream_t s) : stream(s)
     OPMGPU_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
     if (const char* e = std::getenv("OPMGPU_CLOSED")) closed_form_level0 = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_CPR_SPECULATE")) cpr_speculate = std::atoi(e) != 0;
+    if (const char* e = std::getenv("OPMGPU_CPR_WEIGHTS")) cpr_weight_mode = std::atoi(e);
 }
 LinSolver::~LinSolver()
 {
@@ -840,7 +856,7 @@ template <class S> void LinSolver::cpr_prepare()
     if (!w.amg) w.amg.reset(new AmgHierarchy<S>(stream));
     w.cprw.alloc(3 * size_t(plan.nbp));
     hipLaunchKernelGGL((k_cpr_weights<S>), dim3(grid_for(plan.nb)), dim3(kBlock), 0, stream, plan.nb, plan.nbp, dp.slice_ptr.p, dp.rowlen.p, dp.nlower.p,
-                       dp.tpos.p, matrix<S>(), w.cprw.p);
+                       dp.tpos.p, matrix<S>(), w.cprw.p, cpr_weight_mode);
     if (!w.amg->ready()) {
         // first matrix with this pattern: pressure values to the host, aggregation hierarchy (structure only) built there
         DevArray<S> tmp; tmp.alloc(ne);
