@@ -336,6 +336,8 @@ void AmgHierarchy<S>::setup(const Plan& P, const int32_t* d_slice_ptr, const int
     if (const char* e = std::getenv("OPMGPU_AMG_NPRE")) npre = std::atoi(e);
     if (const char* e = std::getenv("OPMGPU_AMG_NPOST")) npost = std::atoi(e);
     if (const char* e = std::getenv("OPMGPU_AMG_FUSE")) fuse = std::atoi(e) != 0;
+    if (const char* e = std::getenv("OPMGPU_AMG_GRAPH")) use_graph = std::atoi(e) != 0;
+    if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
     npost0 = npost;
     if (const char* e = std::getenv("OPMGPU_AMG_NPOST0")) npost0 = std::atoi(e);
     HostCsr A;
@@ -505,6 +507,26 @@ void AmgHierarchy<S>::vcycle(const SolveCtl* ctl, bool level0_presmoothed)
         }
         for (auto& m : marks) (void)hipEventDestroy(m.second);
     }
+}
+
+// V-cycle through a captured graph: the launches of one cycle are recorded once per (ctl, presmoothed) and replayed.  Valid
+// because a cycle performs an even number of x/x2 swaps per level (1 + 2 sweeps), so the buffer roles are the same at every entry.
+template <class S>
+void AmgHierarchy<S>::vcycle_graph(const SolveCtl* ctl, bool level0_presmoothed)
+{
+    const bool even = (npost % 2 == 0) && (npost0 % 2 == 0) && npre == 1;
+    if (!use_graph || !even) { vcycle(ctl, level0_presmoothed); return; }
+    if (!graph_exec || graph_ctl != ctl || graph_pre != level0_presmoothed) {
+        if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+        hipGraph_t g = nullptr;
+        OPMGPU_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        vcycle(ctl, level0_presmoothed);
+        OPMGPU_HIP(hipStreamEndCapture(stream, &g));
+        OPMGPU_HIP(hipGraphInstantiate(&graph_exec, g, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(g);
+        graph_ctl = ctl; graph_pre = level0_presmoothed;
+    }
+    OPMGPU_HIP(hipGraphLaunch(graph_exec, stream));
 }
 
 // one damped-Jacobi sweep x <- x + omega D^-1 (b - A x) (ping-pong between x and x2)

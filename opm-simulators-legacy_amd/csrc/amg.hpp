@@ -51,6 +51,11 @@ public:
     // x0 = Vcycle(b0) with b0 in levels[0].b; result in levels[0].x
     // level0_presmoothed: levels[0].x already holds omega D^-1 b (the caller's kernel did the first sweep)
     void vcycle(const SolveCtl* ctl, bool level0_presmoothed = false);
+    // the same cycle replayed from a captured hipGraph (OPMGPU_AMG_GRAPH=1; A/B knob)
+    void vcycle_graph(const SolveCtl* ctl, bool level0_presmoothed);
+    hipGraphExec_t graph_exec = nullptr;
+    const SolveCtl* graph_ctl = nullptr;
+    bool graph_pre = false, use_graph = false;
     std::vector<std::unique_ptr<AmgLevel<S>>> levels;
     std::vector<std::unique_ptr<DevArray<int32_t>>> coarse_dev;   // per fine level: device entry id of every coarse csr entry
     DevArray<double> dense_inv;      // coarsest: explicit inverse (double), n_c x n_c

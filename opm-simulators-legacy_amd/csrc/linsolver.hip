@@ -879,7 +879,7 @@ template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, con
     AmgLevel<S>& L0 = *w.amg->levels[0];
     const int g = grid_for(plan.nb);
     hipLaunchKernelGGL((k_cpr_sum_eqs<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, plan.nbp, d, (const S*)w.cprw.p, L0.b.p, S(w.amg->omega), (const S*)L0.dinv.p, L0.x.p, ctl);
-    w.amg->vcycle(ctl, true);
+    w.amg->vcycle_graph(ctl, true);
     const S* xp = L0.x.p;
     if (comm) {
         // multi-GPU: the AMG is rank-local (additive Schwarz: ghost rows are identity rows); the owners' x_p is copied
