@@ -721,6 +721,7 @@ LinSolver::LinSolver(hipStream_t s) : stream(s)
     if (const char* e = std::getenv("OPMGPU_CLOSED")) closed_form_level0 = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_CPR_SPECULATE")) cpr_speculate = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_CPR_WEIGHTS")) cpr_weight_mode = std::atoi(e);
+    if (const char* e = std::getenv("OPMGPU_AMG_LAG")) amg_lag = std::atoi(e);
 }
 LinSolver::~LinSolver()
 {
@@ -854,6 +855,8 @@ template <class S> void LinSolver::cpr_prepare()
     SolverWork<S>& w = work<S>();
     const long ne = plan.nentries;
     if (!w.amg) w.amg.reset(new AmgHierarchy<S>(stream));
+    // OPMGPU_AMG_LAG=k (experiment): refresh the pressure hierarchy's numbers only on every k-th matrix
+    if (amg_lag > 1 && w.amg->ready() && w.cprw.p && (++amg_age % amg_lag) != 0) return;
     w.cprw.alloc(3 * size_t(plan.nbp));
     hipLaunchKernelGGL((k_cpr_weights<S>), dim3(grid_for(plan.nb)), dim3(kBlock), 0, stream, plan.nb, plan.nbp, dp.slice_ptr.p, dp.rowlen.p, dp.nlower.p,
                        dp.tpos.p, matrix<S>(), w.cprw.p, cpr_weight_mode);
