@@ -5,7 +5,7 @@ What `flow_legacy` gets from opm-parser + `DerivedGeology` (opm/autodiff/GeoProp
 
   RUNSPEC   DIMENS TABDIMS OIL WATER GAS DISGAS VAPOIL METRIC ENDSCALE
   GRID      DX DY DZ / DXV DYV DZV, TOPS (+BOX for the top layer) or DEPTHZ (flat), PORO PERMX PERMY PERMZ NTG ACTNUM
-            MULTX MULTY MULTZ MULTPV NNC
+            MULTX MULTY MULTZ MULTX- MULTY- MULTZ- MULTPV NNC
   PROPS     SWOF SGOF PVTO PVDO PVCDO PVTG PVDG PVTW DENSITY ROCK ROCKTAB VAPPARS SCALECRS
             SWL SWCR SWU SOWCR SGL SGCR SGU SOGCR
   REGIONS   PVTNUM SATNUM
@@ -200,7 +200,7 @@ class Deck:
         idx = np.arange(n).reshape(nz, ny, nx)
         dxr, dyr, dzr = dx.ravel(), dy.ravel(), dz.ravel()
 
-        def faces(a, b, kperm, area_a, area_b, da, db, horiz, mult):
+        def faces(a, b, kperm, area_a, area_b, da, db, horiz, mult, mult_minus):
             a, b = a.ravel(), b.ravel()
             h1 = kperm[a] * area_a[a] / (da[a] / 2.0); h2 = kperm[b] * area_b[b] / (db[b] / 2.0)
             if horiz:
@@ -209,12 +209,14 @@ class Deck:
                 t = 1.0 / (1.0 / h1 + 1.0 / h2)
             t = np.where(np.isfinite(t), t, 0.0)
             if mult is not None:
-                t = t * mult[a]                                    # MULTX applies to the face towards +x of the cell it is given for
+                t = t * np.where(np.isnan(mult[a]), 1.0, mult[a])              # MULTX: the face towards +x of the cell it is given for
+            if mult_minus is not None:
+                t = t * np.where(np.isnan(mult_minus[b]), 1.0, mult_minus[b])  # MULTX-: the face towards -x of that cell
             return np.stack([a, b], 1), t
         ayz, axz, axy = dyr * dzr, dxr * dzr, dxr * dyr
-        cx, tx = faces(idx[:, :, :-1], idx[:, :, 1:], kx, ayz, ayz, dxr, dxr, True, self.array("MULTX", n))
-        cy, ty = faces(idx[:, :-1, :], idx[:, 1:, :], ky, axz, axz, dyr, dyr, True, self.array("MULTY", n))
-        cz, tz = faces(idx[:-1, :, :], idx[1:, :, :], kz, axy, axy, dzr, dzr, False, self.array("MULTZ", n))
+        cx, tx = faces(idx[:, :, :-1], idx[:, :, 1:], kx, ayz, ayz, dxr, dxr, True, self.array("MULTX", n), self.array("MULTX-", n))
+        cy, ty = faces(idx[:, :-1, :], idx[:, 1:, :], ky, axz, axz, dyr, dyr, True, self.array("MULTY", n), self.array("MULTY-", n))
+        cz, tz = faces(idx[:-1, :, :], idx[1:, :, :], kz, axy, axy, dzr, dzr, False, self.array("MULTZ", n), self.array("MULTZ-", n))
         conn = np.concatenate([cx, cy, cz]); trans = np.concatenate([tx, ty, tz])
         if self.has("NNC"):
             for r in self.records("NNC"):

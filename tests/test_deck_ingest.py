@@ -120,3 +120,31 @@ def test_satfunc_known_answers_from_the_deck_files(oracle, case, fname):
         for key, got in (("krw", kr[:, 0]), ("kro", kr[:, 1]), ("DkrwDsw", dkr[:, 0]), ("DkroDsw", dkr[:, 1]), ("DkroDsg", dkr[:, 7])):
             exp = np.asarray(pick(G[key]))
             assert np.all((np.abs(got - exp) <= tol * np.maximum(np.abs(got), np.abs(exp))) | ((np.abs(got) < 1e-14) & (np.abs(exp) < 1e-14))), (case, icell, key)
+
+
+def test_transmissibility_multipliers_like_the_reference_test(tmp_path):
+    """tests/test_transmissibilitymultipliers.cpp: a 2x2x2 deck with MULT? = 1..8 / MULT?- = 1..8 / NTG = 0.5 against the plain deck
+    -- trans(face) * (inside cell + 1) with MULT?, * (outside cell + 1) with MULT?-, * 0.5 on horizontal faces with NTG."""
+    pre = "RUNSPEC\nTABDIMS\n/\nOIL\nGAS\nWATER\nMETRIC\nDIMENS\n2 2 2/\nGRID\nDXV\n1.0 2.0 /\nDYV\n3.0 4.0 /\nDZV\n5.0 6.0/\nTOPS\n4*100 /\n"
+    post = "PROPS\nPORO\n8*0.3 /\nPERMX\n8*1 /\nSCHEDULE\nTSTEP\n1.0 2.0 3.0 4.0 /\n"
+    one8 = "1 2 3 4 5 6 7 8 /\n"
+    texts = {"orig": pre + post,
+             "mult": pre + "MULTX\n" + one8 + "MULTY\n" + one8 + "MULTZ\n" + one8 + post,
+             "minus": pre + "MULTX-\n" + one8 + "MULTY-\n" + one8 + "MULTZ-\n" + one8 + post,
+             "ntg": pre + "NTG\n8*0.5 /\n" + post}
+    g = {}
+    for k, t in texts.items():
+        p = tmp_path / (k + ".DATA")
+        p.write_text(t)
+        g[k] = deck.read_deck(str(p)).grid()
+    o = g["orig"]
+    assert o.nc == 8 and o.nconn == 12
+    for k in ("mult", "minus", "ntg"):
+        assert np.array_equal(g[k].conn_cells, o.conn_cells)
+    inside, outside = o.conn_cells[:, 0], o.conn_cells[:, 1]
+    assert np.all(inside < outside)
+    assert np.allclose(g["mult"].trans, o.trans * (inside + 1), rtol=1e-8)
+    assert np.allclose(g["minus"].trans, o.trans * (outside + 1), rtol=1e-8)
+    same_layer = (inside // 4) == (outside // 4)
+    assert np.allclose(g["ntg"].trans[same_layer], 0.5 * o.trans[same_layer], rtol=1e-8)
+    assert np.allclose(g["ntg"].trans[~same_layer], o.trans[~same_layer], rtol=1e-8)
