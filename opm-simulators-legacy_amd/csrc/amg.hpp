@@ -43,6 +43,9 @@ template <class S>
 class AmgHierarchy {
 public:
     explicit AmgHierarchy(hipStream_t s) : stream(s) {}
+    ~AmgHierarchy() { if (graph_exec) (void)hipGraphExecDestroy(graph_exec); }
+    AmgHierarchy(const AmgHierarchy&) = delete;
+    AmgHierarchy& operator=(const AmgHierarchy&) = delete;
     // structure from the block plan + the level-0 pressure values (host copy, entry-indexed); builds all levels
     void setup(const Plan& P, const int32_t* d_slice_ptr, const int32_t* d_col, const std::vector<double>& ap_host);
     bool ready() const { return !levels.empty(); }
