@@ -140,6 +140,7 @@ public:
     const CommBase* light_ok_for = nullptr;
     template <class S> void lowrank_reduce(const S* x, const SolveCtl* ctl);
     bool closed_form_level0 = true; // k_spmv shortcut on level-0 rows (A/B switch: OPMGPU_CLOSED=0)
+    bool cpr_halo_xp = true;        // multi-GPU CPR: halo-exchange the pressure correction before stage 2 (A/B: OPMGPU_CPR_HALO_XP=0)
     int amg_lag = 1, amg_age = 0;   // A/B: OPMGPU_AMG_LAG
     int cpr_weight_mode = 0;        // 0 = formEllipticSystem's 0/1 dominance weights (reference); 1 = quasi-IMPES (A/B: OPMGPU_CPR_WEIGHTS=1)
     bool cpr_speculate = false;     // CPR: enqueue the next iteration before the convergence result is known (A/B: OPMGPU_CPR_SPECULATE=1)

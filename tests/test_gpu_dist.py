@@ -83,6 +83,7 @@ def test_self_halo_reproduces_plain_grid(gpu_lib, oracle, single, cpr):
         dxA = A.solveJacobianSystem(want_dx=True, single_precision=single)
         dxB = B.solveJacobianSystem(want_dx=True, single_precision=single)
         assert B.linear_iterations >= 1 and B.linear_reduction < red
+        print("self-halo cpr=%d single=%d it %d: linear iterations plain %d, decomposed %d" % (cpr, single, it, A.linear_iterations, B.linear_iterations))
         if not single:
             for a in range(3):
                 blkA, blkB = dxA[a * n:(a + 1) * n], dxB[a * nB:a * nB + n]
