@@ -723,6 +723,8 @@ LinSolver::LinSolver(hipStream_t s) : stream(s)
     if (const char* e = std::getenv("OPMGPU_CPR_WEIGHTS")) cpr_weight_mode = std::atoi(e);
     if (const char* e = std::getenv("OPMGPU_AMG_LAG")) amg_lag = std::atoi(e);
     if (const char* e = std::getenv("OPMGPU_CPR_HALO_XP")) cpr_halo_xp = std::atoi(e) != 0;
+    if (const char* e = std::getenv("OPMGPU_EMULATE_RANKS")) emulate_ranks = std::atoi(e);
+    if (const char* e = std::getenv("OPMGPU_EMULATE_WHAT")) emulate_what = std::atoi(e);
 }
 LinSolver::~LinSolver()
 {
@@ -784,16 +786,50 @@ void LinSolver::widen_matrix()
     hipLaunchKernelGGL((k_convert<float, double>), dim3(std::min(grid_for(n), kMaxRedBlocks)), dim3(kBlock), 0, stream, n, (const float*)wf.A.p, Ad.p);
     matrix_is_float = false;
 }
-template <> void LinSolver::prepare<double>(bool) { ensure_work<double>(); widen_matrix(); }
+template <> void LinSolver::prepare<double>(bool matrix_changed) { ensure_work<double>(); widen_matrix(); if (matrix_changed) pre_stale = true; }
 template <> void LinSolver::prepare<float>(bool matrix_changed)
 {
     ensure_work<float>();
+    if (matrix_changed) pre_stale = true;
     if (!matrix_changed || matrix_is_float) return;
     const long n = long(plan.nentries) * 9;
     hipLaunchKernelGGL((k_convert<double, float>), dim3(std::min(grid_for(n), kMaxRedBlocks)), dim3(kBlock), 0, stream, n, Ad.p, wf.A.p);
 }
 template <> const double* LinSolver::matrix<double>() { return Ad.p; }
 template <> const float* LinSolver::matrix<float>() { return wf.A.p; }
+
+// Diagnostic (OPMGPU_EMULATE_RANKS=N, single GPU): the preconditioner is built from a copy of the matrix whose blocks across the
+// cuts of an N-slab decomposition (contiguous caller-index ranges, like slab_partition) are zeroed -- block-Jacobi ILU0 and a
+// subdomain-local AMG, i.e. the iteration counts of an N-rank run without N GPUs.  The operator itself stays the full matrix.
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_cut_copy(int nb, int nranks, const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
+                                                     const int32_t* __restrict__ nat, const S* __restrict__ A, S* __restrict__ out)
+{
+    const int row = blockIdx.x * kBlock + threadIdx.x;
+    if (row >= nb) return;
+    const int base = slice_ptr[row >> 6], width = slice_ptr[(row >> 6) + 1] - base, lane = row & 63;
+    const long mine = long(nat[row]) * nranks / nb;
+    for (int k = 0; k < width; ++k) {
+        const long e = long(base + k) * 64 + lane;
+        const bool keep = long(nat[col[e]]) * nranks / nb == mine;
+        const S* b = A + (e >> 6) * 576 + (e & 63);
+        S* o = out + (e >> 6) * 576 + (e & 63);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) o[q * 64] = keep ? b[q * 64] : S(0);
+    }
+}
+template <class S> const S* LinSolver::pre_matrix()
+{
+    if (emulate_ranks <= 1) return matrix<S>();
+    SolverWork<S>& w = work<S>();
+    w.Apre.alloc(size_t(plan.nentries) * 9);
+    if (pre_stale) {
+        hipLaunchKernelGGL((k_cut_copy<S>), dim3(grid_for(plan.nb)), dim3(kBlock), 0, stream, plan.nb, emulate_ranks, dp.slice_ptr.p, dp.col.p, dp.nat.p,
+                           matrix<S>(), w.Apre.p);
+        pre_stale = false;
+    }
+    return w.Apre.p;
+}
 
 template <class S> int LinSolver::factor()
 {
@@ -803,7 +839,7 @@ template <class S> int LinSolver::factor()
         const int lo = plan.level_ptr[l], hi = plan.level_ptr[l + 1];
         if (hi == lo) continue;
         hipLaunchKernelGGL((k_ilu_factor<S>), dim3(grid_for(hi - lo)), dim3(kBlock), 0, stream, lo, hi, dp.slice_ptr.p, dp.col.p,
-                           dp.nlower.p, dp.trip_ptr.p, dp.trip_l.p, dp.trip_u.p, dp.trip_t.p, matrix<S>(), dp.rowlen.p, w.LU.p, flags.p);
+                           dp.nlower.p, dp.trip_ptr.p, dp.trip_l.p, dp.trip_u.p, dp.trip_t.p, ((emulate_what & 1) ? pre_matrix<S>() : matrix<S>()), dp.rowlen.p, w.LU.p, flags.p);
     }
     OPMGPU_HIP(hipMemcpyAsync(h_flags, flags.p, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     OPMGPU_HIP(hipStreamSynchronize(stream));
@@ -860,18 +896,18 @@ template <class S> void LinSolver::cpr_prepare()
     if (amg_lag > 1 && w.amg->ready() && w.cprw.p && (++amg_age % amg_lag) != 0) return;
     w.cprw.alloc(3 * size_t(plan.nbp));
     hipLaunchKernelGGL((k_cpr_weights<S>), dim3(grid_for(plan.nb)), dim3(kBlock), 0, stream, plan.nb, plan.nbp, dp.slice_ptr.p, dp.rowlen.p, dp.nlower.p,
-                       dp.tpos.p, matrix<S>(), w.cprw.p, cpr_weight_mode);
+                       dp.tpos.p, ((emulate_what & 2) ? pre_matrix<S>() : matrix<S>()), w.cprw.p, cpr_weight_mode);
     if (!w.amg->ready()) {
         // first matrix with this pattern: pressure values to the host, aggregation hierarchy (structure only) built there
         DevArray<S> tmp; tmp.alloc(ne);
-        hipLaunchKernelGGL((k_extract_pressure<S>), dim3(grid_for(plan.nbp)), dim3(kBlock), 0, stream, plan.nb, plan.nbp, dp.slice_ptr.p, (const S*)w.cprw.p, matrix<S>(), tmp.p);
+        hipLaunchKernelGGL((k_extract_pressure<S>), dim3(grid_for(plan.nbp)), dim3(kBlock), 0, stream, plan.nb, plan.nbp, dp.slice_ptr.p, (const S*)w.cprw.p, ((emulate_what & 2) ? pre_matrix<S>() : matrix<S>()), tmp.p);
         std::vector<S> h(ne);
         tmp.download(h.data(), ne, stream);
         OPMGPU_HIP(hipStreamSynchronize(stream));
         std::vector<double> hd(h.begin(), h.end());
         w.amg->setup(plan, dp.slice_ptr.p, dp.col.p, hd);
     }
-    hipLaunchKernelGGL((k_extract_pressure<S>), dim3(grid_for(plan.nbp)), dim3(kBlock), 0, stream, plan.nb, plan.nbp, dp.slice_ptr.p, (const S*)w.cprw.p, matrix<S>(),
+    hipLaunchKernelGGL((k_extract_pressure<S>), dim3(grid_for(plan.nbp)), dim3(kBlock), 0, stream, plan.nb, plan.nbp, dp.slice_ptr.p, (const S*)w.cprw.p, ((emulate_what & 2) ? pre_matrix<S>() : matrix<S>()),
                        w.amg->levels[0]->val.p);
     w.amg->galerkin();
 }
@@ -918,7 +954,7 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
     // neighbours is a ghost whose entry of M^-1 p is overwritten by the halo exchange (multi-GPU: light_ok masks those rows out)
     const bool cpr = prm.use_cpr != 0;                   // multi-GPU: rank-local (additive Schwarz) AMG + block-Jacobi ILU0
     if (cpr) cpr_prepare<S>();
-    const bool closed = closed_form_level0;
+    const bool closed = closed_form_level0 && emulate_ranks <= 1;
     const int8_t* lightmask = nullptr;
     if (comm && closed) {
         if (light_ok_for != comm || light_ok.n != size_t(plan.nbp)) {
@@ -1283,6 +1319,7 @@ double LinSolver::time_kernel(int kernel, int reps, int single_precision)
     template void LinSolver::ilu_apply<S>(const S*, S*, double, const SolveCtl*);        \
     template void LinSolver::spmv<S>(const S*, S*);                                      \
     template void LinSolver::cpr_prepare<S>();                                           \
+    template const S* LinSolver::pre_matrix<S>();                                        \
     template void LinSolver::cpr_apply<S>(const S*, S*, double, const SolveCtl*);        \
     template SolveResult LinSolver::bicgstab<S>(const opmgpu_params&);                   \
     template SolveResult LinSolver::gmres<S>(const opmgpu_params&);                      \

@@ -65,6 +65,7 @@ template <class S>
 struct SolverWork {
     DevArray<S> A;      // float copy of the matrix (unused for double: the double matrix is used in place)
     DevArray<S> LU;
+    DevArray<S> Apre;   // OPMGPU_EMULATE_RANKS: matrix copy without the blocks across the emulated cuts
     DevArray<S> r, rt, p, v, t, y, x, b, z, hx;  // z: scratch of the CPR second stage; hx: halo staging of x_p (multi-GPU)
     DevArray<S> kry;                             // GMRES: Krylov basis, (restart + 1) vectors
     DevArray<S> cprw;                            // [3][nbp] per-cell weights of the pressure equation (formEllipticSystem)
@@ -93,6 +94,9 @@ public:
     // make the matrix available in precision S (float: converts Ad -> wf.A)
     template <class S> void prepare(bool matrix_changed = true);
     template <class S> const S* matrix();
+    template <class S> const S* pre_matrix();      // what the preconditioner is built from (== matrix() unless OPMGPU_EMULATE_RANKS)
+    int emulate_ranks = 1, emulate_what = 3;      // bit 0: cut the ILU0's matrix, bit 1: cut the AMG's
+    bool pre_stale = true;
 
     template <class S> int factor();                                // ILU0 numeric factorisation
     template <class S> void ilu_apply(const S* d, S* v, double relax, const SolveCtl* ctl = nullptr);
