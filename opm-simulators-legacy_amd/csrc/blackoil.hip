@@ -947,6 +947,7 @@ void BlackoilDevice::assemble(double dt, bool initial)
     has_rhs_extra = false;
     if (initial) d_dx_old.zero(stream);
     const bool host_wells = nperf > 0 && !device_wells;
+    ls.coarse_single_ok = nperf == 0;          // no wells of either kind: the global constant is the near-null-space vector
     ls.matrix_is_float = assemble_single && !host_wells;
     if (ls.matrix_is_float) assemble_kernels<float>(dt, initial, ls.matrix_f());
     else assemble_kernels<double>(dt, initial, ls.matrix_d());

@@ -132,6 +132,13 @@ void RcclComm::rebuild(const Plan& P, hipStream_t s)
     OPMGPU_HIP(hipStreamSynchronize(s));
 }
 
+void RcclComm::subdomain_of_rows(const Plan& P, std::vector<int32_t>& sub) const
+{
+    sub.assign(P.nbp, rank);
+    for (size_t q = 0; q < neigh_rank.size(); ++q)
+        for (int k = recv_ptr[q]; k < recv_ptr[q + 1]; ++k) sub[P.pos[recv_cells[k]]] = neigh_rank[q];
+}
+
 template <class S> void RcclComm::halo_t(S* v, hipStream_t s)
 {
     const int ns = int(send_cells.size()), nr = int(recv_cells.size());

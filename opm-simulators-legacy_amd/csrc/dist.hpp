@@ -20,6 +20,9 @@ public:
     void allreduce_sum(double* dbuf, int n, hipStream_t s) override;
     void allreduce_max(double* dbuf, int n, hipStream_t s) override;
     const int8_t* owner_mask() const override { return d_mask.p; }
+    int my_rank() const override { return rank; }
+    int num_ranks() const override { return nranks; }
+    void subdomain_of_rows(const Plan& P, std::vector<int32_t>& sub) const override;
 
     int rank = 0, nranks = 1, n_owned = 0, n_local = 0, nbp = 0;
     double pvsum_global = 0.0;

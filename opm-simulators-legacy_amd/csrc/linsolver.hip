@@ -725,6 +725,7 @@ LinSolver::LinSolver(hipStream_t s) : stream(s)
     if (const char* e = std::getenv("OPMGPU_CPR_HALO_XP")) cpr_halo_xp = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_EMULATE_RANKS")) emulate_ranks = std::atoi(e);
     if (const char* e = std::getenv("OPMGPU_EMULATE_WHAT")) emulate_what = std::atoi(e);
+    if (const char* e = std::getenv("OPMGPU_COARSE")) coarse_mode = std::atoi(e);
 }
 LinSolver::~LinSolver()
 {
@@ -887,6 +888,275 @@ template <class S> void LinSolver::lowrank_reduce(const S* x, const SolveCtl* ct
 static void halo_dispatch(CommBase* c, float* v, hipStream_t s) { c->halo_exchange_f(v, s); }
 static void halo_dispatch(CommBase* c, double* v, hipStream_t s) { c->halo_exchange_d(v, s); }
 
+// ---- global coarse space of the CPR pressure stage (multi-GPU / emulated ranks): one unknown per subdomain ----
+// The AMG is subdomain-local, so nothing in it couples the subdomains: pressure error that is smooth across several of them is
+// only reduced at the cuts and the iteration count grows with the number of ranks (measured with OPMGPU_EMULATE_RANKS: 4.3 -> 8.0
+// iterations at 8 slabs).  Classical remedy (Nicolaides coarse space): before the local V-cycle the residual is corrected by the
+// Galerkin problem on the span of the subdomains' indicator vectors, A_c = P^T A_p P (n_sub x n_sub, inverted on every rank),
+//   e = A_c^-1 P^T r ;  r' = r - A_p P e ;  x_p = P e + Vcycle(r') .
+// P e is constant per subdomain, so its ghost entries are known without a halo exchange; the only communication is the sum of the
+// n_sub restricted residuals (one small all-reduce per application) and of the rows of A_c (once per matrix).
+__global__ __launch_bounds__(kBlock) void k_cs_sub_emulated(int nb, int nbp, int nranks, const int32_t* __restrict__ nat, int32_t* __restrict__ sub)
+{
+    const int row = blockIdx.x * kBlock + threadIdx.x;
+    if (row >= nbp) return;
+    sub[row] = row < nb ? int32_t(long(nat[row]) * nranks / nb) : 0;
+}
+// partial sums per workgroup: out[block][k] for k < ns2 (fixed order inside the block: thread 0 adds the per-thread tables of its
+// block serially -- small tables, rows of one block belong to one or two subdomains).  Deterministic.
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_cs_matrix(int nb, int nbp, int ns, const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
+                                                      const int16_t* __restrict__ rowlen, const int32_t* __restrict__ sub, const int8_t* __restrict__ owned,
+                                                      const S* __restrict__ w, const S* __restrict__ A, double* __restrict__ cA)
+{
+    const int row = blockIdx.x * kBlock + threadIdx.x;
+    if (row >= nb || (owned && !owned[row])) return;
+    const int base = slice_ptr[row >> 6], lane = row & 63, a = sub[row];
+    const double w0 = double(w[row]), w1 = double(w[nbp + row]), w2 = double(w[2 * long(nbp) + row]);
+    int bcur = -1; double acc = 0.0;
+    for (int k = 0, len = rowlen[row]; k < len; ++k) {
+        const long e = long(base + k) * 64 + lane;
+        const S* bl = A + (e >> 6) * 576 + (e & 63);
+        const double v = w0 * double(bl[0]) + w1 * double(bl[192]) + w2 * double(bl[384]);
+        const int b = sub[col[e]];
+        if (b != bcur) { if (bcur >= 0) atomicAdd(&cA[a * ns + bcur], acc); bcur = b; acc = 0.0; }
+        acc += v;
+    }
+    if (bcur >= 0) atomicAdd(&cA[a * ns + bcur], acc);
+}
+__global__ void k_cs_invert(int ns, const double* __restrict__ cA, double* __restrict__ inv)
+{
+    // Gauss-Jordan with partial pivoting, one thread (ns <= 64)
+    extern __shared__ double m[];          // [ns][2 ns]
+    const int n2 = 2 * ns;
+    for (int i = 0; i < ns; ++i) for (int j = 0; j < n2; ++j) m[i * n2 + j] = j < ns ? cA[i * ns + j] : (j - ns == i ? 1.0 : 0.0);
+    for (int p = 0; p < ns; ++p) {
+        int piv = p;
+        for (int i = p + 1; i < ns; ++i) if (fabs(m[i * n2 + p]) > fabs(m[piv * n2 + p])) piv = i;
+        if (m[piv * n2 + p] == 0.0) { for (int i = 0; i < ns * ns; ++i) inv[i] = 0.0; return; }     // singular: no correction
+        if (piv != p) for (int j = 0; j < n2; ++j) { const double t = m[p * n2 + j]; m[p * n2 + j] = m[piv * n2 + j]; m[piv * n2 + j] = t; }
+        const double d = 1.0 / m[p * n2 + p];
+        for (int j = 0; j < n2; ++j) m[p * n2 + j] *= d;
+        for (int i = 0; i < ns; ++i) if (i != p) { const double f = m[i * n2 + p]; for (int j = 0; j < n2; ++j) m[i * n2 + j] -= f * m[p * n2 + j]; }
+    }
+    for (int i = 0; i < ns; ++i) for (int j = 0; j < ns; ++j) inv[i * ns + j] = m[i * n2 + ns + j];
+}
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_cs_restrict(int nb, const int32_t* __restrict__ sub, const int8_t* __restrict__ owned, const S* __restrict__ r,
+                                                        double* __restrict__ cr, const SolveCtl* __restrict__ ctl)
+{
+    if (ctl && ctl->done) return;
+    const int row = blockIdx.x * kBlock + threadIdx.x;
+    const bool act = row < nb && (!owned || owned[row]);
+    const int a = act ? sub[row] : -1;
+    const double v = act ? double(r[row]) : 0.0;
+    // wave-uniform subdomain (the usual case): one atomic per wave, fixed lane order inside it
+    const int a0 = __shfl(a, 0, 64);
+    if (__all(a == a0)) { const double s_ = wave_sum(v); if ((threadIdx.x & 63) == 0 && a0 >= 0) atomicAdd(&cr[a0], s_); }
+    else if (act) atomicAdd(&cr[a], v);
+}
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_cs_correct(int nb, int nbp, int ns, const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
+                                                       const int16_t* __restrict__ rowlen, const int32_t* __restrict__ sub, const S* __restrict__ w,
+                                                       const S* __restrict__ A, const double* __restrict__ inv, const double* __restrict__ cr, S omega,
+                                                       const S* __restrict__ dinv, S* __restrict__ b, S* __restrict__ x0, S* __restrict__ xc,
+                                                       const SolveCtl* __restrict__ ctl)
+{
+    __shared__ double e[64];
+    if (ctl && ctl->done) return;
+    if (threadIdx.x < ns) { double s_ = 0.0; for (int k = 0; k < ns; ++k) s_ += inv[threadIdx.x * ns + k] * cr[k]; e[threadIdx.x] = s_; }
+    __syncthreads();
+    const int row = blockIdx.x * kBlock + threadIdx.x;
+    if (row >= nb) return;
+    const int base = slice_ptr[row >> 6], lane = row & 63;
+    const double w0 = double(w[row]), w1 = double(w[nbp + row]), w2 = double(w[2 * long(nbp) + row]);
+    double acc = 0.0;
+    for (int k = 0, len = rowlen[row]; k < len; ++k) {
+        const long en = long(base + k) * 64 + lane;
+        const S* bl = A + (en >> 6) * 576 + (en & 63);
+        acc += (w0 * double(bl[0]) + w1 * double(bl[192]) + w2 * double(bl[384])) * e[sub[col[en]]];
+    }
+    const S rn = S(double(b[row]) - acc);
+    b[row] = rn; x0[row] = omega * dinv[row] * rn; xc[row] = S(e[sub[row]]);
+}
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_cs_add(int nb, const S* __restrict__ x, const S* __restrict__ xc, S* __restrict__ out, const SolveCtl* __restrict__ ctl)
+{
+    if (ctl && ctl->done) return;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < nb) out[i] = x[i] + xc[i];
+}
+
+// real multi-GPU (one subdomain per process): deterministic versions -- per-workgroup partials, re-reduced in a fixed order
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_cs_rsum(int nb, const int8_t* __restrict__ owned, const S* __restrict__ r, double* __restrict__ parts,
+                                                    const SolveCtl* __restrict__ ctl)
+{
+    __shared__ double sm[4];
+    if (ctl && ctl->done) return;
+    double acc[1] = { 0.0 };
+    for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < nb; i += long(gridDim.x) * kBlock) if (!owned || owned[i]) acc[0] += double(r[i]);
+    block_sum<1>(acc, sm);
+    if (threadIdx.x == 0) parts[blockIdx.x] = acc[0];
+}
+__global__ __launch_bounds__(kBlock) void k_cs_place(int np, const double* __restrict__ parts, int ns, int mine, double* __restrict__ cr,
+                                                     const SolveCtl* __restrict__ ctl)
+{
+    __shared__ double sm[12];
+    if (ctl && ctl->done) return;
+    const double* const arr[1] = { parts };
+    double s_[1];
+    reduce_partials<1>(arr, np, s_, sm);
+    if (threadIdx.x < ns) cr[threadIdx.x] = threadIdx.x == mine ? s_[0] : 0.0;
+}
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_cs_rowparts(int nb, int nbp, LinSolver::CsSlots sl, const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
+                                                        const int16_t* __restrict__ rowlen, const int32_t* __restrict__ sub, const int8_t* __restrict__ owned,
+                                                        const S* __restrict__ w, const S* __restrict__ A, double* __restrict__ parts, S* __restrict__ T)
+{
+    // T[q][row] = sum_j A_p(row, j) [subdomain(j) == slot q]: what the per-application correction needs of the matrix
+    __shared__ double sm[32];
+    double acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    for (long row = blockIdx.x * long(kBlock) + threadIdx.x; row < nb; row += long(gridDim.x) * kBlock) {
+        if (owned && !owned[row]) { for (int q = 0; q < sl.n; ++q) T[long(q) * nbp + row] = S(0); continue; }
+        double mine[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        const int base = slice_ptr[row >> 6], lane = row & 63;
+        const double w0 = double(w[row]), w1 = double(w[nbp + row]), w2 = double(w[2 * long(nbp) + row]);
+        for (int k = 0, len = rowlen[row]; k < len; ++k) {
+            const long e = long(base + k) * 64 + lane;
+            const S* bl = A + (e >> 6) * 576 + (e & 63);
+            const double v = w0 * double(bl[0]) + w1 * double(bl[192]) + w2 * double(bl[384]);
+            const int s_ = sl.slot_of_sub[sub[col[e]]];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) mine[q] += (q == s_) ? v : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { acc[q] += mine[q]; if (q < sl.n) T[long(q) * nbp + row] = S(mine[q]); }
+    }
+    block_sum<8>(acc, sm);
+    if (threadIdx.x == 0) for (int q = 0; q < 8; ++q) parts[long(q) * gridDim.x + blockIdx.x] = acc[q];
+}
+__global__ __launch_bounds__(kBlock) void k_cs_place_row(int np, const double* __restrict__ parts, LinSolver::CsSlots sl, int ns, int mine, double* __restrict__ cA)
+{
+    __shared__ double sm[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int q = 0; q < sl.n; ++q) {
+        double v = 0.0;
+        for (int i = threadIdx.x; i < np; i += kBlock) v += parts[long(q) * np + i];
+        const double s_ = wave_sum(v);
+        __syncthreads();
+        if (lane == 0) sm[wv] = s_;
+        __syncthreads();
+        if (threadIdx.x == 0) cA[mine * ns + sl.sub_of_slot[q]] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    }
+}
+
+// wells (rank-7 operator per well, all perforations on this rank): their part of P^T (A_p + wells) P and of the row sums.  Without it
+// a rate-controlled well's diagonal terms are counted although the Schur complement cancels them for a constant pressure shift.
+// One workgroup per well, fixed reduction order; k_cs_wells_sum then adds the per-well totals to A_c(mine, mine) in well order.
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_cs_wells(LowRankOp lr, int nbp, const S* __restrict__ w, S* __restrict__ T0, double* __restrict__ well_tot)
+{
+    __shared__ double sm[28];
+    __shared__ double q7s[7];
+    const int wl = blockIdx.x;
+    double q7[7] = { 0, 0, 0, 0, 0, 0, 0 };
+    for (int j = lr.connpos[wl] + threadIdx.x; j < lr.connpos[wl + 1]; j += kBlock)
+        for (int k = 0; k < 7; ++k) q7[k] += lr.Q[21 * long(j) + 3 * k];              // pressure column of Q_j
+    block_sum<7>(q7, sm);
+    if (threadIdx.x == 0) for (int k = 0; k < 7; ++k) q7s[k] = q7[k];
+    __syncthreads();
+    double tot[1] = { 0.0 };
+    for (int i = lr.connpos[wl] + threadIdx.x; i < lr.connpos[wl + 1]; i += kBlock) {
+        const int row = lr.perf_row[i];
+        const double wa[3] = { double(w[row]), double(w[nbp + row]), double(w[2 * long(nbp) + row]) };
+        double t = 0.0;
+        for (int a = 0; a < 3; ++a) { double pa = 0.0; for (int k = 0; k < 7; ++k) pa += lr.P[21 * long(i) + 7 * a + k] * q7s[k]; t += wa[a] * pa; }
+        T0[row] = S(double(T0[row]) + t);
+        tot[0] += t;
+    }
+    __syncthreads();
+    block_sum<1>(tot, sm);
+    if (threadIdx.x == 0) well_tot[wl] = tot[0];
+}
+__global__ void k_cs_wells_sum(int nw, const double* __restrict__ well_tot, int mine, int ns, double* __restrict__ cA)
+{
+    double s_ = 0.0;
+    for (int wl = 0; wl < nw; ++wl) s_ += well_tot[wl];
+    cA[mine * ns + mine] += s_;
+}
+
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_cs_correct_fast(int nb, int nbp, int ns, LinSolver::CsSlots sl, const int32_t* __restrict__ sub, const S* __restrict__ T,
+                                                            const double* __restrict__ inv, const double* __restrict__ cr, S omega, const S* __restrict__ dinv,
+                                                            S* __restrict__ b, S* __restrict__ x0, S* __restrict__ xc, const SolveCtl* __restrict__ ctl)
+{
+    __shared__ double e[64];
+    if (ctl && ctl->done) return;
+    if (threadIdx.x < ns) { double s_ = 0.0; for (int k = 0; k < ns; ++k) s_ += inv[threadIdx.x * ns + k] * cr[k]; e[threadIdx.x] = s_; }
+    __syncthreads();
+    const int row = blockIdx.x * kBlock + threadIdx.x;
+    if (row >= nb) return;
+    double acc = 0.0;
+    for (int q = 0; q < sl.n; ++q) acc += e[sl.sub_of_slot[q]] * double(T[long(q) * nbp + row]);
+    const S rn = S(double(b[row]) - acc);
+    b[row] = rn; x0[row] = omega * dinv[row] * rn; xc[row] = S(e[sub[row]]);
+}
+
+template <class S> void LinSolver::coarse_setup()
+{
+    SolverWork<S>& w = work<S>();
+    const int ns = coarse_nsub;
+    const void* key = comm ? static_cast<const void*>(comm) : static_cast<const void*>(this);
+    const bool emulated = !comm && emulate_ranks > 1;
+    const int mine = comm ? comm->my_rank() : 0;
+    if (!cs_sub.p || cs_sub.n != size_t(plan.nbp) || cs_for != key) {
+        cs_sub.alloc(plan.nbp);
+        if (!emulated) {
+            std::vector<int32_t> sub;
+            if (comm) comm->subdomain_of_rows(plan, sub); else sub.assign(plan.nbp, 0);
+            cs_sub.upload(sub, stream);
+            // slots = own subdomain first, then the distinct neighbour subdomains seen in ghost rows
+            cs_slots.n = 0;
+            for (int i = 0; i < 64; ++i) cs_slots.slot_of_sub[i] = 0;
+            bool overflow = false;
+            auto add = [&](int sd) {
+                for (int q = 0; q < cs_slots.n; ++q) if (cs_slots.sub_of_slot[q] == sd) return;
+                if (cs_slots.n < 8 && sd >= 0 && sd < 64) { cs_slots.slot_of_sub[sd] = int8_t(cs_slots.n); cs_slots.sub_of_slot[cs_slots.n++] = sd; }
+                else overflow = true;
+            };
+            add(mine);
+            for (int32_t sd : sub) if (sd != mine) add(sd);
+            if (overflow) throw HipError(OPMGPU_EINVAL, "coarse space: more than 7 neighbour ranks or more than 64 ranks (set OPMGPU_COARSE=0)");
+            OPMGPU_HIP(hipStreamSynchronize(stream));
+        } else {
+            hipLaunchKernelGGL(k_cs_sub_emulated, dim3(grid_for(plan.nbp)), dim3(kBlock), 0, stream, plan.nb, plan.nbp, ns, dp.nat.p, cs_sub.p);
+        }
+        cs_for = key;
+    }
+    cs_buf.alloc(size_t(2) * ns * ns + ns + kMaxPart);
+    OPMGPU_HIP(hipMemsetAsync(cs_buf.p, 0, (size_t(2) * ns * ns + ns) * sizeof(double), stream));
+    w.cxc.alloc(plan.nbp);
+    double* cA = cs_buf.p; double* inv = cA + ns * ns;
+    if (!emulated) {
+        w.csT.alloc(size_t(cs_slots.n) * plan.nbp);
+        const int gp = std::min(grid_for(plan.nb), kMaxPart / 8);
+        hipLaunchKernelGGL((k_cs_rowparts<S>), dim3(gp), dim3(kBlock), 0, stream, plan.nb, plan.nbp, cs_slots, dp.slice_ptr.p, dp.col.p, dp.rowlen.p, cs_sub.p,
+                           comm ? comm->owner_mask() : (const int8_t*)nullptr, (const S*)w.cprw.p, matrix<S>(), partials.p, w.csT.p);
+        hipLaunchKernelGGL(k_cs_place_row, dim3(1), dim3(kBlock), 0, stream, gp, (const double*)partials.p, cs_slots, ns, mine, cA);
+        if (lowrank.nw > 0) {
+            cs_well_tot.alloc(lowrank.nw);
+            hipLaunchKernelGGL((k_cs_wells<S>), dim3(lowrank.nw), dim3(kBlock), 0, stream, lowrank, plan.nbp, (const S*)w.cprw.p, w.csT.p, cs_well_tot.p);
+            hipLaunchKernelGGL(k_cs_wells_sum, dim3(1), dim3(1), 0, stream, lowrank.nw, (const double*)cs_well_tot.p, mine, ns, cA);
+        }
+        if (comm) comm->allreduce_sum(cA, ns * ns, stream);
+    } else {
+        hipLaunchKernelGGL((k_cs_matrix<S>), dim3(grid_for(plan.nb)), dim3(kBlock), 0, stream, plan.nb, plan.nbp, ns, dp.slice_ptr.p, dp.col.p, dp.rowlen.p, cs_sub.p,
+                           (const int8_t*)nullptr, (const S*)w.cprw.p, matrix<S>(), cA);
+    }
+    hipLaunchKernelGGL(k_cs_invert, dim3(1), dim3(1), size_t(2) * ns * ns * sizeof(double), stream, ns, (const double*)cA, inv);
+}
+
 template <class S> void LinSolver::cpr_prepare()
 {
     SolverWork<S>& w = work<S>();
@@ -910,6 +1180,15 @@ template <class S> void LinSolver::cpr_prepare()
     hipLaunchKernelGGL((k_extract_pressure<S>), dim3(grid_for(plan.nbp)), dim3(kBlock), 0, stream, plan.nb, plan.nbp, dp.slice_ptr.p, (const S*)w.cprw.p, ((emulate_what & 2) ? pre_matrix<S>() : matrix<S>()),
                        w.amg->levels[0]->val.p);
     w.amg->galerkin();
+    // global coarse space: real ranks, or the emulated ones
+    // one subdomain (single GPU) is the global constant: the near-null-space vector of a closed, slightly compressible system
+    // (wells with a pressure control anchor the level: measured, the constant then costs more than it gains -- so with one
+    // subdomain it is used for well-free systems only; coarse_mode 2 forces it, 0 switches the whole coarse space off)
+    const int nsub = comm ? comm->num_ranks() : (emulate_ranks > 1 ? emulate_ranks : 1);
+    const bool single_ok = coarse_mode == 2 || (coarse_single_ok && lowrank.nw == 0);
+    coarse_nsub = coarse_mode != 0 && (nsub >= 2 || single_ok) ? nsub : 0;
+    if (coarse_nsub > 64) coarse_nsub = 0;        // table sizes of the kernels
+    if (coarse_nsub >= 1) coarse_setup<S>();
 }
 
 // M^-1 d = [x_p;0;0] + ILU0^-1 (d - A [x_p;0;0]),  x_p = Vcycle(sum of the equations of d)
@@ -919,9 +1198,35 @@ template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, con
     AmgLevel<S>& L0 = *w.amg->levels[0];
     const int g = grid_for(plan.nb);
     hipLaunchKernelGGL((k_cpr_sum_eqs<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, plan.nbp, d, (const S*)w.cprw.p, L0.b.p, S(w.amg->omega), (const S*)L0.dinv.p, L0.x.p, ctl);
+    const bool coarse = coarse_nsub >= 1;
+    if (coarse) {
+        const int ns = coarse_nsub;
+        double* inv = cs_buf.p + ns * ns; double* cr = inv + ns * ns;
+        const bool emulated = !comm && emulate_ranks > 1;
+        if (!emulated) {
+            const int gp = std::min(grid_for(plan.nb), kMaxPart);
+            double* parts = cs_buf.p + size_t(2) * ns * ns + ns;   // own scratch (the BiCGStab partial arrays are live across a preconditioner application)
+            hipLaunchKernelGGL((k_cs_rsum<S>), dim3(gp), dim3(kBlock), 0, stream, plan.nb, comm ? comm->owner_mask() : (const int8_t*)nullptr, (const S*)L0.b.p, parts, ctl);
+            hipLaunchKernelGGL(k_cs_place, dim3(1), dim3(kBlock), 0, stream, gp, (const double*)parts, ns, comm ? comm->my_rank() : 0, cr, ctl);
+            if (comm) comm->allreduce_sum(cr, ns, stream);
+        } else {
+            OPMGPU_HIP(hipMemsetAsync(cr, 0, ns * sizeof(double), stream));
+            hipLaunchKernelGGL((k_cs_restrict<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, cs_sub.p, (const int8_t*)nullptr, (const S*)L0.b.p, cr, ctl);
+        }
+        if (!emulated)
+            hipLaunchKernelGGL((k_cs_correct_fast<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, plan.nbp, ns, cs_slots, cs_sub.p, (const S*)w.csT.p, (const double*)inv,
+                               (const double*)cr, S(w.amg->omega), (const S*)L0.dinv.p, L0.b.p, L0.x.p, w.cxc.p, ctl);
+        else
+            hipLaunchKernelGGL((k_cs_correct<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, plan.nbp, ns, dp.slice_ptr.p, dp.col.p, dp.rowlen.p, cs_sub.p,
+                               (const S*)w.cprw.p, matrix<S>(), (const double*)inv, (const double*)cr, S(w.amg->omega), (const S*)L0.dinv.p, L0.b.p, L0.x.p, w.cxc.p, ctl);
+    }
     w.amg->vcycle_graph(ctl, true);
     const S* xp = L0.x.p;
-    if (comm && cpr_halo_xp) {
+    if (coarse) {
+        hipLaunchKernelGGL((k_cs_add<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, (const S*)L0.x.p, (const S*)w.cxc.p, w.hx.p, ctl);
+        xp = w.hx.p;
+        if (comm && cpr_halo_xp) halo_dispatch(comm, w.hx.p, stream);
+    } else if (comm && cpr_halo_xp) {
         // multi-GPU: the AMG is rank-local (additive Schwarz: ghost rows are identity rows); the owners' x_p is copied to the
         // ghosts before the full-system residual so that stage 2 sees the neighbours' pressure correction on the rows next to the
         // cut.  Costs two halo exchanges per BiCGStab iteration; without it (OPMGPU_CPR_HALO_XP=0) the one-rank self-halo deck,
@@ -1320,6 +1625,7 @@ double LinSolver::time_kernel(int kernel, int reps, int single_precision)
     template void LinSolver::spmv<S>(const S*, S*);                                      \
     template void LinSolver::cpr_prepare<S>();                                           \
     template const S* LinSolver::pre_matrix<S>();                                        \
+    template void LinSolver::coarse_setup<S>();                                          \
     template void LinSolver::cpr_apply<S>(const S*, S*, double, const SolveCtl*);        \
     template SolveResult LinSolver::bicgstab<S>(const opmgpu_params&);                   \
     template SolveResult LinSolver::gmres<S>(const opmgpu_params&);                      \

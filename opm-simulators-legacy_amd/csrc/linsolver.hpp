@@ -44,6 +44,10 @@ struct CommBase {
     virtual void allreduce_sum(double* dbuf, int n, hipStream_t s) = 0;
     virtual void allreduce_max(double* dbuf, int n, hipStream_t s) = 0;
     virtual const int8_t* owner_mask() const = 0;     // [nbp] internal numbering, 1 = owned
+    virtual int my_rank() const = 0;
+    virtual int num_ranks() const = 0;
+    // owner rank of every local row (internal numbering; ghosts: the rank they are received from)
+    virtual void subdomain_of_rows(const Plan& P, std::vector<int32_t>& sub) const = 0;
     int n_owned_global = 0;
 };
 
@@ -68,6 +72,8 @@ struct SolverWork {
     DevArray<S> Apre;   // OPMGPU_EMULATE_RANKS: matrix copy without the blocks across the emulated cuts
     DevArray<S> r, rt, p, v, t, y, x, b, z, hx;  // z: scratch of the CPR second stage; hx: halo staging of x_p (multi-GPU)
     DevArray<S> kry;                             // GMRES: Krylov basis, (restart + 1) vectors
+    DevArray<S> csT;                             // coarse space: per row, sum of its pressure entries towards each neighbour slot
+    DevArray<S> cxc;                             // coarse-space part of the pressure correction (constant per subdomain)
     DevArray<S> cprw;                            // [3][nbp] per-cell weights of the pressure equation (formEllipticSystem)
     std::unique_ptr<AmgHierarchy<S>> amg;         // CPR pressure stage (built on first use)
     bool allocated = false;
@@ -95,6 +101,16 @@ public:
     template <class S> void prepare(bool matrix_changed = true);
     template <class S> const S* matrix();
     template <class S> const S* pre_matrix();      // what the preconditioner is built from (== matrix() unless OPMGPU_EMULATE_RANKS)
+    // global coarse space of the pressure stage: one unknown per subdomain (0/1 = off)
+    int coarse_nsub = 0;
+    DevArray<int32_t> cs_sub;      // [nbp] subdomain of every row (ghost rows: their owner's)
+    DevArray<double> cs_buf;       // A_c | A_c^-1 | restricted residual
+    struct CsSlots { int n; int8_t slot_of_sub[64]; int32_t sub_of_slot[8]; } cs_slots;   // real multi-GPU: this rank's own + neighbour subdomains
+    const void* cs_for = nullptr;  // communicator / plan the subdomain data was built for
+    bool coarse_single_ok = false; // set by the model: the system has no wells at all (B1 matrices: unknown -> false)
+    DevArray<double> cs_well_tot;
+    int coarse_mode = 1;           // OPMGPU_COARSE: 0 off, 1 on with >= 2 subdomains, 2 on always (tests)
+    template <class S> void coarse_setup();
     int emulate_ranks = 1, emulate_what = 3;      // bit 0: cut the ILU0's matrix, bit 1: cut the AMG's
     bool pre_stale = true;
 

@@ -38,9 +38,14 @@ class _Dom:
     pass
 
 
-@pytest.mark.parametrize("cpr", [0, 1])
+@pytest.mark.parametrize("cpr", [0, 1, 2])
 @pytest.mark.parametrize("single", [False, True])
-def test_self_halo_reproduces_plain_grid(gpu_lib, oracle, single, cpr):
+def test_self_halo_reproduces_plain_grid(gpu_lib, oracle, single, cpr, monkeypatch):
+    # cpr == 2: CPR with the global coarse space of the pressure stage forced on although there is only one subdomain
+    # (OPMGPU_COARSE=2): its multi-GPU kernels (deterministic partial sums, all-reduces, per-subdomain correction) all run
+    if cpr == 2:
+        monkeypatch.setenv("OPMGPU_COARSE", "2")
+        cpr = 1
     gridA, gridB, src, halo = _periodic_pair()
     tab = decks.satfunc_standard_tables()
     stA = decks.initial_state(gridA, tab, perturb=0.01)
