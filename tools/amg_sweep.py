@@ -42,7 +42,11 @@ if __name__ == "__main__":
         sys.exit(0)
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     sigma = sys.argv[2] if len(sys.argv) > 2 else "0.5"
-    if len(sys.argv) > 3 and sys.argv[3] == "grid":
+    if len(sys.argv) > 3 and sys.argv[3] == "grid2":
+        import itertools
+        configs = [{}] + [{"OPMGPU_AMG_PDAMP": a, "OPMGPU_AMG_OMEGA": b, "OPMGPU_AMG_NPOST": c}
+                          for a, b, c in itertools.product(("1.0", "1.3", "1.6", "1.9", "2.2"), ("0.8", "0.9", "1.0"), ("1", "2"))]
+    elif len(sys.argv) > 3 and sys.argv[3] == "grid":
         import itertools
         configs = [{}] + [{"OPMGPU_AMG_PDAMP": a, "OPMGPU_AMG_OMEGA": b, "OPMGPU_AMG_NPOST": c, "OPMGPU_AMG_NPRE": d}
                           for a, b, c, d in itertools.product(("1.6", "1.9", "2.2", "2.5"), ("0.67", "0.8", "0.9", "1.0"), ("1", "2", "3"), ("1", "2"))]
