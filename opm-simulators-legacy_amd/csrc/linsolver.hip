@@ -1134,16 +1134,17 @@ template <class S> void LinSolver::coarse_setup()
         }
         cs_for = key;
     }
-    cs_buf.alloc(size_t(2) * ns * ns + ns + kMaxPart);
+    cs_buf.alloc(size_t(2) * ns * ns + ns + size_t(8) * kMaxPart);
     OPMGPU_HIP(hipMemsetAsync(cs_buf.p, 0, (size_t(2) * ns * ns + ns) * sizeof(double), stream));
     w.cxc.alloc(plan.nbp);
     double* cA = cs_buf.p; double* inv = cA + ns * ns;
     if (!emulated) {
         w.csT.alloc(size_t(cs_slots.n) * plan.nbp);
-        const int gp = std::min(grid_for(plan.nb), kMaxPart / 8);
+        const int gp = std::min(grid_for(plan.nb), kMaxPart);
+        double* rparts = cs_buf.p + size_t(2) * ns * ns + ns;      // 8 slots x gp partials
         hipLaunchKernelGGL((k_cs_rowparts<S>), dim3(gp), dim3(kBlock), 0, stream, plan.nb, plan.nbp, cs_slots, dp.slice_ptr.p, dp.col.p, dp.rowlen.p, cs_sub.p,
-                           comm ? comm->owner_mask() : (const int8_t*)nullptr, (const S*)w.cprw.p, matrix<S>(), partials.p, w.csT.p);
-        hipLaunchKernelGGL(k_cs_place_row, dim3(1), dim3(kBlock), 0, stream, gp, (const double*)partials.p, cs_slots, ns, mine, cA);
+                           comm ? comm->owner_mask() : (const int8_t*)nullptr, (const S*)w.cprw.p, matrix<S>(), rparts, w.csT.p);
+        hipLaunchKernelGGL(k_cs_place_row, dim3(1), dim3(kBlock), 0, stream, gp, (const double*)rparts, cs_slots, ns, mine, cA);
         if (lowrank.nw > 0) {
             cs_well_tot.alloc(lowrank.nw);
             hipLaunchKernelGGL((k_cs_wells<S>), dim3(lowrank.nw), dim3(kBlock), 0, stream, lowrank, plan.nbp, (const S*)w.cprw.p, w.csT.p, cs_well_tot.p);
