@@ -271,3 +271,41 @@ def test_gmres_option(gpu_lib, oracle, single):
     with pytest.raises(LinearSolverProblem):
         s.computeNewtonIncrement(rowptr, col, val, b, single)
     s.close()
+
+
+def test_global_coarse_space_restores_convergence_of_decomposed_preconditioner(gpu_lib, monkeypatch):
+    """The CPR pressure stage's global coarse space (one unknown per subdomain).  OPMGPU_EMULATE_RANKS builds the preconditioner
+    as a 4-rank run would (no coupling across the cuts in the ILU0's and the AMG's matrix): without the coarse space the
+    BiCGStab count grows, with it it is back at the single-domain count; the solution is the same in all cases."""
+    from opmgpu.model import GpuBlackoilModel
+    grid = decks.cartesian_grid(24, 24, 96, lognormal_sigma=0.5)
+    tab = decks.satfunc_standard_tables()
+    st = decks.initial_state(grid, tab, perturb=0.002)
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = GpuBlackoilModel(grid, tab, capi.default_params(use_cpr=1, linear_solver_reduction=1e-6, linear_solver_maxiter=200))
+        m.prepareStep(5 * decks.DAY, st)
+        its = 0
+        for it in range(3):
+            m.assemble(it == 0); m.getConvergence()
+            dx = m.solveJacobianSystem(want_dx=True, single_precision=False)
+            its += m.linear_iterations
+            m.updateState()
+        out = m.getState()
+        m.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        return its, out
+
+    base_its, base = run({"OPMGPU_COARSE": "0"})
+    cut_its, cut = run({"OPMGPU_COARSE": "0", "OPMGPU_EMULATE_RANKS": "4"})
+    fix_its, fix = run({"OPMGPU_COARSE": "1", "OPMGPU_EMULATE_RANKS": "4"})
+    one_its, one = run({"OPMGPU_COARSE": "1"})
+    assert cut_its > 1.3 * base_its, (base_its, cut_its)                 # the decomposition hurts ...
+    assert fix_its <= 1.25 * base_its and fix_its <= 0.7 * cut_its, (base_its, cut_its, fix_its)     # ... the coarse space repairs it
+    assert one_its < base_its, (base_its, one_its)                        # and the global constant alone already helps
+    for s in (cut, fix, one):
+        # same Newton path up to the linear tolerance (1e-6 on the residual, three iterations)
+        assert np.abs(s.p - base.p).max() <= 1e-5 * np.abs(base.p).max() and np.abs(s.sat - base.sat).max() <= 3e-4
