@@ -1231,13 +1231,15 @@ template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, con
         // multi-GPU: the AMG is rank-local (additive Schwarz: ghost rows are identity rows); the owners' x_p is copied to the
         // ghosts before the full-system residual so that stage 2 sees the neighbours' pressure correction on the rows next to the
         // cut.  Costs two halo exchanges per BiCGStab iteration; without it (OPMGPU_CPR_HALO_XP=0) the one-rank self-halo deck,
-        // where half of the rows touch the cut, needs 25 % more iterations.
+        // where half of the rows touch the cut, needs 25 % more iterations -- and with the coarse space it is essential: the
+        // subdomain constants jump at the cut, and a stage 2 that does not see the jump needs 2.5x the iterations (emulated 8
+        // ranks: 4.4 -> 11.5, OPMGPU_EMULATE_WHAT=7).
         OPMGPU_HIP(hipMemcpyAsync(w.hx.p, L0.x.p, size_t(plan.nb) * sizeof(S), hipMemcpyDeviceToDevice, stream));
         halo_dispatch(comm, w.hx.p, stream);
         xp = w.hx.p;
     }
     hipLaunchKernelGGL((k_cpr_presidual<S>), dim3(grid8_for(plan.nb)), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p,
-                       matrix<S>(), d, xp, w.z.p, comm ? comm->owner_mask() : (const int8_t*)nullptr, ctl);
+                       ((emulate_what & 4) ? pre_matrix<S>() : matrix<S>()), d, xp, w.z.p, comm ? comm->owner_mask() : (const int8_t*)nullptr, ctl);
     ilu_apply<S>(w.z.p, v, relax, ctl);
     hipLaunchKernelGGL((k_cpr_add_p<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, xp, v, ctl);
 }

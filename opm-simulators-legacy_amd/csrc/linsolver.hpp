@@ -111,7 +111,7 @@ public:
     DevArray<double> cs_well_tot;
     int coarse_mode = 1;           // OPMGPU_COARSE: 0 off, 1 on with >= 2 subdomains, 2 on always (tests)
     template <class S> void coarse_setup();
-    int emulate_ranks = 1, emulate_what = 3;      // bit 0: cut the ILU0's matrix, bit 1: cut the AMG's
+    int emulate_ranks = 1, emulate_what = 3;      // bit 0: cut the ILU0's matrix, bit 1: the AMG's, bit 2: the stage-2 residual's (= no x_p halo exchange)
     bool pre_stale = true;
 
     template <class S> int factor();                                // ILU0 numeric factorisation
