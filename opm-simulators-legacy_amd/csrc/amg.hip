@@ -355,7 +355,10 @@ void AmgHierarchy<S>::setup(const Plan& P, const int32_t* d_slice_ptr, const int
     std::unique_ptr<AmgLevel<S>> L(new AmgLevel<S>());
     L->n = P.nb; L->nslices = P.nslices; L->nentries = P.nentries; L->slice_ptr = d_slice_ptr; L->col = d_col;
     L->diag_entry.upload(diag0, stream);
-    const int kMaxDense = kDenseMax, kMaxLevels = 12;
+    const int kMaxDense = kDenseMax;
+    int kMaxLevels = 12;
+    if (const char* e = std::getenv("OPMGPU_AMG_MAXLEVELS")) kMaxLevels = std::max(2, std::atoi(e));
+    if (const char* e = std::getenv("OPMGPU_AMG_COARSE_SWEEPS")) coarse_sweeps = std::max(0, std::atoi(e));
     while (true) {
         const int n = A.n;
         L->val.alloc(L->nentries); L->dinv.alloc(n); L->x.alloc(n); L->b.alloc(n); L->r.alloc(n); L->x2.alloc(n);
@@ -472,7 +475,7 @@ void AmgHierarchy<S>::vcycle(const SolveCtl* ctl, bool level0_presmoothed)
         hipLaunchKernelGGL((k_dense_apply<S>), dim3((B.n + 3) / 4), dim3(kBlock), 0, stream, B.n, dense_inv.p, B.b.p, B.x.p, ctl);
     } else {        // coarsening stalled above the dense limit: a few Jacobi sweeps stand in for the coarse solve
         hipLaunchKernelGGL((k_amg_smooth0<S>), dim3(grid_for(B.n)), dim3(kBlock), 0, stream, B.n, om, B.dinv.p, B.b.p, B.x.p, ctl);
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < coarse_sweeps; ++s) {
             hipLaunchKernelGGL((k_amg_residual<S, 1>), dim3(grid_for(B.n)), dim3(kBlock), 0, stream, B.n, B.slice_ptr, B.col, B.val.p, B.b.p, B.x.p, om, B.dinv.p, B.x2.p, ctl);
             hipLaunchKernelGGL((k_amg_residual<S, 1>), dim3(grid_for(B.n)), dim3(kBlock), 0, stream, B.n, B.slice_ptr, B.col, B.val.p, B.b.p, B.x2.p, om, B.dinv.p, B.x.p, ctl);
         }

@@ -72,6 +72,7 @@ public:
     double pdamp = 1.9;           // coarse-grid correction scaling (dune-istl's prolongation damping factor)
     int npre = 1, npost = 2;      // smoothing sweeps before / after the coarse-grid correction
     int npost0 = 2;               // post-smoothing sweeps on level 0 (cheap per sweep there; coarse levels are launch-latency bound)
+    int coarse_sweeps = 4;        // pairs of Jacobi sweeps standing in for the coarsest solve when it is too big for the dense inverse
     bool fuse = true;             // launch fusions of the V-cycle (A/B: OPMGPU_AMG_FUSE=0)
     void sweep(AmgLevel<S>& F, const SolveCtl* ctl);
 };
