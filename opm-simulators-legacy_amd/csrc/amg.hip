@@ -277,16 +277,16 @@ __global__ __launch_bounds__(kBlock) void k_amg_prolong(int n, const int32_t* __
     if (i >= n) return;
     x[i] += pdamp * xc[agg[i]];
 }
-// coarsest level: the sparse operator is scattered into LDS and inverted IN PLACE by Gauss-Jordan (n <= kDenseMax = 96:
-// 72 KiB of the 160 KiB per CU); one workgroup of 1024 threads, no pivoting (the pressure operators are diagonally
+// coarsest level: the sparse operator is scattered into LDS and inverted by Gauss-Jordan between two LDS copies (ping-pong: every
+// element of step p is a function of the previous copy only, so ONE barrier per pivot instead of three; n <= kDenseMax = 96:
+// 2 x 72 KiB of the 160 KiB per CU); one workgroup of 1024 threads, no pivoting (the pressure operators are diagonally
 // dominant M-matrix-like).  Thread (i0, j) owns column j of rows i0, i0 + rows_per_pass, ...: no integer division in the loop.
 constexpr int kDenseMax = 96;
 template <class S>
 __global__ __launch_bounds__(1024) void k_dense_invert(int n, int log2_np, const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
                                                        const S* __restrict__ val, double* __restrict__ inv)
 {
-    extern __shared__ double a[];    // [n][n]
-    __shared__ double f[kDenseMax];
+    extern __shared__ double a[];    // 2 x [n][n]
     for (int t = threadIdx.x; t < n * n; t += blockDim.x) a[t] = 0.0;
     __syncthreads();
     for (int row = threadIdx.x; row < n; row += blockDim.x) {
@@ -295,21 +295,22 @@ __global__ __launch_bounds__(1024) void k_dense_invert(int n, int log2_np, const
     }
     __syncthreads();
     const int np = 1 << log2_np, j = threadIdx.x & (np - 1), i0 = threadIdx.x >> log2_np, istep = blockDim.x >> log2_np;
+    double* cur = a;
+    double* nxt = a + n * n;
     for (int p = 0; p < n; ++p) {
-        const double d = 1.0 / a[p * n + p];
-        if (j < n && i0 == 0) f[j] = (j == p) ? 0.0 : a[j * n + p];      // column p (multipliers), before it is overwritten
-        __syncthreads();
-        if (i0 == 0 && j < n) a[p * n + j] = (j == p) ? d : a[p * n + j] * d;
-        if (j == p) for (int i = i0; i < n; i += istep) if (i != p) a[i * n + p] = 0.0;
-        __syncthreads();
         if (j < n) {
-            const double apj = a[p * n + j];
-            for (int i = i0; i < n; i += istep) if (i != p) a[i * n + j] -= f[i] * apj;
+            const double d = 1.0 / cur[p * n + p];
+            const double apj = (j == p) ? d : cur[p * n + j] * d;          // row p of the next copy
+            for (int i = i0; i < n; i += istep) {
+                const double aip = cur[i * n + p];
+                nxt[i * n + j] = (i == p) ? apj : ((j == p) ? 0.0 : cur[i * n + j]) - aip * apj;
+            }
         }
         __syncthreads();
+        double* t = cur; cur = nxt; nxt = t;
     }
     // stored TRANSPOSED (inv[j*n + i] = Ainv(i,j)) so that k_dense_apply's loads are contiguous across lanes
-    if (j < n) for (int i = i0; i < n; i += istep) inv[j * n + i] = a[i * n + j];
+    if (j < n) for (int i = i0; i < n; i += istep) inv[j * n + i] = cur[i * n + j];
 }
 // x = Ainv b on the coarsest level: one wavefront per row (inv is stored transposed, so row i is read with stride n by
 // its wave -- n <= 256 keeps that inside a few cache lines per step; what matters is 64-way parallelism per row)
@@ -402,7 +403,7 @@ void AmgHierarchy<S>::setup(const Plan& P, const int32_t* d_slice_ptr, const int
     }
     n_coarsest = levels.back()->n;
     if (n_coarsest <= kDenseMax)        // > 64 KiB of dynamic LDS must be requested explicitly
-        OPMGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_invert<S>), hipFuncAttributeMaxDynamicSharedMemorySize, kDenseMax * kDenseMax * int(sizeof(double))));
+        OPMGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_invert<S>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kDenseMax * kDenseMax * int(sizeof(double))));
     if (std::getenv("OPMGPU_VERBOSE")) { std::fprintf(stderr, "[opmgpu] AMG levels:"); for (int n : level_sizes) std::fprintf(stderr, " %d", n); std::fprintf(stderr, "\n"); }
     if (n_coarsest <= kDenseMax) {
         dense_inv.alloc(size_t(n_coarsest) * n_coarsest);
@@ -427,7 +428,7 @@ void AmgHierarchy<S>::galerkin()
     hipLaunchKernelGGL((k_amg_dinv<S>), dim3(grid_for(B.n)), dim3(kBlock), 0, stream, B.n, B.diag_entry.p, B.val.p, B.dinv.p);
     if (n_coarsest <= kDenseMax) {
         int lg = 0; while ((1 << lg) < B.n) ++lg;
-        hipLaunchKernelGGL((k_dense_invert<S>), dim3(1), dim3(1024), size_t(B.n) * B.n * sizeof(double), stream, B.n, lg, B.slice_ptr, B.col, B.val.p, dense_inv.p);
+        hipLaunchKernelGGL((k_dense_invert<S>), dim3(1), dim3(1024), size_t(2) * B.n * B.n * sizeof(double), stream, B.n, lg, B.slice_ptr, B.col, B.val.p, dense_inv.p);
         OPMGPU_HIP(hipGetLastError());
     }
 }

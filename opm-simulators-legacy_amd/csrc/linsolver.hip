@@ -25,6 +25,7 @@ int xcd_mode()
 }
 
 constexpr int kMaxPart = 1024;      // workgroups (= partials) of every reducing kernel
+constexpr int kCsRowParts = 8192;   // ... of the fused CPR row pass (one row per thread up to 2M rows: latency-bound, wants occupancy)
 
 // ------------------------------------------------------------------------------------------
 // kernels
@@ -545,13 +546,8 @@ __global__ __launch_bounds__(kBlock) void k_copy16(long n16, const double2* __re
 // with the reference's fix-up for a weak oil equation (:233-252): if no equation is strong the oil equation alone is used.
 // Equations here are ordered water, oil, gas (the reference swaps oil first: "a concession to MRST").  Weights are 0 / 1.
 template <class S>
-__global__ __launch_bounds__(kBlock) void k_cpr_weights(int nb, int nbp, const int32_t* __restrict__ slice_ptr, const int16_t* __restrict__ rowlen,
-                                                        const int16_t* __restrict__ nlower, const int32_t* __restrict__ tpos, const S* __restrict__ A,
-                                                        S* __restrict__ w, int mode)
+__device__ inline void cpr_row_weights(int lane, int base, int len, int nl, const int32_t* __restrict__ tpos, const S* __restrict__ A, int mode, S w[3])
 {
-    const int row = blockIdx.x * kBlock + threadIdx.x;
-    if (row >= nb) return;
-    const int base = slice_ptr[row >> 6], lane = row & 63, len = rowlen[row], nl = nlower[row];
     if (mode == 1) {
         // quasi-IMPES: w = first row of A_ii^-1, i.e. the combination of the cell's equations that eliminates its own saturation /
         // composition unknowns from the diagonal block (w . A_ii = [1 0 0]); not what the reference does (experiment knob)
@@ -564,10 +560,10 @@ __global__ __launch_bounds__(kBlock) void k_cpr_weights(int nb, int nbp, const i
         const double id = (det != 0.0 && det == det) ? 1.0 / det : 0.0;
         double w0 = c0 * id, w1 = (m[2] * m[7] - m[1] * m[8]) * id, w2 = (m[1] * m[5] - m[2] * m[4]) * id;
         if (id == 0.0) { w0 = 1.0; w1 = 1.0; w2 = 1.0; }
-        w[row] = S(w0); w[nbp + row] = S(w1); w[2 * long(nbp) + row] = S(w2);
+        w[0] = S(w0); w[1] = S(w1); w[2] = S(w2);
         return;
     }
-    double sod[3] = { 0.0, 0.0, 0.0 }, dj[3];
+    double sod[3] = { 0.0, 0.0, 0.0 }, dj[3] = { 0.0, 0.0, 0.0 };
     for (int k = 0; k < len; ++k) {
         const long e = long(base + k) * 64 + lane;
         if (k == nl) {
@@ -583,7 +579,18 @@ __global__ __launch_bounds__(kBlock) void k_cpr_weights(int nb, int nbp, const i
     const bool sw = dj[0] / sod[0] > 0.01, sg = dj[2] / sod[2] > 0.01;       // NaN (0/0) compares false like the reference's Eigen cast
     bool so = dj[1] / sod[1] > 0.01;
     if (!so && !sw && !sg) so = true;
-    w[row] = sw ? S(1) : S(0); w[nbp + row] = so ? S(1) : S(0); w[2 * long(nbp) + row] = sg ? S(1) : S(0);
+    w[0] = sw ? S(1) : S(0); w[1] = so ? S(1) : S(0); w[2] = sg ? S(1) : S(0);
+}
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_cpr_weights(int nb, int nbp, const int32_t* __restrict__ slice_ptr, const int16_t* __restrict__ rowlen,
+                                                        const int16_t* __restrict__ nlower, const int32_t* __restrict__ tpos, const S* __restrict__ A,
+                                                        S* __restrict__ w, int mode)
+{
+    const int row = blockIdx.x * kBlock + threadIdx.x;
+    if (row >= nb) return;
+    S ww[3];
+    cpr_row_weights<S>(row & 63, slice_ptr[row >> 6], rowlen[row], nlower[row], tpos, A, mode, ww);
+    w[row] = ww[0]; w[nbp + row] = ww[1]; w[2 * long(nbp) + row] = ww[2];
 }
 // A_p(i,j) = sum over the selected equations of A_ij[eq][pressure]; one thread per row (padding slots included: value 0)
 template <class S>
@@ -1036,6 +1043,48 @@ __global__ __launch_bounds__(kBlock) void k_cs_rowparts(int nb, int nbp, LinSolv
     block_sum<8>(acc, sm);
     if (threadIdx.x == 0) for (int q = 0; q < 8; ++q) parts[long(q) * gridDim.x + blockIdx.x] = acc[q];
 }
+// the whole per-row set-up of the pressure stage in ONE pass over the matrix (per Newton iteration): weights (k_cpr_weights), the
+// pressure matrix (k_extract_pressure) and, with CS, the coarse-space row parts (k_cs_rowparts) -- same arithmetic as the three
+template <class S, bool CS>
+__global__ __launch_bounds__(kBlock) void k_cpr_rows(int nb, int nbp, int mode, LinSolver::CsSlots sl, const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
+                                                     const int16_t* __restrict__ rowlen, const int16_t* __restrict__ nlower, const int32_t* __restrict__ tpos,
+                                                     const int32_t* __restrict__ sub, const int8_t* __restrict__ owned, const S* __restrict__ A,
+                                                     S* __restrict__ w, S* __restrict__ Ap, double* __restrict__ parts, S* __restrict__ T)
+{
+    __shared__ double sm[32];
+    double acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    for (long row = blockIdx.x * long(kBlock) + threadIdx.x; row < nbp; row += long(gridDim.x) * kBlock) {
+        const int base = slice_ptr[row >> 6], width = slice_ptr[(row >> 6) + 1] - base, lane = row & 63;
+        if (row >= nb) { for (int k = 0; k < width; ++k) Ap[long(base + k) * 64 + lane] = S(0); continue; }
+        const int len = rowlen[row];
+        S ww[3];
+        cpr_row_weights<S>(lane, base, len, nlower[row], tpos, A, mode, ww);
+        w[row] = ww[0]; w[nbp + row] = ww[1]; w[2 * long(nbp) + row] = ww[2];
+        const bool cs = CS && !(owned && !owned[row]);
+        const double w0 = double(ww[0]), w1 = double(ww[1]), w2 = double(ww[2]);
+        double mine[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        for (int k = 0; k < width; ++k) {
+            const long e = long(base + k) * 64 + lane;
+            const S* bl = A + (e >> 6) * 576 + (e & 63);
+            const S b0 = bl[0], b1 = bl[192], b2 = bl[384];
+            Ap[e] = ww[0] * b0 + ww[1] * b1 + ww[2] * b2;
+            if (cs && k < len) {
+                const double v = w0 * double(b0) + w1 * double(b1) + w2 * double(b2);
+                const int s_ = sl.slot_of_sub[sub[col[e]]];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) mine[q] += (q == s_) ? v : 0.0;
+            }
+        }
+        if (CS) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { acc[q] += mine[q]; if (q < sl.n) T[long(q) * nbp + row] = S(mine[q]); }
+        }
+    }
+    if (CS) {
+        block_sum<8>(acc, sm);
+        if (threadIdx.x == 0) for (int q = 0; q < 8; ++q) parts[long(q) * gridDim.x + blockIdx.x] = acc[q];
+    }
+}
 __global__ __launch_bounds__(kBlock) void k_cs_place_row(int np, const double* __restrict__ parts, LinSolver::CsSlots sl, int ns, int mine, double* __restrict__ cA)
 {
     __shared__ double sm[4];
@@ -1103,7 +1152,34 @@ __global__ __launch_bounds__(kBlock) void k_cs_correct_fast(int nb, int nbp, int
     b[row] = rn; x0[row] = omega * dinv[row] * rn; xc[row] = S(e[sub[row]]);
 }
 
-template <class S> void LinSolver::coarse_setup()
+template <class S> void LinSolver::coarse_setup(bool rowparts_done)
+{
+    SolverWork<S>& w = work<S>();
+    const int ns = coarse_nsub;
+    const bool emulated = !comm && emulate_ranks > 1;
+    const int mine = comm ? comm->my_rank() : 0;
+    double* cA = cs_buf.p; double* inv = cA + ns * ns;
+    if (!emulated) {
+        const int gp = rowparts_done ? std::min(grid_for(plan.nbp), kCsRowParts) : std::min(grid_for(plan.nb), kMaxPart);
+        double* rparts = cs_buf.p + size_t(2) * ns * ns + ns;      // 8 slots x gp partials
+        if (!rowparts_done)
+            hipLaunchKernelGGL((k_cs_rowparts<S>), dim3(gp), dim3(kBlock), 0, stream, plan.nb, plan.nbp, cs_slots, dp.slice_ptr.p, dp.col.p, dp.rowlen.p, cs_sub.p,
+                               comm ? comm->owner_mask() : (const int8_t*)nullptr, (const S*)w.cprw.p, matrix<S>(), rparts, w.csT.p);
+        hipLaunchKernelGGL(k_cs_place_row, dim3(1), dim3(kBlock), 0, stream, gp, (const double*)rparts, cs_slots, ns, mine, cA);
+        if (lowrank.nw > 0) {
+            cs_well_tot.alloc(lowrank.nw);
+            hipLaunchKernelGGL((k_cs_wells<S>), dim3(lowrank.nw), dim3(kBlock), 0, stream, lowrank, plan.nbp, (const S*)w.cprw.p, w.csT.p, cs_well_tot.p);
+            hipLaunchKernelGGL(k_cs_wells_sum, dim3(1), dim3(1), 0, stream, lowrank.nw, (const double*)cs_well_tot.p, mine, ns, cA);
+        }
+        if (comm) comm->allreduce_sum(cA, ns * ns, stream);
+    } else {
+        hipLaunchKernelGGL((k_cs_matrix<S>), dim3(grid_for(plan.nb)), dim3(kBlock), 0, stream, plan.nb, plan.nbp, ns, dp.slice_ptr.p, dp.col.p, dp.rowlen.p, cs_sub.p,
+                           (const int8_t*)nullptr, (const S*)w.cprw.p, matrix<S>(), cA);
+    }
+    hipLaunchKernelGGL(k_cs_invert, dim3(1), dim3(1), size_t(2) * ns * ns * sizeof(double), stream, ns, (const double*)cA, inv);
+}
+// subdomain map, slots and buffers of the coarse space (before the fused row pass writes into them)
+template <class S> void LinSolver::coarse_begin()
 {
     SolverWork<S>& w = work<S>();
     const int ns = coarse_nsub;
@@ -1134,28 +1210,10 @@ template <class S> void LinSolver::coarse_setup()
         }
         cs_for = key;
     }
-    cs_buf.alloc(size_t(2) * ns * ns + ns + size_t(8) * kMaxPart);
+    cs_buf.alloc(size_t(2) * ns * ns + ns + size_t(8) * kCsRowParts);
     OPMGPU_HIP(hipMemsetAsync(cs_buf.p, 0, (size_t(2) * ns * ns + ns) * sizeof(double), stream));
     w.cxc.alloc(plan.nbp);
-    double* cA = cs_buf.p; double* inv = cA + ns * ns;
-    if (!emulated) {
-        w.csT.alloc(size_t(cs_slots.n) * plan.nbp);
-        const int gp = std::min(grid_for(plan.nb), kMaxPart);
-        double* rparts = cs_buf.p + size_t(2) * ns * ns + ns;      // 8 slots x gp partials
-        hipLaunchKernelGGL((k_cs_rowparts<S>), dim3(gp), dim3(kBlock), 0, stream, plan.nb, plan.nbp, cs_slots, dp.slice_ptr.p, dp.col.p, dp.rowlen.p, cs_sub.p,
-                           comm ? comm->owner_mask() : (const int8_t*)nullptr, (const S*)w.cprw.p, matrix<S>(), rparts, w.csT.p);
-        hipLaunchKernelGGL(k_cs_place_row, dim3(1), dim3(kBlock), 0, stream, gp, (const double*)rparts, cs_slots, ns, mine, cA);
-        if (lowrank.nw > 0) {
-            cs_well_tot.alloc(lowrank.nw);
-            hipLaunchKernelGGL((k_cs_wells<S>), dim3(lowrank.nw), dim3(kBlock), 0, stream, lowrank, plan.nbp, (const S*)w.cprw.p, w.csT.p, cs_well_tot.p);
-            hipLaunchKernelGGL(k_cs_wells_sum, dim3(1), dim3(1), 0, stream, lowrank.nw, (const double*)cs_well_tot.p, mine, ns, cA);
-        }
-        if (comm) comm->allreduce_sum(cA, ns * ns, stream);
-    } else {
-        hipLaunchKernelGGL((k_cs_matrix<S>), dim3(grid_for(plan.nb)), dim3(kBlock), 0, stream, plan.nb, plan.nbp, ns, dp.slice_ptr.p, dp.col.p, dp.rowlen.p, cs_sub.p,
-                           (const int8_t*)nullptr, (const S*)w.cprw.p, matrix<S>(), cA);
-    }
-    hipLaunchKernelGGL(k_cs_invert, dim3(1), dim3(1), size_t(2) * ns * ns * sizeof(double), stream, ns, (const double*)cA, inv);
+    if (!emulated) w.csT.alloc(size_t(cs_slots.n) * plan.nbp);
 }
 
 template <class S> void LinSolver::cpr_prepare()
@@ -1166,6 +1224,32 @@ template <class S> void LinSolver::cpr_prepare()
     // OPMGPU_AMG_LAG=k (experiment): refresh the pressure hierarchy's numbers only on every k-th matrix
     if (amg_lag > 1 && w.amg->ready() && w.cprw.p && (++amg_age % amg_lag) != 0) return;
     w.cprw.alloc(3 * size_t(plan.nbp));
+    // global coarse space: real ranks, or the emulated ones
+    // one subdomain (single GPU) is the global constant: the near-null-space vector of a closed, slightly compressible system
+    // (wells with a pressure control anchor the level: measured, the constant then costs more than it gains -- so with one
+    // subdomain it is used for well-free systems only; coarse_mode 2 forces it, 0 switches the whole coarse space off)
+    const int nsub = comm ? comm->num_ranks() : (emulate_ranks > 1 ? emulate_ranks : 1);
+    const bool single_ok = coarse_mode == 2 || (coarse_single_ok && lowrank.nw == 0);
+    coarse_nsub = coarse_mode != 0 && (nsub >= 2 || single_ok) ? nsub : 0;
+    if (coarse_nsub > 64) coarse_nsub = 0;        // table sizes of the kernels
+    const bool emulated = !comm && emulate_ranks > 1;
+    if (w.amg->ready() && !emulated) {
+        // the usual case: one pass over the matrix does weights + pressure matrix (+ coarse-space row parts)
+        const int gp = std::min(grid_for(plan.nbp), kCsRowParts);
+        if (coarse_nsub >= 1) {
+            coarse_begin<S>();
+            hipLaunchKernelGGL((k_cpr_rows<S, true>), dim3(gp), dim3(kBlock), 0, stream, plan.nb, plan.nbp, cpr_weight_mode, cs_slots, dp.slice_ptr.p, dp.col.p, dp.rowlen.p,
+                               dp.nlower.p, dp.tpos.p, cs_sub.p, comm ? comm->owner_mask() : (const int8_t*)nullptr, matrix<S>(), w.cprw.p,
+                               w.amg->levels[0]->val.p, cs_buf.p + size_t(2) * coarse_nsub * coarse_nsub + coarse_nsub, w.csT.p);
+        } else {
+            hipLaunchKernelGGL((k_cpr_rows<S, false>), dim3(gp), dim3(kBlock), 0, stream, plan.nb, plan.nbp, cpr_weight_mode, cs_slots, dp.slice_ptr.p, dp.col.p, dp.rowlen.p,
+                               dp.nlower.p, dp.tpos.p, (const int32_t*)nullptr, (const int8_t*)nullptr, matrix<S>(), w.cprw.p,
+                               w.amg->levels[0]->val.p, (double*)nullptr, (S*)nullptr);
+        }
+        w.amg->galerkin();
+        if (coarse_nsub >= 1) coarse_setup<S>(true);
+        return;
+    }
     hipLaunchKernelGGL((k_cpr_weights<S>), dim3(grid_for(plan.nb)), dim3(kBlock), 0, stream, plan.nb, plan.nbp, dp.slice_ptr.p, dp.rowlen.p, dp.nlower.p,
                        dp.tpos.p, ((emulate_what & 2) ? pre_matrix<S>() : matrix<S>()), w.cprw.p, cpr_weight_mode);
     if (!w.amg->ready()) {
@@ -1181,15 +1265,7 @@ template <class S> void LinSolver::cpr_prepare()
     hipLaunchKernelGGL((k_extract_pressure<S>), dim3(grid_for(plan.nbp)), dim3(kBlock), 0, stream, plan.nb, plan.nbp, dp.slice_ptr.p, (const S*)w.cprw.p, ((emulate_what & 2) ? pre_matrix<S>() : matrix<S>()),
                        w.amg->levels[0]->val.p);
     w.amg->galerkin();
-    // global coarse space: real ranks, or the emulated ones
-    // one subdomain (single GPU) is the global constant: the near-null-space vector of a closed, slightly compressible system
-    // (wells with a pressure control anchor the level: measured, the constant then costs more than it gains -- so with one
-    // subdomain it is used for well-free systems only; coarse_mode 2 forces it, 0 switches the whole coarse space off)
-    const int nsub = comm ? comm->num_ranks() : (emulate_ranks > 1 ? emulate_ranks : 1);
-    const bool single_ok = coarse_mode == 2 || (coarse_single_ok && lowrank.nw == 0);
-    coarse_nsub = coarse_mode != 0 && (nsub >= 2 || single_ok) ? nsub : 0;
-    if (coarse_nsub > 64) coarse_nsub = 0;        // table sizes of the kernels
-    if (coarse_nsub >= 1) coarse_setup<S>();
+    if (coarse_nsub >= 1) { coarse_begin<S>(); coarse_setup<S>(false); }
 }
 
 // M^-1 d = [x_p;0;0] + ILU0^-1 (d - A [x_p;0;0]),  x_p = Vcycle(sum of the equations of d)
@@ -1628,7 +1704,8 @@ double LinSolver::time_kernel(int kernel, int reps, int single_precision)
     template void LinSolver::spmv<S>(const S*, S*);                                      \
     template void LinSolver::cpr_prepare<S>();                                           \
     template const S* LinSolver::pre_matrix<S>();                                        \
-    template void LinSolver::coarse_setup<S>();                                          \
+    template void LinSolver::coarse_setup<S>(bool);                                      \
+    template void LinSolver::coarse_begin<S>();                                          \
     template void LinSolver::cpr_apply<S>(const S*, S*, double, const SolveCtl*);        \
     template SolveResult LinSolver::bicgstab<S>(const opmgpu_params&);                   \
     template SolveResult LinSolver::gmres<S>(const opmgpu_params&);                      \

@@ -110,7 +110,8 @@ public:
     bool coarse_single_ok = false; // set by the model: the system has no wells at all (B1 matrices: unknown -> false)
     DevArray<double> cs_well_tot;
     int coarse_mode = 1;           // OPMGPU_COARSE: 0 off, 1 on with >= 2 subdomains, 2 on always (tests)
-    template <class S> void coarse_setup();
+    template <class S> void coarse_begin();
+    template <class S> void coarse_setup(bool rowparts_done);
     int emulate_ranks = 1, emulate_what = 3;      // bit 0: cut the ILU0's matrix, bit 1: the AMG's, bit 2: the stage-2 residual's (= no x_p halo exchange)
     bool pre_stale = true;
 
