@@ -410,28 +410,37 @@ __global__ __launch_bounds__(kBlock) void k_flux(int xm, int nb, int nbp, const 
 #pragma unroll
     for (int a = 0; a < 3; ++a) { own[a] = load_phase(props, pstate, nbp, row, a); ownU[a] = load4(props, PL_U + 4 * a, nbp, row); }
     const V4 ownRs = load4(props, PL_RS, nbp, row), ownRv = load4(props, PL_RV, nbp, row);
-    for (int k = 0; k < len; ++k) {
-        if (k == nl) continue;
-        const long e = long(base + k) * 64 + lane;
-        const int code = conn_code[e];
+    // The loop is a chain of dependent loads (connection code -> neighbour index -> neighbour record -> upwind-dependent planes) at
+    // 2 waves per SIMD (212 VGPRs), i.e. latency bound: the code/index of the NEXT connection are fetched while this one is
+    // computed, and all upwind-dependent loads of a connection (U of three phases, rs, rv) are issued together after the three
+    // potential differences, not one phase at a time.  (Forcing 3 waves per SIMD spills 200 B per lane: 265 -> 490 us.)
+    int k0 = (nl == 0) ? 1 : 0;
+    int code_n = 0, nbr_n = 0;
+    if (k0 < len) { const long e0 = long(base + k0) * 64 + lane; code_n = conn_code[e0]; nbr_n = col[e0]; }
+    for (int k = k0; k < len; ) {
+        const int code = code_n, nbr = nbr_n;
+        const int kn = (k + 1 == nl) ? k + 2 : k + 1;
+        if (kn < len) { const long en = long(base + kn) * 64 + lane; code_n = conn_code[en]; nbr_n = col[en]; }
         MS* bptr = A + long(base + k) * 576 + lane;
+        k = kn;
         if (code < 0) {          // pure well fill: the host adds the Schur block later
 #pragma unroll
             for (int q = 0; q < 9; ++q) bptr[q * 64] = MS(0);
             continue;
         }
-        const int nbr = col[e];
         const int conn = code >> 1, side = code & 1;       // side 0: this row is c1 (ngrad +1), side 1: it is c2
         const double Tf = trans[conn], g = gdz[conn];
         const double thp = thpres ? thpres[conn] : 0.0;
         // F[a], dF/d(c1 vars), dF/d(c2 vars)
-        double F[3], dF1[3][3], dF2[3][3];
+        double F[3], dF1[3][3], dF2[3][3], d1[3][3], d2[3][3], Tdh[3];
         int up[3];
+        PhaseIn qn[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) qn[a] = load_phase(props, pstate, nbp, nbr, a);
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const PhaseIn qn = load_phase(props, pstate, nbp, nbr, a);
-            const PhaseIn q1 = side ? qn : own[a];
-            const PhaseIn q2 = side ? own[a] : qn;
+            const PhaseIn q1 = side ? qn[a] : own[a];
+            const PhaseIn q2 = side ? own[a] : qn[a];
             double dh = (q1.p - q2.p) - g * (0.5 * q1.rho + 0.5 * q2.rho);
             double keep = 1.0;
             if (thpres) {
@@ -440,24 +449,29 @@ __global__ __launch_bounds__(kBlock) void k_flux(int xm, int nb, int nbp, const 
                 dh = keep * (dh - sg_ * thp);
             }
             const double hg = 0.5 * g;
-            const double d1[3] = { keep * (1.0 - hg * q1.drp), keep * (q1.dpw - hg * q1.drw), keep * (q1.dpx - hg * q1.drx) };
-            const double d2[3] = { keep * (-1.0 - hg * q2.drp), keep * (-q2.dpw - hg * q2.drw), keep * (-q2.dpx - hg * q2.drx) };
+            d1[a][0] = keep * (1.0 - hg * q1.drp); d1[a][1] = keep * (q1.dpw - hg * q1.drw); d1[a][2] = keep * (q1.dpx - hg * q1.drx);
+            d2[a][0] = keep * (-1.0 - hg * q2.drp); d2[a][1] = keep * (-q2.dpw - hg * q2.drw); d2[a][2] = keep * (-q2.dpx - hg * q2.drx);
             up[a] = (dh >= 0.0) ? 0 : 1;
-            V4 U = ownU[a];
-            if (up[a] != side) U = load4(props, PL_U + 4 * a, nbp, nbr);          // the upwind cell is the neighbour
-            const double Tdh = Tf * dh;
-            F[a] = U.v * Tdh;
-            const double dU[3] = { U.p, U.w, U.x };
+            Tdh[a] = Tf * dh;
+        }
+        // upwind-dependent planes of the neighbour, one batch
+        V4 U[3] = { ownU[0], ownU[1], ownU[2] };
+        V4 rsu = ownRs, rvu = ownRv;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) if (up[a] != side) U[a] = load4(props, PL_U + 4 * a, nbp, nbr);          // the upwind cell is the neighbour
+        if (up[1] != side) rsu = load4(props, PL_RS, nbp, nbr);
+        if (up[2] != side) rvu = load4(props, PL_RV, nbp, nbr);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            F[a] = U[a].v * Tdh[a];
+            const double dU[3] = { U[a].p, U[a].w, U[a].x };
 #pragma unroll
             for (int v = 0; v < 3; ++v) {
-                dF1[a][v] = U.v * (Tf * d1[v]) + (up[a] == 0 ? dU[v] * Tdh : 0.0);
-                dF2[a][v] = U.v * (Tf * d2[v]) + (up[a] == 1 ? dU[v] * Tdh : 0.0);
+                dF1[a][v] = U[a].v * (Tf * d1[a][v]) + (up[a] == 0 ? dU[v] * Tdh[a] : 0.0);
+                dF2[a][v] = U[a].v * (Tf * d2[a][v]) + (up[a] == 1 ? dU[v] * Tdh[a] : 0.0);
             }
         }
         // G_o = F_o + rv_up(g) F_g ; G_g = F_g + rs_up(o) F_o
-        V4 rsu = ownRs, rvu = ownRv;
-        if (up[1] != side) rsu = load4(props, PL_RS, nbp, nbr);
-        if (up[2] != side) rvu = load4(props, PL_RV, nbp, nbr);
         const double drs[3] = { rsu.p, rsu.w, rsu.x }, drv[3] = { rvu.p, rvu.w, rvu.x };
         double G[3] = { F[0], F[1] + rvu.v * F[2], F[2] + rsu.v * F[1] };
         double dG1[3][3], dG2[3][3];
