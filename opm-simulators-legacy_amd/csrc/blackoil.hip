@@ -300,10 +300,15 @@ __device__ void eval_cell(const opmgpu_tables& T, const EpsD& E, double so_max, 
 // ------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void st4(double* __restrict__ props, int plane, long nbp, int row, const V4& a)
+// Face-input planes: the VALUE planes (pressures, densities, b*mobility, rs, rv: they enter the residual) are always double; the
+// DERIVATIVE planes (they enter only the Jacobian) are stored in the Jacobian's precision PS -- a float Jacobian (assemble_single)
+// rounds its entries to 24 bits anyway, and k_flux is bound by the bytes of the seven cell records it reads per row
+// (PMC: 1.34 GB fetched per launch at 100^3 against 0.48 GB of distinct lines, 50 % L2 hit rate).
+template <class PS>
+__device__ __forceinline__ void st4(double* __restrict__ props, PS* __restrict__ pd, int plane, long nbp, int row, const V4& a)
 {
-    props[long(plane) * nbp + row] = a.v; props[long(plane + 1) * nbp + row] = a.p;
-    props[long(plane + 2) * nbp + row] = a.w; props[long(plane + 3) * nbp + row] = a.x;
+    props[long(plane) * nbp + row] = a.v; pd[long(plane + 1) * nbp + row] = PS(a.p);
+    pd[long(plane + 2) * nbp + row] = PS(a.w); pd[long(plane + 3) * nbp + row] = PS(a.x);
 }
 
 template <class MS>
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(kBlock) void k_cell_props(int nb, int nbp, opmgpu_t
                                                        const int32_t* __restrict__ slice_ptr, const int16_t* __restrict__ nlower,
                                                        const double* __restrict__ eps, const double* __restrict__ eps_u0,
                                                        const double* __restrict__ somax,
-                                                       double* __restrict__ props, double* __restrict__ accum0, double* __restrict__ R,
+                                                       double* __restrict__ props, MS* __restrict__ pd, double* __restrict__ accum0, double* __restrict__ R,
                                                        double* __restrict__ binv, MS* __restrict__ A, const double* __restrict__ tab_blob, int tab_words)
 {
     extern __shared__ double tab_lds[];
@@ -327,14 +332,14 @@ __global__ __launch_bounds__(kBlock) void k_cell_props(int nb, int nbp, opmgpu_t
     eps_load(eps, eps_u0, nbp, row, satnum[row], E);
     eval_cell(T, E, somax[row], pvtnum[row], satnum[row], p[row], sw[row], sg[row], rs[row], rv[row], hc[row], q);
     props[long(PL_PW) * nbp + row] = q.pw.v; props[long(PL_PG) * nbp + row] = q.pg.v;
-    props[long(PL_DPW_W) * nbp + row] = q.pw.w; props[long(PL_DPG_W) * nbp + row] = q.pg.w; props[long(PL_DPG_X) * nbp + row] = q.pg.x;
+    pd[long(PL_DPW_W) * nbp + row] = MS(q.pw.w); pd[long(PL_DPG_W) * nbp + row] = MS(q.pg.w); pd[long(PL_DPG_X) * nbp + row] = MS(q.pg.x);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        st4(props, PL_RHO + 4 * a, nbp, row, q.rho[a]);
-        st4(props, PL_U + 4 * a, nbp, row, vmul(q.b[a], q.mob[a]));
+        st4(props, pd, PL_RHO + 4 * a, nbp, row, q.rho[a]);
+        st4(props, pd, PL_U + 4 * a, nbp, row, vmul(q.b[a], q.mob[a]));
         binv[long(a) * nbp + row] = 1.0 / q.b[a].v;
     }
-    st4(props, PL_RS, nbp, row, q.rs); st4(props, PL_RV, nbp, row, q.rv);
+    st4(props, pd, PL_RS, nbp, row, q.rs); st4(props, pd, PL_RV, nbp, row, q.rv);
     // accumulation term pvdt * (accum1 - accum0) and its diagonal-block contribution
     const double pvdt = pv[row] * inv_dt;
     const double scale[3] = { s0, s1, s2 };
@@ -352,20 +357,22 @@ __global__ __launch_bounds__(kBlock) void k_cell_props(int nb, int nbp, opmgpu_t
 
 struct PhaseIn { double p, dpw, dpx, rho, drp, drw, drx; };    // dp/dP == 1 for every phase
 
-__device__ __forceinline__ PhaseIn load_phase(const double* __restrict__ props, const double* __restrict__ pstate, long nbp, int c, int a)
+template <class PS>
+__device__ __forceinline__ PhaseIn load_phase(const double* __restrict__ props, const PS* __restrict__ pd, const double* __restrict__ pstate, long nbp, int c, int a)
 {
     PhaseIn r;
-    if (a == 0) { r.p = props[long(PL_PW) * nbp + c]; r.dpw = props[long(PL_DPW_W) * nbp + c]; r.dpx = 0.0; }
+    if (a == 0) { r.p = props[long(PL_PW) * nbp + c]; r.dpw = double(pd[long(PL_DPW_W) * nbp + c]); r.dpx = 0.0; }
     else if (a == 1) { r.p = pstate[c]; r.dpw = 0.0; r.dpx = 0.0; }
-    else { r.p = props[long(PL_PG) * nbp + c]; r.dpw = props[long(PL_DPG_W) * nbp + c]; r.dpx = props[long(PL_DPG_X) * nbp + c]; }
-    const double* q = props + long(PL_RHO + 4 * a) * nbp + c;
-    r.rho = q[0]; r.drp = q[nbp]; r.drw = q[2 * nbp]; r.drx = q[3 * nbp];
+    else { r.p = props[long(PL_PG) * nbp + c]; r.dpw = double(pd[long(PL_DPG_W) * nbp + c]); r.dpx = double(pd[long(PL_DPG_X) * nbp + c]); }
+    const long o = long(PL_RHO + 4 * a) * nbp + c;
+    r.rho = props[o]; r.drp = double(pd[o + nbp]); r.drw = double(pd[o + 2 * nbp]); r.drx = double(pd[o + 3 * nbp]);
     return r;
 }
-__device__ __forceinline__ V4 load4(const double* __restrict__ props, int plane, long nbp, int c)
+template <class PS>
+__device__ __forceinline__ V4 load4(const double* __restrict__ props, const PS* __restrict__ pd, int plane, long nbp, int c)
 {
-    const double* q = props + long(plane) * nbp + c;
-    return mk(q[0], q[nbp], q[2 * nbp], q[3 * nbp]);
+    const long o = long(plane) * nbp + c;
+    return mk(props[o], double(pd[o + nbp]), double(pd[o + 2 * nbp]), double(pd[o + 3 * nbp]));
 }
 
 // TPFA flux residual + 3x3 Jacobian blocks, one thread per row
@@ -376,7 +383,7 @@ __global__ __launch_bounds__(kBlock) void k_flux(int xm, int nb, int nbp, const 
                                                  const int16_t* __restrict__ rowlen, const int16_t* __restrict__ nlower,
                                                  const int32_t* __restrict__ conn_code, const double* __restrict__ trans,
                                                  const double* __restrict__ gdz, const double* __restrict__ thpres,
-                                                 const double* __restrict__ pstate, const double* __restrict__ props,
+                                                 const double* __restrict__ pstate, const double* __restrict__ props, const MS* __restrict__ pd,
                                                  double s0, double s1, double s2, const int8_t* __restrict__ mask,
                                                  double* __restrict__ R, MS* __restrict__ A)
 {
@@ -408,8 +415,8 @@ __global__ __launch_bounds__(kBlock) void k_flux(int xm, int nb, int nbp, const 
     PhaseIn own[3];
     V4 ownU[3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { own[a] = load_phase(props, pstate, nbp, row, a); ownU[a] = load4(props, PL_U + 4 * a, nbp, row); }
-    const V4 ownRs = load4(props, PL_RS, nbp, row), ownRv = load4(props, PL_RV, nbp, row);
+    for (int a = 0; a < 3; ++a) { own[a] = load_phase(props, pd, pstate, nbp, row, a); ownU[a] = load4(props, pd, PL_U + 4 * a, nbp, row); }
+    const V4 ownRs = load4(props, pd, PL_RS, nbp, row), ownRv = load4(props, pd, PL_RV, nbp, row);
     // The loop is a chain of dependent loads (connection code -> neighbour index -> neighbour record -> upwind-dependent planes) at
     // 2 waves per SIMD (212 VGPRs), i.e. latency bound: the code/index of the NEXT connection are fetched while this one is
     // computed, and all upwind-dependent loads of a connection (U of three phases, rs, rv) are issued together after the three
@@ -436,7 +443,7 @@ __global__ __launch_bounds__(kBlock) void k_flux(int xm, int nb, int nbp, const 
         int up[3];
         PhaseIn qn[3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) qn[a] = load_phase(props, pstate, nbp, nbr, a);
+        for (int a = 0; a < 3; ++a) qn[a] = load_phase(props, pd, pstate, nbp, nbr, a);
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const PhaseIn q1 = side ? qn[a] : own[a];
@@ -458,9 +465,9 @@ __global__ __launch_bounds__(kBlock) void k_flux(int xm, int nb, int nbp, const 
         V4 U[3] = { ownU[0], ownU[1], ownU[2] };
         V4 rsu = ownRs, rvu = ownRv;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) if (up[a] != side) U[a] = load4(props, PL_U + 4 * a, nbp, nbr);          // the upwind cell is the neighbour
-        if (up[1] != side) rsu = load4(props, PL_RS, nbp, nbr);
-        if (up[2] != side) rvu = load4(props, PL_RV, nbp, nbr);
+        for (int a = 0; a < 3; ++a) if (up[a] != side) U[a] = load4(props, pd, PL_U + 4 * a, nbp, nbr);          // the upwind cell is the neighbour
+        if (up[1] != side) rsu = load4(props, pd, PL_RS, nbp, nbr);
+        if (up[2] != side) rvu = load4(props, pd, PL_RV, nbp, nbr);
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             F[a] = U[a].v * Tdh[a];
@@ -944,13 +951,21 @@ template <class MS> void BlackoilDevice::assemble_kernels(double dt, bool initia
 {
     const Plan& P = ls.plan;
     const double* sc = prm.matbalscale;
+    MS* pd = deriv_planes<MS>();
     hipLaunchKernelGGL((k_cell_props<MS>), dim3(grid_for(nc)), dim3(kBlock), tab_lds_bytes(), stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_pv.p,
                        d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, 1.0 / dt, int(initial), sc[0], sc[1], sc[2],
-                       ls.dp.slice_ptr.p, ls.dp.nlower.p, eps_planes(), d_eps_u0.p, d_somax.p, d_props.p, d_accum0.p, d_R.p, d_binv.p, A,
+                       ls.dp.slice_ptr.p, ls.dp.nlower.p, eps_planes(), d_eps_u0.p, d_somax.p, d_props.p, pd, d_accum0.p, d_R.p, d_binv.p, A,
                        (const double*)d_tab.p, tab_lds_words());
     hipLaunchKernelGGL((k_flux<MS>), dim3(grid8_for(nc)), dim3(kBlock), 0, stream, xcd_mode(), nc, P.nbp, ls.dp.slice_ptr.p, ls.dp.col.p, ls.dp.rowlen.p,
                        ls.dp.nlower.p, d_conn_code.p, d_trans.p, d_gdz.p, use_thpres ? d_thpres.p : (const double*)nullptr,
-                       d_p.p, d_props.p, sc[0], sc[1], sc[2], ls.comm ? ls.comm->owner_mask() : (const int8_t*)nullptr, d_R.p, A);
+                       d_p.p, d_props.p, (const MS*)pd, sc[0], sc[1], sc[2], ls.comm ? ls.comm->owner_mask() : (const int8_t*)nullptr, d_R.p, A);
+}
+// derivative planes in the Jacobian's precision: the double ones live in d_props itself, the float ones in their own buffer
+template <> double* BlackoilDevice::deriv_planes<double>() { return d_props.p; }
+template <> float* BlackoilDevice::deriv_planes<float>()
+{
+    if (!d_props_f.p) { d_props_f.alloc(size_t(PL_COUNT) * ls.plan.nbp); d_props_f.zero(stream); }
+    return d_props_f.p;
 }
 
 // The Jacobian is written in the precision of the coming solve (opmgpu_set_solve_precision): float saves the f64 -> f32 copy
@@ -979,7 +994,7 @@ double BlackoilDevice::time_assemble(int reps, int props_only)
         if (props_only)
             hipLaunchKernelGGL((k_cell_props<double>), dim3(grid_for(nc)), dim3(kBlock), tab_lds_bytes(), stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_pv.p,
                                d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, 1.0 / dt, 0, sc[0], sc[1], sc[2],
-                               ls.dp.slice_ptr.p, ls.dp.nlower.p, eps_planes(), d_eps_u0.p, d_somax.p, d_props.p, d_accum0.p, d_R.p, d_binv.p, ls.matrix_d(),
+                               ls.dp.slice_ptr.p, ls.dp.nlower.p, eps_planes(), d_eps_u0.p, d_somax.p, d_props.p, d_props.p, d_accum0.p, d_R.p, d_binv.p, ls.matrix_d(),
                                (const double*)d_tab.p, tab_lds_words());
         else assemble(dt, false);
     };

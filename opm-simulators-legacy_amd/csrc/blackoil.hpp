@@ -109,6 +109,8 @@ private:
     DevArray<double> d_p, d_sw, d_so, d_sg, d_rs, d_rv;
     DevArray<int8_t> d_hc;
     // device: work
+    DevArray<float> d_props_f;      // derivative planes of a float Jacobian (see st4 in blackoil.hip)
+    template <class MS> MS* deriv_planes();
     DevArray<double> d_props, d_accum0, d_R, d_binv, d_dx, d_dx_old, d_red, d_perf, d_rhs_extra;
     double* h_red = nullptr;
     std::vector<double> hbuf;
