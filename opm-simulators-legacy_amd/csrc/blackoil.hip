@@ -1227,7 +1227,7 @@ void BlackoilDevice::dx_to_host(double* dx)
 void BlackoilDevice::update_state(const double* dx_host, double relax)
 {
     const Plan& P = ls.plan;
-    if (dx_host) { ls.vec_from_host<double>(dx_host, VEC_EQUATION_MAJOR, d_dx.p); has_dx = true; }
+    if (dx_host) { ls.vec_from_host<double>(dx_host, VEC_EQUATION_MAJOR, d_dx.p); OPMGPU_HIP(hipStreamSynchronize(stream)); has_dx = true; }   // caller's buffer: done with it on return
     if (device_wells) wells_update(relax);          // recoverVariable + updateWellState from the same increment
     hipLaunchKernelGGL(k_update_state, dim3(grid_for(nc)), dim3(kBlock), tab_lds_bytes(), stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_dx.p, relax,
                        prm.dp_max_rel, prm.ds_max, prm.dr_max_rel, d_p.p, d_sw.p, d_so.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, eps_planes(), d_eps_u0.p, d_somax.p,

@@ -24,7 +24,11 @@ struct opmgpu_ctx {
     int cur_single = 0;          // precision of the loaded / prepared matrix
     bool matrix_loaded = false;
     bool factored = false;
-    double t_assemble = 0, t_solve = 0, t_update = 0;
+    // phase timings (assemble, solve, update): events recorded around the phase, resolved only when opmgpu_last_timings asks --
+    // a synchronisation at the end of every call would leave the GPU idle until the host has enqueued the next phase
+    double t_phase[3] = { 0, 0, 0 };
+    hipEvent_t evp[3][2] = { { nullptr, nullptr }, { nullptr, nullptr }, { nullptr, nullptr } };
+    bool ev_pending[3] = { false, false, false };
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::unique_ptr<RcclComm> comm;   // multi-GPU (dist.hip); empty = single GPU
 };
@@ -55,28 +59,27 @@ int make_ctx(opmgpu_ctx** out, int device, const opmgpu_params* params)
     if (hipSetDevice(device) != hipSuccess) return OPMGPU_ENODEVICE;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return OPMGPU_ENODEVICE;
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return OPMGPU_ENODEVICE;
+    for (auto& pr : c->evp) for (auto& e : pr) if (hipEventCreate(&e) != hipSuccess) return OPMGPU_ENODEVICE;
     try { c->ls.reset(new LinSolver(c->stream)); } catch (const HipError& e) { return e.code; }
     *out = c.release();
     return OPMGPU_OK;
 }
 
+enum { PH_ASSEMBLE = 0, PH_SOLVE = 1, PH_UPDATE = 2 };
 struct Timed {
-    opmgpu_ctx* c; double* dst;
-    Timed(opmgpu_ctx* c_, double* d) : c(c_), dst(d) { (void)hipEventRecord(c->ev0, c->stream); }
-    ~Timed() {
-        (void)hipEventRecord(c->ev1, c->stream); (void)hipEventSynchronize(c->ev1);
-        float ms = 0.f; (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); *dst = ms;
-    }
+    opmgpu_ctx* c; int ph;
+    Timed(opmgpu_ctx* c_, int phase) : c(c_), ph(phase) { c->ev_pending[ph] = false; (void)hipEventRecord(c->evp[ph][0], c->stream); }
+    ~Timed() { (void)hipEventRecord(c->evp[ph][1], c->stream); c->ev_pending[ph] = true; }
 };
 
 template <class S> int solve_loaded(opmgpu_ctx* c, bool matrix_changed, SolveResult& res)
 {
     LinSolver& ls = *c->ls;
     ls.prepare<S>(matrix_changed);
-    const int st = ls.factor<S>();
-    if (st != OPMGPU_OK) return fail(c, st, "singular diagonal block in ILU0");
-    c->factored = true;
+    (void)ls.factor<S>(false);           // status read below: the solver's own final synchronisation covers it
     res = c->prm.newton_use_gmres ? ls.gmres<S>(c->prm) : ls.bicgstab<S>(c->prm);
+    if (ls.factor_status() != OPMGPU_OK) { c->factored = false; return fail(c, OPMGPU_ESINGULAR, "singular diagonal block in ILU0"); }
+    c->factored = true;
     if (res.status == OPMGPU_ELINSOLVE) c->err = "Convergence failure for linear solver.";
     if (res.status == OPMGPU_EBREAKDOWN) c->err = "breakdown in BiCGSTAB";
     return res.status;
@@ -125,6 +128,7 @@ void opmgpu_destroy(opmgpu_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->model.reset(); c->ls.reset(); c->comm.reset();
+    for (auto& pr : c->evp) for (auto& e : pr) if (e) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -163,9 +167,10 @@ int opmgpu_assemble(opmgpu_ctx* c, double dt, int initial, const double* p, cons
             c->model->set_state(p, sat, rs, rv, hc);
         }
         if (!c->model->has_state) return fail(c, OPMGPU_EINVAL, "no reservoir state on the device");
-        c->t_solve = 0.0; c->t_update = 0.0;       // a Newton iteration that converges here runs no solve / update
+        c->t_phase[PH_SOLVE] = 0.0; c->t_phase[PH_UPDATE] = 0.0;       // a Newton iteration that converges here runs no solve / update
+        c->ev_pending[PH_SOLVE] = false; c->ev_pending[PH_UPDATE] = false;
         {
-            Timed t(c, &c->t_assemble);
+            Timed t(c, PH_ASSEMBLE);
             c->model->assemble(dt, initial != 0);
         }
         c->matrix_loaded = true; c->factored = false; c->cur_single = -1;
@@ -220,7 +225,7 @@ int opmgpu_solve(opmgpu_ctx* c, int single_precision, double* dx, int* iters, do
         SolveResult res;
         int st;
         {
-            Timed t(c, &c->t_solve);
+            Timed t(c, PH_SOLVE);
             if (single_precision) { c->ls->ensure_work<float>(); c->model->build_rhs<float>(); st = solve_loaded<float>(c, true, res); if (st == OPMGPU_OK || st == OPMGPU_ELINSOLVE) c->model->store_dx<float>(); }
             else { c->ls->ensure_work<double>(); c->model->build_rhs<double>(); st = solve_loaded<double>(c, true, res); if (st == OPMGPU_OK || st == OPMGPU_ELINSOLVE) c->model->store_dx<double>(); }
         }
@@ -237,7 +242,7 @@ int opmgpu_update_state(opmgpu_ctx* c, const double* dx, double relax)
     if (!c || !c->model || !c->model->has_state) return OPMGPU_EINVAL;
     if (!dx && !c->model->has_dx) return fail(c, OPMGPU_EINVAL, "no resident Newton increment");
     return guarded(c, [&]() {
-        Timed t(c, &c->t_update);
+        Timed t(c, PH_UPDATE);
         c->model->update_state(dx, relax);
         return OPMGPU_OK;
     });
@@ -342,7 +347,7 @@ int opmgpu_solve_bsr(opmgpu_ctx* c, int nb, const int32_t* rowptr, const int32_t
     return guarded(c, [&]() {
         SolveResult res; int st;
         {
-            Timed t(c, &c->t_solve);
+            Timed t(c, PH_SOLVE);
             if (single_precision) { c->ls->vec_from_host<float>(rhs3, VEC_BLOCK_INTERLEAVED, c->ls->work<float>().b.p); st = solve_loaded<float>(c, false, res); }
             else { c->ls->vec_from_host<double>(rhs3, VEC_BLOCK_INTERLEAVED, c->ls->work<double>().b.p); st = solve_loaded<double>(c, false, res); }
         }
@@ -470,9 +475,15 @@ int opmgpu_time_kernel(opmgpu_ctx* c, int kernel, int reps, double* ms_per_launc
 int opmgpu_last_timings(opmgpu_ctx* c, double* assemble_ms, double* solve_ms, double* update_ms)
 {
     if (!c) return OPMGPU_EINVAL;
-    if (assemble_ms) *assemble_ms = c->t_assemble;
-    if (solve_ms) *solve_ms = c->t_solve;
-    if (update_ms) *update_ms = c->t_update;
+    for (int ph = 0; ph < 3; ++ph) {
+        if (!c->ev_pending[ph]) continue;
+        float ms = 0.f;
+        if (hipEventSynchronize(c->evp[ph][1]) == hipSuccess && hipEventElapsedTime(&ms, c->evp[ph][0], c->evp[ph][1]) == hipSuccess) c->t_phase[ph] = ms;
+        c->ev_pending[ph] = false;
+    }
+    if (assemble_ms) *assemble_ms = c->t_phase[PH_ASSEMBLE];
+    if (solve_ms) *solve_ms = c->t_phase[PH_SOLVE];
+    if (update_ms) *update_ms = c->t_phase[PH_UPDATE];
     return OPMGPU_OK;
 }
 

@@ -12,6 +12,8 @@
 #include "linsolver.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -475,10 +477,12 @@ __global__ __launch_bounds__(kBlock) void k_update_xr2(long n, int j, SolveCtl* 
 }
 
 // convergence test after the last enqueued iteration (what k_update_p(j+1) would have done)
-__global__ __launch_bounds__(kBlock) void k_final_check(int j, SolveCtl* __restrict__ ctl, SolveCtl* __restrict__ hst, const double* __restrict__ p_n2, int np)
+// tick (optional): a host-mapped word the host spins on instead of synchronising the stream -- written last, after a system fence
+__global__ __launch_bounds__(kBlock) void k_final_check(int j, SolveCtl* __restrict__ ctl, SolveCtl* __restrict__ hst, const double* __restrict__ p_n2, int np,
+                                                        int* __restrict__ tick_ptr = nullptr, int tick = 0)
 {
     __shared__ double sm[12];
-    if (ctl->done) { if (threadIdx.x == 0) publish(ctl, hst); return; }
+    if (ctl->done) { if (threadIdx.x == 0) { publish(ctl, hst); if (tick_ptr) { __threadfence_system(); *(volatile int*)tick_ptr = tick; } } return; }
     const double* const arr[1] = { p_n2 };
     double s[1];
     reduce_partials<1>(arr, np, s, sm);
@@ -487,6 +491,7 @@ __global__ __launch_bounds__(kBlock) void k_final_check(int j, SolveCtl* __restr
         ctl->iters = j;
         if (s[0] < ctl->thresh2 || s[0] < 1e-60) ctl->done = 1;
         publish(ctl, hst);
+        if (tick_ptr) { __threadfence_system(); *(volatile int*)tick_ptr = tick; }
     }
 }
 __global__ void k_ctl_init(SolveCtl* ctl, SolveCtl* hst, double red)
@@ -721,6 +726,10 @@ LinSolver::LinSolver(hipStream_t s) : stream(s)
     OPMGPU_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_ctl), sizeof(SolveCtl), hipHostMallocMapped));
     std::memset(h_ctl, 0, sizeof(SolveCtl));
     OPMGPU_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h_ctl_dev), h_ctl, 0));
+    OPMGPU_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_tick), sizeof(int), hipHostMallocMapped));
+    *h_tick = 0;
+    OPMGPU_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h_tick_dev), h_tick, 0));
+    if (const char* e = std::getenv("OPMGPU_POLL")) poll_status = std::atoi(e) != 0;
     ctl.alloc(1); ctl.zero(stream);
     OPMGPU_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_flags), 4 * sizeof(int32_t)));
     OPMGPU_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
@@ -737,6 +746,7 @@ LinSolver::LinSolver(hipStream_t s) : stream(s)
 LinSolver::~LinSolver()
 {
     if (h_ctl) (void)hipHostFree(h_ctl);
+    if (h_tick) (void)hipHostFree(h_tick);
     if (h_flags) (void)hipHostFree(h_flags);
     if (ev[0]) (void)hipEventDestroy(ev[0]);
     if (ev[1]) (void)hipEventDestroy(ev[1]);
@@ -839,7 +849,7 @@ template <class S> const S* LinSolver::pre_matrix()
     return w.Apre.p;
 }
 
-template <class S> int LinSolver::factor()
+template <class S> int LinSolver::factor(bool wait)
 {
     SolverWork<S>& w = work<S>();
     flags.zero(stream);
@@ -850,8 +860,9 @@ template <class S> int LinSolver::factor()
                            dp.nlower.p, dp.trip_ptr.p, dp.trip_l.p, dp.trip_u.p, dp.trip_t.p, ((emulate_what & 1) ? pre_matrix<S>() : matrix<S>()), dp.rowlen.p, w.LU.p, flags.p);
     }
     OPMGPU_HIP(hipMemcpyAsync(h_flags, flags.p, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    if (!wait) return OPMGPU_OK;          // the caller reads factor_status() after its next synchronisation (no pipeline bubble per solve)
     OPMGPU_HIP(hipStreamSynchronize(stream));
-    return (h_flags[0] & 1) ? OPMGPU_ESINGULAR : OPMGPU_OK;
+    return factor_status();
 }
 
 template <class S> void LinSolver::ilu_apply(const S* d, S* v, double relax, const SolveCtl* ctl)
@@ -1324,6 +1335,23 @@ template <class S> static void halo(CommBase* c, S* v, hipStream_t s);
 template <> void halo<float>(CommBase* c, float* v, hipStream_t s) { c->halo_exchange_f(v, s); }
 template <> void halo<double>(CommBase* c, double* v, hipStream_t s) { c->halo_exchange_d(v, s); }
 
+// Wait for the status block of the check kernel just enqueued.  Spinning on a host-mapped word the kernel writes last sees the result
+// a few microseconds after the kernel retires; hipStreamSynchronize takes an interrupt round trip (~20 us of idle GPU per check).
+// Falls back to the stream synchronisation after 20 ms (a faulted kernel never ticks; the synchronisation then reports the error).
+void LinSolver::wait_tick(int tick)
+{
+    if (poll_status) {
+        const auto t0 = std::chrono::steady_clock::now();
+        volatile int* t = h_tick;
+        for (long spins = 0; *t != tick; ++spins) {
+            if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+            __builtin_ia32_pause();
+        }
+        if (*t == tick) { std::atomic_thread_fence(std::memory_order_acquire); return; }
+    }
+    OPMGPU_HIP(hipStreamSynchronize(stream));
+}
+
 template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
 {
     SolverWork<S>& w = work<S>();
@@ -1354,11 +1382,15 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
     double* P_h = partials.p, *P_n1 = P_h + npart, *P_tr = P_n1 + npart, *P_tt = P_tr + npart, *P_n2 = P_tt + npart, *P_rho = P_n2 + npart;
     double* red = P_rho + npart;                               // 8 all-reduced scalars (multi-GPU)
     // (multi-GPU) collapse partial arrays of np entries into red[slot..] and all-reduce them; consumers then read 1 entry
-    auto bridge = [&](double*& a0, double*& a1, int& np, int slot) {
+    // defer > 0: no all-reduce now, the NEXT bridge (whose slots follow this one's) reduces `defer` more values in the same call
+    int deferred = 0;
+    auto bridge = [&](double*& a0, double*& a1, int& np, int slot, bool defer = false) {
         if (!comm) return;
         if (a1) hipLaunchKernelGGL((k_sum_partials<2>), dim3(1), dim3(kBlock), 0, stream, a0, a1, np, red + slot);
         else hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(kBlock), 0, stream, a0, (const double*)nullptr, np, red + slot);
-        comm->allreduce_sum(red + slot, a1 ? 2 : 1, stream);
+        const int nv = a1 ? 2 : 1;
+        if (defer) deferred += nv;
+        else { comm->allreduce_sum(red + slot - deferred, nv + deferred, stream); deferred = 0; }
         a0 = red + slot; if (a1) a1 = red + slot + 1; np = 1;
     };
     // x = 0, r = rt = b, p = v = 0
@@ -1372,8 +1404,9 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
     bridge(a_n2, none, np_n2, 0); a_rho = a_n2;
     hipLaunchKernelGGL(k_ctl_thresh, dim3(1), dim3(kBlock), 0, stream, d_ctl, prm.linear_solver_reduction, (const double*)a_n2, np_n2);
     int j = 1, last = 0, target = 0;
-    bool stop = false;
+    bool stop = false, checked = false;      // checked: the last enqueued iteration has been tested and the status block is current
     for (; j <= maxit && !stop; ++j) {
+        checked = false;
         hipLaunchKernelGGL((k_update_p<S>), dim3(gv), dim3(kBlock), 0, stream, n, j, eps, d_ctl, h_ctl_dev, (const double*)a_n2, (const double*)a_rho, np_n2,
                            w.r.p, w.v.p, w.p.p);
         if (cpr) cpr_apply<S>(w.p.p, w.y.p, prm.ilu_relaxation, d_ctl); else ilu_apply<S>(w.p.p, w.y.p, prm.ilu_relaxation, d_ctl);
@@ -1386,7 +1419,7 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
         hipLaunchKernelGGL((k_update_xr1<S>), dim3(gv), dim3(kBlock), 0, stream, n, j, eps, d_ctl, h_ctl_dev, (const double*)a_h, np_h, w.y.p, w.v.p,
                            w.x.p, w.r.p, P_n1);
         double* a_n1 = P_n1; int np_n1 = gv; none = nullptr;
-        bridge(a_n1, none, np_n1, 2);
+        bridge(a_n1, none, np_n1, 2, true);      // ||r||^2 of the half step is consumed by k_update_xr2: reduced together with <t,r>, <t,t> (slots 2..4)
         if (cpr) cpr_apply<S>(w.r.p, w.y.p, prm.ilu_relaxation, d_ctl); else ilu_apply<S>(w.r.p, w.y.p, prm.ilu_relaxation, d_ctl);
         if (comm) halo<S>(comm, w.y.p, stream);
         lowrank_reduce<S>(w.y.p, d_ctl);
@@ -1402,9 +1435,11 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
         if (cpr && !cpr_speculate) {
             // CPR iterations are long (~0.6 ms of kernels) and few (~5): a speculative extra iteration of ~50 no-op
             // launches costs more than one host round trip, so test convergence at the END of the iteration and wait.
-            hipLaunchKernelGGL(k_final_check, dim3(1), dim3(kBlock), 0, stream, j, d_ctl, h_ctl_dev, (const double*)a_n2, np_n2);
-            OPMGPU_HIP(hipStreamSynchronize(stream));
+            const int tick = ++tick_seq;
+            hipLaunchKernelGGL(k_final_check, dim3(1), dim3(kBlock), 0, stream, j, d_ctl, h_ctl_dev, (const double*)a_n2, np_n2, poll_status ? h_tick_dev : (int*)nullptr, tick);
+            wait_tick(tick);
             if (h_ctl->done) stop = true;
+            checked = true;
             continue;
         }
         OPMGPU_HIP(hipEventRecord(ev[j & 1], stream));
@@ -1419,8 +1454,10 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
         }
         if (target != 0 && j >= target) stop = true;
     }
-    hipLaunchKernelGGL(k_final_check, dim3(1), dim3(kBlock), 0, stream, last, d_ctl, h_ctl_dev, (const double*)a_n2, np_n2);
-    OPMGPU_HIP(hipStreamSynchronize(stream));
+    if (!checked) {
+        hipLaunchKernelGGL(k_final_check, dim3(1), dim3(kBlock), 0, stream, last, d_ctl, h_ctl_dev, (const double*)a_n2, np_n2);
+        OPMGPU_HIP(hipStreamSynchronize(stream));
+    }
     const double norm0 = std::sqrt(h_ctl->norm0_2), norm = std::sqrt(h_ctl->norm2);
     res.converged = h_ctl->done && h_ctl->flag == 0;
     res.iterations = h_ctl->done ? h_ctl->iters : maxit;
@@ -1699,7 +1736,7 @@ double LinSolver::time_kernel(int kernel, int reps, int single_precision)
 // explicit instantiations
 #define OPMGPU_INST(S)                                                                  \
     template void LinSolver::ensure_work<S>();                                           \
-    template int LinSolver::factor<S>();                                                 \
+    template int LinSolver::factor<S>(bool);                                                 \
     template void LinSolver::ilu_apply<S>(const S*, S*, double, const SolveCtl*);        \
     template void LinSolver::spmv<S>(const S*, S*);                                      \
     template void LinSolver::cpr_prepare<S>();                                           \

@@ -115,7 +115,8 @@ public:
     int emulate_ranks = 1, emulate_what = 3;      // bit 0: cut the ILU0's matrix, bit 1: the AMG's, bit 2: the stage-2 residual's (= no x_p halo exchange)
     bool pre_stale = true;
 
-    template <class S> int factor();                                // ILU0 numeric factorisation
+    template <class S> int factor(bool wait = true);                                // ILU0 numeric factorisation
+    int factor_status() const { return (h_flags[0] & 1) ? OPMGPU_ESINGULAR : OPMGPU_OK; }   // valid after a stream synchronisation
     template <class S> void ilu_apply(const S* d, S* v, double relax, const SolveCtl* ctl = nullptr);
     template <class S> void spmv(const S* x, S* y);
     // CPR (solver_approach=cpr): build / refresh the pressure AMG for the current matrix; two-stage apply
@@ -151,6 +152,11 @@ public:
     DevArray<double> gmbuf;        // GMRES: Hessenberg matrix, s, cs, sn, y
     SolveCtl* h_ctl = nullptr;     // host-mapped status copy (device publishes, host polls after an event)
     SolveCtl* h_ctl_dev = nullptr; // device alias of h_ctl
+    int* h_tick = nullptr;         // host-mapped sequence word of the status checks (wait_tick)
+    int* h_tick_dev = nullptr;
+    int tick_seq = 0;
+    bool poll_status = true;       // OPMGPU_POLL=0: synchronise the stream instead
+    void wait_tick(int tick);
     DevArray<SolveCtl> ctl;        // device-resident control block read by every kernel
     int32_t* h_flags = nullptr;    // pinned
     int cur_ordering = -1;
