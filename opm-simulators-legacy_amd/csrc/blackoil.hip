@@ -423,11 +423,11 @@ __global__ __launch_bounds__(kBlock) void k_flux(int xm, int nb, int nbp, const 
     // potential differences, not one phase at a time.  (Forcing 3 waves per SIMD spills 200 B per lane: 265 -> 490 us.)
     int k0 = (nl == 0) ? 1 : 0;
     int code_n = 0, nbr_n = 0;
-    if (k0 < len) { const long e0 = long(base + k0) * 64 + lane; code_n = conn_code[e0]; nbr_n = col[e0]; }
+    if (k0 < len) { const long e0 = long(base + k0) * 64 + lane; code_n = __builtin_nontemporal_load(&conn_code[e0]); nbr_n = __builtin_nontemporal_load(&col[e0]); }
     for (int k = k0; k < len; ) {
         const int code = code_n, nbr = nbr_n;
         const int kn = (k + 1 == nl) ? k + 2 : k + 1;
-        if (kn < len) { const long en = long(base + kn) * 64 + lane; code_n = conn_code[en]; nbr_n = col[en]; }
+        if (kn < len) { const long en = long(base + kn) * 64 + lane; code_n = __builtin_nontemporal_load(&conn_code[en]); nbr_n = __builtin_nontemporal_load(&col[en]); }
         MS* bptr = A + long(base + k) * 576 + lane;
         k = kn;
         if (code < 0) {          // pure well fill: the host adds the Schur block later
@@ -499,12 +499,12 @@ __global__ __launch_bounds__(kBlock) void k_flux(int xm, int nb, int nbp, const 
                 const double own = side ? dG2[a][v] : dG1[a][v];
                 const double oth = side ? dG1[a][v] : dG2[a][v];
                 D[3 * a + v] += s * scale[a] * own;
-                bptr[(3 * a + v) * 64] = MS(s * scale[a] * oth);
+                __builtin_nontemporal_store(MS(s * scale[a] * oth), &bptr[(3 * a + v) * 64]);
             }
         }
     }
 #pragma unroll
-    for (int q = 0; q < 9; ++q) dptr[q * 64] = MS(D[q]);
+    for (int q = 0; q < 9; ++q) __builtin_nontemporal_store(MS(D[q]), &dptr[q * 64]);
     R[row] = Rl[0]; R[nbp + row] = Rl[1]; R[2 * long(nbp) + row] = Rl[2];
 }
 
