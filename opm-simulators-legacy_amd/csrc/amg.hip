@@ -425,11 +425,12 @@ void AmgHierarchy<S>::setup(const Plan& P, const int32_t* d_slice_ptr, const int
 }
 
 template <class S>
-void AmgHierarchy<S>::galerkin()
+void AmgHierarchy<S>::galerkin(bool coarse_levels)
 {
     for (size_t l = 0; l + 1 < levels.size(); ++l) {
         AmgLevel<S>& F = *levels[l]; AmgLevel<S>& C = *levels[l + 1];
         hipLaunchKernelGGL((k_amg_dinv<S>), dim3(grid_for(F.n)), dim3(kBlock), 0, stream, F.n, F.diag_entry.p, F.val.p, F.dinv.p);
+        if (!coarse_levels) return;           // (experiment OPMGPU_AMG_LAG_COARSE) level 0 follows the matrix, the coarse operators lag
         if (F.nentries_coarse > 400000)
             hipLaunchKernelGGL((k_amg_galerkin<S>), dim3(grid_for(F.nentries_coarse)), dim3(kBlock), 0, stream, F.nentries_coarse,
                                F.contrib_ptr.p, F.contrib_idx.p, coarse_dev[l]->p, F.val.p, C.val.p);

@@ -50,7 +50,7 @@ public:
     void setup(const Plan& P, const int32_t* d_slice_ptr, const int32_t* d_col, const std::vector<double>& ap_host);
     bool ready() const { return !levels.empty(); }
     // numeric phase for a new matrix: level-0 values are already in levels[0].val
-    void galerkin();
+    void galerkin(bool coarse_levels = true);
     // x0 = Vcycle(b0) with b0 in levels[0].b; result in levels[0].x
     // level0_presmoothed: levels[0].x already holds omega D^-1 b (the caller's kernel did the first sweep)
     void vcycle(const SolveCtl* ctl, bool level0_presmoothed = false);

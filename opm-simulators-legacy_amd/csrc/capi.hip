@@ -78,6 +78,11 @@ template <class S> int solve_loaded(opmgpu_ctx* c, bool matrix_changed, SolveRes
     ls.prepare<S>(matrix_changed);
     (void)ls.factor<S>(false);           // status read below: the solver's own final synchronisation covers it
     res = c->prm.newton_use_gmres ? ls.gmres<S>(c->prm) : ls.bicgstab<S>(c->prm);
+    if (res.status != OPMGPU_OK && c->prm.use_cpr && !ls.refreshed && ls.factor_status() == OPMGPU_OK) {
+        // the solve ran on lagged coarse operators of the pressure hierarchy (LinSolver::cpr_prepare): once more on fresh ones
+        ls.force_refresh = true; ls.lag_block = 8;
+        res = c->prm.newton_use_gmres ? ls.gmres<S>(c->prm) : ls.bicgstab<S>(c->prm);
+    }
     if (ls.factor_status() != OPMGPU_OK) { c->factored = false; return fail(c, OPMGPU_ESINGULAR, "singular diagonal block in ILU0"); }
     c->factored = true;
     if (res.status == OPMGPU_ELINSOLVE) c->err = "Convergence failure for linear solver.";

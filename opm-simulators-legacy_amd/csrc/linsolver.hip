@@ -738,6 +738,7 @@ LinSolver::LinSolver(hipStream_t s) : stream(s)
     if (const char* e = std::getenv("OPMGPU_CPR_SPECULATE")) cpr_speculate = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_CPR_WEIGHTS")) cpr_weight_mode = std::atoi(e);
     if (const char* e = std::getenv("OPMGPU_AMG_LAG")) amg_lag = std::atoi(e);
+    if (const char* e = std::getenv("OPMGPU_AMG_LAG_COARSE")) coarse_lag = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("OPMGPU_CPR_HALO_XP")) cpr_halo_xp = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_EMULATE_RANKS")) emulate_ranks = std::atoi(e);
     if (const char* e = std::getenv("OPMGPU_EMULATE_WHAT")) emulate_what = std::atoi(e);
@@ -791,6 +792,7 @@ template <class S> void LinSolver::ensure_work()
 void LinSolver::load_host_bsr(const double* val9)
 {
     matrix_is_float = false;
+    new_step_hint = true;          // an external matrix: nothing is known about its relation to the previous one
     stage.ensure(std::max(size_t(plan.nnzb) * 9, size_t(3) * plan.nbp));
     OPMGPU_HIP(hipMemcpyAsync(stage.p, val9, size_t(plan.nnzb) * 9 * sizeof(double), hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(k_bsr_to_sell, dim3(grid_for(plan.nentries)), dim3(kBlock), 0, stream, plan.nentries, dp.src.p, stage.p, Ad.p);
@@ -1257,7 +1259,32 @@ template <class S> void LinSolver::cpr_prepare()
                                dp.nlower.p, dp.tpos.p, (const int32_t*)nullptr, (const int8_t*)nullptr, matrix<S>(), w.cprw.p,
                                w.amg->levels[0]->val.p, (double*)nullptr, (S*)nullptr);
         }
-        w.amg->galerkin();
+        // Coarse operators (levels >= 1 and the coarsest inverse, 0.18 of the 0.27 ms set-up) follow the first TWO matrices of a time
+        // step (the first update moves the state most; the second solve is also the reference for the guard below): level 0 (weights,
+        // A_p, its Jacobi diagonal) is rebuilt for every matrix, the coarse-grid corrections of the Newton iterations 3.. of a step
+        // come from the operators of its second matrix.  Measured on both bench decks: same iteration
+        // counts even with operators frozen for 20 iterations, -4..7 % time per Newton iteration.  Two guards:
+        //  * only with the global coarse space active (it is rebuilt for every matrix and corrects the pressure level / the subdomain
+        //    constants exactly): without it -- one GPU with wells -- the hierarchy alone carries the near-null pressure-level mode,
+        //    and a lagged one left 5e-6 relative error in that mode at a 1e-12 residual (tests/test_gpu_dist.py, wells case);
+        //  * a lagged solve that needs clearly more iterations than the solve on the fresh operators (a step far from equilibrium:
+        //    measured 13 instead of 8 iterations over six Newton iterations of such a deck) switches the lag off for the rest of
+        //    this time step and the next 8 (bicgstab's epilogue sets lag_block);
+        //  * only for the loose reductions of Newton solves (>= 1e-4): at 1e-11 a lagged hierarchy stagnated on a grid with isolated
+        //    cells (several near-null modes; tests/test_gpu_fullsize.py, Norne-like); and a lagged solve that fails is repeated once
+        //    on fresh operators before the failure is reported (solve_loaded in capi.hip).
+        // OPMGPU_AMG_LAG_COARSE: 0 = refresh for every matrix, 1 = this policy (default), k > 1 = every k-th matrix, no guards.
+        bool refresh;
+        if (coarse_lag == 0) refresh = true;
+        else if (coarse_lag > 1) refresh = (coarse_age++ % coarse_lag) == 0;
+        else {
+            if (new_step_hint) { if (lag_block > 0) --lag_block; step_matrix = 0; } else ++step_matrix;
+            refresh = step_matrix <= 1 || coarse_nsub == 0 || lag_block > 0 || !lag_allowed || force_refresh;
+        }
+        force_refresh = false;
+        new_step_hint = false;
+        refreshed = refresh;
+        w.amg->galerkin(refresh);
         if (coarse_nsub >= 1) coarse_setup<S>(true);
         return;
     }
@@ -1276,6 +1303,7 @@ template <class S> void LinSolver::cpr_prepare()
     hipLaunchKernelGGL((k_extract_pressure<S>), dim3(grid_for(plan.nbp)), dim3(kBlock), 0, stream, plan.nb, plan.nbp, dp.slice_ptr.p, (const S*)w.cprw.p, ((emulate_what & 2) ? pre_matrix<S>() : matrix<S>()),
                        w.amg->levels[0]->val.p);
     w.amg->galerkin();
+    new_step_hint = false; refreshed = true;
     if (coarse_nsub >= 1) { coarse_begin<S>(); coarse_setup<S>(false); }
 }
 
@@ -1365,6 +1393,7 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
     // closed form of (A M^-1 p) on the level-0 rows -- valid when M is the ILU0 of exactly this matrix and none of the row's
     // neighbours is a ghost whose entry of M^-1 p is overwritten by the halo exchange (multi-GPU: light_ok masks those rows out)
     const bool cpr = prm.use_cpr != 0;                   // multi-GPU: rank-local (additive Schwarz) AMG + block-Jacobi ILU0
+    lag_allowed = prm.linear_solver_reduction >= 1e-4;
     if (cpr) cpr_prepare<S>();
     const bool closed = closed_form_level0 && emulate_ranks <= 1;
     const int8_t* lightmask = nullptr;
@@ -1464,6 +1493,9 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
     res.reduction = norm0 > 0 ? norm / norm0 : 0.0;
     if (h_ctl->flag != 0 || !(norm0 == norm0)) res.status = OPMGPU_EBREAKDOWN;
     else if (!res.converged && !prm.ignore_convergence_failure) res.status = OPMGPU_ELINSOLVE;      // ISTLSolver.hpp:358-368
+    last_its = res.iterations;
+    if (refreshed) its_ref = res.iterations;
+    else if (coarse_lag == 1 && last_its > its_ref + std::max(1, its_ref / 4)) lag_block = 8;     // see cpr_prepare
     return res;
 }
 
@@ -1573,6 +1605,7 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
     const int m = std::max(1, int(prm.linear_solver_restart));
     const int maxit = prm.linear_solver_maxiter;
     const bool cpr = prm.use_cpr != 0;
+    lag_allowed = false;          // (the GMRES option keeps the hierarchy fresh: it is the reference's robustness fallback)
     if (cpr) cpr_prepare<S>();
     w.kry.alloc(size_t(m + 1) * n);
     gmbuf.alloc(size_t(m + 1) * m + (m + 1) + 3 * m + 8);

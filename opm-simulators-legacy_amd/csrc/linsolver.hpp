@@ -169,6 +169,14 @@ public:
     bool closed_form_level0 = true; // k_spmv shortcut on level-0 rows (A/B switch: OPMGPU_CLOSED=0)
     bool cpr_halo_xp = true;        // multi-GPU CPR: halo-exchange the pressure correction before stage 2 (A/B: OPMGPU_CPR_HALO_XP=0)
     int amg_lag = 1, amg_age = 0;   // A/B: OPMGPU_AMG_LAG
+    // refresh policy of the coarse operators of the pressure hierarchy (see cpr_prepare); OPMGPU_AMG_LAG_COARSE
+    int coarse_lag = 1, coarse_age = 0;
+    bool new_step_hint = true;     // set by the caller for the first matrix of a time step (and for every external matrix)
+    bool refreshed = true;         // the current solve runs on freshly built coarse operators
+    int last_its = 0, its_ref = 0; // iterations of the last solve / of the solve right after the last refresh
+    bool lag_allowed = true, force_refresh = false;
+    int step_matrix = 0;           // matrices seen since the time step began
+    int lag_block = 0;             // > 0: time steps during which the coarse operators follow every matrix again
     int cpr_weight_mode = 0;        // 0 = formEllipticSystem's 0/1 dominance weights (reference); 1 = quasi-IMPES (A/B: OPMGPU_CPR_WEIGHTS=1)
     bool cpr_speculate = false;     // CPR: enqueue the next iteration before the convergence result is known (A/B: OPMGPU_CPR_SPECULATE=1)
     hipEvent_t ev[2] = { nullptr, nullptr };
