@@ -217,6 +217,22 @@ __global__ __launch_bounds__(kBlock) void k_amg_residual(int n, const int32_t* _
     const S acc = b[row] - sell_row_dot<S>(val + long(base) * 64 + lane, col + long(base) * 64 + lane, width, [&](int j) { return x[j]; });
     out[row] = MODE == 0 ? acc : x[row] + omega * dinv[row] * acc;
 }
+// level 0 with a two-colour row order (the block plan's multicolour ordering of a grid stencil): Gauss-Seidel by colour.  Rows of one
+// colour do not couple, so the rows [lo, hi) of a colour are updated IN PLACE from the other colour's current values -- the traffic of
+// half a Jacobi sweep per colour, the smoothing of Gauss-Seidel.  MODE 1: x += D^-1 (b - A x) ; MODE 0: out = b - A x (residual rows)
+template <class S, int MODE>
+__global__ __launch_bounds__(kBlock) void k_amg_gs(int lo, int hi, const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
+                                                   const S* __restrict__ val, const S* __restrict__ b, const S* __restrict__ dinv,
+                                                   S* __restrict__ x, S* __restrict__ out, const SolveCtl* __restrict__ ctl)
+{
+    if (ctl && ctl->done) return;
+    const int row = lo + blockIdx.x * kBlock + threadIdx.x;
+    if (row >= hi) return;
+    const int base = slice_ptr[row >> 6], width = slice_ptr[(row >> 6) + 1] - base, lane = row & 63;
+    const S* xr = x;
+    const S acc = b[row] - sell_row_dot<S>(val + long(base) * 64 + lane, col + long(base) * 64 + lane, width, [&](int j) { return xr[j]; });
+    if (MODE == 0) out[row] = acc; else x[row] = x[row] + dinv[row] * acc;
+}
 // small levels: one wavefront per row (aggregated stencils are 30-100 entries wide there; a single thread walking them
 // is latency bound).  MODE 0: r = b - A x ; MODE 1: out = x + omega D^-1 (b - A x) ; MODE 2: x = omega D^-1 b, r = b - A x fused
 template <class S, int MODE>
@@ -351,6 +367,8 @@ void AmgHierarchy<S>::setup(const Plan& P, const int32_t* d_slice_ptr, const int
     if (const char* e = std::getenv("OPMGPU_AMG_NPOST")) npost = std::atoi(e);
     if (const char* e = std::getenv("OPMGPU_AMG_FUSE")) fuse = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_AMG_GRAPH")) use_graph = std::atoi(e) != 0;
+    if (const char* e = std::getenv("OPMGPU_AMG_GS")) use_gs = std::atoi(e) != 0;
+    gs_n0 = (P.nlevels == 2) ? P.level_ptr[1] : 0;        // two colours: rows [0, n0) and [n0, nb)
     if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
     npost0 = npost;
     if (const char* e = std::getenv("OPMGPU_AMG_NPOST0")) npost0 = std::atoi(e);
@@ -465,7 +483,15 @@ void AmgHierarchy<S>::vcycle(const SolveCtl* ctl, bool level0_presmoothed)
     for (int l = 0; l < nl - 1; ++l) {
         AmgLevel<S>& F = *levels[l]; AmgLevel<S>& C = *levels[l + 1];
         const int g = grid_for(F.n);
-        if (F.n > 50000) {
+        if (l == 0 && gs_level0()) {
+            // x = D^-1 b (the first colour's sweep from zero; the caller's fused kernel did it with omega0() = 1), second colour in place,
+            // then the residual: zero on the rows just solved, b - A x on the first colour
+            const int n0 = gs_n0;
+            if (!presmoothed) hipLaunchKernelGGL((k_amg_smooth0<S>), dim3(g), dim3(kBlock), 0, stream, F.n, S(1), F.dinv.p, F.b.p, F.x.p, ctl);
+            hipLaunchKernelGGL((k_amg_gs<S, 1>), dim3(grid_for(F.n - n0)), dim3(kBlock), 0, stream, n0, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, F.dinv.p, F.x.p, (S*)nullptr, ctl);
+            hipLaunchKernelGGL((k_amg_gs<S, 0>), dim3(grid_for(n0)), dim3(kBlock), 0, stream, 0, n0, F.slice_ptr, F.col, F.val.p, F.b.p, F.dinv.p, F.x.p, F.r.p, ctl);
+            OPMGPU_HIP(hipMemsetAsync(F.r.p + n0, 0, size_t(F.n - n0) * sizeof(S), stream));
+        } else if (F.n > 50000) {
             if (!presmoothed) hipLaunchKernelGGL((k_amg_smooth0<S>), dim3(g), dim3(kBlock), 0, stream, F.n, om, F.dinv.p, F.b.p, F.x.p, ctl);
             hipLaunchKernelGGL((k_amg_residual<S, 0>), dim3(g), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, F.x.p, om, F.dinv.p, F.r.p, ctl);
         } else if (F.n > 20000) {
@@ -502,6 +528,16 @@ void AmgHierarchy<S>::vcycle(const SolveCtl* ctl, bool level0_presmoothed)
         const int g = grid_for(F.n);
         int done_sweeps = 0;
         const int npost = l == 0 ? this->npost0 : this->npost;
+        if (l == 0 && gs_level0()) {
+            const int n0 = gs_n0;
+            hipLaunchKernelGGL((k_amg_prolong<S>), dim3(g), dim3(kBlock), 0, stream, F.n, F.agg.p, C.x.p, F.x.p, S(pdamp), ctl);
+            for (int sw = 0; sw < npost; ++sw) {          // colours in reverse order
+                hipLaunchKernelGGL((k_amg_gs<S, 1>), dim3(grid_for(F.n - n0)), dim3(kBlock), 0, stream, n0, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, F.dinv.p, F.x.p, (S*)nullptr, ctl);
+                hipLaunchKernelGGL((k_amg_gs<S, 1>), dim3(grid_for(n0)), dim3(kBlock), 0, stream, 0, n0, F.slice_ptr, F.col, F.val.p, F.b.p, F.dinv.p, F.x.p, (S*)nullptr, ctl);
+            }
+            mark("up L0");
+            continue;
+        }
         if (fuse && npost >= 1 && F.n <= 200000) {
             // small and medium levels: the prolongation is gathered inside the first post-smoothing sweep (one launch less)
             if (F.n > 20000)

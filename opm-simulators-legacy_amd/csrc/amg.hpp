@@ -74,6 +74,10 @@ public:
     int npost0 = 2;               // post-smoothing sweeps on level 0 (cheap per sweep there; coarse levels are launch-latency bound)
     int coarse_sweeps = 4;        // pairs of Jacobi sweeps standing in for the coarsest solve when it is too big for the dense inverse
     bool fuse = true;             // launch fusions of the V-cycle (A/B: OPMGPU_AMG_FUSE=0)
+    bool use_gs = false;          // level 0: Gauss-Seidel by colour instead of damped Jacobi when the row order has two colours (OPMGPU_AMG_GS)
+    int gs_n0 = 0;                // rows [0, gs_n0) are the first colour (0 = no two-colour order)
+    bool gs_level0() const { return use_gs && gs_n0 > 0 && npre == 1; }
+    double omega0() const { return gs_level0() ? 1.0 : omega; }      // weight of the caller's fused first sweep on level 0
     void sweep(AmgLevel<S>& F, const SolveCtl* ctl);
 };
 

@@ -1313,7 +1313,7 @@ template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, con
     SolverWork<S>& w = work<S>();
     AmgLevel<S>& L0 = *w.amg->levels[0];
     const int g = grid_for(plan.nb);
-    hipLaunchKernelGGL((k_cpr_sum_eqs<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, plan.nbp, d, (const S*)w.cprw.p, L0.b.p, S(w.amg->omega), (const S*)L0.dinv.p, L0.x.p, ctl);
+    hipLaunchKernelGGL((k_cpr_sum_eqs<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, plan.nbp, d, (const S*)w.cprw.p, L0.b.p, S(w.amg->omega0()), (const S*)L0.dinv.p, L0.x.p, ctl);
     const bool coarse = coarse_nsub >= 1;
     if (coarse) {
         const int ns = coarse_nsub;
@@ -1331,10 +1331,10 @@ template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, con
         }
         if (!emulated)
             hipLaunchKernelGGL((k_cs_correct_fast<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, plan.nbp, ns, cs_slots, cs_sub.p, (const S*)w.csT.p, (const double*)inv,
-                               (const double*)cr, S(w.amg->omega), (const S*)L0.dinv.p, L0.b.p, L0.x.p, w.cxc.p, ctl);
+                               (const double*)cr, S(w.amg->omega0()), (const S*)L0.dinv.p, L0.b.p, L0.x.p, w.cxc.p, ctl);
         else
             hipLaunchKernelGGL((k_cs_correct<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, plan.nbp, ns, dp.slice_ptr.p, dp.col.p, dp.rowlen.p, cs_sub.p,
-                               (const S*)w.cprw.p, matrix<S>(), (const double*)inv, (const double*)cr, S(w.amg->omega), (const S*)L0.dinv.p, L0.b.p, L0.x.p, w.cxc.p, ctl);
+                               (const S*)w.cprw.p, matrix<S>(), (const double*)inv, (const double*)cr, S(w.amg->omega0()), (const S*)L0.dinv.p, L0.b.p, L0.x.p, w.cxc.p, ctl);
     }
     w.amg->vcycle_graph(ctl, true);
     const S* xp = L0.x.p;

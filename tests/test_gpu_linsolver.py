@@ -1,4 +1,6 @@
 """GPU parity: SELL-64 SpMV, level-scheduled block-ILU0 and BiCGStab vs the CPU oracle, through the C ABI."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse.linalg as spla
@@ -179,6 +181,19 @@ def test_cpr_amg_solve(gpu_lib, oracle, single):
     xs2 = s.computeNewtonIncrement(rowptr, col, val, b, single)
     assert np.array_equal(xs, xs2)
     s.close()
+    # opt-in smoother of level 0: Gauss-Seidel by colour (OPMGPU_AMG_GS=1, read when the hierarchy is built): same contract
+    os.environ["OPMGPU_AMG_GS"] = "1"; os.environ["OPMGPU_AMG_NPOST0"] = "1"
+    try:
+        s = GpuNewtonIteration(capi.default_params(use_cpr=1, linear_solver_reduction=red, linear_solver_maxiter=200))
+        xg = s.computeNewtonIncrement(rowptr, col, val, b, single)
+        assert s.iterations() <= its[0]
+        if single:
+            assert np.linalg.norm(A @ xg - b) <= 30 * red * np.linalg.norm(b)
+        else:
+            assert np.linalg.norm(xg - xe) <= 1e-6 * np.linalg.norm(xe)
+        s.close()
+    finally:
+        del os.environ["OPMGPU_AMG_GS"], os.environ["OPMGPU_AMG_NPOST0"]
 
 
 def test_cpr_pressure_equation_weights(gpu_lib, oracle):
