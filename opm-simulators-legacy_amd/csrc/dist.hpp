@@ -29,6 +29,7 @@ public:
 
 private:
     template <class S> void halo_t(S* v, hipStream_t s);
+    void shm_allreduce(double* d, int n, bool is_max, hipStream_t s);     // test transport (OPMGPU_COMM_TRANSPORT=shm, dist.hip)
     struct Impl;
     Impl* impl;
     std::vector<int32_t> neigh_rank, send_ptr, recv_ptr, send_cells, recv_cells;

@@ -1241,7 +1241,8 @@ template <class S> void LinSolver::cpr_prepare()
     // one subdomain (single GPU) is the global constant: the near-null-space vector of a closed, slightly compressible system
     // (wells with a pressure control anchor the level: measured, the constant then costs more than it gains -- so with one
     // subdomain it is used for well-free systems only; coarse_mode 2 forces it, 0 switches the whole coarse space off)
-    const int nsub = comm ? comm->num_ranks() : (emulate_ranks > 1 ? emulate_ranks : 1);
+    static const int cs_split = std::getenv("OPMGPU_COARSE_SPLIT") ? std::max(1, std::atoi(std::getenv("OPMGPU_COARSE_SPLIT"))) : 1;   // emulation only: coarse unknowns per rank
+    const int nsub = comm ? comm->num_ranks() : (emulate_ranks > 1 ? emulate_ranks * cs_split : 1);
     const bool single_ok = coarse_mode == 2 || (coarse_single_ok && lowrank.nw == 0);
     coarse_nsub = coarse_mode != 0 && (nsub >= 2 || single_ok) ? nsub : 0;
     if (coarse_nsub > 64) coarse_nsub = 0;        // table sizes of the kernels

@@ -1,0 +1,72 @@
+"""One rank of a multi-process run over the shared-memory TEST transport (csrc/dist.hip, OPMGPU_COMM_TRANSPORT=shm): builds the global
+synthetic deck, keeps its slab, joins the communicator, runs Newton iterations and writes its OWNED cells' state.  Started by
+tests/test_gpu_dist_shm.py; every rank uses cuda:0."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "opm-simulators-legacy_amd"))
+
+import numpy as np  # noqa: E402
+
+from opmgpu import capi, decks, partition  # noqa: E402
+from opmgpu import wells as W  # noqa: E402
+from opmgpu.model import GpuBlackoilModel  # noqa: E402
+
+
+def deck(cfg):
+    grid = decks.cartesian_grid(cfg["nx"], cfg["ny"], cfg["nz"], lognormal_sigma=cfg["sigma"], seed=cfg["seed"])
+    tab = decks.satfunc_standard_tables()
+    st = decks.initial_state(grid, tab, perturb=cfg["perturb"], seed=cfg["seed"])
+    return grid, tab, st
+
+
+def wells_of(grid, cfg):
+    """One rate-controlled injector and one BHP producer, each a vertical well inside ONE z-slab (a well lives on one rank)."""
+    nx, ny, nz = cfg["nx"], cfg["ny"], cfg["nz"]
+    wl = W.Wells()
+    WI = 5.0 * float(np.median(grid.trans))
+    col = lambda i, j, ks: [i + nx * (j + ny * k) for k in ks]      # noqa: E731
+    inj = col(1, 1, range(0, 2))
+    prod = col(nx - 2, ny - 2, range(nz - 2, nz))
+    wl.add_well("INJ", W.INJECTOR, grid.z[inj[0]], inj, WI, (1.0, 0.0, 0.0), (W.SURFACE_RATE, cfg["rate"], (1.0, 0.0, 0.0)))
+    wl.add_well("PROD", W.PRODUCER, grid.z[prod[0]], prod, WI, (0.0, 1.0, 0.0), (W.BHP, 150 * decks.BAR))
+    return wl
+
+
+def run(cfg, rank, world, uid, out):
+    grid, tab, st = deck(cfg)
+    prm = capi.default_params(**cfg["params"])
+    if world == 1:
+        model, lst = GpuBlackoilModel(grid, tab, prm), st
+        owned_global = np.arange(grid.nc)
+    else:
+        part = partition.slab_partition(grid, world)
+        dom = partition.LocalDomain(grid, part, rank)
+        model = GpuBlackoilModel(dom.grid, tab, prm)
+        partition.attach_comm(model, dom, rank, world, uid)
+        lst = dom.local_state(st)
+        owned_global = dom.global_of_local[:dom.n_owned]
+    driver = model
+    if cfg["wells"]:
+        wl = wells_of(grid, cfg)
+        if world > 1:
+            wl = dom.local_wells(wl, part)
+        driver = W.DeviceWellModel(model, wl, W.WellState(wl, lst.p))
+    driver.prepareStep(cfg["dt_days"] * decks.DAY, lst)
+    hist = []
+    for it in range(cfg["newton"]):
+        conv, lin = driver.nonlinearIteration(it, single_precision=cfg["single"])
+        hist.append([bool(conv), int(lin)])
+    s = model.getState()
+    n = owned_global.size
+    np.savez(out, ids=owned_global, p=s.p[:n], sat=s.sat[:n], hc=s.hc[:n], hist=np.array(hist, dtype=np.int64))
+    model.close()
+
+
+if __name__ == "__main__":
+    cfg = json.loads(sys.argv[1])
+    rank, world = int(sys.argv[2]), int(sys.argv[3])
+    uid = bytes.fromhex(sys.argv[4]) if sys.argv[4] != "-" else None
+    run(cfg, rank, world, uid, sys.argv[5])
