@@ -65,11 +65,19 @@ def main():
         raise SystemExit("--gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # rehearsal on ONE GPU (OPMGPU_COMM_TRANSPORT=shm): every rank on cuda:0, the library's shared-memory test transport instead of
+    # RCCL and a gloo group for the barrier -- runs the N > 1 code path of this script where no multi-GPU node is available
+    rehearsal = os.environ.get("OPMGPU_COMM_TRANSPORT") == "shm"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     ordering = capi.ORDER_MULTICOLOR if args.ordering == "multicolor" else capi.ORDER_NATURAL
     prm = capi.default_params(ilu_ordering=ordering, use_cpr=int(args.solver == "cpr"))
@@ -100,6 +108,8 @@ def main():
         wl = W.five_spot(grid, rate_m3_per_day=5000.0, bhp_prod_bar=150.0)
         return W.DeviceWellModel(model, wl, W.WellState(wl, st.p))
 
+    sample_phases = os.environ.get("OPMGPU_BENCH_NO_PHASES") is None      # (A/B: what reading the phase events every iteration costs)
+
     def timed_run(model, wells=None):
         """exactly K timed Newton iterations after W warm-up ones; time steps follow each other like in the simulator"""
         core = model
@@ -115,8 +125,9 @@ def main():
                 lin_total = 0
                 t_asm = t_sol = t_upd = 0.0
             converged, lin = model.nonlinearIteration(it)
-            a, s, u = core.timings()
-            t_asm += a; t_sol += s; t_upd += u
+            if sample_phases:
+                a, s, u = core.timings()
+                t_asm += a; t_sol += s; t_upd += u
             lin_total += lin
             it += 1
             if (converged and it >= 1) or it > 10:
@@ -126,7 +137,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         if use_dist:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
         return {"elapsed": elapsed, "lin": lin_total / args.steps, "steps_done": steps_done,

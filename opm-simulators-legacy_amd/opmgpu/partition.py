@@ -126,7 +126,7 @@ def build_distributed_model(nx, ny, nz, tables, params, rank, world, local_rank,
     part = slab_partition(grid, world)
     dom = LocalDomain(grid, part, rank)
     model = GpuBlackoilModel(dom.grid, tables, params, device=local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else torch.device("cpu")      # gloo: one-GPU rehearsal
     idt = torch.zeros(capi.UNIQUE_ID_BYTES, dtype=torch.uint8, device=dev)
     if rank == 0:
         idt.copy_(torch.frombuffer(bytearray(make_unique_id()), dtype=torch.uint8))
