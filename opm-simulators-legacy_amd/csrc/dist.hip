@@ -242,6 +242,24 @@ void RcclComm::subdomain_of_rows(const Plan& P, std::vector<int32_t>& sub) const
         for (int k = recv_ptr[q]; k < recv_ptr[q + 1]; ++k) sub[P.pos[recv_cells[k]]] = neigh_rank[q];
 }
 
+void RcclComm::coarse_blocks_of_rows(const Plan& P, int m, hipStream_t s, std::vector<int32_t>& sub, std::vector<int8_t>& blk)
+{
+    sub.assign(P.nbp, rank * m); blk.assign(P.nbp, int8_t(-1));
+    std::vector<double> h(size_t(3) * P.nbp, 0.0);
+    for (int c = 0; c < n_owned; ++c) {
+        const int b = int(std::min<long>(m - 1, long(c) * m / n_owned));
+        sub[P.pos[c]] = rank * m + b; blk[P.pos[c]] = int8_t(b);
+        h[P.pos[c]] = double(rank * m + b);
+    }
+    // the ghosts' values come from their owners: one halo exchange of a plane vector carrying the ids (exact in a double)
+    DevArray<double> tmp; tmp.alloc(size_t(3) * P.nbp);
+    tmp.upload(h, s);
+    halo_exchange_d(tmp.p, s);
+    tmp.download(h.data(), h.size(), s);
+    OPMGPU_HIP(hipStreamSynchronize(s));
+    for (int c = n_owned; c < n_local; ++c) sub[P.pos[c]] = int32_t(h[P.pos[c]] + 0.5);
+}
+
 template <class S> void RcclComm::halo_t(S* v, hipStream_t s)
 {
     const int ns = int(send_cells.size()), nr = int(recv_cells.size());

@@ -23,6 +23,7 @@ public:
     int my_rank() const override { return rank; }
     int num_ranks() const override { return nranks; }
     void subdomain_of_rows(const Plan& P, std::vector<int32_t>& sub) const override;
+    void coarse_blocks_of_rows(const Plan& P, int m, hipStream_t s, std::vector<int32_t>& sub, std::vector<int8_t>& blk) override;
 
     int rank = 0, nranks = 1, n_owned = 0, n_local = 0, nbp = 0;
     double pvsum_global = 0.0;

@@ -739,6 +739,7 @@ LinSolver::LinSolver(hipStream_t s) : stream(s)
     if (const char* e = std::getenv("OPMGPU_CPR_WEIGHTS")) cpr_weight_mode = std::atoi(e);
     if (const char* e = std::getenv("OPMGPU_AMG_LAG")) amg_lag = std::atoi(e);
     if (const char* e = std::getenv("OPMGPU_AMG_LAG_COARSE")) coarse_lag = std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("OPMGPU_COARSE_BLOCKS")) cs_blocks_req = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("OPMGPU_CPR_HALO_XP")) cpr_halo_xp = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_EMULATE_RANKS")) emulate_ranks = std::atoi(e);
     if (const char* e = std::getenv("OPMGPU_EMULATE_WHAT")) emulate_what = std::atoi(e);
@@ -1113,6 +1114,104 @@ __global__ __launch_bounds__(kBlock) void k_cs_place_row(int np, const double* _
     }
 }
 
+// ---- several coarse unknowns per rank (cs_m index-range blocks of the owned cells; own blocks occupy the slots 0 .. m-1) ----
+// A_c(rank*m + b, sub_of_slot[q]) = sum over the owned rows of block b of T[q][row]; one slot per blockIdx.y, partials per workgroup
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_cs_block_rows(int nb, int nbp, const int8_t* __restrict__ blk, const S* __restrict__ T, double* __restrict__ parts)
+{
+    __shared__ double sm[32];
+    const int q = blockIdx.y;
+    double acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    for (long row = blockIdx.x * long(kBlock) + threadIdx.x; row < nb; row += long(gridDim.x) * kBlock) {
+        const int b = blk[row];
+        if (b < 0) continue;
+        const double v = double(T[long(q) * nbp + row]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] += (u == b) ? v : 0.0;
+    }
+    block_sum<8>(acc, sm);
+    if (threadIdx.x == 0) for (int u = 0; u < 8; ++u) parts[(long(q) * 8 + u) * gridDim.x + blockIdx.x] = acc[u];
+}
+__global__ __launch_bounds__(kBlock) void k_cs_place_blocks(int np, const double* __restrict__ parts, LinSolver::CsSlots sl, int ns, int m, int mine, double* __restrict__ cA)
+{
+    __shared__ double sm[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int q = 0; q < sl.n; ++q)
+        for (int b = 0; b < m; ++b) {
+            double v = 0.0;
+            for (int i = threadIdx.x; i < np; i += kBlock) v += parts[(long(q) * 8 + b) * np + i];
+            const double s_ = wave_sum(v);
+            __syncthreads();
+            if (lane == 0) sm[wv] = s_;
+            __syncthreads();
+            if (threadIdx.x == 0) cA[(mine * m + b) * ns + sl.sub_of_slot[q]] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+        }
+}
+// restricted residual of the own blocks: cr[rank*m + b] = sum over the rows of block b (zeros elsewhere: the all-reduce gathers)
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_cs_rsum_blocks(int nb, const int8_t* __restrict__ blk, const S* __restrict__ r, double* __restrict__ parts,
+                                                           const SolveCtl* __restrict__ ctl)
+{
+    __shared__ double sm[32];
+    if (ctl && ctl->done) return;
+    double acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < nb; i += long(gridDim.x) * kBlock) {
+        const int b = blk[i];
+        if (b < 0) continue;
+        const double v = double(r[i]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] += (u == b) ? v : 0.0;
+    }
+    block_sum<8>(acc, sm);
+    if (threadIdx.x == 0) for (int u = 0; u < 8; ++u) parts[long(u) * gridDim.x + blockIdx.x] = acc[u];
+}
+__global__ __launch_bounds__(kBlock) void k_cs_place_cr(int np, const double* __restrict__ parts, int ns, int m, int mine, double* __restrict__ cr,
+                                                        const SolveCtl* __restrict__ ctl)
+{
+    __shared__ double sm[4];
+    __shared__ double tot[8];
+    if (ctl && ctl->done) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int b = 0; b < m; ++b) {
+        double v = 0.0;
+        for (int i = threadIdx.x; i < np; i += kBlock) v += parts[long(b) * np + i];
+        const double s_ = wave_sum(v);
+        __syncthreads();
+        if (lane == 0) sm[wv] = s_;
+        __syncthreads();
+        if (threadIdx.x == 0) tot[b] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    }
+    __syncthreads();
+    if (threadIdx.x < ns) { const int b = threadIdx.x - mine * m; cr[threadIdx.x] = (b >= 0 && b < m) ? tot[b] : 0.0; }
+}
+// wells with blocks: the pair (perforation i, perforations of block b) adds w_i . P_i . sum_{j in b} Q_j[:, pressure] to T[b][row_i]
+// (own blocks are the slots 0 .. m-1); A_c then takes it from T like every other entry.  One workgroup per well, fixed order.
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_cs_wells_blocks(LowRankOp lr, int nbp, int m, const int8_t* __restrict__ blk, const S* __restrict__ w, S* __restrict__ T)
+{
+    __shared__ double sm[28];
+    __shared__ double q7s[8][7];
+    const int wl = blockIdx.x;
+    for (int b = 0; b < m; ++b) {
+        double q7[7] = { 0, 0, 0, 0, 0, 0, 0 };
+        for (int j = lr.connpos[wl] + threadIdx.x; j < lr.connpos[wl + 1]; j += kBlock)
+            if (blk[lr.perf_row[j]] == b) for (int k = 0; k < 7; ++k) q7[k] += lr.Q[21 * long(j) + 3 * k];
+        __syncthreads();
+        block_sum<7>(q7, sm);
+        if (threadIdx.x == 0) for (int k = 0; k < 7; ++k) q7s[b][k] = q7[k];
+    }
+    __syncthreads();
+    for (int i = lr.connpos[wl] + threadIdx.x; i < lr.connpos[wl + 1]; i += kBlock) {
+        const int row = lr.perf_row[i];
+        const double wa[3] = { double(w[row]), double(w[nbp + row]), double(w[2 * long(nbp) + row]) };
+        for (int b = 0; b < m; ++b) {
+            double t = 0.0;
+            for (int a = 0; a < 3; ++a) { double pa = 0.0; for (int k = 0; k < 7; ++k) pa += lr.P[21 * long(i) + 7 * a + k] * q7s[b][k]; t += wa[a] * pa; }
+            T[long(b) * nbp + row] = S(double(T[long(b) * nbp + row]) + t);
+        }
+    }
+}
+
 // wells (rank-7 operator per well, all perforations on this rank): their part of P^T (A_p + wells) P and of the row sums.  Without it
 // a rate-controlled well's diagonal terms are counted although the Schur complement cancels them for a constant pressure shift.
 // One workgroup per well, fixed reduction order; k_cs_wells_sum then adds the per-well totals to A_c(mine, mine) in well order.
@@ -1172,7 +1271,21 @@ template <class S> void LinSolver::coarse_setup(bool rowparts_done)
     const bool emulated = !comm && emulate_ranks > 1;
     const int mine = comm ? comm->my_rank() : 0;
     double* cA = cs_buf.p; double* inv = cA + ns * ns;
-    if (!emulated) {
+    if (!emulated && cs_m > 1) {
+        // several coarse unknowns per rank: T is complete (fused row pass or k_cs_rowparts below), the rows of A_c are block sums of it
+        double* rparts = cs_buf.p + size_t(2) * ns * ns + ns;
+        if (!rowparts_done) {
+            const int gp0 = std::min(grid_for(plan.nb), kMaxPart);
+            hipLaunchKernelGGL((k_cs_rowparts<S>), dim3(gp0), dim3(kBlock), 0, stream, plan.nb, plan.nbp, cs_slots, dp.slice_ptr.p, dp.col.p, dp.rowlen.p, cs_sub.p,
+                               comm ? comm->owner_mask() : (const int8_t*)nullptr, (const S*)w.cprw.p, matrix<S>(), rparts, w.csT.p);
+        }
+        if (lowrank.nw > 0)
+            hipLaunchKernelGGL((k_cs_wells_blocks<S>), dim3(lowrank.nw), dim3(kBlock), 0, stream, lowrank, plan.nbp, cs_m, (const int8_t*)cs_blk.p, (const S*)w.cprw.p, w.csT.p);
+        const int gp = std::min(grid_for(plan.nb), 128);           // 64 partial arrays (slot x block) of gp entries in the scratch
+        hipLaunchKernelGGL((k_cs_block_rows<S>), dim3(gp, cs_slots.n), dim3(kBlock), 0, stream, plan.nb, plan.nbp, (const int8_t*)cs_blk.p, (const S*)w.csT.p, rparts);
+        hipLaunchKernelGGL(k_cs_place_blocks, dim3(1), dim3(kBlock), 0, stream, gp, (const double*)rparts, cs_slots, ns, cs_m, mine, cA);
+        if (comm) comm->allreduce_sum(cA, ns * ns, stream);
+    } else if (!emulated) {
         const int gp = rowparts_done ? std::min(grid_for(plan.nbp), kCsRowParts) : std::min(grid_for(plan.nb), kMaxPart);
         double* rparts = cs_buf.p + size_t(2) * ns * ns + ns;      // 8 slots x gp partials
         if (!rowparts_done)
@@ -1192,38 +1305,64 @@ template <class S> void LinSolver::coarse_setup(bool rowparts_done)
     hipLaunchKernelGGL(k_cs_invert, dim3(1), dim3(1), size_t(2) * ns * ns * sizeof(double), stream, ns, (const double*)cA, inv);
 }
 // subdomain map, slots and buffers of the coarse space (before the fused row pass writes into them)
+// Subdomains of the coarse space (real ranks or one GPU): m coarse unknowns per rank -- index-range blocks of its owned cells; a single
+// GPU keeps the one global constant -- the largest m <= requested that every rank can hold (own blocks + the neighbours' blocks seen
+// in ghost rows <= 8 slots, n_ranks * m <= 64), agreed collectively.  Cached per communicator / plan.  COLLECTIVE when stale.
+void LinSolver::coarse_domains()
+{
+    const void* key = comm ? static_cast<const void*>(comm) : static_cast<const void*>(this);
+    if (cs_sub.p && cs_sub.n == size_t(plan.nbp) && cs_for == key && cs_blk.p) return;
+    const int mine = comm ? comm->my_rank() : 0;
+    std::vector<int32_t> sub;
+    std::vector<int8_t> blk;
+    int m = comm ? std::max(1, std::min(cs_blocks_req, 8)) : 1;
+    while (m > 1 && comm->num_ranks() * m > 64) m /= 2;
+    for (;; m /= 2) {
+        if (comm) comm->coarse_blocks_of_rows(plan, m, stream, sub, blk); else { sub.assign(plan.nbp, 0); blk.assign(plan.nbp, int8_t(0)); }
+        cs_slots.n = 0;
+        for (int i = 0; i < 64; ++i) cs_slots.slot_of_sub[i] = 0;
+        bool overflow = false;
+        auto add = [&](int sd) {
+            for (int q = 0; q < cs_slots.n; ++q) if (cs_slots.sub_of_slot[q] == sd) return;
+            if (cs_slots.n < 8 && sd >= 0 && sd < 64) { cs_slots.slot_of_sub[sd] = int8_t(cs_slots.n); cs_slots.sub_of_slot[cs_slots.n++] = sd; }
+            else overflow = true;
+        };
+        for (int b = 0; b < m; ++b) add(mine * m + b);             // own blocks: slots 0 .. m-1
+        for (int32_t sd : sub) add(sd);
+        double flag = overflow ? 1.0 : 0.0;
+        if (comm) {
+            DevArray<double> f; f.alloc(1);
+            OPMGPU_HIP(hipMemcpyAsync(f.p, &flag, sizeof(double), hipMemcpyHostToDevice, stream));
+            comm->allreduce_max(f.p, 1, stream);
+            OPMGPU_HIP(hipMemcpyAsync(&flag, f.p, sizeof(double), hipMemcpyDeviceToHost, stream));
+            OPMGPU_HIP(hipStreamSynchronize(stream));
+        }
+        if (flag == 0.0) break;
+        if (m == 1) throw HipError(OPMGPU_EINVAL, "coarse space: more than 7 neighbour ranks or more than 64 ranks (set OPMGPU_COARSE=0)");
+    }
+    cs_m = m;
+    for (int r = plan.nb; r < plan.nbp; ++r) blk[r] = int8_t(-1);
+    cs_sub.alloc(plan.nbp); cs_sub.upload(sub, stream);
+    cs_blk.alloc(plan.nbp); cs_blk.upload(blk, stream);
+    OPMGPU_HIP(hipStreamSynchronize(stream));
+    cs_for = key;
+}
+
+// buffers of the coarse space (before the fused row pass writes into them); the emulated subdomain map
 template <class S> void LinSolver::coarse_begin()
 {
     SolverWork<S>& w = work<S>();
     const int ns = coarse_nsub;
-    const void* key = comm ? static_cast<const void*>(comm) : static_cast<const void*>(this);
     const bool emulated = !comm && emulate_ranks > 1;
-    const int mine = comm ? comm->my_rank() : 0;
-    if (!cs_sub.p || cs_sub.n != size_t(plan.nbp) || cs_for != key) {
-        cs_sub.alloc(plan.nbp);
-        if (!emulated) {
-            std::vector<int32_t> sub;
-            if (comm) comm->subdomain_of_rows(plan, sub); else sub.assign(plan.nbp, 0);
-            cs_sub.upload(sub, stream);
-            // slots = own subdomain first, then the distinct neighbour subdomains seen in ghost rows
-            cs_slots.n = 0;
-            for (int i = 0; i < 64; ++i) cs_slots.slot_of_sub[i] = 0;
-            bool overflow = false;
-            auto add = [&](int sd) {
-                for (int q = 0; q < cs_slots.n; ++q) if (cs_slots.sub_of_slot[q] == sd) return;
-                if (cs_slots.n < 8 && sd >= 0 && sd < 64) { cs_slots.slot_of_sub[sd] = int8_t(cs_slots.n); cs_slots.sub_of_slot[cs_slots.n++] = sd; }
-                else overflow = true;
-            };
-            add(mine);
-            for (int32_t sd : sub) if (sd != mine) add(sd);
-            if (overflow) throw HipError(OPMGPU_EINVAL, "coarse space: more than 7 neighbour ranks or more than 64 ranks (set OPMGPU_COARSE=0)");
-            OPMGPU_HIP(hipStreamSynchronize(stream));
-        } else {
+    if (emulated) {
+        const void* key = static_cast<const void*>(this);
+        if (!cs_sub.p || cs_sub.n != size_t(plan.nbp) || cs_for != key || cs_emulated_ns != ns) {
+            cs_sub.alloc(plan.nbp);
             hipLaunchKernelGGL(k_cs_sub_emulated, dim3(grid_for(plan.nbp)), dim3(kBlock), 0, stream, plan.nb, plan.nbp, ns, dp.nat.p, cs_sub.p);
+            cs_for = key; cs_emulated_ns = ns; cs_blk.release();
         }
-        cs_for = key;
     }
-    cs_buf.alloc(size_t(2) * ns * ns + ns + size_t(8) * kCsRowParts);
+    cs_buf.alloc(size_t(2) * ns * ns + ns + size_t(8) * kCsRowParts);          // scratch: 8 x 8192 partials (also 64 arrays of 128 for the blocks)
     OPMGPU_HIP(hipMemsetAsync(cs_buf.p, 0, (size_t(2) * ns * ns + ns) * sizeof(double), stream));
     w.cxc.alloc(plan.nbp);
     if (!emulated) w.csT.alloc(size_t(cs_slots.n) * plan.nbp);
@@ -1242,7 +1381,9 @@ template <class S> void LinSolver::cpr_prepare()
     // (wells with a pressure control anchor the level: measured, the constant then costs more than it gains -- so with one
     // subdomain it is used for well-free systems only; coarse_mode 2 forces it, 0 switches the whole coarse space off)
     static const int cs_split = std::getenv("OPMGPU_COARSE_SPLIT") ? std::max(1, std::atoi(std::getenv("OPMGPU_COARSE_SPLIT"))) : 1;   // emulation only: coarse unknowns per rank
-    const int nsub = comm ? comm->num_ranks() : (emulate_ranks > 1 ? emulate_ranks * cs_split : 1);
+    const bool emulated_cs = !comm && emulate_ranks > 1;
+    if (coarse_mode != 0 && !emulated_cs) coarse_domains();
+    const int nsub = comm ? comm->num_ranks() * cs_m : (emulate_ranks > 1 ? emulate_ranks * cs_split : 1);
     const bool single_ok = coarse_mode == 2 || (coarse_single_ok && lowrank.nw == 0);
     coarse_nsub = coarse_mode != 0 && (nsub >= 2 || single_ok) ? nsub : 0;
     if (coarse_nsub > 64) coarse_nsub = 0;        // table sizes of the kernels
@@ -1323,8 +1464,13 @@ template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, con
         if (!emulated) {
             const int gp = std::min(grid_for(plan.nb), kMaxPart);
             double* parts = cs_buf.p + size_t(2) * ns * ns + ns;   // own scratch (the BiCGStab partial arrays are live across a preconditioner application)
-            hipLaunchKernelGGL((k_cs_rsum<S>), dim3(gp), dim3(kBlock), 0, stream, plan.nb, comm ? comm->owner_mask() : (const int8_t*)nullptr, (const S*)L0.b.p, parts, ctl);
-            hipLaunchKernelGGL(k_cs_place, dim3(1), dim3(kBlock), 0, stream, gp, (const double*)parts, ns, comm ? comm->my_rank() : 0, cr, ctl);
+            if (cs_m > 1) {
+                hipLaunchKernelGGL((k_cs_rsum_blocks<S>), dim3(gp), dim3(kBlock), 0, stream, plan.nb, (const int8_t*)cs_blk.p, (const S*)L0.b.p, parts, ctl);
+                hipLaunchKernelGGL(k_cs_place_cr, dim3(1), dim3(kBlock), 0, stream, gp, (const double*)parts, ns, cs_m, comm ? comm->my_rank() : 0, cr, ctl);
+            } else {
+                hipLaunchKernelGGL((k_cs_rsum<S>), dim3(gp), dim3(kBlock), 0, stream, plan.nb, comm ? comm->owner_mask() : (const int8_t*)nullptr, (const S*)L0.b.p, parts, ctl);
+                hipLaunchKernelGGL(k_cs_place, dim3(1), dim3(kBlock), 0, stream, gp, (const double*)parts, ns, comm ? comm->my_rank() : 0, cr, ctl);
+            }
             if (comm) comm->allreduce_sum(cr, ns, stream);
         } else {
             OPMGPU_HIP(hipMemsetAsync(cr, 0, ns * sizeof(double), stream));

@@ -48,6 +48,9 @@ struct CommBase {
     virtual int num_ranks() const = 0;
     // owner rank of every local row (internal numbering; ghosts: the rank they are received from)
     virtual void subdomain_of_rows(const Plan& P, std::vector<int32_t>& sub) const = 0;
+    // coarse-space unknown of every local row when every rank splits its owned cells into m index-range blocks: rank * m + block for
+    // owned rows, the OWNER's value for ghost rows (one halo exchange); blk = own block of a row or -1 (ghost / padding)
+    virtual void coarse_blocks_of_rows(const Plan& P, int m, hipStream_t s, std::vector<int32_t>& sub, std::vector<int8_t>& blk) = 0;
     int n_owned_global = 0;
 };
 
@@ -107,9 +110,14 @@ public:
     DevArray<double> cs_buf;       // A_c | A_c^-1 | restricted residual
     struct CsSlots { int n; int8_t slot_of_sub[64]; int32_t sub_of_slot[8]; } cs_slots;   // real multi-GPU: this rank's own + neighbour subdomains
     const void* cs_for = nullptr;  // communicator / plan the subdomain data was built for
+    int cs_m = 1;                  // coarse unknowns per rank (index-range blocks of its owned cells; OPMGPU_COARSE_BLOCKS, multi-GPU only)
+    int cs_blocks_req = 4;
+    int cs_emulated_ns = 0;
+    DevArray<int8_t> cs_blk;       // [nbp] own block of every row, -1 = not owned
     bool coarse_single_ok = false; // set by the model: the system has no wells at all (B1 matrices: unknown -> false)
     DevArray<double> cs_well_tot;
     int coarse_mode = 1;           // OPMGPU_COARSE: 0 off, 1 on with >= 2 subdomains, 2 on always (tests)
+    void coarse_domains();
     template <class S> void coarse_begin();
     template <class S> void coarse_setup(bool rowparts_done);
     int emulate_ranks = 1, emulate_what = 3;      // bit 0: cut the ILU0's matrix, bit 1: the AMG's, bit 2: the stage-2 residual's (= no x_p halo exchange)
