@@ -263,6 +263,7 @@ int opmgpu_set_device_wells(opmgpu_ctx* c, const opmgpu_wells* wells)
         if (c->comm && wells->nw > 0 && wells->well_connpos && wells->well_cells)
             for (int j = 0; j < wells->well_connpos[wells->nw]; ++j)
                 if (wells->well_cells[j] >= c->model->n_owned_cells) return fail(c, OPMGPU_EINVAL, "multi-GPU: a well perforates a ghost cell; keep every well on one rank");
+        c->ls->run_has_wells = true; c->ls->cs_for = nullptr;       // the coarse space of the pressure stage keeps one unknown per rank then
         const int st = c->model->set_device_wells(wells);
         if (st != OPMGPU_OK) return fail(c, st, "invalid well specification (missing array, cell out of range or perforated twice)");
         return st;

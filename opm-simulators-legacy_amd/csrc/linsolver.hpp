@@ -112,6 +112,7 @@ public:
     const void* cs_for = nullptr;  // communicator / plan the subdomain data was built for
     int cs_m = 1;                  // coarse unknowns per rank (index-range blocks of its owned cells; OPMGPU_COARSE_BLOCKS, multi-GPU only)
     int cs_blocks_req = 4;
+    bool run_has_wells = false;    // set by opmgpu_set_device_wells on EVERY rank of a run with wells (also ranks that own none)
     int cs_emulated_ns = 0;
     DevArray<int8_t> cs_blk;       // [nbp] own block of every row, -1 = not owned
     bool coarse_single_ok = false; // set by the model: the system has no wells at all (B1 matrices: unknown -> false)
