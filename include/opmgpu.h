@@ -237,7 +237,9 @@ typedef struct opmgpu_wells {
     const double*  ctrl_distr;     /* [nw*3] rate-control phase weights; NULL = 0              */
 } opmgpu_wells;
 
-int opmgpu_set_device_wells(opmgpu_ctx* ctx, const opmgpu_wells* wells);   /* nw == 0 removes them */
+/* nw == 0 removes them.  Multi-GPU: a well lives on ONE rank, and EVERY rank of a run with wells makes this call (nw = 0 where it owns
+ * none) -- opmgpu_well_convergence is collective, and the call tells the pressure stage's coarse space that the run has wells. */
+int opmgpu_set_device_wells(opmgpu_ctx* ctx, const opmgpu_wells* wells);
 /* WellStateFullyImplicitBlackoil fields: bhp[nw], wellRates qs[nw*3]; perf_rates[nperf*3] may be NULL (keep) */
 int opmgpu_well_state_set(opmgpu_ctx* ctx, const double* bhp, const double* qs, const double* perf_rates);
 int opmgpu_well_state_get(opmgpu_ctx* ctx, double* bhp, double* qs, double* perf_press, double* perf_rates);
