@@ -54,11 +54,22 @@ def run(cfg, rank, world, uid, out):
         if world > 1:
             wl = dom.local_wells(wl, part)
         driver = W.DeviceWellModel(model, wl, W.WellState(wl, lst.p))
-    driver.prepareStep(cfg["dt_days"] * decks.DAY, lst)
     hist = []
-    for it in range(cfg["newton"]):
-        conv, lin = driver.nonlinearIteration(it, single_precision=cfg["single"])
-        hist.append([bool(conv), int(lin)])
+    if cfg.get("ats"):
+        # one report step through the adaptive sub-stepping loop (restart on failure): every decision in it -- Newton convergence,
+        # the relative change that feeds the PID controller -- is a collective result, so all ranks chop and grow the same way
+        from opmgpu import timestepping as ts
+        from opmgpu.model import NonlinearSolver
+        model.setState(lst)
+        ats = ts.AdaptiveTimeStepping(initial_timestep_days=cfg["ats"]["first_days"])
+        rep = ats.step(0.0, cfg["ats"]["report_days"] * decks.DAY, NonlinearSolver(max_iter=cfg["ats"]["max_iter"]), model)
+        assert rep["converged"]
+        hist = [[int(round(dt)), 1] for dt in rep["substeps"]] + [[int(round(f[0])), 0] for f in rep["failed"]]
+    else:
+        driver.prepareStep(cfg["dt_days"] * decks.DAY, lst)
+        for it in range(cfg["newton"]):
+            conv, lin = driver.nonlinearIteration(it, single_precision=cfg["single"])
+            hist.append([bool(conv), int(lin)])
     s = model.getState()
     n = owned_global.size
     np.savez(out, ids=owned_global, p=s.p[:n], sat=s.sat[:n], hc=s.hc[:n], hist=np.array(hist, dtype=np.int64))

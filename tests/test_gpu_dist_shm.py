@@ -66,6 +66,9 @@ CASES = {
     "cpr": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=500, use_cpr=1), wells=False, single=False),
     "cpr_wells": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=500, use_cpr=1), wells=True, single=False),
     "cpr_f32_default_tolerance": dict(params=dict(use_cpr=1), wells=False, single=True),
+    # a 30-day report step through the adaptive sub-stepping loop, first sub-step too long for 3 Newton iterations: chopped and redone
+    "cpr_adaptive_substeps": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=500, use_cpr=1), wells=False, single=False,
+                                  ats=dict(first_days=30.0, report_days=30.0, max_iter=3)),
 }
 
 
@@ -82,6 +85,9 @@ def test_decomposed_runs_walk_the_single_domain_newton_path(gpu_lib, case):
                 # counts collective; this case is about the float kernels / merged reductions running decomposed at all
                 assert np.abs(got[0] - ref[0]).max() <= 2e-3 * np.abs(ref[0]).max() and np.abs(got[1] - ref[1]).max() <= 2e-2
                 continue
+            if "ats" in c:
+                assert np.array_equal(got[3], ref[3]), (case, world, got[3].tolist(), ref[3].tolist())      # same sub-steps, same failures
+                assert (ref[3][:, 1] == 0).any()                                                              # (there was a chopped one)
             assert np.array_equal(got[2], ref[2]), (case, world)
             assert np.abs(got[0] - ref[0]).max() <= 1e-6 * np.abs(ref[0]).max(), (case, world)
             assert np.abs(got[1] - ref[1]).max() <= 1e-6, (case, world)
