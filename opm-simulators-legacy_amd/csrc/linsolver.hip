@@ -763,7 +763,7 @@ int LinSolver::set_pattern(int nb, const int32_t* rowptr, const int32_t* col, in
         std::memcmp(plan.rowptr.data(), rowptr, sizeof(int32_t) * (nb + 1)) == 0 &&
         std::memcmp(plan.col.data(), col, sizeof(int32_t) * plan.nnzb) == 0)
         return OPMGPU_OK;
-    light_ok_for = nullptr;
+    light_ok_for = nullptr; cs_for = nullptr;        // row numbering changes: the masks / subdomain maps built for the old plan are stale
     Plan P;
     const int st = build_plan(nb, rowptr, col, ordering, P);
     if (st != OPMGPU_OK) return st;
