@@ -238,7 +238,8 @@ template <class S>
 __global__ __launch_bounds__(kBlock) void k_ilu_upper(int xm, int lo, int hi, int n0, int nbp, S w, const int32_t* __restrict__ slice_ptr,
                                                       const int32_t* __restrict__ col, const int16_t* __restrict__ nlower,
                                                       const int16_t* __restrict__ rowlen, const S* __restrict__ lu,
-                                                      const S* __restrict__ d, S* __restrict__ v, const SolveCtl* __restrict__ ctl)
+                                                      const S* __restrict__ d, S* __restrict__ v, const SolveCtl* __restrict__ ctl,
+                                                      const int8_t* __restrict__ simple, const S* __restrict__ A)
 {
     if (ctl && ctl->done) return;
     const int nchunks = (hi - lo + kBlock - 1) / kBlock;
@@ -247,7 +248,10 @@ __global__ __launch_bounds__(kBlock) void k_ilu_upper(int xm, int lo, int hi, in
     const int row = lo + ch * kBlock + threadIdx.x;
     if (row >= hi) return;
     const int base = slice_ptr[row >> 6], lane = row & 63, nl = nlower[row], len = rowlen[row];
+    // U entries of a "simple" row (all its ILU0 updates hit the diagonal block) are the entries of the factorised matrix itself: the
+    // factorisation does not copy them (k_ilu_factor), they are read from A -- which the SpMV keeps warm in the Infinity Cache anyway
     const S* __restrict__ m = lu + vidx(base, lane);
+    const S* __restrict__ mu = (simple[row] ? A : lu) + vidx(base, lane);
     const int32_t* __restrict__ c = col + long(base) * 64 + lane;
     S r0, r1, r2;
     if (row < n0) { r0 = w * d[row]; r1 = w * d[nbp + row]; r2 = w * d[2 * nbp + row]; }
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(kBlock) void k_ilu_upper(int xm, int lo, int hi, in
     for (int k = nl + 1; k < len; ++k) {
         const int cc = c[k * 64];
         const S x0 = v[cc], x1 = v[nbp + cc], x2 = v[2 * nbp + cc];
-        const S* __restrict__ b = m + k * 576;
+        const S* __restrict__ b = mu + k * 576;
         r0 -= b[0] * x0 + b[64] * x1 + b[128] * x2;
         r1 -= b[192] * x0 + b[256] * x1 + b[320] * x2;
         r2 -= b[384] * x0 + b[448] * x1 + b[512] * x2;
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(kBlock) void k_ilu_factor(int lo, int hi, const int
                                                        const int16_t* __restrict__ nlower, const int32_t* __restrict__ trip_ptr,
                                                        const int32_t* __restrict__ trip_l, const int32_t* __restrict__ trip_u,
                                                        const int32_t* __restrict__ trip_t, const S* __restrict__ A, const int16_t* __restrict__ rowlen,
-                                                       S* __restrict__ lu, int32_t* __restrict__ flags)
+                                                       S* __restrict__ lu, int32_t* __restrict__ flags, const int8_t* __restrict__ simple_row, int copy_upper)
 {
     const int row = lo + blockIdx.x * kBlock + threadIdx.x;
     if (row >= hi) return;
@@ -305,8 +309,7 @@ __global__ __launch_bounds__(kBlock) void k_ilu_factor(int lo, int hi, const int
     // Fast path (every row of a multicolour ordering on a grid stencil): all updates of this row hit its diagonal block, so the
     // diagonal is accumulated in registers and every entry of A is read once and every entry of LU written once -- the generic
     // path below goes through memory for each update (copy, re-load, store; measured 2.6x the traffic of this one).
-    bool simple = true;
-    for (int q = tp; q < te; ++q) simple = simple && (trip_t[q] == ed);
+    const bool simple = simple_row[row] != 0;
     S m[9], o[9];
     if (simple) {
         ld9(A, ed, m);
@@ -318,19 +321,21 @@ __global__ __launch_bounds__(kBlock) void k_ilu_factor(int lo, int hi, const int
             ld9(A, e, a); ld9(lu, ej, dj);
             mm9(a, dj, L);
             st9(lu, e, L);
+            const S* usrc = simple_row[j] ? A : lu;          // row j's U entries: not copied when they equal A's
             while (tp < te && trip_l[tp] == e) {
                 S u[9], bb[9];
-                ld9(lu, trip_u[tp], u);
+                ld9(usrc, trip_u[tp], u);
                 mm9(L, u, bb);
 #pragma unroll
                 for (int q = 0; q < 9; ++q) m[q] -= bb[q];
                 ++tp;
             }
         }
-        for (int k = nl + 1; k < len; ++k) {           // upper part: unchanged copy of A
-            const int32_t e = (base + k) * 64 + lane;
-            S t[9]; ld9(A, e, t); st9(lu, e, t);
-        }
+        if (copy_upper)
+            for (int k = nl + 1; k < len; ++k) {       // upper part: unchanged copy of A -- k_ilu_upper reads it from A, so only on request (get_lu_bsr)
+                const int32_t e = (base + k) * 64 + lane;
+                S t[9]; ld9(A, e, t); st9(lu, e, t);
+            }
     } else {
         // generic IKJ: this row of LU starts as a copy of the row of A, updates go through memory
         for (int k = 0; k < len; ++k) {
@@ -345,9 +350,10 @@ __global__ __launch_bounds__(kBlock) void k_ilu_factor(int lo, int hi, const int
             ld9(lu, e, a); ld9(lu, ej, dj);
             mm9(a, dj, L);
             st9(lu, e, L);
+            const S* usrc = simple_row[j] ? A : lu;
             while (tp < te && trip_l[tp] == e) {
                 S u[9], t[9], bb[9];
-                ld9(lu, trip_u[tp], u); ld9(lu, trip_t[tp], t);
+                ld9(usrc, trip_u[tp], u); ld9(lu, trip_t[tp], t);
                 mm9(L, u, bb);
 #pragma unroll
                 for (int q = 0; q < 9; ++q) t[q] -= bb[q];
@@ -712,7 +718,7 @@ void DevPlan::upload(const Plan& P, hipStream_t s)
     std::vector<int32_t> one(1, 0);      // hipMalloc(0) is avoided: keep at least one element
     trip_l.upload(P.trip_l.empty() ? one : P.trip_l, s); trip_u.upload(P.trip_u.empty() ? one : P.trip_u, s);
     trip_t.upload(P.trip_t.empty() ? one : P.trip_t, s);
-    rowlen.upload(P.rowlen, s); nlower.upload(P.nlower, s); tpos.upload(P.tpos, s);
+    rowlen.upload(P.rowlen, s); nlower.upload(P.nlower, s); tpos.upload(P.tpos, s); simple.upload(P.simple, s);
     level_ptr = P.level_ptr;
     OPMGPU_HIP(hipStreamSynchronize(s));      // the host vectors may go away
 }
@@ -860,7 +866,8 @@ template <class S> int LinSolver::factor(bool wait)
         const int lo = plan.level_ptr[l], hi = plan.level_ptr[l + 1];
         if (hi == lo) continue;
         hipLaunchKernelGGL((k_ilu_factor<S>), dim3(grid_for(hi - lo)), dim3(kBlock), 0, stream, lo, hi, dp.slice_ptr.p, dp.col.p,
-                           dp.nlower.p, dp.trip_ptr.p, dp.trip_l.p, dp.trip_u.p, dp.trip_t.p, ((emulate_what & 1) ? pre_matrix<S>() : matrix<S>()), dp.rowlen.p, w.LU.p, flags.p);
+                           dp.nlower.p, dp.trip_ptr.p, dp.trip_l.p, dp.trip_u.p, dp.trip_t.p, ((emulate_what & 1) ? pre_matrix<S>() : matrix<S>()), dp.rowlen.p, w.LU.p, flags.p,
+                           (const int8_t*)dp.simple.p, int(lu_copy_upper));
     }
     OPMGPU_HIP(hipMemcpyAsync(h_flags, flags.p, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     if (!wait) return OPMGPU_OK;          // the caller reads factor_status() after its next synchronisation (no pipeline bubble per solve)
@@ -888,7 +895,7 @@ template <class S> void LinSolver::ilu_apply(const S* d, S* v, double relax, con
         const int lo = plan.level_ptr[l], hi = plan.level_ptr[l + 1];
         if (hi == lo) continue;
         hipLaunchKernelGGL((k_ilu_upper<S>), dim3(grid8_for(hi - lo)), dim3(kBlock), 0, stream, xcd_mode(), lo, hi, n0, plan.nbp, S(relax), dp.slice_ptr.p, dp.col.p,
-                           dp.nlower.p, dp.rowlen.p, w.LU.p, d, v, ctl);
+                           dp.nlower.p, dp.rowlen.p, w.LU.p, d, v, ctl, (const int8_t*)dp.simple.p, ((emulate_what & 1) ? pre_matrix<S>() : matrix<S>()));
     }
 }
 
@@ -1853,6 +1860,10 @@ void LinSolver::get_matrix_bsr(const double* sell, double* val9)
 }
 template <class S> void LinSolver::get_lu_bsr(double* val9)
 {
+    // the solver's factorisation leaves out the U entries that equal A's (k_ilu_upper reads those from A): factorise once more in full
+    lu_copy_upper = true;
+    (void)factor<S>(true);
+    lu_copy_upper = false;
     stage.ensure(std::max(size_t(plan.nnzb) * 9, size_t(3) * plan.nbp));
     hipLaunchKernelGGL((k_sell_to_bsr<S>), dim3(grid_for(plan.nnzb)), dim3(kBlock), 0, stream, plan.nnzb, dp.entry_of_block.p, work<S>().LU.p, stage.p);
     OPMGPU_HIP(hipMemcpyAsync(val9, stage.p, size_t(plan.nnzb) * 9 * sizeof(double), hipMemcpyDeviceToHost, stream));

@@ -16,6 +16,7 @@ struct DevPlan {
     int nb = 0, nbp = 0, nslices = 0, nentries = 0, nlevels = 0, nnzb = 0;
     DevArray<int32_t> slice_ptr, col, src, entry_of_block, nat, pos, trip_ptr, trip_l, trip_u, trip_t, tpos;
     DevArray<int16_t> rowlen, nlower;
+    DevArray<int8_t> simple;
     std::vector<int32_t> level_ptr;
     void upload(const Plan& P, hipStream_t s);
 };
@@ -183,6 +184,7 @@ public:
     bool new_step_hint = true;     // set by the caller for the first matrix of a time step (and for every external matrix)
     bool refreshed = true;         // the current solve runs on freshly built coarse operators
     int last_its = 0, its_ref = 0; // iterations of the last solve / of the solve right after the last refresh
+    bool lu_copy_upper = false;    // factor(): also store the U entries that equal A's (diagnostic read-back of the factors)
     bool lag_allowed = true, force_refresh = false;
     int step_matrix = 0;           // matrices seen since the time step began
     int lag_block = 0;             // > 0: time steps during which the coarse operators follow every matrix again

@@ -187,6 +187,13 @@ int build_plan(int nb, const int32_t* rowptr, const int32_t* col, int ordering, 
         for (int k = 0; k < len; ++k) slot_of[P.sell_col[P.entry(i, k)]] = -1;
         P.trip_ptr[i + 1] = int32_t(P.trip_l.size());
     }
+    P.simple.assign(P.nbp, 0);
+    for (int i = 0; i < nb; ++i) {
+        const int32_t ed = P.entry(i, P.nlower[i]);
+        bool sm = true;
+        for (int q = P.trip_ptr[i]; q < P.trip_ptr[i + 1]; ++q) sm = sm && (P.trip_t[q] == ed);
+        P.simple[i] = sm ? 1 : 0;
+    }
     return OPMGPU_OK;
 }
 

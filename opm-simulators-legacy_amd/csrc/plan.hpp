@@ -46,6 +46,7 @@ struct Plan {
     //   target(i,k) -= L(i,j) * U(j,k)
     std::vector<int32_t> trip_ptr;         // [nb+1]
     std::vector<int32_t> trip_l, trip_u, trip_t;   // entry ids
+    std::vector<int8_t> simple;            // [nbp] 1 = every ILU0 update of the row hits its diagonal block: its U entries are those of A
     std::vector<int32_t> tpos;             // [nentries] entry id of the transposed block (j,i) of entry (i,j); -1: none / padding
 
     static inline int64_t val_index(int32_t entry, int comp) { return int64_t(entry >> 6) * 576 + comp * 64 + (entry & 63); }
