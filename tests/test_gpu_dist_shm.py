@@ -63,6 +63,7 @@ def _launch(cfg, world, tmp):
 
 CASES = {
     "ilu0": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=1500), wells=False, single=False),
+    "ilu0_natural_order": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=1500, ilu_ordering=0), wells=False, single=False),
     "cpr": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=500, use_cpr=1), wells=False, single=False),
     "cpr_wells": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=500, use_cpr=1), wells=True, single=False),
     "cpr_f32_default_tolerance": dict(params=dict(use_cpr=1), wells=False, single=True),
