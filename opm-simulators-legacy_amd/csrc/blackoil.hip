@@ -385,7 +385,7 @@ __global__ __launch_bounds__(kBlock) void k_flux(int xm, int nb, int nbp, const 
                                                  const double* __restrict__ gdz, const double* __restrict__ thpres,
                                                  const double* __restrict__ pstate, const double* __restrict__ props, const MS* __restrict__ pd,
                                                  double s0, double s1, double s2, const int8_t* __restrict__ mask,
-                                                 double* __restrict__ R, MS* __restrict__ A)
+                                                 double* __restrict__ R, MS* __restrict__ A, MS* __restrict__ wout)
 {
     const int nchunks = (nb + kBlock - 1) / kBlock;
     const int ch = xcd_first(nchunks, xm);
@@ -401,9 +401,14 @@ __global__ __launch_bounds__(kBlock) void k_flux(int xm, int nb, int nbp, const 
             for (int q = 0; q < 9; ++q) bptr[q * 64] = (k == nl && (q == 0 || q == 4 || q == 8)) ? MS(1) : MS(0);
         }
         R[row] = 0.0; R[nbp + row] = 0.0; R[2 * long(nbp) + row] = 0.0;
+        if (wout) { wout[row] = MS(1); wout[nbp + row] = MS(0); wout[2 * long(nbp) + row] = MS(0); }      // identity row: its pressure entry
         return;
     }
     const double scale[3] = { s0, s1, s2 };
+    // CPR weights (formEllipticSystem, see k_cpr_weights): column sums of |dR_j[eq]/dp_i| over the rows j != i.  The block (j, i) is
+    // the other side's view of THIS connection -- minus this row's own-variable derivative of the same flux -- so the sums come for
+    // free here and the pressure stage needs no transposed gathers (systems without wells; k_cpr_weights stays for everything else)
+    double sod[3] = { 0.0, 0.0, 0.0 };
     double Rl[3] = { R[row], R[nbp + row], R[2 * long(nbp) + row] };
     double D[9];
     MS* dptr = A + long(base + nl) * 576 + lane;
@@ -498,6 +503,7 @@ __global__ __launch_bounds__(kBlock) void k_flux(int xm, int nb, int nbp, const 
             for (int v = 0; v < 3; ++v) {
                 const double own = side ? dG2[a][v] : dG1[a][v];
                 const double oth = side ? dG1[a][v] : dG2[a][v];
+                if (v == 0) sod[a] += fabs(scale[a] * own);
                 D[3 * a + v] += s * scale[a] * own;
                 __builtin_nontemporal_store(MS(s * scale[a] * oth), &bptr[(3 * a + v) * 64]);
             }
@@ -505,6 +511,12 @@ __global__ __launch_bounds__(kBlock) void k_flux(int xm, int nb, int nbp, const 
     }
 #pragma unroll
     for (int q = 0; q < 9; ++q) __builtin_nontemporal_store(MS(D[q]), &dptr[q * 64]);
+    if (wout) {
+        const bool sw = fabs(D[0]) / sod[0] > 0.01, sg = fabs(D[6]) / sod[2] > 0.01;       // NaN (0/0) compares false like the reference's Eigen cast
+        bool so = fabs(D[3]) / sod[1] > 0.01;
+        if (!so && !sw && !sg) so = true;
+        wout[row] = sw ? MS(1) : MS(0); wout[nbp + row] = so ? MS(1) : MS(0); wout[2 * long(nbp) + row] = sg ? MS(1) : MS(0);
+    }
     R[row] = Rl[0]; R[nbp + row] = Rl[1]; R[2 * long(nbp) + row] = Rl[2];
 }
 
@@ -952,13 +964,17 @@ template <class MS> void BlackoilDevice::assemble_kernels(double dt, bool initia
     const Plan& P = ls.plan;
     const double* sc = prm.matbalscale;
     MS* pd = deriv_planes<MS>();
+    // CPR on a system without wells: k_flux also writes the weights of the pressure equation
+    MS* wout = nullptr;
+    if (prm.use_cpr && nperf == 0 && ls.cpr_weight_mode == 0 && ls.emulate_ranks <= 1) { ls.ensure_work<MS>(); ls.work<MS>().cprw.alloc(3 * size_t(P.nbp)); wout = ls.work<MS>().cprw.p; }
     hipLaunchKernelGGL((k_cell_props<MS>), dim3(grid_for(nc)), dim3(kBlock), tab_lds_bytes(), stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_pv.p,
                        d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, 1.0 / dt, int(initial), sc[0], sc[1], sc[2],
                        ls.dp.slice_ptr.p, ls.dp.nlower.p, eps_planes(), d_eps_u0.p, d_somax.p, d_props.p, pd, d_accum0.p, d_R.p, d_binv.p, A,
                        (const double*)d_tab.p, tab_lds_words());
     hipLaunchKernelGGL((k_flux<MS>), dim3(grid8_for(nc)), dim3(kBlock), 0, stream, xcd_mode(), nc, P.nbp, ls.dp.slice_ptr.p, ls.dp.col.p, ls.dp.rowlen.p,
                        ls.dp.nlower.p, d_conn_code.p, d_trans.p, d_gdz.p, use_thpres ? d_thpres.p : (const double*)nullptr,
-                       d_p.p, d_props.p, (const MS*)pd, sc[0], sc[1], sc[2], ls.comm ? ls.comm->owner_mask() : (const int8_t*)nullptr, d_R.p, A);
+                       d_p.p, d_props.p, (const MS*)pd, sc[0], sc[1], sc[2], ls.comm ? ls.comm->owner_mask() : (const int8_t*)nullptr, d_R.p, A, wout);
+    ls.weights_from_assembly = wout != nullptr;
 }
 // derivative planes in the Jacobian's precision: the double ones live in d_props itself, the float ones in their own buffer
 template <> double* BlackoilDevice::deriv_planes<double>() { return d_props.p; }

@@ -798,7 +798,7 @@ template <class S> void LinSolver::ensure_work()
 
 void LinSolver::load_host_bsr(const double* val9)
 {
-    matrix_is_float = false;
+    matrix_is_float = false; weights_from_assembly = false;
     new_step_hint = true;          // an external matrix: nothing is known about its relation to the previous one
     stage.ensure(std::max(size_t(plan.nnzb) * 9, size_t(3) * plan.nbp));
     OPMGPU_HIP(hipMemcpyAsync(stage.p, val9, size_t(plan.nnzb) * 9 * sizeof(double), hipMemcpyHostToDevice, stream));
@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__(kBlock) void k_cs_rowparts(int nb, int nbp, LinSolv
 }
 // the whole per-row set-up of the pressure stage in ONE pass over the matrix (per Newton iteration): weights (k_cpr_weights), the
 // pressure matrix (k_extract_pressure) and, with CS, the coarse-space row parts (k_cs_rowparts) -- same arithmetic as the three
-template <class S, bool CS>
+template <class S, bool CS, bool WR>
 __global__ __launch_bounds__(kBlock) void k_cpr_rows(int nb, int nbp, int mode, LinSolver::CsSlots sl, const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
                                                      const int16_t* __restrict__ rowlen, const int16_t* __restrict__ nlower, const int32_t* __restrict__ tpos,
                                                      const int32_t* __restrict__ sub, const int8_t* __restrict__ owned, const S* __restrict__ A,
@@ -1079,8 +1079,11 @@ __global__ __launch_bounds__(kBlock) void k_cpr_rows(int nb, int nbp, int mode, 
         if (row >= nb) { for (int k = 0; k < width; ++k) Ap[long(base + k) * 64 + lane] = S(0); continue; }
         const int len = rowlen[row];
         S ww[3];
-        cpr_row_weights<S>(lane, base, len, nlower[row], tpos, A, mode, ww);
-        w[row] = ww[0]; w[nbp + row] = ww[1]; w[2 * long(nbp) + row] = ww[2];
+        if (WR) { ww[0] = w[row]; ww[1] = w[nbp + row]; ww[2] = w[2 * long(nbp) + row]; }       // written by the assembly (k_flux)
+        else {
+            cpr_row_weights<S>(lane, base, len, nlower[row], tpos, A, mode, ww);
+            w[row] = ww[0]; w[nbp + row] = ww[1]; w[2 * long(nbp) + row] = ww[2];
+        }
         const bool cs = CS && !(owned && !owned[row]);
         const double w0 = double(ww[0]), w1 = double(ww[1]), w2 = double(ww[2]);
         double mine[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -1402,11 +1405,13 @@ template <class S> void LinSolver::cpr_prepare()
         const int gp = std::min(grid_for(plan.nbp), kCsRowParts);
         if (coarse_nsub >= 1) {
             coarse_begin<S>();
-            hipLaunchKernelGGL((k_cpr_rows<S, true>), dim3(gp), dim3(kBlock), 0, stream, plan.nb, plan.nbp, cpr_weight_mode, cs_slots, dp.slice_ptr.p, dp.col.p, dp.rowlen.p,
+            auto kern = weights_from_assembly ? k_cpr_rows<S, true, true> : k_cpr_rows<S, true, false>;
+            hipLaunchKernelGGL(kern, dim3(gp), dim3(kBlock), 0, stream, plan.nb, plan.nbp, cpr_weight_mode, cs_slots, dp.slice_ptr.p, dp.col.p, dp.rowlen.p,
                                dp.nlower.p, dp.tpos.p, cs_sub.p, comm ? comm->owner_mask() : (const int8_t*)nullptr, matrix<S>(), w.cprw.p,
                                w.amg->levels[0]->val.p, cs_buf.p + size_t(2) * coarse_nsub * coarse_nsub + coarse_nsub, w.csT.p);
         } else {
-            hipLaunchKernelGGL((k_cpr_rows<S, false>), dim3(gp), dim3(kBlock), 0, stream, plan.nb, plan.nbp, cpr_weight_mode, cs_slots, dp.slice_ptr.p, dp.col.p, dp.rowlen.p,
+            auto kern = weights_from_assembly ? k_cpr_rows<S, false, true> : k_cpr_rows<S, false, false>;
+            hipLaunchKernelGGL(kern, dim3(gp), dim3(kBlock), 0, stream, plan.nb, plan.nbp, cpr_weight_mode, cs_slots, dp.slice_ptr.p, dp.col.p, dp.rowlen.p,
                                dp.nlower.p, dp.tpos.p, (const int32_t*)nullptr, (const int8_t*)nullptr, matrix<S>(), w.cprw.p,
                                w.amg->levels[0]->val.p, (double*)nullptr, (S*)nullptr);
         }
@@ -1439,8 +1444,9 @@ template <class S> void LinSolver::cpr_prepare()
         if (coarse_nsub >= 1) coarse_setup<S>(true);
         return;
     }
-    hipLaunchKernelGGL((k_cpr_weights<S>), dim3(grid_for(plan.nb)), dim3(kBlock), 0, stream, plan.nb, plan.nbp, dp.slice_ptr.p, dp.rowlen.p, dp.nlower.p,
-                       dp.tpos.p, ((emulate_what & 2) ? pre_matrix<S>() : matrix<S>()), w.cprw.p, cpr_weight_mode);
+    if (!weights_from_assembly)
+        hipLaunchKernelGGL((k_cpr_weights<S>), dim3(grid_for(plan.nb)), dim3(kBlock), 0, stream, plan.nb, plan.nbp, dp.slice_ptr.p, dp.rowlen.p, dp.nlower.p,
+                           dp.tpos.p, ((emulate_what & 2) ? pre_matrix<S>() : matrix<S>()), w.cprw.p, cpr_weight_mode);
     if (!w.amg->ready()) {
         // first matrix with this pattern: pressure values to the host, aggregation hierarchy (structure only) built there
         DevArray<S> tmp; tmp.alloc(ne);

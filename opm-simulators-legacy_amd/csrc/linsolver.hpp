@@ -184,6 +184,7 @@ public:
     bool new_step_hint = true;     // set by the caller for the first matrix of a time step (and for every external matrix)
     bool refreshed = true;         // the current solve runs on freshly built coarse operators
     int last_its = 0, its_ref = 0; // iterations of the last solve / of the solve right after the last refresh
+    bool weights_from_assembly = false;   // cprw of the current matrix was written by the assembly kernel (k_flux), not by k_cpr_weights
     bool lu_copy_upper = false;    // factor(): also store the U entries that equal A's (diagnostic read-back of the factors)
     bool lag_allowed = true, force_refresh = false;
     int step_matrix = 0;           // matrices seen since the time step began
