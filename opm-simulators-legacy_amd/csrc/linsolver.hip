@@ -619,17 +619,37 @@ __global__ __launch_bounds__(kBlock) void k_extract_pressure(int nb, int nbp, co
         Ap[e] = w0 * b[0] + w1 * b[192] + w2 * b[384];
     }
 }
-// r_p = the same combination of the three (scaled) phase residuals
-template <class S>
+// r_p = the same combination of the three (scaled) phase residuals.  CSM (coarse space of the pressure stage): 0 = none -- the first
+// pre-smoothing sweep of the V-cycle from a zero guess is fused here (one launch less); 1 / 2 = the restriction of r_p onto the one
+// unknown / the blocks of this rank is fused instead (per-workgroup partials, k_cs_place / k_cs_place_cr reduce them in a fixed order;
+// the coarse-space correction then writes the first sweep from the corrected residual)
+template <class S, int CSM>
 __global__ __launch_bounds__(kBlock) void k_cpr_sum_eqs(int nb, int nbp, const S* __restrict__ d, const S* __restrict__ w, S* __restrict__ bp, S omega,
-                                                        const S* __restrict__ dinv, S* __restrict__ x0, const SolveCtl* __restrict__ ctl)
+                                                        const S* __restrict__ dinv, S* __restrict__ x0, const SolveCtl* __restrict__ ctl,
+                                                        const int8_t* __restrict__ owned, const int8_t* __restrict__ blk, double* __restrict__ parts)
 {
+    __shared__ double sm[32];
     if (ctl && ctl->done) return;
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= nb) return;
-    const S b = w[i] * d[i] + w[nbp + i] * d[nbp + i] + w[2 * long(nbp) + i] * d[2 * long(nbp) + i];
-    bp[i] = b;
-    x0[i] = omega * dinv[i] * b;          // first pre-smoothing sweep of the V-cycle from a zero guess, fused (one launch less)
+    S b = S(0);
+    if (i < nb) {
+        b = w[i] * d[i] + w[nbp + i] * d[nbp + i] + w[2 * long(nbp) + i] * d[2 * long(nbp) + i];
+        bp[i] = b;
+        if (CSM == 0) x0[i] = omega * dinv[i] * b;
+    }
+    if (CSM == 1) {
+        double acc[1] = { (i < nb && (!owned || owned[i])) ? double(b) : 0.0 };
+        block_sum<1>(acc, sm);
+        if (threadIdx.x == 0) parts[blockIdx.x] = acc[0];
+    }
+    if (CSM == 2) {
+        const int bl = i < nb ? int(blk[i]) : -1;
+        double acc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] = (u == bl) ? double(b) : 0.0;
+        block_sum<8>(acc, sm);
+        if (threadIdx.x == 0) for (int u = 0; u < 8; ++u) parts[long(u) * gridDim.x + blockIdx.x] = acc[u];
+    }
 }
 // z = d - A [x_p; 0; 0]   (only the pressure column of every block is read: 1/3 of the matrix)
 template <class S>
@@ -1470,20 +1490,30 @@ template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, con
     SolverWork<S>& w = work<S>();
     AmgLevel<S>& L0 = *w.amg->levels[0];
     const int g = grid_for(plan.nb);
-    hipLaunchKernelGGL((k_cpr_sum_eqs<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, plan.nbp, d, (const S*)w.cprw.p, L0.b.p, S(w.amg->omega0()), (const S*)L0.dinv.p, L0.x.p, ctl);
     const bool coarse = coarse_nsub >= 1;
+    const bool fused_rsum = coarse && !(!comm && emulate_ranks > 1) && g <= kCsRowParts;       // real coarse space: restriction fused into the kernel below
+    double* const cs_parts = coarse ? cs_buf.p + size_t(2) * coarse_nsub * coarse_nsub + coarse_nsub : nullptr;   // own scratch (the BiCGStab partial arrays are live across an application)
+    if (!fused_rsum)
+        hipLaunchKernelGGL((k_cpr_sum_eqs<S, 0>), dim3(g), dim3(kBlock), 0, stream, plan.nb, plan.nbp, d, (const S*)w.cprw.p, L0.b.p, S(w.amg->omega0()), (const S*)L0.dinv.p, L0.x.p, ctl,
+                           (const int8_t*)nullptr, (const int8_t*)nullptr, (double*)nullptr);
+    else if (cs_m > 1)
+        hipLaunchKernelGGL((k_cpr_sum_eqs<S, 2>), dim3(g), dim3(kBlock), 0, stream, plan.nb, plan.nbp, d, (const S*)w.cprw.p, L0.b.p, S(w.amg->omega0()), (const S*)L0.dinv.p, L0.x.p, ctl,
+                           (const int8_t*)nullptr, (const int8_t*)cs_blk.p, cs_parts);
+    else
+        hipLaunchKernelGGL((k_cpr_sum_eqs<S, 1>), dim3(g), dim3(kBlock), 0, stream, plan.nb, plan.nbp, d, (const S*)w.cprw.p, L0.b.p, S(w.amg->omega0()), (const S*)L0.dinv.p, L0.x.p, ctl,
+                           comm ? comm->owner_mask() : (const int8_t*)nullptr, (const int8_t*)nullptr, cs_parts);
     if (coarse) {
         const int ns = coarse_nsub;
         double* inv = cs_buf.p + ns * ns; double* cr = inv + ns * ns;
         const bool emulated = !comm && emulate_ranks > 1;
         if (!emulated) {
-            const int gp = std::min(grid_for(plan.nb), kMaxPart);
-            double* parts = cs_buf.p + size_t(2) * ns * ns + ns;   // own scratch (the BiCGStab partial arrays are live across a preconditioner application)
+            const int gp = fused_rsum ? g : std::min(grid_for(plan.nb), kMaxPart);
+            double* parts = cs_parts;
             if (cs_m > 1) {
-                hipLaunchKernelGGL((k_cs_rsum_blocks<S>), dim3(gp), dim3(kBlock), 0, stream, plan.nb, (const int8_t*)cs_blk.p, (const S*)L0.b.p, parts, ctl);
+                if (!fused_rsum) hipLaunchKernelGGL((k_cs_rsum_blocks<S>), dim3(gp), dim3(kBlock), 0, stream, plan.nb, (const int8_t*)cs_blk.p, (const S*)L0.b.p, parts, ctl);
                 hipLaunchKernelGGL(k_cs_place_cr, dim3(1), dim3(kBlock), 0, stream, gp, (const double*)parts, ns, cs_m, comm ? comm->my_rank() : 0, cr, ctl);
             } else {
-                hipLaunchKernelGGL((k_cs_rsum<S>), dim3(gp), dim3(kBlock), 0, stream, plan.nb, comm ? comm->owner_mask() : (const int8_t*)nullptr, (const S*)L0.b.p, parts, ctl);
+                if (!fused_rsum) hipLaunchKernelGGL((k_cs_rsum<S>), dim3(gp), dim3(kBlock), 0, stream, plan.nb, comm ? comm->owner_mask() : (const int8_t*)nullptr, (const S*)L0.b.p, parts, ctl);
                 hipLaunchKernelGGL(k_cs_place, dim3(1), dim3(kBlock), 0, stream, gp, (const double*)parts, ns, comm ? comm->my_rank() : 0, cr, ctl);
             }
             if (comm) comm->allreduce_sum(cr, ns, stream);
