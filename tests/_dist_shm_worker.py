@@ -16,7 +16,11 @@ from opmgpu.model import GpuBlackoilModel  # noqa: E402
 
 
 def deck(cfg):
-    grid = decks.cartesian_grid(cfg["nx"], cfg["ny"], cfg["nz"], lognormal_sigma=cfg["sigma"], seed=cfg["seed"])
+    kw = {}
+    if cfg.get("unstructured"):          # inactive cells + non-neighbour connections: index-range partition, ranks with several neighbours
+        kw["actnum"] = np.random.default_rng(cfg["seed"]).random(cfg["nx"] * cfg["ny"] * cfg["nz"]) > 0.3
+        kw["nnc_fraction"] = 0.05
+    grid = decks.cartesian_grid(cfg["nx"], cfg["ny"], cfg["nz"], lognormal_sigma=cfg["sigma"], seed=cfg["seed"], **kw)
     tab = decks.satfunc_standard_tables()
     st = decks.initial_state(grid, tab, perturb=cfg["perturb"], seed=cfg["seed"])
     return grid, tab, st
@@ -42,7 +46,7 @@ def run(cfg, rank, world, uid, out):
         model, lst = GpuBlackoilModel(grid, tab, prm), st
         owned_global = np.arange(grid.nc)
     else:
-        part = partition.slab_partition(grid, world)
+        part = partition.slab_partition(grid, world, axis=cfg.get("axis", 2))
         dom = partition.LocalDomain(grid, part, rank)
         model = GpuBlackoilModel(dom.grid, tab, prm)
         partition.attach_comm(model, dom, rank, world, uid)

@@ -65,6 +65,9 @@ CASES = {
     "ilu0": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=1500), wells=False, single=False),
     "ilu0_natural_order": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=1500, ilu_ordering=0), wells=False, single=False),
     "cpr": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=500, use_cpr=1), wells=False, single=False),
+    # inactive cells + non-neighbour connections: contiguous index ranges as subdomains, ranks with more than two neighbours
+    "cpr_unstructured": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=800, use_cpr=1), wells=False, single=False, unstructured=True),
+    "ilu0_j_slabs": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=1500), wells=False, single=False, axis=1),
     "cpr_wells": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=500, use_cpr=1), wells=True, single=False),
     "cpr_f32_default_tolerance": dict(params=dict(use_cpr=1), wells=False, single=True),
     # a 30-day report step through the adaptive sub-stepping loop, first sub-step too long for 3 Newton iterations: chopped and redone
