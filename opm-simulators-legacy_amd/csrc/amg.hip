@@ -362,7 +362,7 @@ void AmgHierarchy<S>::setup(const Plan& P, const int32_t* d_slice_ptr, const int
 {
     levels.clear(); level_sizes.clear(); coarse_dev.clear();
     if (const char* e = std::getenv("OPMGPU_AMG_OMEGA")) omega = std::atof(e);
-    if (const char* e = std::getenv("OPMGPU_AMG_PDAMP")) pdamp = std::atof(e);
+    if (const char* e = std::getenv("OPMGPU_AMG_PDAMP")) { pdamp = std::atof(e); pdamp_user = true; }
     if (const char* e = std::getenv("OPMGPU_AMG_NPRE")) npre = std::atoi(e);
     if (const char* e = std::getenv("OPMGPU_AMG_NPOST")) npost = std::atoi(e);
     if (const char* e = std::getenv("OPMGPU_AMG_FUSE")) fuse = std::atoi(e) != 0;

@@ -69,7 +69,8 @@ public:
     // plain-aggregation correction is too small by a factor ~2 (dune-istl scales it by 1.6 for the same reason); 1.9 / 0.9 / 1+2
     // sweeps was the best setting that helped on both decks (-19 % and -7 % time per Newton iteration).  Env OPMGPU_AMG_* override.
     double omega = 0.9;           // damped-Jacobi weight
-    double pdamp = 1.9;           // coarse-grid correction scaling (dune-istl's prolongation damping factor)
+    double pdamp = 1.9;           // coarse-grid correction scaling (dune-istl's prolongation damping factor); see LinSolver::cpr_prepare for 2.2
+    bool pdamp_user = false;      // OPMGPU_AMG_PDAMP given: no automatic choice
     int npre = 1, npost = 2;      // smoothing sweeps before / after the coarse-grid correction
     int npost0 = 2;               // post-smoothing sweeps on level 0 (cheap per sweep there; coarse levels are launch-latency bound)
     int coarse_sweeps = 4;        // pairs of Jacobi sweeps standing in for the coarsest solve when it is too big for the dense inverse

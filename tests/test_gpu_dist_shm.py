@@ -93,6 +93,9 @@ def test_decomposed_runs_walk_the_single_domain_newton_path(gpu_lib, case):
                 assert np.array_equal(got[3], ref[3]), (case, world, got[3].tolist(), ref[3].tolist())      # same sub-steps, same failures
                 assert (ref[3][:, 1] == 0).any()                                                              # (there was a chopped one)
             assert np.array_equal(got[2], ref[2]), (case, world)
-            assert np.abs(got[0] - ref[0]).max() <= 1e-6 * np.abs(ref[0]).max(), (case, world)
-            assert np.abs(got[1] - ref[1]).max() <= 1e-6, (case, world)
+            # one Newton step: 1e-6; a whole report step (a dozen Newton iterations, each solved to 1e-10 in the RESIDUAL of a system
+            # with a condition number of 1e5-1e6, over several sub-steps) accumulates the solves' errors: 1e-4
+            tol = 1e-4 if "ats" in c else 1e-6
+            assert np.abs(got[0] - ref[0]).max() <= tol * np.abs(ref[0]).max(), (case, world)
+            assert np.abs(got[1] - ref[1]).max() <= tol, (case, world)
             assert np.array_equal(got[3][:, 0], ref[3][:, 0]), (case, world)      # same convergence decisions

@@ -158,7 +158,9 @@ def test_spe10_like_heterogeneity(gpu_lib, oracle):
     tab = decks.satfunc_standard_tables()
     st = decks.initial_state(grid, tab, p_ref=413.0 * decks.BAR, z_ref=3657.6, perturb=0.005, seed=10)
     for cpr in (0, 1):
-        prm = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=1500, use_cpr=cpr)
+        # four orders of magnitude of contrast: the error of a solve is cond(A) x its residual reduction, and which side of the 1e-6
+        # state tolerance a 1e-11 reduction lands on depends on the Krylov path (measured 0.9e-6 .. 1.1e-6) -- hence 1e-12
+        prm = capi.default_params(linear_solver_reduction=1e-12, linear_solver_maxiter=1500, use_cpr=cpr)
         _newton_parity(gpu_lib, oracle, grid, tab, st, 2 * decks.DAY, prm)
 
 
