@@ -362,7 +362,8 @@ void AmgHierarchy<S>::setup(const Plan& P, const int32_t* d_slice_ptr, const int
 {
     levels.clear(); level_sizes.clear(); coarse_dev.clear();
     if (const char* e = std::getenv("OPMGPU_AMG_OMEGA")) omega = std::atof(e);
-    if (const char* e = std::getenv("OPMGPU_AMG_PDAMP")) { pdamp = std::atof(e); pdamp_user = true; }
+    if (const char* e = std::getenv("OPMGPU_AMG_PDAMP")) { pdamp = std::atof(e); pdamp0 = pdamp; pdamp_user = true; }
+    if (const char* e = std::getenv("OPMGPU_AMG_PDAMP0")) { pdamp0 = std::atof(e); pdamp_user = true; }
     if (const char* e = std::getenv("OPMGPU_AMG_NPRE")) npre = std::atoi(e);
     if (const char* e = std::getenv("OPMGPU_AMG_NPOST")) npost = std::atoi(e);
     if (const char* e = std::getenv("OPMGPU_AMG_FUSE")) fuse = std::atoi(e) != 0;
@@ -528,6 +529,7 @@ void AmgHierarchy<S>::vcycle(const SolveCtl* ctl, bool level0_presmoothed)
         const int g = grid_for(F.n);
         int done_sweeps = 0;
         const int npost = l == 0 ? this->npost0 : this->npost;
+        const double pdamp = l == 0 ? this->pdamp0 : this->pdamp;          // (shadows the member: the correction INTO level l)
         if (l == 0 && gs_level0()) {
             const int n0 = gs_n0;
             hipLaunchKernelGGL((k_amg_prolong<S>), dim3(g), dim3(kBlock), 0, stream, F.n, F.agg.p, C.x.p, F.x.p, S(pdamp), ctl);

@@ -70,6 +70,7 @@ public:
     // sweeps was the best setting that helped on both decks (-19 % and -7 % time per Newton iteration).  Env OPMGPU_AMG_* override.
     double omega = 0.9;           // damped-Jacobi weight
     double pdamp = 1.9;           // coarse-grid correction scaling (dune-istl's prolongation damping factor); see LinSolver::cpr_prepare for 2.2
+    double pdamp0 = 1.9;          // ... of the correction into level 0 (OPMGPU_AMG_PDAMP0)
     bool pdamp_user = false;      // OPMGPU_AMG_PDAMP given: no automatic choice
     int npre = 1, npost = 2;      // smoothing sweeps before / after the coarse-grid correction
     int npost0 = 2;               // post-smoothing sweeps on level 0 (cheap per sweep there; coarse levels are launch-latency bound)

@@ -1419,11 +1419,12 @@ template <class S> void LinSolver::cpr_prepare()
     const bool single_ok = coarse_mode == 2 || (coarse_single_ok && lowrank.nw == 0);
     coarse_nsub = coarse_mode != 0 && (nsub >= 2 || single_ok) ? nsub : 0;
     if (coarse_nsub > 64) coarse_nsub = 0;        // table sizes of the kernels
-    // Scaling of the coarse-grid corrections: 1.9 in general; 2.2 when ONE subdomain carries the coarse space (one GPU, no wells) -- the
-    // global constant is then removed exactly for the whole domain and the hierarchy is global, and the larger factor measured -6 %
-    // (100^3) / -10 % (200^3) time per Newton iteration, 0 % on the sigma = 2 deck.  Not with wells (3.7 -> 4.4 iterations on the
-    // 5-spot deck) and not decomposed (emulated 8 ranks: 4.8 -> 5.6; real 4 ranks: unchanged).
-    if (!w.amg->pdamp_user) w.amg->pdamp = (coarse_nsub == 1 && lowrank.nw == 0) ? 2.2 : 1.9;
+    // Scaling of the coarse-grid corrections: 1.9 in general; the correction into level 0 by 2.2 when ONE subdomain carries the coarse
+    // space (one GPU, no wells) -- the global constant is then removed exactly for the whole domain and the hierarchy is global:
+    // measured +4 % (100^3), +9 % (200^3), +7 % (300^3) throughput, 0 % on the sigma = 2 deck (2.2 on every level: better at 100^3 /
+    // 200^3, -15 % at 300^3).  Not with wells (3.7 -> 4.4 iterations on the 5-spot deck) and not decomposed (emulated 8 ranks: 4.8 ->
+    // 5.6; real 4 ranks: unchanged).
+    if (!w.amg->pdamp_user) { w.amg->pdamp0 = (coarse_nsub == 1 && lowrank.nw == 0) ? 2.2 : 1.9; w.amg->pdamp = 1.9; }
     const bool emulated = !comm && emulate_ranks > 1;
     if (w.amg->ready() && !emulated) {
         // the usual case: one pass over the matrix does weights + pressure matrix (+ coarse-space row parts)
