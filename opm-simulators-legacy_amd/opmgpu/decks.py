@@ -269,7 +269,10 @@ def cartesian_grid(nx, ny, nz, dx=10.0, dy=10.0, dz=2.0, tops=2000.0, poro=0.2, 
     th = None
     if thpres is not None:
         th = np.full(conn.shape[0], float(thpres))
-    return GridData(n, conn, trans, pv, zc, thpres=th, dims=(nx, ny, nz))
+    g = GridData(n, conn, trans, pv, zc, thpres=th, dims=(nx, ny, nz))
+    # Cartesian (global) index -> active cell index, -1 for inactive cells (opm-grid's global_cell, inverted)
+    g.active_index = np.arange(nx * ny * nz) if actnum is None else newid
+    return g
 
 
 # ------------------------------------------------------------------------------------------

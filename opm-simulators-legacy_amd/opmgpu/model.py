@@ -271,6 +271,13 @@ class GpuBlackoilModel:
         self._chk(self.lib.opmgpu_get_jacobian_bsr(self.ctx, capi.iptr(rowptr), capi.iptr(col), capi.dptr(val)))
         return rowptr, col, val
 
+    def spmv(self, x3):
+        """y = J x with the assembled system (block-interleaved [nc][3]); with device wells J includes their factored
+        Schur complement (the rank-7 operator per well), i.e. the operator the linear solver sees."""
+        y = np.zeros(3 * self.nc)
+        self._chk(self.lib.opmgpu_spmv(self.ctx, capi.dptr(capi.f64(x3)), capi.dptr(y)))
+        return y
+
     def perfProps(self, nperf):
         out = np.zeros((nperf, capi.PERF_K))
         self._chk(self.lib.opmgpu_perf_props(self.ctx, capi.dptr(out)))

@@ -419,3 +419,35 @@ def five_spot(grid, rate_m3_per_day=500.0, bhp_prod_bar=150.0, wi=None):
     for k, (i, j) in enumerate([(0, 0), (nx - 1, 0), (0, ny - 1), (nx - 1, ny - 1)]):
         wells.add_well("PROD%d" % k, PRODUCER, z[col(i, j)[0]], col(i, j), WI, (0.0, 1.0, 0.0), (BHP, bhp_prod_bar * 1e5))
     return wells
+
+
+def column_wells(grid, n_wells, n_injectors=1, seed=0, inj_layers=None, prod_layers=None, inj_rate_m3_per_day=800.0,
+                 prod_bhp_bar=150.0, prod_oil_rate_m3_per_day=None, wi=None):
+    """Vertical wells in distinct random (i, j) columns of a Cartesian deck with inactive cells (SPE9-like: 1 rate-controlled water
+    injector + 25 producers; Norne-like: 36 wells through whatever is active in their column).  A well perforates the ACTIVE cells of
+    its column inside the layer range; columns without an active cell there are skipped.  Producers alternate between BHP control and
+    (if `prod_oil_rate_m3_per_day` is given) oil SURFACE_RATE control, so both control equations occur."""
+    nx, ny, nz = grid.dims
+    act = np.asarray(grid.active_index)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    WI = wi if wi is not None else 10.0 * float(np.median(grid.trans))
+    wells = Wells()
+    for colidx in rng.permutation(nx * ny):
+        if wells.nw == n_wells:
+            break
+        w = wells.nw
+        inj = w < n_injectors
+        layers = (inj_layers if inj else prod_layers) or range(nz)
+        cells = [int(act[colidx + nx * ny * k]) for k in layers if act[colidx + nx * ny * k] >= 0]
+        if not cells:
+            continue
+        zref = grid.z[cells[0]]
+        if inj:
+            wells.add_well("INJ%d" % w, INJECTOR, zref, cells, WI, (1.0, 0.0, 0.0), (SURFACE_RATE, inj_rate_m3_per_day / 86400.0, (1.0, 0.0, 0.0)))
+        elif prod_oil_rate_m3_per_day is not None and w % 2 == 0:
+            wells.add_well("PROD%d" % w, PRODUCER, zref, cells, WI, (0.0, 1.0, 0.0), (SURFACE_RATE, -prod_oil_rate_m3_per_day / 86400.0, (0.0, 1.0, 0.0)))
+        else:
+            wells.add_well("PROD%d" % w, PRODUCER, zref, cells, WI, (0.0, 1.0, 0.0), (BHP, prod_bhp_bar * 1e5))
+    if wells.nw < n_wells:
+        raise ValueError("not enough columns with active cells for %d wells" % n_wells)
+    return wells

@@ -1,5 +1,9 @@
-"""BASELINE.json configurations at FULL size on the GPU, checked through size-independent properties
-(the oracle is too slow to be the checker at 1 M cells), plus the SPE9-like case against the oracle."""
+"""BASELINE.json configurations at FULL size on the GPU against the oracle (which assembles a 1 M-cell system in about a second
+and solves it in seconds, so it IS the checker at these sizes): residual, Jacobian / coupled operator, convergence scalars and the
+post-update reservoir + well state of the first Newton iterations, then the Newton iteration count of a whole time step at the
+reference's default tolerances.  Decks: 100x100x100 with the 5-spot (device wells), 60x220x85 with sigma_lnK = 2.5 and a 5-spot,
+46x112x22 with 60 % inactive cells + NNCs + threshold pressures + 36 wells, 24x25x15 with 26 wells.  The size-independent
+property checks and the small -like cases of round 1 stay below them."""
 import numpy as np
 import pytest
 
@@ -177,3 +181,195 @@ def test_norne_like_unstructured(gpu_lib, oracle):
     for cpr in (0, 1):
         prm = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=1500, use_cpr=cpr)
         _newton_parity(gpu_lib, oracle, grid, tab, st, 3 * decks.DAY, prm)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# full-size oracle parity
+# ------------------------------------------------------------------------------------------------------------------------
+def _perforated_diag_mask(rowptr, col, cells):
+    """blocks (c, c) of the perforated cells: the only Jacobian entries the device well model changes in the matrix itself"""
+    nb = rowptr.size - 1
+    rows = np.repeat(np.arange(nb, dtype=np.int64), np.diff(rowptr))
+    perf = np.zeros(nb, bool); perf[np.asarray(cells, int)] = True
+    return (rows == col) & perf[rows]
+
+
+def _lockstep_parity(gpu_lib, oracle, grid, tab, st, dt, wl, niter=2, cpr=1, reduction=1e-10, maxiter=2000, tol_p=1e-6, tol_s=1e-6):
+    """Newton iterations 0..niter-1 of one time step, GPU (device wells, CPR or ILU0, f64 solve) and oracle (+ host well model with
+    the explicit Schur complement) side by side.  Every assembly is compared at rounding level; after every update the two states are
+    compared at the linear tolerance and the oracle then CONTINUES FROM THE GPU's state, so the next assembly is again a rounding-level
+    comparison (a free-running comparison is test_*_newton_count below)."""
+    from opmgpu import wells as W
+    from util import OracleBackend, rel_err
+    oracle.set_threads(16)
+    prm_g = capi.default_params(linear_solver_reduction=reduction, linear_solver_maxiter=maxiter, use_cpr=cpr)
+    prm_o = capi.default_params(linear_solver_reduction=reduction, linear_solver_maxiter=4 * maxiter)
+    nc = grid.nc
+    gm = GpuBlackoilModel(grid, tab, prm_g)
+    rowptr0, col0 = oracle.pattern(grid)
+    scale = np.asarray(prm_g.matbalscale[:])
+    if wl is not None:
+        md = W.DeviceWellModel(gm, wl, W.WellState(wl, st.p))
+        ob = OracleBackend(oracle, grid, tab, prm_o, wells=wl.arrays())
+        mo = W.WellCoupledModel(ob, W.StandardWellsHost(wl, grid.z, tab.surface_density[0]), W.WellState(wl, st.p))
+        diag_perf = _perforated_diag_mask(rowptr0, col0, wl.cells)
+    else:
+        md, ob = gm, OracleBackend(oracle, grid, tab, prm_o)
+        mo = ob
+    md.prepareStep(dt, st); mo.prepareStep(dt, st)
+    rng = np.random.default_rng(5)
+    for it in range(niter):
+        # ---- assembly ----
+        gm.setSolvePrecision(False)
+        gm.assemble(it == 0)
+        ob.assemble(it == 0)
+        r_res, val_res = ob.r.copy(), None
+        if wl is not None:
+            # reservoir-only oracle Jacobian on the stencil pattern: everything but the perforated cells' diagonal blocks must match it
+            _, val_res, _, _ = oracle.assemble(grid, tab, dt, ob.st, rowptr0, col0, scale=tuple(scale), accum0=ob.acc0)
+            pp = ob.perfProps(wl.nperf).reshape(wl.nperf, 9, 4)
+            if it == 0:
+                mo.wh.compute_connection_pressures(pp, mo.ws)
+            resid_delta, rc, blocks, rhs_delta = mo.wh.assemble(pp, mo.ws)
+            ob.addWellTerms(resid_delta, rc, blocks); ob.addWellRhs(rhs_delta)
+        gr, gc, gv = gm.jacobian()
+        assert np.array_equal(gr, rowptr0) and np.array_equal(gc, col0)
+        assert rel_err(gm.residual(), ob.r) < 1e-11, (it, rel_err(gm.residual(), ob.r))
+        if wl is None:
+            assert rel_err(gv, ob.val) < 1e-11, it
+        else:
+            keep = ~diag_perf
+            assert rel_err(gv[keep], val_res[keep]) < 1e-11, it
+            # the coupled operator (matrix + factored rank-7 Schur complement per well) against the oracle's explicit clique matrix
+            for _ in range(2):
+                x3 = rng.standard_normal(3 * nc) * np.tile([1e5, 1e-2, 1e-2], nc)
+                yo = oracle.spmv(ob.rowptr, ob.col, ob.val, x3)
+                yg = gm.spmv(x3)
+                assert rel_err(yg, yo) < 1e-9, (it, rel_err(yg, yo))
+        del gv, val_res
+        # ---- convergence scalars ----
+        cg = gm.getConvergence(); co = ob.getConvergence()
+        assert np.allclose(gm.CNV, ob.CNV, rtol=1e-9) and np.allclose(gm.MB, ob.MB, rtol=1e-7, atol=1e-18) and np.allclose(gm.B_avg, ob.B_avg, rtol=1e-12)
+        if wl is not None:
+            cg = md.wellConvergence() and cg; co = mo.wh.converged(ob.B_avg) and co
+            assert np.allclose(md.well_flux_residual, mo.wh.well_flux_residual, rtol=1e-7, atol=1e-14)
+            assert md.well_ctrl_residual == pytest.approx(mo.wh.well_ctrl_residual, rel=1e-7, abs=1e-14)
+        assert cg == co
+        # ---- solve + update ----
+        gm.solveJacobianSystem(single_precision=False)
+        gm.updateState()
+        ob.solveJacobianSystem(single_precision=False)
+        if wl is not None:
+            mo.wh.recover_and_update(ob.perfDx(wl.nperf), mo.ws)
+        ob.updateState()
+        a, b = gm.getState(), ob.getState()
+        assert np.array_equal(a.hc, b.hc), it
+        assert np.abs(a.p - b.p).max() <= tol_p * np.abs(b.p).max(), (it, np.abs(a.p - b.p).max() / np.abs(b.p).max())
+        assert np.abs(a.sat - b.sat).max() <= tol_s, (it, np.abs(a.sat - b.sat).max())
+        assert np.abs(a.rs - b.rs).max() <= 1e-5 * max(np.abs(b.rs).max(), 1.0) and np.abs(a.rv - b.rv).max() <= 1e-5 * max(np.abs(b.rv).max(), 1e-3)
+        ob.st = a.copy()                                 # lockstep: the oracle continues from the device state
+        if wl is not None:
+            ws = md.pull_well_state()
+            assert np.allclose(ws.bhp, mo.ws.bhp, rtol=1e-6), (it, ws.bhp, mo.ws.bhp)
+            assert np.allclose(ws.qs, mo.ws.qs, rtol=1e-5, atol=1e-8 * np.abs(mo.ws.qs).max()), it
+            mo.ws.assign(ws)
+    gm.close()
+
+
+def _run_time_step(model, backend, dt, st, single, max_iter=15):
+    """NonlinearSolver::step (NonlinearSolver_impl.hpp:119-174), plain Newton: returns the number of nonlinear iterations"""
+    model.prepareStep(dt, st)
+    it = 0
+    while True:
+        if model is backend and not hasattr(model, "nonlinearIteration"):        # bare oracle backend (no wells)
+            backend.assemble(it == 0)
+            conv = backend.getConvergence()
+            if not conv or it < 1:
+                backend.solveJacobianSystem(single_precision=single); backend.updateState()
+        else:
+            conv, _ = model.nonlinearIteration(it, single_precision=single)
+        it += 1
+        if (conv and it > 1) or it > max_iter:
+            return it
+
+
+def _check_newton_count(gpu_lib, oracle, grid, tab, st, dt, wl):
+    """One whole time step at the reference's DEFAULT tolerances (MB 1e-5, CNV 1e-2, linear reduction 1e-2, float solve for dt < 20 d)
+    free-running on both sides: the device (reference-default ILU0 and CPR) needs the same number of Newton iterations as the oracle
+    (natural-order ILU0 + BiCGStab like flow_legacy)."""
+    from opmgpu import wells as W
+    from util import OracleBackend
+    oracle.set_threads(16)
+    single = dt < 20 * decks.DAY
+    ob = OracleBackend(oracle, grid, tab, capi.default_params(), wells=None if wl is None else wl.arrays())
+    mo = ob if wl is None else W.WellCoupledModel(ob, W.StandardWellsHost(wl, grid.z, tab.surface_density[0]), W.WellState(wl, st.p))
+    n_oracle = _run_time_step(mo, ob, dt, st, single)
+    b = ob.getState()
+    for cpr in (0, 1):
+        gm = GpuBlackoilModel(grid, tab, capi.default_params(use_cpr=cpr))
+        md = gm if wl is None else W.DeviceWellModel(gm, wl, W.WellState(wl, st.p))
+        n_gpu = _run_time_step(md, gm, dt, st, single)
+        a = gm.getState()
+        gm.close()
+        assert n_gpu == n_oracle and n_gpu <= 15, (cpr, n_gpu, n_oracle)
+        # both are converged solutions of the same nonlinear system at the Newton tolerance (CNV 1e-2)
+        assert (a.hc != b.hc).mean() < 1e-3
+        assert np.abs(a.p - b.p).max() <= 1e-3 * np.abs(b.p).max() and np.abs(a.sat - b.sat).max() <= 2e-2
+
+
+def _cart100():
+    grid = decks.cartesian_grid(100, 100, 100, lognormal_sigma=0.5, seed=12345)
+    tab = decks.satfunc_standard_tables()
+    st = decks.initial_state(grid, tab, perturb=0.002, seed=12345)
+    from opmgpu import wells as W
+    return grid, tab, st, W.five_spot(grid, rate_m3_per_day=5000.0, bhp_prod_bar=150.0)
+
+
+def _spe10_like():
+    """SPE10 Model 2 dimensions and cell sizes (20 x 10 x 2 ft), channel-free lognormal permeability with sigma_lnK = 2.5 (the SPE10
+    permeability file is not available offline), 5-spot like the original: central water injector, four corner producers."""
+    grid = decks.cartesian_grid(60, 220, 85, dx=6.096, dy=3.048, dz=0.6096, tops=3657.6, lognormal_sigma=2.5, seed=10)
+    tab = decks.satfunc_standard_tables()
+    st = decks.initial_state(grid, tab, p_ref=413.0 * decks.BAR, z_ref=3657.6, perturb=0.002, seed=10)
+    from opmgpu import wells as W
+    return grid, tab, st, W.five_spot(grid, rate_m3_per_day=800.0, bhp_prod_bar=275.0)
+
+
+def _norne_like():
+    """Norne's Cartesian box 46 x 112 x 22 with 60 % of the cells inactive (~45 k active), fault-style NNCs (5 % extra connections),
+    threshold pressures, 36 wells (4 water injectors, producers on BHP or oil-rate control)."""
+    rng = np.random.default_rng(44)
+    act = rng.random(46 * 112 * 22) > 0.6
+    grid = decks.cartesian_grid(46, 112, 22, dx=80.0, dy=80.0, dz=4.0, tops=2500.0, actnum=act, nnc_fraction=0.05, lognormal_sigma=1.0, thpres=0.02 * decks.BAR, seed=44)
+    tab = decks.satfunc_standard_tables()
+    st = decks.initial_state(grid, tab, p_ref=270.0 * decks.BAR, z_ref=2500.0, perturb=0.005, seed=44)
+    from opmgpu import wells as W
+    return grid, tab, st, W.column_wells(grid, 36, n_injectors=4, seed=44, inj_rate_m3_per_day=300.0, prod_bhp_bar=200.0, prod_oil_rate_m3_per_day=40.0)
+
+
+def _spe9_like():
+    """SPE9 dimensions (24 x 25 x 15, 300 ft cells), 26 wells: one water injector completed in layers 11-15 and 25 producers in
+    layers 2-4 (half on BHP, half on oil-rate control)."""
+    grid = decks.cartesian_grid(24, 25, 15, dx=91.44, dy=91.44, dz=6.0, tops=2743.0, lognormal_sigma=1.0, seed=9)
+    tab = decks.satfunc_standard_tables()
+    st = decks.initial_state(grid, tab, p_ref=248.0 * decks.BAR, z_ref=2743.0, perturb=0.005, seed=9)
+    from opmgpu import wells as W
+    return grid, tab, st, W.column_wells(grid, 26, n_injectors=1, seed=9, inj_layers=range(10, 15), prod_layers=range(1, 4),
+                                         inj_rate_m3_per_day=800.0, prod_bhp_bar=150.0, prod_oil_rate_m3_per_day=60.0)
+
+
+DECKS = {"cart100": (_cart100, 5.0), "spe10like": (_spe10_like, 2.0), "nornelike": (_norne_like, 3.0), "spe9like": (_spe9_like, 10.0)}
+
+
+@pytest.mark.parametrize("name", list(DECKS))
+def test_fullsize_lockstep_parity(gpu_lib, oracle, name):
+    make, dt_days = DECKS[name]
+    grid, tab, st, wl = make()
+    _lockstep_parity(gpu_lib, oracle, grid, tab, st, dt_days * decks.DAY, wl)
+
+
+@pytest.mark.parametrize("name", list(DECKS))
+def test_fullsize_newton_count(gpu_lib, oracle, name):
+    make, dt_days = DECKS[name]
+    grid, tab, st, wl = make()
+    _check_newton_count(gpu_lib, oracle, grid, tab, st, dt_days * decks.DAY, wl)
