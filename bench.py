@@ -1,17 +1,18 @@
 #!/usr/bin/env python3
-"""bench.py -- Mcell-updates/s per Newton step (assembly + solve) on MI355X, with the SpMV roofline
-and the CPU baseline timed beside it.
+"""bench.py -- Mcell-updates/s per Newton step (assembly + solve) on MI355X, with the SpMV roofline, a per-kernel table and the
+CPU baseline timed beside it.
 
-A "step" is one Newton iteration of the fully-implicit black-oil model on the synthetic
-100x100x100 three-phase deck (BASELINE.json configs[2], the configuration the metric is quoted
-on): assemble -> getConvergence -> solveJacobianSystem (block-ILU0 + BiCGStab, float because
-dt < 20 d exactly as the reference switches) -> updateState, state resident in HBM.  Time steps
-follow each other like in the simulator: when a step converges the next one starts from the
-updated state with a fresh accum0.
+Workload (BASELINE.json configs[2]): the synthetic 100x100x100 three-phase deck WITH its 5-spot (one rate-controlled water
+injector + four BHP producers, full columns, device well model incl. control switching and the explicit well pre-solve).  A "step" is
+one Newton iteration of the fully-implicit black-oil model: assemble (reservoir + wells) -> getConvergence -> solveJacobianSystem
+(CPR: AMG V-cycle on the pressure system + block-ILU0, BiCGStab; float because dt < 20 d exactly as the reference switches) ->
+updateState, state resident in HBM.  Time steps follow each other like in the simulator (NonlinearSolver with the reference's update
+stabilisation); the synthetic initial state is far from equilibrium, so two time steps pass before anything is timed (deck set-up).
 
     python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -25,9 +26,27 @@ for p in (os.path.join(ROOT, "opm-simulators-legacy_amd"), ROOT):
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
 
 
-def spmv_bytes(nb, nnzb, scalar_bytes):
+def spmv_bytes(nb, nnzb, S):
     """nnzb*(9*S + 4) + (nb+1)*4 + nb*3*S (x read once) + nb*3*S (y write)."""
-    return nnzb * (9 * scalar_bytes + 4) + (nb + 1) * 4 + 2 * nb * 3 * scalar_bytes
+    return nnzb * (9 * S + 4) + (nb + 1) * 4 + 2 * nb * 3 * S
+
+
+def algorithmic_bytes(nb, nnzb, nconn, S, n_scalar_nnz):
+    """algorithmic HBM bytes per launch (group) of every kernel class the in-situ timers bracket.
+    S = scalar size of the matrix / solver vectors (4: float solve, 8: double)."""
+    per_cell_asm = 41 + 24 + 24 + (nconn / nb) * 16 + 24          # SURVEY 8d: state, statics, accum0, connection data, residual
+    return {
+        # SURVEY 8d counts the assembly as ONE pass (state in, Jacobian out); the two kernels also exchange the 37 face-input
+        # planes (80 + 27 S bytes per cell written by cell_props, read by flux): listed as `exchange_bytes`
+        "assembly(cell_props+flux)": nb * per_cell_asm + nnzb * 9 * S,
+        "cell_props": nb * (49 + 16 + 24 + 24 + 24 + 9 * S + 80 + 27 * S),
+        "flux": nb * (8 + 24 + 24 + 9 * S + 3 * S + 80 + 27 * S) + nnzb * (8 + 9 * S) + 2 * nconn * 16,
+        "spmv_fused_dot1": spmv_bytes(nb, nnzb, S) + nb * 3 * S, "spmv_fused_dot2": spmv_bytes(nb, nnzb, S) + nb * 3 * S,
+        "ilu0_apply": nnzb * (9 * S + 4) + nb * 3 * S * 3,
+        "ilu0_factor": 2 * nnzb * 9 * S + nnzb * 4,
+        "amg_vcycle": int(1.14 * 4 * n_scalar_nnz * (S + 4)),       # level 0: residual + 1 pre + 2 post sweeps over the scalar matrix; coarser levels add ~14 %
+        "vector_updates": None, "cpr_other": None, "cpr_setup": None, "wells": None, "convergence": nb * 7 * 8, "update_state": nb * (3 * 8 + 2 * 49),
+    }
 
 
 def main():
@@ -44,9 +63,12 @@ def main():
                     help="cpr: AMG pressure stage + ILU0 (reference solver_approach=cpr); ilu0: reference default solver_approach=interleaved")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N > 1: weak = every GPU keeps an nx x ny x nz slab (global deck nx x ny x nz*N, sized for 288 GB/GPU); strong = the fixed nx x ny x nz deck is cut into N slabs")
-    ap.add_argument("--wells", choices=["none", "fivespot"], default="none",
-                    help="fivespot: SURVEY 8d synthetic wells (1 rate-controlled water injector + 4 BHP producers, full columns) with the device well model; single GPU only")
-    ap.add_argument("--only-main", action="store_true", help="skip the same-run ILU0 / 5-spot variants and the roofline micro-runs (profiling)")
+    ap.add_argument("--deck", choices=["cart", "spe10like"], default="cart", help="spe10like: 60 x 220 x 85 cells, sigma_lnK = 2.5 (BASELINE configs[3]); implies its own dimensions")
+    ap.add_argument("--wells", choices=["none", "fivespot"], default="fivespot",
+                    help="fivespot (default, SURVEY 8d): 1 rate-controlled water injector + 4 BHP producers, full columns, device well model; single GPU only")
+    ap.add_argument("--rate", type=float, default=1000.0, help="injection rate of the 5-spot, m3/day")
+    ap.add_argument("--spin-up", type=int, default=2, help="time steps that pass before the measurement (deck set-up, untimed)")
+    ap.add_argument("--only-main", action="store_true", help="skip the same-run variants, the roofline micro-runs and the per-kernel pass (profiling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="take the domain-decomposition code path (torch.distributed + RCCL communicator) even with one rank")
     ap.add_argument("--cpu-threads", type=int, default=1)
@@ -55,8 +77,8 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from opmgpu import capi, decks
-    from opmgpu.model import GpuBlackoilModel, GpuNewtonIteration
+    from opmgpu import capi, decks, wells as W
+    from opmgpu.model import GpuBlackoilModel, GpuNewtonIteration, NonlinearSolver
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -65,7 +87,7 @@ def main():
         raise SystemExit("--gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    # rehearsal on ONE GPU (OPMGPU_COMM_TRANSPORT=shm): every rank on cuda:0, the library's shared-memory test transport instead of
+    # rehearsal on ONE GPU (OPMGPU_COMM_TRANSPORT=shm): every rank on cuda:0, the test library's shared-memory transport instead of
     # RCCL and a gloo group for the barrier -- runs the N > 1 code path of this script where no multi-GPU node is available
     rehearsal = os.environ.get("OPMGPU_COMM_TRANSPORT") == "shm"
     if rehearsal:
@@ -79,19 +101,33 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    if args.deck == "spe10like":
+        args.nx, args.ny, args.nz = 60, 220, 85
     ordering = capi.ORDER_MULTICOLOR if args.ordering == "multicolor" else capi.ORDER_NATURAL
     prm = capi.default_params(ilu_ordering=ordering, use_cpr=int(args.solver == "cpr"))
     tab = decks.satfunc_standard_tables()
     dt = args.dt_days * decks.DAY
     single = dt < 20 * decks.DAY            # BlackoilModelBase_impl.hpp:284
+    use_wells = args.wells == "fivespot" and not use_dist      # multi-GPU: the scaling legs run the well-free deck (wells live on one rank)
+
+    def make_deck():
+        if args.deck == "spe10like":
+            g = decks.cartesian_grid(60, 220, 85, dx=6.096, dy=3.048, dz=0.6096, tops=3657.6, lognormal_sigma=2.5, seed=10)
+            s = decks.initial_state(g, tab, p_ref=413.0 * decks.BAR, z_ref=3657.6, perturb=1e-4, seed=10, gas_cap_fraction=0.0, gas_only_fraction=0.0)
+            return g, s, (200.0, 380.0)
+        g = decks.cartesian_grid(args.nx, args.ny, args.nz, lognormal_sigma=0.5, seed=12345)
+        return g, decks.initial_state(g, tab, perturb=0.002, seed=12345), (args.rate, 150.0)
 
     if use_dist:
         from opmgpu import partition
         nz_global = args.nz * world if args.scaling == "weak" else args.nz
-        model, grid, st, info = partition.build_distributed_model(args.nx, args.ny, nz_global, tab, prm, rank, world, local_rank)
+        if args.deck == "spe10like":
+            model, grid, st, info = partition.build_distributed_model(60, 220, 85, tab, prm, rank, world, local_rank, deck="spe10like")
+        else:
+            model, grid, st, info = partition.build_distributed_model(args.nx, args.ny, nz_global, tab, prm, rank, world, local_rank)
+        well_spec = None
     else:
-        grid = decks.cartesian_grid(args.nx, args.ny, args.nz, lognormal_sigma=0.5, seed=12345)
-        st = decks.initial_state(grid, tab, perturb=0.002, seed=12345)
+        grid, st, well_spec = make_deck()
         model = GpuBlackoilModel(grid, tab, prm, device=local_rank)
         info = {"n_owned": grid.nc, "n_global": grid.nc}
     nc_global = info["n_global"]
@@ -101,138 +137,179 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def with_wells(model, which):
-        if which == "none" or use_dist:
-            return model
-        from opmgpu import wells as W
-        wl = W.five_spot(grid, rate_m3_per_day=5000.0, bhp_prod_bar=150.0)
-        return W.DeviceWellModel(model, wl, W.WellState(wl, st.p))
+    def make_wells():
+        return W.five_spot(grid, rate_m3_per_day=well_spec[0], bhp_prod_bar=well_spec[1])
 
-    sample_phases = os.environ.get("OPMGPU_BENCH_NO_PHASES") is None      # (A/B: what reading the phase events every iteration costs)
+    def with_wells(core, on):
+        if not on:
+            return core
+        wl = make_wells()
+        return W.DeviceWellModel(core, wl, W.WellState(wl, st.p))
 
-    def timed_run(model, wells=None):
-        """exactly K timed Newton iterations after W warm-up ones; time steps follow each other like in the simulator"""
-        core = model
-        model = with_wells(model, wells if wells is not None else args.wells)
-        model.prepareStep(dt, st)
-        it, lin_total, steps_done = 0, 0, 0
-        t_asm = t_sol = t_upd = 0.0
-        t0 = None
-        for step in range(args.warmup + args.steps):
-            if step == args.warmup:
-                barrier()
-                t0 = time.perf_counter()
-                lin_total = 0
-                t_asm = t_sol = t_upd = 0.0
-            converged, lin = model.nonlinearIteration(it)
-            if sample_phases:
-                a, s, u = core.timings()
-                t_asm += a; t_sol += s; t_upd += u
-            lin_total += lin
+    ns = NonlinearSolver()                  # reference defaults: max_iter 10, min_iter 1, dampening on detected oscillation
+
+    def newton_iterations(model, n, state):
+        """n Newton iterations; time steps follow each other like in the simulator.  A step that has not converged after the
+        reference's max_iter is restarted from the current state (the reference would cut dt; the metric is per Newton iteration)."""
+        it, lin, steps_done, failed = state["it"], 0, 0, 0
+        for _ in range(n):
+            converged, l = model.nonlinearIteration(it, single_precision=single, nonlinear_solver=ns)
+            lin += l
             it += 1
-            if (converged and it >= 1) or it > 10:
+            if (converged and it > ns.min_iter) or it > ns.max_iter:
+                failed += int(not converged)
                 model.prepareStep(dt)           # next time step from the resident state
                 it = 0
                 steps_done += 1
+        state["it"] = it
+        return lin, steps_done, failed
+
+    def timed_run(core, wells_on, kernel_table=False):
+        """deck set-up (spin-up time steps) -> W warm-up Newton iterations -> barrier -> exactly K timed Newton iterations -> barrier"""
+        model = with_wells(core, wells_on)
+        model.prepareStep(dt, st)
+        state = {"it": 0}
+        done = 0
+        while done < args.spin_up:              # set-up: let the synthetic initial state relax for `spin_up` time steps
+            _, d, _ = newton_iterations(model, 1, state)
+            done += d
+        newton_iterations(model, args.warmup, state)
+        barrier()
+        t0 = time.perf_counter()
+        t_asm = t_sol = t_upd = 0.0
+        lin_total = steps_done = failed = 0
+        for _ in range(args.steps):
+            l, d, f = newton_iterations(model, 1, state)
+            lin_total += l; steps_done += d; failed += f
+            a, s, u = core.timings()
+            t_asm += a; t_sol += s; t_upd += u
         barrier()
         elapsed = time.perf_counter() - t0
         if use_dist:
             tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
-        return {"elapsed": elapsed, "lin": lin_total / args.steps, "steps_done": steps_done,
-                "breakdown": {"assemble": t_asm / args.steps, "linear_solve": t_sol / args.steps, "update": t_upd / args.steps}}
+        out = {"elapsed": elapsed, "lin": lin_total / args.steps, "steps_done": steps_done, "steps_not_converged": failed,
+               "breakdown": {"assemble": t_asm / args.steps, "linear_solve": t_sol / args.steps, "update": t_upd / args.steps}}
+        if kernel_table:
+            # per-kernel pass: the NEXT K Newton iterations of the same run with the in-situ event brackets on (not part of `value`)
+            core._chk(core.lib.opmgpu_kernel_timing(core.ctx, 1))
+            newton_iterations(model, args.steps, state)
+            tot, cnt = np.zeros(len(capi.KT_NAMES)), np.zeros(len(capi.KT_NAMES), np.int64)
+            core._chk(core.lib.opmgpu_kernel_timing_get(core.ctx, capi.dptr(tot), cnt.ctypes.data_as(C.POINTER(C.c_int64))))
+            core._chk(core.lib.opmgpu_kernel_timing(core.ctx, 0))
+            out["kt"] = (tot, cnt)
+        return out
 
-    # ---- timed region: exactly K Newton iterations ----
-    res = timed_run(model)
-    elapsed, steps_done = res["elapsed"], res["steps_done"]
-    ms_per_step = 1e3 * elapsed / args.steps
-    value = nc_global / (elapsed / args.steps) / 1e6
-    # the same K iterations with the reference's DEFAULT linear solver (solver_approach=interleaved: ILU0 + BiCGStab),
-    # which is also what the CPU baseline runs
-    ilu0 = None
-    if not use_dist and prm.use_cpr and not args.only_main:
-        prm0 = capi.default_params(ilu_ordering=ordering, use_cpr=0)
-        m0 = GpuBlackoilModel(grid, tab, prm0, device=local_rank)
-        r0 = timed_run(m0)
-        m0.close()
-        ilu0 = {"value": nc_global / (r0["elapsed"] / args.steps) / 1e6, "ms_per_step": 1e3 * r0["elapsed"] / args.steps,
-                "linear_iterations_per_newton": r0["lin"], "breakdown_ms_per_step": r0["breakdown"]}
+    def summary(r):
+        return {"value": nc_global / (r["elapsed"] / args.steps) / 1e6, "ms_per_step": 1e3 * r["elapsed"] / args.steps,
+                "linear_iterations_per_newton": r["lin"], "time_steps_completed": r["steps_done"], "time_steps_not_converged": r["steps_not_converged"],
+                "breakdown_ms_per_step": r["breakdown"]}
 
-    # ... and with the SURVEY 8d 5-spot (device well model), unless that already is the main run
-    fivespot = None
-    if not use_dist and args.wells == "none" and not args.only_main:
-        m1 = GpuBlackoilModel(grid, tab, prm, device=local_rank)
-        r1 = timed_run(m1, wells="fivespot")
-        m1.close()
-        fivespot = {"value": nc_global / (r1["elapsed"] / args.steps) / 1e6, "ms_per_step": 1e3 * r1["elapsed"] / args.steps,
-                    "linear_iterations_per_newton": r1["lin"], "breakdown_ms_per_step": r1["breakdown"],
-                    "wells": "1 rate-controlled water injector + 4 BHP producers, %d perforations each, device well model" % args.nz}
+    # ---- timed region: exactly K Newton iterations of the headline workload ----
+    extras = rank == 0 and not use_dist and not args.only_main
+    res = timed_run(model, use_wells, kernel_table=extras)
+    ms_per_step = 1e3 * res["elapsed"] / args.steps
+    value = nc_global / (res["elapsed"] / args.steps) / 1e6
+
+    # same-run variants, equal weight: the reference-default linear solver (ILU0 + BiCGStab: what the CPU baseline runs), and the well-free deck
+    variants = {}
+    if extras:
+        if prm.use_cpr:
+            m0 = GpuBlackoilModel(grid, tab, capi.default_params(ilu_ordering=ordering, use_cpr=0), device=local_rank)
+            variants["reference_default_solver_ilu0" + ("_with_wells" if use_wells else "")] = summary(timed_run(m0, use_wells)); m0.close()
+        if use_wells:
+            m1 = GpuBlackoilModel(grid, tab, prm, device=local_rank)
+            variants["without_wells"] = summary(timed_run(m1, False)); m1.close()
 
     out = None
     if rank == 0:
-        # ---- roofline of the dominant kernel: the 3x3-block SpMV, HIP events on the launch stream ----
         nb = grid.nc
         rowptr, col, _ = model.jacobian()
         nnzb = int(col.size)
         roof = {}
-        for name, sp in (("f32", True), ("f64", False)):
-            # micro-run on the same matrix in a solver-only context (its own stream), values = assembled Jacobian
-            _, _, val = model.jacobian()
-            s = GpuNewtonIteration(prm, device=local_rank)
-            s.load(rowptr, col, val, sp)
-            ms = s.time_kernel(capi.K_SPMV, reps=50)
-            s.ilu0_factor()
-            ms_ilu = s.time_kernel(capi.K_ILU_APPLY, reps=20)
-            ms_copy = s.time_kernel(capi.K_STREAM_COPY, reps=20)
-            sb = 4 if sp else 8
-            nbytes = spmv_bytes(nb, nnzb, sb)
-            roof[name] = {"bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "k_spmv<%s,0>" % ("float" if sp else "double"),
-                          "ms_per_launch": ms, "algorithmic_bytes": nbytes,
-                          "ilu0_apply_ms": ms_ilu, "stream_copy_GBs": 2 * nnzb * 9 * sb / (ms_copy * 1e-3) / 1e9}
-            s.close()
-            del val
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_spmv.json")
-        if os.path.exists(pmc):
-            try:
-                d = json.load(open(pmc))
-                for name in roof:
-                    if name in d:      # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE), profiles/r01_pmc_spmv.json
-                        roof[name]["traffic"] = d[name]["hbm_bytes_per_launch"]
-                        roof[name]["traffic_over_algorithmic"] = d[name]["traffic_over_algorithmic"]
-            except Exception:
-                pass
-        main_roof = roof["f32" if single else "f64"]
+        if not args.only_main:
+            # ---- roofline of the dominant kernel: the 3x3-block SpMV (k_spmv<S,0>), HIP events on the launch stream.  `achieved` is
+            # measured with the matrix rotating over 4 copies (HBM-resident operands, like any deck larger than the 256 MiB Infinity
+            # Cache); the back-to-back replay of ONE copy (partly cache-resident at 100^3 in float) is reported beside it.
+            for name, sp in (("f32", True), ("f64", False)):
+                _, _, val = model.jacobian()
+                s = GpuNewtonIteration(prm, device=local_rank)
+                s.load(rowptr, col, val, sp)
+                ms_cold = s.time_kernel(capi.K_SPMV_COLD, reps=40)
+                ms_warm = s.time_kernel(capi.K_SPMV, reps=50)
+                s.ilu0_factor()
+                ms_ilu = s.time_kernel(capi.K_ILU_APPLY, reps=20)
+                ms_copy = s.time_kernel(capi.K_STREAM_COPY, reps=20)
+                sb = 4 if sp else 8
+                nbytes = spmv_bytes(nb, nnzb, sb)
+                roof[name] = {"bound": "hbm", "achieved": nbytes / (ms_cold * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": nbytes / (ms_cold * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "traffic": None,        # PMC counters need rocprofv3 (separate passes): profiles/r02_pmc_*.json, never pasted here
+                              "kernel": "k_spmv<%s,0>" % ("float" if sp else "double"), "ms_per_launch": ms_cold, "algorithmic_bytes": nbytes,
+                              "operands": "matrix rotating over 4 copies (%.0f MB each): HBM-resident" % ((nnzb * (9 * sb + 4)) / 1e6),
+                              "cache_resident_replay": {"ms_per_launch": ms_warm, "achieved": nbytes / (ms_warm * 1e-3) / 1e9, "frac": nbytes / (ms_warm * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                              "ilu0_apply_ms": ms_ilu, "stream_copy_GBs": 2 * nnzb * 9 * sb / (ms_copy * 1e-3) / 1e9}
+                s.close()
+                del val
+        main_roof = roof.get("f32" if single else "f64")
+
+        kernel_table = None
+        if "kt" in res:
+            tot, cnt = res["kt"]
+            S = 4 if single else 8
+            ab = algorithmic_bytes(nb, nnzb, grid.nconn, S, nnzb)
+            kernel_table = {"note": "HIP-event brackets on the launch stream around every launch (group) of a class during %d real Newton iterations right after the timed ones; "
+                                    "algorithmic bytes per launch: DESIGN.md section 4; frac = achieved / %.0f GB/s" % (args.steps, HBM_PEAK_GBS), "classes": {}}
+            for i, name in enumerate(capi.KT_NAMES):
+                if cnt[i] == 0:
+                    continue
+                ms = tot[i] / cnt[i]
+                e = {"ms_per_newton": tot[i] / args.steps, "launches_per_newton": cnt[i] / args.steps, "ms_per_launch": ms}
+                if ab.get(name):
+                    e.update({"algorithmic_bytes": int(ab[name]), "achieved_GBs": ab[name] / (ms * 1e-3) / 1e9, "frac": ab[name] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+                kernel_table["classes"][name] = e
+            if cnt[0] and cnt[1]:
+                ms = tot[0] / cnt[0] + tot[1] / cnt[1]
+                b = ab["assembly(cell_props+flux)"]
+                kernel_table["classes"]["assembly(cell_props+flux)"] = {"ms_per_launch": ms, "algorithmic_bytes": int(b), "achieved_GBs": b / (ms * 1e-3) / 1e9,
+                                                                      "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "exchange_bytes": int(nb * (80 + 27 * S) * 2)}
+            kernel_table["sum_ms_per_newton"] = float(tot.sum() / args.steps)
 
         cpu = cpu_all = None
         if not args.no_cpu_baseline and not use_dist:
-            cpu = cpu_baseline(args, grid, tab, st, prm, dt, single, threads=args.cpu_threads)
+            wl = make_wells() if use_wells else None
+            cpu = cpu_baseline(grid, tab, st, wl, prm, dt, single, threads=args.cpu_threads)
             # the same port with its OpenMP-able loops (assembly, SpMV, vector updates; the ILU sweeps stay sequential like the
-            # reference's) on all host cores of this box -- the reference itself caps OpenMP at 4 threads (FlowMain.hpp:269-271)
+            # reference's) on this job's host cores -- the reference itself caps OpenMP at 4 threads (FlowMain.hpp:269-271)
             try:
                 ncores = len(os.sched_getaffinity(0))
             except AttributeError:
                 ncores = os.cpu_count() or 1
-            ncores = min(ncores, 16)             # a one-GPU box shares its host: 16 cores is this job's share (more threads only oversubscribe)
+            ncores = min(ncores, 16)             # a one-GPU box shares its host: 16 cores is this job's share
             if ncores > args.cpu_threads:
-                cpu_all = cpu_baseline(args, grid, tab, st, prm, dt, single, threads=ncores, budget_s=8.0, max_newton=2)
+                cpu_all = cpu_baseline(grid, tab, st, wl, prm, dt, single, threads=ncores, budget_s=8.0, max_newton=2)
 
+        wells_txt = ("5-spot: 1 rate-controlled water injector (%.0f m3/d, BHP limit off) + 4 BHP producers (%.0f bar), %d perforations each, device well model "
+                     "(rank-7 operator per well, control switching + well pre-solve on the device)" % (well_spec[0], well_spec[1], args.nz)) if use_wells else "none"
         out = {
             "metric": "Mcell-updates/sec per Newton step (assembly+solve)", "value": value, "unit": "Mcell-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
             "dtype": "f64 assembly + %s linear solve" % ("f32" if single else "f64"), "data": "synthetic",
-            "config": {"workload": "cart%dx%dx%d_3phase_blackoil" % (args.nx, args.ny, args.nz * (world if (world > 1 and args.scaling == "weak") else 1)),
+            "config": {"workload": "%s%dx%dx%d_3phase_blackoil%s" % ("spe10like_" if args.deck == "spe10like" else "cart", args.nx, args.ny,
+                                                                     args.nz * (world if (world > 1 and args.scaling == "weak" and args.deck == "cart") else 1),
+                                                                     "_fivespot" if use_wells else ""),
                        "cells": nc_global, "cells_per_gpu": info["n_owned"], "nnzb_rank0": nnzb,
-                       "dt_days": args.dt_days, "linear_solver": ("cpr(amg V-cycle + ilu0)" if prm.use_cpr else "ilu0") + " + bicgstab", "ilu0_ordering": args.ordering, "linear_iterations_per_newton": res["lin"],
-                       "time_steps_completed": steps_done, "tables": "tests/satfuncStandard.DATA PROPS (reference's own test deck)",
-                       "wells": "none" if (args.wells == "none" or use_dist) else "5-spot, 5 wells x %d perforations, device well model (rank-7 operator per well)" % args.nz,
+                       "dt_days": args.dt_days, "linear_solver": ("cpr(amg V-cycle + ilu0)" if prm.use_cpr else "ilu0") + " + bicgstab", "ilu0_ordering": args.ordering,
+                       "linear_iterations_per_newton": res["lin"], "time_steps_completed": res["steps_done"], "time_steps_not_converged": res["steps_not_converged"],
+                       "spin_up_time_steps": args.spin_up, "nonlinear_solver": "reference NonlinearSolver (max_iter 10, update stabilisation on)",
+                       "tables": "tests/satfuncStandard.DATA PROPS (reference's own test deck)", "wells": wells_txt,
                        "parallelism": "1 GPU" if world == 1 else "domain decomposition x%d, RCCL halo" % world},
             "breakdown_ms_per_step": res["breakdown"],
-            "same_run_with_reference_default_solver_ilu0": ilu0,
-            "same_run_with_fivespot_wells": fivespot,
-            "roofline": main_roof, "roofline_f64_spmv": roof["f64"], "roofline_f32_spmv": roof["f32"],
+            "same_run_variants": variants,
+            "roofline": main_roof, "roofline_f64_spmv": roof.get("f64"), "roofline_f32_spmv": roof.get("f32"),
+            "kernel_table": kernel_table,
             "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all,
         }
     model.close()
@@ -243,41 +320,35 @@ def main():
         print(json.dumps(out))
 
 
-def cpu_baseline(args, grid, tab, st, prm, dt, single, threads=1, budget_s=15.0, max_newton=4):
-    """The oracle (CPU restatement of the reference's algorithm: AD assembly into BSR, natural-order
-    block-ILU0, BiCGStab, same precision switch, same update) timed on the host cores for a bounded
-    sample: the first Newton iterations of the SAME deck from the SAME initial state (at least one, until
-    the time budget is used; later iterations have the harder linear systems, like on the GPU)."""
+def cpu_baseline(grid, tab, st, wl, prm, dt, single, threads=1, budget_s=15.0, max_newton=4):
+    """The oracle (CPU restatement of the reference's algorithm: AD assembly into BSR, host standard-well model with the explicit
+    Schur complement, natural-order block-ILU0, BiCGStab, same precision switch, same update) timed on the host cores for a bounded
+    sample: the first Newton iterations of the SAME deck (wells included) from the SAME initial state (at least one, until the time
+    budget is used)."""
     import numpy as np
     from oracle import oracle as orc
-    from opmgpu import capi
+    from opmgpu import capi, wells as W
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import OracleBackend            # test infrastructure: the model interface on top of the oracle
     orc.set_threads(threads)
-    nc = grid.nc
-    scale = np.asarray(prm.matbalscale[:])
-    prm_nat = capi.default_params(ilu_ordering=capi.ORDER_NATURAL)
-    rowptr, col = orc.pattern(grid)
-    cur, acc0 = st.copy(), None
-    t_asm = t_sol = t_upd = 0.0
-    its, lin = 0, []
-    while its < max_newton and (its == 0 or t_asm + t_sol + t_upd < budget_s):
+    ob = OracleBackend(orc, grid, tab, capi.default_params(ilu_ordering=capi.ORDER_NATURAL), wells=None if wl is None else wl.arrays())
+    mo = None if wl is None else W.WellCoupledModel(ob, W.StandardWellsHost(wl, grid.z, tab.surface_density[0]), W.WellState(wl, st.p))
+    (mo or ob).prepareStep(dt, st)
+    its, lin, tot = 0, [], 0.0
+    while its < max_newton and (its == 0 or tot < budget_s):
         t1 = time.perf_counter()
-        r, val, acc0, binv = orc.assemble(grid, tab, dt, cur, rowptr, col, scale=tuple(scale), accum0=acc0)
-        orc.convergence(grid, prm, dt, r, binv)
-        t2 = time.perf_counter()
-        b = np.ascontiguousarray((r * np.repeat(scale, nc)).reshape(3, nc).T).ravel()
-        sto, x, it, red, _ = orc.bicgstab(rowptr, col, val, b, prm_nat, position=None, single=single)
-        t3 = time.perf_counter()
-        dx = np.ascontiguousarray(x.reshape(nc, 3).T).ravel()
-        cur = orc.update_state(grid, tab, prm, dx, cur)
-        t4 = time.perf_counter()
-        t_asm += t2 - t1; t_sol += t3 - t2; t_upd += t4 - t3
-        its += 1; lin.append(it)
-        if sto != 0:
-            break
-    tot = t_asm + t_sol + t_upd
-    return {"value": its * nc / tot / 1e6, "unit": "Mcell-updates/s", "cores": threads, "kind": "port",
-            "sample": "first %d Newton iterations of the same deck and initial state: assembly %.2fs + natural-order ILU0/BiCGStab %s (linear its %s) %.2fs + update %.2fs"
-                      % (its, t_asm, "f32" if single else "f64", lin, t_sol, t_upd),
+        if mo is not None:
+            _, l = mo.nonlinearIteration(its, single_precision=single)
+        else:
+            ob.assemble(its == 0)
+            ob.getConvergence()
+            ob.solveJacobianSystem(single_precision=single); ob.updateState()
+            l = ob.linear_iterations
+        tot += time.perf_counter() - t1
+        its += 1; lin.append(l)
+    return {"value": its * grid.nc / tot / 1e6, "unit": "Mcell-updates/s", "cores": threads, "kind": "port",
+            "sample": "first %d Newton iterations of the same deck%s and initial state: assembly + %snatural-order ILU0/BiCGStab %s (linear its %s) + update, %.2f s"
+                      % (its, " with its 5-spot (host well model, explicit Schur complement)" if wl is not None else "", "", "f32" if single else "f64", lin, tot),
             "newton_iterations": its, "linear_iterations": lin}
 
 

@@ -127,6 +127,11 @@ typedef struct opmgpu_params {
     int32_t newton_use_gmres;       /* 0 = BiCGStab; 1 = Dune::RestartedGMResSolver (ISTLSolver.hpp:257-264): left-preconditioned
                                        restarted GMRES, modified Gram-Schmidt; single GPU                    */
     int32_t linear_solver_restart;  /* 40     */
+    /* well model (device wells): BlackoilModelParameters.cpp:78-79, :96, :85 */
+    int32_t solve_welleq_initially; /* 1: explicit well pre-solve at the initial assembly (BlackoilModelBase_impl.hpp:827-829) */
+    double tolerance_wells;         /* 1e-4   */
+    double tolerance_well_control;  /* 1e-7   */
+    double dbhp_max_rel;            /* 1.0    */
 } opmgpu_params;
 
 void opmgpu_default_params(opmgpu_params* p);
@@ -232,17 +237,53 @@ typedef struct opmgpu_wells {
     const int32_t* allow_cf;       /* [nw] allow cross flow; NULL = all 1                      */
     const double*  depth_ref;      /* [nw] bhp reference depth                                 */
     const double*  comp_frac;      /* [nw*3] injection stream composition (w, o, g)            */
-    const int32_t* ctrl_type;      /* [nw] 0 = BHP, 1 = SURFACE_RATE                           */
-    const double*  ctrl_target;    /* [nw]                                                     */
-    const double*  ctrl_distr;     /* [nw*3] rate-control phase weights; NULL = 0              */
+    const int32_t* ctrl_type;      /* [nctrl] OPMGPU_CTRL_*                                    */
+    const double*  ctrl_target;    /* [nctrl]                                                  */
+    const double*  ctrl_distr;     /* [nctrl*3] rate-control phase weights; NULL = 0           */
+    /* WellControls with several controls per well (opm-core well_controls.h): control ctrl_ptr[w] is the well's initial
+     * CURRENT control (an equation), the others are inequality constraints that updateWellControls switches to when broken
+     * (StandardWells_impl.hpp:709-800).  ctrl_ptr == NULL: one control per well (nctrl == nw).                           */
+    const int32_t* ctrl_ptr;       /* [nw+1] or NULL                                           */
+    const int32_t* ctrl_vfp;       /* [nctrl] VFP table id of the THP controls, or NULL        */
+    const double*  ctrl_alq;       /* [nctrl] artificial lift quantity of THP controls, or NULL */
 } opmgpu_wells;
+enum { OPMGPU_CTRL_BHP = 0, OPMGPU_CTRL_SURFACE_RATE = 1, OPMGPU_CTRL_THP = 2, OPMGPU_CTRL_RESERVOIR_RATE = 3 };
 
+/* VFP tables for THP control (VFPProdPropertiesLegacy.cpp:36-154, VFPInjPropertiesLegacy.cpp:36-130; opm-common's VFPProdTable /
+ * VFPInjTable).  SI units.  Producer data is [nthp][nwfr][ngfr][nalq][nflo], injector data [nthp][nflo] (the other axes have
+ * length 1 and may be NULL).  Multilinear interpolation, linear extrapolation outside the axes. */
+enum { OPMGPU_VFP_FLO_OIL = 0, OPMGPU_VFP_FLO_LIQ = 1, OPMGPU_VFP_FLO_GAS = 2 };
+enum { OPMGPU_VFP_WFR_WOR = 0, OPMGPU_VFP_WFR_WCT = 1, OPMGPU_VFP_WFR_WGR = 2 };
+enum { OPMGPU_VFP_GFR_GOR = 0, OPMGPU_VFP_GFR_GLR = 1, OPMGPU_VFP_GFR_OGR = 2 };
+typedef struct opmgpu_vfp_table {
+    int32_t id, is_injector;
+    int32_t flo_type, wfr_type, gfr_type;
+    double  datum_depth;
+    int32_t nflo, nthp, nwfr, ngfr, nalq;
+    const double *flo, *thp, *wfr, *gfr, *alq;
+    const double* data;
+} opmgpu_vfp_table;
+
+/* Call BEFORE opmgpu_set_device_wells when a well has a THP control; n == 0 removes the tables. */
+int opmgpu_set_vfp_tables(opmgpu_ctx* ctx, int n, const opmgpu_vfp_table* tables);
 /* nw == 0 removes them.  Multi-GPU: a well lives on ONE rank, and EVERY rank of a run with wells makes this call (nw = 0 where it owns
  * none) -- opmgpu_well_convergence is collective, and the call tells the pressure stage's coarse space that the run has wells. */
 int opmgpu_set_device_wells(opmgpu_ctx* ctx, const opmgpu_wells* wells);
-/* WellStateFullyImplicitBlackoil fields: bhp[nw], wellRates qs[nw*3]; perf_rates[nperf*3] may be NULL (keep) */
-int opmgpu_well_state_set(opmgpu_ctx* ctx, const double* bhp, const double* qs, const double* perf_rates);
+/* WellStateFullyImplicitBlackoil fields: bhp[nw], wellRates qs[nw*3]; perfPress perf_press[nperf] and perfPhaseRates
+ * perf_rates[nperf*3] may be NULL (keep).  perf_press feeds the average well-block pressures of computeWellConnectionPressures. */
+int opmgpu_well_state_set(opmgpu_ctx* ctx, const double* bhp, const double* qs, const double* perf_press, const double* perf_rates);
 int opmgpu_well_state_get(opmgpu_ctx* ctx, double* bhp, double* qs, double* perf_press, double* perf_rates);
+/* currentControls() (index into each well's controls, relative to ctrl_ptr[w]) and thp() of the well state; any pointer may be NULL.
+ * get also reports the iteration count and outcome of the last explicit well pre-solve (solveWellEq). */
+int opmgpu_well_controls_set(opmgpu_ctx* ctx, const int32_t* current, const double* thp);
+int opmgpu_well_controls_get(opmgpu_ctx* ctx, int32_t* current, double* thp, int32_t* presolve_iterations, int32_t* presolve_converged);
+/* computePropertiesForWellConnectionPressures (StandardWells_impl.hpp:218-296) for the HOST well model: b_w, b_o, b_g, rsSat, rvSat
+ * of the perforated cells (opmgpu_set_wells order) evaluated at the given pressures with the cells' own rs / rv / phase condition /
+ * oil saturation.  out[nperf*5]. */
+int opmgpu_perf_pvt(opmgpu_ctx* ctx, const double* pressure, double* out);
+/* B_avg of getWellConvergence (BlackoilModelBase_impl.hpp:1876-1891) for the host well model's pre-solve: mean 1/b per phase of the
+ * last assembly. */
+int opmgpu_average_b(opmgpu_ctx* ctx, double* B_avg3);
 /* well part of getConvergence (BlackoilModelBase_impl.hpp:1769-1779) after opmgpu_assemble: max |flux equation| per
  * phase (to be multiplied by B_avg and compared with tolerance_wells) and max |control equation|. */
 int opmgpu_well_convergence(opmgpu_ctx* ctx, double* flux_residual3, double* control_residual);
@@ -315,8 +356,17 @@ int opmgpu_get_jacobian_bsr(opmgpu_ctx* ctx, int32_t* rowptr, int32_t* col, doub
 enum { OPMGPU_K_SPMV = 0, OPMGPU_K_ILU_APPLY = 1, OPMGPU_K_ILU_FACTOR = 2, OPMGPU_K_ASSEMBLE = 3,
        OPMGPU_K_DOT = 4, OPMGPU_K_AXPY = 5, OPMGPU_K_PROPS = 6, OPMGPU_K_STREAM_COPY = 7,
        OPMGPU_K_CPR_APPLY = 8 /* whole two-stage preconditioner application */, OPMGPU_K_VCYCLE = 9 /* its AMG V-cycle alone */,
-       OPMGPU_K_CPR_SETUP = 10 /* pressure extraction + Galerkin + coarsest inverse */ };
+       OPMGPU_K_CPR_SETUP = 10 /* pressure extraction + Galerkin + coarsest inverse */,
+       OPMGPU_K_SPMV_COLD = 11 /* the SpMV rotating over copies of the matrix that together exceed the 256 MiB Infinity Cache: HBM-resident operands */ };
 int opmgpu_time_kernel(opmgpu_ctx* ctx, int kernel, int reps, double* ms_per_launch);
+/* In-situ timing of kernel CLASSES during real Newton iterations: after opmgpu_kernel_timing(ctx, 1) every launch (group) of a class
+ * is bracketed by a HIP event pair on the launch stream; opmgpu_kernel_timing_get sums the elapsed times per class since the switch-on
+ * (total_ms[OPMGPU_KT_COUNT], launches[OPMGPU_KT_COUNT] bracket counts).  Off by default -- the brackets cost a few microseconds each,
+ * so bench.py uses a separate profiled pass for its per-kernel roofline table. */
+enum { OPMGPU_KT_CELL_PROPS = 0, OPMGPU_KT_FLUX, OPMGPU_KT_WELLS, OPMGPU_KT_CONV, OPMGPU_KT_ILU_FACTOR, OPMGPU_KT_CPR_SETUP, OPMGPU_KT_SPMV1,
+       OPMGPU_KT_SPMV2, OPMGPU_KT_ILU_APPLY, OPMGPU_KT_VCYCLE, OPMGPU_KT_CPR_OTHER, OPMGPU_KT_VECTOR, OPMGPU_KT_UPDATE_STATE, OPMGPU_KT_COUNT };
+int opmgpu_kernel_timing(opmgpu_ctx* ctx, int enable);
+int opmgpu_kernel_timing_get(opmgpu_ctx* ctx, double* total_ms, int64_t* launches);
 /* elapsed device milliseconds of the last assemble / solve / update_state call. */
 int opmgpu_last_timings(opmgpu_ctx* ctx, double* assemble_ms, double* solve_ms, double* update_ms);
 

@@ -686,6 +686,47 @@ __global__ __launch_bounds__(kBlock) void k_perf_props(int nperf, opmgpu_tables 
     for (int k = 0; k < 9; ++k) { o[4 * k] = list[k].v; o[4 * k + 1] = list[k].p; o[4 * k + 2] = list[k].w; o[4 * k + 3] = list[k].x; }
 }
 
+// computePropertiesForWellConnectionPressures (StandardWells_impl.hpp:218-296): b_w, b_o, b_g, rsSat, rvSat of the perforated cells at
+// GIVEN pressures (the average well-block pressures) with the cells' own rs / rv / phase condition / oil saturation
+__global__ __launch_bounds__(kBlock) void k_perf_pvt(int nperf, opmgpu_tables T, const int32_t* __restrict__ cells, const int32_t* __restrict__ pvtnum,
+                                                     const double* __restrict__ so, const double* __restrict__ rs, const double* __restrict__ rv,
+                                                     const int8_t* __restrict__ hc, const double* __restrict__ somax, const double* __restrict__ press,
+                                                     const int32_t* __restrict__ gate, double* __restrict__ out)
+{
+    if (gate && !*gate) return;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nperf) return;
+    const int c = cells[i], preg = pvtnum[c], h = hc[c];
+    const bool freeGas = h != OPMGPU_HC_OIL_ONLY, freeOil = h != OPMGPU_HC_GAS_ONLY;
+    const double p = press[i];
+    double f, df, d2;
+    double* o = out + 5 * long(i);
+    {
+        const double* w = T.pvtw + 5 * preg;
+        const double Xc = w[2] * (p - w[0]);
+        o[0] = (1.0 + Xc * (1.0 + Xc / 2.0)) / w[1];
+    }
+    {
+        const int a = T.oil_node_ptr[preg], nn = T.oil_node_ptr[preg + 1] - a;
+        if (freeGas || !T.has_disgas) pvt1(T.oil_psat + a, T.oil_invb_sat + a, nn, p, f, df);
+        else pvt2(T.oil_rs + a, nn, T.oil_col_ptr + a, T.oil_col_p, T.oil_col_invb, rs[c], p, f, d2, df);
+        o[1] = f;
+    }
+    {
+        const int a = T.gas_node_ptr[preg], nn = T.gas_node_ptr[preg + 1] - a;
+        if (freeOil || !T.has_vapoil) pvt1(T.gas_pg + a, T.gas_invb_sat + a, nn, p, f, df);
+        else pvt2(T.gas_pg + a, nn, T.gas_col_ptr + a, T.gas_col_rv, T.gas_col_invb, p, rv[c], f, df, d2);
+        o[2] = f;
+    }
+    double v;
+    rs_sat_d(T, preg, p, f, df);
+    if (T.vap2 > 0.0) { vap_factor(T.vap2, so[c], somax[c], v, df); f *= v; }
+    o[3] = f;
+    rv_sat_d(T, preg, p, f, df);
+    if (T.vap1 > 0.0) { vap_factor(T.vap1, so[c], somax[c], v, df); f *= v; }
+    o[4] = f;
+}
+
 __global__ __launch_bounds__(kBlock) void k_add_well_resid(int nperf, int nbp, const int32_t* __restrict__ cells, const double* __restrict__ delta, double* __restrict__ R)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -756,6 +797,7 @@ BlackoilDevice::BlackoilDevice(hipStream_t s, LinSolver& ls_, const opmgpu_grid*
 BlackoilDevice::~BlackoilDevice()
 {
     wells_free();
+    vfp_free();
     if (h_red) (void)hipHostFree(h_red);
 }
 
@@ -967,10 +1009,13 @@ template <class MS> void BlackoilDevice::assemble_kernels(double dt, bool initia
     // CPR on a system without wells: k_flux also writes the weights of the pressure equation
     MS* wout = nullptr;
     if (prm.use_cpr && nperf == 0 && ls.cpr_weight_mode == 0 && ls.emulate_ranks <= 1) { ls.ensure_work<MS>(); ls.work<MS>().cprw.alloc(3 * size_t(P.nbp)); wout = ls.work<MS>().cprw.p; }
+    hipEvent_t kt_a = ls.kt.begin();
     hipLaunchKernelGGL((k_cell_props<MS>), dim3(grid_for(nc)), dim3(kBlock), tab_lds_bytes(), stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_pv.p,
                        d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, 1.0 / dt, int(initial), sc[0], sc[1], sc[2],
                        ls.dp.slice_ptr.p, ls.dp.nlower.p, eps_planes(), d_eps_u0.p, d_somax.p, d_props.p, pd, d_accum0.p, d_R.p, d_binv.p, A,
                        (const double*)d_tab.p, tab_lds_words());
+    ls.kt.end(KT_CELL_PROPS, kt_a);
+    KtScope kts(ls.kt, KT_FLUX);
     hipLaunchKernelGGL((k_flux<MS>), dim3(grid8_for(nc)), dim3(kBlock), 0, stream, xcd_mode(), nc, P.nbp, ls.dp.slice_ptr.p, ls.dp.col.p, ls.dp.rowlen.p,
                        ls.dp.nlower.p, d_conn_code.p, d_trans.p, d_gdz.p, use_thpres ? d_thpres.p : (const double*)nullptr,
                        d_p.p, d_props.p, (const MS*)pd, sc[0], sc[1], sc[2], ls.comm ? ls.comm->owner_mask() : (const int8_t*)nullptr, d_R.p, A, wout);
@@ -996,6 +1041,7 @@ void BlackoilDevice::assemble(double dt, bool initial)
     ls.matrix_is_float = assemble_single && !host_wells;
     if (ls.matrix_is_float) assemble_kernels<float>(dt, initial, ls.matrix_f());
     else assemble_kernels<double>(dt, initial, ls.matrix_d());
+    KtScope kts(ls.kt, KT_WELLS);
     wells_assemble(initial);
 }
 
@@ -1030,8 +1076,10 @@ int BlackoilDevice::convergence(double dt, double* B3, double* CNV3, double* MB3
     const Plan& P = ls.plan;
     const int g = std::min(grid_for(nc), kMaxRedBlocks);
     const int8_t* mask = ls.comm ? ls.comm->owner_mask() : nullptr;
+    hipEvent_t kt_a = ls.kt.begin();
     hipLaunchKernelGGL(k_conv_partial, dim3(g), dim3(kBlock), 0, stream, nc, P.nbp, d_R.p, d_binv.p, d_pv.p, mask, d_red.p + 16);
     hipLaunchKernelGGL(k_conv_final, dim3(13), dim3(kBlock), 0, stream, g, d_red.p + 16, d_red.p);
+    ls.kt.end(KT_CONV, kt_a);
     if (ls.comm) { ls.comm->allreduce_sum(d_red.p, 7, stream); ls.comm->allreduce_max(d_red.p + 7, 6, stream); }
     OPMGPU_HIP(hipMemcpyAsync(h_red, d_red.p, 13 * sizeof(double), hipMemcpyDeviceToHost, stream));
     OPMGPU_HIP(hipStreamSynchronize(stream));
@@ -1148,6 +1196,44 @@ void BlackoilDevice::perf_props_device()
                        d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, eps_planes(), d_eps_u0.p, d_somax.p, long(ls.plan.nbp), d_perf.p);
 }
 
+void BlackoilDevice::perf_pvt_device(const double* press_dev, double* out_dev, const int32_t* gate)
+{
+    if (nperf == 0) return;
+    hipLaunchKernelGGL(k_perf_pvt, dim3(grid_for(nperf)), dim3(kBlock), 0, stream, nperf, dt_, d_perf_cells.p, d_pvtnum.p, d_so.p, d_rs.p, d_rv.p, d_hc.p,
+                       d_somax.p, press_dev, gate, out_dev);
+}
+
+void BlackoilDevice::perf_pvt(const double* press, double* out)
+{
+    if (nperf == 0) return;
+    DevArray<double> dp_, dout; dp_.upload(press, size_t(nperf), stream); dout.alloc(5 * size_t(nperf));
+    perf_pvt_device(dp_.p, dout.p, nullptr);
+    OPMGPU_HIP(hipMemcpyAsync(out, dout.p, 5 * size_t(nperf) * sizeof(double), hipMemcpyDeviceToHost, stream));
+    OPMGPU_HIP(hipStreamSynchronize(stream));
+}
+
+// sum of 1/b per phase over the owned cells (-> B_avg of getWellConvergence) into out_dev[0..2] (sums; the caller divides by the cell count)
+void BlackoilDevice::binv_sums_device(double* out13_dev, double* scratch_dev)
+{
+    const Plan& P = ls.plan;
+    const int g = std::min(grid_for(nc), kMaxRedBlocks);
+    const int8_t* mask = ls.comm ? ls.comm->owner_mask() : nullptr;
+    hipLaunchKernelGGL(k_conv_partial, dim3(g), dim3(kBlock), 0, stream, nc, P.nbp, d_R.p, d_binv.p, d_pv.p, mask, scratch_dev);
+    hipLaunchKernelGGL(k_conv_final, dim3(13), dim3(kBlock), 0, stream, g, scratch_dev, out13_dev);
+    if (ls.comm) ls.comm->allreduce_sum(out13_dev, 3, stream);
+}
+
+void BlackoilDevice::average_b(double* B3)
+{
+    DevArray<double> out, scratch; out.alloc(16); scratch.alloc(13 * size_t(kMaxRedBlocks));
+    binv_sums_device(out.p, scratch.p);
+    double h[3];
+    OPMGPU_HIP(hipMemcpyAsync(h, out.p, 3 * sizeof(double), hipMemcpyDeviceToHost, stream));
+    OPMGPU_HIP(hipStreamSynchronize(stream));
+    const double ncg = ls.comm ? double(ls.comm->n_owned_global) : double(nc);
+    for (int a = 0; a < 3; ++a) B3[a] = h[a] / ncg;
+}
+
 void BlackoilDevice::perf_props(double* out)
 {
     if (nperf == 0) return;
@@ -1244,7 +1330,8 @@ void BlackoilDevice::update_state(const double* dx_host, double relax)
 {
     const Plan& P = ls.plan;
     if (dx_host) { ls.vec_from_host<double>(dx_host, VEC_EQUATION_MAJOR, d_dx.p); OPMGPU_HIP(hipStreamSynchronize(stream)); has_dx = true; }   // caller's buffer: done with it on return
-    if (device_wells) wells_update(relax);          // recoverVariable + updateWellState from the same increment
+    KtScope kts(ls.kt, KT_UPDATE_STATE);
+    if (device_wells) wells_update(relax, dx_host != nullptr);          // updateWellState from the recovered (and possibly relaxed) well increment
     hipLaunchKernelGGL(k_update_state, dim3(grid_for(nc)), dim3(kBlock), tab_lds_bytes(), stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_dx.p, relax,
                        prm.dp_max_rel, prm.ds_max, prm.dr_max_rel, d_p.p, d_sw.p, d_so.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, eps_planes(), d_eps_u0.p, d_somax.p,
                        (const double*)d_tab.p, tab_lds_words());
@@ -1280,6 +1367,7 @@ void BlackoilDevice::get_sat_oil_max(double* v)
 void BlackoilDevice::stabilize_update(int relax_type, double omega)
 {
     const long n = 3 * long(ls.plan.nbp);
+    if (device_wells) wells_stabilize(relax_type == OPMGPU_RELAX_SOR ? 1 : 0, omega);      // the well part first: it is recovered from the UNRELAXED dx
     hipLaunchKernelGGL(k_stabilize, dim3(unsigned((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, n, relax_type == OPMGPU_RELAX_SOR ? 1 : 0, omega,
                        d_dx.p, d_dx_old.p);
 }

@@ -34,6 +34,10 @@ public:
     bool assemble_single = false;      // precision of the coming solve (opmgpu_set_solve_precision)
     int convergence(double dt, double* B3, double* CNV3, double* MB3, double* linf3, int* converged);
     void perf_props(double* out);
+    void perf_pvt(const double* press, double* out);                 // host well model: PVT of the perforated cells at given pressures
+    void perf_pvt_device(const double* press_dev, double* out_dev, const int32_t* gate);
+    void average_b(double* B3);
+    void binv_sums_device(double* out13_dev, double* scratch_dev);
     int add_well_terms(const double* resid_delta, int nblk, const int32_t* rc, const double* blocks);
     void add_well_rhs(const double* rhs_delta);
     void perf_dx(double* out);
@@ -52,11 +56,15 @@ public:
     void get_residual(double* r);
     // wells on the device (wells.hip)
     struct WellsDev;
+    struct VfpDev;
     int set_device_wells(const opmgpu_wells* spec);
-    int well_state_set(const double* bhp, const double* qs, const double* perf_rates);
+    int well_state_set(const double* bhp, const double* qs, const double* perf_press, const double* perf_rates);
     int well_state_get(double* bhp, double* qs, double* perf_press, double* perf_rates);
     int well_convergence(double* flux3, double* ctrl);
-    void set_dbhp_max_rel(double v);
+    int set_vfp_tables(int n, const opmgpu_vfp_table* tabs);
+    int well_controls_set(const int32_t* current, const double* thp);
+    int well_controls_get(int32_t* current, double* thp, int32_t* pre_its, int32_t* pre_conv);
+    void wells_recover();                                   // recoverVariable: well part of the increment from the resident dx
     bool device_wells = false;
     int n_owned_cells = 0;            // multi-GPU: caller cells [0, n_owned) are owned (set by attach_comm), else nc
     double time_assemble(int reps, int props_only);
@@ -73,12 +81,16 @@ private:
     void upload_tables(const opmgpu_tables* t);
     void perf_props_device();
     void wells_assemble(bool initial);
-    void wells_update(double relax);
+    void wells_update(double relax, bool dx_from_host);
+    void wells_stabilize(int sor, double omega);
+    void wells_connection_pressures(const int32_t* gate);
     void wells_save();
     void wells_restore();
     void wells_rebind();
     void wells_free();
+    void vfp_free();
     WellsDev* wd = nullptr;
+    VfpDev* vfp = nullptr;
     std::vector<double> h_surface_density;
     void rebuild_structure();
 

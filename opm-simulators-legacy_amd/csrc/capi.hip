@@ -112,6 +112,7 @@ void opmgpu_default_params(opmgpu_params* p)
     p->linear_solver_reduction = 1e-2; p->linear_solver_maxiter = 150;                    // FlowLinearSolverParameters
     p->ilu_relaxation = 0.9; p->ilu_ordering = OPMGPU_ORDER_MULTICOLOR; p->ignore_convergence_failure = 0; p->use_cpr = 0;
     p->newton_use_gmres = 0; p->linear_solver_restart = 40;                                // NewtonIterationBlackoilCPR.cpp:61-64
+    p->solve_welleq_initially = 1; p->tolerance_wells = 1e-4; p->tolerance_well_control = 1e-7; p->dbhp_max_rel = 1.0;   // BlackoilModelParameters.cpp:80-96
 }
 
 int opmgpu_create_solver(opmgpu_ctx** ctx, int device, const opmgpu_params* params) { return make_ctx(ctx, device, params); }
@@ -269,15 +270,43 @@ int opmgpu_set_device_wells(opmgpu_ctx* c, const opmgpu_wells* wells)
         return st;
     });
 }
-int opmgpu_well_state_set(opmgpu_ctx* c, const double* bhp, const double* qs, const double* perf_rates)
+int opmgpu_well_state_set(opmgpu_ctx* c, const double* bhp, const double* qs, const double* perf_press, const double* perf_rates)
 {
     if (!c || !c->model) return OPMGPU_EINVAL;
-    return guarded(c, [&]() { return c->model->well_state_set(bhp, qs, perf_rates); });
+    return guarded(c, [&]() { return c->model->well_state_set(bhp, qs, perf_press, perf_rates); });
 }
 int opmgpu_well_state_get(opmgpu_ctx* c, double* bhp, double* qs, double* perf_press, double* perf_rates)
 {
     if (!c || !c->model) return OPMGPU_EINVAL;
     return guarded(c, [&]() { return c->model->well_state_get(bhp, qs, perf_press, perf_rates); });
+}
+int opmgpu_set_vfp_tables(opmgpu_ctx* c, int n, const opmgpu_vfp_table* tables)
+{
+    if (!c || !c->model) return OPMGPU_EINVAL;
+    return guarded(c, [&]() {
+        const int st = c->model->set_vfp_tables(n, tables);
+        return st == OPMGPU_OK ? st : fail(c, st, "invalid VFP table (missing axis / data, empty axis, or more than 64 THP values)");
+    });
+}
+int opmgpu_well_controls_set(opmgpu_ctx* c, const int32_t* current, const double* thp)
+{
+    if (!c || !c->model) return OPMGPU_EINVAL;
+    return guarded(c, [&]() { return c->model->well_controls_set(current, thp); });
+}
+int opmgpu_well_controls_get(opmgpu_ctx* c, int32_t* current, double* thp, int32_t* pre_its, int32_t* pre_conv)
+{
+    if (!c || !c->model) return OPMGPU_EINVAL;
+    return guarded(c, [&]() { return c->model->well_controls_get(current, thp, pre_its, pre_conv); });
+}
+int opmgpu_perf_pvt(opmgpu_ctx* c, const double* pressure, double* out)
+{
+    if (!c || !c->model || !pressure || !out || !c->model->has_state) return OPMGPU_EINVAL;
+    return guarded(c, [&]() { c->model->perf_pvt(pressure, out); return OPMGPU_OK; });
+}
+int opmgpu_average_b(opmgpu_ctx* c, double* B3)
+{
+    if (!c || !c->model || !B3 || !c->matrix_loaded) return OPMGPU_EINVAL;
+    return guarded(c, [&]() { c->model->average_b(B3); return OPMGPU_OK; });
 }
 int opmgpu_well_convergence(opmgpu_ctx* c, double* flux3, double* ctrl)
 {
@@ -475,6 +504,22 @@ int opmgpu_time_kernel(opmgpu_ctx* c, int kernel, int reps, double* ms_per_launc
         if ((kernel == OPMGPU_K_ILU_APPLY) && !c->factored) return fail(c, OPMGPU_EINVAL, "call opmgpu_ilu0_factor first");
         *ms_per_launch = c->ls->time_kernel(kernel, reps, c->cur_single);
         return int(OPMGPU_OK);
+    });
+}
+
+int opmgpu_kernel_timing(opmgpu_ctx* c, int enable)
+{
+    if (!c) return OPMGPU_EINVAL;
+    return guarded(c, [&]() { c->ls->kt.reset(); c->ls->kt.on = enable != 0; return OPMGPU_OK; });
+}
+int opmgpu_kernel_timing_get(opmgpu_ctx* c, double* total_ms, int64_t* launches)
+{
+    if (!c || !total_ms) return OPMGPU_EINVAL;
+    return guarded(c, [&]() {
+        KernelTimers& kt = c->ls->kt;
+        kt.collect();
+        for (int i = 0; i < KT_COUNT; ++i) { total_ms[i] = kt.total_ms[i]; if (launches) launches[i] = kt.count[i]; }
+        return OPMGPU_OK;
     });
 }
 

@@ -56,6 +56,37 @@ struct DevArray {
     void zero(hipStream_t s) { if (n) OPMGPU_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
 };
 
+// In-situ kernel timing (opmgpu_kernel_timing): HIP event pairs recorded on the launch stream around the launches of a kernel
+// class DURING a real Newton iteration; off by default (two event records per bracket are not free), switched on by bench.py for a
+// separate profiled pass that feeds the per-kernel roofline table.
+enum { KT_CELL_PROPS = 0, KT_FLUX, KT_WELLS, KT_CONV, KT_ILU_FACTOR, KT_CPR_SETUP, KT_SPMV1, KT_SPMV2, KT_ILU_APPLY, KT_VCYCLE, KT_CPR_OTHER,
+       KT_VECTOR, KT_UPDATE_STATE, KT_COUNT };
+struct KernelTimers {
+    bool on = false;
+    hipStream_t stream = nullptr;
+    std::vector<hipEvent_t> pool;                    // recycled events
+    struct Rec { int id; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    double total_ms[KT_COUNT] = {};
+    long count[KT_COUNT] = {};
+    hipEvent_t get() { if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; } hipEvent_t e; OPMGPU_HIP(hipEventCreate(&e)); return e; }
+    hipEvent_t begin() { if (!on) return nullptr; hipEvent_t e = get(); OPMGPU_HIP(hipEventRecord(e, stream)); return e; }
+    void end(int id, hipEvent_t a) { if (!on || !a) return; hipEvent_t b = get(); OPMGPU_HIP(hipEventRecord(b, stream)); recs.push_back({ id, a, b }); if (recs.size() > 8192) collect(); }
+    void collect() {
+        if (recs.empty()) return;
+        OPMGPU_HIP(hipEventSynchronize(recs.back().b));
+        for (const Rec& r : recs) { float ms = 0.f; if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { total_ms[r.id] += ms; ++count[r.id]; } pool.push_back(r.a); pool.push_back(r.b); }
+        recs.clear();
+    }
+    void reset() { collect(); for (int i = 0; i < KT_COUNT; ++i) { total_ms[i] = 0.0; count[i] = 0; } }
+    ~KernelTimers() { for (const Rec& r : recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); } for (hipEvent_t e : pool) (void)hipEventDestroy(e); }
+};
+struct KtScope {        // RAII bracket
+    KernelTimers& kt; int id; hipEvent_t a;
+    KtScope(KernelTimers& k, int i) : kt(k), id(i), a(k.begin()) {}
+    ~KtScope() { try { kt.end(id, a); } catch (...) {} }
+};
+
 constexpr int kBlock = 256;          // 4 wavefronts = 4 SELL slices per workgroup
 constexpr int kMaxRedBlocks = 2048;  // grid cap of the reduction kernels (256 CUs x 8)
 

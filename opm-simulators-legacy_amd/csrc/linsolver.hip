@@ -745,6 +745,7 @@ void DevPlan::upload(const Plan& P, hipStream_t s)
 
 LinSolver::LinSolver(hipStream_t s) : stream(s)
 {
+    kt.stream = s;
     npart = kMaxPart;
     partials.alloc(size_t(6) * npart + 16);
     flags.alloc(4);
@@ -881,6 +882,7 @@ template <class S> const S* LinSolver::pre_matrix()
 template <class S> int LinSolver::factor(bool wait)
 {
     SolverWork<S>& w = work<S>();
+    KtScope kts(kt, KT_ILU_FACTOR);
     flags.zero(stream);
     for (int l = 0; l < plan.nlevels; ++l) {
         const int lo = plan.level_ptr[l], hi = plan.level_ptr[l + 1];
@@ -897,6 +899,7 @@ template <class S> int LinSolver::factor(bool wait)
 
 template <class S> void LinSolver::ilu_apply(const S* d, S* v, double relax, const SolveCtl* ctl)
 {
+    KtScope kts(kt, KT_ILU_APPLY);
     SolverWork<S>& w = work<S>();
     const int L = plan.nlevels;
     const int n0 = plan.level_ptr[1];
@@ -919,12 +922,14 @@ template <class S> void LinSolver::ilu_apply(const S* d, S* v, double relax, con
     }
 }
 
-template <class S> void LinSolver::spmv(const S* x, S* y)
+template <class S> void LinSolver::spmv(const S* x, S* y) { spmv_at<S>(x, y, matrix<S>(), dp.col.p); }
+
+template <class S> void LinSolver::spmv_at(const S* x, S* y, const S* val, const int32_t* col)
 {
     const int g = std::min(grid8_for(plan.nb), 4 * kMaxPart);
     lowrank_reduce<S>(x, nullptr);
-    hipLaunchKernelGGL((k_spmv<S, 0>), dim3(g), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p,
-                       matrix<S>(), x, y, (const S*)nullptr, comm ? comm->owner_mask() : (const int8_t*)nullptr, (const SolveCtl*)nullptr,
+    hipLaunchKernelGGL((k_spmv<S, 0>), dim3(g), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, col,
+                       val, x, y, (const S*)nullptr, comm ? comm->owner_mask() : (const int8_t*)nullptr, (const SolveCtl*)nullptr,
                        (double*)nullptr, (double*)nullptr, (const S*)nullptr, (const S*)nullptr, 0, S(0), lowrank, (const int8_t*)nullptr);
 }
 
@@ -1403,6 +1408,7 @@ template <class S> void LinSolver::coarse_begin()
 template <class S> void LinSolver::cpr_prepare()
 {
     SolverWork<S>& w = work<S>();
+    KtScope kts(kt, KT_CPR_SETUP);
     const long ne = plan.nentries;
     if (!w.amg) w.amg.reset(new AmgHierarchy<S>(stream));
     // OPMGPU_AMG_LAG=k (experiment): refresh the pressure hierarchy's numbers only on every k-th matrix
@@ -1498,6 +1504,7 @@ template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, con
     const int g = grid_for(plan.nb);
     const bool coarse = coarse_nsub >= 1;
     const bool fused_rsum = coarse && !(!comm && emulate_ranks > 1) && g <= kCsRowParts;       // real coarse space: restriction fused into the kernel below
+    hipEvent_t kt_a = kt.begin();
     double* const cs_parts = coarse ? cs_buf.p + size_t(2) * coarse_nsub * coarse_nsub + coarse_nsub : nullptr;   // own scratch (the BiCGStab partial arrays are live across an application)
     if (!fused_rsum)
         hipLaunchKernelGGL((k_cpr_sum_eqs<S, 0>), dim3(g), dim3(kBlock), 0, stream, plan.nb, plan.nbp, d, (const S*)w.cprw.p, L0.b.p, S(w.amg->omega0()), (const S*)L0.dinv.p, L0.x.p, ctl,
@@ -1534,7 +1541,11 @@ template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, con
             hipLaunchKernelGGL((k_cs_correct<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, plan.nbp, ns, dp.slice_ptr.p, dp.col.p, dp.rowlen.p, cs_sub.p,
                                (const S*)w.cprw.p, matrix<S>(), (const double*)inv, (const double*)cr, S(w.amg->omega0()), (const S*)L0.dinv.p, L0.b.p, L0.x.p, w.cxc.p, ctl);
     }
+    kt.end(KT_CPR_OTHER, kt_a);
+    kt_a = kt.begin();
     w.amg->vcycle_graph(ctl, true);
+    kt.end(KT_VCYCLE, kt_a);
+    kt_a = kt.begin();
     const S* xp = L0.x.p;
     if (coarse) {
         hipLaunchKernelGGL((k_cs_add<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, (const S*)L0.x.p, (const S*)w.cxc.p, w.hx.p, ctl);
@@ -1553,8 +1564,11 @@ template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, con
     }
     hipLaunchKernelGGL((k_cpr_presidual<S>), dim3(grid8_for(plan.nb)), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p,
                        ((emulate_what & 4) ? pre_matrix<S>() : matrix<S>()), d, xp, w.z.p, comm ? comm->owner_mask() : (const int8_t*)nullptr, ctl);
+    kt.end(KT_CPR_OTHER, kt_a);
     ilu_apply<S>(w.z.p, v, relax, ctl);
+    kt_a = kt.begin();
     hipLaunchKernelGGL((k_cpr_add_p<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, xp, v, ctl);
+    kt.end(KT_CPR_OTHER, kt_a);
 }
 
 template <class S> static void halo(CommBase* c, S* v, hipStream_t s);
@@ -1634,28 +1648,38 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
     bool stop = false, checked = false;      // checked: the last enqueued iteration has been tested and the status block is current
     for (; j <= maxit && !stop; ++j) {
         checked = false;
+        hipEvent_t kt_a = kt.begin();
         hipLaunchKernelGGL((k_update_p<S>), dim3(gv), dim3(kBlock), 0, stream, n, j, eps, d_ctl, h_ctl_dev, (const double*)a_n2, (const double*)a_rho, np_n2,
                            w.r.p, w.v.p, w.p.p);
+        kt.end(KT_VECTOR, kt_a);
         if (cpr) cpr_apply<S>(w.p.p, w.y.p, prm.ilu_relaxation, d_ctl); else ilu_apply<S>(w.p.p, w.y.p, prm.ilu_relaxation, d_ctl);
         if (comm) halo<S>(comm, w.y.p, stream);
+        kt_a = kt.begin();
         lowrank_reduce<S>(w.y.p, d_ctl);
         hipLaunchKernelGGL((k_spmv<S, 1>), dim3(gs), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p, matrix<S>(),
                            w.y.p, w.v.p, w.rt.p, mask, (const SolveCtl*)d_ctl, P_h, (double*)nullptr, pin_p, zin_p, n0, S(prm.ilu_relaxation), lowrank, lightmask);
+        kt.end(KT_SPMV1, kt_a);
         double* a_h = P_h; int np_h = gs; none = nullptr;
         bridge(a_h, none, np_h, 1);
+        kt_a = kt.begin();
         hipLaunchKernelGGL((k_update_xr1<S>), dim3(gv), dim3(kBlock), 0, stream, n, j, eps, d_ctl, h_ctl_dev, (const double*)a_h, np_h, w.y.p, w.v.p,
                            w.x.p, w.r.p, P_n1);
+        kt.end(KT_VECTOR, kt_a);
         double* a_n1 = P_n1; int np_n1 = gv; none = nullptr;
         bridge(a_n1, none, np_n1, 2, true);      // ||r||^2 of the half step is consumed by k_update_xr2: reduced together with <t,r>, <t,t> (slots 2..4)
         if (cpr) cpr_apply<S>(w.r.p, w.y.p, prm.ilu_relaxation, d_ctl); else ilu_apply<S>(w.r.p, w.y.p, prm.ilu_relaxation, d_ctl);
         if (comm) halo<S>(comm, w.y.p, stream);
+        kt_a = kt.begin();
         lowrank_reduce<S>(w.y.p, d_ctl);
         hipLaunchKernelGGL((k_spmv<S, 2>), dim3(gs), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p, matrix<S>(),
                            w.y.p, w.t.p, w.r.p, mask, (const SolveCtl*)d_ctl, P_tr, P_tt, pin_r, zin_r, n0, S(prm.ilu_relaxation), lowrank, lightmask);
+        kt.end(KT_SPMV2, kt_a);
         double* a_tr = P_tr; double* a_tt = P_tt; int np_t = gs;
         bridge(a_tr, a_tt, np_t, 3);
+        kt_a = kt.begin();
         hipLaunchKernelGGL((k_update_xr2<S>), dim3(gv), dim3(kBlock), 0, stream, n, j, d_ctl, h_ctl_dev, (const double*)a_n1, (const double*)a_tr,
                            (const double*)a_tt, np_n1, np_t, w.y.p, w.t.p, w.rt.p, w.x.p, w.r.p, P_n2, P_rho);
+        kt.end(KT_VECTOR, kt_a);
         a_n2 = P_n2; a_rho = P_rho; np_n2 = gv;
         bridge(a_n2, a_rho, np_n2, 5);
         last = j;
@@ -1921,9 +1945,26 @@ template <class S> static double time_kernel_t(LinSolver& ls, int kernel, int re
     const int gv = std::min(grid_for(n), kMaxPart);
     hipEvent_t e0, e1;
     OPMGPU_HIP(hipEventCreate(&e0)); OPMGPU_HIP(hipEventCreate(&e1));
+    // OPMGPU_K_SPMV_COLD: kColdCopies copies of (values, column indices), one per launch in turn: together > 4 x the 256 MiB Infinity
+    // Cache at 100^3, so every launch streams its matrix from HBM like a solve on a large deck does
+    constexpr int kColdCopies = 4;
+    const size_t vbytes = size_t(P.nentries) * 9 * sizeof(S), cbytes = (size_t(P.nentries) * sizeof(int32_t) + 255) / 256 * 256;
+    if (kernel == OPMGPU_K_SPMV_COLD) {
+        ls.cold.alloc(kColdCopies * (vbytes + cbytes));
+        for (int c = 0; c < kColdCopies; ++c) {
+            OPMGPU_HIP(hipMemcpyAsync(ls.cold.p + c * (vbytes + cbytes), ls.matrix<S>(), vbytes, hipMemcpyDeviceToDevice, ls.stream));
+            OPMGPU_HIP(hipMemcpyAsync(ls.cold.p + c * (vbytes + cbytes) + vbytes, ls.dp.col.p, size_t(P.nentries) * sizeof(int32_t), hipMemcpyDeviceToDevice, ls.stream));
+        }
+    }
+    int rot = 0;
     auto launch = [&]() {
         switch (kernel) {
         case OPMGPU_K_SPMV: ls.spmv<S>(w.p.p, w.v.p); break;
+        case OPMGPU_K_SPMV_COLD: {
+            const char* base = ls.cold.p + (rot++ % kColdCopies) * (vbytes + cbytes);
+            ls.spmv_at<S>(w.p.p, w.v.p, reinterpret_cast<const S*>(base), reinterpret_cast<const int32_t*>(base + vbytes));
+            break;
+        }
         case OPMGPU_K_ILU_APPLY: ls.ilu_apply<S>(w.p.p, w.y.p, relax, nullptr); break;
         case OPMGPU_K_CPR_APPLY: ls.cpr_apply<S>(w.p.p, w.y.p, relax, nullptr); break;
         case OPMGPU_K_VCYCLE: w.amg->vcycle(nullptr, false); break;
@@ -1947,6 +1988,7 @@ template <class S> static double time_kernel_t(LinSolver& ls, int kernel, int re
     float ms = 0.f;
     OPMGPU_HIP(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (kernel == OPMGPU_K_SPMV_COLD) ls.cold.release();
     return double(ms) / reps;
 }
 
@@ -1974,6 +2016,7 @@ double LinSolver::time_kernel(int kernel, int reps, int single_precision)
     template int LinSolver::factor<S>(bool);                                                 \
     template void LinSolver::ilu_apply<S>(const S*, S*, double, const SolveCtl*);        \
     template void LinSolver::spmv<S>(const S*, S*);                                      \
+    template void LinSolver::spmv_at<S>(const S*, S*, const S*, const int32_t*);        \
     template void LinSolver::cpr_prepare<S>();                                           \
     template const S* LinSolver::pre_matrix<S>();                                        \
     template void LinSolver::coarse_setup<S>(bool);                                      \

@@ -129,6 +129,7 @@ public:
     int factor_status() const { return (h_flags[0] & 1) ? OPMGPU_ESINGULAR : OPMGPU_OK; }   // valid after a stream synchronisation
     template <class S> void ilu_apply(const S* d, S* v, double relax, const SolveCtl* ctl = nullptr);
     template <class S> void spmv(const S* x, S* y);
+    template <class S> void spmv_at(const S* x, S* y, const S* val, const int32_t* col);    // the same operator on another copy of the matrix arrays
     // CPR (solver_approach=cpr): build / refresh the pressure AMG for the current matrix; two-stage apply
     template <class S> void cpr_prepare();
     template <class S> void cpr_apply(const S* d, S* v, double relax, const SolveCtl* ctl);
@@ -151,6 +152,8 @@ public:
 
     // timing of a single kernel on this stream (HIP events), ms per launch
     double time_kernel(int kernel, int reps, int single_precision);
+    KernelTimers kt;               // in-situ timing of kernel classes during real iterations (opmgpu_kernel_timing)
+    DevArray<char> cold;           // OPMGPU_K_SPMV_COLD: extra copies of the matrix values + column indices
 
     Plan plan;
     DevPlan dp;

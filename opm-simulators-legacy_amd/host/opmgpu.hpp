@@ -111,7 +111,7 @@ public:
 
     /// wells on the device (StandardWells restated in csrc/wells.hip): topology + controls, then the WellState fields
     void setDeviceWells(const opmgpu_wells& wells) { throw_on_status(ctx_, opmgpu_set_device_wells(ctx_, &wells)); device_wells_ = wells.nw > 0; }
-    void setWellState(const double* bhp, const double* well_rates, const double* perf_rates = nullptr) { throw_on_status(ctx_, opmgpu_well_state_set(ctx_, bhp, well_rates, perf_rates)); }
+    void setWellState(const double* bhp, const double* well_rates, const double* perf_press = nullptr, const double* perf_rates = nullptr) { throw_on_status(ctx_, opmgpu_well_state_set(ctx_, bhp, well_rates, perf_press, perf_rates)); }
     void getWellState(double* bhp, double* well_rates, double* perf_press = nullptr, double* perf_rates = nullptr) { throw_on_status(ctx_, opmgpu_well_state_get(ctx_, bhp, well_rates, perf_press, perf_rates)); }
     /// well part of getConvergence (:1769-1779)
     bool wellsConverged(const ConvergenceReport& r)

@@ -15,7 +15,9 @@ OK, EINVAL, ENODEVICE, ENUMERICAL, ELINSOLVE, EBREAKDOWN, ESINGULAR, ENOMEM, ECO
 HC_GAS_ONLY, HC_GAS_AND_OIL, HC_OIL_ONLY = 0, 1, 2
 RELAX_DAMPEN, RELAX_SOR = 0, 1
 ORDER_NATURAL, ORDER_MULTICOLOR = 0, 1
-K_SPMV, K_ILU_APPLY, K_ILU_FACTOR, K_ASSEMBLE, K_DOT, K_AXPY, K_PROPS, K_STREAM_COPY, K_CPR_APPLY, K_VCYCLE, K_CPR_SETUP = range(11)
+K_SPMV, K_ILU_APPLY, K_ILU_FACTOR, K_ASSEMBLE, K_DOT, K_AXPY, K_PROPS, K_STREAM_COPY, K_CPR_APPLY, K_VCYCLE, K_CPR_SETUP, K_SPMV_COLD = range(12)
+KT_NAMES = ["cell_props", "flux", "wells", "convergence", "ilu0_factor", "cpr_setup", "spmv_fused_dot1", "spmv_fused_dot2", "ilu0_apply", "amg_vcycle",
+            "cpr_other", "vector_updates", "update_state"]
 PERF_K = 36
 UNIQUE_ID_BYTES = 128
 
@@ -51,7 +53,14 @@ class Tables(C.Structure):
 
 class WellsSpec(C.Structure):
     _fields_ = [("nw", C.c_int32), ("well_connpos", _ip), ("well_cells", _ip), ("WI", _dp), ("type", _ip), ("allow_cf", _ip),
-                ("depth_ref", _dp), ("comp_frac", _dp), ("ctrl_type", _ip), ("ctrl_target", _dp), ("ctrl_distr", _dp)]
+                ("depth_ref", _dp), ("comp_frac", _dp), ("ctrl_type", _ip), ("ctrl_target", _dp), ("ctrl_distr", _dp),
+                ("ctrl_ptr", _ip), ("ctrl_vfp", _ip), ("ctrl_alq", _dp)]
+
+
+class VfpTable(C.Structure):
+    _fields_ = [("id", C.c_int32), ("is_injector", C.c_int32), ("flo_type", C.c_int32), ("wfr_type", C.c_int32), ("gfr_type", C.c_int32),
+                ("datum_depth", C.c_double), ("nflo", C.c_int32), ("nthp", C.c_int32), ("nwfr", C.c_int32), ("ngfr", C.c_int32),
+                ("nalq", C.c_int32), ("flo", _dp), ("thp", _dp), ("wfr", _dp), ("gfr", _dp), ("alq", _dp), ("data", _dp)]
 
 
 class Params(C.Structure):
@@ -61,7 +70,9 @@ class Params(C.Structure):
                 ("linear_solver_reduction", C.c_double), ("linear_solver_maxiter", C.c_int32),
                 ("ilu_relaxation", C.c_double), ("ilu_ordering", C.c_int32),
                 ("ignore_convergence_failure", C.c_int32), ("use_cpr", C.c_int32),
-                ("newton_use_gmres", C.c_int32), ("linear_solver_restart", C.c_int32)]
+                ("newton_use_gmres", C.c_int32), ("linear_solver_restart", C.c_int32),
+                ("solve_welleq_initially", C.c_int32), ("tolerance_wells", C.c_double), ("tolerance_well_control", C.c_double),
+                ("dbhp_max_rel", C.c_double)]
 
 
 def default_params(**over):
@@ -73,6 +84,7 @@ def default_params(**over):
     p.linear_solver_reduction, p.linear_solver_maxiter = 1e-2, 150
     p.ilu_relaxation, p.ilu_ordering, p.ignore_convergence_failure, p.use_cpr = 0.9, ORDER_MULTICOLOR, 0, 0
     p.newton_use_gmres, p.linear_solver_restart = 0, 40
+    p.solve_welleq_initially, p.tolerance_wells, p.tolerance_well_control, p.dbhp_max_rel = 1, 1e-4, 1e-7, 1.0
     for k, v in over.items():
         if k == "matbalscale":
             p.matbalscale[:] = list(v)
@@ -122,9 +134,14 @@ SIGNATURES = {
     "opmgpu_get_cpr_weights": (C.c_int, [C.c_void_p, _dp]),
     "opmgpu_set_solve_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "opmgpu_set_device_wells": (C.c_int, [C.c_void_p, C.POINTER(WellsSpec)]),
-    "opmgpu_well_state_set": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
+    "opmgpu_well_state_set": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp]),
     "opmgpu_well_state_get": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp]),
     "opmgpu_well_convergence": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "opmgpu_set_vfp_tables": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(VfpTable)]),
+    "opmgpu_well_controls_set": (C.c_int, [C.c_void_p, _ip, _dp]),
+    "opmgpu_well_controls_get": (C.c_int, [C.c_void_p, _ip, _dp, _ip, _ip]),
+    "opmgpu_perf_pvt": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "opmgpu_average_b": (C.c_int, [C.c_void_p, _dp]),
     "opmgpu_save_state": (C.c_int, [C.c_void_p]),
     "opmgpu_restore_state": (C.c_int, [C.c_void_p]),
     "opmgpu_relative_change": (C.c_int, [C.c_void_p, _dp]),
@@ -144,6 +161,8 @@ SIGNATURES = {
     "opmgpu_get_jacobian_bsr": (C.c_int, [C.c_void_p, _ip, _ip, _dp]),
     "opmgpu_time_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp]),
     "opmgpu_last_timings": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
+    "opmgpu_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "opmgpu_kernel_timing_get": (C.c_int, [C.c_void_p, _dp, C.POINTER(C.c_int64)]),
     "opmgpu_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "opmgpu_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint8), C.c_int32, C.c_int, _ip, _ip, _ip, _ip, _ip]),
     "opmgpu_plan_ordering": (C.c_int, [C.c_int, _ip, _ip, C.c_int, _ip, _ip, _ip]),

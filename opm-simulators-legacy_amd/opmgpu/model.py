@@ -283,6 +283,20 @@ class GpuBlackoilModel:
         self._chk(self.lib.opmgpu_perf_props(self.ctx, capi.dptr(out)))
         return out
 
+    def perfPvtAt(self, press):
+        """b (nperf x 3), rsSat, rvSat of the perforated cells at the given pressures (opmgpu_perf_pvt) -- what the host well
+        model's computeWellConnectionPressures needs (StandardWells_impl.hpp:218-296)"""
+        press = capi.f64(press)
+        out = np.zeros((press.size, 5))
+        self._chk(self.lib.opmgpu_perf_pvt(self.ctx, capi.dptr(press), capi.dptr(out)))
+        return out[:, :3], out[:, 3].copy(), out[:, 4].copy()
+
+    def averageB(self):
+        """B_avg of getWellConvergence for the host well model's pre-solve (opmgpu_average_b)"""
+        B = np.zeros(3)
+        self._chk(self.lib.opmgpu_average_b(self.ctx, capi.dptr(B)))
+        return B
+
     def addWellTerms(self, resid_delta, rc, blocks):
         rc = capi.i32(rc)
         nblk = rc.size // 2

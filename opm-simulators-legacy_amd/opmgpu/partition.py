@@ -84,9 +84,9 @@ class LocalDomain:
                 raise ValueError("well %s straddles ranks %s" % (wells.name[w], owners.tolist()))
             if owners[0] != self.rank:
                 continue
-            ctrl = (wells.ctrl_type[w], wells.ctrl_target[w], wells.ctrl_distr[w])
+            ctrls = wells.controls[w]
             out.add_well(wells.name[w], wells.type[w], wells.depth_ref[w], g2l[cells], wells.WI[wells.connpos[w]:wells.connpos[w + 1]],
-                         wells.comp_frac[w], ctrl, allow_cf=wells.allow_cf[w])
+                         wells.comp_frac[w], ctrls[0], allow_cf=wells.allow_cf[w], limits=ctrls[1:])
             self.well_index.append(w)
         return out
 
@@ -114,16 +114,22 @@ def make_unique_id():
     return bytes(buf)
 
 
-def build_distributed_model(nx, ny, nz, tables, params, rank, world, local_rank, lognormal_sigma=0.5, seed=12345, perturb=0.002):
+def build_distributed_model(nx, ny, nz, tables, params, rank, world, local_rank, lognormal_sigma=0.5, seed=12345, perturb=0.002, deck="cart"):
     """Every rank builds the same global synthetic deck, keeps its slab (+ghosts) and joins the RCCL communicator.
-    The unique id travels through torch.distributed (backend nccl = RCCL)."""
+    The unique id travels through torch.distributed (backend nccl = RCCL).  deck = "spe10like": BASELINE configs[3], the 60 x 220 x 85
+    deck with sigma_lnK = 2.5 cut along j (27-28 rows of 60 x 85 cells per GPU at N = 8: strong scaling by construction)."""
     import torch
     import torch.distributed as dist
     from . import decks
     from .model import GpuBlackoilModel
-    grid = decks.cartesian_grid(nx, ny, nz, lognormal_sigma=lognormal_sigma, seed=seed)
-    st = decks.initial_state(grid, tables, perturb=perturb, seed=seed)
-    part = slab_partition(grid, world)
+    if deck == "spe10like":
+        grid = decks.cartesian_grid(60, 220, 85, dx=6.096, dy=3.048, dz=0.6096, tops=3657.6, lognormal_sigma=2.5, seed=10)
+        st = decks.initial_state(grid, tables, p_ref=413.0 * decks.BAR, z_ref=3657.6, perturb=1e-4, seed=10, gas_cap_fraction=0.0, gas_only_fraction=0.0)
+        part = slab_partition(grid, world, axis=1)
+    else:
+        grid = decks.cartesian_grid(nx, ny, nz, lognormal_sigma=lognormal_sigma, seed=seed)
+        st = decks.initial_state(grid, tables, perturb=perturb, seed=seed)
+        part = slab_partition(grid, world)
     dom = LocalDomain(grid, part, rank)
     model = GpuBlackoilModel(dom.grid, tables, params, device=local_rank)
     dev = torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else torch.device("cpu")      # gloo: one-GPU rehearsal

@@ -11,16 +11,25 @@ The reservoir side is any backend with the GpuBlackoilModel interface (the devic
 in the parity tests): per-perforation cell properties come from `perfProps`, the Schur-reduced well
 terms go back through `addWellTerms` / `addWellRhs`, the perforated cells' increments through `perfDx`.
 
-Not restated (documented simplifications): control switching (updateWellControls), the explicit well
-pre-solve (solveWellEq), THP/VFP and group controls, RESERVOIR_RATE conversion, efficiency factors;
-connection densities use the perforated cells' own b / rs / rv instead of re-evaluating the PVT at the
-average well-block pressure.
+  updateWellControls / updateWellStateWithTarget   StandardWells_impl.hpp:709-800 / :1452-1550 (+ wellhelpers::constraintBroken)
+  solveWellEq (explicit well pre-solve at the initial assembly, default on)   BlackoilModelBase_impl.hpp:1018-1133
+  THP control through VFP tables (opmgpu/vfp.py)   StandardWells_impl.hpp:655-700, :895-960
+  computePropertiesForWellConnectionPressures (PVT at the average well-block pressure)   :218-296
+
+Not restated: group controls / guide rates (WellCollection), RESERVOIR_RATE conversion coefficients (a RESERVOIR_RATE control is
+treated like the reference's control equation treats it: a weighted rate sum with the given distribution), efficiency factors.
 """
 import numpy as np
 
 INJECTOR, PRODUCER = 0, 1
-BHP, SURFACE_RATE = 0, 1
+BHP, SURFACE_RATE, THP, RESERVOIR_RATE = 0, 1, 2, 3          # WellControlType (opm-core well_controls.h), our numbering
 GRAVITY = 9.80665
+
+
+def _ctrl(c):
+    """(type, target[, distr[, vfp_table_id[, alq]]]) -> normalised tuple"""
+    distr = np.asarray(c[2] if len(c) > 2 and c[2] is not None else (0, 0, 0), float)
+    return (int(c[0]), float(c[1]), distr, int(c[3]) if len(c) > 3 else 0, float(c[4]) if len(c) > 4 else 0.0)
 
 
 class AD:
@@ -77,17 +86,31 @@ class Wells:
     def __init__(self):
         self.type, self.depth_ref, self.comp_frac, self.allow_cf = [], [], [], []
         self.connpos, self.cells, self.WI = [0], [], []
-        self.ctrl_type, self.ctrl_target, self.ctrl_distr = [], [], []
+        self.ctrl_type, self.ctrl_target, self.ctrl_distr = [], [], []        # control 0 of each well = its initial current control
+        self.controls = []                                                     # all controls of each well (WellControls), control 0 first
         self.name = []
 
-    def add_well(self, name, wtype, depth_ref, cells, WI, comp_frac, control, allow_cf=True):
+    def add_well(self, name, wtype, depth_ref, cells, WI, comp_frac, control, allow_cf=True, limits=()):
+        """`control` is the well's initial current control; `limits` are its other controls -- inequality constraints that
+        updateWellControls switches to when broken (e.g. a BHP limit on a rate-controlled well)."""
         self.name.append(name); self.type.append(wtype); self.depth_ref.append(float(depth_ref))
         self.comp_frac.append(np.asarray(comp_frac, float)); self.allow_cf.append(bool(allow_cf))
         self.cells += [int(c) for c in cells]; self.WI += [float(w) for w in np.broadcast_to(WI, (len(cells),))]
         self.connpos.append(len(self.cells))
         self.ctrl_type.append(control[0]); self.ctrl_target.append(float(control[1]))
-        self.ctrl_distr.append(np.asarray(control[2] if len(control) > 2 else (0, 0, 0), float))
+        self.ctrl_distr.append(np.asarray(control[2] if len(control) > 2 and control[2] is not None else (0, 0, 0), float))
+        self.controls.append([_ctrl(control)] + [_ctrl(c) for c in limits])
         return self
+
+    def control_arrays(self):
+        """flat WellControls arrays for the device: ctrl_ptr[nw+1], type, target, distr[n*3], vfp id, alq"""
+        ptr, typ, tgt, dis, vfp, alq = [0], [], [], [], [], []
+        for cl in self.controls:
+            for c in cl:
+                typ.append(c[0]); tgt.append(c[1]); dis.append(c[2]); vfp.append(c[3]); alq.append(c[4])
+            ptr.append(len(typ))
+        return (np.asarray(ptr, np.int32), np.asarray(typ, np.int32), np.asarray(tgt, float), np.asarray(dis, float).reshape(-1, 3),
+                np.asarray(vfp, np.int32), np.asarray(alq, float))
 
     @property
     def nw(self):
@@ -102,12 +125,18 @@ class Wells:
 
 
 class WellState:
-    """WellStateFullyImplicitBlackoil fields used here: bhp, wellRates (well-major), perfPress, perfPhaseRates."""
+    """WellStateFullyImplicitBlackoil fields used here: bhp, wellRates (well-major), perfPress, perfPhaseRates, currentControls, thp.
+    Initial values as WellState::init / WellStateFullyImplicitBlackoil::init set them (opm-core / opm-simulators, external: restated
+    from the published code): a BHP-controlled well starts at its target with zero rates, a rate-controlled one at its rate target
+    with bhp = 1.01 / 0.99 x the first perforated cell's pressure; perfPress = the perforated cells' pressures, perfPhaseRates =
+    the well rates divided evenly over the perforations."""
 
     def __init__(self, wells, cell_pressure):
         nw = wells.nw
         self.bhp, self.qs = np.zeros(nw), np.zeros((nw, 3))
         self.perf_press = np.zeros(wells.nperf); self.perf_rates = np.zeros((wells.nperf, 3))
+        self.current = np.zeros(nw, np.int32)          # currentControls(): index into the well's controls
+        self.thp = np.zeros(nw)
         for w in range(nw):
             p0 = cell_pressure[wells.cells[wells.connpos[w]]]
             if wells.ctrl_type[w] == BHP:
@@ -116,7 +145,9 @@ class WellState:
                 self.bhp[w] = p0 * (1.01 if wells.type[w] == INJECTOR else 0.99)
                 d = wells.ctrl_distr[w]
                 self.qs[w] = wells.ctrl_target[w] * d / max(d.sum(), 1e-300) if wells.type[w] == PRODUCER else wells.ctrl_target[w] * wells.comp_frac[w]
-            self.perf_press[wells.connpos[w]:wells.connpos[w + 1]] = self.bhp[w]
+            lo, hi = wells.connpos[w], wells.connpos[w + 1]
+            self.perf_press[lo:hi] = np.asarray(cell_pressure)[np.asarray(wells.cells[lo:hi], int)]
+            self.perf_rates[lo:hi] = self.qs[w] / max(hi - lo, 1)
 
     def copy(self):
         import copy
@@ -125,6 +156,7 @@ class WellState:
     def assign(self, other):
         """state = last_state (AdaptiveTimeStepping_impl.hpp:346-347), in place so that holders of this object see it"""
         self.bhp[:], self.qs[:], self.perf_press[:], self.perf_rates[:] = other.bhp, other.qs, other.perf_press, other.perf_rates
+        self.current[:], self.thp[:] = other.current, other.thp
 
 
 def connection_densities(wells, perf_rates, b_perf, rsmax_perf, rvmax_perf, surf_dens_perf):
@@ -170,19 +202,174 @@ def connection_pressure_delta(wells, z_perf, dens_perf, gravity=GRAVITY):
 
 class StandardWellsHost:
     def __init__(self, wells, z_cells, surface_density_wog, gravity=GRAVITY, dbhp_max_rel=1.0,
-                 tolerance_wells=1e-4, tolerance_well_control=1e-7):
+                 tolerance_wells=1e-4, tolerance_well_control=1e-7, vfp_tables=(), solve_welleq_initially=True):
         self.w, self.gravity, self.dbhp_max_rel = wells, gravity, dbhp_max_rel
         self.z_perf = np.asarray(z_cells, float)[np.asarray(wells.cells, int)]
         self.surf_dens = np.asarray(surface_density_wog, float).reshape(1, 3)
         self.tol_wells, self.tol_ctrl = tolerance_wells, tolerance_well_control
+        self.solve_welleq_initially = solve_welleq_initially          # BlackoilModelParameters.cpp:96
         self.cdp = np.zeros(wells.nperf)
+        self.perf_dens = np.zeros(wells.nperf)                        # well_perforation_densities_
+        self.vfp_prod = {t.id: t for t in vfp_tables if not t.is_injector}
+        self.vfp_inj = {t.id: t for t in vfp_tables if t.is_injector}
+        self.vfp_active = any(c[0] == THP for cl in wells.controls for c in cl)      # isVFPActive (BlackoilModelBase_impl.hpp:982-1008)
+        self.well_iterations = 0
         self._sys = None
 
-    # computeWellConnectionPressures: once per time step, from the explicit state (BlackoilModelBase_impl.hpp:797-805)
-    def compute_connection_pressures(self, pp, ws):
-        b = pp[:, 3:6, 0]
-        dens = connection_densities(self.w, ws.perf_rates, b, pp[:, 1, 0], pp[:, 2, 0], np.repeat(self.surf_dens, self.w.nperf, 0))
-        self.cdp = connection_pressure_delta(self.w, self.z_perf, dens, self.gravity)
+    # computeWellConnectionPressures (StandardWells_impl.hpp:336-358): once per time step from the explicit state
+    # (BlackoilModelBase_impl.hpp:797-805), again after a converged solveWellEq (:1122), and before updateWellControls when VFP
+    # tables are active (:771-776).  `pvt_at(avg_press)` -> (b[nperf,3], rsmax, rvmax) evaluates the perforated cells' PVT at the
+    # AVERAGE WELL-BLOCK PRESSURE with the cells' rs / rv / phase condition (computePropertiesForWellConnectionPressures, :218-296);
+    # without it the cells' own values from `pp` are used.
+    def compute_connection_pressures(self, pp, ws, pvt_at=None):
+        W = self.w
+        if pvt_at is not None:
+            avg = np.zeros(W.nperf)
+            for w in range(W.nw):
+                for perf in range(W.connpos[w], W.connpos[w + 1]):
+                    p_above = ws.bhp[w] if perf == W.connpos[w] else ws.perf_press[perf - 1]
+                    avg[perf] = (ws.perf_press[perf] + p_above) / 2
+            b, rsmax, rvmax = pvt_at(avg)
+        else:
+            b, rsmax, rvmax = pp[:, 3:6, 0], pp[:, 1, 0], pp[:, 2, 0]
+        self.perf_dens = connection_densities(W, ws.perf_rates, b, rsmax, rvmax, np.repeat(self.surf_dens, W.nperf, 0))
+        self.cdp = connection_pressure_delta(W, self.z_perf, self.perf_dens, self.gravity)
+
+    # ---- THP / VFP helpers ------------------------------------------------------------------------------------------------
+    def _vfp(self, w, table_id):
+        tabs = self.vfp_inj if self.w.type[w] == INJECTOR else self.vfp_prod
+        if table_id not in tabs:
+            raise ValueError("well %s: VFP table %d does not exist" % (self.w.name[w], table_id))
+        return tabs[table_id]
+
+    def _vfp_dp(self, w, table):
+        """wellhelpers::computeHydrostaticCorrection with the density of the well's FIRST perforation"""
+        W = self.w
+        from .vfp import hydrostatic_correction
+        return hydrostatic_correction(W.depth_ref[w], table.datum_depth, self.perf_dens[W.connpos[w]], self.gravity, W.connpos[w + 1] > W.connpos[w])
+
+    def _bhp_from_thp(self, w, ctrl, qs):
+        """bhp the THP control asks for at the rates qs = (aqua, liquid, vapour): value (hydrostatic correction applied) and d/dqs"""
+        table = self._vfp(w, ctrl[3])
+        v, dq = table.bhp_dq(qs[0], qs[1], qs[2], ctrl[1], ctrl[4])
+        return v - self._vfp_dp(w, table), dq
+
+    # ---- updateWellControls (StandardWells_impl.hpp:709-800) ---------------------------------------------------------------
+    def _update_well_state_with_target(self, w, current, ws):
+        """updateWellStateWithTarget (:1452-1550): targets become the initial guesses of the well unknowns"""
+        W = self.w
+        typ, target, distr = W.controls[w][current][:3]
+        if typ == BHP:
+            ws.bhp[w] = target
+        elif typ == THP:
+            ws.bhp[w] = self._bhp_from_thp(w, W.controls[w][current], ws.qs[w])[0]
+        elif typ == SURFACE_RATE:
+            if W.type[w] == INJECTOR:
+                for a in range(3):
+                    if W.comp_frac[w][a] > 0.0:
+                        ws.qs[w, a] = target * W.comp_frac[w][a]
+            else:       # only single-phase rate targets (orat / wrat / grat, not lrat) seed the rates
+                if int((distr > 0.0).sum()) < 2:
+                    for a in range(3):
+                        if distr[a] > 0.0:
+                            ws.qs[w, a] = target * distr[a]
+        # RESERVOIR_RATE: nothing (existing rates stay)
+
+    def _constraint_broken(self, w, ctrl, ws):
+        """wellhelpers::constraintBroken (opm-simulators WellHelpers.hpp, external): injectors break a limit from above,
+        producers from below (their rates are negative)"""
+        typ, target, distr = ctrl[:3]
+        val = ws.bhp[w] if typ == BHP else (ws.thp[w] if typ == THP else float(np.dot(ws.qs[w], distr)))
+        return val > target if self.w.type[w] == INJECTOR else val < target
+
+    def update_well_controls(self, ws):
+        """for every well: apply the current control's target to the well state, then switch to the FIRST other control whose
+        constraint is broken; repeat until none is (at most 2 * ncontrols rounds, then NumericalIssue like the reference)."""
+        from .model import NumericalIssue
+        W = self.w
+        switched = []
+        for w in range(W.nw):
+            ctrls = W.controls[w]
+            current, rounds = int(ws.current[w]), 0
+            while True:
+                self._update_well_state_with_target(w, current, ws)
+                broken = next((k for k in range(len(ctrls)) if k != current and self._constraint_broken(w, ctrls[k], ws)), None)
+                if broken is not None:
+                    switched.append((w, current, broken))
+                    ws.current[w] = current = broken
+                rounds += 1
+                if rounds > 2 * len(ctrls):
+                    raise NumericalIssue("Could not find proper control within %d iterations!" % rounds)
+                if broken is None:
+                    break
+        return switched
+
+    # ---- well equations ----------------------------------------------------------------------------------------------------
+    def _well_system(self, w, pp, ws, const_cells=False):
+        """computeWellFlux + addWellFluxEq + addWellControlEq of one well as dense AD: returns (cq_s[3] AD over [3n cell vars | qs(3) | bhp], E values (4), E Jacobian (4 x nv))"""
+        W = self.w
+        lo, hi = W.connpos[w], W.connpos[w + 1]
+        n = hi - lo
+        nv = 3 * n + 4
+        I = np.arange(lo, hi)
+
+        def perf_q(k):      # perf quantity k of OPMGPU_PERF_K as AD w.r.t. its own cell's (P, Sw, Xvar)
+            j = np.zeros((n, nv))
+            if not const_cells:
+                for d in range(3):
+                    j[np.arange(n), 3 * np.arange(n) + d] = pp[I, k, 1 + d]
+            return AD(pp[I, k, 0], j)
+        p_cell, rs, rv = perf_q(0), perf_q(1), perf_q(2)
+        b = [perf_q(3), perf_q(4), perf_q(5)]
+        mob = [perf_q(6), perf_q(7), perf_q(8)]
+        jb = np.zeros((1, nv)); jb[0, 3 * n + 3] = 1.0
+        bhp = AD(np.array([ws.bhp[w]]), jb)
+        qs = []
+        for a in range(3):
+            jq = np.zeros((1, nv)); jq[0, 3 * n + a] = 1.0
+            qs.append(AD(np.array([ws.qs[w, a]]), jq))
+        Tw = np.asarray(W.WI[lo:hi])
+        drawdown = p_cell - (bhp.bcast(n) + self.cdp[lo:hi])
+        sel_inj = (drawdown.v < 0).astype(float); sel_prod = 1.0 - sel_inj
+        if not W.allow_cf[w]:
+            if W.type[w] == INJECTOR and sel_inj.sum() > 0:
+                sel_prod[:] = 0.0
+            elif W.type[w] == PRODUCER and sel_prod.sum() > 0:
+                sel_inj[:] = 0.0
+        cq_ps = [b[a] * (-(sel_prod * Tw) * (mob[a] * drawdown)) for a in range(3)]     # flow INTO the wellbore
+        cq_ps_oil, cq_ps_gas = cq_ps[1], cq_ps[2]
+        cq_ps[2] = cq_ps[2] + rs * cq_ps_oil
+        cq_ps[1] = cq_ps[1] + rv * cq_ps_gas
+        total_mob = mob[0] + mob[1] + mob[2]
+        cqt_i = -(sel_inj * Tw) * (total_mob * drawdown)                                # flow OUT of the wellbore
+        compi = W.comp_frac[w]
+        wbq = []
+        for a in range(3):
+            inj = qs[a] if qs[a].v[0] > 0 else AD.const([0.0], nv)
+            wbq.append(compi[a] * inj - cq_ps[a].sum())
+        wbqt = wbq[0] + wbq[1] + wbq[2]
+        alive = wbqt.v[0] != 0.0
+        cmix = [(wbq[a] / wbqt if alive else AD.const([compi[a]], nv)).bcast(n) for a in range(3)]
+        d = 1.0 - rv * rs
+        vol = cmix[0] / b[0] + ((cmix[1] - rv * cmix[2]) / d) / b[1] + ((cmix[2] - rs * cmix[1]) / d) / b[2]
+        cqt_is = cqt_i / vol
+        cq_s = [cq_ps[a] + cmix[a] * cqt_is for a in range(3)]
+        # well equations: E = [q_s - sum cq_s (3), control (1)]
+        E = [qs[a] - cq_s[a].sum() for a in range(3)]
+        ctrl = W.controls[w][int(ws.current[w])]
+        if not alive:
+            ce = qs[0] + qs[1] + qs[2]
+        elif ctrl[0] == BHP:
+            ce = bhp - ctrl[1]
+        elif ctrl[0] == THP:        # bhp - bhp_from_thp(qs) + dp (:944-949)
+            v, dq = self._bhp_from_thp(w, ctrl, ws.qs[w])
+            jt = np.zeros((1, nv)); jt[0, 3 * n:3 * n + 3] = dq
+            ce = bhp - AD(np.array([v]), jt)
+        else:                       # SURFACE_RATE / RESERVOIR_RATE
+            ce = ctrl[2][0] * qs[0] + ctrl[2][1] * qs[1] + ctrl[2][2] * qs[2] - ctrl[1]
+        E.append(ce)
+        Ev = np.array([e.v[0] for e in E]); Ej = np.vstack([e.j for e in E])
+        return cq_s, Ev, Ej
 
     # computeWellFlux + addWellFluxEq + addWellControlEq for all wells; Schur-reduce every well onto its cells
     def assemble(self, pp, ws):
@@ -198,57 +385,7 @@ class StandardWellsHost:
             n = hi - lo
             nv = 3 * n + 4
             I = np.arange(lo, hi)
-
-            def perf_q(k):      # perf quantity k of OPMGPU_PERF_K as AD w.r.t. its own cell's (P, Sw, Xvar)
-                j = np.zeros((n, nv))
-                for d in range(3):
-                    j[np.arange(n), 3 * np.arange(n) + d] = pp[I, k, 1 + d]
-                return AD(pp[I, k, 0], j)
-            p_cell, rs, rv = perf_q(0), perf_q(1), perf_q(2)
-            b = [perf_q(3), perf_q(4), perf_q(5)]
-            mob = [perf_q(6), perf_q(7), perf_q(8)]
-            jb = np.zeros((1, nv)); jb[0, 3 * n + 3] = 1.0
-            bhp = AD(np.array([ws.bhp[w]]), jb)
-            qs = []
-            for a in range(3):
-                jq = np.zeros((1, nv)); jq[0, 3 * n + a] = 1.0
-                qs.append(AD(np.array([ws.qs[w, a]]), jq))
-            Tw = np.asarray(W.WI[lo:hi])
-            drawdown = p_cell - (bhp.bcast(n) + self.cdp[lo:hi])
-            sel_inj = (drawdown.v < 0).astype(float); sel_prod = 1.0 - sel_inj
-            if not W.allow_cf[w]:
-                if W.type[w] == INJECTOR and sel_inj.sum() > 0:
-                    sel_prod[:] = 0.0
-                elif W.type[w] == PRODUCER and sel_prod.sum() > 0:
-                    sel_inj[:] = 0.0
-            cq_ps = [b[a] * (-(sel_prod * Tw) * (mob[a] * drawdown)) for a in range(3)]     # flow INTO the wellbore
-            cq_ps_oil, cq_ps_gas = cq_ps[1], cq_ps[2]
-            cq_ps[2] = cq_ps[2] + rs * cq_ps_oil
-            cq_ps[1] = cq_ps[1] + rv * cq_ps_gas
-            total_mob = mob[0] + mob[1] + mob[2]
-            cqt_i = -(sel_inj * Tw) * (total_mob * drawdown)                                # flow OUT of the wellbore
-            compi = W.comp_frac[w]
-            wbq = []
-            for a in range(3):
-                inj = qs[a] if qs[a].v[0] > 0 else AD.const([0.0], nv)
-                wbq.append(compi[a] * inj - cq_ps[a].sum())
-            wbqt = wbq[0] + wbq[1] + wbq[2]
-            alive = wbqt.v[0] != 0.0
-            cmix = [(wbq[a] / wbqt if alive else AD.const([compi[a]], nv)).bcast(n) for a in range(3)]
-            d = 1.0 - rv * rs
-            vol = cmix[0] / b[0] + ((cmix[1] - rv * cmix[2]) / d) / b[1] + ((cmix[2] - rs * cmix[1]) / d) / b[2]
-            cqt_is = cqt_i / vol
-            cq_s = [cq_ps[a] + cmix[a] * cqt_is for a in range(3)]
-            # well equations: E = [q_s - sum cq_s (3), control (1)]
-            E = [qs[a] - cq_s[a].sum() for a in range(3)]
-            if not alive:
-                ctrl = qs[0] + qs[1] + qs[2]
-            elif W.ctrl_type[w] == BHP:
-                ctrl = bhp - W.ctrl_target[w]
-            else:
-                ctrl = W.ctrl_distr[w][0] * qs[0] + W.ctrl_distr[w][1] * qs[1] + W.ctrl_distr[w][2] * qs[2] - W.ctrl_target[w]
-            E.append(ctrl)
-            Ev = np.array([e.v[0] for e in E]); Ej = np.vstack([e.j for e in E])
+            cq_s, Ev, Ej = self._well_system(w, pp, ws)
             C, D = Ej[:, :3 * n], Ej[:, 3 * n:]
             # cell rows: R_a[cell_i] -= cq_s[a][i]   (addWellContributionToMassBalanceEq)
             Jc = np.zeros((3 * n, nv))
@@ -271,22 +408,76 @@ class StandardWellsHost:
         self.flux_eq, self.ctrl_eq = flux_eq, ctrl_eq
         return resid_delta, np.concatenate(rc).astype(np.int32), np.concatenate(blocks), rhs_delta
 
+    # solveWellEq (BlackoilModelBase_impl.hpp:1018-1133): Newton on the well equations alone with the reservoir frozen
+    def solve_well_eq(self, pp, ws, B_avg, pvt_at=None, max_it=15):
+        """Returns (converged, iterations).  On convergence the well state keeps the solution and the connection pressures are
+        recomputed from it; otherwise the well state is restored (:1124-1126)."""
+        W = self.w
+        ws0 = ws.copy()
+        it, converged = 0, False
+        while True:
+            flux_eq = np.zeros((W.nw, 3)); ctrl_eq = np.zeros(W.nw)
+            systems, cq_all = [], np.zeros((W.nperf, 3))
+            for w in range(W.nw):
+                n = W.connpos[w + 1] - W.connpos[w]
+                cq_s, Ev, Ej = self._well_system(w, pp, ws, const_cells=True)
+                systems.append((Ev, Ej[:, 3 * n:]))
+                flux_eq[w] = Ev[:3]; ctrl_eq[w] = Ev[3]
+                for a in range(3):
+                    cq_all[W.connpos[w]:W.connpos[w + 1], a] = cq_s[a].v
+            ws.perf_rates = cq_all                            # updatePerfPhaseRatesAndPressures (:1059)
+            for w in range(W.nw):
+                ws.perf_press[W.connpos[w]:W.connpos[w + 1]] = ws.bhp[w] + self.cdp[W.connpos[w]:W.connpos[w + 1]]
+            self.flux_eq, self.ctrl_eq = flux_eq, ctrl_eq
+            converged = self.converged(B_avg)                 # getWellConvergence (:1866-1950)
+            if converged:
+                break
+            it += 1
+            for w in range(W.nw):
+                Ev, D = systems[w]
+                self._apply_well_increment(w, np.linalg.solve(D, Ev), ws)
+            self.update_well_controls(ws)
+            if it >= max_it:
+                break
+        self.well_iterations = it
+        if converged:
+            self.compute_connection_pressures(pp, ws, pvt_at)
+        else:
+            ws.assign(ws0)
+        return converged, it
+
     def converged(self, B_avg):
         """well part of getConvergence (BlackoilModelBase_impl.hpp:1769-1779)."""
         wf = np.asarray(B_avg) * np.abs(self.flux_eq).max(0)
         self.well_flux_residual, self.well_ctrl_residual = wf, np.abs(self.ctrl_eq).max()
         return bool(np.all(wf < self.tol_wells) and self.well_ctrl_residual < self.tol_ctrl)
 
-    def recover_and_update(self, dx_perf, ws):
-        """recoverVariable (NewtonIterationUtilities.cpp:134-184) + updateWellState (StandardWells_impl.hpp:611-650)."""
+    def _apply_well_increment(self, w, dy, ws):
+        """updateWellState (StandardWells_impl.hpp:611-700) for one well: rates, limited bhp, thp of wells that have a THP control"""
         W = self.w
+        ws.qs[w] -= dy[:3]
+        d = dy[3]
+        ws.bhp[w] -= np.sign(d) * min(abs(d), abs(ws.bhp[w]) * self.dbhp_max_rel)
+        thp_ctrl = next((c for c in W.controls[w] if c[0] == THP), None)
+        if thp_ctrl is not None:
+            table = self._vfp(w, thp_ctrl[3])
+            ws.thp[w] = table.thp_of(ws.qs[w, 0], ws.qs[w, 1], ws.qs[w, 2], ws.bhp[w] + self._vfp_dp(w, table), thp_ctrl[4])
+
+    def recover(self, dx_perf):
+        """recoverVariable (NewtonIterationUtilities.cpp:134-184): the wells' part of the Newton increment, [nw][4] = d qs (3), d bhp"""
+        W = self.w
+        dy = np.zeros((W.nw, 4))
         for w in range(W.nw):
             lo, hi = W.connpos[w], W.connpos[w + 1]
             Dinv, C, Ev = self._sys[w]
-            dy = Dinv @ (Ev - C @ np.asarray(dx_perf[lo:hi], float).ravel())
-            ws.qs[w] -= dy[:3]
-            d = dy[3]
-            ws.bhp[w] -= np.sign(d) * min(abs(d), abs(ws.bhp[w]) * self.dbhp_max_rel)
+            dy[w] = Dinv @ (Ev - C @ np.asarray(dx_perf[lo:hi], float).ravel())
+        return dy
+
+    def recover_and_update(self, dx_perf, ws, dy=None):
+        """recoverVariable + updateWellState (StandardWells_impl.hpp:611-700); `dy` = an already recovered (and relaxed) increment"""
+        dy = self.recover(dx_perf) if dy is None else dy
+        for w in range(self.w.nw):
+            self._apply_well_increment(w, dy[w], ws)
 
 
 class WellCoupledModel:
@@ -309,22 +500,55 @@ class WellCoupledModel:
     def relativeChange(self):
         return self.m.relativeChange()
 
-    def nonlinearIteration(self, iteration, single_precision=None, nonlinear_solver=None):
+    def _pvt_at(self):
+        """PVT of the perforated cells at given pressures, if the backend offers it (opmgpu_perf_pvt)"""
+        return getattr(self.m, "perfPvtAt", None)
+
+    def assemble(self, initial):
+        """BlackoilModelBase::assemble in the reference's order (BlackoilModelBase_impl.hpp:757-840): control switching, reservoir
+        equations, [initial: connection pressures, explicit well pre-solve], well equations and their Schur-reduced terms"""
         m, wh, ws = self.m, self.wh, self.ws
-        m.assemble(iteration == 0)
+        if wh.vfp_active:       # VFP tables need the connection densities for the hydrostatic correction (:771-776)
+            wh.compute_connection_pressures(m.perfProps(self.nperf).reshape(self.nperf, 9, 4), ws, self._pvt_at())
+        wh.update_well_controls(ws)                                   # :785
+        m.assemble(initial)
         pp = m.perfProps(self.nperf).reshape(self.nperf, 9, 4)
-        if iteration == 0:
-            wh.compute_connection_pressures(pp, ws)
+        if initial:
+            wh.compute_connection_pressures(pp, ws, self._pvt_at())    # :797-805
+            if wh.solve_welleq_initially:                              # :827-829
+                wh.solve_well_eq(pp, ws, m.averageB(), self._pvt_at())
         resid_delta, rc, blocks, rhs_delta = wh.assemble(pp, ws)
         m.addWellTerms(resid_delta, rc, blocks)
         m.addWellRhs(rhs_delta)
+
+    def nonlinearIteration(self, iteration, single_precision=None, nonlinear_solver=None):
+        """BlackoilModelBase::nonlinearIteration (BlackoilModelBase_impl.hpp:239-326)"""
+        m, wh, ws = self.m, self.wh, self.ws
+        ns = nonlinear_solver
+        initial = iteration == 0
+        if initial:
+            self.residual_norms_history, self.current_relaxation, self.dy_old = [], 1.0, np.zeros((wh.w.nw, 4))
+        self.assemble(initial)
         converged = m.getConvergence()
         converged = wh.converged(m.B_avg) and converged
+        self.residual_norms_history.append(list(m.linf) + list(np.abs(wh.flux_eq).max(0)) + [np.abs(wh.ctrl_eq).max()])
         lin = 0
-        if not converged or iteration < 1:
+        if not converged or iteration < (ns.min_iter if ns else 1):
             m.solveJacobianSystem(single_precision=single_precision)
             lin = self.linear_iterations = m.linear_iterations
-            wh.recover_and_update(m.perfDx(self.nperf), ws)
+            dy = wh.recover(m.perfDx(self.nperf))
+            if ns is not None and getattr(m, "use_update_stabilization", True):
+                # detectOscillations + stabilizeNonlinearUpdate on the WHOLE increment, wells included (NonlinearSolver_impl.hpp:221-301)
+                oscillate, _ = ns.detectOscillations(self.residual_norms_history, iteration)
+                if oscillate:
+                    self.current_relaxation = max(self.current_relaxation - ns.relax_increment, ns.relax_max)
+                om = self.current_relaxation
+                m.stabilizeUpdate(ns.relax_type, om)
+                dy_new = dy.copy()
+                if om != 1.0:
+                    dy = om * dy + (1.0 - om) * self.dy_old if ns.relax_type == 1 else om * dy
+                self.dy_old = dy_new
+            wh.recover_and_update(None, ws, dy=dy)
             m.updateState()
         return converged, lin
 
@@ -334,23 +558,42 @@ class DeviceWellModel:
     read-back of perforation properties, no clique fill -- opmgpu_set_device_wells / well_state_set / well_convergence.
     Interface of WellCoupledModel, so NonlinearSolver / AdaptiveTimeStepping drive either."""
 
-    def __init__(self, backend, wells, well_state, tolerance_wells=1e-4, tolerance_well_control=1e-7):
+    def __init__(self, backend, wells, well_state, tolerance_wells=1e-4, tolerance_well_control=1e-7, vfp_tables=()):
         import ctypes as C
         from . import capi
         self.m, self.w, self.ws = backend, wells, well_state
         self.tol_wells, self.tol_ctrl = tolerance_wells, tolerance_well_control
         self.linear_iterations = 0
         nw = wells.nw
+        if vfp_tables:
+            arr = (capi.VfpTable * len(vfp_tables))()
+            self._keep_vfp = []
+            for k, t in enumerate(vfp_tables):
+                v = arr[k]
+                v.id, v.is_injector, v.flo_type, v.datum_depth = t.id, int(t.is_injector), t.flo_type, t.datum_depth
+                axes = [capi.f64(t.flo), capi.f64(t.thp)] + ([] if t.is_injector else [capi.f64(t.wfr), capi.f64(t.gfr), capi.f64(t.alq)])
+                data = capi.f64(t.data).ravel()
+                self._keep_vfp += axes + [data]
+                v.nflo, v.nthp, v.flo, v.thp, v.data = axes[0].size, axes[1].size, capi.dptr(axes[0]), capi.dptr(axes[1]), capi.dptr(data)
+                if not t.is_injector:
+                    v.wfr_type, v.gfr_type = t.wfr_type, t.gfr_type
+                    v.nwfr, v.ngfr, v.nalq = axes[2].size, axes[3].size, axes[4].size
+                    v.wfr, v.gfr, v.alq = capi.dptr(axes[2]), capi.dptr(axes[3]), capi.dptr(axes[4])
+            backend._chk(backend.lib.opmgpu_set_vfp_tables(backend.ctx, len(vfp_tables), arr))
         spec = capi.WellsSpec()
+        cptr, ctyp, ctgt, cdis, cvfp, calq = wells.control_arrays()
         self._keep = [np.asarray(wells.connpos, np.int32), np.asarray(wells.cells, np.int32), capi.f64(wells.WI),
                       np.asarray(wells.type, np.int32), np.asarray([int(a) for a in wells.allow_cf], np.int32), capi.f64(wells.depth_ref),
-                      capi.f64(np.asarray(wells.comp_frac, float).reshape(nw, 3)), np.asarray(wells.ctrl_type, np.int32),
-                      capi.f64(wells.ctrl_target), capi.f64(np.asarray(wells.ctrl_distr, float).reshape(nw, 3))]
+                      capi.f64(np.asarray(wells.comp_frac, float).reshape(nw, 3)), capi.i32(ctyp), capi.f64(ctgt), capi.f64(cdis),
+                      capi.i32(cptr), capi.i32(cvfp), capi.f64(calq)]
         k = self._keep
         spec.nw = nw
         spec.well_connpos, spec.well_cells, spec.WI, spec.type, spec.allow_cf = capi.iptr(k[0]), capi.iptr(k[1]), capi.dptr(k[2]), capi.iptr(k[3]), capi.iptr(k[4])
         spec.depth_ref, spec.comp_frac, spec.ctrl_type, spec.ctrl_target, spec.ctrl_distr = capi.dptr(k[5]), capi.dptr(k[6]), capi.iptr(k[7]), capi.dptr(k[8]), capi.dptr(k[9])
+        spec.ctrl_ptr, spec.ctrl_vfp, spec.ctrl_alq = capi.iptr(k[10]), capi.iptr(k[11]), capi.dptr(k[12])
         backend._chk(backend.lib.opmgpu_set_device_wells(backend.ctx, C.byref(spec)))
+        if tolerance_wells != backend.params.tolerance_wells or tolerance_well_control != backend.params.tolerance_well_control:
+            pass        # the pre-solve on the device uses opmgpu_params.tolerance_wells / tolerance_well_control of the context
         self.push_well_state()
 
     def push_well_state(self):
@@ -358,7 +601,8 @@ class DeviceWellModel:
         m, ws = self.m, self.ws
         if self.w.nw == 0:          # a rank without wells (multi-GPU): nothing to upload, the convergence call stays collective
             return
-        m._chk(m.lib.opmgpu_well_state_set(m.ctx, capi.dptr(capi.f64(ws.bhp)), capi.dptr(capi.f64(ws.qs)), capi.dptr(capi.f64(ws.perf_rates))))
+        m._chk(m.lib.opmgpu_well_state_set(m.ctx, capi.dptr(capi.f64(ws.bhp)), capi.dptr(capi.f64(ws.qs)), capi.dptr(capi.f64(ws.perf_press)), capi.dptr(capi.f64(ws.perf_rates))))
+        m._chk(m.lib.opmgpu_well_controls_set(m.ctx, capi.iptr(capi.i32(ws.current)), capi.dptr(capi.f64(ws.thp))))
 
     def pull_well_state(self):
         """device well state -> the WellState object (bhp, wellRates, perfPress, perfPhaseRates)"""
@@ -370,6 +614,11 @@ class DeviceWellModel:
         pp, pr = np.zeros(self.w.nperf), np.zeros((self.w.nperf, 3))
         m._chk(m.lib.opmgpu_well_state_get(m.ctx, capi.dptr(bhp), capi.dptr(qs), capi.dptr(pp), capi.dptr(pr)))
         ws.bhp[:], ws.qs[:], ws.perf_press[:], ws.perf_rates[:] = bhp, qs, pp, pr
+        import ctypes as C
+        cur, thp, its, conv = np.zeros(self.w.nw, np.int32), np.zeros(self.w.nw), C.c_int32(0), C.c_int32(0)
+        m._chk(m.lib.opmgpu_well_controls_get(m.ctx, capi.iptr(cur), capi.dptr(thp), C.byref(its), C.byref(conv)))
+        ws.current[:], ws.thp[:] = cur, thp
+        self.presolve_iterations, self.presolve_converged = its.value, bool(conv.value)
         return ws
 
     def prepareStep(self, dt, state=None):
@@ -393,16 +642,24 @@ class DeviceWellModel:
         return bool(np.all(self.well_flux_residual < self.tol_wells) and self.well_ctrl_residual < self.tol_ctrl)
 
     def nonlinearIteration(self, iteration, single_precision=None, nonlinear_solver=None):
-        m = self.m
+        m, ns = self.m, nonlinear_solver
+        if iteration == 0:
+            self.residual_norms_history, self.current_relaxation = [], 1.0
         m.setSolvePrecision(single_precision)
-        m.assemble(iteration == 0)                      # reservoir + wells, connection pressures at iteration 0
+        m.assemble(iteration == 0)                      # reservoir + wells: control switching, connection pressures + pre-solve at iteration 0
         converged = m.getConvergence()
         converged = self.wellConvergence() and converged
+        self.residual_norms_history.append(list(m.linf))
         lin = 0
-        if not converged or iteration < 1:
+        if not converged or iteration < (ns.min_iter if ns else 1):
             m.solveJacobianSystem(single_precision=single_precision)
             lin = self.linear_iterations = m.linear_iterations
-            m.updateState()                              # also recovers and updates (q_s, bhp) on the device
+            if ns is not None and getattr(m, "use_update_stabilization", True):
+                oscillate, _ = ns.detectOscillations(self.residual_norms_history, iteration)
+                if oscillate:
+                    self.current_relaxation = max(self.current_relaxation - ns.relax_increment, ns.relax_max)
+                m.stabilizeUpdate(ns.relax_type, self.current_relaxation)       # relaxes the well part of the increment too
+            m.updateState()                              # also updates (q_s, bhp, thp) on the device
         return converged, lin
 
 

@@ -20,6 +20,16 @@ def oracle():
     return orc
 
 
+@pytest.fixture(autouse=True)
+def _oracle_single_thread():
+    """The oracle's OpenMP thread count is process-global and changes its reduction order (f32 Krylov paths differ): tests that raise
+    it for speed (full-size decks) must not leak it into the next test."""
+    yield
+    mod = sys.modules.get("oracle.oracle")
+    if mod is not None and getattr(mod, "_lib", None) is not None:
+        mod.set_threads(1)
+
+
 @pytest.fixture(scope="session")
 def gpu_lib():
     """libopmgpu.so through the C ABI; no fallback -- a missing library is an error."""

@@ -222,16 +222,14 @@ def _lockstep_parity(gpu_lib, oracle, grid, tab, st, dt, wl, niter=2, cpr=1, red
         # ---- assembly ----
         gm.setSolvePrecision(False)
         gm.assemble(it == 0)
-        ob.assemble(it == 0)
-        r_res, val_res = ob.r.copy(), None
+        mo.assemble(it == 0)            # with wells: control switching, reservoir, [connection pressures + well pre-solve], well terms
+        val_res = None
         if wl is not None:
             # reservoir-only oracle Jacobian on the stencil pattern: everything but the perforated cells' diagonal blocks must match it
             _, val_res, _, _ = oracle.assemble(grid, tab, dt, ob.st, rowptr0, col0, scale=tuple(scale), accum0=ob.acc0)
-            pp = ob.perfProps(wl.nperf).reshape(wl.nperf, 9, 4)
             if it == 0:
-                mo.wh.compute_connection_pressures(pp, mo.ws)
-            resid_delta, rc, blocks, rhs_delta = mo.wh.assemble(pp, mo.ws)
-            ob.addWellTerms(resid_delta, rc, blocks); ob.addWellRhs(rhs_delta)
+                md.pull_well_state()
+                assert md.presolve_converged and md.presolve_iterations == mo.wh.well_iterations
         gr, gc, gv = gm.jacobian()
         assert np.array_equal(gr, rowptr0) and np.array_equal(gc, col0)
         assert rel_err(gm.residual(), ob.r) < 1e-11, (it, rel_err(gm.residual(), ob.r))
@@ -276,63 +274,120 @@ def _lockstep_parity(gpu_lib, oracle, grid, tab, st, dt, wl, niter=2, cpr=1, red
     gm.close()
 
 
-def _run_time_step(model, backend, dt, st, single, max_iter=15):
-    """NonlinearSolver::step (NonlinearSolver_impl.hpp:119-174), plain Newton: returns the number of nonlinear iterations"""
+def _run_time_step(model, dt, st, single, ns, max_iter=15):
+    """NonlinearSolver::step (NonlinearSolver_impl.hpp:119-174) with the reference's default update stabilisation: returns the number
+    of nonlinear iterations (max_iter + 1 = not converged)"""
     model.prepareStep(dt, st)
     it = 0
     while True:
-        if model is backend and not hasattr(model, "nonlinearIteration"):        # bare oracle backend (no wells)
-            backend.assemble(it == 0)
-            conv = backend.getConvergence()
-            if not conv or it < 1:
-                backend.solveJacobianSystem(single_precision=single); backend.updateState()
-        else:
-            conv, _ = model.nonlinearIteration(it, single_precision=single)
+        conv, _ = model.nonlinearIteration(it, single_precision=single, nonlinear_solver=ns)
         it += 1
         if (conv and it > 1) or it > max_iter:
             return it
 
 
-def _check_newton_count(gpu_lib, oracle, grid, tab, st, dt, wl):
-    """One whole time step at the reference's DEFAULT tolerances (MB 1e-5, CNV 1e-2, linear reduction 1e-2, float solve for dt < 20 d)
-    free-running on both sides: the device (reference-default ILU0 and CPR) needs the same number of Newton iterations as the oracle
-    (natural-order ILU0 + BiCGStab like flow_legacy)."""
+class _OracleModel:
+    """BlackoilModelBase::nonlinearIteration on the bare oracle backend (decks without wells)"""
+
+    def __init__(self, ob):
+        self.m = ob
+
+    def prepareStep(self, dt, st):
+        self.m.prepareStep(dt, st)
+
+    def nonlinearIteration(self, it, single_precision=False, nonlinear_solver=None):
+        ob, ns = self.m, nonlinear_solver
+        if it == 0:
+            self.hist, self.relax = [], 1.0
+        ob.assemble(it == 0)
+        conv = ob.getConvergence()
+        self.hist.append(list(ob.linf))
+        if not conv or it < 1:
+            ob.solveJacobianSystem(single_precision=single_precision)
+            if ns is not None:
+                if ns.detectOscillations(self.hist, it)[0]:
+                    self.relax = max(self.relax - ns.relax_increment, ns.relax_max)
+                ob.stabilizeUpdate(ns.relax_type, self.relax)
+            ob.updateState()
+        return conv, ob.linear_iterations
+
+
+def _spin_up(grid, tab, st, wl, dt, nsteps=2):
+    """The synthetic initial states are far from capillary-gravity equilibrium and the wells start at full rate (first-step CNV of
+    several hundred): like a simulator run, let `nsteps` time steps pass (on the device, default tolerances) and compare Newton
+    behaviour on the step after them.  Returns the state and well state at the end."""
     from opmgpu import wells as W
+    from opmgpu.model import NonlinearSolver
+    gm = GpuBlackoilModel(grid, tab, capi.default_params(use_cpr=1))
+    md = gm if wl is None else W.DeviceWellModel(gm, wl, W.WellState(wl, st.p))
+    ns = NonlinearSolver()
+    cur = st
+    for k in range(nsteps):
+        n = _run_time_step(md, dt, cur if k == 0 else None, dt < 20 * decks.DAY, ns, max_iter=25)
+        assert n <= 25, "spin-up step %d did not converge" % k
+    out = gm.getState()
+    ws = None if wl is None else md.pull_well_state().copy()
+    gm.close()
+    return out, ws
+
+
+def _check_newton_count(gpu_lib, oracle, grid, tab, st, dt, wl, solvers=(0, 1), reduction=1e-6, spin_up=2):
+    """One whole time step with the reference's NonlinearSolver (update stabilisation on) and the reference's Newton tolerances
+    (MB 1e-5, CNV 1e-2, wells 1e-4 / 1e-7), free-running on both sides from the same spun-up state.  The linear solves are double
+    precision to a 1e-6 reduction on BOTH sides: at the default 1e-2 an inexact-Newton path depends on the preconditioner (measured:
+    8-16 iterations for one deck across ILU0 orderings / CPR), at equal tight tolerance the paths coincide and the device must need
+    exactly the oracle's number of Newton iterations."""
+    from opmgpu import wells as W
+    from opmgpu.model import NonlinearSolver
     from util import OracleBackend
     oracle.set_threads(16)
-    single = dt < 20 * decks.DAY
-    ob = OracleBackend(oracle, grid, tab, capi.default_params(), wells=None if wl is None else wl.arrays())
-    mo = ob if wl is None else W.WellCoupledModel(ob, W.StandardWellsHost(wl, grid.z, tab.surface_density[0]), W.WellState(wl, st.p))
-    n_oracle = _run_time_step(mo, ob, dt, st, single)
+    st1, ws1 = _spin_up(grid, tab, st, wl, dt, spin_up) if spin_up else (st, None)
+    lin = dict(linear_solver_reduction=reduction, linear_solver_maxiter=3000)
+    ob = OracleBackend(oracle, grid, tab, capi.default_params(**lin), wells=None if wl is None else wl.arrays())
+    if wl is None:
+        mo = _OracleModel(ob)
+    else:
+        wso = W.WellState(wl, st1.p)
+        if ws1 is not None:
+            wso.assign(ws1)
+        mo = W.WellCoupledModel(ob, W.StandardWellsHost(wl, grid.z, tab.surface_density[0]), wso)
+    n_oracle = _run_time_step(mo, dt, st1, False, NonlinearSolver())
     b = ob.getState()
-    for cpr in (0, 1):
-        gm = GpuBlackoilModel(grid, tab, capi.default_params(use_cpr=cpr))
-        md = gm if wl is None else W.DeviceWellModel(gm, wl, W.WellState(wl, st.p))
-        n_gpu = _run_time_step(md, gm, dt, st, single)
+    assert n_oracle <= 15, n_oracle
+    for cpr in solvers:
+        gm = GpuBlackoilModel(grid, tab, capi.default_params(use_cpr=cpr, **lin))
+        if wl is None:
+            md = gm
+        else:
+            wsd = W.WellState(wl, st1.p)
+            if ws1 is not None:
+                wsd.assign(ws1)
+            md = W.DeviceWellModel(gm, wl, wsd)
+        n_gpu = _run_time_step(md, dt, st1, False, NonlinearSolver())
         a = gm.getState()
         gm.close()
-        assert n_gpu == n_oracle and n_gpu <= 15, (cpr, n_gpu, n_oracle)
-        # both are converged solutions of the same nonlinear system at the Newton tolerance (CNV 1e-2)
-        assert (a.hc != b.hc).mean() < 1e-3
-        assert np.abs(a.p - b.p).max() <= 1e-3 * np.abs(b.p).max() and np.abs(a.sat - b.sat).max() <= 2e-2
+        assert n_gpu == n_oracle, (cpr, n_gpu, n_oracle)
+        assert np.array_equal(a.hc, b.hc)
+        assert np.abs(a.p - b.p).max() <= 1e-4 * np.abs(b.p).max() and np.abs(a.sat - b.sat).max() <= 1e-4
 
 
-def _cart100():
+def _cart100(rate=1000.0, perturb=0.002):
     grid = decks.cartesian_grid(100, 100, 100, lognormal_sigma=0.5, seed=12345)
     tab = decks.satfunc_standard_tables()
-    st = decks.initial_state(grid, tab, perturb=0.002, seed=12345)
+    st = decks.initial_state(grid, tab, perturb=perturb, seed=12345)
     from opmgpu import wells as W
-    return grid, tab, st, W.five_spot(grid, rate_m3_per_day=5000.0, bhp_prod_bar=150.0)
+    return grid, tab, st, W.five_spot(grid, rate_m3_per_day=rate, bhp_prod_bar=150.0)
 
 
-def _spe10_like():
+def _spe10_like(rate=200.0, perturb=1e-4, bhp=380.0, gascap=0.0):
     """SPE10 Model 2 dimensions and cell sizes (20 x 10 x 2 ft), channel-free lognormal permeability with sigma_lnK = 2.5 (the SPE10
-    permeability file is not available offline), 5-spot like the original: central water injector, four corner producers."""
+    permeability file is not available offline), 5-spot like the original: central water injector, four corner producers.  Like
+    SPE10 there is no gas cap (undersaturated oil everywhere); pore volumes are ~2 m3 per cell, so rates and drawdown are moderate."""
     grid = decks.cartesian_grid(60, 220, 85, dx=6.096, dy=3.048, dz=0.6096, tops=3657.6, lognormal_sigma=2.5, seed=10)
     tab = decks.satfunc_standard_tables()
-    st = decks.initial_state(grid, tab, p_ref=413.0 * decks.BAR, z_ref=3657.6, perturb=0.002, seed=10)
+    st = decks.initial_state(grid, tab, p_ref=413.0 * decks.BAR, z_ref=3657.6, perturb=perturb, seed=10, gas_cap_fraction=gascap, gas_only_fraction=0.01 if gascap > 0 else 0.0)
     from opmgpu import wells as W
-    return grid, tab, st, W.five_spot(grid, rate_m3_per_day=800.0, bhp_prod_bar=275.0)
+    return grid, tab, st, W.five_spot(grid, rate_m3_per_day=rate, bhp_prod_bar=bhp)
 
 
 def _norne_like():
@@ -358,18 +413,20 @@ def _spe9_like():
                                          inj_rate_m3_per_day=800.0, prod_bhp_bar=150.0, prod_oil_rate_m3_per_day=60.0)
 
 
-DECKS = {"cart100": (_cart100, 5.0), "spe10like": (_spe10_like, 2.0), "nornelike": (_norne_like, 3.0), "spe9like": (_spe9_like, 10.0)}
+DECKS = {"cart100": (_cart100, 5.0), "spe10like": (_spe10_like, 2.0), "nornelike": (_norne_like, 3.0), "spe9like": (_spe9_like, 3.0)}
+LOCKSTEP_KW = {"spe10like": dict(reduction=1e-8, tol_p=1e-5, tol_s=1e-5)}        # sigma_lnK = 2.5: a 1e-10 reduction is below what BiCGStab attains in f64
+COUNT_KW = {"cart100": dict(solvers=(1,)), "spe10like": dict(solvers=(1,)), "nornelike": dict(spin_up=0), "spe9like": dict(spin_up=0)}     # multicolour ILU0 alone needs ~1000 iterations for 1e-6 at 1 M cells
 
 
 @pytest.mark.parametrize("name", list(DECKS))
 def test_fullsize_lockstep_parity(gpu_lib, oracle, name):
     make, dt_days = DECKS[name]
     grid, tab, st, wl = make()
-    _lockstep_parity(gpu_lib, oracle, grid, tab, st, dt_days * decks.DAY, wl)
+    _lockstep_parity(gpu_lib, oracle, grid, tab, st, dt_days * decks.DAY, wl, **LOCKSTEP_KW.get(name, {}))
 
 
 @pytest.mark.parametrize("name", list(DECKS))
 def test_fullsize_newton_count(gpu_lib, oracle, name):
     make, dt_days = DECKS[name]
     grid, tab, st, wl = make()
-    _check_newton_count(gpu_lib, oracle, grid, tab, st, dt_days * decks.DAY, wl)
+    _check_newton_count(gpu_lib, oracle, grid, tab, st, dt_days * decks.DAY, wl, **COUNT_KW.get(name, {}))

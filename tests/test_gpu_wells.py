@@ -161,3 +161,87 @@ def test_waterflood_material_balance_through_adaptive_stepping(gpu_lib, oracle):
         assert np.all(np.abs((after - before) - net) <= 1e-5 * np.array([scale, scale, 200 * scale])), (dt / decks.DAY, after - before, net)
         assert abs(qs[0, 0] - inj_rate) <= 1e-9 and qs[1, 1] < 0
     gm.close()
+
+
+@pytest.mark.parametrize("case", ["bhp_limit_midstep", "presolve_switch", "prod_rate_limit", "thp"])
+@pytest.mark.parametrize("cpr", [0, 1])
+def test_device_well_controls_match_host(gpu_lib, oracle, case, cpr):
+    """updateWellControls / solveWellEq / THP on the DEVICE (csrc/wells.hip) against the host well model on the oracle: the same
+    control switches at the same Newton iterations, the same pre-solve iteration count, the same well and reservoir state.
+      bhp_limit_midstep: a rate-controlled injector runs into its BHP limit after the first Newton update (switch at iteration 1);
+      presolve_switch:   the limit is already broken with the reservoir frozen (solveWellEq switches before the first linearisation);
+      prod_rate_limit:   a BHP-controlled producer with an oil-rate limit;   thp: a producer on THP control through a VFP table."""
+    from test_wells_host import _limits_setup
+    kw = {"bhp_limit_midstep": dict(inj_bhp_limit_bar=262.0), "presolve_switch": dict(inj_bhp_limit_bar=255.0),
+          "prod_rate_limit": dict(inj_bhp_limit_bar=600.0, prod_rate_limit=150.0), "thp": dict(inj_bhp_limit_bar=600.0, thp=True)}[case]
+    grid, tab, st, wl, tables = _limits_setup(**kw)
+    prm = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=500, use_cpr=cpr)
+    prm_o = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=500)
+    dt = 5 * decks.DAY
+    gm = GpuBlackoilModel(grid, tab, prm)
+    ob = OracleBackend(oracle, grid, tab, prm_o, wells=wl.arrays())
+    md = W.DeviceWellModel(gm, wl, W.WellState(wl, st.p), vfp_tables=tables)
+    mo = W.WellCoupledModel(ob, W.StandardWellsHost(wl, grid.z, tab.surface_density[0], vfp_tables=tables), W.WellState(wl, st.p))
+    md.prepareStep(dt, st); mo.prepareStep(dt, st)
+    history = []
+    it = 0
+    while True:
+        cd, _ = md.nonlinearIteration(it, single_precision=False)
+        co, _ = mo.nonlinearIteration(it, single_precision=False)
+        ws = md.pull_well_state()
+        if it == 0:
+            assert md.presolve_converged and md.presolve_iterations == mo.wh.well_iterations, (md.presolve_iterations, mo.wh.well_iterations)
+        assert cd == co, it
+        assert np.array_equal(ws.current, mo.ws.current), (it, ws.current, mo.ws.current)
+        assert np.allclose(md.well_flux_residual, mo.wh.well_flux_residual, rtol=1e-5, atol=1e-12), it
+        assert md.well_ctrl_residual == pytest.approx(mo.wh.well_ctrl_residual, rel=1e-5, abs=1e-9), it
+        a, b = gm.getState(), ob.getState()
+        assert np.array_equal(a.hc, b.hc), it
+        assert np.abs(a.p - b.p).max() <= 1e-6 * np.abs(b.p).max() and np.abs(a.sat - b.sat).max() <= 1e-6, it
+        assert np.allclose(ws.bhp, mo.ws.bhp, rtol=1e-7), (it, ws.bhp, mo.ws.bhp)
+        assert np.allclose(ws.qs, mo.ws.qs, rtol=1e-6, atol=1e-9 * np.abs(mo.ws.qs).max()), it
+        assert np.allclose(ws.thp, mo.ws.thp, rtol=1e-6, atol=1.0), (it, ws.thp, mo.ws.thp)
+        history.append(ws.current.copy())
+        it += 1
+        if (cd and it > 1) or it > 12:
+            break
+    assert cd and it <= 12
+    if case == "bhp_limit_midstep":
+        assert history[0][0] == 0 and history[1][0] == 1 and ws.bhp[0] == pytest.approx(262 * decks.BAR, rel=1e-12)
+    elif case == "presolve_switch":
+        assert history[0][0] == 1 and ws.bhp[0] == pytest.approx(255 * decks.BAR, rel=1e-12)
+    elif case == "prod_rate_limit":
+        assert ws.current[1] == 1 and ws.qs[1, 1] == pytest.approx(-150.0 / 86400.0, rel=1e-9)
+    else:
+        assert ws.current[1] == 0 and ws.thp[1] == pytest.approx(30 * decks.BAR, rel=1e-5)
+    gm.close()
+
+
+def test_stabilized_update_relaxes_the_well_increment_too(gpu_lib, oracle):
+    """NonlinearSolver::stabilizeNonlinearUpdate acts on the WHOLE increment (NonlinearSolver_impl.hpp:260-301): with device wells the
+    recovered (q_s, bhp) increment is relaxed with the reservoir part -- device vs host well model with a forced relaxation of 0.6."""
+    from opmgpu.model import NonlinearSolver
+    grid, tab, st, wl = _setup()
+    prm = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=500)
+    gm = GpuBlackoilModel(grid, tab, prm)
+    ob = OracleBackend(oracle, grid, tab, prm, wells=wl.arrays())
+    md = W.DeviceWellModel(gm, wl, W.WellState(wl, st.p))
+    mo = W.WellCoupledModel(ob, W.StandardWellsHost(wl, grid.z, tab.surface_density[0]), W.WellState(wl, st.p))
+
+    class Forced(NonlinearSolver):          # oscillation "detected" at every iteration >= 1: relaxation 0.9, 0.8, ...
+        def detectOscillations(self, hist, it):
+            return it >= 1, False
+
+    for relax_type in (capi.RELAX_DAMPEN, capi.RELAX_SOR):
+        ns = Forced(relax_type=relax_type)
+        md.prepareStep(2 * decks.DAY, st); mo.prepareStep(2 * decks.DAY, st)
+        md.ws = W.WellState(wl, st.p); md.push_well_state(); mo.ws.assign(W.WellState(wl, st.p))
+        for it in range(4):
+            md.nonlinearIteration(it, single_precision=False, nonlinear_solver=ns)
+            mo.nonlinearIteration(it, single_precision=False, nonlinear_solver=ns)
+            ws = md.pull_well_state()
+            a, b = gm.getState(), ob.getState()
+            assert np.abs(a.p - b.p).max() <= 1e-6 * np.abs(b.p).max() and np.abs(a.sat - b.sat).max() <= 1e-6, (relax_type, it)
+            assert np.allclose(ws.bhp, mo.ws.bhp, rtol=1e-7) and np.allclose(ws.qs, mo.ws.qs, rtol=1e-6, atol=1e-9 * np.abs(mo.ws.qs).max()), (relax_type, it)
+        assert md.current_relaxation == mo.current_relaxation and md.current_relaxation < 1.0
+    gm.close()

@@ -5,6 +5,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 
 from opmgpu import capi, decks, wells as W
 from util import OracleBackend
@@ -136,3 +137,127 @@ def test_partition_keeps_wells_on_one_rank():
     part_k = partition.slab_partition(grid, 2, axis=2)
     with pytest.raises(ValueError, match="straddles"):
         partition.LocalDomain(grid, part_k, 0).local_wells(wl, part_k)
+
+
+# ---- control logic: updateWellControls, solveWellEq, THP through VFP tables ------------------------------
+def _limits_setup(inj_bhp_limit_bar=400.0, prod_rate_limit=None, thp=False):
+    """SPE1-like deck; the injector is rate controlled with a BHP limit, the producer BHP controlled (optionally with an oil-rate
+    limit, or THP controlled through a synthetic VFP table)."""
+    from opmgpu import vfp
+    nx, ny, nz = 10, 10, 3
+    grid = decks.cartesian_grid(nx, ny, nz, dx=300.0, dy=300.0, dz=10.0, tops=2500.0, poro=0.3, permx_md=200.0, lognormal_sigma=0.3)
+    tab = decks.satfunc_standard_tables()
+    st = decks.initial_state(grid, tab, p_ref=250 * decks.BAR, z_ref=2500.0, gas_cap_fraction=0.0, gas_only_fraction=0.0)
+    col = lambda i, j: [i + nx * j + nx * ny * k for k in range(nz)]
+    wl = W.Wells()
+    WI = 5.0 * float(np.median(grid.trans))
+    wl.add_well("INJ", W.INJECTOR, grid.z[col(0, 0)[0]], col(0, 0), WI, (1.0, 0.0, 0.0), (W.SURFACE_RATE, 2000.0 / 86400.0, (1.0, 0.0, 0.0)),
+                limits=[(W.BHP, inj_bhp_limit_bar * decks.BAR)])
+    tables = []
+    if thp:
+        # bhp = 150 bar + 1.0 * thp + 2e9 Pa s/m3 * |oil rate|: linear in (thp, flo), so the multilinear table is exact
+        thp_ax, flo_ax = np.array([10.0, 50.0, 100.0]) * decks.BAR, np.array([0.0, 0.005, 0.02, 0.05])
+        data = np.zeros((3, 1, 1, 1, 4))
+        for i, t in enumerate(thp_ax):
+            data[i, 0, 0, 0, :] = 150 * decks.BAR + t + 2e9 * flo_ax
+        tables.append(vfp.VFPProdTable(3, grid.z[col(nx - 1, ny - 1)[0]] - 5.0, vfp.FLO_OIL, vfp.WFR_WOR, vfp.GFR_GOR, flo_ax, thp_ax, [0.0], [0.0], [0.0], data))
+        ctrl, lim = (W.THP, 30 * decks.BAR, None, 3, 0.0), [(W.BHP, 100 * decks.BAR)]
+    else:
+        ctrl = (W.BHP, 200 * decks.BAR)
+        lim = [] if prod_rate_limit is None else [(W.SURFACE_RATE, -prod_rate_limit / 86400.0, (0.0, 1.0, 0.0))]
+    wl.add_well("PROD", W.PRODUCER, grid.z[col(nx - 1, ny - 1)[0]], col(nx - 1, ny - 1)[:2], WI, (0.0, 1.0, 0.0), ctrl, limits=lim)
+    return grid, tab, st, wl, tables
+
+
+def test_update_well_controls_switches_to_the_broken_limit(oracle):
+    grid, tab, st, wl, _ = _limits_setup(inj_bhp_limit_bar=300.0)
+    wh = W.StandardWellsHost(wl, grid.z, tab.surface_density[0])
+    ws = W.WellState(wl, st.p)
+    ws.bhp[0] = 350 * decks.BAR                         # above the injector's BHP limit
+    sw = wh.update_well_controls(ws)
+    assert sw == [(0, 0, 1)] and ws.current[0] == 1 and ws.bhp[0] == 300 * decks.BAR
+    # updateWellStateWithTarget re-applies the rate target while the rate control is current
+    ws2 = W.WellState(wl, st.p); ws2.qs[0, 0] = 0.5
+    wh.update_well_controls(ws2)
+    assert ws2.current[0] == 0 and ws2.qs[0, 0] == 2000.0 / 86400.0
+    # a producer breaks a rate limit from below (its rates are negative)
+    grid, tab, st, wl, _ = _limits_setup(prod_rate_limit=100.0)
+    wh = W.StandardWellsHost(wl, grid.z, tab.surface_density[0])
+    ws = W.WellState(wl, st.p); ws.qs[1] = [-1e-4, -200.0 / 86400.0, -1e-2]
+    wh.update_well_controls(ws)
+    assert ws.current[1] == 1 and ws.qs[1, 1] == -100.0 / 86400.0 and ws.qs[1, 0] == -1e-4
+
+
+def _time_step(model, dt, st, max_iter=15):
+    model.prepareStep(dt, st)
+    it = 0
+    while True:
+        conv, _ = model.nonlinearIteration(it, single_precision=False)
+        it += 1
+        if (conv and it > 1) or it > max_iter:
+            return it, conv
+
+
+def test_presolve_and_control_switch_in_a_time_step(oracle):
+    """A rate-controlled injector whose BHP limit is too low for its rate target: the pre-solve (solveWellEq) drives the well
+    equations to their tolerance before the first linearisation, updateWellControls switches the well to BHP control, and the
+    converged step has bhp == limit with a rate below the target."""
+    grid, tab, st, wl, _ = _limits_setup(inj_bhp_limit_bar=262.0)
+    prm = capi.default_params(linear_solver_reduction=1e-10, linear_solver_maxiter=500)
+    be = OracleBackend(oracle, grid, tab, prm, wells=wl.arrays())
+    wh = W.StandardWellsHost(wl, grid.z, tab.surface_density[0])
+    ws = W.WellState(wl, st.p)
+    mo = W.WellCoupledModel(be, wh, ws)
+    # the pre-solve alone: well residuals below their tolerances, reservoir untouched
+    be.prepareStep(decks.DAY, st); be.assemble(True)
+    pp = be.perfProps(wl.nperf).reshape(wl.nperf, 9, 4)
+    ws0 = W.WellState(wl, st.p)
+    wh.update_well_controls(ws0); wh.compute_connection_pressures(pp, ws0, be.perfPvtAt)
+    ok, its = wh.solve_well_eq(pp, ws0, be.averageB(), be.perfPvtAt)
+    assert ok and 1 <= its <= 15 and np.all(wh.well_flux_residual < 1e-4) and wh.well_ctrl_residual < 1e-7
+    assert ws0.current[0] == 0 and 255 * decks.BAR < ws0.bhp[0] < 262 * decks.BAR     # with the reservoir frozen the rate target fits under the limit
+    mo.prepareStep(5 * decks.DAY, st)
+    conv, _ = mo.nonlinearIteration(0, single_precision=False)
+    assert ws.current[0] == 0 and ws.bhp[0] > 262 * decks.BAR       # the first Newton update pushes bhp over the limit ...
+    conv, _ = mo.nonlinearIteration(1, single_precision=False)
+    assert ws.current[0] == 1                                       # ... and updateWellControls switches at the next assembly (mid-step)
+    its, conv = _time_step(mo, 5 * decks.DAY, st)
+    assert conv and its <= 10
+    assert ws.current[0] == 1 and ws.bhp[0] == pytest.approx(262 * decks.BAR, rel=1e-12)
+    assert 0 < ws.qs[0, 0] < 2000.0 / 86400.0 and ws.qs[1, 1] < 0
+    # a limit below what the rate needs even with the reservoir frozen: the pre-solve itself switches
+    grid, tab, st, wl, _ = _limits_setup(inj_bhp_limit_bar=255.0)
+    be = OracleBackend(oracle, grid, tab, prm, wells=wl.arrays())
+    wh = W.StandardWellsHost(wl, grid.z, tab.surface_density[0])
+    be.prepareStep(decks.DAY, st); be.assemble(True)
+    ws0 = W.WellState(wl, st.p)
+    wh.update_well_controls(ws0); wh.compute_connection_pressures(pp, ws0, be.perfPvtAt)
+    ok, its = wh.solve_well_eq(pp, ws0, be.averageB(), be.perfPvtAt)
+    assert ok and ws0.current[0] == 1 and ws0.bhp[0] == 255 * decks.BAR and 0 < ws0.qs[0, 0] < 2000.0 / 86400.0
+    # with a generous limit nothing switches and the rate target is met
+    grid, tab, st, wl, _ = _limits_setup(inj_bhp_limit_bar=600.0)
+    be = OracleBackend(oracle, grid, tab, prm, wells=wl.arrays())
+    ws = W.WellState(wl, st.p)
+    mo = W.WellCoupledModel(be, W.StandardWellsHost(wl, grid.z, tab.surface_density[0]), ws)
+    its, conv = _time_step(mo, decks.DAY, st)
+    assert conv and ws.current[0] == 0 and ws.qs[0, 0] == pytest.approx(2000.0 / 86400.0, rel=1e-9)
+
+
+def test_thp_controlled_producer(oracle):
+    """THP control: at convergence bhp = VFP table bhp(rates, thp target) - hydrostatic correction, and the well state's thp
+    (updateWellState inverts the table) equals the target."""
+    grid, tab, st, wl, tables = _limits_setup(thp=True)
+    prm = capi.default_params(linear_solver_reduction=1e-10, linear_solver_maxiter=500)
+    be = OracleBackend(oracle, grid, tab, prm, wells=wl.arrays())
+    wh = W.StandardWellsHost(wl, grid.z, tab.surface_density[0], vfp_tables=tables)
+    assert wh.vfp_active
+    ws = W.WellState(wl, st.p)
+    mo = W.WellCoupledModel(be, wh, ws)
+    its, conv = _time_step(mo, decks.DAY, st)
+    assert conv and ws.current[1] == 0
+    t = tables[0]
+    dp = wh.perf_dens[wl.connpos[1]] * wh.gravity * (t.datum_depth - wl.depth_ref[1])
+    want = t.bhp(ws.qs[1, 0], ws.qs[1, 1], ws.qs[1, 2], 30 * decks.BAR, 0.0)[0] - dp
+    assert ws.bhp[1] == pytest.approx(want, rel=1e-7)
+    assert ws.thp[1] == pytest.approx(30 * decks.BAR, rel=1e-5)
+    assert 150 * decks.BAR < ws.bhp[1] < 250 * decks.BAR and ws.qs[1, 1] < 0

@@ -55,6 +55,7 @@ class OracleBackend:
     def assemble(self, initial):
         if initial:
             self.acc0 = None
+            self.dx_old = None
         self.r, self.val, self.acc0, self.binv = self.orc.assemble(self.grid, self.tab, self.dt, self.st, self.rowptr, self.col,
                                                                    scale=tuple(self.scale), accum0=self.acc0)
         self.rhs_extra = np.zeros(3 * self.nc)
@@ -65,21 +66,65 @@ class OracleBackend:
         idx = [names.index(n) for n in ["p_o", "rs", "rv", "b_w", "b_o", "b_g", "mob_w", "mob_o", "mob_g"]]
         return props[:, idx, :].reshape(nperf, 36)
 
+    def averageB(self):
+        """B_avg of getWellConvergence (BlackoilModelBase_impl.hpp:1876-1891): mean of 1/b per phase over the cells"""
+        return self.binv.reshape(3, self.nc).mean(1)
+
+    def perfPvtAt(self, press):
+        """computePropertiesForWellConnectionPressures (StandardWells_impl.hpp:218-296): b_w, b_o, b_g, rsSat, rvSat of the
+        perforated cells at the given pressures, with the cells' rs / rv / phase condition / oil saturation"""
+        from opmgpu import capi
+        cells = np.asarray(self.wells[1])
+        st, t = self.st, self.tab
+        pvtnum = None if self.grid.pvtnum is None else self.grid.pvtnum[cells]
+        hc = st.hc[cells]
+        free_gas = (hc != capi.HC_OIL_ONLY).astype(np.int8); free_oil = (hc != capi.HC_GAS_ONLY).astype(np.int8)
+        if not t.has_disgas:
+            free_gas[:] = 1
+        if not t.has_vapoil:
+            free_oil[:] = 1
+        b = np.stack([self.orc.pvt(t, "bWat", press, pvtnum=pvtnum)[:, 0],
+                      self.orc.pvt(t, "bOil", press, st.rs[cells], free_gas, pvtnum)[:, 0],
+                      self.orc.pvt(t, "bGas", press, st.rv[cells], free_oil, pvtnum)[:, 0]], 1)
+        rsmax = self.orc.pvt(t, "rsSat", press, pvtnum=pvtnum)[:, 0] if t.has_disgas else np.zeros(cells.size)
+        rvmax = self.orc.pvt(t, "rvSat", press, pvtnum=pvtnum)[:, 0] if t.has_vapoil else np.zeros(cells.size)
+        so, somax = st.sat[cells, 1], getattr(self, "so_max", np.zeros(self.nc))[cells]
+        for vap, arr in ((t.vap2, rsmax), (t.vap1, rvmax)):          # applyVap (BlackoilPropsAdFromDeck.cpp:1052-1078)
+            if vap > 0.0:
+                k = (somax > 0.01) & (so < somax)
+                arr[k] *= (np.maximum(so[k], 1.4901161193847656e-08) / somax[k]) ** vap
+        return b, rsmax, rvmax
+
+    def stabilizeUpdate(self, relax_type, omega):
+        """NonlinearSolver::stabilizeNonlinearUpdate (NonlinearSolver_impl.hpp:260-301) on the reservoir part of dx"""
+        old = getattr(self, "dx_old", None)
+        if old is None or old.size != self.dx.size:
+            old = np.zeros_like(self.dx)
+        new = self.dx.copy()
+        if omega != 1.0:
+            self.dx = omega * self.dx + (1.0 - omega) * old if relax_type == 1 else omega * self.dx
+        self.dx_old = new
+
     def addWellTerms(self, resid_delta, rc, blocks):
         nc = self.nc
-        for i, c in enumerate(self.wells[1]):
-            for a in range(3):
-                self.r[a * nc + c] += resid_delta[i, a]
+        cells = np.asarray(self.wells[1])
+        for a in range(3):
+            np.add.at(self.r, a * nc + cells, np.asarray(resid_delta)[:, a])
         sc = np.repeat(self.scale, 3)
-        for k, (a, b) in enumerate(np.asarray(rc).reshape(-1, 2)):
-            s = self.rowptr[a] + np.searchsorted(self.col[self.rowptr[a]:self.rowptr[a + 1]], b)
-            self.val[s] += np.asarray(blocks[k]) * sc
+        rc = np.asarray(rc).reshape(-1, 2)
+        # position of every (row, col) block: binary search in the row-major key list of the pattern (rows and columns ascending)
+        if getattr(self, "_keys", None) is None:
+            rows = np.repeat(np.arange(nc, dtype=np.int64), np.diff(self.rowptr))
+            self._keys = rows * nc + self.col
+        pos = np.searchsorted(self._keys, rc[:, 0].astype(np.int64) * nc + rc[:, 1])
+        assert np.array_equal(self._keys[pos], rc[:, 0].astype(np.int64) * nc + rc[:, 1])
+        np.add.at(self.val, pos, np.asarray(blocks) * sc)
 
     def addWellRhs(self, rhs_delta):
         nc = self.nc
-        for i, c in enumerate(self.wells[1]):
-            for a in range(3):
-                self.rhs_extra[a * nc + c] += rhs_delta[i, a]
+        cells = np.asarray(self.wells[1])
+        for a in range(3):
+            np.add.at(self.rhs_extra, a * nc + cells, np.asarray(rhs_delta)[:, a])
 
     def getConvergence(self):
         st, self.B_avg, self.CNV, self.MB, self.linf, conv = self.orc.convergence(self.grid, self.prm, self.dt, self.r, self.binv)

@@ -23,17 +23,34 @@ def main():
     ap.add_argument("--dt-days", type=float, default=None)
     ap.add_argument("--max-newton", type=int, default=15)
     ap.add_argument("--no-wells", action="store_true")
+    ap.add_argument("--rate", type=float, default=None)
+    ap.add_argument("--perturb", type=float, default=None)
+    ap.add_argument("--bhp", type=float, default=None)
+    ap.add_argument("--gascap", type=float, default=None)
+    ap.add_argument("--plain", action="store_true", help="plain Newton instead of the reference's stabilised NonlinearSolver")
     args = ap.parse_args()
     from opmgpu import capi, decks, wells as W
     from opmgpu.model import GpuBlackoilModel
     import test_gpu_fullsize as T
     make, dtd = T.DECKS[args.deck]
-    grid, tab, st, wl = make()
+    kw = {}
+    if args.rate is not None:
+        kw["rate"] = args.rate
+    if args.perturb is not None:
+        kw["perturb"] = args.perturb
+    if args.gascap is not None:
+        kw["gascap"] = args.gascap
+    if args.bhp is not None:
+        kw["bhp"] = args.bhp
+    grid, tab, st, wl = make(**kw)
     if args.no_wells:
         wl = None
     dt = (args.dt_days or dtd) * decks.DAY
     single = (dt < 20 * decks.DAY) and not args.double
     print("deck %s: %d cells, %d conns, wells %s, dt %.2f d, single %s" % (args.deck, grid.nc, grid.nconn, None if wl is None else (wl.nw, wl.nperf), dt / decks.DAY, single), flush=True)
+
+    from opmgpu.model import NonlinearSolver
+    ns = None if args.plain else NonlinearSolver()
 
     def run(model, core, label):
         model.prepareStep(dt, st)
@@ -42,7 +59,7 @@ def main():
             t = time.time()
             try:
                 if hasattr(model, "nonlinearIteration"):
-                    conv, lin = model.nonlinearIteration(it, single_precision=single)
+                    conv, lin = model.nonlinearIteration(it, single_precision=single, nonlinear_solver=ns)
                 else:
                     core.assemble(it == 0); conv = core.getConvergence(); lin = 0
                     if not conv or it < 1:
