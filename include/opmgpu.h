@@ -117,7 +117,7 @@ typedef struct opmgpu_params {
     double tolerance_cnv;           /* 1e-2   */
     double matbalscale[3];          /* {1.1169, 1.0031, 0.0031}                                 */
     double linear_solver_reduction; /* 1e-2   */
-    int32_t linear_solver_maxiter;  /* 150    */
+    int32_t linear_solver_maxiter;  /* 150 (solver_approach=interleaved); the reference's CPR plug-in defaults to 50 (NewtonIterationBlackoilCPR.cpp:63) */
     double ilu_relaxation;          /* 0.9    */
     int32_t ilu_ordering;           /* OPMGPU_ORDER_*                                           */
     int32_t ignore_convergence_failure; /* 0  */

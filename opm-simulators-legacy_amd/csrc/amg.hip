@@ -401,6 +401,15 @@ void AmgHierarchy<S>::setup(const Plan& P, const int32_t* d_slice_ptr, const int
         int na = 0;
         const bool stop = n <= kMaxDense || int(levels.size()) + 1 >= kMaxLevels;
         if (!stop) na = aggregate(A, 0.25, agg);
+        // aggressive coarsening (OPMGPU_AMG_AGGR=l: from level l on, aggregate twice and compose): the levels below ~100 k rows are
+        // launch-latency bound (~5 us per dependent kernel), so fewer of them shortens the cycle; costs convergence per cycle
+        static const int aggr_from = std::getenv("OPMGPU_AMG_AGGR") ? std::atoi(std::getenv("OPMGPU_AMG_AGGR")) : -1;
+        if (!stop && aggr_from >= 0 && int(levels.size()) >= aggr_from && na > kMaxDense && na * 10 <= n * 8) {
+            HostCsr C1; std::vector<int32_t> cof1, aptr1, arows1, agg2;
+            coarsen(A, agg, na, C1, cof1, aptr1, arows1);
+            const int na2 = aggregate(C1, 0.25, agg2);
+            if (na2 >= 1 && na2 * 10 <= na * 8) { for (int i = 0; i < n; ++i) agg[i] = agg2[agg[i]]; na = na2; }
+        }
         if (stop || na * 10 > n * 8 || na < 1) {           // coarsest level (or coarsening stalled)
             levels.push_back(std::move(L));
             break;
@@ -573,7 +582,12 @@ void AmgHierarchy<S>::vcycle_graph(const SolveCtl* ctl, bool level0_presmoothed)
 {
     const bool even = (npost % 2 == 0) && (npost0 % 2 == 0) && npre == 1;
     if (!use_graph || !even) { vcycle(ctl, level0_presmoothed); return; }
-    if (!graph_exec || graph_ctl != ctl || graph_pre != level0_presmoothed) {
+    // the captured launches carry the smoother / correction constants as baked-in kernel arguments: they are part of the cache key
+    const double key[6] = { pdamp0, pdamp, omega0(), double(npost), double(npost0), double(npre) };
+    bool same = graph_exec && graph_ctl == ctl && graph_pre == level0_presmoothed;
+    for (int k = 0; k < 6 && same; ++k) same = graph_key[k] == key[k];
+    if (!same) {
+        for (int k = 0; k < 6; ++k) graph_key[k] = key[k];
         if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
         hipGraph_t g = nullptr;
         OPMGPU_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));

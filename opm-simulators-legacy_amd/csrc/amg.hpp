@@ -58,6 +58,7 @@ public:
     void vcycle_graph(const SolveCtl* ctl, bool level0_presmoothed);
     hipGraphExec_t graph_exec = nullptr;
     const SolveCtl* graph_ctl = nullptr;
+    double graph_key[6] = { 0, 0, 0, 0, 0, 0 };
     bool graph_pre = false, use_graph = false;
     std::vector<std::unique_ptr<AmgLevel<S>>> levels;
     std::vector<std::unique_ptr<DevArray<int32_t>>> coarse_dev;   // per fine level: device entry id of every coarse csr entry

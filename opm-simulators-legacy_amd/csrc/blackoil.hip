@@ -385,11 +385,12 @@ __global__ __launch_bounds__(kBlock) void k_flux(int xm, int nb, int nbp, const 
                                                  const double* __restrict__ gdz, const double* __restrict__ thpres,
                                                  const double* __restrict__ pstate, const double* __restrict__ props, const MS* __restrict__ pd,
                                                  double s0, double s1, double s2, const int8_t* __restrict__ mask,
-                                                 double* __restrict__ R, MS* __restrict__ A, MS* __restrict__ wout)
+                                                 double* __restrict__ R, MS* __restrict__ A, MS* __restrict__ wout, const int32_t* __restrict__ chunk_perm)
 {
     const int nchunks = (nb + kBlock - 1) / kBlock;
-    const int ch = xcd_first(nchunks, xm);
-    if (ch >= xcd_end(nchunks, xm)) return;
+    const int lch = xcd_first(nchunks, xm);
+    if (lch >= xcd_end(nchunks, xm)) return;
+    const int ch = chunk_perm[lch];
     const int row = ch * kBlock + threadIdx.x;
     if (row >= nb) return;
     const int base = slice_ptr[row >> 6], lane = row & 63, nl = nlower[row], len = rowlen[row];
@@ -1018,7 +1019,8 @@ template <class MS> void BlackoilDevice::assemble_kernels(double dt, bool initia
     KtScope kts(ls.kt, KT_FLUX);
     hipLaunchKernelGGL((k_flux<MS>), dim3(grid8_for(nc)), dim3(kBlock), 0, stream, xcd_mode(), nc, P.nbp, ls.dp.slice_ptr.p, ls.dp.col.p, ls.dp.rowlen.p,
                        ls.dp.nlower.p, d_conn_code.p, d_trans.p, d_gdz.p, use_thpres ? d_thpres.p : (const double*)nullptr,
-                       d_p.p, d_props.p, (const MS*)pd, sc[0], sc[1], sc[2], ls.comm ? ls.comm->owner_mask() : (const int8_t*)nullptr, d_R.p, A, wout);
+                       d_p.p, d_props.p, (const MS*)pd, sc[0], sc[1], sc[2], ls.comm ? ls.comm->owner_mask() : (const int8_t*)nullptr, d_R.p, A, wout,
+                       (const int32_t*)ls.dp.flux_perm.p);
     ls.weights_from_assembly = wout != nullptr;
 }
 // derivative planes in the Jacobian's precision: the double ones live in d_props itself, the float ones in their own buffer

@@ -739,6 +739,7 @@ void DevPlan::upload(const Plan& P, hipStream_t s)
     trip_l.upload(P.trip_l.empty() ? one : P.trip_l, s); trip_u.upload(P.trip_u.empty() ? one : P.trip_u, s);
     trip_t.upload(P.trip_t.empty() ? one : P.trip_t, s);
     rowlen.upload(P.rowlen, s); nlower.upload(P.nlower, s); tpos.upload(P.tpos, s); simple.upload(P.simple, s);
+    flux_perm.upload(P.flux_perm, s);
     level_ptr = P.level_ptr;
     OPMGPU_HIP(hipStreamSynchronize(s));      // the host vectors may go away
 }

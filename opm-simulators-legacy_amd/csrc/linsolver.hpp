@@ -14,7 +14,7 @@ namespace opmgpu {
 
 struct DevPlan {
     int nb = 0, nbp = 0, nslices = 0, nentries = 0, nlevels = 0, nnzb = 0;
-    DevArray<int32_t> slice_ptr, col, src, entry_of_block, nat, pos, trip_ptr, trip_l, trip_u, trip_t, tpos;
+    DevArray<int32_t> slice_ptr, col, src, entry_of_block, nat, pos, trip_ptr, trip_l, trip_u, trip_t, tpos, flux_perm;
     DevArray<int16_t> rowlen, nlower;
     DevArray<int8_t> simple;
     std::vector<int32_t> level_ptr;

@@ -2,6 +2,7 @@
 #include "plan.hpp"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <numeric>
@@ -116,6 +117,21 @@ int build_plan(int nb, const int32_t* rowptr, const int32_t* col, int ordering, 
     {
         int B = kDefaultZBlock, nx = 0, ny = 0, nz = 0;
         if (const char* e = std::getenv("OPMGPU_ZBLOCK")) B = std::atoi(e);
+        // OPMGPU_BRICK=bx,by,bz: rows of a level ordered brick by brick (bricks x-fastest, cells inside a brick x-fastest).  With the
+        // level-interleaved chunk order of the assembly kernel (flux_perm below) the rows in flight on one XCD are then BOTH colours of a
+        // compact set of bricks: a cell record is fetched once and found in the L2 by the six rows that need it, instead of once per
+        // colour pass plus every time its k-plane neighbours come round.
+        int bx = 0, by = 0, bz = 0;
+        if (const char* e = std::getenv("OPMGPU_BRICK")) std::sscanf(e, "%d,%d,%d", &bx, &by, &bz);
+        if (bx > 0 && by > 0 && bz > 0 && ordering == OPMGPU_ORDER_MULTICOLOR && infer_cartesian_dims(nb, rowptr, col, nx, ny, nz)) {
+            lkey.resize(nb);
+            const int64_t nbi = (nx + bx - 1) / bx, nbj = (ny + by - 1) / by;
+            for (int c = 0; c < nb; ++c) {
+                const int64_t i = c % nx, j = (c / nx) % ny, k = c / (int64_t(nx) * ny);
+                const int64_t brick = ((k / bz) * nbj + (j / by)) * nbi + (i / bx);
+                lkey[c] = ((brick * bz + (k % bz)) * by + (j % by)) * bx + (i % bx);
+            }
+        } else
         if (B > 1 && ordering == OPMGPU_ORDER_MULTICOLOR && infer_cartesian_dims(nb, rowptr, col, nx, ny, nz)) {
             lkey.resize(nb);
             for (int c = 0; c < nb; ++c) {
@@ -131,6 +147,24 @@ int build_plan(int nb, const int32_t* rowptr, const int32_t* col, int ordering, 
     P.level.resize(nb); P.nlevels = nlev; P.level_ptr.assign(nlev + 1, 0);
     for (int r = 0; r < nb; ++r) { P.level[r] = lev[P.nat[r]]; P.level_ptr[P.level[r] + 1]++; }
     for (int l = 0; l < nlev; ++l) P.level_ptr[l + 1] += P.level_ptr[l];
+    // --- launch order of the assembly's 256-row chunks: the chunks of all levels interleaved in proportion to their position inside
+    // their level (chunk q of level l has key q / chunks(l)), so that rows of different colours that sit in the same place are in
+    // flight together.  Identity unless OPMGPU_FLUX_INTERLEAVE=1 (needs an intra-level order that means the same place in every
+    // level: the brick order above).
+    {
+        const int nch = (nb + 255) / 256;
+        P.flux_perm.resize(nch); std::iota(P.flux_perm.begin(), P.flux_perm.end(), 0);
+        const char* e = std::getenv("OPMGPU_FLUX_INTERLEAVE");
+        if (e && std::atoi(e) != 0 && nlev > 1 && nlev <= 16) {
+            std::vector<double> key(nch);
+            for (int ch = 0; ch < nch; ++ch) {
+                const int r = ch * 256, l = P.level[r];
+                const double lo = P.level_ptr[l], len = std::max(1, P.level_ptr[l + 1] - P.level_ptr[l]);
+                key[ch] = (r - lo) / len + 1e-9 * l;
+            }
+            std::stable_sort(P.flux_perm.begin(), P.flux_perm.end(), [&](int a, int b) { return key[a] < key[b]; });
+        }
+    }
     // --- SELL-64
     P.nslices = P.nbp / 64; P.slice_ptr.assign(P.nslices + 1, 0);
     P.rowlen.assign(P.nbp, 0); P.nlower.assign(P.nbp, 0);

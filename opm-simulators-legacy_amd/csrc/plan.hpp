@@ -48,6 +48,7 @@ struct Plan {
     std::vector<int32_t> trip_l, trip_u, trip_t;   // entry ids
     std::vector<int8_t> simple;            // [nbp] 1 = every ILU0 update of the row hits its diagonal block: its U entries are those of A
     std::vector<int32_t> tpos;             // [nentries] entry id of the transposed block (j,i) of entry (i,j); -1: none / padding
+    std::vector<int32_t> flux_perm;        // [ceil(nb / 256)] launch order of the assembly kernel's 256-row chunks (see build_plan)
 
     static inline int64_t val_index(int32_t entry, int comp) { return int64_t(entry >> 6) * 576 + comp * 64 + (entry & 63); }
     int32_t entry(int row, int slot) const { return (slice_ptr[row >> 6] + slot) * 64 + (row & 63); }

@@ -90,6 +90,8 @@ def default_params(**over):
             p.matbalscale[:] = list(v)
         else:
             setattr(p, k, v)
+    if p.use_cpr and "linear_solver_maxiter" not in over:
+        p.linear_solver_maxiter = 50          # the reference's CPR plug-in has its own default (NewtonIterationBlackoilCPR.cpp:61-66: maxit 50, restart 40)
     return p
 
 

@@ -31,6 +31,8 @@ class PIDTimeStepControl:
             raise NumericalIssue("non-finite relative change in the time step control")
         if e[2] > self.tol:                       # error too large: shrink proportionally
             return dt * self.tol / e[2]
+        if e[2] == 0.0 or e[1] == 0.0:            # unchanged state: the reference's floating-point division gives +inf, the caller's growth limits clip it
+            return float("inf")
         kP, kI, kD = 0.075, 0.175, 0.01
         return dt * (e[1] / e[2]) ** kP * (self.tol / e[2]) ** kI * (e[0] * e[0] / e[1] / e[2]) ** kD
 

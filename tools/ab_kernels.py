@@ -15,8 +15,14 @@ m = GpuBlackoilModel(grid, tab, prm)
 m.prepareStep(5 * decks.DAY, st)
 m.assemble(True)
 t_asm = m.time_kernel(capi.K_ASSEMBLE, 10); t_props = m.time_kernel(capi.K_PROPS, 10)
+m.setSolvePrecision(True)          # float Jacobian (what a dt < 20 d step assembles)
+m.assemble(False)
+t_asm_f = m.time_kernel(capi.K_ASSEMBLE, 10)
+m.setSolvePrecision(False)
+m.assemble(False)
 rowptr, col, val = m.jacobian()
-out = {"cluster": os.environ.get("OPMGPU_CLUSTER", "0"), "assemble_ms": round(t_asm, 4), "props_ms": round(t_props, 4)}
+out = {"knobs": {k: v for k, v in os.environ.items() if k.startswith("OPMGPU_")}, "assemble_f64_ms": round(t_asm, 4), "assemble_f32_ms": round(t_asm_f, 4),
+       "props_f64_ms": round(t_props, 4), "flux_f64_ms": round(t_asm - t_props, 4)}
 for name, sp in (("f32", True), ("f64", False)):
     s = GpuNewtonIteration(prm); s.load(rowptr, col, val, sp); s.ilu0_factor()
     out["spmv_" + name] = round(s.time_kernel(capi.K_SPMV, 50), 4)
