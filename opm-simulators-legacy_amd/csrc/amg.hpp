@@ -15,6 +15,7 @@
 #define OPMGPU_AMG_HPP
 
 #include <memory>
+#include <vector>
 
 #include "common.hpp"
 #include "plan.hpp"
@@ -37,6 +38,25 @@ struct AmgLevel {
     DevArray<int32_t> agg_ptr, agg_rows;        // rows of every aggregate (restriction, fixed order)
     DevArray<int32_t> contrib_ptr, contrib_idx; // fine entries summed into every coarse entry (Galerkin)
     int n_coarse = 0, nentries_coarse = 0;
+    // Level 0 only -- BORDERED operator [A_p Bc; Cr Dw]: one extra unknown per well (its bhp) that couples the well's perforated cells
+    // like the reference's explicit Schur complement does, without filling the borrowed block-plan structure with a clique per well.
+    // Vectors of a bordered level have n + nw entries (well k at index n + k); the border values live behind the SELL values:
+    // val[nentries + j] = column entry of perforation j (row perf_row[j], column n + well), val[nentries + nperf + j] = row entry
+    // (row n + well, column perf_row[j]), val[nentries + 2 nperf + k] = diagonal of well k.
+    int nw = 0, nperf = 0;
+    const int32_t* b_connpos = nullptr;         // [nw+1]  (device, owned by the well model)
+    const int32_t* b_perf_row = nullptr;        // [nperf]
+    const int32_t* b_perf_of_row = nullptr;     // [>= n] perforation of a row or -1
+    const int32_t* b_perf_well = nullptr;       // [nperf]
+    int ntot() const { return n + nw; }
+};
+
+// host description of the border handed to AmgHierarchy::setup
+struct AmgBorderSpec {
+    int nw = 0, nperf = 0;
+    std::vector<int32_t> connpos, perf_row;     // internal rows
+    std::vector<double> bcol, crow, dw;         // representative values (first matrix) for the aggregation strengths
+    const int32_t *d_connpos = nullptr, *d_perf_row = nullptr, *d_perf_of_row = nullptr, *d_perf_well = nullptr;
 };
 
 template <class S>
@@ -47,7 +67,8 @@ public:
     AmgHierarchy(const AmgHierarchy&) = delete;
     AmgHierarchy& operator=(const AmgHierarchy&) = delete;
     // structure from the block plan + the level-0 pressure values (host copy, entry-indexed); builds all levels
-    void setup(const Plan& P, const int32_t* d_slice_ptr, const int32_t* d_col, const std::vector<double>& ap_host);
+    void setup(const Plan& P, const int32_t* d_slice_ptr, const int32_t* d_col, const std::vector<double>& ap_host, const AmgBorderSpec* border = nullptr);
+    int border_nw() const { return levels.empty() ? 0 : levels[0]->nw; }
     bool ready() const { return !levels.empty(); }
     // numeric phase for a new matrix: level-0 values are already in levels[0].val
     void galerkin(bool coarse_levels = true);

@@ -67,6 +67,12 @@ struct LowRankOp {
     const double* P = nullptr;             // [nperf][3][7], rows already matbal-scaled
     const double* Q = nullptr;             // [nperf][7][3]
     double* t = nullptr;                   // [nw][7] scratch
+    // for the bordered pressure system of the CPR stage (one bhp unknown per well, amg.hpp): d cq_s / d (cell, mixture, bhp) per
+    // perforation as the well assembly saved them ([nperf][21]: F 3x3, M 3x3, fb 3), the control equation's gradient per well
+    // ([nw][4]: d g / d qs (3), d g / d bhp), and the matbal scaling of the cell rows
+    const double* Fsave = nullptr;
+    const double* ctrl_row = nullptr;
+    double scale[3] = { 1.0, 1.0, 1.0 };
 };
 
 template <class S>
