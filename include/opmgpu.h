@@ -384,6 +384,24 @@ int opmgpu_comm_init(opmgpu_ctx* ctx, int rank, int nranks, const uint8_t* id, i
                      int n_neigh, const int32_t* neigh_rank, const int32_t* send_ptr,
                      const int32_t* send_cells, const int32_t* recv_ptr, const int32_t* recv_cells);
 
+/* The same communicator over a caller-supplied TRANSPORT instead of RCCL -- e.g. the MPI communicator flow_legacy already owns
+ * (ParallelISTLInformation), or the shared-memory test transport of tests/support.  The library calls back for its two
+ * primitives, both on device buffers and ordered on the given HIP stream (the callback enqueues on it or synchronises it):
+ *   allreduce: in-place sum (is_max = 0) or max of n doubles;
+ *   exchange:  for every neighbour q send scount[q] bytes from sbuf + soff[q] to rank neigh_rank[q] and receive rcount[q] bytes
+ *              from it into rbuf + roff[q] (byte offsets / counts).
+ * A non-zero return value becomes OPMGPU_ECOMM.  The struct is copied; `destroy(self)` is called when the context goes away. */
+typedef struct opmgpu_transport {
+    void* self;
+    int  (*allreduce)(void* self, double* dbuf, int n, int is_max, void* hip_stream);
+    int  (*exchange)(void* self, int n_neigh, const int32_t* neigh_rank, const void* sbuf, const int64_t* soff, const int64_t* scount,
+                     void* rbuf, const int64_t* roff, const int64_t* rcount, void* hip_stream);
+    void (*destroy)(void* self);
+} opmgpu_transport;
+int opmgpu_comm_init_transport(opmgpu_ctx* ctx, int rank, int nranks, const opmgpu_transport* transport, int32_t n_owned,
+                               int n_neigh, const int32_t* neigh_rank, const int32_t* send_ptr,
+                               const int32_t* send_cells, const int32_t* recv_ptr, const int32_t* recv_cells);
+
 /* Host-only planning entry (no device needed): elimination position and level of every row for
  * the given ordering -- the same plan opmgpu_get_ordering reports for a loaded matrix. */
 int opmgpu_plan_ordering(int nb, const int32_t* rowptr, const int32_t* col, int ordering,

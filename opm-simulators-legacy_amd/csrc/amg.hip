@@ -25,15 +25,16 @@ struct HostCsr {
 
 // greedy strength-based aggregation (Vanek-style, as in dune-istl's aggregation AMG): a node whose strong
 // neighbours are all free seeds an aggregate with them; leftovers join their strongest aggregated neighbour.
-int aggregate(const HostCsr& A, double theta, std::vector<int32_t>& agg)
+// npin: the last npin rows (well unknowns of the bordered pressure system) stay singletons on every level
+int aggregate(const HostCsr& A, double theta, std::vector<int32_t>& agg, int npin = 0)
 {
-    const int n = A.n;
-    agg.assign(n, -1);
-    std::vector<double> maxoff(n, 0.0);
+    const int n = A.n - npin;
+    agg.assign(A.n, -1);
+    std::vector<double> maxoff(A.n, 0.0);
     for (int i = 0; i < n; ++i)
         for (int s = A.rowptr[i]; s < A.rowptr[i + 1]; ++s)
-            if (A.col[s] != i) maxoff[i] = std::max(maxoff[i], std::fabs(A.val[s]));
-    auto strong = [&](int i, int s) { return A.col[s] != i && std::fabs(A.val[s]) >= theta * maxoff[i] && maxoff[i] > 0.0; };
+            if (A.col[s] != i && A.col[s] < n) maxoff[i] = std::max(maxoff[i], std::fabs(A.val[s]));
+    auto strong = [&](int i, int s) { return A.col[s] != i && A.col[s] < n && std::fabs(A.val[s]) >= theta * maxoff[i] && maxoff[i] > 0.0; };
     int na = 0;
     for (int i = 0; i < n; ++i) {
         if (agg[i] >= 0) continue;
@@ -51,6 +52,7 @@ int aggregate(const HostCsr& A, double theta, std::vector<int32_t>& agg)
             if (strong(i, s) && agg[A.col[s]] >= 0 && std::fabs(A.val[s]) > best) { best = std::fabs(A.val[s]); bj = A.col[s]; }
         agg[i] = bj >= 0 ? agg[bj] : na++;
     }
+    for (int i = n; i < A.n; ++i) agg[i] = na++;
     return na;
 }
 
@@ -183,17 +185,50 @@ __device__ __forceinline__ S sell_row_dot(const S* __restrict__ v, const int32_t
     return acc;
 }
 
+// Border of a level-0 operator (amg.hpp): the row kernels get `gcells` workgroups for the cell rows plus one workgroup per well.
+template <class S>
+struct Border {
+    int nw = 0, n = 0, gcells = 0;
+    const int32_t *connpos = nullptr, *perf_row = nullptr, *perf_of_row = nullptr, *perf_well = nullptr;
+    const S *bcol = nullptr, *crow = nullptr, *dw = nullptr;
+};
+// cell row: the column entry towards its well's unknown
+template <class S, class XF>
+__device__ __forceinline__ S border_cell(const Border<S>& B, int row, XF xfun)
+{
+    if (!B.nw) return S(0);
+    const int j = B.perf_of_row[row];
+    return j >= 0 ? B.bcol[j] * xfun(B.n + B.perf_well[j]) : S(0);
+}
+// well row k by one workgroup: sum_j crow[j] xfun(perf_row[j]) + dw[k] xfun(n + k); result valid in thread 0 (fixed order: deterministic)
+template <class S, class XF>
+__device__ double border_well(const Border<S>& B, int k, XF xfun)
+{
+    __shared__ double sm[4];
+    double acc[1] = { 0.0 };
+    for (int j = B.connpos[k] + threadIdx.x; j < B.connpos[k + 1]; j += kBlock) acc[0] += double(B.crow[j]) * double(xfun(B.perf_row[j]));
+    block_sum<1>(acc, sm);
+    return acc[0] + double(B.dw[k]) * double(xfun(B.n + k));
+}
+
 // pre-smoothing from a zero guess fused with the residual (small, launch-bound levels): x = omega D^-1 b ; r = b - A x
 template <class S>
 __global__ __launch_bounds__(kBlock) void k_amg_smooth0_residual(int n, const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
                                                                  const S* __restrict__ val, const S* __restrict__ b, S omega, const S* __restrict__ dinv,
-                                                                 S* __restrict__ x, S* __restrict__ r, const SolveCtl* __restrict__ ctl)
+                                                                 S* __restrict__ x, S* __restrict__ r, const SolveCtl* __restrict__ ctl, Border<S> B = Border<S>())
 {
     if (ctl && ctl->done) return;
+    auto xf = [&](int j) { return omega * dinv[j] * b[j]; };
+    if (B.nw && int(blockIdx.x) >= B.gcells) {
+        const int k = blockIdx.x - B.gcells;
+        const double ax = border_well(B, k, xf);
+        if (threadIdx.x == 0) { x[n + k] = xf(n + k); r[n + k] = b[n + k] - S(ax); }
+        return;
+    }
     const int row = blockIdx.x * kBlock + threadIdx.x;
     if (row >= n) return;
     const int base = slice_ptr[row >> 6], width = slice_ptr[(row >> 6) + 1] - base, lane = row & 63;
-    const S ax = sell_row_dot<S>(val + long(base) * 64 + lane, col + long(base) * 64 + lane, width, [&](int j) { return omega * dinv[j] * b[j]; });
+    const S ax = sell_row_dot<S>(val + long(base) * 64 + lane, col + long(base) * 64 + lane, width, xf) + border_cell(B, row, xf);
     x[row] = omega * dinv[row] * b[row];
     r[row] = b[row] - ax;
 }
@@ -203,18 +238,33 @@ template <class S, int MODE>
 __global__ __launch_bounds__(kBlock) void k_amg_residual(int n, const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
                                                          const S* __restrict__ val, const S* __restrict__ b, const S* __restrict__ x,
                                                          S omega, const S* __restrict__ dinv, S* __restrict__ out, const SolveCtl* __restrict__ ctl,
-                                                         const int32_t* __restrict__ agg = nullptr, const S* __restrict__ xc = nullptr, S pdamp = S(0))
+                                                         const int32_t* __restrict__ agg = nullptr, const S* __restrict__ xc = nullptr, S pdamp = S(0),
+                                                         Border<S> B = Border<S>())
 {
     if (ctl && ctl->done) return;
+    if (B.nw && int(blockIdx.x) >= B.gcells) {          // a well row of the bordered level 0
+        const int k = blockIdx.x - B.gcells, i = n + k;
+        double ax;
+        if (MODE == 3) ax = border_well(B, k, [&](int j) { return x[j] + pdamp * xc[agg[j]]; });
+        else ax = border_well(B, k, [&](int j) { return x[j]; });
+        if (threadIdx.x == 0) {
+            const S acc = b[i] - S(ax);
+            if (MODE == 3) out[i] = (x[i] + pdamp * xc[agg[i]]) + omega * dinv[i] * acc;
+            else out[i] = MODE == 0 ? acc : x[i] + omega * dinv[i] * acc;
+        }
+        return;
+    }
     const int row = blockIdx.x * kBlock + threadIdx.x;
     if (row >= n) return;
     const int base = slice_ptr[row >> 6], width = slice_ptr[(row >> 6) + 1] - base, lane = row & 63;
     if (MODE == 3) {
-        const S acc = b[row] - sell_row_dot<S>(val + long(base) * 64 + lane, col + long(base) * 64 + lane, width, [&](int j) { return x[j] + pdamp * xc[agg[j]]; });
+        auto xf = [&](int j) { return x[j] + pdamp * xc[agg[j]]; };
+        const S acc = b[row] - sell_row_dot<S>(val + long(base) * 64 + lane, col + long(base) * 64 + lane, width, xf) - border_cell(B, row, xf);
         out[row] = (x[row] + pdamp * xc[agg[row]]) + omega * dinv[row] * acc;
         return;
     }
-    const S acc = b[row] - sell_row_dot<S>(val + long(base) * 64 + lane, col + long(base) * 64 + lane, width, [&](int j) { return x[j]; });
+    auto xf = [&](int j) { return x[j]; };
+    const S acc = b[row] - sell_row_dot<S>(val + long(base) * 64 + lane, col + long(base) * 64 + lane, width, xf) - border_cell(B, row, xf);
     out[row] = MODE == 0 ? acc : x[row] + omega * dinv[row] * acc;
 }
 // level 0 with a two-colour row order (the block plan's multicolour ordering of a grid stencil): Gauss-Seidel by colour.  Rows of one
@@ -240,9 +290,23 @@ __global__ __launch_bounds__(kBlock) void k_amg_row_wave(int n, const int32_t* _
                                                          const S* __restrict__ val, const S* __restrict__ b, const S* __restrict__ x,
                                                          S omega, const S* __restrict__ dinv, S* __restrict__ out, S* __restrict__ xout,
                                                          const SolveCtl* __restrict__ ctl,
-                                                         const int32_t* __restrict__ agg = nullptr, const S* __restrict__ xc = nullptr, S pdamp = S(0))
+                                                         const int32_t* __restrict__ agg = nullptr, const S* __restrict__ xc = nullptr, S pdamp = S(0),
+                                                         Border<S> B = Border<S>())
 {
     if (ctl && ctl->done) return;
+    auto xf = [&](int j) { return MODE == 2 ? omega * dinv[j] * b[j] : (MODE == 3 ? x[j] + pdamp * xc[agg[j]] : x[j]); };
+    if (B.nw && int(blockIdx.x) >= B.gcells) {          // a well row of the bordered level 0
+        const int k = blockIdx.x - B.gcells, i = n + k;
+        const double ax = border_well(B, k, xf);
+        if (threadIdx.x == 0) {
+            const S res = b[i] - S(ax);
+            if (MODE == 0) out[i] = res;
+            else if (MODE == 1) out[i] = x[i] + omega * dinv[i] * res;
+            else if (MODE == 3) out[i] = (x[i] + pdamp * xc[agg[i]]) + omega * dinv[i] * res;
+            else { out[i] = res; xout[i] = omega * dinv[i] * b[i]; }
+        }
+        return;
+    }
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
     if (row >= n) return;
     const int base = slice_ptr[row >> 6], width = slice_ptr[(row >> 6) + 1] - base, lane = row & 63;
@@ -250,9 +314,9 @@ __global__ __launch_bounds__(kBlock) void k_amg_row_wave(int n, const int32_t* _
     for (int k = l; k < width; k += 64) {
         const long e = long(base + k) * 64 + lane;
         const int j = col[e];
-        const S xj = MODE == 2 ? omega * dinv[j] * b[j] : (MODE == 3 ? x[j] + pdamp * xc[agg[j]] : x[j]);
-        acc += double(val[e]) * double(xj);
+        acc += double(val[e]) * double(xf(j));
     }
+    if (l == 0) acc += double(border_cell(B, row, xf));
     acc = wave_sum(acc);
     if (l == 0) {
         const S res = b[row] - S(acc);
@@ -358,7 +422,7 @@ __global__ __launch_bounds__(kBlock) void k_dense_apply(int n, const double* __r
 
 // ---------------------------------------------------------------- host driver
 template <class S>
-void AmgHierarchy<S>::setup(const Plan& P, const int32_t* d_slice_ptr, const int32_t* d_col, const std::vector<double>& ap_host)
+void AmgHierarchy<S>::setup(const Plan& P, const int32_t* d_slice_ptr, const int32_t* d_col, const std::vector<double>& ap_host, const AmgBorderSpec* border)
 {
     levels.clear(); level_sizes.clear(); coarse_dev.clear();
     if (const char* e = std::getenv("OPMGPU_AMG_OMEGA")) omega = std::atof(e);
@@ -373,41 +437,63 @@ void AmgHierarchy<S>::setup(const Plan& P, const int32_t* d_slice_ptr, const int
     if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
     npost0 = npost;
     if (const char* e = std::getenv("OPMGPU_AMG_NPOST0")) npost0 = std::atoi(e);
+    // bordered level 0 (amg.hpp): one extra unknown per well; too many wells for the dense coarsest level -> no border
+    const int nwb = (border && border->nw > 0 && border->nw <= kDenseMax / 2) ? border->nw : 0;
+    const int npb = nwb ? border->nperf : 0;
+    std::vector<int32_t> perf_of(P.nb, -1);
+    for (int j = 0; j < npb; ++j) perf_of[border->perf_row[j]] = j;
     HostCsr A;
-    A.n = P.nb; A.rowptr.assign(P.nb + 1, 0);
-    for (int r = 0; r < P.nb; ++r) A.rowptr[r + 1] = A.rowptr[r] + P.rowlen[r];
-    A.col.resize(A.rowptr[P.nb]); A.val.resize(A.col.size()); A.dev.resize(A.col.size());
-    std::vector<int32_t> diag0(P.nb, 0);
-    for (int r = 0; r < P.nb; ++r)
+    A.n = P.nb + nwb; A.rowptr.assign(A.n + 1, 0);
+    for (int r = 0; r < P.nb; ++r) A.rowptr[r + 1] = A.rowptr[r] + P.rowlen[r] + (perf_of[r] >= 0 ? 1 : 0);
+    for (int k = 0; k < nwb; ++k) A.rowptr[P.nb + k + 1] = A.rowptr[P.nb + k] + (border->connpos[k + 1] - border->connpos[k]) + 1;
+    A.col.resize(A.rowptr[A.n]); A.val.resize(A.col.size()); A.dev.resize(A.col.size());
+    std::vector<int32_t> diag0(A.n, 0), well_of(npb, 0);
+    for (int k = 0; k < nwb; ++k) for (int j = border->connpos[k]; j < border->connpos[k + 1]; ++j) well_of[j] = k;
+    for (int r = 0; r < P.nb; ++r) {
         for (int k = 0; k < P.rowlen[r]; ++k) {
             const int e = P.entry(r, k), s = A.rowptr[r] + k;
             A.col[s] = P.sell_col[e]; A.val[s] = ap_host[e]; A.dev[s] = e;
             if (A.col[s] == r) diag0[r] = e;
         }
+        if (perf_of[r] >= 0) {          // column entry towards the well's unknown: device id behind the SELL values
+            const int j = perf_of[r], s = A.rowptr[r] + P.rowlen[r];
+            A.col[s] = P.nb + well_of[j]; A.val[s] = border->bcol[j]; A.dev[s] = P.nentries + j;
+        }
+    }
+    for (int k = 0; k < nwb; ++k) {
+        int s = A.rowptr[P.nb + k];
+        for (int j = border->connpos[k]; j < border->connpos[k + 1]; ++j, ++s) { A.col[s] = border->perf_row[j]; A.val[s] = border->crow[j]; A.dev[s] = P.nentries + npb + j; }
+        A.col[s] = P.nb + k; A.val[s] = border->dw[k]; A.dev[s] = P.nentries + 2 * npb + k;
+        diag0[P.nb + k] = A.dev[s];
+    }
     // level 0 borrows the block plan's SELL structure
     std::unique_ptr<AmgLevel<S>> L(new AmgLevel<S>());
     L->n = P.nb; L->nslices = P.nslices; L->nentries = P.nentries; L->slice_ptr = d_slice_ptr; L->col = d_col;
+    L->nw = nwb; L->nperf = npb;
+    if (nwb) { L->b_connpos = border->d_connpos; L->b_perf_row = border->d_perf_row; L->b_perf_of_row = border->d_perf_of_row; L->b_perf_well = border->d_perf_well; }
     L->diag_entry.upload(diag0, stream);
+    int npin = nwb;
     const int kMaxDense = kDenseMax;
     int kMaxLevels = 12;
     if (const char* e = std::getenv("OPMGPU_AMG_MAXLEVELS")) kMaxLevels = std::max(2, std::atoi(e));
     if (const char* e = std::getenv("OPMGPU_AMG_COARSE_SWEEPS")) coarse_sweeps = std::max(0, std::atoi(e));
     while (true) {
-        const int n = A.n;
-        L->val.alloc(L->nentries); L->dinv.alloc(n); L->x.alloc(n); L->b.alloc(n); L->r.alloc(n); L->x2.alloc(n);
+        const int n = A.n;              // unknowns of this level (a bordered level 0: cells + wells)
+        L->val.alloc(L->nentries + 2 * size_t(L->nperf) + L->nw); L->dinv.alloc(n); L->x.alloc(n); L->b.alloc(n); L->r.alloc(n); L->x2.alloc(n);
+        L->x.zero(stream); L->b.zero(stream); L->r.zero(stream); L->x2.zero(stream);
         if (!levels.empty()) L->val.zero(stream);
         level_sizes.push_back(n);
         std::vector<int32_t> agg;
         int na = 0;
         const bool stop = n <= kMaxDense || int(levels.size()) + 1 >= kMaxLevels;
-        if (!stop) na = aggregate(A, 0.25, agg);
+        if (!stop) na = aggregate(A, 0.25, agg, npin);
         // aggressive coarsening (OPMGPU_AMG_AGGR=l: from level l on, aggregate twice and compose): the levels below ~100 k rows are
         // launch-latency bound (~5 us per dependent kernel), so fewer of them shortens the cycle; costs convergence per cycle
         static const int aggr_from = std::getenv("OPMGPU_AMG_AGGR") ? std::atoi(std::getenv("OPMGPU_AMG_AGGR")) : -1;
         if (!stop && aggr_from >= 0 && int(levels.size()) >= aggr_from && na > kMaxDense && na * 10 <= n * 8) {
             HostCsr C1; std::vector<int32_t> cof1, aptr1, arows1, agg2;
             coarsen(A, agg, na, C1, cof1, aptr1, arows1);
-            const int na2 = aggregate(C1, 0.25, agg2);
+            const int na2 = aggregate(C1, 0.25, agg2, npin);
             if (na2 >= 1 && na2 * 10 <= na * 8) { for (int i = 0; i < n; ++i) agg[i] = agg2[agg[i]]; na = na2; }
         }
         if (stop || na * 10 > n * 8 || na < 1) {           // coarsest level (or coarsening stalled)
@@ -457,7 +543,7 @@ void AmgHierarchy<S>::galerkin(bool coarse_levels)
 {
     for (size_t l = 0; l + 1 < levels.size(); ++l) {
         AmgLevel<S>& F = *levels[l]; AmgLevel<S>& C = *levels[l + 1];
-        hipLaunchKernelGGL((k_amg_dinv<S>), dim3(grid_for(F.n)), dim3(kBlock), 0, stream, F.n, F.diag_entry.p, F.val.p, F.dinv.p);
+        hipLaunchKernelGGL((k_amg_dinv<S>), dim3(grid_for(F.ntot())), dim3(kBlock), 0, stream, F.ntot(), F.diag_entry.p, F.val.p, F.dinv.p);
         if (!coarse_levels) return;           // (experiment OPMGPU_AMG_LAG_COARSE) level 0 follows the matrix, the coarse operators lag
         if (F.nentries_coarse > 400000)
             hipLaunchKernelGGL((k_amg_galerkin<S>), dim3(grid_for(F.nentries_coarse)), dim3(kBlock), 0, stream, F.nentries_coarse,
@@ -481,6 +567,14 @@ void AmgHierarchy<S>::vcycle(const SolveCtl* ctl, bool level0_presmoothed)
 {
     const S om = S(omega);
     const int nl = int(levels.size());
+    // bordered level 0: `gcells` workgroups for the cell rows + one per well (see Border)
+    auto bord = [&](const AmgLevel<S>& F, int gcells) {
+        Border<S> B;
+        if (F.nw == 0) return B;
+        B.nw = F.nw; B.n = F.n; B.gcells = gcells; B.connpos = F.b_connpos; B.perf_row = F.b_perf_row; B.perf_of_row = F.b_perf_of_row; B.perf_well = F.b_perf_well;
+        B.bcol = F.val.p + F.nentries; B.crow = B.bcol + F.nperf; B.dw = B.crow + F.nperf;
+        return B;
+    };
     // OPMGPU_AMG_TIME=1: HIP events between the launches of ONE cycle, printed to stderr (diagnostic; no profiler distortion)
     static const bool timing = std::getenv("OPMGPU_AMG_TIME") != nullptr;
     std::vector<std::pair<std::string, hipEvent_t>> marks;
@@ -493,7 +587,7 @@ void AmgHierarchy<S>::vcycle(const SolveCtl* ctl, bool level0_presmoothed)
     for (int l = 0; l < nl - 1; ++l) {
         AmgLevel<S>& F = *levels[l]; AmgLevel<S>& C = *levels[l + 1];
         const int g = grid_for(F.n);
-        if (l == 0 && gs_level0()) {
+        if (l == 0 && gs_level0() && F.nw == 0) {
             // x = D^-1 b (the first colour's sweep from zero; the caller's fused kernel did it with omega0() = 1), second colour in place,
             // then the residual: zero on the rows just solved, b - A x on the first colour
             const int n0 = gs_n0;
@@ -502,19 +596,23 @@ void AmgHierarchy<S>::vcycle(const SolveCtl* ctl, bool level0_presmoothed)
             hipLaunchKernelGGL((k_amg_gs<S, 0>), dim3(grid_for(n0)), dim3(kBlock), 0, stream, 0, n0, F.slice_ptr, F.col, F.val.p, F.b.p, F.dinv.p, F.x.p, F.r.p, ctl);
             OPMGPU_HIP(hipMemsetAsync(F.r.p + n0, 0, size_t(F.n - n0) * sizeof(S), stream));
         } else if (F.n > 50000) {
-            if (!presmoothed) hipLaunchKernelGGL((k_amg_smooth0<S>), dim3(g), dim3(kBlock), 0, stream, F.n, om, F.dinv.p, F.b.p, F.x.p, ctl);
-            hipLaunchKernelGGL((k_amg_residual<S, 0>), dim3(g), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, F.x.p, om, F.dinv.p, F.r.p, ctl);
+            if (!presmoothed) hipLaunchKernelGGL((k_amg_smooth0<S>), dim3(grid_for(F.ntot())), dim3(kBlock), 0, stream, F.ntot(), om, F.dinv.p, F.b.p, F.x.p, ctl);
+            hipLaunchKernelGGL((k_amg_residual<S, 0>), dim3(g + F.nw), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, F.x.p, om, F.dinv.p, F.r.p, ctl,
+                               (const int32_t*)nullptr, (const S*)nullptr, S(0), bord(F, g));
         } else if (F.n > 20000) {
-            hipLaunchKernelGGL((k_amg_smooth0_residual<S>), dim3(g), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, om, F.dinv.p, F.x.p, F.r.p, ctl);
+            hipLaunchKernelGGL((k_amg_smooth0_residual<S>), dim3(g + F.nw), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, om, F.dinv.p, F.x.p, F.r.p, ctl, bord(F, g));
         } else {
-            hipLaunchKernelGGL((k_amg_row_wave<S, 2>), dim3((F.n + 3) / 4), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, (const S*)F.x.p, om, F.dinv.p, F.r.p, F.x.p, ctl);
+            hipLaunchKernelGGL((k_amg_row_wave<S, 2>), dim3((F.n + 3) / 4 + F.nw), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, (const S*)F.x.p, om, F.dinv.p, F.r.p, F.x.p, ctl,
+                               (const int32_t*)nullptr, (const S*)nullptr, S(0), bord(F, (F.n + 3) / 4));
         }
         for (int sw = 1; sw < npre; ++sw) {      // further pre-smoothing sweeps, then the residual again
             sweep(F, ctl);
             if (F.n > 20000)
-                hipLaunchKernelGGL((k_amg_residual<S, 0>), dim3(g), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, F.x.p, om, F.dinv.p, F.r.p, ctl);
+                hipLaunchKernelGGL((k_amg_residual<S, 0>), dim3(g + F.nw), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, F.x.p, om, F.dinv.p, F.r.p, ctl,
+                                   (const int32_t*)nullptr, (const S*)nullptr, S(0), bord(F, g));
             else
-                hipLaunchKernelGGL((k_amg_row_wave<S, 0>), dim3((F.n + 3) / 4), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, (const S*)F.x.p, om, F.dinv.p, F.r.p, (S*)nullptr, ctl);
+                hipLaunchKernelGGL((k_amg_row_wave<S, 0>), dim3((F.n + 3) / 4 + F.nw), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, (const S*)F.x.p, om, F.dinv.p, F.r.p, (S*)nullptr, ctl,
+                                   (const int32_t*)nullptr, (const S*)nullptr, S(0), bord(F, (F.n + 3) / 4));
         }
         // the restriction also performs the coarse level's first sweep when that level would launch a separate kernel for it
         presmoothed = fuse && (l + 1 < nl - 1) && C.n > 50000;
@@ -539,7 +637,7 @@ void AmgHierarchy<S>::vcycle(const SolveCtl* ctl, bool level0_presmoothed)
         int done_sweeps = 0;
         const int npost = l == 0 ? this->npost0 : this->npost;
         const double pdamp = l == 0 ? this->pdamp0 : this->pdamp;          // (shadows the member: the correction INTO level l)
-        if (l == 0 && gs_level0()) {
+        if (l == 0 && gs_level0() && F.nw == 0) {
             const int n0 = gs_n0;
             hipLaunchKernelGGL((k_amg_prolong<S>), dim3(g), dim3(kBlock), 0, stream, F.n, F.agg.p, C.x.p, F.x.p, S(pdamp), ctl);
             for (int sw = 0; sw < npost; ++sw) {          // colours in reverse order
@@ -552,15 +650,15 @@ void AmgHierarchy<S>::vcycle(const SolveCtl* ctl, bool level0_presmoothed)
         if (fuse && npost >= 1 && F.n <= 200000) {
             // small and medium levels: the prolongation is gathered inside the first post-smoothing sweep (one launch less)
             if (F.n > 20000)
-                hipLaunchKernelGGL((k_amg_residual<S, 3>), dim3(g), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, (const S*)F.x.p, om, F.dinv.p, F.x2.p, ctl,
-                                   (const int32_t*)F.agg.p, (const S*)C.x.p, S(pdamp));
+                hipLaunchKernelGGL((k_amg_residual<S, 3>), dim3(g + F.nw), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, (const S*)F.x.p, om, F.dinv.p, F.x2.p, ctl,
+                                   (const int32_t*)F.agg.p, (const S*)C.x.p, S(pdamp), bord(F, g));
             else
-                hipLaunchKernelGGL((k_amg_row_wave<S, 3>), dim3((F.n + 3) / 4), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, (const S*)F.x.p, om, F.dinv.p, F.x2.p,
-                                   (S*)nullptr, ctl, (const int32_t*)F.agg.p, (const S*)C.x.p, S(pdamp));
+                hipLaunchKernelGGL((k_amg_row_wave<S, 3>), dim3((F.n + 3) / 4 + F.nw), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, (const S*)F.x.p, om, F.dinv.p, F.x2.p,
+                                   (S*)nullptr, ctl, (const int32_t*)F.agg.p, (const S*)C.x.p, S(pdamp), bord(F, (F.n + 3) / 4));
             std::swap(F.x.p, F.x2.p);
             done_sweeps = 1;
         } else {
-            hipLaunchKernelGGL((k_amg_prolong<S>), dim3(g), dim3(kBlock), 0, stream, F.n, F.agg.p, C.x.p, F.x.p, S(pdamp), ctl);
+            hipLaunchKernelGGL((k_amg_prolong<S>), dim3(grid_for(F.ntot())), dim3(kBlock), 0, stream, F.ntot(), F.agg.p, C.x.p, F.x.p, S(pdamp), ctl);
         }
         for (int sw = done_sweeps; sw < npost; ++sw) sweep(F, ctl);
         mark("up L" + std::to_string(l));
@@ -605,10 +703,20 @@ template <class S>
 void AmgHierarchy<S>::sweep(AmgLevel<S>& F, const SolveCtl* ctl)
 {
     const S om = S(omega);
-    if (F.n > 20000)
-        hipLaunchKernelGGL((k_amg_residual<S, 1>), dim3(grid_for(F.n)), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, F.x.p, om, F.dinv.p, F.x2.p, ctl);
-    else
-        hipLaunchKernelGGL((k_amg_row_wave<S, 1>), dim3((F.n + 3) / 4), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, (const S*)F.x.p, om, F.dinv.p, F.x2.p, (S*)nullptr, ctl);
+    Border<S> B;
+    if (F.nw) {
+        B.nw = F.nw; B.n = F.n; B.connpos = F.b_connpos; B.perf_row = F.b_perf_row; B.perf_of_row = F.b_perf_of_row; B.perf_well = F.b_perf_well;
+        B.bcol = F.val.p + F.nentries; B.crow = B.bcol + F.nperf; B.dw = B.crow + F.nperf;
+    }
+    if (F.n > 20000) {
+        B.gcells = grid_for(F.n);
+        hipLaunchKernelGGL((k_amg_residual<S, 1>), dim3(grid_for(F.n) + F.nw), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, F.x.p, om, F.dinv.p, F.x2.p, ctl,
+                           (const int32_t*)nullptr, (const S*)nullptr, S(0), B);
+    } else {
+        B.gcells = (F.n + 3) / 4;
+        hipLaunchKernelGGL((k_amg_row_wave<S, 1>), dim3((F.n + 3) / 4 + F.nw), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, (const S*)F.x.p, om, F.dinv.p, F.x2.p, (S*)nullptr, ctl,
+                           (const int32_t*)nullptr, (const S*)nullptr, S(0), B);
+    }
     std::swap(F.x.p, F.x2.p);       // the swept iterate becomes x (buffers are the same size)
 }
 

@@ -544,17 +544,17 @@ int opmgpu_comm_unique_id(uint8_t* id)
     try { return RcclComm::unique_id(id); } catch (...) { return OPMGPU_ECOMM; }
 }
 
-int opmgpu_comm_init(opmgpu_ctx* c, int rank, int nranks, const uint8_t* id, int32_t n_owned, int n_neigh, const int32_t* neigh_rank,
-                     const int32_t* send_ptr, const int32_t* send_cells, const int32_t* recv_ptr, const int32_t* recv_cells)
+static int comm_init_common(opmgpu_ctx* c, int rank, int nranks, const uint8_t* id, const opmgpu_transport* transport, int32_t n_owned, int n_neigh,
+                            const int32_t* neigh_rank, const int32_t* send_ptr, const int32_t* send_cells, const int32_t* recv_ptr, const int32_t* recv_cells)
 {
-    if (!c || !c->model || !id || nranks < 1 || rank < 0 || rank >= nranks || n_owned <= 0 || n_owned > c->model->nc || n_neigh < 0) return OPMGPU_EINVAL;
+    if (!c || !c->model || (!id && !transport) || nranks < 1 || rank < 0 || rank >= nranks || n_owned <= 0 || n_owned > c->model->nc || n_neigh < 0) return OPMGPU_EINVAL;
     if (n_neigh > 0 && (!neigh_rank || !send_ptr || !send_cells || !recv_ptr || !recv_cells)) return OPMGPU_EINVAL;
     return guarded(c, [&]() {
         std::unique_ptr<RcclComm> cm(new RcclComm());
         static const int32_t zero2[2] = { 0, 0 };
-        const int st = cm->init(rank, nranks, id, n_owned, c->model->nc, n_neigh, neigh_rank, n_neigh ? send_ptr : zero2, send_cells,
+        const int st = cm->init(rank, nranks, id, transport, n_owned, c->model->nc, n_neigh, neigh_rank, n_neigh ? send_ptr : zero2, send_cells,
                                 n_neigh ? recv_ptr : zero2, recv_cells);
-        if (st != OPMGPU_OK) return fail(c, st, "RCCL communicator initialisation failed");
+        if (st != OPMGPU_OK) return fail(c, st, transport ? "invalid transport / neighbour lists" : "RCCL communicator initialisation failed");
         cm->rebuild(c->model->plan(), c->stream);
         c->comm = std::move(cm);
         c->model->attach_comm(c->comm.get(), n_owned);
@@ -563,7 +563,20 @@ int opmgpu_comm_init(opmgpu_ctx* c, int rank, int nranks, const uint8_t* id, int
     });
 }
 
-// host-only planning entry (no device needed): used by the CPU unit tests of the ordering logic
+int opmgpu_comm_init(opmgpu_ctx* c, int rank, int nranks, const uint8_t* id, int32_t n_owned, int n_neigh, const int32_t* neigh_rank,
+                     const int32_t* send_ptr, const int32_t* send_cells, const int32_t* recv_ptr, const int32_t* recv_cells)
+{
+    if (!id) return OPMGPU_EINVAL;
+    return comm_init_common(c, rank, nranks, id, nullptr, n_owned, n_neigh, neigh_rank, send_ptr, send_cells, recv_ptr, recv_cells);
+}
+
+int opmgpu_comm_init_transport(opmgpu_ctx* c, int rank, int nranks, const opmgpu_transport* transport, int32_t n_owned, int n_neigh,
+                               const int32_t* neigh_rank, const int32_t* send_ptr, const int32_t* send_cells, const int32_t* recv_ptr, const int32_t* recv_cells)
+{
+    if (!transport) return OPMGPU_EINVAL;
+    return comm_init_common(c, rank, nranks, nullptr, transport, n_owned, n_neigh, neigh_rank, send_ptr, send_cells, recv_ptr, recv_cells);
+}
+
 int opmgpu_plan_ordering(int nb, const int32_t* rowptr, const int32_t* col, int ordering, int32_t* position, int32_t* level, int32_t* nlevels)
 {
     Plan P;

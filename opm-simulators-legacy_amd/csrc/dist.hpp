@@ -12,8 +12,11 @@ public:
     ~RcclComm() override;
     static int unique_id(uint8_t* id);
     // cells in rank-local caller numbering: [0, n_owned) owned, [n_owned, n_local) ghosts
-    int init(int rank, int nranks, const uint8_t* id, int n_owned, int n_local, int n_neigh, const int32_t* neigh_rank,
+    // id: RCCL unique id (transport == nullptr), or an external transport (opmgpu_comm_init_transport)
+    int init(int rank, int nranks, const uint8_t* id, const opmgpu_transport* transport, int n_owned, int n_local, int n_neigh, const int32_t* neigh_rank,
              const int32_t* send_ptr, const int32_t* send_cells, const int32_t* recv_ptr, const int32_t* recv_cells);
+    void check_async() override;                         // asynchronous communicator errors (ncclCommGetAsyncError) -> OPMGPU_ECOMM
+    struct Transport;
     void rebuild(const Plan& P, hipStream_t s);          // internal row lists + owner mask for the current plan
     void halo_exchange_f(float* v, hipStream_t s) override;
     void halo_exchange_d(double* v, hipStream_t s) override;
@@ -30,9 +33,7 @@ public:
 
 private:
     template <class S> void halo_t(S* v, hipStream_t s);
-    void shm_allreduce(double* d, int n, bool is_max, hipStream_t s);     // test transport (OPMGPU_COMM_TRANSPORT=shm, dist.hip)
-    struct Impl;
-    Impl* impl;
+    Transport* transport = nullptr;
     std::vector<int32_t> neigh_rank, send_ptr, recv_ptr, send_cells, recv_cells;
     DevArray<int32_t> d_send_rows, d_recv_rows;
     DevArray<int8_t> d_mask;

@@ -651,6 +651,36 @@ __global__ __launch_bounds__(kBlock) void k_cpr_sum_eqs(int nb, int nbp, const S
         if (threadIdx.x == 0) for (int u = 0; u < 8; ++u) parts[long(u) * gridDim.x + blockIdx.x] = acc[u];
     }
 }
+// Border of the level-0 pressure system (amg.hpp): one unknown per well, its bhp.  With q_a = sum_j cq_s[a][j] (flux equations) the
+// well's control equation g(q, bhp) = 0 is the extra ROW: sum_j (sum_a g_a dcq_s[a][j]/dp_j) dp_j + (g_bhp + sum_a g_a sum_j dcq_s[a][j]/dbhp)
+// dbhp; the extra COLUMN is what the cells' (matbal-scaled, CPR-weighted) equations see of bhp: -sum_a w_a(row) scale_a dcq_s[a][j]/dbhp.
+// Eliminating the unknown again gives the pressure part of the explicit Schur complement the reference forms (minus the wellbore-mixture
+// terms) -- without its clique fill.  One workgroup per well; out = [bcol (nperf) | crow (nperf) | dw (nw)].
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_cpr_border(LowRankOp lr, int nbp, const S* __restrict__ w, S* __restrict__ out)
+{
+    __shared__ double sm[4];
+    const int k = blockIdx.x;
+    const double* g = lr.ctrl_row + 4 * k;
+    double acc[1] = { 0.0 };
+    for (int j = lr.connpos[k] + threadIdx.x; j < lr.connpos[k + 1]; j += kBlock) {
+        const double* Fs = lr.Fsave + 21 * long(j);
+        const int row = lr.perf_row[j];
+        double bc = 0.0, cr = 0.0;
+        for (int a = 0; a < 3; ++a) {
+            bc -= double(w[long(a) * nbp + row]) * lr.scale[a] * Fs[18 + a];
+            cr += g[a] * Fs[3 * a];
+            acc[0] += g[a] * Fs[18 + a];
+        }
+        out[j] = S(bc); out[lr.nperf + j] = S(cr);
+    }
+    block_sum<1>(acc, sm);
+    if (threadIdx.x == 0) {
+        double d = g[3] + acc[0];
+        if (d == 0.0 || !(d == d)) d = 1.0;          // a decoupled (dead) well: identity row
+        out[2 * lr.nperf + k] = S(d);
+    }
+}
 // z = d - A [x_p; 0; 0]   (only the pressure column of every block is read: 1/3 of the matrix)
 template <class S>
 __global__ __launch_bounds__(kBlock) void k_cpr_presidual(int xm, int nb, int nbp, const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
@@ -1473,6 +1503,8 @@ template <class S> void LinSolver::cpr_prepare()
         force_refresh = false;
         new_step_hint = false;
         refreshed = refresh;
+        if (w.amg->border_nw() > 0)
+            hipLaunchKernelGGL((k_cpr_border<S>), dim3(lowrank.nw), dim3(kBlock), 0, stream, lowrank, plan.nbp, (const S*)w.cprw.p, w.amg->levels[0]->val.p + w.amg->levels[0]->nentries);
         w.amg->galerkin(refresh);
         if (coarse_nsub >= 1) coarse_setup<S>(true);
         return;
@@ -1488,14 +1520,34 @@ template <class S> void LinSolver::cpr_prepare()
         tmp.download(h.data(), ne, stream);
         OPMGPU_HIP(hipStreamSynchronize(stream));
         std::vector<double> hd(h.begin(), h.end());
-        w.amg->setup(plan, dp.slice_ptr.p, dp.col.p, hd);
+        // wells: the pressure system gets one bordering unknown per well (OPMGPU_CPR_WELL_BORDER=0: the wells stay invisible to the AMG)
+        static const bool border_on = !(std::getenv("OPMGPU_CPR_WELL_BORDER") && std::atoi(std::getenv("OPMGPU_CPR_WELL_BORDER")) == 0);
+        AmgBorderSpec bs;
+        if (border_on && lowrank.nw > 0 && lowrank.Fsave && lowrank.ctrl_row && emulate_ranks <= 1) {
+            bs.nw = lowrank.nw; bs.nperf = lowrank.nperf;
+            bs.connpos.resize(bs.nw + 1); bs.perf_row.resize(bs.nperf);
+            OPMGPU_HIP(hipMemcpyAsync(bs.connpos.data(), lowrank.connpos, (bs.nw + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            OPMGPU_HIP(hipMemcpyAsync(bs.perf_row.data(), lowrank.perf_row, bs.nperf * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            DevArray<S> bt; bt.alloc(2 * size_t(bs.nperf) + bs.nw);
+            hipLaunchKernelGGL((k_cpr_border<S>), dim3(lowrank.nw), dim3(kBlock), 0, stream, lowrank, plan.nbp, (const S*)w.cprw.p, bt.p);
+            std::vector<S> hb(bt.n);
+            bt.download(hb.data(), bt.n, stream);
+            OPMGPU_HIP(hipStreamSynchronize(stream));
+            bs.bcol.assign(hb.begin(), hb.begin() + bs.nperf); bs.crow.assign(hb.begin() + bs.nperf, hb.begin() + 2 * bs.nperf); bs.dw.assign(hb.begin() + 2 * bs.nperf, hb.end());
+            bs.d_connpos = lowrank.connpos; bs.d_perf_row = lowrank.perf_row; bs.d_perf_of_row = lowrank.perf_of_row; bs.d_perf_well = lowrank.perf_well;
+        }
+        w.amg->setup(plan, dp.slice_ptr.p, dp.col.p, hd, bs.nw > 0 ? &bs : nullptr);
     }
     hipLaunchKernelGGL((k_extract_pressure<S>), dim3(grid_for(plan.nbp)), dim3(kBlock), 0, stream, plan.nb, plan.nbp, dp.slice_ptr.p, (const S*)w.cprw.p, ((emulate_what & 2) ? pre_matrix<S>() : matrix<S>()),
                        w.amg->levels[0]->val.p);
+    if (w.amg->border_nw() > 0)
+        hipLaunchKernelGGL((k_cpr_border<S>), dim3(lowrank.nw), dim3(kBlock), 0, stream, lowrank, plan.nbp, (const S*)w.cprw.p, w.amg->levels[0]->val.p + w.amg->levels[0]->nentries);
     w.amg->galerkin();
     new_step_hint = false; refreshed = true;
     if (coarse_nsub >= 1) { coarse_begin<S>(); coarse_setup<S>(false); }
 }
+
+void LinSolver::drop_hierarchies() { wd.amg.reset(); wf.amg.reset(); }
 
 // M^-1 d = [x_p;0;0] + ILU0^-1 (d - A [x_p;0;0]),  x_p = Vcycle(sum of the equations of d)
 template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, const SolveCtl* ctl)
@@ -1507,6 +1559,7 @@ template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, con
     const bool fused_rsum = coarse && !(!comm && emulate_ranks > 1) && g <= kCsRowParts;       // real coarse space: restriction fused into the kernel below
     hipEvent_t kt_a = kt.begin();
     double* const cs_parts = coarse ? cs_buf.p + size_t(2) * coarse_nsub * coarse_nsub + coarse_nsub : nullptr;   // own scratch (the BiCGStab partial arrays are live across an application)
+    if (L0.nw > 0) OPMGPU_HIP(hipMemsetAsync(L0.x.p + L0.n, 0, L0.nw * sizeof(S), stream));      // the wells' unknowns start from zero (their right-hand side is zero)
     if (!fused_rsum)
         hipLaunchKernelGGL((k_cpr_sum_eqs<S, 0>), dim3(g), dim3(kBlock), 0, stream, plan.nb, plan.nbp, d, (const S*)w.cprw.p, L0.b.p, S(w.amg->omega0()), (const S*)L0.dinv.p, L0.x.p, ctl,
                            (const int8_t*)nullptr, (const int8_t*)nullptr, (double*)nullptr);
@@ -1710,6 +1763,7 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
         hipLaunchKernelGGL(k_final_check, dim3(1), dim3(kBlock), 0, stream, last, d_ctl, h_ctl_dev, (const double*)a_n2, np_n2);
         OPMGPU_HIP(hipStreamSynchronize(stream));
     }
+    if (comm) comm->check_async();          // a collective that failed asynchronously must not pass as a converged solve
     const double norm0 = std::sqrt(h_ctl->norm0_2), norm = std::sqrt(h_ctl->norm2);
     res.converged = h_ctl->done && h_ctl->flag == 0;
     res.iterations = h_ctl->done ? h_ctl->iters : maxit;

@@ -45,6 +45,7 @@ struct CommBase {
     virtual void allreduce_sum(double* dbuf, int n, hipStream_t s) = 0;
     virtual void allreduce_max(double* dbuf, int n, hipStream_t s) = 0;
     virtual const int8_t* owner_mask() const = 0;     // [nbp] internal numbering, 1 = owned
+    virtual void check_async() {}          // asynchronous transport errors -> HipError(OPMGPU_ECOMM)
     virtual int my_rank() const = 0;
     virtual int num_ranks() const = 0;
     // owner rank of every local row (internal numbering; ghosts: the rank they are received from)
@@ -138,6 +139,7 @@ public:
     template <class S> void spmv_at(const S* x, S* y, const S* val, const int32_t* col);    // the same operator on another copy of the matrix arrays
     // CPR (solver_approach=cpr): build / refresh the pressure AMG for the current matrix; two-stage apply
     template <class S> void cpr_prepare();
+    void drop_hierarchies();            // the wells changed: the bordered pressure hierarchy is rebuilt from the next matrix
     template <class S> void cpr_apply(const S* d, S* v, double relax, const SolveCtl* ctl);
     // x0 = 0; rhs in work<S>().b; solution in work<S>().x
     template <class S> SolveResult bicgstab(const opmgpu_params& prm);

@@ -179,6 +179,7 @@ struct WellArgs {
     double* perf_dens;           // [nperf] well_perforation_densities_
     const double* perf_pvt;      // [nperf][5] b_w b_o b_g rsSat rvSat at the average well-block pressure (k_perf_pvt)
     double* wdy;                 // [nw][4] recovered Newton increment of the well unknowns
+    double* ctrl_row;            // [nw][4] d control equation / d (qs, bhp)
     VfpArgs V;
     double gravity;
     const double* perf;          // [nperf][OPMGPU_PERF_K]
@@ -484,6 +485,7 @@ __device__ void well_assemble_dev(const WellArgs& A, int w, const int32_t* __res
         double Di[16];
         if (!inv4(D, Di)) { atomicOr(&flags[WF_ERR], 2); for (int k = 0; k < 16; ++k) Di[k] = 0.0; }
         for (int k = 0; k < 16; ++k) { wl[20 + k] = Di[k]; A.Dinv[16 * w + k] = Di[k]; }
+        if (!PRE) for (int k = 0; k < 4; ++k) A.ctrl_row[4 * w + k] = D[12 + k];      // gradient of the control equation (bordered pressure system, linsolver.hip)
         for (int k = 0; k < 4; ++k) {
             wl[36 + k] = E[k];
             if (publish) __hip_atomic_store(&Eout[k], E[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else Eout[k] = E[k];
@@ -730,7 +732,7 @@ struct BlackoilDevice::WellsDev {
     DevArray<int32_t> connpos, perf_row, perf_well, perf_of_row, type, allow_cf, ctrl_type, ctrl_ptr, ctrl_vfp, thp_ctrl, current, isnap, isaved;
     DevArray<double> WI, comp_frac, ctrl_target, ctrl_distr, ctrl_alq, depth_ref, z_perf, surf_dens_perf;
     DevArray<double> wstate, thp, cdp, perf_dens, perf_pvt, avgp, perf_rates, perf_press, P, Q, Fsave, wellE, Dinv, t, wdy, wdy_old;
-    DevArray<double> bsums, bscratch, snap, presolve_sync;
+    DevArray<double> bsums, bscratch, snap, presolve_sync, ctrl_row;
     DevArray<double> saved;         // snapshot for AdaptiveTimeStepping: wstate | thp | cdp | perf_rates | perf_press | perf_dens
     DevArray<int32_t> flags;
     std::vector<int32_t> h_connpos, h_cells, h_ctrl_ptr;
@@ -748,7 +750,7 @@ static WellArgs args_of(BlackoilDevice::WellsDev& W, BlackoilDevice::VfpDev* V, 
     A.connpos = W.connpos.p; A.perf_row = W.perf_row.p; A.type = W.type.p; A.allow_cf = W.allow_cf.p; A.ctrl_type = W.ctrl_type.p;
     A.WI = W.WI.p; A.comp_frac = W.comp_frac.p; A.ctrl_target = W.ctrl_target.p; A.ctrl_distr = W.ctrl_distr.p; A.depth_ref = W.depth_ref.p;
     A.ctrl_ptr = W.ctrl_ptr.p; A.ctrl_vfp = W.ctrl_vfp.p; A.thp_ctrl = W.thp_ctrl.p; A.ctrl_alq = W.ctrl_alq.p; A.current = W.current.p; A.thp = W.thp.p;
-    A.perf_dens = W.perf_dens.p; A.perf_pvt = W.perf_pvt.p; A.wdy = W.wdy.p; A.gravity = gravity;
+    A.perf_dens = W.perf_dens.p; A.perf_pvt = W.perf_pvt.p; A.wdy = W.wdy.p; A.gravity = gravity; A.ctrl_row = W.ctrl_row.p;
     A.V.ntab = V ? V->ntab : 0; A.V.meta = V ? V->meta.p : nullptr; A.V.datum = V ? V->datum.p : nullptr; A.V.blob = V ? V->blob.p : nullptr;
     A.z_perf = W.z_perf.p; A.surf_dens_perf = W.surf_dens_perf.p; A.perf = perf;
     A.wstate = W.wstate.p; A.cdp = W.cdp.p; A.perf_rates = W.perf_rates.p; A.perf_press = W.perf_press.p; A.P = W.P.p; A.Q = W.Q.p;
@@ -790,7 +792,7 @@ int BlackoilDevice::set_vfp_tables(int n, const opmgpu_vfp_table* tabs)
 int BlackoilDevice::set_device_wells(const opmgpu_wells* s)
 {
     if (!s || s->nw < 0) return OPMGPU_EINVAL;
-    if (s->nw == 0) { wells_free(); device_wells = false; ls.lowrank = LowRankOp(); return set_wells(0, nullptr, nullptr); }
+    if (s->nw == 0) { wells_free(); device_wells = false; ls.lowrank = LowRankOp(); ls.drop_hierarchies(); return set_wells(0, nullptr, nullptr); }
     if (!s->well_connpos || !s->well_cells || !s->WI || !s->type || !s->depth_ref || !s->comp_frac || !s->ctrl_type || !s->ctrl_target) return OPMGPU_EINVAL;
     const int nw = s->nw, np = s->well_connpos[nw];
     if (s->ctrl_ptr && s->ctrl_ptr[0] != 0) return OPMGPU_EINVAL;
@@ -843,6 +845,7 @@ int BlackoilDevice::set_device_wells(const opmgpu_wells* s)
     W.current.alloc(nw); W.current.zero(stream); W.isnap.alloc(nw); W.isaved.alloc(nw);
     W.thp.alloc(nw); W.thp.zero(stream);
     W.perf_dens.alloc(np); W.perf_dens.zero(stream); W.perf_pvt.alloc(5 * size_t(np)); W.avgp.alloc(np);
+    W.ctrl_row.alloc(4 * size_t(nw)); W.ctrl_row.zero(stream);
     W.wdy.alloc(4 * size_t(nw)); W.wdy.zero(stream); W.wdy_old.alloc(4 * size_t(nw)); W.wdy_old.zero(stream);
     W.bsums.alloc(16); W.bscratch.alloc(13 * size_t(kMaxRedBlocks)); W.snap.alloc(5 * size_t(nw) + 4 * size_t(np));
     std::vector<double> zp(np), sd(3 * size_t(np));
@@ -880,6 +883,9 @@ void BlackoilDevice::wells_rebind()
     LowRankOp& L = ls.lowrank;
     L.nw = W.nw; L.nperf = np; L.connpos = W.connpos.p; L.perf_row = W.perf_row.p; L.perf_well = W.perf_well.p; L.perf_of_row = W.perf_of_row.p;
     L.P = W.P.p; L.Q = W.Q.p; L.t = W.t.p;
+    L.Fsave = W.Fsave.p; L.ctrl_row = W.ctrl_row.p;
+    for (int a = 0; a < 3; ++a) L.scale[a] = prm.matbalscale[a];
+    ls.drop_hierarchies();
 }
 
 int BlackoilDevice::well_state_set(const double* bhp, const double* qs, const double* perf_press, const double* perf_rates)

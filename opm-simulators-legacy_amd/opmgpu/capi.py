@@ -63,6 +63,11 @@ class VfpTable(C.Structure):
                 ("nalq", C.c_int32), ("flo", _dp), ("thp", _dp), ("wfr", _dp), ("gfr", _dp), ("alq", _dp), ("data", _dp)]
 
 
+class Transport(C.Structure):
+    """opmgpu_transport: caller-supplied all-reduce / neighbour exchange (include/opmgpu.h)"""
+    _fields_ = [("self", C.c_void_p), ("allreduce", C.c_void_p), ("exchange", C.c_void_p), ("destroy", C.c_void_p)]
+
+
 class Params(C.Structure):
     _fields_ = [("dp_max_rel", C.c_double), ("ds_max", C.c_double), ("dr_max_rel", C.c_double),
                 ("max_residual_allowed", C.c_double), ("tolerance_mb", C.c_double),
@@ -167,6 +172,7 @@ SIGNATURES = {
     "opmgpu_kernel_timing_get": (C.c_int, [C.c_void_p, _dp, C.POINTER(C.c_int64)]),
     "opmgpu_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "opmgpu_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint8), C.c_int32, C.c_int, _ip, _ip, _ip, _ip, _ip]),
+    "opmgpu_comm_init_transport": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Transport), C.c_int32, C.c_int, _ip, _ip, _ip, _ip, _ip]),
     "opmgpu_plan_ordering": (C.c_int, [C.c_int, _ip, _ip, C.c_int, _ip, _ip, _ip]),
     "opmgpu_version": (C.c_char_p, []),
     "opmgpu_device_count": (C.c_int, []),

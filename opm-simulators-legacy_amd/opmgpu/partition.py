@@ -7,6 +7,7 @@ neighbour and that neighbour's receive list name the same cells in the same (glo
 halo exchange is a plain pack / send / recv / unpack.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -95,17 +96,42 @@ class LocalDomain:
         return State(st.p[g], st.sat[g], st.rs[g], st.rv[g], st.hc[g])
 
 
+SHM_TEST_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "support", "_build", "libshmtransport.so")
+
+
+def shm_test_transport_wanted():
+    """OPMGPU_COMM_TRANSPORT=shm: the multi-rank TESTS / the one-GPU rehearsal of bench.py couple their ranks (processes of one host,
+    usually sharing one GPU) through the shared-memory test transport of tests/support instead of RCCL.  The product library knows
+    nothing about it: it comes in through the public transport hook (opmgpu_comm_init_transport)."""
+    return os.environ.get("OPMGPU_COMM_TRANSPORT") == "shm"
+
+
 def attach_comm(model, dom, rank, world, unique_id):
-    """opmgpu_comm_init for a model created on dom.grid."""
+    """opmgpu_comm_init (RCCL) -- or opmgpu_comm_init_transport with the shared-memory test transport -- for a model created on dom.grid."""
     lib = capi.load()
-    idb = (C.c_uint8 * capi.UNIQUE_ID_BYTES).from_buffer_copy(bytes(unique_id))
-    st = lib.opmgpu_comm_init(model.ctx, rank, world, idb, dom.n_owned, int(dom.neigh_rank.size), capi.iptr(dom.neigh_rank),
-                              capi.iptr(dom.send_ptr), capi.iptr(dom.send_cells), capi.iptr(dom.recv_ptr), capi.iptr(dom.recv_cells))
+    lists = (dom.n_owned, int(dom.neigh_rank.size), capi.iptr(dom.neigh_rank), capi.iptr(dom.send_ptr), capi.iptr(dom.send_cells),
+             capi.iptr(dom.recv_ptr), capi.iptr(dom.recv_cells))
+    if shm_test_transport_wanted():
+        if not os.path.exists(SHM_TEST_LIB):
+            raise RuntimeError("test transport not built: make -C tests/support")
+        tl = C.CDLL(SHM_TEST_LIB)
+        tl.shm_transport_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(capi.Transport)]
+        tr = capi.Transport()
+        name = b"/opmgpu_" + bytes(unique_id)[:8].hex().encode()
+        if tl.shm_transport_create(name, rank, world, C.byref(tr)) != 0:
+            raise RuntimeError("shm test transport: could not open the segment")
+        model._keep_transport = (tl, tr)
+        st = lib.opmgpu_comm_init_transport(model.ctx, rank, world, C.byref(tr), *lists)
+    else:
+        idb = (C.c_uint8 * capi.UNIQUE_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        st = lib.opmgpu_comm_init(model.ctx, rank, world, idb, *lists)
     if st != capi.OK:
         raise RuntimeError("opmgpu_comm_init failed with status %d: %s" % (st, lib.opmgpu_last_error(model.ctx)))
 
 
 def make_unique_id():
+    if shm_test_transport_wanted():           # a random segment name instead of an RCCL id
+        return os.urandom(capi.UNIQUE_ID_BYTES)
     lib = capi.load()
     buf = (C.c_uint8 * capi.UNIQUE_ID_BYTES)()
     st = lib.opmgpu_comm_unique_id(buf)

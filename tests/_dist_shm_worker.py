@@ -1,4 +1,4 @@
-"""One rank of a multi-process run over the shared-memory TEST transport (csrc/dist.hip, OPMGPU_COMM_TRANSPORT=shm): builds the global
+"""One rank of a multi-process run over the shared-memory TEST transport (tests/support/shm_transport.cpp, OPMGPU_COMM_TRANSPORT=shm): builds the global
 synthetic deck, keeps its slab, joins the communicator, runs Newton iterations and writes its OWNED cells' state.  Started by
 tests/test_gpu_dist_shm.py; every rank uses cuda:0."""
 import json

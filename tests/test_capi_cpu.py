@@ -124,3 +124,17 @@ def test_detect_oscillations_rule():
     assert ns.detectOscillations(hist, 2) == (False, False)
     hist = [[1.0, 1.0, 1.0], [1.0, 1.0, 1.0 + 5e-4], [0.5, 0.4, 0.3]]     # nothing moved between it-2 and it-1: stagnation
     assert ns.detectOscillations(hist, 2) == (False, True)
+
+
+def test_no_test_scaffolding_in_the_product_library():
+    """The shared-memory transport of the multi-rank tests lives in tests/support and reaches the library through its public
+    transport hook; libopmgpu.so itself must not reference POSIX shared memory."""
+    import subprocess
+    from opmgpu import capi
+    syms = subprocess.run(["nm", "-D", "--undefined-only", capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "shm_open" not in syms and "shm_unlink" not in syms
+    import ctypes as C
+    from opmgpu import partition
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(os.path.dirname(partition.SHM_TEST_LIB))])
+    tl = C.CDLL(partition.SHM_TEST_LIB)
+    assert hasattr(tl, "shm_transport_create")

@@ -1,6 +1,7 @@
 """GPU: REAL multi-rank runs on one GPU.  W processes (one rank each, all on cuda:0) are coupled by the shared-memory TEST transport of
-csrc/dist.hip (OPMGPU_COMM_TRANSPORT=shm: host-staged all-reduce / halo exchange through /dev/shm) -- everything above the three
-transport primitives is the code the RCCL path runs: slab partition, send / receive lists, owner masks, ghost rows, block-Jacobi
+tests/support/shm_transport.cpp (OPMGPU_COMM_TRANSPORT=shm: host-staged all-reduce / halo exchange through /dev/shm, plugged into the
+library through its public transport hook opmgpu_comm_init_transport) -- everything above the two transport primitives is the code
+the RCCL path runs: slab partition, send / receive lists, owner masks, ghost rows, block-Jacobi
 ILU0, rank-local AMG + global coarse space, merged all-reduces of the BiCGStab scalars, collective well convergence.  The
 decomposed runs must walk the single-domain Newton path (tight linear tolerance: the preconditioner differs, the solution must not).
 RCCL itself (ncclAllReduce / ncclSend / ncclRecv on a stream) is exercised by the one-rank communicator of test_gpu_dist.py."""
