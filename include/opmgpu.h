@@ -68,6 +68,22 @@ typedef struct opmgpu_grid {
      * EclEpsScalingPointsInfo holds them (materialLawParams(cell), SaturationPropsFromDeck.cpp:91-92).  Either all
      * eight are given or all are NULL (no end-point scaling).  Order: SWL SWCR SWU SOWCR SGL SGCR SGU SOGCR. */
     const double*  eps[8];
+    /* SCALECRS YES: three-point horizontal scaling of the relative-permeability curves (EclEpsScalingPoints with
+     * enableThreePointKrSatScaling): the critical saturation of the displacing phase is a third fixed point -- krw [SWCR,
+     * 1-SOWCR-SGL, SWU], krow (in Sw) [SWL+SGL, SWCR+SGL, 1-SOWCR-SGL], krg [SGCR, 1-SOGCR-SWL, SGU], krog (in So) [SOGCR,
+     * 1-SGCR-SWL, 1-SWL-SGL]; capillary pressures stay two-point.  Needs eps[]. */
+    int32_t        scalecrs;
+    /* vertical scaling (ENDSCALE with KRW / KRO / KRG / PCW / PCG arrays): per-cell maximum of the curve; the table value is
+     * multiplied by (cell maximum / table maximum) (EclEpsTwoPhaseLaw::unscaledToScaledKrw_ etc.).  Any pointer may be NULL. */
+    const double*  eps_v[5];            /* KRW, KRO, KRG, PCW, PCG */
+    /* Relative-permeability hysteresis (SATOPTS HYSTER, EHYSTR item 2 = 0: Carlson's model for the non-wetting phases -- oil in the
+     * oil-water system, gas in the gas-oil system -- drainage curves for the wetting phases, EHYSTR item 5 = KR: no capillary
+     * pressure hysteresis; EclHysteresisTwoPhaseLaw, reached from SaturationPropsFromDeck.cpp:74-204 / updateSatHyst :206-222).
+     * imbnum: 0-based saturation region of every cell's IMBIBITION curves (IMBNUM), NULL = no hysteresis.  ieps: scaled end points
+     * of the imbibition curves (ISWL ISWCR ISWU ISOWCR ISGL ISGCR ISGU ISOGCR), all eight or all NULL (= the drainage ones, eps[]).
+     * The history (minimum wetting saturation seen by each two-phase system) lives on the device: opmgpu_update_hysteresis. */
+    const int32_t* imbnum;
+    const double*  ieps[8];
 } opmgpu_grid;
 
 /* Fluid tables, already converted to SI and pre-processed the way opm-material stores
@@ -303,6 +319,14 @@ int opmgpu_relative_change(opmgpu_ctx* ctx, double* value);
 int opmgpu_set_sat_oil_max(opmgpu_ctx* ctx, const double* so_max);
 int opmgpu_update_sat_oil_max(opmgpu_ctx* ctx);
 int opmgpu_get_sat_oil_max(opmgpu_ctx* ctx, double* so_max);
+
+/* Hysteresis history (EclHysteresisTwoPhaseLawParams::update, called once per report step by SimulatorBase_impl.hpp:190-191 ->
+ * BlackoilPropsAdFromDeck::updateSatHyst): update = take the resident state's saturations into the history (krnSwMdc of both two-phase
+ * systems = running minimum of 1 - So resp. 1 - Sg, the reference's "inconsistent" update) and recompute the Carlson shifts.
+ * set / get: the two history planes [nc] each (restart); they start at the no-history value 2.0 (EclHysteresisTwoPhaseLawParams). */
+int opmgpu_update_hysteresis(opmgpu_ctx* ctx);
+int opmgpu_set_hysteresis(opmgpu_ctx* ctx, const double* krn_sw_mdc_ow, const double* krn_sw_mdc_go);
+int opmgpu_get_hysteresis(opmgpu_ctx* ctx, double* krn_sw_mdc_ow, double* krn_sw_mdc_go, double* delta_ow, double* delta_go);
 
 /* NonlinearSolver::stabilizeNonlinearUpdate (NonlinearSolver_impl.hpp:260-301) on the resident
  * increment: dx_old <- dx, then DAMPEN: dx *= omega, SOR: dx = omega*dx + (1-omega)*dx_old(previous).

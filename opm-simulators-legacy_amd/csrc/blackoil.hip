@@ -92,31 +92,60 @@ __device__ __forceinline__ void rv_sat_d(const opmgpu_tables& T, int reg, double
     pvt1(T.gas_pg + a, T.gas_rvsat + a, T.gas_node_ptr[reg + 1] - a, p, f, df);
 }
 
-// ENDSCALE (two-point): per curve S_unscaled = u0 + (S - s0) * k with k = (u2 - u0) / (s2 - s0) precomputed on the host
-// (BlackoilDevice::rebuild_structure).  Curve order: krw, krow, pcow, krg, krog (in oil saturation), pcgo.
+// ENDSCALE: per curve S_unscaled = u0 + (S - s0) * k (two-point, k = (u2 - u0) / (s2 - s0)); with SCALECRS the relative-permeability
+// curves go through a middle point: S >= s1 -> u1 + (S - s1) * k1 (scaledToUnscaledSatThreePoint_).  Vertical scaling (KRW / KRO / KRG /
+// PCW / PCG): the table value times v = cell maximum / table maximum.  All precomputed on the host (BlackoilDevice::rebuild_structure).
+// Curve order: krw, krow, pcow, krg, krog (in oil saturation), pcgo.
 enum { EC_KRW = 0, EC_KROW, EC_PCOW, EC_KRG, EC_KROG, EC_PCGO, EC_COUNT };
+constexpr int kEpsPlanes = 5 * EC_COUNT;       // [s0 | k | s1 | k1 | v] x 6 curves, stride nbp
+constexpr int kEpsRegion = 2 * EC_COUNT;       // [u0 | u1] x 6 curves per saturation region
 struct EpsD {
     bool on;
-    double u0[EC_COUNT], s0[EC_COUNT], k[EC_COUNT];
+    double u0[EC_COUNT], s0[EC_COUNT], k[EC_COUNT], u1[EC_COUNT], s1[EC_COUNT], k1[EC_COUNT], v[EC_COUNT];
 };
-// eps: 12 planes [s0 x6 | k x6] of stride nbp (nullptr = no ENDSCALE); u0: [n_sat_regions][6]
-__device__ __forceinline__ void eps_load(const double* __restrict__ eps, const double* __restrict__ u0, long nbp, int row, int sreg, EpsD& e)
+__device__ __forceinline__ void eps_load(const double* __restrict__ eps, const double* __restrict__ ureg, long nbp, int row, int sreg, EpsD& e)
 {
     e.on = eps != nullptr;
     if (!e.on) return;
 #pragma unroll
     for (int c = 0; c < EC_COUNT; ++c) {
-        e.u0[c] = u0[EC_COUNT * sreg + c];
+        e.u0[c] = ureg[kEpsRegion * sreg + c]; e.u1[c] = ureg[kEpsRegion * sreg + EC_COUNT + c];
         e.s0[c] = eps[long(c) * nbp + row];
         e.k[c] = eps[long(EC_COUNT + c) * nbp + row];
+        e.s1[c] = eps[long(2 * EC_COUNT + c) * nbp + row];
+        e.k1[c] = eps[long(3 * EC_COUNT + c) * nbp + row];
+        e.v[c] = eps[long(4 * EC_COUNT + c) * nbp + row];
     }
+}
+// scaled -> unscaled saturation of curve c and the slope of the map there
+__device__ __forceinline__ double eps_map(const EpsD& e, int c, double sv, double& slope)
+{
+    if (sv >= e.s1[c]) { slope = e.k1[c]; return e.u1[c] + (sv - e.s1[c]) * e.k1[c]; }
+    slope = e.k[c];
+    return e.u0[c] + (sv - e.s0[c]) * e.k[c];
+}
+__device__ __forceinline__ double eps_unmap(const EpsD& e, int c, double su)       // unscaled -> scaled (inverse map)
+{
+    return su >= e.u1[c] && e.s1[c] < 1e30 ? e.s1[c] + (su - e.u1[c]) / e.k1[c] : e.s0[c] + (su - e.u0[c]) / e.k[c];
 }
 template <bool RIGHT>
 __device__ __forceinline__ void sat_curve(const double* __restrict__ x, const double* __restrict__ y, int n, double sv, const EpsD& e, int c, double& f, double& df)
 {
     if (!e.on) { sat_eval<RIGHT>(x, y, n, sv, f, df); return; }
-    sat_eval<RIGHT>(x, y, n, e.u0[c] + (sv - e.s0[c]) * e.k[c], f, df);
-    df *= e.k[c];
+    double slope;
+    sat_eval<RIGHT>(x, y, n, eps_map(e, c, sv, slope), f, df);
+    f *= e.v[c]; df *= slope * e.v[c];
+}
+// Relative-permeability hysteresis of a cell (EclHysteresisTwoPhaseLaw, Carlson for the non-wetting phases, KR only): the history
+// planes hold the smallest wetting saturation each two-phase system has seen (2.0 = none) and the shift of the imbibition curve.
+struct HystD { bool on; int ireg; double mdc_ow, mdc_go, d_ow, d_go; };
+struct HystArgs { const int32_t* imbnum; const double* hist; const double* ieps; };      // kernel argument: imbnum == nullptr = no hysteresis
+__device__ __forceinline__ void hyst_load(const int32_t* __restrict__ imbnum, const double* __restrict__ hist, long nbp, int row, HystD& h)
+{
+    h.on = imbnum != nullptr;
+    if (!h.on) return;
+    h.ireg = imbnum[row];
+    h.mdc_ow = hist[row]; h.mdc_go = hist[nbp + row]; h.d_ow = hist[2 * nbp + row]; h.d_go = hist[3 * nbp + row];
 }
 
 // Tables in LDS: every table function is two dependent memory round trips (find the segment, read its end points) and a cell
@@ -165,7 +194,7 @@ struct CellEval {
 
 // SolutionState + ReservoirResidualQuant of one cell (BlackoilModelBase_impl.hpp:614-751, 1484-1497, 2009-2027)
 __device__ void eval_cell(const opmgpu_tables& T, const EpsD& E, double so_max, int preg, int sreg, double p, double sw_, double sg_, double rs_, double rv_, int hc,
-                          CellEval& q)
+                          CellEval& q, const HystD& H = HystD{ false, 0, 2.0, 2.0, 0.0, 0.0 }, const EpsD* EI = nullptr)
 {
     const bool isSg = hc == OPMGPU_HC_GAS_AND_OIL, isRs = hc == OPMGPU_HC_OIL_ONLY, isRv = hc == OPMGPU_HC_GAS_ONLY;
     const bool freeOil = isSg || isRs, freeGas = isSg || isRv;
@@ -188,20 +217,27 @@ __device__ void eval_cell(const opmgpu_tables& T, const EpsD& E, double so_max, 
     q.pg = mk(p + f, 1, df * sg.w, df * sg.x);
     sat_curve<false>(xsw, T.swof_krw + wa, nw, sw_, E, EC_KRW, f, df);
     const V4 krw = mk(f, 0, df, 0);
-    sat_curve<true>(xsg, T.sgof_krg + ga, ng, sg.v, E, EC_KRG, f, df);
+    if (H.on && (1.0 - sg.v) > H.mdc_go) {       // gas on its (shifted) imbibition curve: krn_imb(Sw + delta) = krg_imb(Sg - delta)
+        const int gi = T.sgof_ptr[H.ireg];
+        sat_curve<true>(T.sgof_sg + gi, T.sgof_krg + gi, T.sgof_ptr[H.ireg + 1] - gi, sg.v - H.d_go, *EI, EC_KRG, f, df);
+    } else sat_curve<true>(xsg, T.sgof_krg + ga, ng, sg.v, E, EC_KRG, f, df);
     const V4 krg = vchain(f, df, sg);
     V4 kro;
     {   // EclDefaultMaterial::krn
         const double swco = E.on ? E.s0[EC_PCOW] : xsw[0];      // (scaled) connate water
         const V4 swp = (sw_ > swco) ? W : mk(swco, 0, 0, 0);
         const V4 swow = vadd(sg, swp);
-        sat_curve<false>(xsw, T.swof_krow + wa, nw, swow.v, E, EC_KROW, f, df);
+        if (H.on && swow.v > H.mdc_ow) {         // oil against water on its (shifted) imbibition curve
+            const int wi = T.swof_ptr[H.ireg];
+            sat_curve<false>(T.swof_sw + wi, T.swof_krow + wi, T.swof_ptr[H.ireg + 1] - wi, swow.v + H.d_ow, *EI, EC_KROW, f, df);
+        } else sat_curve<false>(xsw, T.swof_krow + wa, nw, swow.v, E, EC_KROW, f, df);
         const V4 kow = vchain(f, df, swow);
         const V4 sgeq = mk(swow.v - swco, swow.p, swow.w, swow.x);
         if (E.on) {     // krog is tabulated against the oil saturation 1 - Swco_table - Sg; the scaling acts on that axis
-            const double so_u = E.u0[EC_KROG] + ((1.0 - swow.v) - E.s0[EC_KROG]) * E.k[EC_KROG];
+            double slope;
+            const double so_u = eps_map(E, EC_KROG, 1.0 - swow.v, slope);
             sat_eval<true>(xsg, T.sgof_krog + ga, ng, 1.0 - xsw[0] - so_u, f, df);
-            df *= E.k[EC_KROG];
+            f *= E.v[EC_KROG]; df *= slope * E.v[EC_KROG];
         } else sat_eval<true>(xsg, T.sgof_krog + ga, ng, sgeq.v, f, df);
         const V4 kgo = vchain(f, df, sgeq);
         const double eps = 1e-5;
@@ -321,16 +357,19 @@ __global__ __launch_bounds__(kBlock) void k_cell_props(int nb, int nbp, opmgpu_t
                                                        const double* __restrict__ eps, const double* __restrict__ eps_u0,
                                                        const double* __restrict__ somax,
                                                        double* __restrict__ props, MS* __restrict__ pd, double* __restrict__ accum0, double* __restrict__ R,
-                                                       double* __restrict__ binv, MS* __restrict__ A, const double* __restrict__ tab_blob, int tab_words)
+                                                       double* __restrict__ binv, MS* __restrict__ A, const double* __restrict__ tab_blob, int tab_words, HystArgs hy)
 {
     extern __shared__ double tab_lds[];
     stage_tables(T, tab_blob, tab_words, tab_lds);
     const int row = blockIdx.x * kBlock + threadIdx.x;
     if (row >= nb) return;
     CellEval q;
-    EpsD E;
+    EpsD E, EI;
+    HystD H;
     eps_load(eps, eps_u0, nbp, row, satnum[row], E);
-    eval_cell(T, E, somax[row], pvtnum[row], satnum[row], p[row], sw[row], sg[row], rs[row], rv[row], hc[row], q);
+    hyst_load(hy.imbnum, hy.hist, nbp, row, H);
+    if (H.on) eps_load(hy.ieps, eps_u0, nbp, row, H.ireg, EI);
+    eval_cell(T, E, somax[row], pvtnum[row], satnum[row], p[row], sw[row], sg[row], rs[row], rv[row], hc[row], q, H, &EI);
     props[long(PL_PW) * nbp + row] = q.pw.v; props[long(PL_PG) * nbp + row] = q.pg.v;
     pd[long(PL_DPW_W) * nbp + row] = MS(q.pw.w); pd[long(PL_DPG_W) * nbp + row] = MS(q.pg.w); pd[long(PL_DPG_X) * nbp + row] = MS(q.pg.x);
 #pragma unroll
@@ -672,15 +711,18 @@ __global__ __launch_bounds__(kBlock) void k_perf_props(int nperf, opmgpu_tables 
                                                        const double* __restrict__ sg, const double* __restrict__ rs, const double* __restrict__ rv,
                                                        const int8_t* __restrict__ hc, const double* __restrict__ eps,
                                                        const double* __restrict__ eps_u0, const double* __restrict__ somax, long nbp,
-                                                       double* __restrict__ out)
+                                                       double* __restrict__ out, HystArgs hy)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= nperf) return;
     const int c = cells[i];
     CellEval q;
-    EpsD E;
+    EpsD E, EI;
+    HystD H;
     eps_load(eps, eps_u0, nbp, c, satnum[c], E);
-    eval_cell(T, E, somax[c], pvtnum[c], satnum[c], p[c], sw[c], sg[c], rs[c], rv[c], hc[c], q);
+    hyst_load(hy.imbnum, hy.hist, nbp, c, H);
+    if (H.on) eps_load(hy.ieps, eps_u0, nbp, c, H.ireg, EI);
+    eval_cell(T, E, somax[c], pvtnum[c], satnum[c], p[c], sw[c], sg[c], rs[c], rv[c], hc[c], q, H, &EI);
     const V4 list[9] = { mk(p[c], 1, 0, 0), q.rs, q.rv, q.b[0], q.b[1], q.b[2], q.mob[0], q.mob[1], q.mob[2] };
     double* o = out + long(i) * OPMGPU_PERF_K;
 #pragma unroll
@@ -781,12 +823,28 @@ BlackoilDevice::BlackoilDevice(hipStream_t s, LinSolver& ls_, const opmgpu_grid*
     h_pvtnum.assign(nc, 0); h_satnum.assign(nc, 0);
     if (g->pvtnum) h_pvtnum.assign(g->pvtnum, g->pvtnum + nc);
     if (g->satnum) h_satnum.assign(g->satnum, g->satnum + nc);
-    use_eps = g->eps[0] != nullptr;
-    if (use_eps)
+    has_endpoints = g->eps[0] != nullptr;
+    if (has_endpoints)
         for (int k = 0; k < 8; ++k) {
             if (!g->eps[k]) throw HipError(OPMGPU_EINVAL, "ENDSCALE needs all eight end-point arrays (SWL SWCR SWU SOWCR SGL SGCR SGU SOGCR)");
             h_eps[k].assign(g->eps[k], g->eps[k] + nc);
         }
+    scalecrs = g->scalecrs != 0;
+    if (scalecrs && !has_endpoints) throw HipError(OPMGPU_EINVAL, "SCALECRS needs the end-point arrays");
+    bool vert = false;
+    for (int k = 0; k < 5; ++k) if (g->eps_v[k]) { h_eps_v[k].assign(g->eps_v[k], g->eps_v[k] + nc); vert = true; }
+    use_hyst = g->imbnum != nullptr;
+    if (use_hyst) {
+        h_imbnum.assign(g->imbnum, g->imbnum + nc);
+        for (int c = 0; c < nc; ++c) if (h_imbnum[c] < 0 || h_imbnum[c] >= t->n_sat_regions) throw HipError(OPMGPU_EINVAL, "IMBNUM region out of range");
+        has_iendpoints = g->ieps[0] != nullptr;
+        if (has_iendpoints)
+            for (int k = 0; k < 8; ++k) {
+                if (!g->ieps[k]) throw HipError(OPMGPU_EINVAL, "imbibition end points: all eight arrays or none");
+                h_ieps[k].assign(g->ieps[k], g->ieps[k] + nc);
+            }
+    }
+    use_eps = has_endpoints || vert || use_hyst;
     pvsum = 0.0;
     for (int c = 0; c < nc; ++c) pvsum += h_pv[c];
     upload_tables(t);
@@ -872,6 +930,14 @@ void BlackoilDevice::upload_tables(const opmgpu_tables* t)
         u[4] = t->sgof_sg[b]; u[5] = last_zero(t->sgof_sg + b, t->sgof_krg + b, ng); u[6] = t->sgof_sg[b + ng - 1];
         u[7] = 1.0 - first_zero(t->sgof_sg + b, t->sgof_krog + b, ng);
     }
+    // table maxima the vertical scaling refers to, per region in curve order: krw(Swu), krow(Swl), pcow(Swl), krg(Sgu), krog(Sgl), pcgo(Sgu)
+    h_tabmax.assign(6 * size_t(ns), 0.0);
+    for (int r = 0; r < ns; ++r) {
+        const int a = t->swof_ptr[r], nw = t->swof_ptr[r + 1] - a, b = t->sgof_ptr[r], ng = t->sgof_ptr[r + 1] - b;
+        double* m = &h_tabmax[6 * size_t(r)];
+        m[0] = t->swof_krw[a + nw - 1]; m[1] = t->swof_krow[a]; m[2] = t->swof_pcow[a];
+        m[3] = t->sgof_krg[b + ng - 1]; m[4] = t->sgof_krog[b]; m[5] = t->sgof_pcgo[b + ng - 1];
+    }
     OPMGPU_HIP(hipStreamSynchronize(stream));
 }
 
@@ -898,31 +964,34 @@ void BlackoilDevice::rebuild_structure()
     for (int r = 0; r < nc; ++r) { pvi[r] = h_pv[P.nat[r]]; pn[r] = h_pvtnum[P.nat[r]]; sn[r] = h_satnum[P.nat[r]]; }
     d_pv.upload(pvi, stream); d_pvtnum.upload(pn, stream); d_satnum.upload(sn, stream);
     if (use_eps) {
-        // two-point scaling maps per cell and curve: (scaled s0, slope k); the unscaled u0 is per region
+        // per region: unscaled fixed points of every curve (u0 | u1); per cell: the maps and the vertical factors (build_eps_planes)
         const int ns = dt_.n_sat_regions;
-        std::vector<double> u0(size_t(EC_COUNT) * ns), ep(size_t(2 * EC_COUNT) * nbp, 0.0);
+        std::vector<double> ureg(size_t(kEpsRegion) * ns);
         for (int r = 0; r < ns; ++r) {
             const double* u = &h_unscaled[8 * size_t(r)];
-            double* o = &u0[size_t(EC_COUNT) * r];
+            double* o = &ureg[size_t(kEpsRegion) * r];
             o[EC_KRW] = u[1]; o[EC_KROW] = u[0] + u[4]; o[EC_PCOW] = u[0]; o[EC_KRG] = u[5]; o[EC_KROG] = u[7]; o[EC_PCGO] = u[4];
+            double* m = o + EC_COUNT;       // middle points (SCALECRS): krw 1-Sowcr-Sgl, krow Swcr+Sgl, krg 1-Sogcr-Swl, krog 1-Sgcr-Swl
+            m[EC_KRW] = 1.0 - u[3] - u[4]; m[EC_KROW] = u[1] + u[4]; m[EC_PCOW] = 0.0; m[EC_KRG] = 1.0 - u[7] - u[0]; m[EC_KROG] = 1.0 - u[5] - u[0]; m[EC_PCGO] = 0.0;
         }
-        for (int r = 0; r < nbp; ++r) {
-            const int c = r < nc ? P.nat[r] : -1;
-            const double* u = &h_unscaled[8 * size_t(c < 0 ? 0 : h_satnum[c])];
-            double e[8];
-            for (int k = 0; k < 8; ++k) e[k] = c < 0 ? u[k] : h_eps[k][c];
-            const double SWL = e[0], SWCR = e[1], SWU = e[2], SOWCR = e[3], SGL = e[4], SGCR = e[5], SGU = e[6], SOGCR = e[7];
-            const double s0[EC_COUNT] = { SWCR, SWL + SGL, SWL, SGCR, SOGCR, SGL };
-            const double s2[EC_COUNT] = { SWU, 1.0 - SOWCR - SGL, SWU, SGU, 1.0 - SWL - SGL, SGU };
-            const double u0c[EC_COUNT] = { u[1], u[0] + u[4], u[0], u[5], u[7], u[4] };
-            const double u2c[EC_COUNT] = { u[2], 1.0 - u[3] - u[4], u[2], u[6], 1.0 - u[0] - u[4], u[6] };
-            for (int k = 0; k < EC_COUNT; ++k) {
-                if (c >= 0 && !(s2[k] > s0[k])) throw HipError(OPMGPU_EINVAL, "ENDSCALE end points of a cell are not increasing");
-                ep[size_t(k) * nbp + r] = s0[k];
-                ep[size_t(EC_COUNT + k) * nbp + r] = (u2c[k] - u0c[k]) / (s2[k] - s0[k]);
-            }
+        d_eps_u0.upload(ureg, stream);
+        std::vector<double> planes;
+        build_eps_planes(h_eps, has_endpoints, false, planes);
+        d_eps.upload(planes, stream);
+        if (use_hyst) {
+            build_eps_planes(has_iendpoints ? h_ieps : h_eps, has_iendpoints || has_endpoints, true, planes);
+            d_ieps.upload(planes, stream);
+            std::vector<int32_t> im(nbp, 0);
+            for (int r = 0; r < nc; ++r) im[r] = h_imbnum[P.nat[r]];
+            d_imbnum.upload(im, stream);
+            std::vector<double> hist;
+            if (d_hist.p && has_state) { hist.resize(4 * size_t(nc)); get_hysteresis(hist.data(), hist.data() + nc, hist.data() + 2 * size_t(nc), hist.data() + 3 * size_t(nc)); }
+            std::vector<double> hp(4 * size_t(nbp), 0.0);
+            for (int r = 0; r < nbp; ++r) { hp[r] = 2.0; hp[size_t(nbp) + r] = 2.0; }       // no history
+            if (!hist.empty())
+                for (int r = 0; r < nc; ++r) for (int k = 0; k < 4; ++k) hp[size_t(k) * nbp + r] = hist[size_t(k) * nc + P.nat[r]];
+            d_hist.upload(hp, stream);
         }
-        d_eps.upload(ep, stream); d_eps_u0.upload(u0, stream);
     }
     std::vector<double> gdz(std::max(nconn, 1), 0.0);
     for (int f = 0; f < nconn; ++f) gdz[f] = gravity * (h_z[h_conn[2 * f]] - h_z[h_conn[2 * f + 1]]);
@@ -952,6 +1021,137 @@ void BlackoilDevice::rebuild_structure()
     if (!smax.empty()) set_sat_oil_max(smax.data());
     wells_rebind();
     if (has_state) set_state(sp.data(), ssat.data(), srs.data(), srv.data(), shc.data());
+}
+
+HystArgs BlackoilDevice::hyst_args() const
+{
+    HystArgs h;
+    h.imbnum = use_hyst ? d_imbnum.p : nullptr; h.hist = d_hist.p; h.ieps = d_ieps.p;
+    return h;
+}
+
+// per-cell planes [s0 | k | s1 | k1 | v] x 6 curves (internal numbering) for the table of the cell's region `reg_of` against the end
+// points ep8 (caller numbering; have_points = false: identity maps); imbibition planes use the IMBNUM region's table
+void BlackoilDevice::build_eps_planes(const std::vector<double>* ep8, bool have_points, bool imbibition, std::vector<double>& ep) const
+{
+    const Plan& P = ls.plan;
+    const int nbp = P.nbp;
+    ep.assign(size_t(kEpsPlanes) * nbp, 0.0);
+    for (int r = 0; r < nbp; ++r) {
+        const int c = r < nc ? P.nat[r] : -1;
+        // which table: the drainage region, or (planes built for the imbibition curves) the IMBNUM region
+        const int reg = c < 0 ? 0 : (imbibition ? h_imbnum[c] : h_satnum[c]);
+        const double* u = &h_unscaled[8 * size_t(reg)];
+        double e[8];
+        for (int k = 0; k < 8; ++k) e[k] = (c < 0 || !have_points) ? u[k] : ep8[k][c];
+        const double SWL = e[0], SWCR = e[1], SWU = e[2], SOWCR = e[3], SGL = e[4], SGCR = e[5], SGU = e[6], SOGCR = e[7];
+        const double s0[EC_COUNT] = { SWCR, SWL + SGL, SWL, SGCR, SOGCR, SGL };
+        const double s1[EC_COUNT] = { 1.0 - SOWCR - SGL, SWCR + SGL, 0.0, 1.0 - SOGCR - SWL, 1.0 - SGCR - SWL, 0.0 };
+        const double s2[EC_COUNT] = { SWU, 1.0 - SOWCR - SGL, SWU, SGU, 1.0 - SWL - SGL, SGU };
+        const double u0c[EC_COUNT] = { u[1], u[0] + u[4], u[0], u[5], u[7], u[4] };
+        const double u1c[EC_COUNT] = { 1.0 - u[3] - u[4], u[1] + u[4], 0.0, 1.0 - u[7] - u[0], 1.0 - u[5] - u[0], 0.0 };
+        const double u2c[EC_COUNT] = { u[2], 1.0 - u[3] - u[4], u[2], u[6], 1.0 - u[0] - u[4], u[6] };
+        for (int k = 0; k < EC_COUNT; ++k) {
+            if (c >= 0 && !(s2[k] > s0[k])) throw HipError(OPMGPU_EINVAL, "ENDSCALE end points of a cell are not increasing");
+            const bool three = scalecrs && have_points && k != EC_PCOW && k != EC_PCGO;
+            if (three && c >= 0 && !(s1[k] > s0[k] && s2[k] > s1[k])) throw HipError(OPMGPU_EINVAL, "SCALECRS: a cell's critical saturation is not between its end points");
+            ep[size_t(k) * nbp + r] = s0[k];
+            ep[size_t(EC_COUNT + k) * nbp + r] = three ? (u1c[k] - u0c[k]) / (s1[k] - s0[k]) : (u2c[k] - u0c[k]) / (s2[k] - s0[k]);
+            ep[size_t(2 * EC_COUNT + k) * nbp + r] = three ? s1[k] : 1e300;
+            ep[size_t(3 * EC_COUNT + k) * nbp + r] = three ? (u2c[k] - u1c[k]) / (s2[k] - s1[k]) : 1.0;
+        }
+        // vertical factors: cell maximum / table maximum (KRW at Swu, KRO at Swl resp. Sgl, KRG at Sgu, PCW at Swl, PCG at Sgu)
+        double* v[EC_COUNT];
+        for (int k = 0; k < EC_COUNT; ++k) { v[k] = &ep[size_t(4 * EC_COUNT + k) * nbp + r]; *v[k] = 1.0; }
+        if (c >= 0) {
+            const double* tm = &h_tabmax[6 * size_t(reg)];
+            const int src[EC_COUNT] = { 0, 1, 3, 2, 1, 4 };     // KRW, KRO, PCW, KRG, KRO, PCG
+            for (int k = 0; k < EC_COUNT; ++k) if (!h_eps_v[src[k]].empty() && tm[k] != 0.0) *v[k] = h_eps_v[src[k]][c] / tm[k];
+        }
+    }
+}
+
+// ---- hysteresis history -------------------------------------------------------------------------------------------------------
+// smallest abscissa at which the monotone piecewise-linear table takes the value yv (flat pieces: the left end)
+__device__ double table_inverse(const double* __restrict__ x, const double* __restrict__ y, int n, double yv, bool ascending)
+{
+    if (ascending) {
+        if (yv <= y[0]) return x[0];
+        for (int i = 0; i + 1 < n; ++i) if (y[i] < yv && yv <= y[i + 1]) return x[i] + (yv - y[i]) / (y[i + 1] - y[i]) * (x[i + 1] - x[i]);
+        return x[n - 1];
+    }
+    if (yv >= y[0]) return x[0];
+    for (int i = 0; i + 1 < n; ++i) if (y[i] > yv && yv >= y[i + 1]) return x[i] + (yv - y[i]) / (y[i + 1] - y[i]) * (x[i + 1] - x[i]);
+    return x[n - 1];
+}
+// EclDefaultMaterial::updateHysteresis ("inconsistent" form: krnSw = 1 - So / 1 - Sg) + EclHysteresisTwoPhaseLawParams::update +
+// updateDynamicParams_ (Carlson shift: delta = Sw_imb(krn_drain(mdc)) - mdc), one thread per cell
+__global__ __launch_bounds__(kBlock) void k_hyst_update(int nb, int nbp, opmgpu_tables T, const int32_t* __restrict__ satnum, const int32_t* __restrict__ imbnum,
+                                                        const double* __restrict__ so, const double* __restrict__ sg, const double* __restrict__ eps,
+                                                        const double* __restrict__ ieps, const double* __restrict__ ureg, double* __restrict__ hist, int force)
+{
+    const int c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= nb) return;
+    double mow = hist[c], mgo = hist[nbp + c];
+    bool upd = force != 0;
+    const double sgc = fmin(1.0, fmax(0.0, sg[c]));
+    if (!force) {
+        if (1.0 - so[c] < mow) { mow = 1.0 - so[c]; upd = true; }
+        if (1.0 - sgc < mgo) { mgo = 1.0 - sgc; upd = true; }
+    }
+    if (!upd) return;
+    const int sreg = satnum[c], ireg = imbnum[c];
+    EpsD E, EI;
+    eps_load(eps, ureg, nbp, c, sreg, E);
+    eps_load(ieps, ureg, nbp, c, ireg, EI);
+    double dow = 0.0, dgo = 0.0, f, df;
+    if (mow < 2.0) {
+        const int wa = T.swof_ptr[sreg], wi = T.swof_ptr[ireg];
+        sat_curve<false>(T.swof_sw + wa, T.swof_krow + wa, T.swof_ptr[sreg + 1] - wa, mow, E, EC_KROW, f, df);
+        const double ku = f / EI.v[EC_KROW];
+        if (ku > 0.0) dow = eps_unmap(EI, EC_KROW, table_inverse(T.swof_sw + wi, T.swof_krow + wi, T.swof_ptr[ireg + 1] - wi, ku, false)) - mow;
+    }
+    if (mgo < 2.0) {
+        const int ga = T.sgof_ptr[sreg], gi = T.sgof_ptr[ireg];
+        const double sgm = 1.0 - mgo;
+        sat_curve<true>(T.sgof_sg + ga, T.sgof_krg + ga, T.sgof_ptr[sreg + 1] - ga, sgm, E, EC_KRG, f, df);
+        const double ku = f / EI.v[EC_KRG];
+        if (ku > 0.0) dgo = sgm - eps_unmap(EI, EC_KRG, table_inverse(T.sgof_sg + gi, T.sgof_krg + gi, T.sgof_ptr[ireg + 1] - gi, ku, true));
+    }
+    hist[c] = mow; hist[nbp + c] = mgo; hist[2 * long(nbp) + c] = dow; hist[3 * long(nbp) + c] = dgo;
+}
+
+int BlackoilDevice::update_hysteresis()
+{
+    if (!use_hyst) return OPMGPU_OK;
+    if (!has_state) return OPMGPU_EINVAL;
+    hipLaunchKernelGGL(k_hyst_update, dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, ls.plan.nbp, dt_, d_satnum.p, d_imbnum.p, d_so.p, d_sg.p,
+                       (const double*)d_eps.p, (const double*)d_ieps.p, (const double*)d_eps_u0.p, d_hist.p, 0);
+    return OPMGPU_OK;
+}
+int BlackoilDevice::set_hysteresis(const double* mdc_ow, const double* mdc_go)
+{
+    if (!use_hyst || !mdc_ow || !mdc_go) return OPMGPU_EINVAL;
+    const Plan& P = ls.plan;
+    std::vector<double> hp(4 * size_t(P.nbp), 0.0);
+    for (int r = 0; r < P.nbp; ++r) { hp[r] = r < nc ? mdc_ow[P.nat[r]] : 2.0; hp[size_t(P.nbp) + r] = r < nc ? mdc_go[P.nat[r]] : 2.0; }
+    d_hist.upload(hp, stream);
+    // the shifts follow from the history
+    hipLaunchKernelGGL(k_hyst_update, dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, P.nbp, dt_, d_satnum.p, d_imbnum.p, d_so.p, d_sg.p,
+                       (const double*)d_eps.p, (const double*)d_ieps.p, (const double*)d_eps_u0.p, d_hist.p, 1);
+    OPMGPU_HIP(hipStreamSynchronize(stream));
+    return OPMGPU_OK;
+}
+int BlackoilDevice::get_hysteresis(double* mdc_ow, double* mdc_go, double* d_ow, double* d_go)
+{
+    if (!use_hyst) return OPMGPU_EINVAL;
+    const Plan& P = ls.plan;
+    std::vector<double> hp(4 * size_t(P.nbp));
+    d_hist.download(hp.data(), hp.size(), stream);
+    OPMGPU_HIP(hipStreamSynchronize(stream));
+    double* out[4] = { mdc_ow, mdc_go, d_ow, d_go };
+    for (int k = 0; k < 4; ++k) if (out[k]) for (int r = 0; r < nc; ++r) out[k][P.nat[r]] = hp[size_t(k) * P.nbp + r];
+    return OPMGPU_OK;
 }
 
 int BlackoilDevice::set_wells(int nw, const int32_t* connpos, const int32_t* cells)
@@ -1014,7 +1214,7 @@ template <class MS> void BlackoilDevice::assemble_kernels(double dt, bool initia
     hipLaunchKernelGGL((k_cell_props<MS>), dim3(grid_for(nc)), dim3(kBlock), tab_lds_bytes(), stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_pv.p,
                        d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, 1.0 / dt, int(initial), sc[0], sc[1], sc[2],
                        ls.dp.slice_ptr.p, ls.dp.nlower.p, eps_planes(), d_eps_u0.p, d_somax.p, d_props.p, pd, d_accum0.p, d_R.p, d_binv.p, A,
-                       (const double*)d_tab.p, tab_lds_words());
+                       (const double*)d_tab.p, tab_lds_words(), hyst_args());
     ls.kt.end(KT_CELL_PROPS, kt_a);
     KtScope kts(ls.kt, KT_FLUX);
     hipLaunchKernelGGL((k_flux<MS>), dim3(grid8_for(nc)), dim3(kBlock), 0, stream, xcd_mode(), nc, P.nbp, ls.dp.slice_ptr.p, ls.dp.col.p, ls.dp.rowlen.p,
@@ -1059,7 +1259,7 @@ double BlackoilDevice::time_assemble(int reps, int props_only)
             hipLaunchKernelGGL((k_cell_props<double>), dim3(grid_for(nc)), dim3(kBlock), tab_lds_bytes(), stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_pv.p,
                                d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, 1.0 / dt, 0, sc[0], sc[1], sc[2],
                                ls.dp.slice_ptr.p, ls.dp.nlower.p, eps_planes(), d_eps_u0.p, d_somax.p, d_props.p, d_props.p, d_accum0.p, d_R.p, d_binv.p, ls.matrix_d(),
-                               (const double*)d_tab.p, tab_lds_words());
+                               (const double*)d_tab.p, tab_lds_words(), hyst_args());
         else assemble(dt, false);
     };
     launch();
@@ -1195,7 +1395,7 @@ void BlackoilDevice::perf_props_device()
 {
     if (nperf == 0) return;
     hipLaunchKernelGGL(k_perf_props, dim3(grid_for(nperf)), dim3(kBlock), 0, stream, nperf, dt_, d_perf_cells.p, d_pvtnum.p, d_satnum.p,
-                       d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, eps_planes(), d_eps_u0.p, d_somax.p, long(ls.plan.nbp), d_perf.p);
+                       d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, eps_planes(), d_eps_u0.p, d_somax.p, long(ls.plan.nbp), d_perf.p, hyst_args());
 }
 
 void BlackoilDevice::perf_pvt_device(const double* press_dev, double* out_dev, const int32_t* gate)
@@ -1240,7 +1440,7 @@ void BlackoilDevice::perf_props(double* out)
 {
     if (nperf == 0) return;
     hipLaunchKernelGGL(k_perf_props, dim3(grid_for(nperf)), dim3(kBlock), 0, stream, nperf, dt_, d_perf_cells.p, d_pvtnum.p, d_satnum.p,
-                       d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, eps_planes(), d_eps_u0.p, d_somax.p, long(ls.plan.nbp), d_perf.p);
+                       d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, eps_planes(), d_eps_u0.p, d_somax.p, long(ls.plan.nbp), d_perf.p, hyst_args());
     OPMGPU_HIP(hipMemcpyAsync(out, d_perf.p, size_t(nperf) * OPMGPU_PERF_K * sizeof(double), hipMemcpyDeviceToHost, stream));
     OPMGPU_HIP(hipStreamSynchronize(stream));
 }

@@ -12,6 +12,8 @@
 
 namespace opmgpu {
 
+struct HystArgs;
+
 // per-cell planes handed from the property kernel to the flux kernel (doubles, stride nbp)
 enum {
     PL_PW = 0, PL_PG, PL_DPW_W, PL_DPG_W, PL_DPG_X,
@@ -53,6 +55,9 @@ public:
     void update_sat_oil_max();
     void set_sat_oil_max(const double* v);
     void get_sat_oil_max(double* v);
+    int update_hysteresis();
+    int set_hysteresis(const double* mdc_ow, const double* mdc_go);
+    int get_hysteresis(double* mdc_ow, double* mdc_go, double* d_ow, double* d_go);
     void get_residual(double* r);
     // wells on the device (wells.hip)
     struct WellsDev;
@@ -102,9 +107,15 @@ private:
     double gravity = 0.0, pvsum = 0.0, pvsum_global = 0.0;
     bool use_thpres = false;
     // ENDSCALE: per-cell scaled end points (caller numbering), unscaled points per saturation region
-    bool use_eps = false;
-    std::vector<double> h_eps[8], h_unscaled;
-    DevArray<double> d_eps, d_eps_u0, d_somax, d_saved;
+    bool use_eps = false;           // any saturation-function scaling: horizontal end points and / or vertical maxima
+    bool has_endpoints = false, scalecrs = false, use_hyst = false, has_iendpoints = false;
+    std::vector<double> h_eps[8], h_unscaled, h_eps_v[5], h_ieps[8];
+    std::vector<int32_t> h_imbnum;
+    DevArray<double> d_eps, d_eps_u0, d_somax, d_saved, d_ieps, d_hist;     // d_hist: [mdc_ow | mdc_go | d_ow | d_go] planes
+    DevArray<int32_t> d_imbnum;
+    HystArgs hyst_args() const;
+    void build_eps_planes(const std::vector<double>* ep8, bool have_points, bool imbibition, std::vector<double>& planes) const;
+    std::vector<double> h_tabmax;
     DevArray<int8_t> d_saved_hc;
     const double* eps_planes() const { return use_eps ? d_eps.p : nullptr; }
     // device: tables

@@ -348,6 +348,22 @@ int opmgpu_get_sat_oil_max(opmgpu_ctx* c, double* so_max)
     return guarded(c, [&]() { c->model->get_sat_oil_max(so_max); return OPMGPU_OK; });
 }
 
+int opmgpu_update_hysteresis(opmgpu_ctx* c)
+{
+    if (!c || !c->model) return OPMGPU_EINVAL;
+    return guarded(c, [&]() { return c->model->update_hysteresis(); });
+}
+int opmgpu_set_hysteresis(opmgpu_ctx* c, const double* mdc_ow, const double* mdc_go)
+{
+    if (!c || !c->model) return OPMGPU_EINVAL;
+    return guarded(c, [&]() { return c->model->set_hysteresis(mdc_ow, mdc_go); });
+}
+int opmgpu_get_hysteresis(opmgpu_ctx* c, double* mdc_ow, double* mdc_go, double* d_ow, double* d_go)
+{
+    if (!c || !c->model) return OPMGPU_EINVAL;
+    return guarded(c, [&]() { return c->model->get_hysteresis(mdc_ow, mdc_go, d_ow, d_go); });
+}
+
 int opmgpu_stabilize_update(opmgpu_ctx* c, int relax_type, double omega)
 {
     if (!c || !c->model || (relax_type != OPMGPU_RELAX_DAMPEN && relax_type != OPMGPU_RELAX_SOR)) return OPMGPU_EINVAL;

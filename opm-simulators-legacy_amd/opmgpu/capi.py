@@ -29,7 +29,8 @@ _bp = C.POINTER(C.c_int8)
 class Grid(C.Structure):
     _fields_ = [("nc", C.c_int32), ("nconn", C.c_int32), ("conn_cells", _ip), ("trans", _dp),
                 ("pv", _dp), ("z", _dp), ("gravity", C.c_double), ("thpres", _dp),
-                ("pvtnum", _ip), ("satnum", _ip), ("eps", _dp * 8)]
+                ("pvtnum", _ip), ("satnum", _ip), ("eps", _dp * 8),
+                ("scalecrs", C.c_int32), ("eps_v", _dp * 5), ("imbnum", _ip), ("ieps", _dp * 8)]
 
 
 class Tables(C.Structure):
@@ -138,6 +139,9 @@ SIGNATURES = {
     "opmgpu_solve": (C.c_int, [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int), _dp]),
     "opmgpu_update_state": (C.c_int, [C.c_void_p, _dp, C.c_double]),
     "opmgpu_stabilize_update": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
+    "opmgpu_update_hysteresis": (C.c_int, [C.c_void_p]),
+    "opmgpu_set_hysteresis": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "opmgpu_get_hysteresis": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp]),
     "opmgpu_get_cpr_weights": (C.c_int, [C.c_void_p, _dp]),
     "opmgpu_set_solve_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "opmgpu_set_device_wells": (C.c_int, [C.c_void_p, C.POINTER(WellsSpec)]),

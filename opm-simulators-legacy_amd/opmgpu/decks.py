@@ -181,8 +181,10 @@ class GridData:
     """Static grid data matching `opmgpu_grid`."""
 
     EPS_NAMES = ("SWL", "SWCR", "SWU", "SOWCR", "SGL", "SGCR", "SGU", "SOGCR")
+    EPSV_NAMES = ("KRW", "KRO", "KRG", "PCW", "PCG")
 
-    def __init__(self, nc, conn_cells, trans, pv, z, gravity=GRAVITY, thpres=None, pvtnum=None, satnum=None, dims=None, eps=None):
+    def __init__(self, nc, conn_cells, trans, pv, z, gravity=GRAVITY, thpres=None, pvtnum=None, satnum=None, dims=None, eps=None,
+                 scalecrs=False, eps_v=None, imbnum=None, ieps=None):
         self.nc = int(nc)
         self.conn_cells = capi.i32(conn_cells).reshape(-1, 2)
         self.nconn = self.conn_cells.shape[0]
@@ -194,6 +196,12 @@ class GridData:
         self.dims = dims
         # ENDSCALE: dict name -> per-cell array for the eight scaled end points (all or none)
         self.eps = None if eps is None else [capi.f64(np.broadcast_to(eps[k], (self.nc,))) for k in self.EPS_NAMES]
+        # SCALECRS (three-point kr scaling), vertical scaling maxima (dict KRW / KRO / KRG / PCW / PCG -> per-cell array, any subset;
+        # PCW / PCG in Pa), hysteresis: IMBNUM regions (0-based) and optionally the imbibition curves' scaled end points (ISWL ... as SWL ...)
+        self.scalecrs = bool(scalecrs)
+        self.eps_v = None if eps_v is None else {k: capi.f64(np.broadcast_to(v, (self.nc,))) for k, v in eps_v.items()}
+        self.imbnum = None if imbnum is None else capi.i32(np.broadcast_to(imbnum, (self.nc,)))
+        self.ieps = None if ieps is None else [capi.f64(np.broadcast_to(ieps[k], (self.nc,))) for k in self.EPS_NAMES]
         self._struct = None
 
     def struct(self):
@@ -205,14 +213,23 @@ class GridData:
             g.thpres, g.pvtnum, g.satnum = capi.dptr(self.thpres), capi.iptr(self.pvtnum), capi.iptr(self.satnum)
             for k in range(8):
                 g.eps[k] = capi.dptr(None if self.eps is None else self.eps[k])
+                g.ieps[k] = capi.dptr(None if self.ieps is None else self.ieps[k])
+            g.scalecrs = int(self.scalecrs)
+            for k, name in enumerate(self.EPSV_NAMES):
+                g.eps_v[k] = capi.dptr(None if self.eps_v is None else self.eps_v.get(name))
+            g.imbnum = capi.iptr(self.imbnum)
             self._struct = g
         return self._struct
 
 
-def with_endpoints(grid, eps):
-    """Copy of `grid` carrying ENDSCALE end points (dict name -> scalar / per-cell array, all eight names)."""
-    return GridData(grid.nc, grid.conn_cells, grid.trans, grid.pv, grid.z, gravity=grid.gravity, thpres=grid.thpres,
-                    pvtnum=grid.pvtnum, satnum=grid.satnum, dims=grid.dims, eps=eps)
+def with_endpoints(grid, eps, **more):
+    """Copy of `grid` carrying ENDSCALE end points (dict name -> scalar / per-cell array, all eight names); more = scalecrs=True,
+    eps_v={KRW..}, imbnum=..., ieps={...} (see GridData)."""
+    g = GridData(grid.nc, grid.conn_cells, grid.trans, grid.pv, grid.z, gravity=grid.gravity, thpres=grid.thpres,
+                 pvtnum=grid.pvtnum, satnum=grid.satnum, dims=grid.dims, eps=eps, **more)
+    if hasattr(grid, "active_index"):
+        g.active_index = grid.active_index
+    return g
 
 
 def random_endpoints(grid, seed=0, base=None, jitter=0.06):

@@ -226,6 +226,19 @@ class GpuBlackoilModel:
         self._chk(self.lib.opmgpu_get_sat_oil_max(self.ctx, capi.dptr(out)))
         return out
 
+    # hysteresis history (SaturationPropsFromDeck::updateSatHyst, called once per report step: SimulatorBase_impl.hpp:190-191)
+    def updateHysteresis(self):
+        self._chk(self.lib.opmgpu_update_hysteresis(self.ctx))
+
+    def getHysteresis(self):
+        """(krnSwMdc_ow, krnSwMdc_go, delta_ow, delta_go), caller cell order"""
+        out = [np.zeros(self.nc) for _ in range(4)]
+        self._chk(self.lib.opmgpu_get_hysteresis(self.ctx, *[capi.dptr(a) for a in out]))
+        return out
+
+    def setHysteresis(self, mdc_ow, mdc_go):
+        self._chk(self.lib.opmgpu_set_hysteresis(self.ctx, capi.dptr(capi.f64(mdc_ow)), capi.dptr(capi.f64(mdc_go))))
+
     def setSolvePrecision(self, single_precision=None):
         """residual_.singlePrecision = dt < maxSinglePrecisionTimeStep (:284), told to the device BEFORE the assembly so that
         the Jacobian is written in the solve's precision."""

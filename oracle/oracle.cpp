@@ -103,73 +103,135 @@ SatTab sat_tab(const opmgpu_tables* t, int reg)
     return s;
 }
 
-// ENDSCALE, two-point scaling (opm-material EclEpsTwoPhaseLaw / EclEpsScalingPoints, SCALECRS NO):
-//   S_unscaled = u0 + (S - s0) * ((u2 - u0) / (s2 - s0))
+// ENDSCALE (opm-material EclEpsTwoPhaseLaw / EclEpsScalingPoints).  Horizontal scaling maps the scaled saturation S to the table's
+// unscaled one: two-point (SCALECRS NO)  S_u = u0 + (S - s0) * ((u2 - u0) / (s2 - s0));  three-point (SCALECRS YES, relative
+// permeabilities only) the same through a middle point (s1, u1): first segment below s1, second above (scaledToUnscaledSatThreePoint_).
 // Unscaled points of a table (EclEpsScalingPointsInfo::extractUnscaled): Swl = first Sw, Swu = last Sw, Swcr = last Sw with
 // krw == 0, Sowcr = 1 - (first Sw with krow == 0); Sgl, Sgu, Sgcr alike, Sogcr = 1 - (first Sg with krog == 0)  [no Swl
 // subtracted: pinned by tests/test_boprops_ad.cpp:197-208 (0.13) and the EPS_A derivatives of tests/test_satfunc.cpp:299-307].
-// Pairs of (scaled, unscaled) points per curve: krw [Swcr, Swu]; krow [Swl+Sgl, 1-Sowcr-Sgl]; pcow [Swl, Swu];
-// krg [Sgcr, Sgu]; krog in oil saturation [Sogcr, 1-Swl-Sgl]; pcgo [Sgl, Sgu].  Pinned by tests/test_satfunc.cpp:140-379.
-struct Lin { double u0, s0, k; };
-inline double lin_map(const Lin& m, double s) { return m.u0 + (s - m.s0) * m.k; }
+// Points per curve (scaled <-> unscaled): krw [Swcr, (1-Sowcr-Sgl), Swu]; krow in Sw [Swl+Sgl, (Swcr+Sgl), 1-Sowcr-Sgl]; pcow [Swl, Swu];
+// krg [Sgcr, (1-Sogcr-Swl), Sgu]; krog in oil saturation [Sogcr, (1-Sgcr-Swl), 1-Swl-Sgl]; pcgo [Sgl, Sgu]; the bracketed middle points
+// only with SCALECRS.  The two-point forms are pinned by tests/test_satfunc.cpp:140-379; the three-point middle points, the vertical
+// scaling and the hysteresis below are restated from opm-material's published code with no reference vectors: parity unpinned.
+// Vertical scaling (KRW / KRO / KRG / PCW / PCG): value * (cell maximum / table maximum), unscaledToScaledKrw_ etc.
+struct Lin { double u0, s0, k, s1, u1, k1; bool three; };
+inline double lin_map(const Lin& m, double s) { return (m.three && s >= m.s1) ? m.u1 + (s - m.s1) * m.k1 : m.u0 + (s - m.s0) * m.k; }
+inline double lin_slope(const Lin& m, double s) { return (m.three && s >= m.s1) ? m.k1 : m.k; }
+// scaled saturation of an unscaled one (inverse map; unscaledToScaledSat*)
+inline double lin_inv(const Lin& m, double u) { return (m.three && u >= m.u1) ? m.s1 + (u - m.u1) / m.k1 : m.s0 + (u - m.u0) / m.k; }
 struct Eps {
     bool on;
     Lin krw, krow, pcow, krg, krog, pcgo;
+    double v[6];       // vertical factors of krw, krow, pcow, krg, krog, pcgo (1 = none)
     double swl;        // scaled connate water used by the three-phase law (params.Swl())
     double swl_t;      // unscaled Swco of the table (the SGOF oil-saturation abscissa is 1 - swl_t - Sg)
 };
-Eps eps_for_cell(const opmgpu_grid* g, const SatTab& s, int c)
+enum { V_KRW = 0, V_KROW, V_PCOW, V_KRG, V_KROG, V_PCGO };
+// end points `ep8` (SWL SWCR SWU SOWCR SGL SGCR SGU SOGCR of cell c) against the table `s`; vertical maxima from g->eps_v
+Eps eps_build(const opmgpu_grid* g, const SatTab& s, int c, const double* const* ep8)
 {
-    Eps e; e.on = g && g->eps[0] != nullptr; e.swl = s.swco; e.swl_t = s.swco;
+    Eps e; e.on = ep8 && ep8[0] != nullptr; e.swl = s.swco; e.swl_t = s.swco;
+    for (int k = 0; k < 6; ++k) e.v[k] = 1.0;
+    if (g) {
+        const double* const* ev = g->eps_v;
+        auto last = [](const double* y, int n) { return y[n - 1]; };
+        if (ev[0] && last(s.krw, s.nw) != 0.0) e.v[V_KRW] = ev[0][c] / last(s.krw, s.nw);              // maxKrw: at Swu
+        if (ev[1] && s.krow[0] != 0.0) e.v[V_KROW] = ev[1][c] / s.krow[0];                             // maxKrn (oil): at Swl
+        if (ev[1] && s.krog[0] != 0.0) e.v[V_KROG] = ev[1][c] / s.krog[0];                             // gas-oil system: oil at Sgl
+        if (ev[2] && last(s.krg, s.ng) != 0.0) e.v[V_KRG] = ev[2][c] / last(s.krg, s.ng);              // at Sgu
+        if (ev[3] && s.pcow[0] != 0.0) e.v[V_PCOW] = ev[3][c] / s.pcow[0];                             // maxPcow: at Swl
+        if (ev[4] && last(s.pcgo, s.ng) != 0.0) e.v[V_PCGO] = ev[4][c] / last(s.pcgo, s.ng);           // maxPcgo: at Sgu
+    }
     if (!e.on) return e;
     auto last_zero = [](const double* x, const double* y, int n) { int i = 0; while (i + 1 < n && y[i + 1] == 0.0) ++i; return x[i]; };
     auto first_zero = [](const double* x, const double* y, int n) { int i = 0; while (i < n - 1 && y[i] != 0.0) ++i; return x[i]; };
     const double Swl = s.sw[0], Swu = s.sw[s.nw - 1], Swcr = last_zero(s.sw, s.krw, s.nw), Sowcr = 1.0 - first_zero(s.sw, s.krow, s.nw);
     const double Sgl = s.sg[0], Sgu = s.sg[s.ng - 1], Sgcr = last_zero(s.sg, s.krg, s.ng), Sogcr = 1.0 - first_zero(s.sg, s.krog, s.ng);
-    const double SWL = g->eps[0][c], SWCR = g->eps[1][c], SWU = g->eps[2][c], SOWCR = g->eps[3][c];
-    const double SGL = g->eps[4][c], SGCR = g->eps[5][c], SGU = g->eps[6][c], SOGCR = g->eps[7][c];
-    auto mk = [](double u0, double u2, double s0, double s2) { Lin m; m.u0 = u0; m.s0 = s0; m.k = (u2 - u0) / (s2 - s0); return m; };
-    e.krw = mk(Swcr, Swu, SWCR, SWU);
-    e.krow = mk(Swl + Sgl, 1.0 - Sowcr - Sgl, SWL + SGL, 1.0 - SOWCR - SGL);
-    e.pcow = mk(Swl, Swu, SWL, SWU);
-    e.krg = mk(Sgcr, Sgu, SGCR, SGU);
-    e.krog = mk(Sogcr, 1.0 - Swl - Sgl, SOGCR, 1.0 - SWL - SGL);
-    e.pcgo = mk(Sgl, Sgu, SGL, SGU);
+    const double SWL = ep8[0][c], SWCR = ep8[1][c], SWU = ep8[2][c], SOWCR = ep8[3][c];
+    const double SGL = ep8[4][c], SGCR = ep8[5][c], SGU = ep8[6][c], SOGCR = ep8[7][c];
+    const bool three = g && g->scalecrs != 0;
+    auto mk2 = [](double u0, double u2, double s0, double s2) { Lin m; m.u0 = u0; m.s0 = s0; m.k = (u2 - u0) / (s2 - s0); m.three = false; m.s1 = 0; m.u1 = 0; m.k1 = m.k; return m; };
+    auto mk3 = [&](double u0, double u1, double u2, double s0, double s1, double s2) {
+        Lin m = mk2(u0, u2, s0, s2);
+        if (!three) return m;
+        m.three = true; m.k = (u1 - u0) / (s1 - s0); m.s1 = s1; m.u1 = u1; m.k1 = (u2 - u1) / (s2 - s1);
+        return m;
+    };
+    e.krw = mk3(Swcr, 1.0 - Sowcr - Sgl, Swu, SWCR, 1.0 - SOWCR - SGL, SWU);
+    e.krow = mk3(Swl + Sgl, Swcr + Sgl, 1.0 - Sowcr - Sgl, SWL + SGL, SWCR + SGL, 1.0 - SOWCR - SGL);
+    e.pcow = mk2(Swl, Swu, SWL, SWU);
+    e.krg = mk3(Sgcr, 1.0 - Sogcr - Swl, Sgu, SGCR, 1.0 - SOGCR - SWL, SGU);
+    e.krog = mk3(Sogcr, 1.0 - Sgcr - Swl, 1.0 - Swl - Sgl, SOGCR, 1.0 - SGCR - SWL, 1.0 - SWL - SGL);
+    e.pcgo = mk2(Sgl, Sgu, SGL, SGU);
     e.swl = SWL;
     return e;
 }
-// table value at the (possibly scaled) saturation S; RIGHT selects the SGOF segment rule
+Eps eps_for_cell(const opmgpu_grid* g, const SatTab& s, int c) { return eps_build(g, s, c, g ? g->eps : nullptr); }
+// table value at the (possibly scaled) saturation S times the vertical factor vf; RIGHT selects the SGOF segment rule
 template <int N, bool RIGHT>
-Dual<N> sat_curve(const double* x, const double* y, int n, const Dual<N>& S, bool on, const Lin& m)
+Dual<N> sat_curve(const double* x, const double* y, int n, const Dual<N>& S, bool on, const Lin& m, double vf = 1.0)
 {
     double f, df;
-    if (!on) { if (RIGHT) sat_right(x, y, n, S.v, f, df); else sat_left(x, y, n, S.v, f, df); return chain(f, df, S); }
+    if (!on) { if (RIGHT) sat_right(x, y, n, S.v, f, df); else sat_left(x, y, n, S.v, f, df); return chain(vf * f, vf * df, S); }
     const double su = lin_map(m, S.v);
     if (RIGHT) sat_right(x, y, n, su, f, df); else sat_left(x, y, n, su, f, df);
-    return chain(f, df * m.k, S);
+    return chain(vf * f, vf * df * lin_slope(m, S.v), S);
+}
+
+// Relative-permeability hysteresis of one cell (EclHysteresisTwoPhaseLaw with EHYSTR item 2 = 0, KR only): the non-wetting phase of
+// each two-phase system (oil against water: krow in Sw_ow; gas against oil: krg in 1 - Sg) follows its drainage curve down to the
+// smallest wetting saturation seen so far (mdc) and from there the IMBIBITION curve shifted by delta (Carlson: the shift makes the two
+// curves meet at the turning point, EclHysteresisTwoPhaseLawParams::updateDynamicParams_).  Wetting phases: drainage curves.
+struct Hyst {
+    bool on = false;
+    SatTab imb;            // imbibition tables (IMBNUM region)
+    Eps eimb;              // their end-point scaling
+    double mdc_ow = 2.0, mdc_go = 2.0, d_ow = 0.0, d_go = 0.0;
+};
+const double* g_hyst_ow = nullptr;      // history planes set by oracle_set_hysteresis (krnSwMdc of both systems, deltas)
+const double* g_hyst_go = nullptr;
+const double* g_hyst_dow = nullptr;
+const double* g_hyst_dgo = nullptr;
+Hyst hyst_for_cell(const opmgpu_grid* g, const opmgpu_tables* t, int c)
+{
+    Hyst h;
+    if (!g || !g->imbnum) return h;
+    h.on = true;
+    h.imb = sat_tab(t, g->imbnum[c]);
+    h.eimb = eps_build(g, h.imb, c, g->ieps[0] ? g->ieps : g->eps);
+    if (g_hyst_ow) { h.mdc_ow = g_hyst_ow[c]; h.mdc_go = g_hyst_go[c]; h.d_ow = g_hyst_dow[c]; h.d_go = g_hyst_dgo[c]; }
+    return h;
 }
 
 // EclDefaultMaterial::{krw,krg,krn} (opm-material; reached from SaturationPropsFromDeck.cpp:91-92).
 // Generic in the AD width so the same code serves oracle_relperm (independent sw,so,sg) and the model.
 template <int N>
-void relperm3(const SatTab& s, const Eps& e, const Dual<N>& Sw, const Dual<N>& Sg, Dual<N>& krw, Dual<N>& kro, Dual<N>& krg)
+void relperm3(const SatTab& s, const Eps& e, const Dual<N>& Sw, const Dual<N>& Sg, Dual<N>& krw, Dual<N>& kro, Dual<N>& krg, const Hyst* h = nullptr)
 {
-    krw = sat_curve<N, false>(s.sw, s.krw, s.nw, Sw, e.on, e.krw);
-    krg = sat_curve<N, true>(s.sg, s.krg, s.ng, Sg, e.on, e.krg);
+    krw = sat_curve<N, false>(s.sw, s.krw, s.nw, Sw, e.on, e.krw, e.v[V_KRW]);
+    // gas: non-wetting phase of the gas-oil system, wetting saturation 1 - Sg
+    if (h && h->on && (1.0 - Sg.v) > h->mdc_go) {
+        const Dual<N> Sgi = Sg - h->d_go;               // krn_imb(Sw + delta) = krg_imb(Sg - delta)
+        krg = sat_curve<N, true>(h->imb.sg, h->imb.krg, h->imb.ng, Sgi, h->eimb.on, h->eimb.krg, h->eimb.v[V_KRG]);
+    } else krg = sat_curve<N, true>(s.sg, s.krg, s.ng, Sg, e.on, e.krg, e.v[V_KRG]);
     const double Swco = e.swl;
     Dual<N> Swp = (Sw.v > Swco) ? Sw : Dual<N>(Swco);       // max(Swco, Sw)
     Dual<N> Sw_ow = Sg + Swp;
-    Dual<N> kro_ow = sat_curve<N, false>(s.sw, s.krow, s.nw, Sw_ow, e.on, e.krow);
+    Dual<N> kro_ow;
+    if (h && h->on && Sw_ow.v > h->mdc_ow) {
+        const Dual<N> Swi = Sw_ow + h->d_ow;
+        kro_ow = sat_curve<N, false>(h->imb.sw, h->imb.krow, h->imb.nw, Swi, h->eimb.on, h->eimb.krow, h->eimb.v[V_KROW]);
+    } else kro_ow = sat_curve<N, false>(s.sw, s.krow, s.nw, Sw_ow, e.on, e.krow, e.v[V_KROW]);
     // krog is tabulated against the oil saturation So = 1 - swl_t - Sg of the gas-oil system; left-in-So == right-in-Sg
     Dual<N> So_go = 1.0 - Sw_ow;
     Dual<N> kro_go;
     {
-        const double k = e.on ? e.krog.k : 1.0;
+        const double k = e.on ? lin_slope(e.krog, So_go.v) : 1.0;
         const double so_u = e.on ? lin_map(e.krog, So_go.v) : So_go.v + (Swco - e.swl_t);   // unscaled: Sg_eq = Sw_ow - Swco
         const double sg_eq = 1.0 - e.swl_t - so_u;
         double f, df;
         sat_right(s.sg, s.krog, s.ng, e.on ? sg_eq : Sw_ow.v - Swco, f, df);
-        kro_go = chain(f, -df * k, So_go);
+        kro_go = chain(e.v[V_KROG] * f, -e.v[V_KROG] * df * k, So_go);
     }
     const double eps = 1e-5;
     if (Sw_ow.v - Swco < eps) {
@@ -185,13 +247,49 @@ void relperm3(const SatTab& s, const Eps& e, const Dual<N>& Sw, const Dual<N>& S
         kro = (Sg * kro_go + (Swp - Swco) * kro_ow) / (Sw_ow - Swco);
     }
 }
+// smallest abscissa at which the piecewise-linear, monotone table y(x) takes the value yv (PiecewiseLinearTwoPhaseMaterial's
+// twoPhaseSatKrnInv; flat pieces: the left end).  ascending = y grows with x.
+double table_inverse(const double* x, const double* y, int n, double yv, bool ascending)
+{
+    if (ascending) {
+        if (yv <= y[0]) return x[0];
+        for (int i = 0; i + 1 < n; ++i) if (y[i] < yv && yv <= y[i + 1]) return x[i] + (yv - y[i]) / (y[i + 1] - y[i]) * (x[i + 1] - x[i]);
+        return x[n - 1];
+    }
+    if (yv >= y[0]) return x[0];
+    for (int i = 0; i + 1 < n; ++i) if (y[i] > yv && yv >= y[i + 1]) return x[i] + (yv - y[i]) / (y[i + 1] - y[i]) * (x[i + 1] - x[i]);
+    return x[n - 1];
+}
+// Carlson shift of one two-phase system after its history moved to mdc (updateDynamicParams_): delta = Sw_imb(krn_drain(mdc)) - mdc
+void hyst_deltas(const SatTab& s, const Eps& e, const Hyst& h, double mdc_ow, double mdc_go, double& d_ow, double& d_go)
+{
+    d_ow = 0.0; d_go = 0.0;
+    if (mdc_ow < 2.0) {        // oil against water: krow curves in Sw
+        const Dual<1> kd = sat_curve<1, false>(s.sw, s.krow, s.nw, Dual<1>(mdc_ow), e.on, e.krow, e.v[V_KROW]);
+        const double ku = kd.v / h.eimb.v[V_KROW];
+        if (ku > 0.0) {
+            const double su = table_inverse(h.imb.sw, h.imb.krow, h.imb.nw, ku, false);
+            d_ow = (h.eimb.on ? lin_inv(h.eimb.krow, su) : su) - mdc_ow;
+        }
+    }
+    if (mdc_go < 2.0) {        // gas against oil: krg curves in Sg = 1 - Sw
+        const double sgm = 1.0 - mdc_go;
+        const Dual<1> kd = sat_curve<1, true>(s.sg, s.krg, s.ng, Dual<1>(sgm), e.on, e.krg, e.v[V_KRG]);
+        const double ku = kd.v / h.eimb.v[V_KRG];
+        if (ku > 0.0) {
+            const double su = table_inverse(h.imb.sg, h.imb.krg, h.imb.ng, ku, true);
+            const double sg_imb = h.eimb.on ? lin_inv(h.eimb.krg, su) : su;
+            d_go = sgm - sg_imb;        // Sw_imb - mdc with Sw = 1 - Sg
+        }
+    }
+}
 // EclDefaultMaterial::capillaryPressures + the sign / reference-phase shift of
 // SaturationPropsFromDeck.cpp:163-174: pc[w] = pcow(Sw), pc[o] = 0, pc[g] = pcgo(Sg).
 template <int N>
 void cappress3(const SatTab& s, const Eps& e, const Dual<N>& Sw, const Dual<N>& Sg, Dual<N>& pcow, Dual<N>& pcgo)
 {
-    pcow = sat_curve<N, false>(s.sw, s.pcow, s.nw, Sw, e.on, e.pcow);
-    pcgo = sat_curve<N, true>(s.sg, s.pcgo, s.ng, Sg, e.on, e.pcgo);
+    pcow = sat_curve<N, false>(s.sw, s.pcow, s.nw, Sw, e.on, e.pcow, e.v[V_PCOW]);
+    pcgo = sat_curve<N, true>(s.sg, s.pcgo, s.ng, Sg, e.on, e.pcgo, e.v[V_PCGO]);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -394,7 +492,8 @@ CellQ cell_eval(const opmgpu_grid* g, const opmgpu_tables* t, int c, double p, d
     { const PvtOut o = b_gas(t, preg, q.pg.v, q.rv.v, freeOil);  q.b[2]  = chain2(o.v, o.dp, q.pg, o.dr, q.rv); }
     { const PvtOut o = mu_gas(t, preg, q.pg.v, q.rv.v, freeOil); q.mu[2] = chain2(o.v, o.dp, q.pg, o.dr, q.rv); }
     // computeRelPerm, :1395-1419
-    relperm3(st, ep, W, sg, q.kr[0], q.kr[1], q.kr[2]);
+    const Hyst hy = hyst_for_cell(g, t, c);
+    relperm3(st, ep, W, sg, q.kr[0], q.kr[1], q.kr[2], &hy);
     // poroMult / transMult, :2089-2145 ; RockCompressibility.cpp:86-125
     D3 pvm(1.0), trm(1.0);
     if (t->rocktab_n > 0) {
@@ -755,8 +854,9 @@ void oracle_relperm_eps(const opmgpu_tables* t, const opmgpu_grid* g, int n, con
         const int c = cells ? cells[i] : 0;
         const SatTab st = sat_tab(t, (g && g->satnum) ? g->satnum[c] : 0);
         const Eps ep = eps_for_cell(g, st, c);
+        const Hyst hy = hyst_for_cell(g, t, c);
         D3 Sw = D3::var(s[3 * i], 0), Sg = D3::var(s[3 * i + 2], 2), k[3];
-        relperm3(st, ep, Sw, Sg, k[0], k[1], k[2]);
+        relperm3(st, ep, Sw, Sg, k[0], k[1], k[2], &hy);
         for (int a = 0; a < 3; ++a) {
             kr[3 * i + a] = k[a].v;
             if (dkrds) for (int b = 0; b < 3; ++b) dkrds[9 * i + 3 * b + a] = k[a].d[b];
@@ -766,10 +866,9 @@ void oracle_relperm_eps(const opmgpu_tables* t, const opmgpu_grid* g, int n, con
 
 void oracle_relperm(const opmgpu_tables* t, int n, const double* s, const int32_t* satnum, double* kr, double* dkrds)
 {
-    const Eps ep = Eps();
     for (int i = 0; i < n; ++i) {
         const SatTab st = sat_tab(t, satnum ? satnum[i] : 0);
-        Eps e0 = ep; e0.on = false; e0.swl = st.swco; e0.swl_t = st.swco;
+        Eps e0 = eps_build(nullptr, st, 0, nullptr);
         D3 Sw = D3::var(s[3 * i], 0), Sg = D3::var(s[3 * i + 2], 2), k[3];
         relperm3(st, e0, Sw, Sg, k[0], k[1], k[2]);
         for (int a = 0; a < 3; ++a) {
@@ -783,7 +882,7 @@ void oracle_cappress(const opmgpu_tables* t, int n, const double* s, const int32
 {
     for (int i = 0; i < n; ++i) {
         const SatTab st = sat_tab(t, satnum ? satnum[i] : 0);
-        Eps e0; e0.on = false; e0.swl = st.swco; e0.swl_t = st.swco;
+        Eps e0 = eps_build(nullptr, st, 0, nullptr);
         D3 Sw = D3::var(s[3 * i], 0), Sg = D3::var(s[3 * i + 2], 2), pcow, pcgo;
         cappress3(st, e0, Sw, Sg, pcow, pcgo);
         const D3 k[3] = { pcow, D3(0.0), pcgo };
@@ -791,6 +890,30 @@ void oracle_cappress(const opmgpu_tables* t, int n, const double* s, const int32
             pc[3 * i + a] = k[a].v;
             if (dpcds) for (int b = 0; b < 3; ++b) dpcds[9 * i + 3 * b + a] = k[a].d[b];
         }
+    }
+}
+
+// hysteresis history for every later cell_props / assemble / relperm_eps call (nullptr = none): krnSwMdc and Carlson shift of the
+// oil-water and gas-oil systems, [nc] each
+void oracle_set_hysteresis(const double* mdc_ow, const double* mdc_go, const double* d_ow, const double* d_go)
+{
+    g_hyst_ow = mdc_ow; g_hyst_go = mdc_go; g_hyst_dow = d_ow; g_hyst_dgo = d_go;
+}
+// EclDefaultMaterial::updateHysteresis (the "inconsistent" update: krnSw = 1 - So for oil-water, 1 - Sg for gas-oil) +
+// EclHysteresisTwoPhaseLawParams::update / updateDynamicParams_, in place on the four [nc] arrays
+void oracle_update_hysteresis(const opmgpu_grid* g, const opmgpu_tables* t, const double* sat, double* mdc_ow, double* mdc_go, double* d_ow, double* d_go)
+{
+    if (!g->imbnum) return;
+    for (int c = 0; c < g->nc; ++c) {
+        const double so = sat[3 * c + 1], sg = std::min(1.0, std::max(0.0, sat[3 * c + 2]));
+        bool upd = false;
+        if (1.0 - so < mdc_ow[c]) { mdc_ow[c] = 1.0 - so; upd = true; }
+        if (1.0 - sg < mdc_go[c]) { mdc_go[c] = 1.0 - sg; upd = true; }
+        if (!upd) continue;
+        const SatTab st = sat_tab(t, g->satnum ? g->satnum[c] : 0);
+        const Eps ep = eps_for_cell(g, st, c);
+        Hyst h; h.on = true; h.imb = sat_tab(t, g->imbnum[c]); h.eimb = eps_build(g, h.imb, c, g->ieps[0] ? g->ieps : g->eps);
+        hyst_deltas(st, ep, h, mdc_ow[c], mdc_go[c], d_ow[c], d_go[c]);
     }
 }
 

@@ -107,6 +107,14 @@ int oracle_bicgstab_ilu0(int nb, const int32_t* rowptr, const int32_t* col, cons
                          int single_precision, double* x3, int* iters, double* reduction,
                          double* hist, int nhist, int* nhist_out);
 
+/* Relative-permeability hysteresis (EclHysteresisTwoPhaseLaw, Carlson / KR only; opmgpu_grid.imbnum): history planes used by every
+ * later call (NULL = none), and the once-per-report-step update (EclDefaultMaterial::updateHysteresis, "inconsistent" form:
+ * krnSw = 1 - So resp. 1 - Sg; EclHysteresisTwoPhaseLawParams::update + updateDynamicParams_) in place on four [nc] arrays.
+ * Restated from opm-material's published code; the reference holds no vectors for it: parity unpinned. */
+void oracle_set_hysteresis(const double* mdc_ow, const double* mdc_go, const double* d_ow, const double* d_go);
+void oracle_update_hysteresis(const opmgpu_grid* g, const opmgpu_tables* t, const double* sat, double* mdc_ow, double* mdc_go,
+                              double* d_ow, double* d_go);
+
 /* timing helper for bench.py's cpu_baseline: threads used by the OpenMP-able loops
  * (assembly, SpMV, vector updates; the ILU sweeps stay sequential like the reference's). */
 void oracle_set_threads(int n);

@@ -53,6 +53,8 @@ def lib():
         L.oracle_bicgstab_ilu0.argtypes = [C.c_int, _ip, _ip, _dp, _dp, _ip, _P, C.c_int, _dp, C.POINTER(C.c_int), _dp, _dp, C.c_int, C.POINTER(C.c_int)]
         L.oracle_bicgstab_ilu0.restype = C.c_int
         L.oracle_set_sat_oil_max.argtypes = [_dp]
+        L.oracle_set_hysteresis.argtypes = [_dp, _dp, _dp, _dp]
+        L.oracle_update_hysteresis.argtypes = [_G, _T, _dp, _dp, _dp, _dp, _dp]
         L.oracle_set_threads.argtypes = [C.c_int]
         L.oracle_get_threads.restype = C.c_int
         _lib = L
@@ -71,6 +73,32 @@ def set_sat_oil_max(so_max):
     global _so_max_keepalive
     _so_max_keepalive = None if so_max is None else capi.f64(so_max).copy()
     lib().oracle_set_sat_oil_max(capi.dptr(_so_max_keepalive))
+
+
+_hyst_keepalive = None
+
+
+class Hysteresis:
+    """History of the relative-permeability hysteresis: krnSwMdc of the oil-water / gas-oil system and the Carlson shifts (start:
+    2.0 = no history, EclHysteresisTwoPhaseLawParams)."""
+
+    def __init__(self, nc):
+        self.mdc_ow, self.mdc_go = np.full(nc, 2.0), np.full(nc, 2.0)
+        self.d_ow, self.d_go = np.zeros(nc), np.zeros(nc)
+
+    def update(self, grid, tables, sat):
+        lib().oracle_update_hysteresis(C.byref(grid.struct()), C.byref(tables.struct()), capi.dptr(capi.f64(sat)), capi.dptr(self.mdc_ow),
+                                       capi.dptr(self.mdc_go), capi.dptr(self.d_ow), capi.dptr(self.d_go))
+
+
+def set_hysteresis(h):
+    """use history `h` (Hysteresis or None) in every later cell_props / assemble / relperm_eps call"""
+    global _hyst_keepalive
+    _hyst_keepalive = h
+    if h is None:
+        lib().oracle_set_hysteresis(None, None, None, None)
+    else:
+        lib().oracle_set_hysteresis(capi.dptr(h.mdc_ow), capi.dptr(h.mdc_go), capi.dptr(h.d_ow), capi.dptr(h.d_go))
 
 
 def relperm(tables, s, satnum=None):

@@ -457,3 +457,79 @@ def test_float_assembly_for_a_float_solve(gpu_lib, oracle):
     a.setState(st); a.setSolvePrecision(True); a.assemble(True); a.getConvergence()
     a.solveJacobianSystem(single_precision=False)
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("case", ["scalecrs", "vertical", "hysteresis", "all"])
+def test_satfunc_options_parity(gpu_lib, oracle, case):
+    """SURVEY row a5 beyond two-point ENDSCALE -- three-point scaling (SCALECRS), vertical scaling (KRW / KRO / KRG / PCW / PCG) and
+    Carlson relative-permeability hysteresis (IMBNUM regions, history on the device) -- device assembly, hysteresis update and
+    updateState against the oracle (whose options are checked against their defining properties in tests/test_satfunc_options.py)."""
+    from test_satfunc_options import _hyst_tables
+    tab = _hyst_tables()                                   # region 0 = drainage curves, region 1 = imbibition curves
+    base = decks.cartesian_grid(7, 6, 5, lognormal_sigma=0.5)
+    nc = base.nc
+    rng = np.random.default_rng(5)
+    eps = decks.random_endpoints(base, seed=3)
+    eps["SOWCR"] = np.clip(eps["SOWCR"] + 0.08, 0.0, 0.5); eps["SOGCR"] = np.clip(eps["SOGCR"] + 0.05, 0.0, 0.5)
+    kw = {}
+    if case in ("scalecrs", "all"):
+        kw["scalecrs"] = True
+    if case in ("vertical", "all"):
+        kw["eps_v"] = {"KRW": rng.uniform(0.3, 0.9, nc), "KRO": rng.uniform(0.6, 1.0, nc), "KRG": rng.uniform(0.5, 1.0, nc),
+                       "PCW": rng.uniform(0.5, 2.0, nc) * decks.BAR, "PCG": rng.uniform(1.0, 3.0, nc) * decks.BAR}
+    if case in ("hysteresis", "all"):
+        kw["imbnum"] = np.ones(nc, np.int32)
+        if case == "all":
+            ie = decks.random_endpoints(base, seed=4)
+            ie["SGCR"] = np.clip(ie["SGCR"] + 0.15, 0.0, 0.6)
+            kw["ieps"] = ie
+    if case == "hysteresis":                               # hysteresis alone: no end-point scaling at all
+        grid = decks.GridData(nc, base.conn_cells, base.trans, base.pv, base.z, dims=base.dims, satnum=np.zeros(nc, np.int32), imbnum=kw["imbnum"])
+    else:
+        grid = decks.with_endpoints(base, eps, **kw)
+    prm = capi.default_params()
+    scale = tuple(prm.matbalscale)
+    rowptr, col = oracle.pattern(grid)
+    hist = oracle.Hysteresis(nc) if "imbnum" in kw else None
+    oracle.set_hysteresis(hist)
+    try:
+        m = GpuBlackoilModel(grid, tab, prm)
+        for seed in (1, 2, 3):
+            st = decks.random_state(grid, tab, seed=seed)
+            m.prepareStep(2 * decks.DAY, st)
+            if hist is not None:                           # the state becomes history (start of a report step), then a NEW state is evaluated
+                m.updateHysteresis()
+                hist.update(grid, tab, st.sat)
+                got = m.getHysteresis()
+                for a, b in zip(got, (hist.mdc_ow, hist.mdc_go, hist.d_ow, hist.d_go)):
+                    assert np.allclose(a, b, rtol=1e-13, atol=1e-15)
+                assert np.abs(hist.d_go).max() > 1e-3 and np.abs(hist.d_ow).max() > 1e-3
+                st = decks.random_state(grid, tab, seed=10 + seed)
+                m.prepareStep(2 * decks.DAY, st)
+                on_imb = ((1.0 - st.sat[:, 2]) > hist.mdc_go).mean()
+                assert 0.05 < on_imb < 0.95                # both branches occur
+            m.assemble(True)
+            r0, v0, _, _ = oracle.assemble(grid, tab, 2 * decks.DAY, st, rowptr, col, scale=scale)
+            assert rel_err(m.jacobian()[2], v0) < RTOL_JAC, (case, seed, rel_err(m.jacobian()[2], v0))
+            assert rel_err(m.residual(), r0) < RTOL_JAC
+            dx = np.concatenate([rng.standard_normal(nc) * 30 * decks.BAR, rng.standard_normal(nc) * 0.25,
+                                 rng.standard_normal(nc) * np.where(st.hc == capi.HC_OIL_ONLY, 30.0, np.where(st.hc == capi.HC_GAS_ONLY, 1e-4, 0.25))])
+            m.updateState(dx)
+            g, o = m.getState(), oracle.update_state(grid, tab, prm, dx, st)
+            assert np.array_equal(g.hc, o.hc)
+            assert np.allclose(g.p, o.p, rtol=1e-14, atol=0) and np.allclose(g.sat, o.sat, rtol=0, atol=1e-14)
+        if hist is not None:                               # restart: set the history, the shifts follow
+            m2 = GpuBlackoilModel(grid, tab, prm)
+            m2.prepareStep(2 * decks.DAY, st)
+            m2.setHysteresis(hist.mdc_ow, hist.mdc_go)
+            for a, b in zip(m2.getHysteresis(), (hist.mdc_ow, hist.mdc_go, hist.d_ow, hist.d_go)):
+                assert np.allclose(a, b, rtol=1e-13, atol=1e-15)
+            m2.close()
+        # the options matter: without them the Jacobian differs
+        plain = decks.with_endpoints(base, eps) if case != "hysteresis" else decks.GridData(nc, base.conn_cells, base.trans, base.pv, base.z, dims=base.dims)
+        oracle.set_hysteresis(None)
+        _, v_plain, _, _ = oracle.assemble(plain, tab, 2 * decks.DAY, st, rowptr, col, scale=scale)
+        assert rel_err(v_plain, v0) > 1e-4
+        m.close()
+    finally:
+        oracle.set_hysteresis(None)
