@@ -139,7 +139,7 @@ __device__ __forceinline__ void sat_curve(const double* __restrict__ x, const do
 // Relative-permeability hysteresis of a cell (EclHysteresisTwoPhaseLaw, Carlson for the non-wetting phases, KR only): the history
 // planes hold the smallest wetting saturation each two-phase system has seen (2.0 = none) and the shift of the imbibition curve.
 struct HystD { bool on; int ireg; double mdc_ow, mdc_go, d_ow, d_go; };
-struct HystArgs { const int32_t* imbnum; const double* hist; const double* ieps; };      // kernel argument: imbnum == nullptr = no hysteresis
+struct HystArgs { const int32_t* imbnum; const double* hist; const double* ieps; const double* iureg; };      // kernel argument: imbnum == nullptr = no hysteresis
 __device__ __forceinline__ void hyst_load(const int32_t* __restrict__ imbnum, const double* __restrict__ hist, long nbp, int row, HystD& h)
 {
     h.on = imbnum != nullptr;
@@ -224,7 +224,9 @@ __device__ void eval_cell(const opmgpu_tables& T, const EpsD& E, double so_max, 
     const V4 krg = vchain(f, df, sg);
     V4 kro;
     {   // EclDefaultMaterial::krn
-        const double swco = E.on ? E.s0[EC_PCOW] : xsw[0];      // (scaled) connate water
+        // connate water of the three-phase law: the cell's scaled SWL; a set without horizontal scaling (s0 = u0 = 0, k = 1) has the table's
+        const bool hscaled = E.on && (E.k[EC_PCOW] != 1.0 || E.s0[EC_PCOW] != 0.0 || E.u0[EC_PCOW] != 0.0);
+        const double swco = hscaled ? E.s0[EC_PCOW] : xsw[0];
         const V4 swp = (sw_ > swco) ? W : mk(swco, 0, 0, 0);
         const V4 swow = vadd(sg, swp);
         if (H.on && swow.v > H.mdc_ow) {         // oil against water on its (shifted) imbibition curve
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(kBlock) void k_cell_props(int nb, int nbp, opmgpu_t
     HystD H;
     eps_load(eps, eps_u0, nbp, row, satnum[row], E);
     hyst_load(hy.imbnum, hy.hist, nbp, row, H);
-    if (H.on) eps_load(hy.ieps, eps_u0, nbp, row, H.ireg, EI);
+    if (H.on) eps_load(hy.ieps, hy.iureg, nbp, row, H.ireg, EI);
     eval_cell(T, E, somax[row], pvtnum[row], satnum[row], p[row], sw[row], sg[row], rs[row], rv[row], hc[row], q, H, &EI);
     props[long(PL_PW) * nbp + row] = q.pw.v; props[long(PL_PG) * nbp + row] = q.pg.v;
     pd[long(PL_DPW_W) * nbp + row] = MS(q.pw.w); pd[long(PL_DPG_W) * nbp + row] = MS(q.pg.w); pd[long(PL_DPG_X) * nbp + row] = MS(q.pg.x);
@@ -721,7 +723,7 @@ __global__ __launch_bounds__(kBlock) void k_perf_props(int nperf, opmgpu_tables 
     HystD H;
     eps_load(eps, eps_u0, nbp, c, satnum[c], E);
     hyst_load(hy.imbnum, hy.hist, nbp, c, H);
-    if (H.on) eps_load(hy.ieps, eps_u0, nbp, c, H.ireg, EI);
+    if (H.on) eps_load(hy.ieps, hy.iureg, nbp, c, H.ireg, EI);
     eval_cell(T, E, somax[c], pvtnum[c], satnum[c], p[c], sw[c], sg[c], rs[c], rv[c], hc[c], q, H, &EI);
     const V4 list[9] = { mk(p[c], 1, 0, 0), q.rs, q.rv, q.b[0], q.b[1], q.b[2], q.mob[0], q.mob[1], q.mob[2] };
     double* o = out + long(i) * OPMGPU_PERF_K;
@@ -965,20 +967,26 @@ void BlackoilDevice::rebuild_structure()
     d_pv.upload(pvi, stream); d_pvtnum.upload(pn, stream); d_satnum.upload(sn, stream);
     if (use_eps) {
         // per region: unscaled fixed points of every curve (u0 | u1); per cell: the maps and the vertical factors (build_eps_planes)
+        // A set of curves WITHOUT scaled end points keeps the saturation exactly (S_u = 0 + (S - 0) * 1: states that sit on a table
+        // breakpoint must not move by an ulp), so its region table is zero and build_eps_planes writes s0 = 0, k = 1.
         const int ns = dt_.n_sat_regions;
-        std::vector<double> ureg(size_t(kEpsRegion) * ns);
-        for (int r = 0; r < ns; ++r) {
-            const double* u = &h_unscaled[8 * size_t(r)];
-            double* o = &ureg[size_t(kEpsRegion) * r];
-            o[EC_KRW] = u[1]; o[EC_KROW] = u[0] + u[4]; o[EC_PCOW] = u[0]; o[EC_KRG] = u[5]; o[EC_KROG] = u[7]; o[EC_PCGO] = u[4];
-            double* m = o + EC_COUNT;       // middle points (SCALECRS): krw 1-Sowcr-Sgl, krow Swcr+Sgl, krg 1-Sogcr-Swl, krog 1-Sgcr-Swl
-            m[EC_KRW] = 1.0 - u[3] - u[4]; m[EC_KROW] = u[1] + u[4]; m[EC_PCOW] = 0.0; m[EC_KRG] = 1.0 - u[7] - u[0]; m[EC_KROG] = 1.0 - u[5] - u[0]; m[EC_PCGO] = 0.0;
-        }
-        d_eps_u0.upload(ureg, stream);
+        auto region_table = [&](bool have_points) {
+            std::vector<double> ureg(size_t(kEpsRegion) * ns, 0.0);
+            for (int r = 0; r < ns && have_points; ++r) {
+                const double* u = &h_unscaled[8 * size_t(r)];
+                double* o = &ureg[size_t(kEpsRegion) * r];
+                o[EC_KRW] = u[1]; o[EC_KROW] = u[0] + u[4]; o[EC_PCOW] = u[0]; o[EC_KRG] = u[5]; o[EC_KROG] = u[7]; o[EC_PCGO] = u[4];
+                double* m = o + EC_COUNT;   // middle points (SCALECRS): krw 1-Sowcr-Sgl, krow Swcr+Sgl, krg 1-Sogcr-Swl, krog 1-Sgcr-Swl
+                m[EC_KRW] = 1.0 - u[3] - u[4]; m[EC_KROW] = u[1] + u[4]; m[EC_PCOW] = 0.0; m[EC_KRG] = 1.0 - u[7] - u[0]; m[EC_KROG] = 1.0 - u[5] - u[0]; m[EC_PCGO] = 0.0;
+            }
+            return ureg;
+        };
+        d_eps_u0.upload(region_table(has_endpoints), stream);
         std::vector<double> planes;
         build_eps_planes(h_eps, has_endpoints, false, planes);
         d_eps.upload(planes, stream);
         if (use_hyst) {
+            d_ieps_u0.upload(region_table(has_iendpoints || has_endpoints), stream);
             build_eps_planes(has_iendpoints ? h_ieps : h_eps, has_iendpoints || has_endpoints, true, planes);
             d_ieps.upload(planes, stream);
             std::vector<int32_t> im(nbp, 0);
@@ -1026,7 +1034,7 @@ void BlackoilDevice::rebuild_structure()
 HystArgs BlackoilDevice::hyst_args() const
 {
     HystArgs h;
-    h.imbnum = use_hyst ? d_imbnum.p : nullptr; h.hist = d_hist.p; h.ieps = d_ieps.p;
+    h.imbnum = use_hyst ? d_imbnum.p : nullptr; h.hist = d_hist.p; h.ieps = d_ieps.p; h.iureg = d_ieps_u0.p;
     return h;
 }
 
@@ -1051,7 +1059,10 @@ void BlackoilDevice::build_eps_planes(const std::vector<double>* ep8, bool have_
         const double u0c[EC_COUNT] = { u[1], u[0] + u[4], u[0], u[5], u[7], u[4] };
         const double u1c[EC_COUNT] = { 1.0 - u[3] - u[4], u[1] + u[4], 0.0, 1.0 - u[7] - u[0], 1.0 - u[5] - u[0], 0.0 };
         const double u2c[EC_COUNT] = { u[2], 1.0 - u[3] - u[4], u[2], u[6], 1.0 - u[0] - u[4], u[6] };
-        for (int k = 0; k < EC_COUNT; ++k) {
+        for (int k = 0; k < EC_COUNT && !have_points; ++k) {          // identity map, exact
+            ep[size_t(k) * nbp + r] = 0.0; ep[size_t(EC_COUNT + k) * nbp + r] = 1.0; ep[size_t(2 * EC_COUNT + k) * nbp + r] = 1e300; ep[size_t(3 * EC_COUNT + k) * nbp + r] = 1.0;
+        }
+        for (int k = 0; k < EC_COUNT && have_points; ++k) {
             if (c >= 0 && !(s2[k] > s0[k])) throw HipError(OPMGPU_EINVAL, "ENDSCALE end points of a cell are not increasing");
             const bool three = scalecrs && have_points && k != EC_PCOW && k != EC_PCGO;
             if (three && c >= 0 && !(s1[k] > s0[k] && s2[k] > s1[k])) throw HipError(OPMGPU_EINVAL, "SCALECRS: a cell's critical saturation is not between its end points");
@@ -1088,7 +1099,8 @@ __device__ double table_inverse(const double* __restrict__ x, const double* __re
 // updateDynamicParams_ (Carlson shift: delta = Sw_imb(krn_drain(mdc)) - mdc), one thread per cell
 __global__ __launch_bounds__(kBlock) void k_hyst_update(int nb, int nbp, opmgpu_tables T, const int32_t* __restrict__ satnum, const int32_t* __restrict__ imbnum,
                                                         const double* __restrict__ so, const double* __restrict__ sg, const double* __restrict__ eps,
-                                                        const double* __restrict__ ieps, const double* __restrict__ ureg, double* __restrict__ hist, int force)
+                                                        const double* __restrict__ ieps, const double* __restrict__ ureg, const double* __restrict__ iureg,
+                                                        double* __restrict__ hist, int force)
 {
     const int c = blockIdx.x * kBlock + threadIdx.x;
     if (c >= nb) return;
@@ -1103,7 +1115,7 @@ __global__ __launch_bounds__(kBlock) void k_hyst_update(int nb, int nbp, opmgpu_
     const int sreg = satnum[c], ireg = imbnum[c];
     EpsD E, EI;
     eps_load(eps, ureg, nbp, c, sreg, E);
-    eps_load(ieps, ureg, nbp, c, ireg, EI);
+    eps_load(ieps, iureg, nbp, c, ireg, EI);
     double dow = 0.0, dgo = 0.0, f, df;
     if (mow < 2.0) {
         const int wa = T.swof_ptr[sreg], wi = T.swof_ptr[ireg];
@@ -1126,7 +1138,7 @@ int BlackoilDevice::update_hysteresis()
     if (!use_hyst) return OPMGPU_OK;
     if (!has_state) return OPMGPU_EINVAL;
     hipLaunchKernelGGL(k_hyst_update, dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, ls.plan.nbp, dt_, d_satnum.p, d_imbnum.p, d_so.p, d_sg.p,
-                       (const double*)d_eps.p, (const double*)d_ieps.p, (const double*)d_eps_u0.p, d_hist.p, 0);
+                       (const double*)d_eps.p, (const double*)d_ieps.p, (const double*)d_eps_u0.p, (const double*)d_ieps_u0.p, d_hist.p, 0);
     return OPMGPU_OK;
 }
 int BlackoilDevice::set_hysteresis(const double* mdc_ow, const double* mdc_go)
@@ -1138,7 +1150,7 @@ int BlackoilDevice::set_hysteresis(const double* mdc_ow, const double* mdc_go)
     d_hist.upload(hp, stream);
     // the shifts follow from the history
     hipLaunchKernelGGL(k_hyst_update, dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, P.nbp, dt_, d_satnum.p, d_imbnum.p, d_so.p, d_sg.p,
-                       (const double*)d_eps.p, (const double*)d_ieps.p, (const double*)d_eps_u0.p, d_hist.p, 1);
+                       (const double*)d_eps.p, (const double*)d_ieps.p, (const double*)d_eps_u0.p, (const double*)d_ieps_u0.p, d_hist.p, 1);
     OPMGPU_HIP(hipStreamSynchronize(stream));
     return OPMGPU_OK;
 }

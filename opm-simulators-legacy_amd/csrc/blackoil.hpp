@@ -111,7 +111,7 @@ private:
     bool has_endpoints = false, scalecrs = false, use_hyst = false, has_iendpoints = false;
     std::vector<double> h_eps[8], h_unscaled, h_eps_v[5], h_ieps[8];
     std::vector<int32_t> h_imbnum;
-    DevArray<double> d_eps, d_eps_u0, d_somax, d_saved, d_ieps, d_hist;     // d_hist: [mdc_ow | mdc_go | d_ow | d_go] planes
+    DevArray<double> d_eps, d_eps_u0, d_somax, d_saved, d_ieps, d_ieps_u0, d_hist;     // d_hist: [mdc_ow | mdc_go | d_ow | d_go] planes
     DevArray<int32_t> d_imbnum;
     HystArgs hyst_args() const;
     void build_eps_planes(const std::vector<double>* ep8, bool have_points, bool imbibition, std::vector<double>& planes) const;

@@ -6,9 +6,11 @@ What `flow_legacy` gets from opm-parser + `DerivedGeology` (opm/autodiff/GeoProp
   RUNSPEC   DIMENS TABDIMS OIL WATER GAS DISGAS VAPOIL METRIC ENDSCALE
   GRID      DX DY DZ / DXV DYV DZV, TOPS (+BOX for the top layer) or DEPTHZ (flat), PORO PERMX PERMY PERMZ NTG ACTNUM
             MULTX MULTY MULTZ MULTX- MULTY- MULTZ- MULTPV NNC
-  PROPS     SWOF SGOF PVTO PVDO PVCDO PVTG PVDG PVTW DENSITY ROCK ROCKTAB VAPPARS SCALECRS
-            SWL SWCR SWU SOWCR SGL SGCR SGU SOGCR
-  REGIONS   PVTNUM SATNUM
+  PROPS     SWOF SGOF PVTO PVDO PVCDO PVTG PVDG PVTW DENSITY ROCK ROCKTAB VAPPARS SCALECRS (NO and YES) EHYSTR
+            SWL SWCR SWU SOWCR SGL SGCR SGU SOGCR  KRW KRO KRG PCW PCG  ISWL ISWCR ISWU ISOWCR ISGL ISGCR ISGU ISOGCR
+            (SATOPTS HYSTER in RUNSPEC switches the hysteresis on; EHYSTR item 2 = 0 and item 5 = KR -- Carlson, relative permeabilities
+            only -- is the model the device implements)
+  REGIONS   PVTNUM SATNUM IMBNUM
   SOLUTION  PRESSURE SWAT SGAS RS RV (explicit initial state; EQUIL is outside the hot path)
 
 Block-centred Cartesian geometry only (corner-point COORD/ZCORN needs opm-grid's processing, out of scope).  TPFA
@@ -67,8 +69,9 @@ def _value(tok):
 
 
 class Deck:
-    def __init__(self, keywords):
+    def __init__(self, keywords, schedule=None):
         self.kw = keywords              # name -> list of records (each a list of values), last occurrence wins; BOX-scoped ones keep their box
+        self.schedule = schedule or []  # SCHEDULE section in deck order: [(keyword, records)], every occurrence (opmgpu/schedule.py)
 
     def has(self, name):
         return name in self.kw
@@ -233,20 +236,48 @@ class Deck:
         eps = self.endpoints()
         if eps is not None:
             eps = {k: v[act] for k, v in eps.items()}
-        return GridData(int(act.sum()), conn, trans, pv[act], zc[act], gravity=gravity, pvtnum=reg("PVTNUM"), satnum=reg("SATNUM"),
-                        dims=(nx, ny, nz) if act.all() else None, eps=eps)
+        more = {}
+        if eps is not None and self.has("SCALECRS") and str(self.records("SCALECRS")[0][0]).upper().startswith("Y"):
+            more["scalecrs"] = True
+        ev = {k: self.array(k, n)[act] * (BAR if k.startswith("PC") else 1.0) for k in GridData.EPSV_NAMES if self.has(k)}
+        if ev:
+            if any(np.isnan(v).any() for v in ev.values()):
+                raise ValueError("vertical scaling arrays (KRW KRO KRG PCW PCG) must be given for every cell")
+            more["eps_v"] = ev
+        if self.hysteresis():
+            imb = reg("IMBNUM")
+            more["imbnum"] = imb if imb is not None else (reg("SATNUM") if reg("SATNUM") is not None else np.zeros(int(act.sum()), np.int32))
+            ieps = self.endpoints(prefix="I", regions="IMBNUM")
+            if ieps is not None and any(self.has("I" + k) for k in EPS_NAMES):
+                more["ieps"] = {k: v[act] for k, v in ieps.items()}
+        g = GridData(int(act.sum()), conn, trans, pv[act], zc[act], gravity=gravity, pvtnum=reg("PVTNUM"), satnum=reg("SATNUM"),
+                     dims=(nx, ny, nz), eps=eps, **more)
+        g.active_index = newid
+        return g
 
-    def endpoints(self):
+    def hysteresis(self):
+        """SATOPTS HYSTER with the EHYSTR model the device implements (item 2 = 0: Carlson / drainage for the wetting phase, item 5 = KR)"""
+        if not self.has("SATOPTS") or not any(str(x).upper().startswith("HYST") for r in self.records("SATOPTS") for x in r):
+            return False
+        if self.has("EHYSTR"):
+            r = self.records("EHYSTR")[0]
+            model = int(r[1]) if len(r) > 1 and r[1] is not None else 0
+            what = str(r[4]).upper() if len(r) > 4 and r[4] is not None else "BOTH"
+            if model != 0 or what != "KR":
+                raise ValueError("EHYSTR: only item 2 = 0 (Carlson) with item 5 = KR is supported")
+        return True
+
+    def endpoints(self, prefix="", regions="SATNUM"):
         """ENDSCALE: per-cell scaled end points; the ones the deck does not give default to the cell's table values
-        (EclEpsScalingPointsInfo::extractScaled falls back to the unscaled points)."""
+        (EclEpsScalingPointsInfo::extractScaled falls back to the unscaled points).  prefix "I" / regions "IMBNUM": the
+        imbibition curves' points (ISWL ...)."""
         if not self.has("ENDSCALE"):
             return None
-        if self.has("SCALECRS") and str(self.records("SCALECRS")[0][0]).upper().startswith("Y"):
-            raise ValueError("three-point end-point scaling (SCALECRS YES) is not supported")
         nx, ny, nz = self.dims
         n = nx * ny * nz
         t = self.tables()
-        sat = (self.array("SATNUM", n).astype(int) - 1) if self.has("SATNUM") else np.zeros(n, int)
+        regkw = regions if self.has(regions) else "SATNUM"
+        sat = (self.array(regkw, n).astype(int) - 1) if self.has(regkw) else np.zeros(n, int)
         un = np.zeros((t.n_sat, 8))
         for r in range(t.n_sat):
             a, b = t.swof_ptr[r], t.swof_ptr[r + 1]
@@ -256,7 +287,7 @@ class Deck:
             un[r] = [sw[0], last_zero(sw, krw), sw[-1], 1.0 - first_zero(sw, krow), sg[0], last_zero(sg, krg), sg[-1], 1.0 - first_zero(sg, krog)]
         out = {}
         for k, name in enumerate(EPS_NAMES):
-            a = self.array(name, n, None)
+            a = self.array(prefix + name, n, None)
             dflt = un[sat, k]
             out[name] = dflt if a is None else np.where(np.isnan(a), dflt, a)
         return out
@@ -314,6 +345,7 @@ def read_deck(path):
     kws, cur, open_record = {}, None, False
     box = None
     skip_line = False
+    schedule, in_schedule = [], False
     for toks in lines:
         if not toks:
             continue
@@ -328,6 +360,10 @@ def read_deck(path):
             if name == "ENDBOX":
                 box = None
             kws[name] = cur
+            if name == "SCHEDULE":
+                in_schedule = True
+            elif in_schedule:
+                schedule.append((name, cur["records"]))
             toks = toks[1:]
             if name == "TITLE":
                 cur["closed"] = True
@@ -345,7 +381,7 @@ def read_deck(path):
             else:
                 cur["pending"].extend(_expand(t))
                 open_record = True
-    return Deck(kws)
+    return Deck(kws, schedule)
 
 
 def _is_data(tok):
