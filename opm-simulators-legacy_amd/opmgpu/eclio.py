@@ -1,0 +1,216 @@
+"""ECLIPSE binary output: unified restart (.UNRST), grid (.EGRID), init (.INIT) and summary (.SMSPEC / .UNSMRY)
+files, so that a run of this path can be diffed against a real `flow_legacy` run with opm-common's `compareECL` the way the
+reference's regression tests do (tests/run-regressionTest.sh; tolerances compareECLFiles.cmake:83-118: abs 2e-2, rel 1e-5 on the
+restart, and the summary compared keyword by keyword).
+
+What `flow_legacy` writes through opm-common's EclipseIO (SimulatorFullyImplicitBlackoilOutput.cpp -> external), restated from the
+published file format: Fortran sequential records (4-byte big-endian length before and after), every array = a 16-byte header record
+(8-char keyword, int32 count, 4-char type INTE / REAL / DOUB / LOGI / CHAR / MESS) followed by its data in blocks of at most 1000
+elements (105 for CHAR), all big-endian.  Units METRIC (pressure in bar, rates per day, volumes in m3).  No reference vectors for
+the FILE FORMAT exist in /root/reference (EclipseIO is external): checked here by a reader written against the same description
+(tests/test_eclio.py) -- parity unpinned.
+"""
+import datetime
+import struct
+
+import numpy as np
+
+from .decks import BAR, DAY
+
+_TYPES = {"INTE": (">i4", 4, 1000), "REAL": (">f4", 4, 1000), "DOUB": (">f8", 8, 1000), "LOGI": (">i4", 4, 1000), "CHAR": ("S8", 8, 105)}
+
+
+def _record(f, payload):
+    f.write(struct.pack(">i", len(payload))); f.write(payload); f.write(struct.pack(">i", len(payload)))
+
+
+def write_array(f, name, typ, data):
+    """one keyword: header record + blocked data records"""
+    if typ == "MESS":
+        _record(f, name.ljust(8).encode()[:8] + struct.pack(">i", 0) + b"MESS")
+        return
+    dt, size, block = _TYPES[typ]
+    if typ == "CHAR":
+        arr = np.asarray([str(s).ljust(8)[:8].encode() for s in data], dtype="S8")
+    elif typ == "LOGI":
+        arr = np.where(np.asarray(data, bool), -1, 0).astype(dt)          # .TRUE. is all bits set
+    else:
+        arr = np.ascontiguousarray(data).astype(dt)
+    _record(f, name.ljust(8).encode()[:8] + struct.pack(">i", arr.size) + typ.encode())
+    for i in range(0, arr.size, block):
+        _record(f, arr[i:i + block].tobytes())
+
+
+def read_arrays(path):
+    """[(keyword, type, numpy array)] of a unified file (the checker of tests/test_eclio.py; also handy for diffs)"""
+    out = []
+    with open(path, "rb") as f:
+        blob = f.read()
+    pos = 0
+
+    def rec():
+        nonlocal pos
+        n = struct.unpack(">i", blob[pos:pos + 4])[0]
+        data = blob[pos + 4:pos + 4 + n]
+        assert struct.unpack(">i", blob[pos + 4 + n:pos + 8 + n])[0] == n, "record length mismatch"
+        pos += 8 + n
+        return data
+    while pos < len(blob):
+        h = rec()
+        name, count, typ = h[:8].decode().strip(), struct.unpack(">i", h[8:12])[0], h[12:16].decode()
+        if typ == "MESS":
+            out.append((name, typ, np.zeros(0)))
+            continue
+        dt, size, block = _TYPES[typ]
+        parts, got = [], 0
+        while got < count:
+            d = rec()
+            parts.append(np.frombuffer(d, dtype=dt))
+            got += parts[-1].size
+        a = np.concatenate(parts) if parts else np.zeros(0, dtype=dt)
+        if typ == "CHAR":
+            a = np.array([s.decode().strip() for s in a])
+        elif typ == "LOGI":
+            a = a != 0
+        else:
+            a = a.astype(a.dtype.newbyteorder("="))
+        out.append((name, typ, a))
+    return out
+
+
+def _intehead(dims, nactive, date, nwells=0, ncwmax=0, report=0):
+    """INTEHEAD (411 entries; the ones readers look at): [2] units (1 METRIC), [8..10] NX NY NZ, [11] NACTIV, [14] phase indicator
+    (7 = oil + water + gas), [16] NWELLS, [17] NCWMAX, [24..27] NIWELZ NSWELZ NXWELZ NZWELZ, [32..34] NICONZ NSCONZ NXCONZ,
+    [64..66] day month year, [94] simulator (100 = ECLIPSE 100 conventions), [206..208] hour minute microsecond"""
+    ih = np.zeros(411, np.int32)
+    ih[2] = 1
+    ih[8], ih[9], ih[10], ih[11] = dims[0], dims[1], dims[2], nactive
+    ih[14] = 7
+    ih[16], ih[17] = nwells, ncwmax
+    ih[24], ih[25], ih[26], ih[27] = 155, 122, 130, 3
+    ih[32], ih[33], ih[34] = 25, 41, 58
+    ih[64], ih[65], ih[66] = date.day, date.month, date.year
+    ih[94] = 100
+    ih[410] = 0
+    return ih
+
+
+class EclOutput:
+    """BASE.EGRID / .INIT once, then BASE.UNRST / .SMSPEC / .UNSMRY per report step."""
+
+    def __init__(self, base, dims, active_index, start_date, cell_sizes=None, tops=None, porv=None, extra_init=None):
+        """dims (nx, ny, nz); active_index[cartesian cell] = active cell or -1; cell_sizes = (dx, dy, dz) per Cartesian cell and
+        tops [ny*nx] for the EGRID of a block-centred grid; porv per Cartesian cell [m3]; extra_init = {keyword: per-active-cell array}"""
+        self.base, self.dims = base, tuple(int(d) for d in dims)
+        self.act = np.asarray(active_index)
+        self.nactive = int((self.act >= 0).sum())
+        self.start = start_date
+        self.report = 0
+        self.elapsed = 0.0
+        self.ministep = 0
+        self._smspec_written = False
+        self._vectors = None
+        open(base + ".UNRST", "wb").close(); open(base + ".UNSMRY", "wb").close()
+        if cell_sizes is not None:
+            self._write_egrid(cell_sizes, tops)
+        self._write_init(porv, extra_init or {})
+
+    # ---------------------------------------------------------------- EGRID (corner-point form of the block-centred grid)
+    def _write_egrid(self, cell_sizes, tops):
+        nx, ny, nz = self.dims
+        dx, dy, dz = (np.asarray(a, float).reshape(nz, ny, nx) for a in cell_sizes)
+        top = np.zeros((ny, nx)) if tops is None else np.asarray(tops, float).reshape(ny, nx)
+        xs = np.concatenate([[0.0], np.cumsum(dx[0, 0, :])]); ys = np.concatenate([[0.0], np.cumsum(dy[0, :, 0])])
+        zt = top[None] + np.concatenate([np.zeros((1, ny, nx)), np.cumsum(dz, 0)[:-1]], 0)
+        zb = zt + dz
+        coord = np.zeros((ny + 1, nx + 1, 6))             # vertical pillars
+        coord[..., 0] = xs[None, :]; coord[..., 1] = ys[:, None]; coord[..., 2] = zt.min()
+        coord[..., 3] = xs[None, :]; coord[..., 4] = ys[:, None]; coord[..., 5] = zb.max()
+        zcorn = np.zeros((nz, 2, ny, 2, nx, 2))           # (k, top/bottom, j, y-side, i, x-side)
+        zcorn[:, 0] = zt[:, :, None, :, None]; zcorn[:, 1] = zb[:, :, None, :, None]
+        with open(self.base + ".EGRID", "wb") as f:
+            fh = np.zeros(100, np.int32); fh[0] = 3; fh[1] = 2007; fh[4] = 0; fh[5] = 0
+            write_array(f, "FILEHEAD", "INTE", fh)
+            write_array(f, "GRIDUNIT", "CHAR", ["METRES", ""])
+            gh = np.zeros(100, np.int32); gh[0] = 1; gh[1], gh[2], gh[3] = nx, ny, nz; gh[24] = 1; gh[25] = 1
+            write_array(f, "GRIDHEAD", "INTE", gh)
+            write_array(f, "COORD", "REAL", coord.ravel())
+            write_array(f, "ZCORN", "REAL", zcorn.ravel())
+            write_array(f, "ACTNUM", "INTE", (self.act >= 0).astype(np.int32))
+            write_array(f, "ENDGRID", "INTE", np.zeros(0, np.int32))
+
+    def _write_init(self, porv, extra):
+        with open(self.base + ".INIT", "wb") as f:
+            write_array(f, "INTEHEAD", "INTE", _intehead(self.dims, self.nactive, self.start))
+            write_array(f, "LOGIHEAD", "LOGI", np.zeros(121, bool))
+            write_array(f, "DOUBHEAD", "DOUB", np.zeros(229))
+            if porv is not None:
+                write_array(f, "PORV", "REAL", np.asarray(porv, float))          # PORV is per Cartesian cell
+            for k, v in extra.items():
+                write_array(f, k, "REAL", np.asarray(v, float))
+
+    # ---------------------------------------------------------------- restart
+    def write_restart(self, elapsed_days, state, extra=None):
+        """one report step: PRESSURE [bar], SWAT, SGAS, RS, RV per ACTIVE cell (the solution section `compareECL` diffs)"""
+        self.report += 1
+        self.elapsed = float(elapsed_days)
+        date = self.start + datetime.timedelta(days=self.elapsed)
+        with open(self.base + ".UNRST", "ab") as f:
+            write_array(f, "SEQNUM", "INTE", [self.report])
+            write_array(f, "INTEHEAD", "INTE", _intehead(self.dims, self.nactive, date, report=self.report))
+            write_array(f, "LOGIHEAD", "LOGI", np.zeros(121, bool))
+            dh = np.zeros(229); dh[0] = self.elapsed
+            write_array(f, "DOUBHEAD", "DOUB", dh)
+            write_array(f, "STARTSOL", "MESS", None)
+            write_array(f, "PRESSURE", "REAL", state.p / BAR)
+            write_array(f, "SWAT", "REAL", state.sat[:, 0])
+            write_array(f, "SGAS", "REAL", state.sat[:, 2])
+            write_array(f, "RS", "REAL", state.rs)
+            write_array(f, "RV", "REAL", state.rv)
+            for k, v in (extra or {}).items():
+                write_array(f, k, "REAL", v)
+            write_array(f, "ENDSOL", "MESS", None)
+
+    # ---------------------------------------------------------------- summary
+    def _write_smspec(self, well_names):
+        """vectors: TIME, YEARS, field rates, then per well WBHP WOPR WWPR WGPR WWIR WGIR (positive rates, per day)"""
+        kws, wgn, nums, units = ["TIME", "YEARS"], [":+:+:+:+", ":+:+:+:+"], [0, 0], ["DAYS", "YEARS"]
+        for k, u in (("FOPR", "SM3/DAY"), ("FWPR", "SM3/DAY"), ("FGPR", "SM3/DAY"), ("FWIR", "SM3/DAY"), ("FGIR", "SM3/DAY")):
+            kws.append(k); wgn.append(":+:+:+:+"); nums.append(0); units.append(u)
+        for w in well_names:
+            for k, u in (("WBHP", "BARSA"), ("WOPR", "SM3/DAY"), ("WWPR", "SM3/DAY"), ("WGPR", "SM3/DAY"), ("WWIR", "SM3/DAY"), ("WGIR", "SM3/DAY")):
+                kws.append(k); wgn.append(w); nums.append(0); units.append(u)
+        self._vectors = (kws, wgn)
+        with open(self.base + ".SMSPEC", "wb") as f:
+            write_array(f, "INTEHEAD", "INTE", [1, 100])
+            write_array(f, "RESTART", "CHAR", [""] * 9)
+            write_array(f, "DIMENS", "INTE", [len(kws), self.dims[0], self.dims[1], self.dims[2], 0, -1])
+            write_array(f, "KEYWORDS", "CHAR", kws)
+            write_array(f, "WGNAMES", "CHAR", wgn)
+            write_array(f, "NUMS", "INTE", nums)
+            write_array(f, "UNITS", "CHAR", units)
+            write_array(f, "STARTDAT", "INTE", [self.start.day, self.start.month, self.start.year, 0, 0, 0])
+        self._smspec_written = True
+
+    def write_summary(self, elapsed_days, wells, well_state, new_report_step=False):
+        """one ministep: wells = opmgpu.wells.Wells (names, types), well_state = its WellState (bhp [Pa], qs [m3/s], w-o-g, production < 0)"""
+        names = list(wells.name)
+        if not self._smspec_written:
+            self._write_smspec(names)
+        kws, wgn = self._vectors
+        qs = np.asarray(well_state.qs) * DAY
+        prod = np.maximum(-qs, 0.0); inj = np.maximum(qs, 0.0)
+        row = {("TIME", ":+:+:+:+"): elapsed_days, ("YEARS", ":+:+:+:+"): elapsed_days / 365.25,
+               ("FOPR", ":+:+:+:+"): prod[:, 1].sum(), ("FWPR", ":+:+:+:+"): prod[:, 0].sum(), ("FGPR", ":+:+:+:+"): prod[:, 2].sum(),
+               ("FWIR", ":+:+:+:+"): inj[:, 0].sum(), ("FGIR", ":+:+:+:+"): inj[:, 2].sum()}
+        for w, n in enumerate(names):
+            row[("WBHP", n)] = well_state.bhp[w] / BAR
+            row[("WOPR", n)], row[("WWPR", n)], row[("WGPR", n)] = prod[w, 1], prod[w, 0], prod[w, 2]
+            row[("WWIR", n)], row[("WGIR", n)] = inj[w, 0], inj[w, 2]
+        params = [row.get((k, g), 0.0) for k, g in zip(kws, wgn)]
+        with open(self.base + ".UNSMRY", "ab") as f:
+            if new_report_step or self.ministep == 0:
+                write_array(f, "SEQHDR", "INTE", [self.report + 1])
+            write_array(f, "MINISTEP", "INTE", [self.ministep])
+            write_array(f, "PARAMS", "REAL", params)
+        self.ministep += 1

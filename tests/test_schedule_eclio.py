@@ -1,0 +1,86 @@
+"""SCHEDULE ingest (opmgpu/schedule.py) and ECLIPSE binary output (opmgpu/eclio.py), host-side parts of SURVEY 8f-4."""
+import datetime
+import os
+
+import numpy as np
+import pytest
+
+from opmgpu import deck as deckmod, decks, eclio, schedule, wells as W
+
+DECK = os.path.join(os.path.dirname(__file__), "golden", "decks", "SCHEDULE_SMALL.DATA")
+
+
+def _sched():
+    d = deckmod.read_deck(DECK)
+    g = d.grid()
+    n = 90
+    dx, dy, dz = d._cell_sizes()
+    return d, g, schedule.Schedule(d, g, perm_md=(d.array("PERMX", n), d.array("PERMY", n)), dz=dz.ravel(), dxdy=(dx.ravel(), dy.ravel()), ntg=np.ones(n))
+
+
+def test_schedule_report_steps_and_wells():
+    d, g, s = _sched()
+    assert s.start == datetime.date(2020, 1, 1)
+    assert [x[0] / decks.DAY for x in s.steps] == [10.0, 10.0, 20.0]
+    w0, w1 = s.wells(0), s.wells(1)
+    assert w0.name == ["INJ", "PROD1", "PROD2"] and w0.type == [W.INJECTOR, W.PRODUCER, W.PRODUCER]
+    assert w0.cells[w0.connpos[0]:w0.connpos[1]] == [0, 30, 60]                       # column (1,1), layers 1-3
+    assert w0.cells[w0.connpos[1]:w0.connpos[2]] == [29, 59] and w0.cells[w0.connpos[2]:w0.connpos[3]] == [35]
+    # controls: the deck's mode is the current control, its other limits are the constraints; producer rates negative
+    inj = w0.controls[0]
+    assert inj[0][0] == W.SURFACE_RATE and inj[0][1] == pytest.approx(400.0 / decks.DAY) and list(inj[0][2]) == [1.0, 0.0, 0.0]
+    assert inj[1][0] == W.BHP and inj[1][1] == pytest.approx(320e5)
+    p1 = w0.controls[1]
+    assert p1[0][0] == W.SURFACE_RATE and p1[0][1] == pytest.approx(-150.0 / decks.DAY) and list(p1[0][2]) == [0.0, 1.0, 0.0] and p1[1][:2] == (W.BHP, pytest.approx(180e5))
+    assert w0.controls[2][0][:2] == (W.BHP, pytest.approx(200e5))
+    # the second WCONPROD changes PROD1 to BHP control at 190 bar from report step 1 on
+    assert w1.controls[1][0][:2] == (W.BHP, pytest.approx(190e5)) and len(w1.controls[1]) == 1
+    # connection factors: the given one (30 cP rm3/day/bar) and Peaceman's for the defaulted ones
+    assert w0.WI[3] == pytest.approx(30.0 * schedule.CP_RM3_PER_DAY_BAR)
+    kx, ky, dxy, dz, rw = 200 * decks.MD, 150 * decks.MD, 100.0, 10.0, 0.1
+    r0 = 0.28 * np.sqrt(np.sqrt(ky / kx) * dxy ** 2 + np.sqrt(kx / ky) * dxy ** 2) / ((ky / kx) ** 0.25 + (kx / ky) ** 0.25)
+    assert w0.WI[0] == pytest.approx(2 * np.pi * np.sqrt(kx * ky) * dz / np.log(r0 / rw), rel=1e-12)
+    assert w0.WI[5] == pytest.approx(2 * np.pi * np.sqrt(kx * ky) * dz / (np.log(r0 / rw) + 1.5), rel=1e-12)      # skin
+
+
+def test_eclipse_files_round_trip(tmp_path):
+    d, g, s = _sched()
+    st = d.initial_state(d.tables())
+    base = str(tmp_path / "CASE")
+    n = 90
+    dx, dy, dz = d._cell_sizes()
+    porv = np.zeros(n); porv[d.active] = g.pv
+    out = eclio.EclOutput(base, d.dims, g.active_index, s.start, cell_sizes=(dx, dy, dz), tops=d.array("TOPS"), porv=porv)
+    out.write_restart(0.0, st)
+    wl = s.wells(0)
+    ws = W.WellState(wl, st.p)
+    ws.qs[1] = [-1e-4, -150.0 / decks.DAY, -0.2]
+    st2 = st.copy(); st2.p += 1e5; st2.sat[:, 0] += 0.01; st2.sat[:, 1] -= 0.01
+    out.write_restart(10.0, st2)
+    out.write_summary(10.0, wl, ws, new_report_step=True)
+    # restart: two report steps, headers and solution arrays in the documented order, big-endian, blocked by 1000
+    rst = eclio.read_arrays(base + ".UNRST")
+    names = [a[0] for a in rst]
+    assert names == ["SEQNUM", "INTEHEAD", "LOGIHEAD", "DOUBHEAD", "STARTSOL", "PRESSURE", "SWAT", "SGAS", "RS", "RV", "ENDSOL"] * 2
+    ih = rst[1][2]
+    assert ih.size == 411 and ih[2] == 1 and list(ih[8:12]) == [6, 5, 3, 90] and ih[14] == 7 and list(ih[64:67]) == [1, 1, 2020]
+    assert list(rst[12][2][64:67]) == [11, 1, 2020] and rst[14][2][0] == 10.0
+    assert rst[5][1] == "REAL" and np.allclose(rst[5][2], st.p / 1e5, rtol=1e-7) and np.allclose(rst[16][2], st2.p / 1e5, rtol=1e-7)
+    assert np.allclose(rst[17][2], st2.sat[:, 0], rtol=1e-7)
+    raw = open(base + ".UNRST", "rb").read()
+    assert raw[:4] == (16).to_bytes(4, "big") and raw[4:12] == b"SEQNUM  " and raw[16:20] == b"INTE"
+    # grid: pillars and corner depths of the block-centred cells
+    eg = {a[0]: a[2] for a in eclio.read_arrays(base + ".EGRID")}
+    assert list(eg["GRIDHEAD"][:4]) == [1, 6, 5, 3] and eg["COORD"].size == 6 * 7 * 6 and eg["ZCORN"].size == 8 * 90 and eg["ACTNUM"].sum() == 90
+    z = eg["ZCORN"].reshape(3, 2, 5, 2, 6, 2)
+    assert np.all(z[0, 0] == 2500.0) and np.all(z[2, 1] == 2530.0)
+    # summary: vector list and one ministep
+    sp = {a[0]: a[2] for a in eclio.read_arrays(base + ".SMSPEC")}
+    kws, wgn = list(sp["KEYWORDS"]), list(sp["WGNAMES"])
+    assert kws[:2] == ["TIME", "YEARS"] and sp["DIMENS"][0] == len(kws) and list(sp["STARTDAT"][:3]) == [1, 1, 2020]
+    sm = eclio.read_arrays(base + ".UNSMRY")
+    assert [a[0] for a in sm] == ["SEQHDR", "MINISTEP", "PARAMS"]
+    prm = sm[2][2]
+    idx = lambda k, g: next(i for i, (a, b) in enumerate(zip(kws, wgn)) if a == k and b == g)      # noqa: E731
+    assert prm[idx("TIME", ":+:+:+:+")] == 10.0 and prm[idx("WOPR", "PROD1")] == pytest.approx(150.0, rel=1e-6)
+    assert prm[idx("FOPR", ":+:+:+:+")] == pytest.approx(150.0, rel=1e-6) and prm[idx("WBHP", "PROD2")] == pytest.approx(200.0)
