@@ -253,6 +253,7 @@ class Deck:
         g = GridData(int(act.sum()), conn, trans, pv[act], zc[act], gravity=gravity, pvtnum=reg("PVTNUM"), satnum=reg("SATNUM"),
                      dims=(nx, ny, nz), eps=eps, **more)
         g.active_index = newid
+        self._grid = g
         return g
 
     def hysteresis(self):
@@ -294,7 +295,11 @@ class Deck:
 
     # ---------------------------------------------------------------- SOLUTION
     def initial_state(self, tables):
-        """explicit PRESSURE / SWAT / SGAS / RS / RV arrays (active cells); hydrocarbon state from the saturations"""
+        """EQUIL (opmgpu/equil.py), else explicit PRESSURE / SWAT / SGAS / RS / RV arrays (active cells) with the hydrocarbon state from the
+        saturations (FlowMain.hpp:626-673 takes the same two routes)"""
+        if self.has("EQUIL") and not self.has("PRESSURE"):
+            from . import equil
+            return equil.from_deck(self, self._grid, tables)
         nx, ny, nz = self.dims
         n = nx * ny * nz
         act = self.active

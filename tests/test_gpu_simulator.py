@@ -55,3 +55,32 @@ def test_deck_with_schedule_runs_and_writes_eclipse_files(gpu_lib, oracle, tmp_p
     inj = sum(r[idx("FWIR", ":+:+:+:+")] for r in rows)
     assert dv[0] > 0 and dv[1] < 0 and inj > 0                 # water came in, oil went out
     sim.close()
+
+
+def test_equilibrated_deck_is_stationary_on_the_device(gpu_lib, tmp_path):
+    """EQUIL (opmgpu/equil.py) -> device: without wells a time step from the hydrostatic state moves almost nothing (the discrete
+    equilibrium of the two-point scheme differs from the integrated one only by the density averaging across a face), and the whole deck
+    (EQUIL + SCHEDULE) runs through the report-step driver."""
+    from test_equil import equil_deck
+    from opmgpu import deck as deckmod
+    from opmgpu.model import GpuBlackoilModel
+    path = equil_deck(tmp_path)
+    d = deckmod.read_deck(path)
+    tables, grid = d.tables(), d.grid()
+    st = d.initial_state(tables)
+    prm = capi.default_params(use_cpr=0, tolerance_mb=1e-10, tolerance_cnv=1e-6, linear_solver_reduction=1e-8, linear_solver_maxiter=200)
+    gm = GpuBlackoilModel(grid, tables, prm)
+    gm.prepareStep(1.0 * decks.DAY, st)
+    for it in range(12):
+        conv, _ = gm.nonlinearIteration(it)
+        if conv and it > 0:
+            break
+    assert conv
+    s1 = gm.getState()
+    assert np.abs(s1.p - st.p).max() < 0.05 * decks.BAR
+    assert np.abs(s1.sat - st.sat).max() < 2e-3
+    gm.close()
+    sim = Simulator(path, params=capi.default_params(use_cpr=1))
+    reps = sim.run(max_steps=1)
+    assert reps[0]["days"] == 10.0 and reps[0]["failed"] == 0
+    sim.close()
