@@ -27,6 +27,7 @@ int xcd_mode()
 }
 
 constexpr int kMaxPart = 1024;      // workgroups (= partials) of every reducing kernel
+constexpr int kBndPart = 256;       // + those of the second (cut-adjacent rows) SpMV launch when the halo exchange is overlapped
 constexpr int kCsRowParts = 8192;   // ... of the fused CPR row pass (one row per thread up to 2M rows: latency-bound, wants occupancy)
 
 // ------------------------------------------------------------------------------------------
@@ -121,8 +122,10 @@ __global__ __launch_bounds__(kBlock) void k_spmv(int xm, int nb, int nbp, const 
                                                  const S* __restrict__ w1, const int8_t* __restrict__ mask,
                                                  const SolveCtl* __restrict__ ctl, double* __restrict__ p0, double* __restrict__ p1,
                                                  const S* __restrict__ pin, const S* __restrict__ zin, int n0, S w, LowRankOp lr,
-                                                 const int8_t* __restrict__ lightmask)
+                                                 const int8_t* __restrict__ lightmask, int phase = 0, const int8_t* __restrict__ interior = nullptr)
 {
+    // phase (multi-GPU, halo exchange in flight): 1 = only the rows of `interior` (owned, no ghost neighbour: they read no halo value),
+    // 2 = only the others; 0 = all rows.  The partials of the two launches are laid side by side by the caller.
     __shared__ double sm[8];
     if (ctl && ctl->done) return;
     double acc[2] = { 0.0, 0.0 };
@@ -132,6 +135,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(int xm, int nb, int nbp, const 
         for (int ch = xcd_first(nchunks, xm); ch < xcd_end(nchunks, xm); ch += xcd_stride(xm)) {
             const int row = ch * kBlock + threadIdx.x;
             if (row >= nlight) continue;
+            if (phase && (phase == 1) != (interior[row] != 0)) continue;
             S y0, y1, y2;
             if (!lightmask || lightmask[row]) {
                 const S om = S(1) - w;
@@ -164,6 +168,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(int xm, int nb, int nbp, const 
     for (int ch = xcd_first(nchunks, xm); ch < xcd_end(nchunks, xm); ch += xcd_stride(xm)) {
         const int row = nlight + ch * kBlock + threadIdx.x;
         if (row >= nb) continue;
+        if (phase && (phase == 1) != (interior[row] != 0)) continue;
         const int sl = row >> 6, lane = row & 63;
         const int base = slice_ptr[sl], width = slice_ptr[sl + 1] - base;
         const S* __restrict__ v = val + vidx(base, lane);
@@ -777,7 +782,7 @@ void DevPlan::upload(const Plan& P, hipStream_t s)
 LinSolver::LinSolver(hipStream_t s) : stream(s)
 {
     kt.stream = s;
-    npart = kMaxPart;
+    npart = kMaxPart + kBndPart;
     partials.alloc(size_t(6) * npart + 16);
     flags.alloc(4);
     partials.zero(stream); flags.zero(stream);
@@ -799,6 +804,7 @@ LinSolver::LinSolver(hipStream_t s) : stream(s)
     if (const char* e = std::getenv("OPMGPU_AMG_LAG_COARSE")) coarse_lag = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("OPMGPU_COARSE_BLOCKS")) cs_blocks_req = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("OPMGPU_CPR_HALO_XP")) cpr_halo_xp = std::atoi(e) != 0;
+    if (const char* e = std::getenv("OPMGPU_HALO_OVERLAP")) halo_overlap = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_EMULATE_RANKS")) emulate_ranks = std::atoi(e);
     if (const char* e = std::getenv("OPMGPU_EMULATE_WHAT")) emulate_what = std::atoi(e);
     if (const char* e = std::getenv("OPMGPU_COARSE")) coarse_mode = std::atoi(e);
@@ -810,6 +816,8 @@ LinSolver::~LinSolver()
     if (h_flags) (void)hipHostFree(h_flags);
     if (ev[0]) (void)hipEventDestroy(ev[0]);
     if (ev[1]) (void)hipEventDestroy(ev[1]);
+    for (auto e : ev_halo) if (e) (void)hipEventDestroy(e);
+    if (halo_stream) (void)hipStreamDestroy(halo_stream);
 }
 
 template <> SolverWork<double>& LinSolver::work<double>() { return wd; }
@@ -1663,17 +1671,45 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
     if (cpr) cpr_prepare<S>();
     const bool closed = closed_form_level0 && emulate_ranks <= 1;
     const int8_t* lightmask = nullptr;
-    if (comm && closed) {
+    const bool overlap = comm && halo_overlap;
+    if (comm && (closed || overlap)) {
         if (light_ok_for != comm || light_ok.n != size_t(plan.nbp)) {
             light_ok.alloc(plan.nbp); light_ok.zero(stream);
             hipLaunchKernelGGL(k_light_mask, dim3(grid_for(plan.nb)), dim3(kBlock), 0, stream, plan.nb, dp.slice_ptr.p, dp.col.p, dp.rowlen.p, comm->owner_mask(), light_ok.p);
             light_ok_for = comm;
         }
-        lightmask = light_ok.p;
+        if (closed) lightmask = light_ok.p;
+    }
+    if (overlap && !halo_stream) {
+        OPMGPU_HIP(hipStreamCreateWithFlags(&halo_stream, hipStreamNonBlocking));
+        for (auto& e : ev_halo) OPMGPU_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     const S* pin_p = closed ? w.p.p : nullptr; const S* pin_r = closed ? w.r.p : nullptr;
     const S* zin_p = cpr ? w.z.p : pin_p; const S* zin_r = cpr ? w.z.p : pin_r;     // second-stage input of the last M^-1
     const int n0 = plan.level_ptr[1];
+    // v = A y with the halo exchange of y behind the rows that do not need it; returns the number of partials written
+    auto spmv_halo = [&](auto which, S* yv, S* out, const S* w1, double* q0, double* q1, const S* pin, const S* zin) -> int {
+        constexpr int ND = decltype(which)::value;
+        if (!overlap) {
+            if (comm) halo<S>(comm, yv, stream);
+            lowrank_reduce<S>(yv, (const SolveCtl*)ctl.p);
+            hipLaunchKernelGGL((k_spmv<S, ND>), dim3(gs), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p, matrix<S>(),
+                               yv, out, w1, mask, (const SolveCtl*)ctl.p, q0, q1, pin, zin, n0, S(prm.ilu_relaxation), lowrank, lightmask, 0, (const int8_t*)nullptr);
+            return gs;
+        }
+        OPMGPU_HIP(hipEventRecord(ev_halo[0], stream));
+        OPMGPU_HIP(hipStreamWaitEvent(halo_stream, ev_halo[0], 0));
+        halo<S>(comm, yv, halo_stream);
+        OPMGPU_HIP(hipEventRecord(ev_halo[1], halo_stream));
+        lowrank_reduce<S>(yv, (const SolveCtl*)ctl.p);                 // wells live on one rank: their perforated cells are owned rows
+        hipLaunchKernelGGL((k_spmv<S, ND>), dim3(gs), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p, matrix<S>(),
+                           yv, out, w1, mask, (const SolveCtl*)ctl.p, q0, q1, pin, zin, n0, S(prm.ilu_relaxation), lowrank, lightmask, 1, (const int8_t*)light_ok.p);
+        OPMGPU_HIP(hipStreamWaitEvent(stream, ev_halo[1], 0));
+        hipLaunchKernelGGL((k_spmv<S, ND>), dim3(kBndPart), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p, matrix<S>(),
+                           yv, out, w1, mask, (const SolveCtl*)ctl.p, q0 + gs, q1 ? q1 + gs : (double*)nullptr, pin, zin, n0, S(prm.ilu_relaxation), lowrank, lightmask, 2,
+                           (const int8_t*)light_ok.p);
+        return gs + kBndPart;
+    };
     double* P_h = partials.p, *P_n1 = P_h + npart, *P_tr = P_n1 + npart, *P_tt = P_tr + npart, *P_n2 = P_tt + npart, *P_rho = P_n2 + npart;
     double* red = P_rho + npart;                               // 8 all-reduced scalars (multi-GPU)
     // (multi-GPU) collapse partial arrays of np entries into red[slot..] and all-reduce them; consumers then read 1 entry
@@ -1707,13 +1743,10 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
                            w.r.p, w.v.p, w.p.p);
         kt.end(KT_VECTOR, kt_a);
         if (cpr) cpr_apply<S>(w.p.p, w.y.p, prm.ilu_relaxation, d_ctl); else ilu_apply<S>(w.p.p, w.y.p, prm.ilu_relaxation, d_ctl);
-        if (comm) halo<S>(comm, w.y.p, stream);
         kt_a = kt.begin();
-        lowrank_reduce<S>(w.y.p, d_ctl);
-        hipLaunchKernelGGL((k_spmv<S, 1>), dim3(gs), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p, matrix<S>(),
-                           w.y.p, w.v.p, w.rt.p, mask, (const SolveCtl*)d_ctl, P_h, (double*)nullptr, pin_p, zin_p, n0, S(prm.ilu_relaxation), lowrank, lightmask);
+        const int np_spmv1 = spmv_halo(std::integral_constant<int, 1>(), w.y.p, w.v.p, w.rt.p, P_h, (double*)nullptr, pin_p, zin_p);
         kt.end(KT_SPMV1, kt_a);
-        double* a_h = P_h; int np_h = gs; none = nullptr;
+        double* a_h = P_h; int np_h = np_spmv1; none = nullptr;
         bridge(a_h, none, np_h, 1);
         kt_a = kt.begin();
         hipLaunchKernelGGL((k_update_xr1<S>), dim3(gv), dim3(kBlock), 0, stream, n, j, eps, d_ctl, h_ctl_dev, (const double*)a_h, np_h, w.y.p, w.v.p,
@@ -1722,13 +1755,10 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
         double* a_n1 = P_n1; int np_n1 = gv; none = nullptr;
         bridge(a_n1, none, np_n1, 2, true);      // ||r||^2 of the half step is consumed by k_update_xr2: reduced together with <t,r>, <t,t> (slots 2..4)
         if (cpr) cpr_apply<S>(w.r.p, w.y.p, prm.ilu_relaxation, d_ctl); else ilu_apply<S>(w.r.p, w.y.p, prm.ilu_relaxation, d_ctl);
-        if (comm) halo<S>(comm, w.y.p, stream);
         kt_a = kt.begin();
-        lowrank_reduce<S>(w.y.p, d_ctl);
-        hipLaunchKernelGGL((k_spmv<S, 2>), dim3(gs), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p, matrix<S>(),
-                           w.y.p, w.t.p, w.r.p, mask, (const SolveCtl*)d_ctl, P_tr, P_tt, pin_r, zin_r, n0, S(prm.ilu_relaxation), lowrank, lightmask);
+        const int np_spmv2 = spmv_halo(std::integral_constant<int, 2>(), w.y.p, w.t.p, w.r.p, P_tr, P_tt, pin_r, zin_r);
         kt.end(KT_SPMV2, kt_a);
-        double* a_tr = P_tr; double* a_tt = P_tt; int np_t = gs;
+        double* a_tr = P_tr; double* a_tt = P_tt; int np_t = np_spmv2;
         bridge(a_tr, a_tt, np_t, 3);
         kt_a = kt.begin();
         hipLaunchKernelGGL((k_update_xr2<S>), dim3(gv), dim3(kBlock), 0, stream, n, j, d_ctl, h_ctl_dev, (const double*)a_n1, (const double*)a_tr,

@@ -203,6 +203,11 @@ public:
     int cpr_weight_mode = 0;        // 0 = formEllipticSystem's 0/1 dominance weights (reference); 1 = quasi-IMPES (A/B: OPMGPU_CPR_WEIGHTS=1)
     bool cpr_speculate = false;     // CPR: enqueue the next iteration before the convergence result is known (A/B: OPMGPU_CPR_SPECULATE=1)
     hipEvent_t ev[2] = { nullptr, nullptr };
+    // multi-GPU: the halo exchange of the SpMV input runs on its own stream while the rows without a ghost neighbour are multiplied
+    // (k_spmv phase 1); the rows next to a cut follow the exchange (phase 2).  A/B: OPMGPU_HALO_OVERLAP=0 serialises them on `stream`.
+    bool halo_overlap = true;
+    hipStream_t halo_stream = nullptr;
+    hipEvent_t ev_halo[2] = { nullptr, nullptr };
 
 private:
     SolverWork<double> wd;
