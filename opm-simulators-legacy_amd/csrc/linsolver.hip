@@ -394,10 +394,16 @@ __device__ __forceinline__ void publish(const SolveCtl* ctl, SolveCtl* hst)
 //   ILU, k_spmv<2>  : y = M^-1 r ; t = A y ; partials <t,r>, <t,t>
 //   k_update_xr2(j) : [test ||r||^2 of the first half step]  omega ; x += omega y ; r -= omega t ; partials ||r||^2, <rt,r>
 // Every workgroup derives the scalars from the partial arrays itself; workgroup 0 records them.
+// Restricted residuals of the subdomain coarse space carried along the BiCGStab recurrences (LinSolver::cs_recur): C(x)[q] = sum over
+// the rows of coarse unknown q of (CPR weights . x) is linear in x, so with the GLOBAL C(v), C(t) of the two products of an iteration
+//   C(r) -= alpha C(v) ; C(r) -= omega C(t) ; C(p) = C(r) + beta (C(p) - omega C(v))
+// hold exactly what restricting r and p would give.  Workgroup 0 of the vector kernels advances them (ns <= 64 <= kBlock).
+struct CsRec { double* Cp; double* Cr; const double* Cv; const double* Ct; const double* C0; int ns; };
+
 template <class S>
 __global__ __launch_bounds__(kBlock) void k_update_p(long n, int j, double eps, SolveCtl* __restrict__ ctl, SolveCtl* __restrict__ hst, const double* __restrict__ p_n2,
                                                      const double* __restrict__ p_rho, int np, const S* __restrict__ r,
-                                                     const S* __restrict__ v, S* __restrict__ p)
+                                                     const S* __restrict__ v, S* __restrict__ p, CsRec cs)
 {
     __shared__ double sm[12];
     if (ctl->done) return;
@@ -410,6 +416,7 @@ __global__ __launch_bounds__(kBlock) void k_update_p(long n, int j, double eps, 
         if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->norm0_2 = norm2; ctl->norm2 = norm2; ctl->rho[1] = rho_new; }
         if (!(norm2 == norm2)) { if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->flag = 2; ctl->decided = j; ctl->done = 1; publish(ctl, hst); } return; }
         if (norm2 < 1e-60) { if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->iters = 0; ctl->decided = j; ctl->done = 1; publish(ctl, hst); } return; }
+        if (blockIdx.x == 0 && int(threadIdx.x) < cs.ns) { const double c = cs.C0[threadIdx.x]; cs.Cr[threadIdx.x] = c; cs.Cp[threadIdx.x] = c; }
         for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) p[i] = r[i];
         return;
     }
@@ -424,14 +431,16 @@ __global__ __launch_bounds__(kBlock) void k_update_p(long n, int j, double eps, 
         return;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->rho[j & 1] = rho_new; ctl->norm2 = norm2; }
-    const S beta = S((rho_new / rho_old) * (alpha / omega)), om = S(omega);
+    const double beta_d = (rho_new / rho_old) * (alpha / omega);
+    const S beta = S(beta_d), om = S(omega);
+    if (blockIdx.x == 0 && int(threadIdx.x) < cs.ns) cs.Cp[threadIdx.x] = cs.Cr[threadIdx.x] + beta_d * (cs.Cp[threadIdx.x] - omega * cs.Cv[threadIdx.x]);
     for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) p[i] = (p[i] - om * v[i]) * beta + r[i];
 }
 
 template <class S>
 __global__ __launch_bounds__(kBlock) void k_update_xr1(long n, int j, double eps, SolveCtl* __restrict__ ctl, SolveCtl* __restrict__ hst, const double* __restrict__ p_h, int np,
                                                        const S* __restrict__ y, const S* __restrict__ q, S* __restrict__ x, S* __restrict__ r,
-                                                       double* __restrict__ p_n1)
+                                                       double* __restrict__ p_n1, CsRec cs)
 {
     __shared__ double sm[12];
     if (ctl->done) return;
@@ -445,6 +454,7 @@ __global__ __launch_bounds__(kBlock) void k_update_xr1(long n, int j, double eps
     }
     const double alpha = ctl->rho[j & 1] / h;
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl->alpha = alpha;
+    if (blockIdx.x == 0 && int(threadIdx.x) < cs.ns) cs.Cr[threadIdx.x] -= alpha * cs.Cv[threadIdx.x];
     const S a = S(alpha);
     double acc[1] = { 0.0 };
     for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) {
@@ -461,7 +471,7 @@ template <class S>
 __global__ __launch_bounds__(kBlock) void k_update_xr2(long n, int j, SolveCtl* __restrict__ ctl, SolveCtl* __restrict__ hst, const double* __restrict__ p_n1,
                                                        const double* __restrict__ p_tr, const double* __restrict__ p_tt, int np_v, int np_s,
                                                        const S* __restrict__ y, const S* __restrict__ q, const S* __restrict__ rt,
-                                                       S* __restrict__ x, S* __restrict__ r, double* __restrict__ p_n2, double* __restrict__ p_rho)
+                                                       S* __restrict__ x, S* __restrict__ r, double* __restrict__ p_n2, double* __restrict__ p_rho, CsRec cs)
 {
     __shared__ double sm[12];
     if (ctl->done) return;
@@ -474,6 +484,7 @@ __global__ __launch_bounds__(kBlock) void k_update_xr2(long n, int j, SolveCtl* 
     { const double* const arr[2] = { p_tr, p_tt }; reduce_partials<2>(arr, np_s, s2, sm); }
     const double omega = s2[0] / s2[1];
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl->omega = omega;
+    if (blockIdx.x == 0 && int(threadIdx.x) < cs.ns) cs.Cr[threadIdx.x] -= omega * cs.Ct[threadIdx.x];
     const S a = S(omega);
     double acc[2] = { 0.0, 0.0 };
     for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) {
@@ -530,6 +541,51 @@ __global__ __launch_bounds__(kBlock) void k_sum_partials(const double* __restric
     double s[2];
     reduce_partials<2>(arr, np, s, sm);
     if (threadIdx.x == 0) { out[0] = s[0]; if (NV == 2) out[1] = s[1]; }
+}
+
+// this rank's block sums of (CPR weights . d): parts[u * gridDim.x + workgroup] for its coarse unknowns u < m (blk: block of a row,
+// -1 = not owned; without blocks the owner mask decides and m = 1)
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_cs_wdot(int nb, int nbp, const S* __restrict__ d, const S* __restrict__ w, const int8_t* __restrict__ owned,
+                                                    const int8_t* __restrict__ blk, int m, double* __restrict__ parts, const SolveCtl* __restrict__ ctl)
+{
+    __shared__ double sm[32];
+    if (ctl && ctl->done) return;
+    double acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < nb; i += long(gridDim.x) * kBlock) {
+        const int b = blk ? int(blk[i]) : ((!owned || owned[i]) ? 0 : -1);
+        if (b < 0) continue;
+        const S bs = w[i] * d[i] + w[nbp + i] * d[nbp + i] + w[2 * long(nbp) + i] * d[2 * long(nbp) + i];      // as k_cpr_sum_eqs forms it
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] += (u == b) ? double(bs) : 0.0;
+    }
+    block_sum<8>(acc, sm);
+    if (threadIdx.x == 0) for (int u = 0; u < m; ++u) parts[long(u) * gridDim.x + blockIdx.x] = acc[u];
+}
+// bridge with the coarse-space sums: out[0..NV) as k_sum_partials, out[NV + q] = this rank's sum for coarse unknown q (its own slots
+// mine*m .. mine*m + m - 1), zero for the others' -- the all-reduce that follows then delivers every rank's
+template <int NV>
+__global__ __launch_bounds__(kBlock) void k_bridge_cs(const double* __restrict__ a0, const double* __restrict__ a1, int np, const double* __restrict__ cparts, int ncp,
+                                                      int ns, int m, int mine, double* __restrict__ out)
+{
+    __shared__ double sm[12];
+    __shared__ double tot[8];
+    const double* const arr[2] = { a0, a1 ? a1 : a0 };
+    double s[2];
+    reduce_partials<2>(arr, np, s, sm);
+    if (threadIdx.x == 0) { out[0] = s[0]; if (NV == 2) out[1] = s[1]; }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int b = 0; b < m; ++b) {
+        double v = 0.0;
+        for (int i = threadIdx.x; i < ncp; i += kBlock) v += cparts[long(b) * ncp + i];
+        const double sw = wave_sum(v);
+        __syncthreads();
+        if (lane == 0) sm[wv] = sw;
+        __syncthreads();
+        if (threadIdx.x == 0) tot[b] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    }
+    __syncthreads();
+    if (int(threadIdx.x) < ns) { const int b = int(threadIdx.x) - mine * m; out[NV + threadIdx.x] = (b >= 0 && b < m) ? tot[b] : 0.0; }
 }
 
 template <class S>
@@ -783,7 +839,7 @@ LinSolver::LinSolver(hipStream_t s) : stream(s)
 {
     kt.stream = s;
     npart = kMaxPart + kBndPart;
-    partials.alloc(size_t(6) * npart + 16);
+    partials.alloc(size_t(6) * npart + 16 + 3 * 64);       // + three coarse-space vectors riding on the scalar all-reduces (cs_recur)
     flags.alloc(4);
     partials.zero(stream); flags.zero(stream);
     OPMGPU_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_ctl), sizeof(SolveCtl), hipHostMallocMapped));
@@ -805,6 +861,7 @@ LinSolver::LinSolver(hipStream_t s) : stream(s)
     if (const char* e = std::getenv("OPMGPU_COARSE_BLOCKS")) cs_blocks_req = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("OPMGPU_CPR_HALO_XP")) cpr_halo_xp = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_HALO_OVERLAP")) halo_overlap = std::atoi(e) != 0;
+    if (const char* e = std::getenv("OPMGPU_CS_RECUR")) cs_recur = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_EMULATE_RANKS")) emulate_ranks = std::atoi(e);
     if (const char* e = std::getenv("OPMGPU_EMULATE_WHAT")) emulate_what = std::atoi(e);
     if (const char* e = std::getenv("OPMGPU_COARSE")) coarse_mode = std::atoi(e);
@@ -1558,7 +1615,7 @@ template <class S> void LinSolver::cpr_prepare()
 void LinSolver::drop_hierarchies() { wd.amg.reset(); wf.amg.reset(); }
 
 // M^-1 d = [x_p;0;0] + ILU0^-1 (d - A [x_p;0;0]),  x_p = Vcycle(sum of the equations of d)
-template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, const SolveCtl* ctl)
+template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, const SolveCtl* ctl, const double* cr_given)
 {
     SolverWork<S>& w = work<S>();
     AmgLevel<S>& L0 = *w.amg->levels[0];
@@ -1581,7 +1638,8 @@ template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, con
         const int ns = coarse_nsub;
         double* inv = cs_buf.p + ns * ns; double* cr = inv + ns * ns;
         const bool emulated = !comm && emulate_ranks > 1;
-        if (!emulated) {
+        if (cr_given) cr = const_cast<double*>(cr_given);       // the caller's recurrences hold the all-reduced restriction of d already
+        else if (!emulated) {
             const int gp = fused_rsum ? g : std::min(grid_for(plan.nb), kMaxPart);
             double* parts = cs_parts;
             if (cs_m > 1) {
@@ -1715,14 +1773,43 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
     // (multi-GPU) collapse partial arrays of np entries into red[slot..] and all-reduce them; consumers then read 1 entry
     // defer > 0: no all-reduce now, the NEXT bridge (whose slots follow this one's) reduces `defer` more values in the same call
     int deferred = 0;
-    auto bridge = [&](double*& a0, double*& a1, int& np, int slot, bool defer = false) {
+    // coarse-space restriction by recurrence (see CsRec): active for the real multi-rank coarse space only
+    // The recurrences run in double next to vectors of precision S: every x -= a y of the vectors leaves a rounding error of eps_S |r_k| in
+    // the REAL restricted residual that the recurrence does not see, so once ||r|| has dropped by about sqrt(eps_S) the carried value is
+    // noise and the correction it drives stalls the iteration (seen: float solve asked for 1e-10).  The host reads ||r||^2 after every
+    // CPR iteration anyway (wait_tick): below cs_floor the applications go back to restricting and all-reducing themselves.
+    const bool cs_rec = cpr && comm && cs_recur && !cpr_speculate && coarse_nsub >= 1 && coarse_nsub <= 64;
+    const double cs_floor = sizeof(S) == 4 ? 1e-3 : 1e-11;
+    bool cs_live = cs_rec;
+    const int ns = cs_rec ? coarse_nsub : 0;
+    // position of all-reduce slot s in `red`: the coarse-space vectors follow slot 0 (initial C(r)), slot 1 (C(v)) and slot 4 (C(t))
+    auto pos = [&](int slot) { return slot + (slot >= 1 ? ns : 0) + (slot >= 2 ? ns : 0) + (slot >= 5 ? ns : 0); };
+    CsRec csr = { nullptr, nullptr, nullptr, nullptr, nullptr, 0 };
+    double* cs_wparts = nullptr; int cs_gp = 0;
+    if (cs_rec) {
+        if (cs_state.n < size_t(2) * ns) cs_state.alloc(size_t(2) * ns);
+        csr.Cp = cs_state.p; csr.Cr = cs_state.p + ns; csr.ns = ns;
+        csr.C0 = red + pos(0) + 1; csr.Cv = red + pos(1) + 1; csr.Ct = red + pos(4) + 1;
+        cs_wparts = cs_buf.p + size_t(2) * ns * ns + ns;       // the scratch of cpr_apply's fused restriction: free between applications
+        cs_gp = std::min(grid_for(plan.nb), kMaxPart);
+    }
+    // cs_vec (cs_rec only): the vector whose restriction is appended behind the scalars of this bridge
+    auto bridge = [&](double*& a0, double*& a1, int& np, int slot, bool defer = false, const S* cs_vec = nullptr) {
         if (!comm) return;
-        if (a1) hipLaunchKernelGGL((k_sum_partials<2>), dim3(1), dim3(kBlock), 0, stream, a0, a1, np, red + slot);
-        else hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(kBlock), 0, stream, a0, (const double*)nullptr, np, red + slot);
+        double* out = red + pos(slot);
         const int nv = a1 ? 2 : 1;
+        int extra = 0;
+        if (cs_live && cs_vec) {
+            hipLaunchKernelGGL((k_cs_wdot<S>), dim3(cs_gp), dim3(kBlock), 0, stream, plan.nb, plan.nbp, cs_vec, (const S*)w.cprw.p, cs_m > 1 ? (const int8_t*)nullptr : mask,
+                               cs_m > 1 ? (const int8_t*)cs_blk.p : (const int8_t*)nullptr, cs_m, cs_wparts, (const SolveCtl*)nullptr);
+            if (a1) hipLaunchKernelGGL((k_bridge_cs<2>), dim3(1), dim3(kBlock), 0, stream, a0, a1, np, (const double*)cs_wparts, cs_gp, ns, cs_m, comm->my_rank(), out);
+            else hipLaunchKernelGGL((k_bridge_cs<1>), dim3(1), dim3(kBlock), 0, stream, a0, (const double*)nullptr, np, (const double*)cs_wparts, cs_gp, ns, cs_m, comm->my_rank(), out);
+            extra = ns;
+        } else if (a1) hipLaunchKernelGGL((k_sum_partials<2>), dim3(1), dim3(kBlock), 0, stream, a0, a1, np, out);
+        else hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(kBlock), 0, stream, a0, (const double*)nullptr, np, out);
         if (defer) deferred += nv;
-        else { comm->allreduce_sum(red + slot - deferred, nv + deferred, stream); deferred = 0; }
-        a0 = red + slot; if (a1) a1 = red + slot + 1; np = 1;
+        else { comm->allreduce_sum(out - deferred, nv + deferred + extra, stream); deferred = 0; }
+        a0 = out; if (a1) a1 = out + 1; np = 1;
     };
     // x = 0, r = rt = b, p = v = 0
     w.x.zero(stream);
@@ -1732,37 +1819,39 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
     hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(1), 0, stream, d_ctl, h_ctl_dev, prm.linear_solver_reduction);
     hipLaunchKernelGGL((k_dot<S>), dim3(gv), dim3(kBlock), 0, stream, n, w.r.p, w.r.p, P_n2);
     double* a_n2 = P_n2; double* a_rho = P_n2; double* none = nullptr; int np_n2 = gv;
-    bridge(a_n2, none, np_n2, 0); a_rho = a_n2;
+    bridge(a_n2, none, np_n2, 0, false, w.r.p); a_rho = a_n2;
     hipLaunchKernelGGL(k_ctl_thresh, dim3(1), dim3(kBlock), 0, stream, d_ctl, prm.linear_solver_reduction, (const double*)a_n2, np_n2);
     int j = 1, last = 0, target = 0;
     bool stop = false, checked = false;      // checked: the last enqueued iteration has been tested and the status block is current
     for (; j <= maxit && !stop; ++j) {
         checked = false;
         hipEvent_t kt_a = kt.begin();
+        const CsRec csr_off = { nullptr, nullptr, nullptr, nullptr, nullptr, 0 };
+        const CsRec csr_it = cs_live ? csr : csr_off;
         hipLaunchKernelGGL((k_update_p<S>), dim3(gv), dim3(kBlock), 0, stream, n, j, eps, d_ctl, h_ctl_dev, (const double*)a_n2, (const double*)a_rho, np_n2,
-                           w.r.p, w.v.p, w.p.p);
+                           w.r.p, w.v.p, w.p.p, csr_it);
         kt.end(KT_VECTOR, kt_a);
-        if (cpr) cpr_apply<S>(w.p.p, w.y.p, prm.ilu_relaxation, d_ctl); else ilu_apply<S>(w.p.p, w.y.p, prm.ilu_relaxation, d_ctl);
+        if (cpr) cpr_apply<S>(w.p.p, w.y.p, prm.ilu_relaxation, d_ctl, csr_it.Cp); else ilu_apply<S>(w.p.p, w.y.p, prm.ilu_relaxation, d_ctl);
         kt_a = kt.begin();
         const int np_spmv1 = spmv_halo(std::integral_constant<int, 1>(), w.y.p, w.v.p, w.rt.p, P_h, (double*)nullptr, pin_p, zin_p);
         kt.end(KT_SPMV1, kt_a);
         double* a_h = P_h; int np_h = np_spmv1; none = nullptr;
-        bridge(a_h, none, np_h, 1);
+        bridge(a_h, none, np_h, 1, false, w.v.p);
         kt_a = kt.begin();
         hipLaunchKernelGGL((k_update_xr1<S>), dim3(gv), dim3(kBlock), 0, stream, n, j, eps, d_ctl, h_ctl_dev, (const double*)a_h, np_h, w.y.p, w.v.p,
-                           w.x.p, w.r.p, P_n1);
+                           w.x.p, w.r.p, P_n1, csr_it);
         kt.end(KT_VECTOR, kt_a);
         double* a_n1 = P_n1; int np_n1 = gv; none = nullptr;
         bridge(a_n1, none, np_n1, 2, true);      // ||r||^2 of the half step is consumed by k_update_xr2: reduced together with <t,r>, <t,t> (slots 2..4)
-        if (cpr) cpr_apply<S>(w.r.p, w.y.p, prm.ilu_relaxation, d_ctl); else ilu_apply<S>(w.r.p, w.y.p, prm.ilu_relaxation, d_ctl);
+        if (cpr) cpr_apply<S>(w.r.p, w.y.p, prm.ilu_relaxation, d_ctl, csr_it.Cr); else ilu_apply<S>(w.r.p, w.y.p, prm.ilu_relaxation, d_ctl);
         kt_a = kt.begin();
         const int np_spmv2 = spmv_halo(std::integral_constant<int, 2>(), w.y.p, w.t.p, w.r.p, P_tr, P_tt, pin_r, zin_r);
         kt.end(KT_SPMV2, kt_a);
         double* a_tr = P_tr; double* a_tt = P_tt; int np_t = np_spmv2;
-        bridge(a_tr, a_tt, np_t, 3);
+        bridge(a_tr, a_tt, np_t, 3, false, w.t.p);
         kt_a = kt.begin();
         hipLaunchKernelGGL((k_update_xr2<S>), dim3(gv), dim3(kBlock), 0, stream, n, j, d_ctl, h_ctl_dev, (const double*)a_n1, (const double*)a_tr,
-                           (const double*)a_tt, np_n1, np_t, w.y.p, w.t.p, w.rt.p, w.x.p, w.r.p, P_n2, P_rho);
+                           (const double*)a_tt, np_n1, np_t, w.y.p, w.t.p, w.rt.p, w.x.p, w.r.p, P_n2, P_rho, csr_it);
         kt.end(KT_VECTOR, kt_a);
         a_n2 = P_n2; a_rho = P_rho; np_n2 = gv;
         bridge(a_n2, a_rho, np_n2, 5);
@@ -1774,6 +1863,7 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
             hipLaunchKernelGGL(k_final_check, dim3(1), dim3(kBlock), 0, stream, j, d_ctl, h_ctl_dev, (const double*)a_n2, np_n2, poll_status ? h_tick_dev : (int*)nullptr, tick);
             wait_tick(tick);
             if (h_ctl->done) stop = true;
+            if (cs_live && !(h_ctl->norm2 > cs_floor * cs_floor * h_ctl->norm0_2)) cs_live = false;      // the same decision on every rank: the norms are collective
             checked = true;
             continue;
         }
@@ -2106,7 +2196,7 @@ double LinSolver::time_kernel(int kernel, int reps, int single_precision)
     template const S* LinSolver::pre_matrix<S>();                                        \
     template void LinSolver::coarse_setup<S>(bool);                                      \
     template void LinSolver::coarse_begin<S>();                                          \
-    template void LinSolver::cpr_apply<S>(const S*, S*, double, const SolveCtl*);        \
+    template void LinSolver::cpr_apply<S>(const S*, S*, double, const SolveCtl*, const double*);        \
     template SolveResult LinSolver::bicgstab<S>(const opmgpu_params&);                   \
     template SolveResult LinSolver::gmres<S>(const opmgpu_params&);                      \
     template void LinSolver::vec_from_host<S>(const double*, int, S*);                   \

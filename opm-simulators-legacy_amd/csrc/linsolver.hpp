@@ -140,7 +140,7 @@ public:
     // CPR (solver_approach=cpr): build / refresh the pressure AMG for the current matrix; two-stage apply
     template <class S> void cpr_prepare();
     void drop_hierarchies();            // the wells changed: the bordered pressure hierarchy is rebuilt from the next matrix
-    template <class S> void cpr_apply(const S* d, S* v, double relax, const SolveCtl* ctl);
+    template <class S> void cpr_apply(const S* d, S* v, double relax, const SolveCtl* ctl, const double* cr_given = nullptr);
     // x0 = 0; rhs in work<S>().b; solution in work<S>().x
     template <class S> SolveResult bicgstab(const opmgpu_params& prm);
     template <class S> SolveResult gmres(const opmgpu_params& prm);      // newton_use_gmres: restarted, left-preconditioned (single GPU)
@@ -206,6 +206,11 @@ public:
     // multi-GPU: the halo exchange of the SpMV input runs on its own stream while the rows without a ghost neighbour are multiplied
     // (k_spmv phase 1); the rows next to a cut follow the exchange (phase 2).  A/B: OPMGPU_HALO_OVERLAP=0 serialises them on `stream`.
     bool halo_overlap = true;
+    // multi-GPU CPR with the subdomain coarse space: the restricted residual of the vector a preconditioner application starts from is
+    // carried by the BiCGStab recurrences (it is linear in the vector), so only <W_b, A y> has to be summed over the ranks -- together
+    // with the scalar products the iteration all-reduces anyway: 3 all-reduces per iteration instead of 5.  A/B: OPMGPU_CS_RECUR=0.
+    bool cs_recur = true;
+    DevArray<double> cs_state;     // [2 ns]: restricted residual of p, of r
     hipStream_t halo_stream = nullptr;
     hipEvent_t ev_halo[2] = { nullptr, nullptr };
 

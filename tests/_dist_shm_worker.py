@@ -65,6 +65,18 @@ def run(cfg, rank, world, uid, out):
         from opmgpu import timestepping as ts
         from opmgpu.model import NonlinearSolver
         model.setState(lst)
+        if os.environ.get("OPMGPU_TEST_TRACE"):         # diagnostic: every Newton iteration's outcome on stderr
+            inner = model.nonlinearIteration
+
+            def traced(it, **kw):
+                try:
+                    r = inner(it, **kw)
+                except Exception as e:
+                    print("[trace] it %d raised %r" % (it, e), file=sys.stderr, flush=True)
+                    raise
+                print("[trace] it %d -> %s" % (it, r), file=sys.stderr, flush=True)
+                return r
+            model.nonlinearIteration = traced
         ats = ts.AdaptiveTimeStepping(initial_timestep_days=cfg["ats"]["first_days"])
         rep = ats.step(0.0, cfg["ats"]["report_days"] * decks.DAY, NonlinearSolver(max_iter=cfg["ats"]["max_iter"]), model)
         assert rep["converged"]

@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -79,8 +80,14 @@ struct Shm {
         }
         return true;
     }
+    long n_allreduce = 0, n_exchange = 0;
     ~Shm()
     {
+        // OPMGPU_SHM_STATS=<path prefix>: the number of collective calls of this rank (tests count the all-reduces of an iteration)
+        if (const char* e = std::getenv("OPMGPU_SHM_STATS")) {
+            const std::string f = std::string(e) + "." + std::to_string(rank);
+            if (FILE* fp = std::fopen(f.c_str(), "w")) { std::fprintf(fp, "%ld %ld\n", n_allreduce, n_exchange); std::fclose(fp); }
+        }
         if (hdr) munmap(hdr, bytes);
         if (rank == 0 && !name.empty()) (void)shm_unlink(name.c_str());
     }
@@ -90,6 +97,7 @@ int shm_allreduce(void* self, double* d, int n, int is_max, void* stream)
 {
     Shm& m = *static_cast<Shm*>(self);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    ++m.n_allreduce;
     if (n > kRedDoubles) return 1;
     std::vector<double> h(n);
     if (hipMemcpyAsync(h.data(), d, size_t(n) * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return 1;
@@ -110,6 +118,7 @@ int shm_exchange(void* self, int nq, const int32_t* neigh, const void* sbuf, con
 {
     Shm& m = *static_cast<Shm*>(self);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    ++m.n_exchange;
     int64_t stot = 0, rtot = 0;
     for (int q = 0; q < nq; ++q) { stot = std::max(stot, soff[q] + scount[q]); rtot = std::max(rtot, roff[q] + rcount[q]); }
     if (size_t(stot) > kMailBytes) return 1;

@@ -20,9 +20,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "_dist_shm_worker.py")
 
 
-def _launch(cfg, world, tmp):
+def _launch(cfg, world, tmp, extra_env=None):
     env = dict(os.environ)
     env["OPMGPU_COMM_TRANSPORT"] = "shm"
+    env.update(extra_env or {})
     env["PYTHONPATH"] = os.path.join(ROOT, "opm-simulators-legacy_amd") + os.pathsep + env.get("PYTHONPATH", "")
     uid = "-"
     if world > 1:
@@ -45,7 +46,7 @@ def _launch(cfg, world, tmp):
             raise
         logs.append(o)
     for r, p in enumerate(procs):
-        assert p.returncode == 0, "rank %d of %d failed:\n%s" % (r, world, logs[r][-3000:])
+        assert p.returncode == 0, "rank %d of %d failed:\n%s" % (r, world, logs[r][-8000:])
     parts = [np.load(o) for o in outs]
     n = sum(int(q["ids"].size) for q in parts)
     p, sat, hc = np.zeros(n), np.zeros((n, 3)), np.zeros(n, np.int8)
@@ -100,3 +101,26 @@ def test_decomposed_runs_walk_the_single_domain_newton_path(gpu_lib, case):
             assert np.abs(got[0] - ref[0]).max() <= tol * np.abs(ref[0]).max(), (case, world)
             assert np.abs(got[1] - ref[1]).max() <= tol, (case, world)
             assert np.array_equal(got[3][:, 0], ref[3][:, 0]), (case, world)      # same convergence decisions
+
+
+def test_coarse_space_restrictions_ride_on_the_scalar_all_reduces(gpu_lib):
+    """CPR with the subdomain coarse space, 4 ranks: the restricted residuals carried by the BiCGStab recurrences (LinSolver::cs_recur)
+    give the iteration counts of the directly restricted ones and save the two coarse-space all-reduces of every iteration
+    (5 -> 3 per iteration; counted by the test transport)."""
+    cfg = dict(nx=10, ny=9, nz=16, sigma=0.7, seed=21, perturb=0.004, dt_days=3.0, newton=4, rate=30.0 / 86400.0, **CASES["cpr"])
+    res = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for recur in (1, 0):
+            stats = os.path.join(tmp, "stats%d" % recur)
+            got = _launch(cfg, 4, tmp, {"OPMGPU_CS_RECUR": str(recur), "OPMGPU_SHM_STATS": stats})
+            calls = [tuple(int(x) for x in open("%s.%d" % (stats, r)).read().split()) for r in range(4)]
+            assert len(set(calls)) == 1                               # every rank made the same collective calls
+            res[recur] = (got, calls[0])
+    (g1, c1), (g0, c0) = res[1], res[0]
+    its1, its0 = g1[3][:, 1], g0[3][:, 1]
+    assert np.abs(its1 - its0).max() <= 1, (its1.tolist(), its0.tolist())
+    assert np.abs(g1[0] - g0[0]).max() <= 1e-6 * np.abs(g0[0]).max()
+    lin = int(its0.sum())
+    # two all-reduces less per BiCGStab iteration (the iteration that converges at its half step has made one of them only)
+    assert c0[0] - c1[0] >= 2 * lin - 2 * len(its0) and c0[0] - c1[0] <= 2 * lin + 2 * len(its0), (c0, c1, lin)
+    assert c1[1] == c0[1] or abs(c1[1] - c0[1]) <= 4 * np.abs(its1 - its0).sum()     # the halo exchanges are untouched
