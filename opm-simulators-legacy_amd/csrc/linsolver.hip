@@ -746,7 +746,8 @@ __global__ __launch_bounds__(kBlock) void k_cpr_border(LowRankOp lr, int nbp, co
 template <class S>
 __global__ __launch_bounds__(kBlock) void k_cpr_presidual(int xm, int nb, int nbp, const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
                                                           const S* __restrict__ val, const S* __restrict__ d, const S* __restrict__ xp,
-                                                          S* __restrict__ z, const int8_t* __restrict__ mask, const SolveCtl* __restrict__ ctl)
+                                                          S* __restrict__ z, const int8_t* __restrict__ mask, const SolveCtl* __restrict__ ctl,
+                                                          int phase = 0, const int8_t* __restrict__ interior = nullptr)
 {
     if (ctl && ctl->done) return;
     const int nchunks = (nb + kBlock - 1) / kBlock;
@@ -754,6 +755,7 @@ __global__ __launch_bounds__(kBlock) void k_cpr_presidual(int xm, int nb, int nb
     if (ch >= xcd_end(nchunks, xm)) return;
     const int row = ch * kBlock + threadIdx.x;
     if (row >= nb) return;
+    if (phase && (phase == 1) != (interior[row] != 0)) return;          // halo exchange of x_p in flight: see k_spmv
     const int base = slice_ptr[row >> 6], width = slice_ptr[(row >> 6) + 1] - base, lane = row & 63;
     const S* __restrict__ v = val + vidx(base, lane);
     const int32_t* __restrict__ c = col + long(base) * 64 + lane;
@@ -1667,23 +1669,41 @@ template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, con
     kt.end(KT_VCYCLE, kt_a);
     kt_a = kt.begin();
     const S* xp = L0.x.p;
+    // multi-GPU: the AMG is rank-local (additive Schwarz: ghost rows are identity rows); the owners' x_p is copied to the
+    // ghosts before the full-system residual so that stage 2 sees the neighbours' pressure correction on the rows next to the
+    // cut.  Costs two halo exchanges per BiCGStab iteration; without it (OPMGPU_CPR_HALO_XP=0) the one-rank self-halo deck,
+    // where half of the rows touch the cut, needs 25 % more iterations -- and with the coarse space it is essential: the
+    // subdomain constants jump at the cut, and a stage 2 that does not see the jump needs 2.5x the iterations (emulated 8
+    // ranks: 4.4 -> 11.5, OPMGPU_EMULATE_WHAT=7).  The exchange runs on the halo stream behind the rows that read no ghost (as in
+    // bicgstab's products).
+    bool exchange = false;
     if (coarse) {
         hipLaunchKernelGGL((k_cs_add<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, (const S*)L0.x.p, (const S*)w.cxc.p, w.hx.p, ctl);
         xp = w.hx.p;
-        if (comm && cpr_halo_xp) halo_dispatch(comm, w.hx.p, stream);
+        exchange = comm && cpr_halo_xp;
     } else if (comm && cpr_halo_xp) {
-        // multi-GPU: the AMG is rank-local (additive Schwarz: ghost rows are identity rows); the owners' x_p is copied to the
-        // ghosts before the full-system residual so that stage 2 sees the neighbours' pressure correction on the rows next to the
-        // cut.  Costs two halo exchanges per BiCGStab iteration; without it (OPMGPU_CPR_HALO_XP=0) the one-rank self-halo deck,
-        // where half of the rows touch the cut, needs 25 % more iterations -- and with the coarse space it is essential: the
-        // subdomain constants jump at the cut, and a stage 2 that does not see the jump needs 2.5x the iterations (emulated 8
-        // ranks: 4.4 -> 11.5, OPMGPU_EMULATE_WHAT=7).
         OPMGPU_HIP(hipMemcpyAsync(w.hx.p, L0.x.p, size_t(plan.nb) * sizeof(S), hipMemcpyDeviceToDevice, stream));
-        halo_dispatch(comm, w.hx.p, stream);
         xp = w.hx.p;
+        exchange = true;
     }
-    hipLaunchKernelGGL((k_cpr_presidual<S>), dim3(grid8_for(plan.nb)), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p,
-                       ((emulate_what & 4) ? pre_matrix<S>() : matrix<S>()), d, xp, w.z.p, comm ? comm->owner_mask() : (const int8_t*)nullptr, ctl);
+    const S* amat = (emulate_what & 4) ? pre_matrix<S>() : matrix<S>();
+    const int8_t* own = comm ? comm->owner_mask() : (const int8_t*)nullptr;
+    const bool overlap = exchange && halo_overlap && halo_stream && light_ok_for == comm && light_ok.n == size_t(plan.nbp);
+    if (!overlap) {
+        if (exchange) halo_dispatch(comm, w.hx.p, stream);
+        hipLaunchKernelGGL((k_cpr_presidual<S>), dim3(grid8_for(plan.nb)), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p, amat, d, xp, w.z.p, own, ctl,
+                           0, (const int8_t*)nullptr);
+    } else {
+        OPMGPU_HIP(hipEventRecord(ev_halo[0], stream));
+        OPMGPU_HIP(hipStreamWaitEvent(halo_stream, ev_halo[0], 0));
+        halo_dispatch(comm, w.hx.p, halo_stream);
+        OPMGPU_HIP(hipEventRecord(ev_halo[1], halo_stream));
+        hipLaunchKernelGGL((k_cpr_presidual<S>), dim3(grid8_for(plan.nb)), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p, amat, d, xp, w.z.p, own, ctl,
+                           1, (const int8_t*)light_ok.p);
+        OPMGPU_HIP(hipStreamWaitEvent(stream, ev_halo[1], 0));
+        hipLaunchKernelGGL((k_cpr_presidual<S>), dim3(grid8_for(plan.nb)), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp, dp.slice_ptr.p, dp.col.p, amat, d, xp, w.z.p, own, ctl,
+                           2, (const int8_t*)light_ok.p);
+    }
     kt.end(KT_CPR_OTHER, kt_a);
     ilu_apply<S>(w.z.p, v, relax, ctl);
     kt_a = kt.begin();
