@@ -326,6 +326,39 @@ __global__ __launch_bounds__(kBlock) void k_amg_row_wave(int n, const int32_t* _
         else { out[row] = res; xout[row] = omega * dinv[row] * b[row]; }
     }
 }
+// middle levels (10^4 .. 10^5.5 rows of 15-30 entries): LPR lanes per row.  A thread per row walks its entries one after the other at
+// two workgroups per CU (latency bound: 12 us for 113 k rows, 3x the time its bytes take), a wavefront per row leaves most lanes idle.
+// Same MODEs as k_amg_row_wave; fixed reduction tree (deterministic); levels without a border only.
+template <class S, int MODE, int LPR>
+__global__ __launch_bounds__(kBlock) void k_amg_row_sub(int n, const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
+                                                        const S* __restrict__ val, const S* __restrict__ b, const S* __restrict__ x,
+                                                        S omega, const S* __restrict__ dinv, S* __restrict__ out, S* __restrict__ xout,
+                                                        const SolveCtl* __restrict__ ctl,
+                                                        const int32_t* __restrict__ agg = nullptr, const S* __restrict__ xc = nullptr, S pdamp = S(0))
+{
+    if (ctl && ctl->done) return;
+    auto xf = [&](int j) { return MODE == 2 ? omega * dinv[j] * b[j] : (MODE == 3 ? x[j] + pdamp * xc[agg[j]] : x[j]); };
+    const int row = blockIdx.x * (kBlock / LPR) + int(threadIdx.x) / LPR, l = int(threadIdx.x) % LPR;
+    const bool live = row < n;
+    double acc = 0.0;
+    if (live) {
+        const int base = slice_ptr[row >> 6], width = slice_ptr[(row >> 6) + 1] - base, lane = row & 63;
+        for (int k = l; k < width; k += LPR) {
+            const long e = long(base + k) * 64 + lane;
+            const int j = col[e];
+            acc += double(val[e]) * double(xf(j));
+        }
+    }
+#pragma unroll
+    for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (live && l == 0) {
+        const S res = b[row] - S(acc);
+        if (MODE == 0) out[row] = res;
+        else if (MODE == 1) out[row] = x[row] + omega * dinv[row] * res;
+        else if (MODE == 3) out[row] = (x[row] + pdamp * xc[agg[row]]) + omega * dinv[row] * res;
+        else { out[row] = res; xout[row] = omega * dinv[row] * b[row]; }
+    }
+}
 template <class S>
 __global__ __launch_bounds__(kBlock) void k_amg_restrict(int nc, const int32_t* __restrict__ aptr, const int32_t* __restrict__ arows,
                                                          const S* __restrict__ r, S* __restrict__ bc, S omega, const S* __restrict__ dinv_c,
@@ -562,6 +595,16 @@ void AmgHierarchy<S>::galerkin(bool coarse_levels)
     }
 }
 
+constexpr int kSubLanes = 8;
+static inline int sub_grid(int n) { return (n + kBlock / kSubLanes - 1) / (kBlock / kSubLanes); }
+// levels whose row kernels run kSubLanes lanes per row (k_amg_row_sub); A/B: OPMGPU_AMG_SUB=lo,hi (0,0 = off)
+template <class S> static bool sub_rows(const AmgLevel<S>& F)
+{
+    static int lo = -1, hi = -1;
+    if (lo < 0) { lo = 2000; hi = 400000; if (const char* e = std::getenv("OPMGPU_AMG_SUB")) std::sscanf(e, "%d,%d", &lo, &hi); }
+    return F.nw == 0 && F.n > lo && F.n <= hi;
+}
+
 template <class S>
 void AmgHierarchy<S>::vcycle(const SolveCtl* ctl, bool level0_presmoothed)
 {
@@ -595,6 +638,10 @@ void AmgHierarchy<S>::vcycle(const SolveCtl* ctl, bool level0_presmoothed)
             hipLaunchKernelGGL((k_amg_gs<S, 1>), dim3(grid_for(F.n - n0)), dim3(kBlock), 0, stream, n0, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, F.dinv.p, F.x.p, (S*)nullptr, ctl);
             hipLaunchKernelGGL((k_amg_gs<S, 0>), dim3(grid_for(n0)), dim3(kBlock), 0, stream, 0, n0, F.slice_ptr, F.col, F.val.p, F.b.p, F.dinv.p, F.x.p, F.r.p, ctl);
             OPMGPU_HIP(hipMemsetAsync(F.r.p + n0, 0, size_t(F.n - n0) * sizeof(S), stream));
+        } else if (sub_rows(F)) {
+            // x = omega D^-1 b came with the restriction (presmoothed) or is formed on the fly (MODE 2)
+            if (presmoothed) hipLaunchKernelGGL((k_amg_row_sub<S, 0, kSubLanes>), dim3(sub_grid(F.n)), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, (const S*)F.x.p, om, F.dinv.p, F.r.p, (S*)nullptr, ctl);
+            else hipLaunchKernelGGL((k_amg_row_sub<S, 2, kSubLanes>), dim3(sub_grid(F.n)), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, (const S*)F.x.p, om, F.dinv.p, F.r.p, F.x.p, ctl);
         } else if (F.n > 50000) {
             if (!presmoothed) hipLaunchKernelGGL((k_amg_smooth0<S>), dim3(grid_for(F.ntot())), dim3(kBlock), 0, stream, F.ntot(), om, F.dinv.p, F.b.p, F.x.p, ctl);
             hipLaunchKernelGGL((k_amg_residual<S, 0>), dim3(g + F.nw), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, F.x.p, om, F.dinv.p, F.r.p, ctl,
@@ -607,7 +654,9 @@ void AmgHierarchy<S>::vcycle(const SolveCtl* ctl, bool level0_presmoothed)
         }
         for (int sw = 1; sw < npre; ++sw) {      // further pre-smoothing sweeps, then the residual again
             sweep(F, ctl);
-            if (F.n > 20000)
+            if (sub_rows(F))
+                hipLaunchKernelGGL((k_amg_row_sub<S, 0, kSubLanes>), dim3(sub_grid(F.n)), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, (const S*)F.x.p, om, F.dinv.p, F.r.p, (S*)nullptr, ctl);
+            else if (F.n > 20000)
                 hipLaunchKernelGGL((k_amg_residual<S, 0>), dim3(g + F.nw), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, F.x.p, om, F.dinv.p, F.r.p, ctl,
                                    (const int32_t*)nullptr, (const S*)nullptr, S(0), bord(F, g));
             else
@@ -649,7 +698,10 @@ void AmgHierarchy<S>::vcycle(const SolveCtl* ctl, bool level0_presmoothed)
         }
         if (fuse && npost >= 1 && F.n <= 200000) {
             // small and medium levels: the prolongation is gathered inside the first post-smoothing sweep (one launch less)
-            if (F.n > 20000)
+            if (sub_rows(F))
+                hipLaunchKernelGGL((k_amg_row_sub<S, 3, kSubLanes>), dim3(sub_grid(F.n)), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, (const S*)F.x.p, om, F.dinv.p, F.x2.p,
+                                   (S*)nullptr, ctl, (const int32_t*)F.agg.p, (const S*)C.x.p, S(pdamp));
+            else if (F.n > 20000)
                 hipLaunchKernelGGL((k_amg_residual<S, 3>), dim3(g + F.nw), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, (const S*)F.x.p, om, F.dinv.p, F.x2.p, ctl,
                                    (const int32_t*)F.agg.p, (const S*)C.x.p, S(pdamp), bord(F, g));
             else
@@ -708,7 +760,9 @@ void AmgHierarchy<S>::sweep(AmgLevel<S>& F, const SolveCtl* ctl)
         B.nw = F.nw; B.n = F.n; B.connpos = F.b_connpos; B.perf_row = F.b_perf_row; B.perf_of_row = F.b_perf_of_row; B.perf_well = F.b_perf_well;
         B.bcol = F.val.p + F.nentries; B.crow = B.bcol + F.nperf; B.dw = B.crow + F.nperf;
     }
-    if (F.n > 20000) {
+    if (sub_rows(F)) {
+        hipLaunchKernelGGL((k_amg_row_sub<S, 1, kSubLanes>), dim3(sub_grid(F.n)), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, (const S*)F.x.p, om, F.dinv.p, F.x2.p, (S*)nullptr, ctl);
+    } else if (F.n > 20000) {
         B.gcells = grid_for(F.n);
         hipLaunchKernelGGL((k_amg_residual<S, 1>), dim3(grid_for(F.n) + F.nw), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, F.x.p, om, F.dinv.p, F.x2.p, ctl,
                            (const int32_t*)nullptr, (const S*)nullptr, S(0), B);
