@@ -414,6 +414,8 @@ int opmgpu_comm_init(opmgpu_ctx* ctx, int rank, int nranks, const uint8_t* id, i
  *   allreduce: in-place sum (is_max = 0) or max of n doubles;
  *   exchange:  for every neighbour q send scount[q] bytes from sbuf + soff[q] to rank neigh_rank[q] and receive rcount[q] bytes
  *              from it into rbuf + roff[q] (byte offsets / counts).
+ * The stream is not always the same one: exchanges of the solver arrive on the library's second ("halo") stream while the rows that
+ * need no ghost value are multiplied on the main stream; calls are issued in the same order on every rank and never concurrently.
  * A non-zero return value becomes OPMGPU_ECOMM.  The struct is copied; `destroy(self)` is called when the context goes away. */
 typedef struct opmgpu_transport {
     void* self;

@@ -1965,9 +1965,9 @@ __global__ __launch_bounds__(kBlock) void k_gm_normalize(long n, int slot, int f
     for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) vout[i] = w[i] * inv;
 }
 // column i of the Hessenberg matrix: previous rotations, new rotation (dune generatePlaneRotation / applyPlaneRotation), |s[i+1]|
-__global__ void k_gm_givens(int i, int m, int j, GmState g, SolveCtl* __restrict__ ctl, SolveCtl* __restrict__ hst)
+__global__ void k_gm_givens(int i, int m, int j, GmState g, SolveCtl* __restrict__ ctl, SolveCtl* __restrict__ hst, int* __restrict__ tick_ptr = nullptr, int tick = 0)
 {
-    if (ctl->done) return;
+    if (ctl->done) { publish(ctl, hst); if (tick_ptr) { __threadfence_system(); *(volatile int*)tick_ptr = tick; } return; }
     double* H = g.H;
     auto rot = [](double& dx, double& dy, double c, double sN) { const double t = c * dx + sN * dy; dy = -sN * dx + c * dy; dx = t; };
     for (int k = 0; k < i; ++k) rot(H[k * m + i], H[(k + 1) * m + i], g.cs[k], g.sn[k]);
@@ -1986,6 +1986,7 @@ __global__ void k_gm_givens(int i, int m, int j, GmState g, SolveCtl* __restrict
     ctl->iters = j;
     if (nrm * nrm < ctl->thresh2) { ctl->done = 1; ctl->decided = j; }
     publish(ctl, hst);
+    if (tick_ptr) { __threadfence_system(); *(volatile int*)tick_ptr = tick; }      // the host spins on this word instead of synchronising the stream (wait_tick)
 }
 // y = R^-1 s (back-substitution over the first cnt columns)
 __global__ void k_gm_solve_y(int cnt, int m, GmState g)
@@ -2022,7 +2023,10 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
     const int m = std::max(1, int(prm.linear_solver_restart));
     const int maxit = prm.linear_solver_maxiter;
     const bool cpr = prm.use_cpr != 0;
-    lag_allowed = false;          // (the GMRES option keeps the hierarchy fresh: it is the reference's robustness fallback)
+    // coarse operators of the pressure hierarchy: the lag policy of the BiCGStab path (cpr_prepare), with solve_loaded's retry on fresh
+    // ones behind it; OPMGPU_GMRES_LAG=0 keeps the hierarchy fresh for every matrix
+    static const bool gm_lag = !(std::getenv("OPMGPU_GMRES_LAG") && std::atoi(std::getenv("OPMGPU_GMRES_LAG")) == 0);
+    lag_allowed = gm_lag && prm.linear_solver_reduction >= 1e-4;
     if (cpr) cpr_prepare<S>();
     w.kry.alloc(size_t(m + 1) * n);
     gmbuf.alloc(size_t(m + 1) * m + (m + 1) + 3 * m + 8);
@@ -2062,8 +2066,9 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
             hipLaunchKernelGGL((k_dot<S>), dim3(gv), dim3(kBlock), 0, stream, n, w.t.p, w.t.p, parts);
             hipLaunchKernelGGL((k_gm_normalize<S>), dim3(gv), dim3(kBlock), 0, stream, n, (i + 1) * m + i, 0, 0.0, (const double*)parts, gv, g.H, g.s,
                                (const S*)w.t.p, V(i + 1), d_ctl, h_ctl_dev);
-            hipLaunchKernelGGL(k_gm_givens, dim3(1), dim3(1), 0, stream, i, m, j, g, d_ctl, h_ctl_dev);
-            OPMGPU_HIP(hipStreamSynchronize(stream));
+            const int tick = ++tick_seq;
+            hipLaunchKernelGGL(k_gm_givens, dim3(1), dim3(1), 0, stream, i, m, j, g, d_ctl, h_ctl_dev, poll_status ? h_tick_dev : (int*)nullptr, tick);
+            wait_tick(tick);
             if (h_ctl->done) stop = true;
         }
         if (h_ctl->flag != 0) break;                                   // breakdown: dune throws, no update

@@ -206,37 +206,60 @@ __global__ void k_well_avg_press(int nw, WellArgs A, const int32_t* __restrict__
     }
 }
 
-// computeWellConnectionPressures: WellDensitySegmented::computeConnectionDensities + computeConnectionPressureDelta, one thread per well
-__global__ void k_well_cdp(int nw, WellArgs A, double gravity, const int32_t* __restrict__ gate)
+// computeWellConnectionPressures: WellDensitySegmented::computeConnectionDensities + computeConnectionPressureDelta.  One wavefront per
+// well: the lanes stage a tile of perforation data in LDS with parallel loads, lane 0 then walks the tile in the reference's order (the
+// running sums are sequential by definition; a thread fetching every perforation's operands itself spends 1.6 us per perforation waiting
+// for them: 164 us for a 100-perforation well, 8x this version).
+constexpr int kCdpTile = 128;
+__global__ __launch_bounds__(64) void k_well_cdp(int nw, WellArgs A, double gravity, const int32_t* __restrict__ gate)
 {
+    __shared__ double s_rate[3 * kCdpTile], s_pvt[5 * kCdpTile], s_sd[3 * kCdpTile], s_z[kCdpTile], s_dens[kCdpTile], s_cdp[kCdpTile];
     if (gate && !*gate) return;
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    const int w = blockIdx.x, lane = threadIdx.x;
     if (w >= nw) return;
     const int lo = A.connpos[w], hi = A.connpos[w + 1];
     // q_out[perf] = flow out of the segment above perforation perf = sum_{k >= perf} (-rate_k) (the reference fills it bottom to
     // top, WellDensitySegmented.cpp:83-95); here: total at the top first, then q_out[perf + 1] = q_out[perf] + rate[perf] going down.
     double q[3] = { 0.0, 0.0, 0.0 };
-    for (int perf = hi - 1; perf >= lo; --perf) for (int a = 0; a < 3; ++a) q[a] -= A.perf_rates[3 * perf + a];
-    double run = 0.0;
-    for (int perf = lo; perf < hi; ++perf) {
-        const double* pv = A.perf_pvt + 5 * long(perf);
-        const double tot = q[0] + q[1] + q[2];
-        double mix[3], x[3];
-        for (int a = 0; a < 3; ++a) { mix[a] = tot != 0.0 ? fabs(q[a] / tot) : A.comp_frac[3 * w + a]; x[a] = mix[a]; }
-        const double rsmax = pv[3], rvmax = pv[4];
-        double rs = 0.0, rv = 0.0;
-        if (mix[1] > 0.0) rs = fmin(mix[2] / mix[1], rsmax);
-        if (mix[2] > 0.0) rv = fmin(mix[1] / mix[2], rvmax);
-        if (rs != 0.0) x[2] = (mix[2] - mix[1] * rs) / (1.0 - rs * rv);
-        if (rv != 0.0) x[1] = (mix[1] - mix[2] * rv) / (1.0 - rs * rv);
-        const double volrat = x[0] / pv[0] + x[1] / pv[1] + x[2] / pv[2];
-        const double* sd = A.surf_dens_perf + 3 * long(perf);
-        const double dens = (sd[0] * mix[0] + sd[1] * mix[1] + sd[2] * mix[2]) / volrat;
-        A.perf_dens[perf] = dens;
-        const double z_above = perf == lo ? A.depth_ref[w] : A.z_perf[perf - 1];
-        run += (A.z_perf[perf] - z_above) * dens * gravity;
-        A.cdp[perf] = run;
-        for (int a = 0; a < 3; ++a) q[a] += A.perf_rates[3 * perf + a];
+    for (int t1 = hi; t1 > lo; t1 -= kCdpTile) {
+        const int t0 = t1 - kCdpTile > lo ? t1 - kCdpTile : lo, nt = t1 - t0;
+        for (int i = lane; i < 3 * nt; i += 64) s_rate[i] = A.perf_rates[3 * long(t0) + i];
+        __syncthreads();
+        if (lane == 0) for (int i = nt - 1; i >= 0; --i) for (int a = 0; a < 3; ++a) q[a] -= s_rate[3 * i + a];
+        __syncthreads();
+    }
+    double run = 0.0, z_above = A.depth_ref[w];
+    for (int t0 = lo; t0 < hi; t0 += kCdpTile) {
+        const int nt = hi - t0 < kCdpTile ? hi - t0 : kCdpTile;
+        for (int i = lane; i < 3 * nt; i += 64) { s_rate[i] = A.perf_rates[3 * long(t0) + i]; s_sd[i] = A.surf_dens_perf[3 * long(t0) + i]; }
+        for (int i = lane; i < 5 * nt; i += 64) s_pvt[i] = A.perf_pvt[5 * long(t0) + i];
+        for (int i = lane; i < nt; i += 64) s_z[i] = A.z_perf[t0 + i];
+        __syncthreads();
+        if (lane == 0) {
+            for (int i = 0; i < nt; ++i) {
+                const double* pv = s_pvt + 5 * i;
+                const double tot = q[0] + q[1] + q[2];
+                double mix[3], x[3];
+                for (int a = 0; a < 3; ++a) { mix[a] = tot != 0.0 ? fabs(q[a] / tot) : A.comp_frac[3 * w + a]; x[a] = mix[a]; }
+                const double rsmax = pv[3], rvmax = pv[4];
+                double rs = 0.0, rv = 0.0;
+                if (mix[1] > 0.0) rs = fmin(mix[2] / mix[1], rsmax);
+                if (mix[2] > 0.0) rv = fmin(mix[1] / mix[2], rvmax);
+                if (rs != 0.0) x[2] = (mix[2] - mix[1] * rs) / (1.0 - rs * rv);
+                if (rv != 0.0) x[1] = (mix[1] - mix[2] * rv) / (1.0 - rs * rv);
+                const double volrat = x[0] / pv[0] + x[1] / pv[1] + x[2] / pv[2];
+                const double* sd = s_sd + 3 * i;
+                const double dens = (sd[0] * mix[0] + sd[1] * mix[1] + sd[2] * mix[2]) / volrat;
+                s_dens[i] = dens;
+                run += (s_z[i] - z_above) * dens * gravity;
+                z_above = s_z[i];
+                s_cdp[i] = run;
+                for (int a = 0; a < 3; ++a) q[a] += s_rate[3 * i + a];
+            }
+        }
+        __syncthreads();
+        for (int i = lane; i < nt; i += 64) { A.perf_dens[t0 + i] = s_dens[i]; A.cdp[t0 + i] = s_cdp[i]; }
+        __syncthreads();
     }
 }
 
@@ -922,7 +945,7 @@ void BlackoilDevice::wells_connection_pressures(const int32_t* gate)
     const int g = (W.nw + 63) / 64;
     hipLaunchKernelGGL(k_well_avg_press, dim3(g), dim3(64), 0, stream, W.nw, A, gate, W.avgp.p);
     perf_pvt_device(W.avgp.p, W.perf_pvt.p, gate);
-    hipLaunchKernelGGL(k_well_cdp, dim3(g), dim3(64), 0, stream, W.nw, A, gravity, gate);
+    hipLaunchKernelGGL(k_well_cdp, dim3(W.nw), dim3(64), 0, stream, W.nw, A, gravity, gate);
 }
 
 // called by assemble() after the reservoir kernels; the well part of BlackoilModelBase::assemble in the reference's order (:757-840)
