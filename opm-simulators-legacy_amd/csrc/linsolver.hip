@@ -2053,11 +2053,14 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
     while (j <= maxit && !stop) {
         int i = 0;
         for (; i < m && j <= maxit && !stop; ++i, ++j) {
+            hipEvent_t kt_a = kt.begin();
             lowrank_reduce<S>(V(i), d_ctl);
             hipLaunchKernelGGL((k_spmv<S, 0>), dim3(std::min(grid8_for(plan.nb), 4 * kMaxPart)), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp,
                                dp.slice_ptr.p, dp.col.p, matrix<S>(), (const S*)V(i), w.v.p, (const S*)nullptr, (const int8_t*)nullptr, (const SolveCtl*)d_ctl,
                                (double*)nullptr, (double*)nullptr, (const S*)nullptr, (const S*)nullptr, 0, S(0), lowrank, (const int8_t*)nullptr);
+            kt.end(KT_SPMV1, kt_a);
             precond(w.v.p, w.t.p);                                     // w = M^-1 A v_i
+            kt_a = kt.begin();
             for (int k = 0; k <= i; ++k) {
                 hipLaunchKernelGGL((k_dot<S>), dim3(gv), dim3(kBlock), 0, stream, n, (const S*)V(k), (const S*)w.t.p, parts);
                 hipLaunchKernelGGL((k_gm_axpy<S>), dim3(gv), dim3(kBlock), 0, stream, n, k * m + i, (const double*)parts, gv, g.H, (const S*)V(k), w.t.p,
@@ -2068,6 +2071,7 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
                                (const S*)w.t.p, V(i + 1), d_ctl, h_ctl_dev);
             const int tick = ++tick_seq;
             hipLaunchKernelGGL(k_gm_givens, dim3(1), dim3(1), 0, stream, i, m, j, g, d_ctl, h_ctl_dev, poll_status ? h_tick_dev : (int*)nullptr, tick);
+            kt.end(KT_VECTOR, kt_a);
             wait_tick(tick);
             if (h_ctl->done) stop = true;
         }
