@@ -597,6 +597,17 @@ __global__ __launch_bounds__(kBlock) void k_dot(long n, const S* __restrict__ a,
     block_sum<1>(acc, sm);
     if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
 }
+// <a, b> over the OWNED rows only (multi-GPU GMRES: the basis vectors carry halo-exchanged ghost entries); mask per row, three planes of nbp
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_dot_owned(long n, int nbp, const int8_t* __restrict__ mask, const S* __restrict__ a, const S* __restrict__ b,
+                                                      double* __restrict__ partials)
+{
+    __shared__ double sm[8];
+    double acc[1] = { 0.0 };
+    for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) if (mask[i % nbp]) acc[0] += double(a[i]) * double(b[i]);
+    block_sum<1>(acc, sm);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+}
 template <class S>
 __global__ __launch_bounds__(kBlock) void k_axpy(long n, S a, const S* __restrict__ x, S* __restrict__ y)
 {
@@ -2016,7 +2027,12 @@ __global__ void k_gm_reset_s(int m, GmState g) { for (int i = 1; i < m + 1; ++i)
 template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
 {
     SolveResult res;
-    if (comm) { res.status = OPMGPU_EINVAL; return res; }            // single GPU (the projections would need one all-reduce each)
+    // multi-GPU: the basis vector is halo-exchanged before every product (ghost rows of the product are zero, like in bicgstab), the
+    // projections are owner-masked dot products whose partial arrays are collapsed and all-reduced before the axpy reads them: one small
+    // all-reduce per projection + one for the norm (j + 2 in iteration j of a cycle; a CPR solve takes ~4 iterations).  Every rank sees
+    // the same Hessenberg matrix, so the Givens / convergence decisions and the final combination are identical everywhere, and the
+    // ghost entries of x are the owners' entries bit for bit (they are the same combination of exchanged basis vectors).
+    const int8_t* mask = comm ? comm->owner_mask() : nullptr;
     SolverWork<S>& w = work<S>();
     const long n = long(3) * plan.nbp;
     const int gv = std::min(grid_for(n), kMaxPart);
@@ -2033,12 +2049,29 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
     gmbuf.zero(stream);
     GmState g; g.H = gmbuf.p; g.s = g.H + size_t(m + 1) * m; g.cs = g.s + (m + 1); g.sn = g.cs + m; g.y = g.sn + m;
     double* parts = partials.p;
+    double* red1 = partials.p + size_t(6) * npart;                   // the all-reduced scalar of a projection (multi-GPU)
     SolveCtl* d_ctl = ctl.p;
+    // <a, b> into a partial array the consumer kernels re-reduce: np entries on one GPU, one all-reduced entry otherwise
+    const double* dot_arr = parts; int dot_np = gv;
+    auto dot = [&](const S* a_, const S* b_) {
+        if (!comm) { hipLaunchKernelGGL((k_dot<S>), dim3(gv), dim3(kBlock), 0, stream, n, a_, b_, parts); dot_arr = parts; dot_np = gv; return; }
+        hipLaunchKernelGGL((k_dot_owned<S>), dim3(gv), dim3(kBlock), 0, stream, n, plan.nbp, mask, a_, b_, parts);
+        hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(kBlock), 0, stream, (const double*)parts, (const double*)nullptr, gv, red1);
+        comm->allreduce_sum(red1, 1, stream);
+        dot_arr = red1; dot_np = 1;
+    };
+    auto product = [&](S* vin, S* out, const SolveCtl* c) {          // out = A vin (vin's ghost entries refreshed first)
+        if (comm) halo<S>(comm, vin, stream);
+        lowrank_reduce<S>(vin, c);
+        hipLaunchKernelGGL((k_spmv<S, 0>), dim3(std::min(grid8_for(plan.nb), 4 * kMaxPart)), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp,
+                           dp.slice_ptr.p, dp.col.p, matrix<S>(), (const S*)vin, out, (const S*)nullptr, mask, c,
+                           (double*)nullptr, (double*)nullptr, (const S*)nullptr, (const S*)nullptr, 0, S(0), lowrank, (const int8_t*)nullptr);
+    };
     auto V = [&](int k) { return w.kry.p + size_t(k) * n; };
     auto precond = [&](const S* d, S* out) { if (cpr) cpr_apply<S>(d, out, prm.ilu_relaxation, d_ctl); else ilu_apply<S>(d, out, prm.ilu_relaxation, d_ctl); };
     auto normalize_start = [&](int first) {          // v0 = M^-1 defect (in w.t), then v0 /= ||v0||, s[0] = ||v0||
-        hipLaunchKernelGGL((k_dot<S>), dim3(gv), dim3(kBlock), 0, stream, n, w.t.p, w.t.p, parts);
-        hipLaunchKernelGGL((k_gm_normalize<S>), dim3(gv), dim3(kBlock), 0, stream, n, -1, first, prm.linear_solver_reduction, (const double*)parts, gv,
+        dot(w.t.p, w.t.p);
+        hipLaunchKernelGGL((k_gm_normalize<S>), dim3(gv), dim3(kBlock), 0, stream, n, -1, first, prm.linear_solver_reduction, dot_arr, dot_np,
                            g.H, g.s, (const S*)w.t.p, V(0), d_ctl, h_ctl_dev);
         hipLaunchKernelGGL(k_gm_reset_s, dim3(1), dim3(1), 0, stream, m, g);
     };
@@ -2054,20 +2087,17 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
         int i = 0;
         for (; i < m && j <= maxit && !stop; ++i, ++j) {
             hipEvent_t kt_a = kt.begin();
-            lowrank_reduce<S>(V(i), d_ctl);
-            hipLaunchKernelGGL((k_spmv<S, 0>), dim3(std::min(grid8_for(plan.nb), 4 * kMaxPart)), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp,
-                               dp.slice_ptr.p, dp.col.p, matrix<S>(), (const S*)V(i), w.v.p, (const S*)nullptr, (const int8_t*)nullptr, (const SolveCtl*)d_ctl,
-                               (double*)nullptr, (double*)nullptr, (const S*)nullptr, (const S*)nullptr, 0, S(0), lowrank, (const int8_t*)nullptr);
+            product(V(i), w.v.p, (const SolveCtl*)d_ctl);
             kt.end(KT_SPMV1, kt_a);
             precond(w.v.p, w.t.p);                                     // w = M^-1 A v_i
             kt_a = kt.begin();
             for (int k = 0; k <= i; ++k) {
-                hipLaunchKernelGGL((k_dot<S>), dim3(gv), dim3(kBlock), 0, stream, n, (const S*)V(k), (const S*)w.t.p, parts);
-                hipLaunchKernelGGL((k_gm_axpy<S>), dim3(gv), dim3(kBlock), 0, stream, n, k * m + i, (const double*)parts, gv, g.H, (const S*)V(k), w.t.p,
+                dot((const S*)V(k), (const S*)w.t.p);
+                hipLaunchKernelGGL((k_gm_axpy<S>), dim3(gv), dim3(kBlock), 0, stream, n, k * m + i, dot_arr, dot_np, g.H, (const S*)V(k), w.t.p,
                                    (const SolveCtl*)d_ctl);
             }
-            hipLaunchKernelGGL((k_dot<S>), dim3(gv), dim3(kBlock), 0, stream, n, w.t.p, w.t.p, parts);
-            hipLaunchKernelGGL((k_gm_normalize<S>), dim3(gv), dim3(kBlock), 0, stream, n, (i + 1) * m + i, 0, 0.0, (const double*)parts, gv, g.H, g.s,
+            dot(w.t.p, w.t.p);
+            hipLaunchKernelGGL((k_gm_normalize<S>), dim3(gv), dim3(kBlock), 0, stream, n, (i + 1) * m + i, 0, 0.0, dot_arr, dot_np, g.H, g.s,
                                (const S*)w.t.p, V(i + 1), d_ctl, h_ctl_dev);
             const int tick = ++tick_seq;
             hipLaunchKernelGGL(k_gm_givens, dim3(1), dim3(1), 0, stream, i, m, j, g, d_ctl, h_ctl_dev, poll_status ? h_tick_dev : (int*)nullptr, tick);
@@ -2080,16 +2110,14 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
         hipLaunchKernelGGL(k_gm_solve_y, dim3(1), dim3(1), 0, stream, i, m, g);
         hipLaunchKernelGGL((k_gm_update_x<S>), dim3(gv), dim3(kBlock), 0, stream, n, i, (const double*)g.y, (const S*)w.kry.p, w.x.p);
         if (!stop && j <= maxit) {                                     // restart from the true defect
-            lowrank_reduce<S>(w.x.p, nullptr);
-            hipLaunchKernelGGL((k_spmv<S, 0>), dim3(std::min(grid8_for(plan.nb), 4 * kMaxPart)), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp,
-                               dp.slice_ptr.p, dp.col.p, matrix<S>(), (const S*)w.x.p, w.v.p, (const S*)nullptr, (const int8_t*)nullptr, (const SolveCtl*)nullptr,
-                               (double*)nullptr, (double*)nullptr, (const S*)nullptr, (const S*)nullptr, 0, S(0), lowrank, (const int8_t*)nullptr);
+            product(w.x.p, w.v.p, (const SolveCtl*)nullptr);
             hipLaunchKernelGGL((k_gm_defect<S>), dim3(gv), dim3(kBlock), 0, stream, n, (const S*)w.b.p, (const S*)w.v.p, w.r.p);
             precond(w.r.p, w.t.p);
             normalize_start(0);
         }
     }
     OPMGPU_HIP(hipStreamSynchronize(stream));
+    if (comm) comm->check_async();
     const double norm0 = std::sqrt(h_ctl->norm0_2), norm = std::sqrt(h_ctl->norm2);
     res.converged = h_ctl->done && h_ctl->flag == 0;
     res.iterations = j - 1;

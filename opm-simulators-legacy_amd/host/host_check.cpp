@@ -107,15 +107,19 @@ int main()
             const int32_t connpos[3] = { 0, 3, 6 };
             const int32_t cells[6] = { 0, 36, 72, 35, 71, 107 };
             const double WI[6] = { 2e-12, 2e-12, 2e-12, 2e-12, 2e-12, 2e-12 };
-            const int32_t type[2] = { 0, 1 }, ctrl_type[2] = { 1, 0 };
+            // controls as WellsManager lays them out: the injector on its rate target with a BHP limit behind it (updateWellControls
+            // switches when the limit is broken; it is not, here), the producer on BHP
+            const int32_t type[2] = { 0, 1 }, ctrl_ptr[3] = { 0, 2, 3 }, ctrl_type[3] = { OPMGPU_CTRL_SURFACE_RATE, OPMGPU_CTRL_BHP, OPMGPU_CTRL_BHP };
             const double depth_ref[2] = { 2001.0, 2001.0 }, comp_frac[6] = { 1, 0, 0, 0, 1, 0 };
-            const double ctrl_target[2] = { 5.0 / 86400.0, 150e5 }, ctrl_distr[6] = { 1, 0, 0, 0, 0, 0 };
+            const double ctrl_target[3] = { 5.0 / 86400.0, 600e5, 150e5 }, ctrl_distr[9] = { 1, 0, 0, 0, 0, 0, 0, 0, 0 };
             opmgpu_wells wells{};
             wells.nw = 2; wells.well_connpos = connpos; wells.well_cells = cells; wells.WI = WI; wells.type = type; wells.depth_ref = depth_ref;
-            wells.comp_frac = comp_frac; wells.ctrl_type = ctrl_type; wells.ctrl_target = ctrl_target; wells.ctrl_distr = ctrl_distr;
+            wells.comp_frac = comp_frac; wells.ctrl_ptr = ctrl_ptr; wells.ctrl_type = ctrl_type; wells.ctrl_target = ctrl_target; wells.ctrl_distr = ctrl_distr;
             model.setDeviceWells(wells);
             const double bhp0[2] = { 1.01 * p[0], 150e5 }, qs0[6] = { 5.0 / 86400.0, 0, 0, 0, 0, 0 };
             model.setWellState(bhp0, qs0);
+            const int32_t current0[2] = { 0, 0 };
+            model.setWellControls(current0);
         }
         // a 20-day report step through the adaptive sub-stepping loop (AdaptiveTimeStepping::stepImpl), state resident on the device
         opmgpu::AdaptiveTimeSteppingGpu ats;
@@ -130,6 +134,12 @@ int main()
         model.getWellState(bhp, qs);
         if (!(std::abs(qs[0] - 5.0 / 86400.0) < 1e-9) || !(qs[4] < 0.0) || !(std::abs(bhp[1] - 150e5) < 1.0) || !(bhp[0] > 150e5)) {
             std::printf("host_check: FAILED, well state after the report step: inj rate %g bhp %g, prod oil rate %g bhp %g\n", qs[0], bhp[0], qs[4], bhp[1]);
+            return 1;
+        }
+        int32_t current[2] = { -1, -1 };
+        model.getWellControls(current);
+        if (current[0] != 0 || current[1] != 0) {
+            std::printf("host_check: FAILED, well controls after the report step: %d %d (no limit was broken)\n", current[0], current[1]);
             return 1;
         }
         std::printf("host_check: wells: injector bhp %.1f bar at %.2f m3/d water, producer %.2f m3/d oil at %.1f bar\n", bhp[0] / 1e5, qs[0] * 86400.0,

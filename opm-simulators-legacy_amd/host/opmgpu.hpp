@@ -113,6 +113,17 @@ public:
     void setDeviceWells(const opmgpu_wells& wells) { throw_on_status(ctx_, opmgpu_set_device_wells(ctx_, &wells)); device_wells_ = wells.nw > 0; }
     void setWellState(const double* bhp, const double* well_rates, const double* perf_press = nullptr, const double* perf_rates = nullptr) { throw_on_status(ctx_, opmgpu_well_state_set(ctx_, bhp, well_rates, perf_press, perf_rates)); }
     void getWellState(double* bhp, double* well_rates, double* perf_press = nullptr, double* perf_rates = nullptr) { throw_on_status(ctx_, opmgpu_well_state_get(ctx_, bhp, well_rates, perf_press, perf_rates)); }
+    /// WellStateFullyImplicitBlackoil::currentControls() / thp(); after an assembly also what solveWellEq did (iterations, converged) per well
+    void setWellControls(const int32_t* current, const double* thp = nullptr) { throw_on_status(ctx_, opmgpu_well_controls_set(ctx_, current, thp)); }
+    void getWellControls(int32_t* current, double* thp = nullptr, int32_t* presolve_iterations = nullptr, int32_t* presolve_converged = nullptr)
+    {
+        throw_on_status(ctx_, opmgpu_well_controls_get(ctx_, current, thp, presolve_iterations, presolve_converged));
+    }
+    /// VFPPROD / VFPINJ tables for THP controls (VFPProperties), before setDeviceWells
+    void setVfpTables(int n, const opmgpu_vfp_table* tables) { throw_on_status(ctx_, opmgpu_set_vfp_tables(ctx_, n, tables)); }
+    /// once per report step, where SimulatorBase::run calls props.updateSatOilMax / updateSatHyst (SimulatorBase_impl.hpp:190-192)
+    void updateSatOilMax() { throw_on_status(ctx_, opmgpu_update_sat_oil_max(ctx_)); }
+    void updateSatHyst() { throw_on_status(ctx_, opmgpu_update_hysteresis(ctx_)); }
     /// well part of getConvergence (:1769-1779)
     bool wellsConverged(const ConvergenceReport& r)
     {

@@ -71,6 +71,10 @@ CASES = {
     "cpr_unstructured": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=800, use_cpr=1), wells=False, single=False, unstructured=True),
     "ilu0_j_slabs": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=1500), wells=False, single=False, axis=1),
     "cpr_wells": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=500, use_cpr=1), wells=True, single=False),
+    # the reference's newton_use_gmres option decomposed: halo-exchanged basis vectors, owner-masked projections, one all-reduce each
+    "cpr_gmres": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=500, use_cpr=1, newton_use_gmres=1), wells=False, single=False),
+    "cpr_gmres_wells": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=500, use_cpr=1, newton_use_gmres=1), wells=True, single=False),
+    "ilu0_gmres": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=1500, newton_use_gmres=1), wells=False, single=False),
     "cpr_f32_default_tolerance": dict(params=dict(use_cpr=1), wells=False, single=True),
     # a 30-day report step through the adaptive sub-stepping loop, first sub-step too long for 3 Newton iterations: chopped and redone
     "cpr_adaptive_substeps": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=500, use_cpr=1), wells=False, single=False,
