@@ -112,11 +112,11 @@ def main():
     tab = decks.satfunc_standard_tables()
     dt = args.dt_days * decks.DAY
     single = dt < 20 * decks.DAY            # BlackoilModelBase_impl.hpp:284
-    use_wells = args.wells == "fivespot" and not use_dist      # multi-GPU: the scaling legs run the well-free deck (wells live on one rank)
+    # multi-GPU, weak scaling: one 5-spot per rank's slab (a well lives on one rank), i.e. N copies of the one-GPU workload stacked along k;
+    # strong scaling cuts the fixed deck along k through its wells, which the device well model does not support: well-free deck there
+    use_wells = args.wells == "fivespot" and not (use_dist and (args.scaling == "strong" or args.deck == "spe10like"))
     if args.krylov == "auto":
-        args.krylov = "gmres" if (use_wells and args.solver == "cpr" and not use_dist) else "bicgstab"
-    if args.krylov == "gmres" and use_dist:
-        raise SystemExit("--krylov gmres is single-GPU only")
+        args.krylov = "gmres" if (use_wells and args.solver == "cpr") else "bicgstab"
     prm = capi.default_params(ilu_ordering=ordering, use_cpr=int(args.solver == "cpr"), newton_use_gmres=int(args.krylov == "gmres"))
 
     def make_deck():
@@ -133,7 +133,8 @@ def main():
         if args.deck == "spe10like":
             model, grid, st, info = partition.build_distributed_model(60, 220, 85, tab, prm, rank, world, local_rank, deck="spe10like")
         else:
-            model, grid, st, info = partition.build_distributed_model(args.nx, args.ny, nz_global, tab, prm, rank, world, local_rank)
+            wells_fn = (lambda g: W.five_spot(g, rate_m3_per_day=args.rate, bhp_prod_bar=150.0, slabs=world)) if use_wells else None
+            model, grid, st, info = partition.build_distributed_model(args.nx, args.ny, nz_global, tab, prm, rank, world, local_rank, wells_fn=wells_fn)
         well_spec = None
     else:
         grid, st, well_spec = make_deck()
@@ -147,6 +148,8 @@ def main():
         torch.cuda.synchronize()
 
     def make_wells():
+        if use_dist:
+            return info["wells"]
         return W.five_spot(grid, rate_m3_per_day=well_spec[0], bhp_prod_bar=well_spec[1])
 
     def with_wells(core, on):
@@ -309,7 +312,8 @@ def main():
                 cpu_all = cpu_baseline(grid, tab, st, wl, prm, dt, single, threads=ncores, budget_s=8.0, max_newton=2)
 
         wells_txt = ("5-spot: 1 rate-controlled water injector (%.0f m3/d, BHP limit off) + 4 BHP producers (%.0f bar), %d perforations each, device well model "
-                     "(rank-7 operator per well, control switching + well pre-solve on the device)" % (well_spec[0], well_spec[1], args.nz)) if use_wells else "none"
+                     "(rank-7 operator per well, control switching + well pre-solve on the device)%s" %
+                     (((well_spec[0], well_spec[1]) if well_spec else (args.rate, 150.0)) + (args.nz, "" if world == 1 else "; one such 5-spot per rank's slab (%d wells)" % (5 * world)))) if use_wells else "none"
         out = {
             "metric": "Mcell-updates/sec per Newton step (assembly+solve)", "value": value, "unit": "Mcell-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,

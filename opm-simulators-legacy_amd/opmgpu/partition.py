@@ -140,7 +140,7 @@ def make_unique_id():
     return bytes(buf)
 
 
-def build_distributed_model(nx, ny, nz, tables, params, rank, world, local_rank, lognormal_sigma=0.5, seed=12345, perturb=0.002, deck="cart"):
+def build_distributed_model(nx, ny, nz, tables, params, rank, world, local_rank, lognormal_sigma=0.5, seed=12345, perturb=0.002, deck="cart", wells_fn=None):
     """Every rank builds the same global synthetic deck, keeps its slab (+ghosts) and joins the RCCL communicator.
     The unique id travels through torch.distributed (backend nccl = RCCL).  deck = "spe10like": BASELINE configs[3], the 60 x 220 x 85
     deck with sigma_lnK = 2.5 cut along j (27-28 rows of 60 x 85 cells per GPU at N = 8: strong scaling by construction)."""
@@ -165,4 +165,6 @@ def build_distributed_model(nx, ny, nz, tables, params, rank, world, local_rank,
     dist.broadcast(idt, src=0)
     attach_comm(model, dom, rank, world, bytes(idt.cpu().numpy().tobytes()))
     info = {"n_owned": dom.n_owned, "n_global": grid.nc, "n_ghost": dom.n_ghost, "neighbours": dom.neigh_rank.tolist()}
+    if wells_fn is not None:          # wells of the GLOBAL deck (every well inside one rank's cells) -> this rank's, in local numbering
+        info["wells"] = dom.local_wells(wells_fn(grid), part)
     return model, dom.grid, dom.local_state(st), info

@@ -663,18 +663,26 @@ class DeviceWellModel:
         return converged, lin
 
 
-def five_spot(grid, rate_m3_per_day=500.0, bhp_prod_bar=150.0, wi=None):
+def five_spot(grid, rate_m3_per_day=500.0, bhp_prod_bar=150.0, wi=None, slabs=1):
     """SURVEY 8d synthetic wells: one water injector (rate controlled, full column) in the centre and four
-    BHP-controlled producers in the corners of a Cartesian grid.  Peaceman-like WI from the cell transmissibility scale."""
+    BHP-controlled producers in the corners of a Cartesian grid.  Peaceman-like WI from the cell transmissibility scale.
+    slabs > 1 (weak-scaling decks stacked along k): one such 5-spot per slab of nz / slabs layers, every well inside its slab (a well lives
+    on one rank); the producers' BHP follows the hydrostatic pressure of the slab's top (700 kg/m3, the gradient decks.initial_state
+    uses) so that every slab sees the drawdown of the first."""
     nx, ny, nz = grid.dims
     wells = Wells()
-    col = lambda i, j: [i + nx * j + nx * ny * k for k in range(nz)]
     WI = wi if wi is not None else 10.0 * float(np.median(grid.trans))
     z = grid.z
-    wells.add_well("INJ", INJECTOR, z[col(nx // 2, ny // 2)[0]], col(nx // 2, ny // 2), WI, (1.0, 0.0, 0.0),
-                   (SURFACE_RATE, rate_m3_per_day / 86400.0, (1.0, 0.0, 0.0)))
-    for k, (i, j) in enumerate([(0, 0), (nx - 1, 0), (0, ny - 1), (nx - 1, ny - 1)]):
-        wells.add_well("PROD%d" % k, PRODUCER, z[col(i, j)[0]], col(i, j), WI, (0.0, 1.0, 0.0), (BHP, bhp_prod_bar * 1e5))
+    per = nz // slabs
+    for s in range(slabs):
+        k0, k1 = s * per, (nz if s == slabs - 1 else (s + 1) * per)
+        col = lambda i, j: [i + nx * j + nx * ny * k for k in range(k0, k1)]      # noqa: E731
+        tag = "" if slabs == 1 else "_S%d" % s
+        dbhp = 700.0 * grid.gravity * (z[col(0, 0)[0]] - z[0])
+        wells.add_well("INJ" + tag, INJECTOR, z[col(nx // 2, ny // 2)[0]], col(nx // 2, ny // 2), WI, (1.0, 0.0, 0.0),
+                       (SURFACE_RATE, rate_m3_per_day / 86400.0, (1.0, 0.0, 0.0)))
+        for k, (i, j) in enumerate([(0, 0), (nx - 1, 0), (0, ny - 1), (nx - 1, ny - 1)]):
+            wells.add_well("PROD%d%s" % (k, tag), PRODUCER, z[col(i, j)[0]], col(i, j), WI, (0.0, 1.0, 0.0), (BHP, bhp_prod_bar * 1e5 + dbhp))
     return wells
 
 
