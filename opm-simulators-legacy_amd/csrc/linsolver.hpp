@@ -143,7 +143,7 @@ public:
     template <class S> void cpr_apply(const S* d, S* v, double relax, const SolveCtl* ctl, const double* cr_given = nullptr);
     // x0 = 0; rhs in work<S>().b; solution in work<S>().x
     template <class S> SolveResult bicgstab(const opmgpu_params& prm);
-    template <class S> SolveResult gmres(const opmgpu_params& prm);      // newton_use_gmres: restarted, left-preconditioned (single GPU)
+    template <class S> SolveResult gmres(const opmgpu_params& prm);      // newton_use_gmres: restarted, left-preconditioned
 
     // host <-> device vector staging (caller numbering <-> internal, component-major planes)
     template <class S> void vec_from_host(const double* h, int layout, S* d);
