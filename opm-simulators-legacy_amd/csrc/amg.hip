@@ -750,6 +750,71 @@ void AmgHierarchy<S>::vcycle_graph(const SolveCtl* ctl, bool level0_presmoothed)
     OPMGPU_HIP(hipGraphLaunch(graph_exec, stream));
 }
 
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_amg_norm2_parts(int n, const S* __restrict__ r, double* __restrict__ parts)
+{
+    __shared__ double sm[4];
+    double acc[1] = { 0.0 };
+    for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) acc[0] += double(r[i]) * double(r[i]);
+    block_sum<1>(acc, sm);
+    if (threadIdx.x == 0) parts[blockIdx.x] = acc[0];
+}
+__global__ __launch_bounds__(kBlock) void k_amg_sum_parts(int np, const double* __restrict__ parts, double* __restrict__ out)
+{
+    __shared__ double sm[4];
+    double acc[1] = { 0.0 };
+    for (int i = threadIdx.x; i < np; i += kBlock) acc[0] += parts[i];
+    block_sum<1>(acc, sm);
+    if (threadIdx.x == 0) out[0] = acc[0];
+}
+template <class S>
+void AmgHierarchy<S>::residual_norm2(double* d_out)
+{
+    AmgLevel<S>& F = *levels[0];
+    const int g = grid_for(F.n);
+    Border<S> B;
+    if (F.nw) {
+        B.nw = F.nw; B.n = F.n; B.gcells = g; B.connpos = F.b_connpos; B.perf_row = F.b_perf_row; B.perf_of_row = F.b_perf_of_row; B.perf_well = F.b_perf_well;
+        B.bcol = F.val.p + F.nentries; B.crow = B.bcol + F.nperf; B.dw = B.crow + F.nperf;
+    }
+    hipLaunchKernelGGL((k_amg_residual<S, 0>), dim3(g + F.nw), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, F.x.p, S(omega), F.dinv.p, F.r.p, (const SolveCtl*)nullptr,
+                       (const int32_t*)nullptr, (const S*)nullptr, S(0), B);
+    const int np = 512;
+    if (tune_parts.n < size_t(np)) tune_parts.alloc(np);
+    hipLaunchKernelGGL((k_amg_norm2_parts<S>), dim3(np), dim3(kBlock), 0, stream, F.ntot(), (const S*)F.r.p, tune_parts.p);
+    hipLaunchKernelGGL(k_amg_sum_parts, dim3(1), dim3(kBlock), 0, stream, np, (const double*)tune_parts.p, d_out);
+}
+
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_amg_hash_fill(int n, S* __restrict__ x)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    uint32_t h = uint32_t(i) * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+    x[i] = S(double(h) / 2147483648.0 - 1.0);
+}
+template <class S>
+void AmgHierarchy<S>::smooth_test_rhs(int sweeps)
+{
+    AmgLevel<S>& F = *levels[0];
+    const size_t nt = size_t(F.ntot());
+    if (tune_b.n < nt) tune_b.alloc(nt);
+    OPMGPU_HIP(hipMemcpyAsync(tune_b.p, F.b.p, nt * sizeof(S), hipMemcpyDeviceToDevice, stream));
+    OPMGPU_HIP(hipMemsetAsync(F.b.p, 0, nt * sizeof(S), stream));
+    hipLaunchKernelGGL((k_amg_hash_fill<S>), dim3(grid_for(F.n)), dim3(kBlock), 0, stream, F.n, F.x.p);
+    if (F.nw) OPMGPU_HIP(hipMemsetAsync(F.x.p + F.n, 0, F.nw * sizeof(S), stream));
+    for (int k = 0; k < 2 * ((sweeps + 1) / 2); ++k) sweep(F, nullptr);       // an even count: x / x2 keep their roles
+    if (tune_parts.n < 512) tune_parts.alloc(512);
+    residual_norm2(tune_parts.p);                                             // r = 0 - A s
+    OPMGPU_HIP(hipMemcpyAsync(F.b.p, F.r.p, nt * sizeof(S), hipMemcpyDeviceToDevice, stream));
+}
+template <class S>
+void AmgHierarchy<S>::restore_rhs()
+{
+    AmgLevel<S>& F = *levels[0];
+    OPMGPU_HIP(hipMemcpyAsync(F.b.p, tune_b.p, size_t(F.ntot()) * sizeof(S), hipMemcpyDeviceToDevice, stream));
+}
+
 // one damped-Jacobi sweep x <- x + omega D^-1 (b - A x) (ping-pong between x and x2)
 template <class S>
 void AmgHierarchy<S>::sweep(AmgLevel<S>& F, const SolveCtl* ctl)

@@ -94,6 +94,15 @@ public:
     double pdamp = 1.9;           // coarse-grid correction scaling (dune-istl's prolongation damping factor); see LinSolver::cpr_prepare for 2.2
     double pdamp0 = 1.9;          // ... of the correction into level 0 (OPMGPU_AMG_PDAMP0)
     bool pdamp_user = false;      // OPMGPU_AMG_PDAMP given: no automatic choice
+    bool tuned = false;           // the correction factors were chosen for this hierarchy (LinSolver::cpr_tune)
+    // ||b - A x||^2 over level 0 (border rows included) into d_out[0]; two launches, fixed summation order
+    void residual_norm2(double* d_out);
+    DevArray<double> tune_parts;
+    // levels[0].b := A s for an algebraically smooth s (pseudo-random start, `sweeps` Jacobi sweeps on A s = 0): the kind of error the
+    // coarse-grid correction of a cycle meets.  The caller's right-hand side is parked in tune_b until restore_rhs().
+    void smooth_test_rhs(int sweeps);
+    void restore_rhs();
+    DevArray<S> tune_b;
     int npre = 1, npost = 2;      // smoothing sweeps before / after the coarse-grid correction
     int npost0 = 2;               // post-smoothing sweeps on level 0 (cheap per sweep there; coarse levels are launch-latency bound)
     int coarse_sweeps = 4;        // pairs of Jacobi sweeps standing in for the coarsest solve when it is too big for the dense inverse

@@ -141,6 +141,9 @@ public:
     template <class S> void cpr_prepare();
     void drop_hierarchies();            // the wells changed: the bordered pressure hierarchy is rebuilt from the next matrix
     template <class S> void cpr_apply(const S* d, S* v, double relax, const SolveCtl* ctl, const double* cr_given = nullptr);
+    // coarse-correction factors of the pressure cycle chosen for THIS matrix on the first right-hand side it sees (see cpr_tune)
+    template <class S> void cpr_tune();
+    bool amg_autotune = false;      // OPMGPU_AMG_AUTOTUNE=1: experiment, measured NOT robust; default: 1.9 (2.2 into level 0 on one well-free subdomain)
     // x0 = 0; rhs in work<S>().b; solution in work<S>().x
     template <class S> SolveResult bicgstab(const opmgpu_params& prm);
     template <class S> SolveResult gmres(const opmgpu_params& prm);      // newton_use_gmres: restarted, left-preconditioned
