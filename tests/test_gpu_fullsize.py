@@ -354,8 +354,9 @@ def _check_newton_count(gpu_lib, oracle, grid, tab, st, dt, wl, solvers=(0, 1), 
     n_oracle = _run_time_step(mo, dt, st1, False, NonlinearSolver())
     b = ob.getState()
     assert n_oracle <= 15, n_oracle
-    for cpr in solvers:
-        gm = GpuBlackoilModel(grid, tab, capi.default_params(use_cpr=cpr, **lin))
+    for code in solvers:          # bit 0: CPR instead of ILU0; bit 1: restarted GMRES instead of BiCGStab (newton_use_gmres)
+        cpr = code & 1
+        gm = GpuBlackoilModel(grid, tab, capi.default_params(use_cpr=cpr, newton_use_gmres=code >> 1, **lin))
         if wl is None:
             md = gm
         else:
@@ -366,7 +367,7 @@ def _check_newton_count(gpu_lib, oracle, grid, tab, st, dt, wl, solvers=(0, 1), 
         n_gpu = _run_time_step(md, dt, st1, False, NonlinearSolver())
         a = gm.getState()
         gm.close()
-        assert n_gpu == n_oracle, (cpr, n_gpu, n_oracle)
+        assert n_gpu == n_oracle, (code, n_gpu, n_oracle)
         assert np.array_equal(a.hc, b.hc)
         assert np.abs(a.p - b.p).max() <= 1e-4 * np.abs(b.p).max() and np.abs(a.sat - b.sat).max() <= 1e-4
 
@@ -415,7 +416,7 @@ def _spe9_like():
 
 DECKS = {"cart100": (_cart100, 5.0), "spe10like": (_spe10_like, 2.0), "nornelike": (_norne_like, 3.0), "spe9like": (_spe9_like, 3.0)}
 LOCKSTEP_KW = {"spe10like": dict(reduction=1e-8, tol_p=1e-5, tol_s=1e-5)}        # sigma_lnK = 2.5: a 1e-10 reduction is below what BiCGStab attains in f64
-COUNT_KW = {"cart100": dict(solvers=(1,)), "spe10like": dict(solvers=(1,)), "nornelike": dict(spin_up=0), "spe9like": dict(spin_up=0)}     # multicolour ILU0 alone needs ~1000 iterations for 1e-6 at 1 M cells
+COUNT_KW = {"cart100": dict(solvers=(1, 3)), "spe10like": dict(solvers=(1,)), "nornelike": dict(spin_up=0, solvers=(0, 1, 3)), "spe9like": dict(spin_up=0, solvers=(0, 1, 2, 3))}     # multicolour ILU0 alone needs ~1000 iterations for 1e-6 at 1 M cells
 
 
 @pytest.mark.parametrize("name", list(DECKS))
