@@ -469,7 +469,7 @@ void AmgHierarchy<S>::setup(const Plan& P, const int32_t* d_slice_ptr, const int
     gs_n0 = (P.nlevels == 2) ? P.level_ptr[1] : 0;        // two colours: rows [0, n0) and [n0, nb)
     if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
     npost0 = npost;
-    if (const char* e = std::getenv("OPMGPU_AMG_NPOST0")) npost0 = std::atoi(e);
+    if (const char* e = std::getenv("OPMGPU_AMG_NPOST0")) { npost0 = std::atoi(e); npost0_user = true; }
     // bordered level 0 (amg.hpp): one extra unknown per well; too many wells for the dense coarsest level -> no border
     const int nwb = (border && border->nw > 0 && border->nw <= kDenseMax / 2) ? border->nw : 0;
     const int npb = nwb ? border->nperf : 0;

@@ -105,6 +105,7 @@ public:
     DevArray<S> tune_b;
     int npre = 1, npost = 2;      // smoothing sweeps before / after the coarse-grid correction
     int npost0 = 2;               // post-smoothing sweeps on level 0 (cheap per sweep there; coarse levels are launch-latency bound)
+    bool npost0_user = false;     // OPMGPU_AMG_NPOST0 given: the solvers do not choose (BiCGStab 2, GMRES 1)
     int coarse_sweeps = 4;        // pairs of Jacobi sweeps standing in for the coarsest solve when it is too big for the dense inverse
     bool fuse = true;             // launch fusions of the V-cycle (A/B: OPMGPU_AMG_FUSE=0)
     bool use_gs = false;          // level 0: Gauss-Seidel by colour instead of damped Jacobi when the row order has two colours (OPMGPU_AMG_GS)

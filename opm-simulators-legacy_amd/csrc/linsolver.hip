@@ -1808,6 +1808,7 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
     const bool cpr = prm.use_cpr != 0;                   // multi-GPU: rank-local (additive Schwarz) AMG + block-Jacobi ILU0
     lag_allowed = prm.linear_solver_reduction >= 1e-4;
     if (cpr) cpr_prepare<S>();
+    if (cpr && !w.amg->npost0_user) w.amg->npost0 = 2;            // post-sweeps on level 0: 2 under BiCGStab, 1 under GMRES (see gmres)
     const bool closed = closed_form_level0 && emulate_ranks <= 1;
     const int8_t* lightmask = nullptr;
     const bool overlap = comm && halo_overlap;
@@ -2094,6 +2095,9 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
     static const bool gm_lag = std::getenv("OPMGPU_GMRES_LAG") && std::atoi(std::getenv("OPMGPU_GMRES_LAG")) != 0;
     lag_allowed = gm_lag && prm.linear_solver_reduction >= 1e-4;
     if (cpr) cpr_prepare<S>();
+    // one post-smoothing sweep on level 0 instead of two: measured over nine decks with wells +1..+5 % under GMRES (the same iteration
+    // counts within 0.1, a cheaper cycle), -7..0 % under BiCGStab on the well-free decks (profiles/r02_amg_sweep_gmres.log)
+    if (cpr && !w.amg->npost0_user) w.amg->npost0 = 1;
     w.kry.alloc(size_t(m + 1) * n);
     gmbuf.alloc(size_t(m + 1) * m + (m + 1) + 3 * m + 8);
     gmbuf.zero(stream);
