@@ -369,7 +369,10 @@ def _check_newton_count(gpu_lib, oracle, grid, tab, st, dt, wl, solvers=(0, 1), 
         gm.close()
         assert n_gpu == n_oracle, (code, n_gpu, n_oracle)
         assert np.array_equal(a.hc, b.hc)
-        assert np.abs(a.p - b.p).max() <= 1e-4 * np.abs(b.p).max() and np.abs(a.sat - b.sat).max() <= 1e-4
+        # left-preconditioned GMRES stops on the PRECONDITIONED residual (as dune's does): its 1e-6 is a looser statement about the true
+        # residual than BiCGStab's, so the converged states sit further from the oracle's (BiCGStab) ones
+        tol = 1e-3 if code >> 1 else 1e-4
+        assert np.abs(a.p - b.p).max() <= tol * np.abs(b.p).max() and np.abs(a.sat - b.sat).max() <= tol, code
 
 
 def _cart100(rate=1000.0, perturb=0.002):
