@@ -434,7 +434,17 @@ __global__ __launch_bounds__(kBlock) void k_update_p(long n, int j, double eps, 
     const double beta_d = (rho_new / rho_old) * (alpha / omega);
     const S beta = S(beta_d), om = S(omega);
     if (blockIdx.x == 0 && int(threadIdx.x) < cs.ns) cs.Cp[threadIdx.x] = cs.Cr[threadIdx.x] + beta_d * (cs.Cp[threadIdx.x] - omega * cs.Cv[threadIdx.x]);
-    for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) p[i] = (p[i] - om * v[i]) * beta + r[i];
+    constexpr int L = 16 / sizeof(S);              // 16-byte lanes (n is a multiple of 192)
+    struct alignas(16) Pack { S v[L]; };
+    const long nv = n / L;
+    for (long q = blockIdx.x * long(kBlock) + threadIdx.x; q < nv; q += long(gridDim.x) * kBlock) {
+        Pack pp = reinterpret_cast<Pack*>(p)[q];
+        const Pack vv = reinterpret_cast<const Pack*>(v)[q], rr = reinterpret_cast<const Pack*>(r)[q];
+#pragma unroll
+        for (int u = 0; u < L; ++u) pp.v[u] = (pp.v[u] - om * vv.v[u]) * beta + rr.v[u];
+        reinterpret_cast<Pack*>(p)[q] = pp;
+    }
+    for (long i = nv * L + blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) p[i] = (p[i] - om * v[i]) * beta + r[i];
 }
 
 template <class S>
@@ -457,7 +467,17 @@ __global__ __launch_bounds__(kBlock) void k_update_xr1(long n, int j, double eps
     if (blockIdx.x == 0 && int(threadIdx.x) < cs.ns) cs.Cr[threadIdx.x] -= alpha * cs.Cv[threadIdx.x];
     const S a = S(alpha);
     double acc[1] = { 0.0 };
-    for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) {
+    constexpr int L = 16 / sizeof(S);
+    struct alignas(16) Pack { S v[L]; };
+    const long nv = n / L;
+    for (long k = blockIdx.x * long(kBlock) + threadIdx.x; k < nv; k += long(gridDim.x) * kBlock) {
+        Pack xx = reinterpret_cast<Pack*>(x)[k], rr = reinterpret_cast<Pack*>(r)[k];
+        const Pack yy = reinterpret_cast<const Pack*>(y)[k], qq = reinterpret_cast<const Pack*>(q)[k];
+#pragma unroll
+        for (int u = 0; u < L; ++u) { xx.v[u] += a * yy.v[u]; rr.v[u] = rr.v[u] - a * qq.v[u]; acc[0] += double(rr.v[u]) * double(rr.v[u]); }
+        reinterpret_cast<Pack*>(x)[k] = xx; reinterpret_cast<Pack*>(r)[k] = rr;
+    }
+    for (long i = nv * L + blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) {
         x[i] += a * y[i];
         const S rn = r[i] - a * q[i];
         r[i] = rn;
@@ -487,7 +507,20 @@ __global__ __launch_bounds__(kBlock) void k_update_xr2(long n, int j, SolveCtl* 
     if (blockIdx.x == 0 && int(threadIdx.x) < cs.ns) cs.Cr[threadIdx.x] -= omega * cs.Ct[threadIdx.x];
     const S a = S(omega);
     double acc[2] = { 0.0, 0.0 };
-    for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) {
+    constexpr int L = 16 / sizeof(S);
+    struct alignas(16) Pack { S v[L]; };
+    const long nv = n / L;
+    for (long k = blockIdx.x * long(kBlock) + threadIdx.x; k < nv; k += long(gridDim.x) * kBlock) {
+        Pack xx = reinterpret_cast<Pack*>(x)[k], rr = reinterpret_cast<Pack*>(r)[k];
+        const Pack yy = reinterpret_cast<const Pack*>(y)[k], qq = reinterpret_cast<const Pack*>(q)[k], tt = reinterpret_cast<const Pack*>(rt)[k];
+#pragma unroll
+        for (int u = 0; u < L; ++u) {
+            xx.v[u] += a * yy.v[u]; rr.v[u] = rr.v[u] - a * qq.v[u];
+            acc[0] += double(rr.v[u]) * double(rr.v[u]); acc[1] += double(tt.v[u]) * double(rr.v[u]);
+        }
+        reinterpret_cast<Pack*>(x)[k] = xx; reinterpret_cast<Pack*>(r)[k] = rr;
+    }
+    for (long i = nv * L + blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) {
         x[i] += a * y[i];
         const S rn = r[i] - a * q[i];
         r[i] = rn;
@@ -593,7 +626,15 @@ __global__ __launch_bounds__(kBlock) void k_dot(long n, const S* __restrict__ a,
 {
     __shared__ double sm[8];
     double acc[1] = { 0.0 };
-    for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) acc[0] += double(a[i]) * double(b[i]);
+    constexpr int L = 16 / sizeof(S);              // 16-byte lanes; a fixed summation order
+    struct alignas(16) Pack { S v[L]; };
+    const long nv = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) ? 0 : n / L;
+    for (long q = blockIdx.x * long(kBlock) + threadIdx.x; q < nv; q += long(gridDim.x) * kBlock) {
+        const Pack x4 = reinterpret_cast<const Pack*>(a)[q], y4 = reinterpret_cast<const Pack*>(b)[q];
+#pragma unroll
+        for (int u = 0; u < L; ++u) acc[0] += double(x4.v[u]) * double(y4.v[u]);
+    }
+    for (long i = nv * L + blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) acc[0] += double(a[i]) * double(b[i]);
     block_sum<1>(acc, sm);
     if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
 }
@@ -1583,7 +1624,8 @@ template <class S> void LinSolver::cpr_prepare()
         else if (coarse_lag > 1) refresh = (coarse_age++ % coarse_lag) == 0;
         else {
             if (new_step_hint) { if (lag_block > 0) --lag_block; step_matrix = 0; } else ++step_matrix;
-            refresh = step_matrix <= 1 || coarse_nsub == 0 || lag_block > 0 || !lag_allowed || force_refresh;
+            static const bool lag_without_cs = std::getenv("OPMGPU_AMG_LAG_NOCS") && std::atoi(std::getenv("OPMGPU_AMG_LAG_NOCS")) != 0;
+            refresh = step_matrix <= 1 || (coarse_nsub == 0 && !lag_without_cs) || lag_block > 0 || !lag_allowed || force_refresh;
         }
         force_refresh = false;
         new_step_hint = false;
@@ -1998,6 +2040,55 @@ __global__ __launch_bounds__(kBlock) void k_gm_axpy(long n, int slot, const doub
     const S h = S(s[0]);
     for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) w[i] -= h * vk[i];
 }
+// One modified-Gram-Schmidt step fused with the next one's projection: w -= h vk with h = sum(parts_in) (recorded in H[slot]), and in the
+// same pass the partials of <vnext, w> for the updated w (vnext == nullptr: of <w, w>, the norm that ends the column).  The same
+// arithmetic as k_gm_axpy followed by k_dot / k_dot_owned (the partial sums run over 16-byte lanes, a fixed order: deterministic); one pass
+// over w instead of two and half the launches.
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_gm_axpy_dot(long n, int nbp, const int8_t* __restrict__ mask, int slot, const double* __restrict__ parts_in, int np,
+                                                        double* __restrict__ H, const S* __restrict__ vk, S* __restrict__ w, const S* __restrict__ vnext,
+                                                        double* __restrict__ parts_out, const SolveCtl* __restrict__ ctl)
+{
+    __shared__ double sm[12];
+    if (ctl->done) return;
+    const double* const arr[1] = { parts_in };
+    double s[1];
+    reduce_partials<1>(arr, np, s, sm);
+    if (blockIdx.x == 0 && threadIdx.x == 0) H[slot] = s[0];
+    const S h = S(s[0]);
+    double acc[1] = { 0.0 };
+    if (!mask) {
+        // 16-byte lanes: three read streams and one write stream of 12 MB each want more bytes in flight per thread than one scalar
+        constexpr int L = 16 / sizeof(S);
+        struct alignas(16) Pack { S v[L]; };
+        const long nv = n / L;
+        const Pack* __restrict__ vk4 = reinterpret_cast<const Pack*>(vk);
+        const Pack* __restrict__ vn4 = reinterpret_cast<const Pack*>(vnext);
+        Pack* __restrict__ w4 = reinterpret_cast<Pack*>(w);
+        for (long q = blockIdx.x * long(kBlock) + threadIdx.x; q < nv; q += long(gridDim.x) * kBlock) {
+            Pack a = w4[q];
+            const Pack b = vk4[q];
+            Pack c = a;
+            if (vnext) c = vn4[q];
+#pragma unroll
+            for (int u = 0; u < L; ++u) { a.v[u] = a.v[u] - h * b.v[u]; acc[0] += double(vnext ? c.v[u] : a.v[u]) * double(a.v[u]); }
+            w4[q] = a;
+        }
+        for (long i = nv * L + blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) {      // (n is a multiple of 192: empty)
+            const S wn = w[i] - h * vk[i];
+            w[i] = wn;
+            acc[0] += double(vnext ? vnext[i] : wn) * double(wn);
+        }
+    } else
+    for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) {
+        const S wn = w[i] - h * vk[i];
+        w[i] = wn;
+        if (mask[i % nbp]) acc[0] += double(vnext ? vnext[i] : wn) * double(wn);
+    }
+    __syncthreads();
+    block_sum<1>(acc, sm);
+    if (threadIdx.x == 0) parts_out[blockIdx.x] = acc[0];
+}
 // vout = w / ||w|| with ||w||^2 in parts; slot >= 0: H[slot] = ||w|| (breakdown flag if ~0); slot < 0: the restart normalisation,
 // s[0] = ||w|| and, at the very first one (first != 0), the convergence threshold
 template <class S>
@@ -2024,7 +2115,16 @@ __global__ __launch_bounds__(kBlock) void k_gm_normalize(long n, int slot, int f
         return;
     }
     const S inv = S(1.0 / nrm);
-    for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) vout[i] = w[i] * inv;
+    constexpr int L = 16 / sizeof(S);
+    struct alignas(16) Pack { S v[L]; };
+    const long nv = n / L;
+    for (long q = blockIdx.x * long(kBlock) + threadIdx.x; q < nv; q += long(gridDim.x) * kBlock) {
+        Pack a = reinterpret_cast<const Pack*>(w)[q];
+#pragma unroll
+        for (int u = 0; u < L; ++u) a.v[u] *= inv;
+        reinterpret_cast<Pack*>(vout)[q] = a;
+    }
+    for (long i = nv * L + blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) vout[i] = w[i] * inv;
 }
 // column i of the Hessenberg matrix: previous rotations, new rotation (dune generatePlaneRotation / applyPlaneRotation), |s[i+1]|
 __global__ void k_gm_givens(int i, int m, int j, GmState g, SolveCtl* __restrict__ ctl, SolveCtl* __restrict__ hst, int* __restrict__ tick_ptr = nullptr, int tick = 0)
@@ -2062,9 +2162,28 @@ __global__ void k_gm_solve_y(int cnt, int m, GmState g)
 template <class S>
 __global__ __launch_bounds__(kBlock) void k_gm_update_x(long n, int cnt, const double* __restrict__ y, const S* __restrict__ kry, S* __restrict__ x)
 {
-    for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) {
+    constexpr int L = 16 / sizeof(S);              // 16-byte lanes (n is a multiple of 192)
+    struct alignas(16) Pack { S v[L]; };
+    const long nv = n / L;
+    Pack* __restrict__ x4 = reinterpret_cast<Pack*>(x);
+    for (long q = blockIdx.x * long(kBlock) + threadIdx.x; q < nv; q += long(gridDim.x) * kBlock) {
+        Pack acc;
+#pragma unroll
+        for (int u = 0; u < L; ++u) acc.v[u] = 0;
+        for (int a = cnt - 1; a >= 0; --a) {                                            // the order of dune's update(): a = i-1 .. 0
+            const Pack k4 = reinterpret_cast<const Pack*>(kry + long(a) * n)[q];
+            const S ya = S(y[a]);
+#pragma unroll
+            for (int u = 0; u < L; ++u) acc.v[u] += ya * k4.v[u];
+        }
+        Pack xv = x4[q];
+#pragma unroll
+        for (int u = 0; u < L; ++u) xv.v[u] += acc.v[u];
+        x4[q] = xv;
+    }
+    for (long i = nv * L + blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) {
         S acc = 0;
-        for (int a = cnt - 1; a >= 0; --a) acc += S(y[a]) * kry[long(a) * n + i];       // the order of dune's update(): a = i-1 .. 0
+        for (int a = cnt - 1; a >= 0; --a) acc += S(y[a]) * kry[long(a) * n + i];
         x[i] += acc;
     }
 }
@@ -2103,6 +2222,7 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
     gmbuf.zero(stream);
     GmState g; g.H = gmbuf.p; g.s = g.H + size_t(m + 1) * m; g.cs = g.s + (m + 1); g.sn = g.cs + m; g.y = g.sn + m;
     double* parts = partials.p;
+    double* parts2 = partials.p + npart;                             // second partial array: producer and consumer of a fused step differ
     double* red1 = partials.p + size_t(6) * npart;                   // the all-reduced scalar of a projection (multi-GPU)
     SolveCtl* d_ctl = ctl.p;
     // <a, b> into a partial array the consumer kernels re-reduce: np entries on one GPU, one all-reduced entry otherwise
@@ -2145,12 +2265,19 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
             kt.end(KT_SPMV1, kt_a);
             precond(w.v.p, w.t.p);                                     // w = M^-1 A v_i
             kt_a = kt.begin();
+            // modified Gram-Schmidt, each step's update fused with the next step's projection (k_gm_axpy_dot)
+            dot((const S*)V(0), (const S*)w.t.p);
             for (int k = 0; k <= i; ++k) {
-                dot((const S*)V(k), (const S*)w.t.p);
-                hipLaunchKernelGGL((k_gm_axpy<S>), dim3(gv), dim3(kBlock), 0, stream, n, k * m + i, dot_arr, dot_np, g.H, (const S*)V(k), w.t.p,
-                                   (const SolveCtl*)d_ctl);
+                double* out = (dot_arr == parts) ? parts2 : parts;
+                hipLaunchKernelGGL((k_gm_axpy_dot<S>), dim3(gv), dim3(kBlock), 0, stream, n, plan.nbp, mask, k * m + i, dot_arr, dot_np, g.H, (const S*)V(k), w.t.p,
+                                   k < i ? (const S*)V(k + 1) : (const S*)nullptr, out, (const SolveCtl*)d_ctl);
+                if (!comm) { dot_arr = out; dot_np = gv; }
+                else {
+                    hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(kBlock), 0, stream, (const double*)out, (const double*)nullptr, gv, red1);
+                    comm->allreduce_sum(red1, 1, stream);
+                    dot_arr = red1; dot_np = 1;
+                }
             }
-            dot(w.t.p, w.t.p);
             hipLaunchKernelGGL((k_gm_normalize<S>), dim3(gv), dim3(kBlock), 0, stream, n, (i + 1) * m + i, 0, 0.0, dot_arr, dot_np, g.H, g.s,
                                (const S*)w.t.p, V(i + 1), d_ctl, h_ctl_dev);
             const int tick = ++tick_seq;
@@ -2178,6 +2305,9 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
     res.reduction = norm0 > 0 ? norm / norm0 : 0.0;
     if (h_ctl->flag != 0 || !(norm0 == norm0)) res.status = OPMGPU_EBREAKDOWN;
     else if (!res.converged && !prm.ignore_convergence_failure) res.status = OPMGPU_ELINSOLVE;
+    last_its = res.iterations;              // the back-off of the lag policy, as at the end of bicgstab (see cpr_prepare)
+    if (refreshed) its_ref = res.iterations;
+    else if (coarse_lag == 1 && last_its > its_ref + std::max(1, its_ref / 4)) lag_block = 8;
     return res;
 }
 
