@@ -578,7 +578,8 @@ void AmgHierarchy<S>::galerkin(bool coarse_levels)
         AmgLevel<S>& F = *levels[l]; AmgLevel<S>& C = *levels[l + 1];
         hipLaunchKernelGGL((k_amg_dinv<S>), dim3(grid_for(F.ntot())), dim3(kBlock), 0, stream, F.ntot(), F.diag_entry.p, F.val.p, F.dinv.p);
         if (!coarse_levels) return;           // (experiment OPMGPU_AMG_LAG_COARSE) level 0 follows the matrix, the coarse operators lag
-        if (F.nentries_coarse > 400000)
+        static const int wave_below = std::getenv("OPMGPU_AMG_GALERKIN_WAVE") ? std::atoi(std::getenv("OPMGPU_AMG_GALERKIN_WAVE")) : 400000;
+        if (F.nentries_coarse > wave_below)
             hipLaunchKernelGGL((k_amg_galerkin<S>), dim3(grid_for(F.nentries_coarse)), dim3(kBlock), 0, stream, F.nentries_coarse,
                                F.contrib_ptr.p, F.contrib_idx.p, coarse_dev[l]->p, F.val.p, C.val.p);
         else
