@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="take the domain-decomposition code path (torch.distributed + RCCL communicator) even with one rank")
     ap.add_argument("--cpu-threads", type=int, default=1)
+    ap.add_argument("--call-by-call", action="store_true", help="drive every Newton iteration through the seven single C calls instead of opmgpu_nonlinear_iteration")
     args = ap.parse_args()
 
     import numpy as np
@@ -106,6 +107,7 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    GpuBlackoilModel.fused_iteration = not args.call_by_call       # one library call per Newton iteration (the same sequence, fewer host round trips)
     if args.deck == "spe10like":
         args.nx, args.ny, args.nz = 60, 220, 85
     ordering = capi.ORDER_MULTICOLOR if args.ordering == "multicolor" else capi.ORDER_NATURAL

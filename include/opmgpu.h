@@ -428,6 +428,27 @@ int opmgpu_comm_init_transport(opmgpu_ctx* ctx, int rank, int nranks, const opmg
                                int n_neigh, const int32_t* neigh_rank, const int32_t* send_ptr,
                                const int32_t* send_cells, const int32_t* recv_ptr, const int32_t* recv_cells);
 
+/* ----------------------------------------------------------------------------------------
+ * One whole Newton iteration in one call: BlackoilModelBase::nonlinearIteration (BlackoilModelBase_impl.hpp:239-326) with the
+ * update stabilisation of NonlinearSolver (NonlinearSolver_impl.hpp:221-301) --
+ *   iteration == 0: the residual-norm history and the relaxation factor are reset;
+ *   assemble(initial = iteration == 0) -> getConvergence (reservoir, and the wells of the device well model) ->
+ *   if not converged, or iteration < min_iter:  solveJacobianSystem -> detectOscillations -> stabilizeNonlinearUpdate -> updateState.
+ * It is the sequence opmgpu_set_solve_precision / assemble / convergence / well_convergence / solve / stabilize_update / update_state
+ * that the host mirrors issue call by call (opmgpu/model.py, host/opmgpu.hpp), with the host round trips between them inside the
+ * library: the GPU idles ~0.1 ms per iteration less.  The history lives in the context.  Status codes as for the single calls.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct opmgpu_newton_ctl {
+    int32_t min_iter;                  /* 1   (NonlinearSolver: min_iter_) */
+    int32_t use_update_stabilization;  /* 1   (BlackoilModelParameters::use_update_stabilization_) */
+    int32_t relax_type;                /* OPMGPU_RELAX_DAMPEN */
+    double  relax_max;                 /* 0.5 */
+    double  relax_increment;           /* 0.1 */
+    double  relax_rel_tol;             /* 0.2 */
+} opmgpu_newton_ctl;
+int opmgpu_nonlinear_iteration(opmgpu_ctx* ctx, double dt, int iteration, int single_precision, const opmgpu_newton_ctl* ctl,
+                               int* converged, int* linear_iterations, double* linf3 /* may be NULL */, double* relaxation /* may be NULL */);
+
 /* Host-only planning entry (no device needed): elimination position and level of every row for
  * the given ordering -- the same plan opmgpu_get_ordering reports for a loaded matrix. */
 int opmgpu_plan_ordering(int nb, const int32_t* rowptr, const int32_t* col, int ordering,

@@ -1295,8 +1295,7 @@ int BlackoilDevice::convergence(double dt, double* B3, double* CNV3, double* MB3
     hipLaunchKernelGGL(k_conv_final, dim3(13), dim3(kBlock), 0, stream, g, d_red.p + 16, d_red.p);
     ls.kt.end(KT_CONV, kt_a);
     if (ls.comm) { ls.comm->allreduce_sum(d_red.p, 7, stream); ls.comm->allreduce_max(d_red.p + 7, 6, stream); }
-    OPMGPU_HIP(hipMemcpyAsync(h_red, d_red.p, 13 * sizeof(double), hipMemcpyDeviceToHost, stream));
-    OPMGPU_HIP(hipStreamSynchronize(stream));
+    std::memcpy(h_red, ls.fetch_words(d_red.p, 26), 13 * sizeof(double));          // (polled host-mapped copy: no stream synchronisation)
     bool conv = true; int status = OPMGPU_OK;
     const double ncg = ls.comm ? double(ls.comm->n_owned_global) : double(nc);
     const double pvs = ls.comm ? pvsum_global : pvsum;

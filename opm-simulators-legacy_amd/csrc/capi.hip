@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <array>
 #include <memory>
 #include <string>
 
@@ -31,6 +32,9 @@ struct opmgpu_ctx {
     bool ev_pending[3] = { false, false, false };
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::unique_ptr<RcclComm> comm;   // multi-GPU (dist.hip); empty = single GPU
+    // opmgpu_nonlinear_iteration: residual_norms_history_ / current_relaxation_ of BlackoilModelBase (:244-247, :300-315)
+    std::vector<std::array<double, 3>> norm_history;
+    double relaxation = 1.0;
 };
 
 namespace {
@@ -312,6 +316,59 @@ int opmgpu_well_convergence(opmgpu_ctx* c, double* flux3, double* ctrl)
 {
     if (!c || !c->model) return OPMGPU_EINVAL;
     return guarded(c, [&]() { return c->model->well_convergence(flux3, ctrl); });
+}
+
+int opmgpu_nonlinear_iteration(opmgpu_ctx* c, double dt, int iteration, int single_precision, const opmgpu_newton_ctl* ctl, int* converged,
+                               int* linear_iterations, double* linf3, double* relaxation)
+{
+    if (!c || !c->model || !ctl || !converged || iteration < 0) return OPMGPU_EINVAL;
+    if (iteration == 0) { c->norm_history.clear(); c->relaxation = 1.0; }
+    if (int(c->norm_history.size()) != iteration) return fail(c, OPMGPU_EINVAL, "opmgpu_nonlinear_iteration: iterations of a time step must be consecutive from 0");
+    *converged = 0;
+    if (linear_iterations) *linear_iterations = 0;
+    int st = opmgpu_set_solve_precision(c, single_precision);
+    if (st == OPMGPU_OK) st = opmgpu_assemble(c, dt, iteration == 0 ? 1 : 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (st != OPMGPU_OK) return st;
+    double B[3], CNV[3], MB[3], linf[3];
+    int conv = 0;
+    st = opmgpu_convergence(c, dt, B, CNV, MB, linf, &conv);
+    if (st != OPMGPU_OK) return st;
+    if (c->model->has_device_wells()) {                    // getWellConvergence (:1769-1779)
+        double flux[3], ctrl = 0.0;
+        st = opmgpu_well_convergence(c, flux, &ctrl);
+        if (st != OPMGPU_OK) return st;
+        bool ok = ctrl < c->prm.tolerance_well_control;
+        for (int a = 0; a < 3; ++a) ok = ok && (B[a] * flux[a] < c->prm.tolerance_wells);
+        conv = conv && ok;
+    }
+    c->norm_history.push_back({ linf[0], linf[1], linf[2] });
+    if (linf3) for (int a = 0; a < 3; ++a) linf3[a] = linf[a];
+    *converged = conv;
+    if (!conv || iteration < ctl->min_iter) {
+        int its = 0;
+        st = opmgpu_solve(c, single_precision, nullptr, &its, nullptr);
+        if (linear_iterations) *linear_iterations = its;
+        if (st != OPMGPU_OK) return st;
+        if (ctl->use_update_stabilization) {
+            // detectOscillations (NonlinearSolver_impl.hpp:221-257): only the three mass-balance norms take part
+            bool oscillate = false;
+            if (iteration >= 2) {
+                const auto &F0 = c->norm_history[iteration], &F1 = c->norm_history[iteration - 1], &F2 = c->norm_history[iteration - 2];
+                int n_osc = 0;
+                for (int p = 0; p < 3; ++p) {
+                    const double d1 = std::fabs((F0[p] - F2[p]) / F0[p]), d2 = std::fabs((F0[p] - F1[p]) / F0[p]);
+                    n_osc += (d1 < ctl->relax_rel_tol) && (ctl->relax_rel_tol < d2);
+                }
+                oscillate = n_osc > 1;
+            }
+            if (oscillate) c->relaxation = std::max(c->relaxation - ctl->relax_increment, ctl->relax_max);
+            st = opmgpu_stabilize_update(c, ctl->relax_type, c->relaxation);
+            if (st != OPMGPU_OK) return st;
+        }
+        st = opmgpu_update_state(c, nullptr, 1.0);
+    }
+    if (relaxation) *relaxation = c->relaxation;
+    return st;
 }
 
 int opmgpu_save_state(opmgpu_ctx* c)

@@ -908,6 +908,8 @@ LinSolver::LinSolver(hipStream_t s) : stream(s)
     OPMGPU_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_tick), sizeof(int), hipHostMallocMapped));
     *h_tick = 0;
     OPMGPU_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h_tick_dev), h_tick, 0));
+    OPMGPU_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_pub), kPubWords * sizeof(uint32_t), hipHostMallocMapped));
+    OPMGPU_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h_pub_dev), h_pub, 0));
     if (const char* e = std::getenv("OPMGPU_POLL")) poll_status = std::atoi(e) != 0;
     ctl.alloc(1); ctl.zero(stream);
     OPMGPU_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_flags), 4 * sizeof(int32_t)));
@@ -931,6 +933,7 @@ LinSolver::~LinSolver()
 {
     if (h_ctl) (void)hipHostFree(h_ctl);
     if (h_tick) (void)hipHostFree(h_tick);
+    if (h_pub) (void)hipHostFree(h_pub);
     if (h_flags) (void)hipHostFree(h_flags);
     if (ev[0]) (void)hipEventDestroy(ev[0]);
     if (ev[1]) (void)hipEventDestroy(ev[1]);
@@ -1835,6 +1838,31 @@ void LinSolver::wait_tick(int tick)
     OPMGPU_HIP(hipStreamSynchronize(stream));
 }
 
+__global__ __launch_bounds__(kBlock) void k_fetch_words(const uint32_t* __restrict__ s0, int n0, const uint32_t* __restrict__ s1, int n1, uint32_t* __restrict__ dst,
+                                                        int* __restrict__ tick_ptr, int tick)
+{
+    for (int i = threadIdx.x; i < n0; i += kBlock) dst[i] = s0[i];
+    for (int i = threadIdx.x; i < n1; i += kBlock) dst[n0 + i] = s1[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) { __threadfence_system(); *(volatile int*)tick_ptr = tick; }
+}
+const uint32_t* LinSolver::fetch_words(const void* src0, int nwords0, const void* src1, int nwords1)
+{
+    if (nwords0 + nwords1 > kPubWords) throw HipError(OPMGPU_EINVAL, "fetch_words: too many words");
+    if (!poll_status) {
+        if (nwords0) OPMGPU_HIP(hipMemcpyAsync(h_pub, src0, size_t(nwords0) * 4, hipMemcpyDeviceToHost, stream));
+        if (nwords1) OPMGPU_HIP(hipMemcpyAsync(h_pub + nwords0, src1, size_t(nwords1) * 4, hipMemcpyDeviceToHost, stream));
+        OPMGPU_HIP(hipStreamSynchronize(stream));
+        return h_pub;
+    }
+    const int tick = ++tick_seq;
+    hipLaunchKernelGGL(k_fetch_words, dim3(1), dim3(kBlock), 0, stream, static_cast<const uint32_t*>(src0), nwords0, static_cast<const uint32_t*>(src1), nwords1, h_pub_dev,
+                       h_tick_dev, tick);
+    wait_tick(tick);
+    return h_pub;
+}
+
 template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
 {
     SolverWork<S>& w = work<S>();
@@ -2297,7 +2325,9 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
             normalize_start(0);
         }
     }
-    OPMGPU_HIP(hipStreamSynchronize(stream));
+    // the status block is current (the last iteration's tick was waited for); what is still in flight (the combination of the basis
+    // vectors into x) is ordered before everything the caller enqueues next on this stream.  Without polling: synchronise.
+    if (!poll_status || !stop) OPMGPU_HIP(hipStreamSynchronize(stream));
     if (comm) comm->check_async();
     const double norm0 = std::sqrt(h_ctl->norm0_2), norm = std::sqrt(h_ctl->norm2);
     res.converged = h_ctl->done && h_ctl->flag == 0;

@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 
 namespace opmgpu {
 
@@ -1008,6 +1009,8 @@ void BlackoilDevice::wells_assemble(bool initial)
 }
 
 // well part of getConvergence (BlackoilModelBase_impl.hpp:1769-1779): max |flux equation| per phase, max |control equation|
+bool BlackoilDevice::has_device_wells() const { return wd != nullptr || ls.run_has_wells; }
+
 int BlackoilDevice::well_convergence(double* flux3, double* ctrl)
 {
     if (!wd && !ls.comm) return OPMGPU_EINVAL;
@@ -1015,10 +1018,16 @@ int BlackoilDevice::well_convergence(double* flux3, double* ctrl)
     bool bad = false, singular = false;
     if (wd) {
         WellsDev& W = *wd;
-        OPMGPU_HIP(hipMemcpyAsync(W.h_pinned, W.wellE.p, 4 * size_t(W.nw) * sizeof(double), hipMemcpyDeviceToHost, stream));
         int32_t fl = 0;
-        OPMGPU_HIP(hipMemcpyAsync(&fl, W.flags.p + WF_ERR, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-        OPMGPU_HIP(hipStreamSynchronize(stream));
+        if (8 * W.nw + 1 <= LinSolver::kPubWords) {
+            const uint32_t* h = ls.fetch_words(W.wellE.p, 8 * W.nw, W.flags.p + WF_ERR, 1);
+            std::memcpy(W.h_pinned, h, 4 * size_t(W.nw) * sizeof(double));
+            std::memcpy(&fl, h + 8 * W.nw, sizeof(int32_t));
+        } else {
+            OPMGPU_HIP(hipMemcpyAsync(W.h_pinned, W.wellE.p, 4 * size_t(W.nw) * sizeof(double), hipMemcpyDeviceToHost, stream));
+            OPMGPU_HIP(hipMemcpyAsync(&fl, W.flags.p + WF_ERR, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            OPMGPU_HIP(hipStreamSynchronize(stream));
+        }
         for (int w = 0; w < W.nw; ++w) {
             for (int a = 0; a < 3; ++a) { const double e = std::fabs(W.h_pinned[4 * w + a]); if (!(e == e)) bad = true; f[a] = std::max(f[a], e); }
             const double e = std::fabs(W.h_pinned[4 * w + 3]); if (!(e == e)) bad = true; c = std::max(c, e);

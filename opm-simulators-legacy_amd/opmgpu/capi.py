@@ -69,6 +69,11 @@ class Transport(C.Structure):
     _fields_ = [("self", C.c_void_p), ("allreduce", C.c_void_p), ("exchange", C.c_void_p), ("destroy", C.c_void_p)]
 
 
+class NewtonCtl(C.Structure):
+    _fields_ = [("min_iter", C.c_int32), ("use_update_stabilization", C.c_int32), ("relax_type", C.c_int32),
+                ("relax_max", C.c_double), ("relax_increment", C.c_double), ("relax_rel_tol", C.c_double)]
+
+
 class Params(C.Structure):
     _fields_ = [("dp_max_rel", C.c_double), ("ds_max", C.c_double), ("dr_max_rel", C.c_double),
                 ("max_residual_allowed", C.c_double), ("tolerance_mb", C.c_double),
@@ -139,6 +144,7 @@ SIGNATURES = {
     "opmgpu_solve": (C.c_int, [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int), _dp]),
     "opmgpu_update_state": (C.c_int, [C.c_void_p, _dp, C.c_double]),
     "opmgpu_stabilize_update": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
+    "opmgpu_nonlinear_iteration": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_int, C.POINTER(NewtonCtl), C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, _dp]),
     "opmgpu_update_hysteresis": (C.c_int, [C.c_void_p]),
     "opmgpu_set_hysteresis": (C.c_int, [C.c_void_p, _dp, _dp]),
     "opmgpu_get_hysteresis": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp]),

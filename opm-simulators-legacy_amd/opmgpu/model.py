@@ -253,6 +253,8 @@ class GpuBlackoilModel:
         """nonlinearIteration (BlackoilModelBase_impl.hpp:239-326). Returns (converged, linear_iterations).
         With a `NonlinearSolver` the update is stabilised exactly like the reference's use_update_stabilization path."""
         ns = nonlinear_solver
+        if self.fused_iteration and ns is not None:
+            return self._fused_iteration(iteration, single_precision, ns)
         if iteration == 0:
             self.residual_norms_history, self.current_relaxation = [], 1.0
         self.setSolvePrecision(single_precision)
@@ -270,6 +272,23 @@ class GpuBlackoilModel:
                 self.stabilizeUpdate(ns.relax_type, self.current_relaxation)
             self.updateState()
         return converged, lin
+
+    # the same iteration through ONE library call (opmgpu_nonlinear_iteration): the host round trips between the phases stay inside the
+    # library.  Off by default here (the call-by-call sequence above is what the parity tests walk); bench.py switches it on.
+    fused_iteration = False
+
+    def _fused_iteration(self, iteration, single_precision, ns):
+        if single_precision is None:
+            single_precision = self.dt < self.max_single_precision_days * 86400.0
+        ctl = capi.NewtonCtl(int(ns.min_iter), int(self.use_update_stabilization), int(ns.relax_type), float(ns.relax_max), float(ns.relax_increment),
+                             float(ns.relax_rel_tol))
+        conv, lin, relax = C.c_int(0), C.c_int(0), C.c_double(1.0)
+        linf = np.zeros(3)
+        st = self.lib.opmgpu_nonlinear_iteration(self.ctx, self.dt, int(iteration), int(bool(single_precision)), C.byref(ctl), C.byref(conv), C.byref(lin),
+                                                 capi.dptr(linf), C.byref(relax))
+        self.linear_iterations, self.linf, self.current_relaxation = lin.value, linf, relax.value
+        self._chk(st)
+        return bool(conv.value), lin.value
 
     # --- parity / bench helpers --------------------------------------------------------------
     def residual(self):

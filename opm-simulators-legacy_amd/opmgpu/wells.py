@@ -643,6 +643,10 @@ class DeviceWellModel:
 
     def nonlinearIteration(self, iteration, single_precision=None, nonlinear_solver=None):
         m, ns = self.m, nonlinear_solver
+        if getattr(m, "fused_iteration", False) and ns is not None and (self.tol_wells, self.tol_ctrl) == (m.params.tolerance_wells, m.params.tolerance_well_control):
+            converged, lin = m._fused_iteration(iteration, single_precision, ns)          # the library checks the wells' convergence itself
+            self.linear_iterations, self.current_relaxation = lin, m.current_relaxation
+            return converged, lin
         if iteration == 0:
             self.residual_norms_history, self.current_relaxation = [], 1.0
         m.setSolvePrecision(single_precision)

@@ -246,3 +246,44 @@ def test_stabilized_update_relaxes_the_well_increment_too(gpu_lib, oracle):
             assert np.allclose(ws.bhp, mo.ws.bhp, rtol=1e-7) and np.allclose(ws.qs, mo.ws.qs, rtol=1e-6, atol=1e-9 * np.abs(mo.ws.qs).max()), (relax_type, it)
         assert md.current_relaxation == pytest.approx(0.7) and mo.current_relaxation == pytest.approx(0.7)
     gm.close()
+
+
+@pytest.mark.parametrize("with_wells", [True, False])
+def test_one_call_newton_iteration_equals_the_call_by_call_sequence(gpu_lib, with_wells):
+    """opmgpu_nonlinear_iteration (the whole of BlackoilModelBase::nonlinearIteration + the NonlinearSolver's update stabilisation in one
+    library call) against the seven single calls the host mirrors issue: same convergence flags, iteration counts, relaxation, and
+    bit-identical reservoir and well states over a time step that needs relaxing."""
+    from opmgpu.model import NonlinearSolver
+    grid, tab, st, wl = _setup()
+    prm = capi.default_params(use_cpr=1)
+    out = []
+    for fused in (False, True):
+        gm = GpuBlackoilModel(grid, tab, prm)
+        gm.fused_iteration = fused
+        md = W.DeviceWellModel(gm, wl, W.WellState(wl, st.p)) if with_wells else gm
+        ns = NonlinearSolver(relax_rel_tol=1e9)        # "oscillation" from the third iteration on whenever two norms moved: the relaxation path runs
+        md.prepareStep(20 * decks.DAY, st)
+        hist = []
+        for it in range(7):
+            conv, lin = md.nonlinearIteration(it, single_precision=True, nonlinear_solver=ns)
+            hist.append((bool(conv), int(lin), float(md.current_relaxation)))
+            if conv and it >= ns.min_iter:
+                break
+        s = gm.getState()
+        ws = md.pull_well_state() if with_wells else None
+        out.append((hist, s, ws))
+        gm.close()
+    (h0, s0, w0), (h1, s1, w1) = out
+    assert h0 == h1, (h0, h1)
+    assert np.array_equal(s0.p, s1.p) and np.array_equal(s0.sat, s1.sat) and np.array_equal(s0.hc, s1.hc)
+    if with_wells:
+        assert np.array_equal(w0.bhp, w1.bhp) and np.array_equal(w0.qs, w1.qs)
+    lib = capi.load()
+    ctl = capi.NewtonCtl(1, 1, capi.RELAX_DAMPEN, 0.5, 0.1, 0.2)
+    gm = GpuBlackoilModel(grid, tab, prm)
+    gm.prepareStep(5 * decks.DAY, st)
+    import ctypes as C
+    conv, lin = C.c_int(0), C.c_int(0)
+    # iterations of a step must be consecutive from 0
+    assert lib.opmgpu_nonlinear_iteration(gm.ctx, gm.dt, 1, 1, C.byref(ctl), C.byref(conv), C.byref(lin), None, None) == capi.EINVAL
+    gm.close()
