@@ -2282,9 +2282,10 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
     hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(1), 0, stream, d_ctl, h_ctl_dev, prm.linear_solver_reduction);
     precond(w.b.p, w.t.p);
     normalize_start(1);
-    OPMGPU_HIP(hipStreamSynchronize(stream));
+    // no synchronisation here: the first iteration is enqueued behind the set-up (factorisation, hierarchy, first application); a zero
+    // defect sets `done` on the device, the iteration's kernels then return at once and its status check reports 0 iterations
     int j = 1;
-    bool stop = h_ctl->done != 0;
+    bool stop = false;
     while (j <= maxit && !stop) {
         int i = 0;
         for (; i < m && j <= maxit && !stop; ++i, ++j) {
@@ -2315,6 +2316,7 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
             if (h_ctl->done) stop = true;
         }
         if (h_ctl->flag != 0) break;                                   // breakdown: dune throws, no update
+        if (h_ctl->done && h_ctl->iters == 0) break;                   // zero defect: x = 0 is the solution, no column was built
         // x += sum_a y_a v_a with R y = s   (i columns were completed)
         hipLaunchKernelGGL(k_gm_solve_y, dim3(1), dim3(1), 0, stream, i, m, g);
         hipLaunchKernelGGL((k_gm_update_x<S>), dim3(gv), dim3(kBlock), 0, stream, n, i, (const double*)g.y, (const S*)w.kry.p, w.x.p);
@@ -2331,7 +2333,7 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
     if (comm) comm->check_async();
     const double norm0 = std::sqrt(h_ctl->norm0_2), norm = std::sqrt(h_ctl->norm2);
     res.converged = h_ctl->done && h_ctl->flag == 0;
-    res.iterations = j - 1;
+    res.iterations = (h_ctl->done && h_ctl->flag == 0) ? h_ctl->iters : j - 1;
     res.reduction = norm0 > 0 ? norm / norm0 : 0.0;
     if (h_ctl->flag != 0 || !(norm0 == norm0)) res.status = OPMGPU_EBREAKDOWN;
     else if (!res.converged && !prm.ignore_convergence_failure) res.status = OPMGPU_ELINSOLVE;

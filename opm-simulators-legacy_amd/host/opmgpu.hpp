@@ -124,6 +124,16 @@ public:
     /// once per report step, where SimulatorBase::run calls props.updateSatOilMax / updateSatHyst (SimulatorBase_impl.hpp:190-192)
     void updateSatOilMax() { throw_on_status(ctx_, opmgpu_update_sat_oil_max(ctx_)); }
     void updateSatHyst() { throw_on_status(ctx_, opmgpu_update_hysteresis(ctx_)); }
+    /// BlackoilModelBase::nonlinearIteration + the NonlinearSolver's update stabilisation in ONE library call (opmgpu_nonlinear_iteration):
+    /// the same sequence NonlinearSolverGpu::step issues call by call, without the host round trips between the phases.
+    /// Returns true when the iteration found the step converged; throws like the single calls do.
+    bool nonlinearIterationOneCall(int iteration, bool single_precision, const opmgpu_newton_ctl& ctl, int* linear_iterations = nullptr)
+    {
+        int conv = 0, lin = 0;
+        throw_on_status(ctx_, opmgpu_nonlinear_iteration(ctx_, dt_, iteration, single_precision ? 1 : 0, &ctl, &conv, &lin, nullptr, nullptr));
+        if (linear_iterations) *linear_iterations = lin;
+        return conv != 0;
+    }
     /// well part of getConvergence (:1769-1779)
     bool wellsConverged(const ConvergenceReport& r)
     {
