@@ -80,7 +80,10 @@ template <class S> int solve_loaded(opmgpu_ctx* c, bool matrix_changed, SolveRes
 {
     LinSolver& ls = *c->ls;
     ls.prepare<S>(matrix_changed);
-    (void)ls.factor<S>(false);           // status read below: the solver's own final synchronisation covers it
+    // next to the pressure stage's set-up (cpr_prepare, inside the solver); not in the emulated-decomposition diagnostics, whose cut copy of
+    // the matrix is built lazily by whichever of the two asks first
+    if (ls.factor_overlap && c->prm.use_cpr && ls.emulate_ranks <= 1) ls.factor_async<S>();
+    else (void)ls.factor<S>(false);      // status read below: the solver's own final synchronisation covers it
     res = c->prm.newton_use_gmres ? ls.gmres<S>(c->prm) : ls.bicgstab<S>(c->prm);
     if (res.status != OPMGPU_OK && c->prm.use_cpr && !ls.refreshed && ls.factor_status() == OPMGPU_OK) {
         // the solve ran on lagged coarse operators of the pressure hierarchy (LinSolver::cpr_prepare): once more on fresh ones

@@ -923,6 +923,7 @@ LinSolver::LinSolver(hipStream_t s) : stream(s)
     if (const char* e = std::getenv("OPMGPU_COARSE_BLOCKS")) cs_blocks_req = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("OPMGPU_CPR_HALO_XP")) cpr_halo_xp = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_HALO_OVERLAP")) halo_overlap = std::atoi(e) != 0;
+    if (const char* e = std::getenv("OPMGPU_FACTOR_OVERLAP")) factor_overlap = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_CS_RECUR")) cs_recur = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_AMG_AUTOTUNE")) amg_autotune = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_EMULATE_RANKS")) emulate_ranks = std::atoi(e);
@@ -939,6 +940,8 @@ LinSolver::~LinSolver()
     if (ev[1]) (void)hipEventDestroy(ev[1]);
     for (auto e : ev_halo) if (e) (void)hipEventDestroy(e);
     if (halo_stream) (void)hipStreamDestroy(halo_stream);
+    for (auto e : ev_factor) if (e) (void)hipEventDestroy(e);
+    if (factor_stream) (void)hipStreamDestroy(factor_stream);
 }
 
 template <> SolverWork<double>& LinSolver::work<double>() { return wd; }
@@ -1057,8 +1060,32 @@ template <class S> int LinSolver::factor(bool wait)
     return factor_status();
 }
 
+template <class S> void LinSolver::factor_async()
+{
+    if (!factor_stream) {
+        OPMGPU_HIP(hipStreamCreateWithFlags(&factor_stream, hipStreamNonBlocking));
+        for (auto& e : ev_factor) OPMGPU_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    OPMGPU_HIP(hipEventRecord(ev_factor[0], stream));
+    OPMGPU_HIP(hipStreamWaitEvent(factor_stream, ev_factor[0], 0));
+    std::swap(stream, factor_stream);
+    const bool timing = kt.on; kt.on = false;            // (event brackets belong to the main stream)
+    (void)factor<S>(false);
+    kt.on = timing;
+    std::swap(stream, factor_stream);
+    OPMGPU_HIP(hipEventRecord(ev_factor[1], factor_stream));
+    factor_pending = true;
+}
+void LinSolver::join_factor()
+{
+    if (!factor_pending) return;
+    OPMGPU_HIP(hipStreamWaitEvent(stream, ev_factor[1], 0));
+    factor_pending = false;
+}
+
 template <class S> void LinSolver::ilu_apply(const S* d, S* v, double relax, const SolveCtl* ctl)
 {
+    join_factor();
     KtScope kts(kt, KT_ILU_APPLY);
     SolverWork<S>& w = work<S>();
     const int L = plan.nlevels;
@@ -2470,6 +2497,7 @@ double LinSolver::time_kernel(int kernel, int reps, int single_precision)
     template void LinSolver::coarse_setup<S>(bool);                                      \
     template void LinSolver::coarse_begin<S>();                                          \
     template void LinSolver::cpr_apply<S>(const S*, S*, double, const SolveCtl*, const double*);        \
+    template void LinSolver::factor_async<S>();                                          \
     template SolveResult LinSolver::bicgstab<S>(const opmgpu_params&);                   \
     template SolveResult LinSolver::gmres<S>(const opmgpu_params&);                      \
     template void LinSolver::vec_from_host<S>(const double*, int, S*);                   \

@@ -215,6 +215,13 @@ public:
     // multi-GPU: the halo exchange of the SpMV input runs on its own stream while the rows without a ghost neighbour are multiplied
     // (k_spmv phase 1); the rows next to a cut follow the exchange (phase 2).  A/B: OPMGPU_HALO_OVERLAP=0 serialises them on `stream`.
     bool halo_overlap = true;
+    // ILU0 factorisation on a second stream next to the set-up of the pressure stage (both only read the matrix); the first ILU0
+    // application joins.  A/B: OPMGPU_FACTOR_OVERLAP
+    bool factor_overlap = true, factor_pending = false;
+    hipStream_t factor_stream = nullptr;
+    hipEvent_t ev_factor[2] = { nullptr, nullptr };
+    template <class S> void factor_async();
+    void join_factor();
     // multi-GPU CPR with the subdomain coarse space: the restricted residual of the vector a preconditioner application starts from is
     // carried by the BiCGStab recurrences (it is linear in the vector), so only <W_b, A y> has to be summed over the ranks -- together
     // with the scalar products the iteration all-reduces anyway: 3 all-reduces per iteration instead of 5.  A/B: OPMGPU_CS_RECUR=0.
