@@ -144,6 +144,16 @@ int main()
         }
         std::printf("host_check: wells: injector bhp %.1f bar at %.2f m3/d water, producer %.2f m3/d oil at %.1f bar\n", bhp[0] / 1e5, qs[0] * 86400.0,
                     -qs[4] * 86400.0, bhp[1] / 1e5);
+        // one more 2-day step driven through the one-call Newton iteration (opmgpu_nonlinear_iteration) from the resident state
+        {
+            opmgpu_newton_ctl ctl{};
+            ctl.min_iter = 1; ctl.use_update_stabilization = 1; ctl.relax_type = OPMGPU_RELAX_DAMPEN; ctl.relax_max = 0.5; ctl.relax_increment = 0.1; ctl.relax_rel_tol = 0.2;
+            model.prepareStep(2 * 86400.0);
+            int it = 0, lin = 0; bool conv = false;
+            do { conv = model.nonlinearIterationOneCall(it, true, ctl, &lin); ++it; } while ((!conv && it <= 10) || it <= ctl.min_iter);
+            if (!conv) { std::printf("host_check: FAILED, the one-call Newton loop did not converge in %d iterations\n", it); return 1; }
+            std::printf("host_check: one-call Newton loop: 2-day step converged in %d iterations\n", it);
+        }
         std::printf("host_check: report step of 20 d in %zu sub-steps (first %.2f d, last %.2f d), %d failed, next suggestion %.2f d\n",
                     ats.substeps.size(), ats.substeps.front() / 86400.0, ats.substeps.back() / 86400.0, ats.failed_substeps,
                     ats.suggested_next_timestep / 86400.0);

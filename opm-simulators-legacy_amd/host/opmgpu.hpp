@@ -151,6 +151,8 @@ public:
         dt_ = dt;
         throw_on_status(ctx_, opmgpu_set_state(ctx_, s.pressure, s.saturation, s.gasoilratio, s.rv, s.hydroCarbonState));
     }
+    /// the next time step from the state that is resident on the device (AdaptiveTimeStepping's sub-steps)
+    void prepareStep(double dt) { dt_ = dt; }
     void assemble(bool initial_assembly) { throw_on_status(ctx_, opmgpu_assemble(ctx_, dt_, initial_assembly ? 1 : 0, nullptr, nullptr, nullptr, nullptr, nullptr)); }
     ConvergenceReport getConvergence()
     {
