@@ -148,9 +148,14 @@ typedef struct opmgpu_params {
     double tolerance_wells;         /* 1e-4   */
     double tolerance_well_control;  /* 1e-7   */
     double dbhp_max_rel;            /* 1.0    */
+    int32_t update_equations_scaling; /* 0; 1: matbalscale[a] = mean over the cells of 1 / b_a of the state being assembled
+                                         (BlackoilModelBase::updateEquationsScaling, BlackoilModelBase_impl.hpp:909, :919-947); the values in
+                                         use are read back with opmgpu_get_matbalscale */
 } opmgpu_params;
 
 void opmgpu_default_params(opmgpu_params* p);
+/* the equation scaling the last assembly used (== params.matbalscale unless update_equations_scaling) */
+int opmgpu_get_matbalscale(opmgpu_ctx* ctx, double* scale3);
 
 /* ------------------------------------------------------------------------------------------
  * B2 boundary: BlackoilModel hooks (BlackoilModelBase_impl.hpp:239-326: assemble ->

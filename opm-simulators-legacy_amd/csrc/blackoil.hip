@@ -1214,7 +1214,7 @@ void BlackoilDevice::get_state(double* p, double* sat, double* rs, double* rv, i
     }
 }
 
-template <class MS> void BlackoilDevice::assemble_kernels(double dt, bool initial, MS* A)
+template <class MS> void BlackoilDevice::assemble_kernels(double dt, bool initial, MS* A, bool props_only)
 {
     const Plan& P = ls.plan;
     const double* sc = prm.matbalscale;
@@ -1228,6 +1228,7 @@ template <class MS> void BlackoilDevice::assemble_kernels(double dt, bool initia
                        ls.dp.slice_ptr.p, ls.dp.nlower.p, eps_planes(), d_eps_u0.p, d_somax.p, d_props.p, pd, d_accum0.p, d_R.p, d_binv.p, A,
                        (const double*)d_tab.p, tab_lds_words(), hyst_args());
     ls.kt.end(KT_CELL_PROPS, kt_a);
+    if (props_only) return;
     KtScope kts(ls.kt, KT_FLUX);
     hipLaunchKernelGGL((k_flux<MS>), dim3(grid8_for(nc)), dim3(kBlock), 0, stream, xcd_mode(), nc, P.nbp, ls.dp.slice_ptr.p, ls.dp.col.p, ls.dp.rowlen.p,
                        ls.dp.nlower.p, d_conn_code.p, d_trans.p, d_gdz.p, use_thpres ? d_thpres.p : (const double*)nullptr,
@@ -1253,6 +1254,17 @@ void BlackoilDevice::assemble(double dt, bool initial)
     const bool host_wells = nperf > 0 && !device_wells;
     ls.coarse_single_ok = nperf == 0;          // no wells of either kind: the global constant is the near-null-space vector
     ls.matrix_is_float = assemble_single && !host_wells;
+    if (prm.update_equations_scaling) {
+        // updateEquationsScaling (BlackoilModelBase_impl.hpp:919-947; default off): every equation scaled by the mean 1/b of its phase in the
+        // state being assembled.  The reference sets it at the end of assemble() and its linear solver scales this assembly's system with
+        // it; here the scaling is applied while the Jacobian is written, so the mean is taken first: one extra property pass (it fills
+        // d_binv), the three sums, then the assembly proper with the new factors (wells and right-hand side read prm.matbalscale too).
+        if (ls.matrix_is_float) assemble_kernels<float>(dt, initial, ls.matrix_f(), true);
+        else assemble_kernels<double>(dt, initial, ls.matrix_d(), true);
+        double B[3];
+        average_b(B);
+        for (int a = 0; a < 3; ++a) prm.matbalscale[a] = B[a];
+    }
     if (ls.matrix_is_float) assemble_kernels<float>(dt, initial, ls.matrix_f());
     else assemble_kernels<double>(dt, initial, ls.matrix_d());
     KtScope kts(ls.kt, KT_WELLS);

@@ -32,7 +32,7 @@ public:
     void set_state(const double* p, const double* sat, const double* rs, const double* rv, const int8_t* hc);
     void get_state(double* p, double* sat, double* rs, double* rv, int8_t* hc);
     void assemble(double dt, bool initial);
-    template <class MS> void assemble_kernels(double dt, bool initial, MS* A);
+    template <class MS> void assemble_kernels(double dt, bool initial, MS* A, bool props_only = false);
     bool assemble_single = false;      // precision of the coming solve (opmgpu_set_solve_precision)
     int convergence(double dt, double* B3, double* CNV3, double* MB3, double* linf3, int* converged);
     void perf_props(double* out);

@@ -119,7 +119,7 @@ void opmgpu_default_params(opmgpu_params* p)
     p->linear_solver_reduction = 1e-2; p->linear_solver_maxiter = 150;                    // FlowLinearSolverParameters
     p->ilu_relaxation = 0.9; p->ilu_ordering = OPMGPU_ORDER_MULTICOLOR; p->ignore_convergence_failure = 0; p->use_cpr = 0;
     p->newton_use_gmres = 0; p->linear_solver_restart = 40;                                // NewtonIterationBlackoilCPR.cpp:61-64
-    p->solve_welleq_initially = 1; p->tolerance_wells = 1e-4; p->tolerance_well_control = 1e-7; p->dbhp_max_rel = 1.0;   // BlackoilModelParameters.cpp:80-96
+    p->solve_welleq_initially = 1; p->tolerance_wells = 1e-4; p->tolerance_well_control = 1e-7; p->dbhp_max_rel = 1.0; p->update_equations_scaling = 0;   // BlackoilModelParameters.cpp:80-96
 }
 
 int opmgpu_create_solver(opmgpu_ctx** ctx, int device, const opmgpu_params* params) { return make_ctx(ctx, device, params); }
@@ -189,6 +189,13 @@ int opmgpu_assemble(opmgpu_ctx* c, double dt, int initial, const double* p, cons
         c->matrix_loaded = true; c->factored = false; c->cur_single = -1;
         return int(OPMGPU_OK);
     });
+}
+
+int opmgpu_get_matbalscale(opmgpu_ctx* c, double* scale3)
+{
+    if (!c || !c->model || !scale3) return OPMGPU_EINVAL;
+    for (int a = 0; a < 3; ++a) scale3[a] = c->model->prm.matbalscale[a];
+    return OPMGPU_OK;
 }
 
 int opmgpu_set_solve_precision(opmgpu_ctx* c, int single_precision)

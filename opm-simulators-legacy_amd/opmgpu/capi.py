@@ -83,7 +83,7 @@ class Params(C.Structure):
                 ("ignore_convergence_failure", C.c_int32), ("use_cpr", C.c_int32),
                 ("newton_use_gmres", C.c_int32), ("linear_solver_restart", C.c_int32),
                 ("solve_welleq_initially", C.c_int32), ("tolerance_wells", C.c_double), ("tolerance_well_control", C.c_double),
-                ("dbhp_max_rel", C.c_double)]
+                ("dbhp_max_rel", C.c_double), ("update_equations_scaling", C.c_int32)]
 
 
 def default_params(**over):
@@ -96,6 +96,7 @@ def default_params(**over):
     p.ilu_relaxation, p.ilu_ordering, p.ignore_convergence_failure, p.use_cpr = 0.9, ORDER_MULTICOLOR, 0, 0
     p.newton_use_gmres, p.linear_solver_restart = 0, 40
     p.solve_welleq_initially, p.tolerance_wells, p.tolerance_well_control, p.dbhp_max_rel = 1, 1e-4, 1e-7, 1.0
+    p.update_equations_scaling = 0
     for k, v in over.items():
         if k == "matbalscale":
             p.matbalscale[:] = list(v)
@@ -144,6 +145,7 @@ SIGNATURES = {
     "opmgpu_solve": (C.c_int, [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int), _dp]),
     "opmgpu_update_state": (C.c_int, [C.c_void_p, _dp, C.c_double]),
     "opmgpu_stabilize_update": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
+    "opmgpu_get_matbalscale": (C.c_int, [C.c_void_p, _dp]),
     "opmgpu_nonlinear_iteration": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_int, C.POINTER(NewtonCtl), C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, _dp]),
     "opmgpu_update_hysteresis": (C.c_int, [C.c_void_p]),
     "opmgpu_set_hysteresis": (C.c_int, [C.c_void_p, _dp, _dp]),

@@ -533,3 +533,52 @@ def test_satfunc_options_parity(gpu_lib, oracle, case):
         m.close()
     finally:
         oracle.set_hysteresis(None)
+
+
+@pytest.mark.parametrize("single", [False, True])
+def test_update_equations_scaling(gpu_lib, oracle, single):
+    """BlackoilModelBase::updateEquationsScaling (BlackoilModelBase_impl.hpp:909, :919-947; default off): matbalscale[a] = mean over the cells
+    of 1 / b_a of the state being assembled; the system of THAT assembly is scaled with it (the reference's linear solver reads
+    residual.matbalscale after assemble).  Device factors == the oracle's cell properties; Jacobian and right-hand side carry them."""
+    tab = decks.satfunc_standard_tables()
+    grid = decks.cartesian_grid(7, 6, 4, lognormal_sigma=0.6, seed=3)
+    st = decks.random_state(grid, tab, seed=5)
+    prm = capi.default_params(update_equations_scaling=1, linear_solver_reduction=1e-10, linear_solver_maxiter=400)
+    m = GpuBlackoilModel(grid, tab, prm)
+    dt = 2 * decks.DAY
+    m.prepareStep(dt, st)
+    m.setSolvePrecision(single)
+    for initial, state in ((True, st), (False, decks.random_state(grid, tab, seed=6))):
+        if not initial:
+            state.hc[:] = st.hc
+            m.setState(state)
+        m.assemble(initial)
+        props = oracle.cell_props(grid, tab, state)
+        want = np.array([np.mean(1.0 / props[:, oracle.PROP_NAMES.index("b_" + c), 0]) for c in "wog"])
+        got = np.zeros(3)
+        m._chk(m.lib.opmgpu_get_matbalscale(m.ctx, capi.dptr(got)))
+        assert np.allclose(got, want, rtol=1e-13), (got, want)
+        rowptr, col = oracle.pattern(grid)
+        if initial:
+            r, v, acc0, _ = oracle.assemble(grid, tab, dt, state, rowptr, col, scale=tuple(want))
+        else:
+            r, v, _, _ = oracle.assemble(grid, tab, dt, state, rowptr, col, scale=tuple(want), accum0=acc0)
+        _, _, gv = m.jacobian()
+        assert rel_err(gv, v) < (2e-6 if single else RTOL_JAC)
+        assert rel_err(m.residual(), r) < RTOL_JAC             # the residual itself is unscaled
+    # the solve uses the same factors for the right-hand side: its dx solves the oracle's scaled system
+    m.getConvergence()
+    dx = m.solveJacobianSystem(want_dx=True, single_precision=False) if not single else None
+    if dx is not None:
+        nc = grid.nc
+        b = np.ascontiguousarray((r * np.repeat(want, nc)).reshape(3, nc).T).ravel()
+        y = oracle.spmv(rowptr, col, v, np.ascontiguousarray(dx.reshape(3, nc).T).ravel())
+        assert np.abs(y - b).max() <= 1e-7 * np.abs(b).max()
+    m.close()
+    # off (the default): the constants of BlackoilModelBase_impl.hpp:139 stay
+    m = GpuBlackoilModel(grid, tab, capi.default_params())
+    m.prepareStep(dt, st); m.assemble(True)
+    got = np.zeros(3)
+    m._chk(m.lib.opmgpu_get_matbalscale(m.ctx, capi.dptr(got)))
+    assert np.array_equal(got, [1.1169, 1.0031, 0.0031])
+    m.close()
