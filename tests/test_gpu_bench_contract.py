@@ -1,0 +1,45 @@
+"""GPU: `python bench.py` on a small deck prints ONE JSON line that carries the driver's contract (metric / value / unit / n_gpus / steps /
+warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload) plus the `roofline` and `cpu_baseline`
+objects, and the same-run variants; the distributed code path with one rank prints the same contract."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*args):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--nx", "24", "--ny", "24", "--nz", "12", "--steps", "4", "--warmup", "1", "--rate", "10", *args],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract(gpu_lib):
+    d = _run()
+    assert d["metric"].startswith("Mcell-updates/sec") and d["unit"] == "Mcell-updates/s"
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and "f64" in d["dtype"]
+    assert d["value"] > 0 and abs(d["value"] - d["config"]["cells"] / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
+    assert d["config"]["workload"].startswith("cart24x24x12") and d["config"]["workload"].endswith("_fivespot") and "model" not in d["config"]
+    assert d["config"]["time_steps_not_converged"] == 0
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["traffic"] is None
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["kernel"].startswith("k_spmv")
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
+    v = d["same_run_variants"]
+    assert {"reference_default_solver_ilu0_with_wells", "without_wells", "cpr_bicgstab_with_wells"} <= set(v)
+    assert "classes" in d["kernel_table"] and "amg_vcycle" in d["kernel_table"]["classes"]
+
+
+def test_bench_distributed_path_with_one_rank(gpu_lib):
+    d = _run("--force-dist", "--only-main", "--no-cpu-baseline")
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "1 GPU"
+    assert d["config"]["linear_solver"].endswith("gmres(40)") and d["config"]["workload"].endswith("_fivespot")
