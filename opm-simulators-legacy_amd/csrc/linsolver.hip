@@ -739,11 +739,13 @@ __global__ __launch_bounds__(kBlock) void k_extract_pressure(int nb, int nbp, co
 template <class S, int CSM>
 __global__ __launch_bounds__(kBlock) void k_cpr_sum_eqs(int nb, int nbp, const S* __restrict__ d, const S* __restrict__ w, S* __restrict__ bp, S omega,
                                                         const S* __restrict__ dinv, S* __restrict__ x0, const SolveCtl* __restrict__ ctl,
-                                                        const int8_t* __restrict__ owned, const int8_t* __restrict__ blk, double* __restrict__ parts)
+                                                        const int8_t* __restrict__ owned, const int8_t* __restrict__ blk, double* __restrict__ parts,
+                                                        S* __restrict__ xw = nullptr, int nw = 0)
 {
     __shared__ double sm[32];
     if (ctl && ctl->done) return;
     const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < nw) xw[i] = S(0);              // bordered level 0: the wells' unknowns start from zero (a memset is two more launches)
     S b = S(0);
     if (i < nb) {
         b = w[i] * d[i] + w[nbp + i] * d[nbp + i] + w[2 * long(nbp) + i] * d[2 * long(nbp) + i];
@@ -1758,16 +1760,16 @@ template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, con
     const bool fused_rsum = coarse && !(!comm && emulate_ranks > 1) && g <= kCsRowParts;       // real coarse space: restriction fused into the kernel below
     hipEvent_t kt_a = kt.begin();
     double* const cs_parts = coarse ? cs_buf.p + size_t(2) * coarse_nsub * coarse_nsub + coarse_nsub : nullptr;   // own scratch (the BiCGStab partial arrays are live across an application)
-    if (L0.nw > 0) OPMGPU_HIP(hipMemsetAsync(L0.x.p + L0.n, 0, L0.nw * sizeof(S), stream));      // the wells' unknowns start from zero (their right-hand side is zero)
+    S* const xw = L0.nw > 0 ? L0.x.p + L0.n : (S*)nullptr;        // the wells' unknowns start from zero (their right-hand side is zero): k_cpr_sum_eqs clears them
     if (!fused_rsum)
         hipLaunchKernelGGL((k_cpr_sum_eqs<S, 0>), dim3(g), dim3(kBlock), 0, stream, plan.nb, plan.nbp, d, (const S*)w.cprw.p, L0.b.p, S(w.amg->omega0()), (const S*)L0.dinv.p, L0.x.p, ctl,
-                           (const int8_t*)nullptr, (const int8_t*)nullptr, (double*)nullptr);
+                           (const int8_t*)nullptr, (const int8_t*)nullptr, (double*)nullptr, xw, L0.nw);
     else if (cs_m > 1)
         hipLaunchKernelGGL((k_cpr_sum_eqs<S, 2>), dim3(g), dim3(kBlock), 0, stream, plan.nb, plan.nbp, d, (const S*)w.cprw.p, L0.b.p, S(w.amg->omega0()), (const S*)L0.dinv.p, L0.x.p, ctl,
-                           (const int8_t*)nullptr, (const int8_t*)cs_blk.p, cs_parts);
+                           (const int8_t*)nullptr, (const int8_t*)cs_blk.p, cs_parts, xw, L0.nw);
     else
         hipLaunchKernelGGL((k_cpr_sum_eqs<S, 1>), dim3(g), dim3(kBlock), 0, stream, plan.nb, plan.nbp, d, (const S*)w.cprw.p, L0.b.p, S(w.amg->omega0()), (const S*)L0.dinv.p, L0.x.p, ctl,
-                           comm ? comm->owner_mask() : (const int8_t*)nullptr, (const int8_t*)nullptr, cs_parts);
+                           comm ? comm->owner_mask() : (const int8_t*)nullptr, (const int8_t*)nullptr, cs_parts, xw, L0.nw);
     if (!w.amg->tuned) cpr_tune<S>();          // first right-hand side of this hierarchy: choose its correction factors
     if (coarse) {
         const int ns = coarse_nsub;
