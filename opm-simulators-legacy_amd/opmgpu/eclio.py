@@ -214,3 +214,46 @@ class EclOutput:
             write_array(f, "MINISTEP", "INTE", [self.ministep])
             write_array(f, "PARAMS", "REAL", params)
         self.ministep += 1
+
+
+def compare(base_a, base_b, abs_tol=2e-2, rel_tol=1e-5, restart_keywords=("PRESSURE", "SWAT", "SGAS", "RS", "RV")):
+    """What the reference's regression tests ask of two runs (tests/run-regressionTest.sh -> compareECL, tolerances of
+    compareECLFiles.cmake:83-85: abs 2e-2, rel 1e-5 or 1e-2): every value of every solution array of every report step of the UNRST
+    files, and every summary vector of every ministep of the UNSMRY files, may deviate by at most abs_tol OR by at most rel_tol of the
+    larger magnitude (opm-common ECLFilesComparator: a deviation counts only when both are exceeded).  Returns the list of violations
+    [(file kind, keyword, occurrence, worst abs deviation, worst rel deviation)]; empty = the runs agree."""
+    import numpy as np
+    bad = []
+
+    def check(kind, name, k, a, b):
+        a, b = np.asarray(a, float), np.asarray(b, float)
+        if a.shape != b.shape:
+            bad.append((kind, name, k, float("inf"), float("inf")))
+            return
+        d = np.abs(a - b)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            rel = np.where(d > 0, d / np.maximum(np.abs(a), np.abs(b)), 0.0)
+        viol = (d > abs_tol) & (rel > rel_tol)
+        if viol.any():
+            bad.append((kind, name, k, float(d[viol].max()), float(rel[viol].max())))
+
+    ra, rb = read_arrays(base_a + ".UNRST"), read_arrays(base_b + ".UNRST")
+    for name in restart_keywords:
+        xa, xb = [x[2] for x in ra if x[0] == name], [x[2] for x in rb if x[0] == name]
+        if len(xa) != len(xb):
+            bad.append(("UNRST", name, -1, float("inf"), float("inf")))
+            continue
+        for k, (a, b) in enumerate(zip(xa, xb)):
+            check("UNRST", name, k, a, b)
+    sa, sb = {x[0]: x[2] for x in read_arrays(base_a + ".SMSPEC")}, {x[0]: x[2] for x in read_arrays(base_b + ".SMSPEC")}
+    if list(sa["KEYWORDS"]) != list(sb["KEYWORDS"]) or list(sa["WGNAMES"]) != list(sb["WGNAMES"]):
+        bad.append(("SMSPEC", "KEYWORDS", -1, float("inf"), float("inf")))
+        return bad
+    pa, pb = [x[2] for x in read_arrays(base_a + ".UNSMRY") if x[0] == "PARAMS"], [x[2] for x in read_arrays(base_b + ".UNSMRY") if x[0] == "PARAMS"]
+    if len(pa) != len(pb):
+        bad.append(("UNSMRY", "PARAMS", -1, float("inf"), float("inf")))
+        return bad
+    for k, (a, b) in enumerate(zip(pa, pb)):
+        for i, (kw, wg) in enumerate(zip(sa["KEYWORDS"], sa["WGNAMES"])):
+            check("UNSMRY", "%s:%s" % (str(kw).strip(), str(wg).strip()), k, [a[i]], [b[i]])
+    return bad

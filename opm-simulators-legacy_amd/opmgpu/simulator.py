@@ -16,7 +16,10 @@ from .model import GpuBlackoilModel, NonlinearSolver
 
 
 class Simulator:
-    def __init__(self, deck_path, params=None, output_base=None, device=0, ats=None, vfp_tables=()):
+    def __init__(self, deck_path, params=None, output_base=None, device=0, ats=None, vfp_tables=(), model_factory=None, well_model_factory=None):
+        """model_factory(grid, tables, params) / well_model_factory(model, wells, well_state): other implementations of the model interface
+        behind the same driver (the tests run the CPU oracle + host well model through it and diff the two runs' output files like the
+        reference's regression tests diff flow_legacy's); default: the device model / the device well model."""
         self.deck = deckmod.read_deck(deck_path)
         self.tables = self.deck.tables()
         self.grid = self.deck.grid()
@@ -29,8 +32,13 @@ class Simulator:
         self.schedule = schedmod.Schedule(self.deck, self.grid, perm_md=(kx, ky), dz=dz.ravel(), dxdy=(dx.ravel(), dy.ravel()),
                                           ntg=self.deck.array("NTG", n, np.ones(n)))
         self.params = params or capi.default_params(use_cpr=1)
-        self.model = GpuBlackoilModel(self.grid, self.tables, self.params, device=device)
-        self.model.setState(self.state0)
+        self.well_model_factory = well_model_factory
+        if model_factory is None:
+            self.model = GpuBlackoilModel(self.grid, self.tables, self.params, device=device)
+            self.model.setState(self.state0)
+        else:
+            self.model = model_factory(self.grid, self.tables, self.params)
+            self.model.prepareStep(1.0, self.state0)
         self.ats = ats or ts.AdaptiveTimeStepping(initial_timestep_days=1.0)
         self.vfp_tables = vfp_tables
         self.out = None
@@ -59,12 +67,19 @@ class Simulator:
                         if prev_ws.current[k] < len(wl.controls[w]):
                             ws.current[w] = prev_ws.current[k]
             event = prev_names != list(wl.name)
-            gm.updateSatOilMax()                          # SimulatorBase_impl.hpp:190-192
-            gm.updateHysteresis()
-            model = W.DeviceWellModel(gm, wl, ws, vfp_tables=self.vfp_tables) if wl.nw > 0 else gm
-            rep = self.ats.step(t, dt, _Solver(), model, event=event)
+            if hasattr(gm, "updateSatOilMax"):
+                gm.updateSatOilMax()                      # SimulatorBase_impl.hpp:190-192
+                gm.updateHysteresis()
+            if wl.nw == 0:
+                model = gm
+            elif self.well_model_factory is not None:
+                model = self.well_model_factory(gm, wl, ws)
+            else:
+                model = W.DeviceWellModel(gm, wl, ws, vfp_tables=self.vfp_tables)
+            host_ws = ws if (wl.nw > 0 and not hasattr(model, "pull_well_state")) else None        # a host well model keeps the well state here
+            rep = self.ats.step(t, dt, _Solver(), model, event=event, well_state=host_ws)
             t += dt
-            if wl.nw > 0:
+            if wl.nw > 0 and hasattr(model, "pull_well_state"):
                 ws = model.pull_well_state()
             self.reports.append({"step": step, "days": t / DAY, "substeps": len(rep["substeps"]), "newton": rep["newton_iterations"],
                                  "linear": rep["linear_iterations"], "failed": len(rep["failed"])})
@@ -76,7 +91,8 @@ class Simulator:
         return self.reports
 
     def close(self):
-        self.model.close()
+        if hasattr(self.model, "close"):
+            self.model.close()
 
 
 class _Solver:

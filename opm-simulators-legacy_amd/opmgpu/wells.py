@@ -558,10 +558,15 @@ class DeviceWellModel:
     read-back of perforation properties, no clique fill -- opmgpu_set_device_wells / well_state_set / well_convergence.
     Interface of WellCoupledModel, so NonlinearSolver / AdaptiveTimeStepping drive either."""
 
-    def __init__(self, backend, wells, well_state, tolerance_wells=1e-4, tolerance_well_control=1e-7, vfp_tables=()):
+    def __init__(self, backend, wells, well_state, tolerance_wells=None, tolerance_well_control=None, vfp_tables=()):
         import ctypes as C
         from . import capi
         self.m, self.w, self.ws = backend, wells, well_state
+        # the tolerances of the context (BlackoilModelParameters: tolerance_wells 1e-4, tolerance_well_control 1e-7) unless given
+        if tolerance_wells is None:
+            tolerance_wells = backend.params.tolerance_wells
+        if tolerance_well_control is None:
+            tolerance_well_control = backend.params.tolerance_well_control
         self.tol_wells, self.tol_ctrl = tolerance_wells, tolerance_well_control
         self.linear_iterations = 0
         nw = wells.nw

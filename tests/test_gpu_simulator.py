@@ -84,3 +84,42 @@ def test_equilibrated_deck_is_stationary_on_the_device(gpu_lib, tmp_path):
     reps = sim.run(max_steps=1)
     assert reps[0]["days"] == 10.0 and reps[0]["failed"] == 0
     sim.close()
+
+
+def test_device_run_against_oracle_run_with_the_regression_tolerances(gpu_lib, oracle, tmp_path):
+    """The reference's end-to-end pin is a diff of output files (tests/run-regressionTest.sh: compareECL on UNRST / UNSMRY, abs 2e-2 and
+    rel 1e-5 for SPE9, 1e-2 for SPE1 / SPE3; compareECLFiles.cmake:83-118).  flow_legacy's own files are not available here; the same
+    diff is applied to two runs of the SCHEDULE deck through the same report-step driver: the device path (CPR, device well model) and
+    the CPU oracle with the host well model (explicit Schur complement, ILU0).  Both solve their linear systems tightly, so the runs
+    must agree to the STRICT pair of tolerances; a deliberately perturbed run must not."""
+    from util import OracleBackend
+    tight = dict(linear_solver_reduction=1e-9, linear_solver_maxiter=600, tolerance_wells=1e-7)
+    base_d, base_o = str(tmp_path / "DEV"), str(tmp_path / "ORC")
+    sim = Simulator(DECK, params=capi.default_params(use_cpr=1, **tight), output_base=base_d)
+    sim.model.max_single_precision_days = 0.0            # double solves on the device too
+    rd = sim.run()
+    sim.close()
+
+    def oracle_model(grid, tables, params):
+        return OracleBackend(oracle, grid, tables, params)
+
+    def host_wells(model, wl, ws):
+        if model.wells is None or list(model.wells[1]) != list(wl.arrays()[1]):      # the pattern carries the wells' cliques
+            model.wells = wl.arrays()
+            model.rowptr, model.col = oracle.pattern(model.grid, *model.wells)
+        return W.WellCoupledModel(model, W.StandardWellsHost(wl, model.grid.z, model.tab.surface_density[0], tolerance_wells=1e-7), ws)
+
+    so = Simulator(DECK, params=capi.default_params(**tight), output_base=base_o, model_factory=oracle_model, well_model_factory=host_wells)
+    ro = so.run()
+    assert [r["days"] for r in rd] == [r["days"] for r in ro]
+    assert [r["substeps"] for r in rd] == [r["substeps"] for r in ro] and [r["newton"] for r in rd] == [r["newton"] for r in ro]
+    bad = eclio.compare(base_d, base_o, abs_tol=2e-2, rel_tol=1e-5)
+    assert not bad, bad
+    # the comparison has teeth: the oracle run once more with the injection rate 2 % higher fails it
+    import re
+    deck2 = str(tmp_path / "PERTURBED.DATA")
+    open(deck2, "w").write(re.sub(r"'RATE' 400 ", "'RATE' 408 ", open(DECK).read()))
+    base_p = str(tmp_path / "PERT")
+    sp = Simulator(deck2, params=capi.default_params(**tight), output_base=base_p, model_factory=oracle_model, well_model_factory=host_wells)
+    sp.run()
+    assert eclio.compare(base_p, base_o, abs_tol=2e-2, rel_tol=1e-5)

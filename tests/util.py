@@ -149,3 +149,16 @@ class OracleBackend:
 
     def getState(self):
         return self.st
+
+    # last_state of AdaptiveTimeStepping and BlackoilModelBase::relativeChange (BlackoilModelBase_impl.hpp:1595-1631)
+    def saveState(self):
+        self.saved = self.st.copy()
+
+    def restoreState(self):
+        self.st = self.saved.copy()
+
+    def relativeChange(self):
+        a, b = self.saved, self.st
+        num = ((a.p - b.p) ** 2).sum() + ((a.sat - b.sat) ** 2).sum()
+        den = (b.p ** 2).sum() + (b.sat ** 2).sum()
+        return num / den if den > 0 else 0.0
