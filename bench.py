@@ -164,15 +164,29 @@ def main():
 
     def newton_iterations(model, n, state):
         """n Newton iterations; time steps follow each other like in the simulator.  A step that has not converged after the
-        reference's max_iter is restarted from the current state (the reference would cut dt; the metric is per Newton iteration)."""
+        reference's max_iter is restarted from the current state.  A Newton iteration that ends in one of the conditions the reference's
+        time stepper catches (NumericalIssue, LinearSolverProblem, ISTLError: AdaptiveTimeStepping_impl.hpp:244-281) is handled the way it
+        handles them: the state of the step's start is restored and the step restarts with 0.33 dt (:346); later steps grow back towards
+        dt.  Such an iteration still counts as one of the n (its work was done); `time_steps_chopped` reports how often it happened."""
+        from opmgpu.model import NumericalIssue, LinearSolverProblem, ISTLError
         it, lin, steps_done, failed = state["it"], 0, 0, 0
         for _ in range(n):
-            converged, l = model.nonlinearIteration(it, single_precision=single, nonlinear_solver=ns)
+            try:
+                converged, l = model.nonlinearIteration(it, single_precision=single, nonlinear_solver=ns)
+            except (NumericalIssue, LinearSolverProblem, ISTLError):
+                model.restoreState()
+                state["dt"] *= 0.33
+                state["chopped"] = state.get("chopped", 0) + 1
+                model.prepareStep(state["dt"])
+                it = 0
+                continue
             lin += l
             it += 1
             if (converged and it > ns.min_iter) or it > ns.max_iter:
                 failed += int(not converged)
-                model.prepareStep(dt)           # next time step from the resident state
+                model.saveState()               # last_state of the time stepper
+                state["dt"] = min(dt, 3.0 * state["dt"])
+                model.prepareStep(state["dt"])  # next time step from the resident state
                 it = 0
                 steps_done += 1
         state["it"] = it
@@ -182,7 +196,8 @@ def main():
         """deck set-up (spin-up time steps) -> W warm-up Newton iterations -> barrier -> exactly K timed Newton iterations -> barrier"""
         model = with_wells(core, wells_on)
         model.prepareStep(dt, st)
-        state = {"it": 0}
+        model.saveState()
+        state = {"it": 0, "dt": dt, "chopped": 0}
         done = 0
         while done < args.spin_up:              # set-up: let the synthetic initial state relax for `spin_up` time steps
             _, d, _ = newton_iterations(model, 1, state)
@@ -207,7 +222,7 @@ def main():
             tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
-        out = {"elapsed": elapsed, "lin": lin_total / args.steps, "steps_done": steps_done, "steps_not_converged": failed,
+        out = {"elapsed": elapsed, "lin": lin_total / args.steps, "steps_done": steps_done, "steps_not_converged": failed, "chopped": state["chopped"],
                "breakdown": {"assemble": t_asm / args.steps, "linear_solve": t_sol / args.steps, "update": t_upd / args.steps}}
         if kernel_table:
             # per-kernel pass: the NEXT K Newton iterations of the same run with the in-situ event brackets on (not part of `value`)
@@ -222,7 +237,7 @@ def main():
     def summary(r):
         return {"value": nc_global / (r["elapsed"] / args.steps) / 1e6, "ms_per_step": 1e3 * r["elapsed"] / args.steps,
                 "linear_iterations_per_newton": r["lin"], "time_steps_completed": r["steps_done"], "time_steps_not_converged": r["steps_not_converged"],
-                "breakdown_ms_per_step": r["breakdown"]}
+                "time_steps_chopped": r["chopped"], "breakdown_ms_per_step": r["breakdown"]}
 
     # ---- timed region: exactly K Newton iterations of the headline workload ----
     extras = rank == 0 and not use_dist and not args.only_main
@@ -330,7 +345,7 @@ def main():
                                                                      "_fivespot" if use_wells else ""),
                        "cells": nc_global, "cells_per_gpu": info["n_owned"], "nnzb_rank0": nnzb,
                        "dt_days": args.dt_days, "linear_solver": ("cpr(amg V-cycle + ilu0)" if prm.use_cpr else "ilu0") + (" + gmres(40)" if prm.newton_use_gmres else " + bicgstab"), "ilu0_ordering": args.ordering,
-                       "linear_iterations_per_newton": res["lin"], "time_steps_completed": res["steps_done"], "time_steps_not_converged": res["steps_not_converged"],
+                       "linear_iterations_per_newton": res["lin"], "time_steps_completed": res["steps_done"], "time_steps_not_converged": res["steps_not_converged"], "time_steps_chopped": res["chopped"],
                        "spin_up_time_steps": args.spin_up, "nonlinear_solver": "reference NonlinearSolver (max_iter 10, update stabilisation on)",
                        "tables": "tests/satfuncStandard.DATA PROPS (reference's own test deck)", "wells": wells_txt,
                        "parallelism": "1 GPU" if world == 1 else "domain decomposition x%d, RCCL halo" % world},
