@@ -150,8 +150,12 @@ class EclOutput:
                 write_array(f, k, "REAL", np.asarray(v, float))
 
     # ---------------------------------------------------------------- restart
-    def write_restart(self, elapsed_days, state, extra=None):
-        """one report step: PRESSURE [bar], SWAT, SGAS, RS, RV per ACTIVE cell (the solution section `compareECL` diffs)"""
+    def write_restart(self, elapsed_days, state, extra=None, wells=None, well_state=None, next_step_days=None):
+        """one report step: PRESSURE [bar], SWAT, SGAS, RS, RV per ACTIVE cell (the solution section `compareECL` diffs).  With wells the
+        header section also carries what a restarted run needs of the well state, like flow_legacy's OPM_XWEL / OPM_IWEL do -- under this
+        library's own keywords, its own layout: OPMGWNAM (names), OPMGXWEL (per well bhp [Pa], thp [Pa], q_s[3] [m3/s], DOUB), OPMGIWEL
+        (current control); OPMGDTNX = the time stepper's suggestion for the next sub-step [days] (flow_legacy's restarts begin with the
+        stepper's initial logic instead; carrying the suggestion makes the restarted run take the full run's sub-steps)."""
         self.report += 1
         self.elapsed = float(elapsed_days)
         date = self.start + datetime.timedelta(days=self.elapsed)
@@ -161,6 +165,13 @@ class EclOutput:
             write_array(f, "LOGIHEAD", "LOGI", np.zeros(121, bool))
             dh = np.zeros(229); dh[0] = self.elapsed
             write_array(f, "DOUBHEAD", "DOUB", dh)
+            if wells is not None and well_state is not None and wells.nw > 0:
+                ws = well_state
+                write_array(f, "OPMGWNAM", "CHAR", [str(n)[:8] for n in wells.name])
+                write_array(f, "OPMGXWEL", "DOUB", np.concatenate([[ws.bhp[w], ws.thp[w], *ws.qs[w]] for w in range(wells.nw)]))
+                write_array(f, "OPMGIWEL", "INTE", np.asarray(ws.current, np.int32))
+            if next_step_days is not None:
+                write_array(f, "OPMGDTNX", "DOUB", [float(next_step_days)])
             write_array(f, "STARTSOL", "MESS", None)
             write_array(f, "PRESSURE", "REAL", state.p / BAR)
             write_array(f, "SWAT", "REAL", state.sat[:, 0])
@@ -216,7 +227,7 @@ class EclOutput:
         self.ministep += 1
 
 
-def compare(base_a, base_b, abs_tol=2e-2, rel_tol=1e-5, restart_keywords=("PRESSURE", "SWAT", "SGAS", "RS", "RV")):
+def compare(base_a, base_b, abs_tol=2e-2, rel_tol=1e-5, restart_keywords=("PRESSURE", "SWAT", "SGAS", "RS", "RV"), by_seqnum=False, summary=True):
     """What the reference's regression tests ask of two runs (tests/run-regressionTest.sh -> compareECL, tolerances of
     compareECLFiles.cmake:83-85: abs 2e-2, rel 1e-5 or 1e-2): every value of every solution array of every report step of the UNRST
     files, and every summary vector of every ministep of the UNSMRY files, may deviate by at most abs_tol OR by at most rel_tol of the
@@ -238,13 +249,34 @@ def compare(base_a, base_b, abs_tol=2e-2, rel_tol=1e-5, restart_keywords=("PRESS
             bad.append((kind, name, k, float(d[viol].max()), float(rel[viol].max())))
 
     ra, rb = read_arrays(base_a + ".UNRST"), read_arrays(base_b + ".UNRST")
-    for name in restart_keywords:
-        xa, xb = [x[2] for x in ra if x[0] == name], [x[2] for x in rb if x[0] == name]
-        if len(xa) != len(xb):
-            bad.append(("UNRST", name, -1, float("inf"), float("inf")))
-            continue
-        for k, (a, b) in enumerate(zip(xa, xb)):
-            check("UNRST", name, k, a, b)
+    if by_seqnum:
+        # a restarted run against the full one (tests/run-restart-regressionTest.sh): the report steps both files hold, matched by SEQNUM
+        def by_report(arrs):
+            out, cur = {}, None
+            for name, _, data in arrs:
+                if name == "SEQNUM":
+                    cur = int(data[0])
+                elif cur is not None:
+                    out.setdefault(cur, {})[name] = data
+            return out
+        ga, gb = by_report(ra), by_report(rb)
+        common = sorted(set(ga) & set(gb))
+        if not common:
+            bad.append(("UNRST", "SEQNUM", -1, float("inf"), float("inf")))
+        for r in common:
+            for name in restart_keywords:
+                if name in ga[r] and name in gb[r]:
+                    check("UNRST", name, r, ga[r][name], gb[r][name])
+    else:
+        for name in restart_keywords:
+            xa, xb = [x[2] for x in ra if x[0] == name], [x[2] for x in rb if x[0] == name]
+            if len(xa) != len(xb):
+                bad.append(("UNRST", name, -1, float("inf"), float("inf")))
+                continue
+            for k, (a, b) in enumerate(zip(xa, xb)):
+                check("UNRST", name, k, a, b)
+    if not summary:
+        return bad
     sa, sb = {x[0]: x[2] for x in read_arrays(base_a + ".SMSPEC")}, {x[0]: x[2] for x in read_arrays(base_b + ".SMSPEC")}
     if list(sa["KEYWORDS"]) != list(sb["KEYWORDS"]) or list(sa["WGNAMES"]) != list(sb["WGNAMES"]):
         bad.append(("SMSPEC", "KEYWORDS", -1, float("inf"), float("inf")))
@@ -257,3 +289,18 @@ def compare(base_a, base_b, abs_tol=2e-2, rel_tol=1e-5, restart_keywords=("PRESS
         for i, (kw, wg) in enumerate(zip(sa["KEYWORDS"], sa["WGNAMES"])):
             check("UNSMRY", "%s:%s" % (str(kw).strip(), str(wg).strip()), k, [a[i]], [b[i]])
     return bad
+
+
+def read_restart(base, report):
+    """the arrays of report step `report` (its SEQNUM) of BASE.UNRST as {keyword: array}; "DAYS" = the elapsed time of DOUBHEAD"""
+    out, cur = {}, None
+    for name, typ, data in read_arrays(base + ".UNRST"):
+        if name == "SEQNUM":
+            cur = int(data[0])
+            continue
+        if cur == report:
+            out[name] = data
+    if not out:
+        raise ValueError("report step %d is not in %s.UNRST" % (report, base))
+    out["DAYS"] = float(out["DOUBHEAD"][0])
+    return out

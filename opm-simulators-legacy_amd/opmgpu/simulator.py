@@ -16,14 +16,22 @@ from .model import GpuBlackoilModel, NonlinearSolver
 
 
 class Simulator:
-    def __init__(self, deck_path, params=None, output_base=None, device=0, ats=None, vfp_tables=(), model_factory=None, well_model_factory=None):
+    def __init__(self, deck_path, params=None, output_base=None, device=0, ats=None, vfp_tables=(), model_factory=None, well_model_factory=None,
+                 restart=None):
         """model_factory(grid, tables, params) / well_model_factory(model, wells, well_state): other implementations of the model interface
         behind the same driver (the tests run the CPU oracle + host well model through it and diff the two runs' output files like the
-        reference's regression tests diff flow_legacy's); default: the device model / the device well model."""
+        reference's regression tests diff flow_legacy's); default: the device model / the device well model.
+        restart = (base, report): start from report step `report` of BASE.UNRST written by an earlier run of the same deck instead of the
+        deck's initial state (what tests/run-restart-regressionTest.sh exercises: the restarted run must reproduce the full one within
+        abs 2e-1 / rel 4e-5): reservoir state, VAPPARS / hysteresis history, well state by name; the run continues with the SCHEDULE's
+        next report step."""
         self.deck = deckmod.read_deck(deck_path)
         self.tables = self.deck.tables()
         self.grid = self.deck.grid()
         self.state0 = self.deck.initial_state(self.tables)
+        self.start_step, self.t0, self._restart_ws = 0, 0.0, None
+        if restart is not None:
+            self._load_restart(*restart)
         nx, ny, nz = self.deck.dims
         n = nx * ny * nz
         dx, dy, dz = self.deck._cell_sizes()
@@ -40,6 +48,8 @@ class Simulator:
             self.model = model_factory(self.grid, self.tables, self.params)
             self.model.prepareStep(1.0, self.state0)
         self.ats = ats or ts.AdaptiveTimeStepping(initial_timestep_days=1.0)
+        if getattr(self, "_restart_dtnx", None) is not None:
+            self.ats.suggested_next_timestep = self._restart_dtnx
         self.vfp_tables = vfp_tables
         self.out = None
         if output_base:
@@ -48,17 +58,48 @@ class Simulator:
             self.out = eclio.EclOutput(output_base, (nx, ny, nz), self.grid.active_index, self.schedule.start, cell_sizes=(dx, dy, dz), tops=tops, porv=porv)
         self.reports = []
 
+    def _load_restart(self, base, report):
+        from .decks import BAR, State
+        r = eclio.read_restart(base, report)
+        sw, sg = np.asarray(r["SWAT"], float), np.asarray(r["SGAS"], float)
+        sat = np.stack([sw, 1.0 - sw - sg, sg], 1)
+        hc = np.where(sg > 0, np.where(sat[:, 1] > 0, capi.HC_GAS_AND_OIL, capi.HC_GAS_ONLY), capi.HC_OIL_ONLY).astype(np.int8)     # initHydroCarbonState
+        if not self.tables.has_disgas:
+            hc[hc == capi.HC_OIL_ONLY] = capi.HC_GAS_AND_OIL
+        self.state0 = State(np.asarray(r["PRESSURE"], float) * BAR, sat, np.asarray(r["RS"], float), np.asarray(r["RV"], float), hc)
+        self.start_step, self.t0 = report - 1, r["DAYS"] * DAY        # report 1 is the initial state, report k + 1 follows schedule step k - 1
+        self._restart_extra = {k: np.asarray(r[k], float) for k in ("SOMAX", "HMDC_OW", "HMDC_GO") if k in r}
+        self._restart_dtnx = float(r["OPMGDTNX"][0]) * DAY if "OPMGDTNX" in r else None
+        if "OPMGXWEL" in r:
+            x = np.asarray(r["OPMGXWEL"], float).reshape(-1, 5)
+            self._restart_ws = ([str(n).strip() for n in r["OPMGWNAM"]], x, np.asarray(r["OPMGIWEL"], int))
+
     def run(self, max_steps=None):
         gm = self.model
-        t, prev_ws, prev_names = 0.0, None, None
+        t, prev_ws, prev_names = self.t0, None, None
+        if self.start_step > 0:
+            ex = getattr(self, "_restart_extra", {})
+            if "SOMAX" in ex and hasattr(gm, "setSatOilMax"):
+                gm.setSatOilMax(ex["SOMAX"])
+            if "HMDC_OW" in ex and hasattr(gm, "setHysteresis"):
+                gm.setHysteresis(ex["HMDC_OW"], ex["HMDC_GO"])
         if self.out:
-            self.out.write_restart(0.0, gm.getState())
+            self.out.report = self.start_step             # the restarted run numbers its report steps like the full one
+            self.out.write_restart(t / DAY, gm.getState())
         nsteps = len(self.schedule.steps) if max_steps is None else min(max_steps, len(self.schedule.steps))
-        for step in range(nsteps):
+        for step in range(self.start_step, nsteps):
             dt = self.schedule.steps[step][0]
             wl = self.schedule.wells(step)
             st = gm.getState()
             ws = W.WellState(wl, st.p)
+            if step == self.start_step and self._restart_ws is not None:          # the restart file's well state, by name
+                names, x, cur = self._restart_ws
+                for w, name in enumerate(wl.name):
+                    if str(name)[:8] in names:
+                        k = names.index(str(name)[:8])
+                        ws.bhp[w], ws.thp[w], ws.qs[w] = x[k, 0], x[k, 1], x[k, 2:5]
+                        if cur[k] < len(wl.controls[w]):
+                            ws.current[w] = cur[k]
             if prev_ws is not None:                       # WellStateFullyImplicitBlackoil::init(..., prevState): same-name wells keep their state
                 for w, name in enumerate(wl.name):
                     if name in prev_names:
@@ -67,6 +108,8 @@ class Simulator:
                         if prev_ws.current[k] < len(wl.controls[w]):
                             ws.current[w] = prev_ws.current[k]
             event = prev_names != list(wl.name)
+            if step == self.start_step and self._restart_ws is not None and [str(n)[:8] for n in wl.name] == self._restart_ws[0]:
+                event = False                             # the same wells as at the end of the run the restart file comes from
             if hasattr(gm, "updateSatOilMax"):
                 gm.updateSatOilMax()                      # SimulatorBase_impl.hpp:190-192
                 gm.updateHysteresis()
@@ -84,7 +127,14 @@ class Simulator:
             self.reports.append({"step": step, "days": t / DAY, "substeps": len(rep["substeps"]), "newton": rep["newton_iterations"],
                                  "linear": rep["linear_iterations"], "failed": len(rep["failed"])})
             if self.out:
-                self.out.write_restart(t / DAY, gm.getState())
+                extra = {}
+                if hasattr(gm, "satOilMax") and self.tables.vap1 + self.tables.vap2 > 0:
+                    extra["SOMAX"] = gm.satOilMax()
+                if hasattr(gm, "getHysteresis") and self.grid.imbnum is not None:
+                    h = gm.getHysteresis()
+                    extra["HMDC_OW"], extra["HMDC_GO"] = h[0], h[1]
+                self.out.write_restart(t / DAY, gm.getState(), extra=extra, wells=wl if wl.nw > 0 else None, well_state=ws if wl.nw > 0 else None,
+                                       next_step_days=self.ats.suggested_next_timestep / DAY)
                 if wl.nw > 0:
                     self.out.write_summary(t / DAY, wl, ws, new_report_step=True)
             prev_ws, prev_names = (ws.copy(), list(wl.name)) if wl.nw > 0 else (None, None)

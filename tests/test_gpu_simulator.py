@@ -123,3 +123,18 @@ def test_device_run_against_oracle_run_with_the_regression_tolerances(gpu_lib, o
     sp = Simulator(deck2, params=capi.default_params(**tight), output_base=base_p, model_factory=oracle_model, well_model_factory=host_wells)
     sp.run()
     assert eclio.compare(base_p, base_o, abs_tol=2e-2, rel_tol=1e-5)
+
+
+def test_restarted_device_run_reproduces_the_full_run(gpu_lib, tmp_path):
+    """tests/run-restart-regressionTest.sh on the device path: restart from report step 2 of the full run's UNRST (state, well state by
+    name, the time stepper's suggestion), same criterion and tolerances (abs 2e-1, rel 4e-5, compareECLFiles.cmake:121-135)."""
+    prm = capi.default_params(use_cpr=1, linear_solver_reduction=1e-6, linear_solver_maxiter=200)
+    full, part = str(tmp_path / "FULL"), str(tmp_path / "RESTARTED")
+    s1 = Simulator(DECK, params=prm, output_base=full)
+    r1 = s1.run()
+    s1.close()
+    s2 = Simulator(DECK, params=prm, output_base=part, restart=(full, 2))
+    r2 = s2.run()
+    s2.close()
+    assert [r["days"] for r in r2] == [r["days"] for r in r1[1:]] and [r["substeps"] for r in r2] == [r["substeps"] for r in r1[1:]]
+    assert not eclio.compare(full, part, abs_tol=2e-1, rel_tol=4e-5, by_seqnum=True, summary=False)

@@ -84,3 +84,47 @@ def test_eclipse_files_round_trip(tmp_path):
     idx = lambda k, g: next(i for i, (a, b) in enumerate(zip(kws, wgn)) if a == k and b == g)      # noqa: E731
     assert prm[idx("TIME", ":+:+:+:+")] == 10.0 and prm[idx("WOPR", "PROD1")] == pytest.approx(150.0, rel=1e-6)
     assert prm[idx("FOPR", ":+:+:+:+")] == pytest.approx(150.0, rel=1e-6) and prm[idx("WBHP", "PROD2")] == pytest.approx(200.0)
+
+
+def test_restarted_run_reproduces_the_full_run(tmp_path):
+    """tests/run-restart-regressionTest.sh: a run restarted from a report step of the full run's UNRST must reproduce the rest of the full
+    run within abs 2e-1 / rel 4e-5 (compareECLFiles.cmake:121-135).  Here with the CPU oracle + host well model behind the report-step
+    driver (the driver, the restart reader and the file comparison are host code; the device path runs the same driver in
+    tests/test_gpu_simulator.py)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import oracle
+    from opmgpu import capi, eclio, wells as W
+    from opmgpu.simulator import Simulator
+    from util import OracleBackend
+    oracle.build()
+
+    def oracle_model(grid, tables, params):
+        return OracleBackend(oracle, grid, tables, params)
+
+    def host_wells(model, wl, ws):
+        if model.wells is None or list(model.wells[1]) != list(wl.arrays()[1]):
+            model.wells = wl.arrays()
+            model.rowptr, model.col = oracle.pattern(model.grid, *model.wells)
+        return W.WellCoupledModel(model, W.StandardWellsHost(wl, model.grid.z, model.tab.surface_density[0]), ws)
+
+    prm = capi.default_params(linear_solver_reduction=1e-8, linear_solver_maxiter=400)
+    full, part = str(tmp_path / "FULL"), str(tmp_path / "RESTARTED")
+    s1 = Simulator(DECK, params=prm, output_base=full, model_factory=oracle_model, well_model_factory=host_wells)
+    r1 = s1.run()
+    s2 = Simulator(DECK, params=prm, output_base=part, model_factory=oracle_model, well_model_factory=host_wells, restart=(full, 2))
+    r2 = s2.run()
+    assert [r["days"] for r in r2] == [r["days"] for r in r1[1:]]
+    seq = [int(a[2][0]) for a in eclio.read_arrays(part + ".UNRST") if a[0] == "SEQNUM"]
+    assert seq == [2, 3, 4]
+    assert not eclio.compare(full, part, abs_tol=2e-1, rel_tol=4e-5, by_seqnum=True, summary=False)
+    # the restart file's well state was used: the first restarted report step starts from the producers' rates of the full run
+    x = eclio.read_restart(full, 2)
+    assert "OPMGXWEL" in x and len(x["OPMGWNAM"]) == 3
+    # and the comparison has teeth: a restart from the WRONG report step does not reproduce the full run
+    wrong = str(tmp_path / "WRONG")
+    s3 = Simulator(DECK, params=prm, output_base=wrong, model_factory=oracle_model, well_model_factory=host_wells, restart=(full, 2))
+    s3.state0.p[:] *= 1.01
+    s3.model.prepareStep(1.0, s3.state0)
+    s3.run()
+    assert eclio.compare(full, wrong, abs_tol=2e-1, rel_tol=4e-5, by_seqnum=True, summary=False)
