@@ -4,7 +4,7 @@ What `flow_legacy` gets from opm-parser + `DerivedGeology` (opm/autodiff/GeoProp
 (opm/autodiff/BlackoilPropsAdFromDeck.cpp:60-240), restricted to what the device path consumes:
 
   RUNSPEC   DIMENS TABDIMS OIL WATER GAS DISGAS VAPOIL METRIC ENDSCALE
-  GRID      DX DY DZ / DXV DYV DZV, TOPS (+BOX for the top layer) or DEPTHZ (flat), PORO PERMX PERMY PERMZ NTG ACTNUM
+  GRID      DX DY DZ / DXV DYV DZV, TOPS (+BOX for the top layer) or DEPTHZ (flat) -- or COORD / ZCORN (corner-point, no faults) --, PORO PERMX PERMY PERMZ NTG ACTNUM
             MULTX MULTY MULTZ MULTX- MULTY- MULTZ- MULTPV NNC
   PROPS     SWOF SGOF PVTO PVDO PVCDO PVTG PVDG PVTW DENSITY ROCK ROCKTAB VAPPARS SCALECRS (NO and YES) EHYSTR
             SWL SWCR SWU SOWCR SGL SGCR SGU SOGCR  KRW KRO KRG PCW PCG  ISWL ISWCR ISWU ISOWCR ISGL ISGCR ISGU ISOGCR
@@ -164,9 +164,75 @@ class Deck:
                            vappars=vappars, rocktab=rocktab)
 
     # ---------------------------------------------------------------- GRID
+    # ---------------------------------------------------------------- corner-point geometry (COORD / ZCORN)
+    def _corner_point(self):
+        """Geometry of a corner-point grid WITHOUT faults: what the reference takes from opm-grid (processEclipseFormat + compute_geometry; a
+        dependency outside its tree) for `DerivedGeology` (GeoProps.hpp:84-195), restated from the published algorithm: a cell is the
+        hexahedron of its eight corners (the ZCORN depths on the four COORD pillars around it); every face is triangulated about the mean
+        of its four nodes (area vector = sum of the triangle normals, centroid = area-weighted mean of the triangle centroids), the cell
+        about the mean of its face centroids (volume = sum of the tetrahedra, centroid = volume-weighted mean).  Neighbouring columns
+        whose shared pillar depths differ (faults, pinch-outs) would need opm-grid's face-intersection pass: ValueError.
+        Pinned only by consistency: the corner-point description of a block-centred grid reproduces the DX / DY / DZ / TOPS result
+        (tests/test_deck_ingest.py)."""
+        if getattr(self, "_cp", None) is not None:
+            return self._cp
+        nx, ny, nz = self.dims
+        coord = self.array("COORD", 6 * (nx + 1) * (ny + 1)).reshape(ny + 1, nx + 1, 6)
+        zc = self.array("ZCORN", 8 * nx * ny * nz).reshape(nz, 2, ny, 2, nx, 2)            # (k, top/bottom, j, y-side, i, x-side)
+        # corner coordinates P[k, j, i, tb, ys, xs, xyz]
+        P = np.zeros((nz, ny, nx, 2, 2, 2, 3))
+        for ys in (0, 1):
+            for xs in (0, 1):
+                pil = coord[ys:ys + ny, xs:xs + nx]                                        # pillar of that corner, [ny, nx, 6]
+                for tb in (0, 1):
+                    z = zc[:, tb, :, ys, :, xs]                                            # [nz, ny, nx]
+                    dzp = pil[..., 5] - pil[..., 2]
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        t = np.where(dzp != 0.0, (z - pil[..., 2]) / dzp, 0.0)
+                    P[:, :, :, tb, ys, xs, 0] = pil[..., 0] + t * (pil[..., 3] - pil[..., 0])
+                    P[:, :, :, tb, ys, xs, 1] = pil[..., 1] + t * (pil[..., 4] - pil[..., 1])
+                    P[:, :, :, tb, ys, xs, 2] = z
+        # faults: the corners two logically neighbouring cells share must coincide
+        tol = 1e-6 * max(1.0, float(np.abs(P[..., 2]).max()))
+        if nx > 1 and np.abs(P[:, :, :-1, :, :, 1] - P[:, :, 1:, :, :, 0]).max() > tol or ny > 1 and np.abs(P[:, :-1, :, :, 1] - P[:, 1:, :, :, 0]).max() > tol:
+            raise ValueError("corner-point grid with faults (neighbouring columns do not share their pillar depths): not supported")
+        if nz > 1 and np.abs(P[:-1, :, :, 1] - P[1:, :, :, 0]).max() > tol:
+            raise ValueError("corner-point grid with gaps between layers: not supported")
+
+        def face(a, b, c, d):                        # nodes in order around the face, each [..., 3]
+            m = 0.25 * (a + b + c + d)
+            nodes = (a, b, c, d)
+            N = np.zeros_like(m); cw = np.zeros_like(m); aw = np.zeros(m.shape[:-1])
+            for q in range(4):
+                u, v = nodes[q] - m, nodes[(q + 1) % 4] - m
+                tn = 0.5 * np.cross(u, v)
+                ta = np.linalg.norm(tn, axis=-1)
+                N += tn; aw += ta
+                cw += ta[..., None] * (m + nodes[q] + nodes[(q + 1) % 4]) / 3.0
+            return cw / np.maximum(aw, 1e-300)[..., None], N, (m, nodes)
+        c = lambda tb, ys, xs: P[:, :, :, tb, ys, xs]                                      # noqa: E731
+        faces = {"x-": face(c(0, 0, 0), c(0, 1, 0), c(1, 1, 0), c(1, 0, 0)), "x+": face(c(0, 0, 1), c(0, 1, 1), c(1, 1, 1), c(1, 0, 1)),
+                 "y-": face(c(0, 0, 0), c(0, 0, 1), c(1, 0, 1), c(1, 0, 0)), "y+": face(c(0, 1, 0), c(0, 1, 1), c(1, 1, 1), c(1, 1, 0)),
+                 "z-": face(c(0, 0, 0), c(0, 0, 1), c(0, 1, 1), c(0, 1, 0)), "z+": face(c(1, 0, 0), c(1, 0, 1), c(1, 1, 1), c(1, 1, 0))}
+        inner = sum(f[0] for f in faces.values()) / 6.0
+        vol = np.zeros(inner.shape[:-1]); cen = np.zeros_like(inner)
+        for fc, _, (m, nodes) in faces.values():
+            for q in range(4):
+                a, b = nodes[q], nodes[(q + 1) % 4]
+                tv = np.abs(np.einsum("...i,...i->...", np.cross(a - inner, b - inner), m - inner)) / 6.0
+                vol += tv
+                cen += tv[..., None] * (inner + a + b + m) / 4.0
+        cen /= np.maximum(vol, 1e-300)[..., None]
+        ext = lambda lo, hi: np.linalg.norm(faces[hi][0] - faces[lo][0], axis=-1)           # noqa: E731  (cube dimensions between face centroids)
+        self._cp = dict(vol=vol, cen=cen, faces=faces, dx=ext("x-", "x+"), dy=ext("y-", "y+"), dz=ext("z-", "z+"), ztop=faces["z-"][0][..., 2], zbot=faces["z+"][0][..., 2])
+        return self._cp
+
     def _cell_sizes(self):
         nx, ny, nz = self.dims
         n = nx * ny * nz
+        if self.has("ZCORN"):
+            cp = self._corner_point()
+            return cp["dx"], cp["dy"], cp["dz"]
 
         def axis(full, vec, count, shape):
             if self.has(full):
@@ -181,15 +247,21 @@ class Deck:
         nx, ny, nz = self.dims
         n = nx * ny * nz
         dx, dy, dz = self._cell_sizes()
-        if self.has("TOPS"):
+        cp = self._corner_point() if self.has("ZCORN") else None
+        if cp is not None:
+            top = None
+        elif self.has("TOPS"):
             t = self.array("TOPS")
             top = t[:nx * ny].reshape(ny, nx) if t.size >= nx * ny else np.full((ny, nx), t[0])
         elif self.has("DEPTHZ"):
             top = np.full((ny, nx), self.array("DEPTHZ")[0])
         else:
             top = np.zeros((ny, nx))
-        ztop = top[None, :, :] + np.concatenate([np.zeros((1, ny, nx)), np.cumsum(dz, axis=0)[:-1]], axis=0)
-        zc = (ztop + 0.5 * dz).ravel()
+        if cp is not None:
+            zc = cp["cen"][..., 2].ravel()
+        else:
+            ztop = top[None, :, :] + np.concatenate([np.zeros((1, ny, nx)), np.cumsum(dz, axis=0)[:-1]], axis=0)
+            zc = (ztop + 0.5 * dz).ravel()
         poro = self.array("PORO", n, np.full(n, 0.0))
         ntg = self.array("NTG", n, np.ones(n))
         kx = self.array("PERMX", n, np.zeros(n)) * MD
@@ -197,7 +269,7 @@ class Deck:
         kz = self.array("PERMZ", n, kx / MD) * MD
         multpv = self.array("MULTPV", n, np.ones(n))
         act = self.array("ACTNUM", n, np.ones(n)) > 0
-        vol = (dx * dy * dz).ravel()
+        vol = cp["vol"].ravel() if cp is not None else (dx * dy * dz).ravel()
         pv = poro * ntg * multpv * vol
         act &= pv > 0.0                                            # MINPV-free: cells without pore volume are inactive
         idx = np.arange(n).reshape(nz, ny, nx)
@@ -217,9 +289,38 @@ class Deck:
                 t = t * np.where(np.isnan(mult_minus[b]), 1.0, mult_minus[b])  # MULTX-: the face towards -x of that cell
             return np.stack([a, b], 1), t
         ayz, axz, axy = dyr * dzr, dxr * dzr, dxr * dyr
-        cx, tx = faces(idx[:, :, :-1], idx[:, :, 1:], kx, ayz, ayz, dxr, dxr, True, self.array("MULTX", n), self.array("MULTX-", n))
-        cy, ty = faces(idx[:, :-1, :], idx[:, 1:, :], ky, axz, axz, dyr, dyr, True, self.array("MULTY", n), self.array("MULTY-", n))
-        cz, tz = faces(idx[:-1, :, :], idx[1:, :, :], kz, axy, axy, dzr, dzr, False, self.array("MULTZ", n), self.array("MULTZ-", n))
+        if cp is not None:
+            # tpfa_htrans_compute (opm-core, restated): hT = |c . K n| / (c . c) with c = face centroid - cell centroid, n = the face's area
+            # vector, K the diagonal permeability tensor; NTG on the horizontal faces (DerivedGeology, GeoProps.hpp:121-159)
+            perm = np.stack([kx, ky, kz], -1).reshape(nz, ny, nx, 3)
+
+            def cp_faces(a, b, lo, hi, horiz, mult, mult_minus):
+                def half(sel, which):
+                    fc, N, _ = cp["faces"][which]
+                    cvec = fc[sel] - cp["cen"][sel]
+                    h = np.abs(np.einsum("...i,...i->...", cvec * perm[sel], N[sel])) / np.einsum("...i,...i->...", cvec, cvec)
+                    return h.ravel()
+                sa = (slice(None, -1) if lo == "z+" else slice(None), slice(None, -1) if lo == "y+" else slice(None), slice(None, -1) if lo == "x+" else slice(None))
+                sb = (slice(1, None) if lo == "z+" else slice(None), slice(1, None) if lo == "y+" else slice(None), slice(1, None) if lo == "x+" else slice(None))
+                a, b = a.ravel(), b.ravel()
+                h1, h2 = half(sa, lo), half(sb, hi)
+                if horiz:
+                    h1, h2 = h1 * ntg[a], h2 * ntg[b]
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    t = 1.0 / (1.0 / h1 + 1.0 / h2)
+                t = np.where(np.isfinite(t), t, 0.0)
+                if mult is not None:
+                    t = t * np.where(np.isnan(mult[a]), 1.0, mult[a])
+                if mult_minus is not None:
+                    t = t * np.where(np.isnan(mult_minus[b]), 1.0, mult_minus[b])
+                return np.stack([a, b], 1), t
+            cx, tx = cp_faces(idx[:, :, :-1], idx[:, :, 1:], "x+", "x-", True, self.array("MULTX", n), self.array("MULTX-", n))
+            cy, ty = cp_faces(idx[:, :-1, :], idx[:, 1:, :], "y+", "y-", True, self.array("MULTY", n), self.array("MULTY-", n))
+            cz, tz = cp_faces(idx[:-1, :, :], idx[1:, :, :], "z+", "z-", False, self.array("MULTZ", n), self.array("MULTZ-", n))
+        else:
+            cx, tx = faces(idx[:, :, :-1], idx[:, :, 1:], kx, ayz, ayz, dxr, dxr, True, self.array("MULTX", n), self.array("MULTX-", n))
+            cy, ty = faces(idx[:, :-1, :], idx[:, 1:, :], ky, axz, axz, dyr, dyr, True, self.array("MULTY", n), self.array("MULTY-", n))
+            cz, tz = faces(idx[:-1, :, :], idx[1:, :, :], kz, axy, axy, dzr, dzr, False, self.array("MULTZ", n), self.array("MULTZ-", n))
         conn = np.concatenate([cx, cy, cz]); trans = np.concatenate([tx, ty, tz])
         if self.has("NNC"):
             for r in self.records("NNC"):

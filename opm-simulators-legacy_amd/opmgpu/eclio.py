@@ -98,7 +98,7 @@ def _intehead(dims, nactive, date, nwells=0, ncwmax=0, report=0):
 class EclOutput:
     """BASE.EGRID / .INIT once, then BASE.UNRST / .SMSPEC / .UNSMRY per report step."""
 
-    def __init__(self, base, dims, active_index, start_date, cell_sizes=None, tops=None, porv=None, extra_init=None):
+    def __init__(self, base, dims, active_index, start_date, cell_sizes=None, tops=None, porv=None, extra_init=None, coord_zcorn=None):
         """dims (nx, ny, nz); active_index[cartesian cell] = active cell or -1; cell_sizes = (dx, dy, dz) per Cartesian cell and
         tops [ny*nx] for the EGRID of a block-centred grid; porv per Cartesian cell [m3]; extra_init = {keyword: per-active-cell array}"""
         self.base, self.dims = base, tuple(int(d) for d in dims)
@@ -111,7 +111,9 @@ class EclOutput:
         self._smspec_written = False
         self._vectors = None
         open(base + ".UNRST", "wb").close(); open(base + ".UNSMRY", "wb").close()
-        if cell_sizes is not None:
+        if coord_zcorn is not None:                       # a corner-point deck: its own COORD / ZCORN
+            self._write_egrid_arrays(*coord_zcorn)
+        elif cell_sizes is not None:
             self._write_egrid(cell_sizes, tops)
         self._write_init(porv, extra_init or {})
 
@@ -128,14 +130,18 @@ class EclOutput:
         coord[..., 3] = xs[None, :]; coord[..., 4] = ys[:, None]; coord[..., 5] = zb.max()
         zcorn = np.zeros((nz, 2, ny, 2, nx, 2))           # (k, top/bottom, j, y-side, i, x-side)
         zcorn[:, 0] = zt[:, :, None, :, None]; zcorn[:, 1] = zb[:, :, None, :, None]
+        self._write_egrid_arrays(coord.ravel(), zcorn.ravel())
+
+    def _write_egrid_arrays(self, coord, zcorn):
+        nx, ny, nz = self.dims
         with open(self.base + ".EGRID", "wb") as f:
             fh = np.zeros(100, np.int32); fh[0] = 3; fh[1] = 2007; fh[4] = 0; fh[5] = 0
             write_array(f, "FILEHEAD", "INTE", fh)
             write_array(f, "GRIDUNIT", "CHAR", ["METRES", ""])
             gh = np.zeros(100, np.int32); gh[0] = 1; gh[1], gh[2], gh[3] = nx, ny, nz; gh[24] = 1; gh[25] = 1
             write_array(f, "GRIDHEAD", "INTE", gh)
-            write_array(f, "COORD", "REAL", coord.ravel())
-            write_array(f, "ZCORN", "REAL", zcorn.ravel())
+            write_array(f, "COORD", "REAL", np.asarray(coord, float).ravel())
+            write_array(f, "ZCORN", "REAL", np.asarray(zcorn, float).ravel())
             write_array(f, "ACTNUM", "INTE", (self.act >= 0).astype(np.int32))
             write_array(f, "ENDGRID", "INTE", np.zeros(0, np.int32))
 

@@ -55,7 +55,9 @@ class Simulator:
         if output_base:
             porv = np.zeros(n); porv[self.deck.active] = self.grid.pv
             tops = self.deck.array("TOPS")[:nx * ny] if self.deck.has("TOPS") and self.deck.array("TOPS").size >= nx * ny else None
-            self.out = eclio.EclOutput(output_base, (nx, ny, nz), self.grid.active_index, self.schedule.start, cell_sizes=(dx, dy, dz), tops=tops, porv=porv)
+            cz = (self.deck.array("COORD"), self.deck.array("ZCORN")) if self.deck.has("ZCORN") else None
+            self.out = eclio.EclOutput(output_base, (nx, ny, nz), self.grid.active_index, self.schedule.start, cell_sizes=(dx, dy, dz), tops=tops, porv=porv,
+                                       coord_zcorn=cz)
         self.reports = []
 
     def _load_restart(self, base, report):

@@ -148,3 +148,64 @@ def test_transmissibility_multipliers_like_the_reference_test(tmp_path):
     same_layer = (inside // 4) == (outside // 4)
     assert np.allclose(g["ntg"].trans[same_layer], 0.5 * o.trans[same_layer], rtol=1e-8)
     assert np.allclose(g["ntg"].trans[~same_layer], o.trans[~same_layer], rtol=1e-8)
+
+
+def _corner_point_deck(tmp_path, mutate=None, name="CP.DATA"):
+    """tests/golden/decks/SCHEDULE_SMALL.DATA with its DXV / DYV / DZV / TOPS replaced by the equivalent COORD / ZCORN"""
+    from opmgpu import deck as D
+    src = open(os.path.join(os.path.dirname(__file__), "golden", "decks", "SCHEDULE_SMALL.DATA")).read()
+    d0 = D.read_deck(os.path.join(os.path.dirname(__file__), "golden", "decks", "SCHEDULE_SMALL.DATA"))
+    nx, ny, nz = d0.dims
+    dx, dy, dz = d0._cell_sizes()
+    xs = np.concatenate([[0.0], np.cumsum(dx[0, 0, :])]); ys = np.concatenate([[0.0], np.cumsum(dy[0, :, 0])])
+    zt = 2500.0 + np.concatenate([np.zeros((1, ny, nx)), np.cumsum(dz, 0)[:-1]], 0)
+    zb = zt + dz
+    coord = np.zeros((ny + 1, nx + 1, 6))
+    coord[..., 0] = xs[None, :]; coord[..., 1] = ys[:, None]; coord[..., 2] = zt.min()
+    coord[..., 3] = xs[None, :]; coord[..., 4] = ys[:, None]; coord[..., 5] = zb.max()
+    zcorn = np.zeros((nz, 2, ny, 2, nx, 2))
+    zcorn[:, 0] = zt[:, :, None, :, None]; zcorn[:, 1] = zb[:, :, None, :, None]
+    if mutate:
+        coord, zcorn = mutate(coord, zcorn)
+    a, b = src.index("DXV"), src.index("PORO")
+    txt = (src[:a] + "COORD\n" + " ".join("%.12g" % v for v in coord.ravel()) + " /\nZCORN\n" + " ".join("%.12g" % v for v in zcorn.ravel()) + " /\n" + src[b:])
+    path = os.path.join(str(tmp_path), name)
+    open(path, "w").write(txt)
+    return d0, D.read_deck(path)
+
+
+def test_corner_point_grid_without_faults(tmp_path):
+    """COORD / ZCORN ingest (opmgpu/deck.py::_corner_point; opm-grid's geometry restated, no reference vectors): the corner-point form of a
+    block-centred grid gives the block-centred transmissibilities, pore volumes and depths; a grid dipping along x keeps its volume and
+    lowers the transmissibility of the tilted faces' neighbours consistently; a fault is refused."""
+    d0, d1 = _corner_point_deck(tmp_path)
+    g0, g1 = d0.grid(), d1.grid()
+    assert np.array_equal(g0.conn_cells, g1.conn_cells)
+    assert np.allclose(g1.trans, g0.trans, rtol=1e-11) and np.allclose(g1.pv, g0.pv, rtol=1e-12) and np.allclose(g1.z, g0.z, atol=1e-9)
+    for a, b in zip(d0._cell_sizes(), d1._cell_sizes()):
+        assert np.allclose(a, b, rtol=1e-12)
+
+    def dip(coord, zcorn):          # every corner 0.05 m deeper per metre of x: a sheared (parallelepiped) grid of the same volume
+        nz, _, ny, _, nx, _ = zcorn.shape
+        xcorner = np.zeros((ny, 2, nx, 2))
+        for xs in (0, 1):
+            for ys in (0, 1):
+                xcorner[:, ys, :, xs] = coord[ys:ys + ny, xs:xs + nx, 0]
+        z2 = zcorn + 0.05 * xcorner[None, None]
+        c2 = coord.copy(); c2[..., 2] = z2.min() - 1.0; c2[..., 5] = z2.max() + 1.0
+        return c2, z2
+    _, d2 = _corner_point_deck(tmp_path, dip, "DIP.DATA")
+    g2 = d2.grid()
+    assert np.allclose(g2.pv, g0.pv, rtol=1e-12)                                   # shearing along z keeps the volumes
+    assert np.allclose(g2.z, g0.z + 0.05 * (np.arange(g0.nc) % 6 * 100.0 + 50.0), atol=1e-9)
+    nxf = 5 * 5 * 3                                                                # x-faces come first in the connection list
+    assert np.all(g2.trans[:nxf] < g0.trans[:nxf]) and np.allclose(g2.trans[:nxf], g0.trans[:nxf] / (1 + 0.05 ** 2), rtol=1e-12)
+    assert np.allclose(g2.trans[nxf:], g0.trans[nxf:], rtol=1e-12)
+
+    def fault(coord, zcorn):        # the columns i >= 3 thrown down by 4 m
+        z2 = zcorn.copy(); z2[:, :, :, :, 3:, :] += 4.0
+        c2 = coord.copy(); c2[..., 5] += 4.0
+        return c2, z2
+    _, d3 = _corner_point_deck(tmp_path, fault, "FAULT.DATA")
+    with pytest.raises(ValueError, match="faults"):
+        d3.grid()
