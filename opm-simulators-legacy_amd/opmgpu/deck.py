@@ -171,7 +171,8 @@ class Deck:
         hexahedron of its eight corners (the ZCORN depths on the four COORD pillars around it); every face is triangulated about the mean
         of its four nodes (area vector = sum of the triangle normals, centroid = area-weighted mean of the triangle centroids), the cell
         about the mean of its face centroids (volume = sum of the tetrahedra, centroid = volume-weighted mean).  Neighbouring columns
-        whose shared pillar depths differ (faults, pinch-outs) would need opm-grid's face-intersection pass: ValueError.
+        whose shared pillar depths differ (faults) are connected cell by cell through the OVERLAP of their faces on the common pillar pair
+        (`_fault_connections`); gaps between layers of one column are refused.
         Pinned only by consistency: the corner-point description of a block-centred grid reproduces the DX / DY / DZ / TOPS result
         (tests/test_deck_ingest.py)."""
         if getattr(self, "_cp", None) is not None:
@@ -192,10 +193,10 @@ class Deck:
                     P[:, :, :, tb, ys, xs, 0] = pil[..., 0] + t * (pil[..., 3] - pil[..., 0])
                     P[:, :, :, tb, ys, xs, 1] = pil[..., 1] + t * (pil[..., 4] - pil[..., 1])
                     P[:, :, :, tb, ys, xs, 2] = z
-        # faults: the corners two logically neighbouring cells share must coincide
+        # faults: neighbouring columns whose shared pillar depths differ are connected through the overlaps of their faces (_fault_connections)
         tol = 1e-6 * max(1.0, float(np.abs(P[..., 2]).max()))
-        if nx > 1 and np.abs(P[:, :, :-1, :, :, 1] - P[:, :, 1:, :, :, 0]).max() > tol or ny > 1 and np.abs(P[:, :-1, :, :, 1] - P[:, 1:, :, :, 0]).max() > tol:
-            raise ValueError("corner-point grid with faults (neighbouring columns do not share their pillar depths): not supported")
+        fault_x = (np.abs(P[:, :, :-1, :, :, 1] - P[:, :, 1:, :, :, 0]).max(axis=(0, 3, 4, 5)) > tol) if nx > 1 else np.zeros((ny, 0), bool)      # [ny, nx-1]
+        fault_y = (np.abs(P[:, :-1, :, :, 1] - P[:, 1:, :, :, 0]).max(axis=(0, 3, 4, 5)) > tol) if ny > 1 else np.zeros((0, nx), bool)            # [ny-1, nx]
         if nz > 1 and np.abs(P[:-1, :, :, 1] - P[1:, :, :, 0]).max() > tol:
             raise ValueError("corner-point grid with gaps between layers: not supported")
 
@@ -224,8 +225,102 @@ class Deck:
                 cen += tv[..., None] * (inner + a + b + m) / 4.0
         cen /= np.maximum(vol, 1e-300)[..., None]
         ext = lambda lo, hi: np.linalg.norm(faces[hi][0] - faces[lo][0], axis=-1)           # noqa: E731  (cube dimensions between face centroids)
-        self._cp = dict(vol=vol, cen=cen, faces=faces, dx=ext("x-", "x+"), dy=ext("y-", "y+"), dz=ext("z-", "z+"), ztop=faces["z-"][0][..., 2], zbot=faces["z+"][0][..., 2])
+        self._cp = dict(vol=vol, cen=cen, faces=faces, dx=ext("x-", "x+"), dy=ext("y-", "y+"), dz=ext("z-", "z+"), ztop=faces["z-"][0][..., 2], zbot=faces["z+"][0][..., 2],
+                        P=P, fault_x=fault_x, fault_y=fault_y)
         return self._cp
+
+    @staticmethod
+    def _face_overlap(A, B):
+        """Overlap of two faces that lie between the same two pillars.  A, B: [2 (top, bottom), 2 (pillar), 3] corner points.  In the
+        pillar-pair plane a face is the region between its top edge and its bottom edge, both straight from pillar 0 (u = 0) to pillar 1
+        (u = 1); the overlap is the region between the deeper of the two top edges and the shallower of the two bottom edges where that
+        gap is positive -- one interval of u, because the gap is concave in u.  Returns (area vector, centroid) or None."""
+        lines = {"tA": A[0], "bA": A[1], "tB": B[0], "bB": B[1]}                  # name -> [2 (u = 0, 1), 3]
+        zat = lambda name, u: lines[name][0][2] + u * (lines[name][1][2] - lines[name][0][2])       # noqa: E731
+        us = {0.0, 1.0}
+        names = list(lines)
+        for a in range(4):
+            for b in range(a + 1, 4):
+                la, lb = lines[names[a]], lines[names[b]]
+                d0, d1 = la[0][2] - lb[0][2], la[1][2] - lb[1][2]
+                if d0 * d1 < 0.0:
+                    us.add(d0 / (d0 - d1))
+        us = sorted(us)
+        gap = lambda u: min(zat("bA", u), zat("bB", u)) - max(zat("tA", u), zat("tB", u))            # noqa: E731
+        eps = 1e-12 * max(1.0, abs(A[0][0][2]))
+        pos = [u for u in us if gap(u) > eps]
+        if not pos:
+            return None
+        lo, hi = us.index(pos[0]), us.index(pos[-1])
+        u0 = us[lo - 1] if lo > 0 and gap(us[lo - 1]) > -eps else pos[0]           # the zero of the gap next to the positive stretch is a breakpoint
+        u1 = us[hi + 1] if hi + 1 < len(us) and gap(us[hi + 1]) > -eps else pos[-1]
+        span = [u for u in us if u0 <= u <= u1]
+        if len(span) < 2 and gap(span[0]) <= eps:
+            return None
+
+        def pt(name, u):
+            return lines[name][0] + u * (lines[name][1] - lines[name][0])
+        upper = [pt("tA" if zat("tA", u) >= zat("tB", u) else "tB", u) for u in span]
+        lower = [pt("bA" if zat("bA", u) <= zat("bB", u) else "bB", u) for u in reversed(span)]
+        poly = []
+        for q in upper + lower:
+            if not poly or np.abs(q - poly[-1]).max() > eps:
+                poly.append(q)
+        if len(poly) > 1 and np.abs(poly[0] - poly[-1]).max() <= eps:
+            poly.pop()
+        if len(poly) < 3:
+            return None
+        poly = np.array(poly)
+        m = poly.mean(0)
+        N = np.zeros(3); cw = np.zeros(3); aw = 0.0
+        for q in range(len(poly)):
+            a, b = poly[q], poly[(q + 1) % len(poly)]
+            tn = 0.5 * np.cross(a - m, b - m)
+            ta = np.linalg.norm(tn)
+            N += tn; aw += ta; cw += ta * (m + a + b) / 3.0
+        if aw <= 0.0:
+            return None
+        return N, cw / aw
+
+    def _fault_connections(self, cp, perm, ntg, mult, mult_minus, direction):
+        """connections across the faulted column pairs of one direction: [(cell a, cell b, transmissibility)] with a on the - side"""
+        nx, ny, nz = self.dims
+        P, cen = cp["P"], cp["cen"]
+        out = []
+        mask = cp["fault_x"] if direction == "x" else cp["fault_y"]
+        for j, i in zip(*np.nonzero(mask)):
+            ja, ia, jb, ib = (j, i, j, i + 1) if direction == "x" else (j, i, j + 1, i)
+            for ka in range(nz):
+                # face of A towards B / of B towards A as [top / bottom][pillar 0 / 1]
+                if direction == "x":
+                    FA = np.array([[P[ka, ja, ia, tb, ys, 1] for ys in (0, 1)] for tb in (0, 1)])
+                else:
+                    FA = np.array([[P[ka, ja, ia, tb, 1, xs] for xs in (0, 1)] for tb in (0, 1)])
+                for kb in range(nz):
+                    if direction == "x":
+                        FB = np.array([[P[kb, jb, ib, tb, ys, 0] for ys in (0, 1)] for tb in (0, 1)])
+                    else:
+                        FB = np.array([[P[kb, jb, ib, tb, 0, xs] for xs in (0, 1)] for tb in (0, 1)])
+                    if FB[0, :, 2].min() >= FA[1, :, 2].max() or FB[1, :, 2].max() <= FA[0, :, 2].min():
+                        continue                                                      # depth ranges do not meet
+                    ov = self._face_overlap(FA, FB)
+                    if ov is None:
+                        continue
+                    N, cf = ov
+                    a, b = ia + nx * (ja + ny * ka), ib + nx * (jb + ny * kb)
+                    h = []
+                    for (kk, jj, ii), cell in (((ka, ja, ia), a), ((kb, jb, ib), b)):
+                        cvec = cf - cen[kk, jj, ii]
+                        h.append(abs(float(np.dot(cvec * perm[kk, jj, ii], N))) / float(np.dot(cvec, cvec)) * ntg[cell])
+                    if h[0] <= 0.0 or h[1] <= 0.0:
+                        continue
+                    t = 1.0 / (1.0 / h[0] + 1.0 / h[1])
+                    if mult is not None and not np.isnan(mult[a]):
+                        t *= mult[a]
+                    if mult_minus is not None and not np.isnan(mult_minus[b]):
+                        t *= mult_minus[b]
+                    out.append((a, b, t))
+        return out
 
     def _cell_sizes(self):
         nx, ny, nz = self.dims
@@ -317,6 +412,14 @@ class Deck:
             cx, tx = cp_faces(idx[:, :, :-1], idx[:, :, 1:], "x+", "x-", True, self.array("MULTX", n), self.array("MULTX-", n))
             cy, ty = cp_faces(idx[:, :-1, :], idx[:, 1:, :], "y+", "y-", True, self.array("MULTY", n), self.array("MULTY-", n))
             cz, tz = cp_faces(idx[:-1, :, :], idx[1:, :, :], "z+", "z-", False, self.array("MULTZ", n), self.array("MULTZ-", n))
+            # faulted column pairs: their layer-to-layer faces do not coincide; the connections come from the face overlaps instead
+            tx = np.where(np.broadcast_to(cp["fault_x"][None], (nz,) + cp["fault_x"].shape).ravel(), 0.0, tx)
+            ty = np.where(np.broadcast_to(cp["fault_y"][None], (nz,) + cp["fault_y"].shape).ravel(), 0.0, ty)
+            fc = (self._fault_connections(cp, perm, ntg, self.array("MULTX", n), self.array("MULTX-", n), "x") +
+                  self._fault_connections(cp, perm, ntg, self.array("MULTY", n), self.array("MULTY-", n), "y"))
+            if fc:
+                cz = np.concatenate([cz, np.array([[a, b] for a, b, _ in fc], dtype=cz.dtype)])
+                tz = np.concatenate([tz, np.array([t for _, _, t in fc])])
         else:
             cx, tx = faces(idx[:, :, :-1], idx[:, :, 1:], kx, ayz, ayz, dxr, dxr, True, self.array("MULTX", n), self.array("MULTX-", n))
             cy, ty = faces(idx[:, :-1, :], idx[:, 1:, :], ky, axz, axz, dyr, dyr, True, self.array("MULTY", n), self.array("MULTY-", n))

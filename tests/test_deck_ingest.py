@@ -174,10 +174,11 @@ def _corner_point_deck(tmp_path, mutate=None, name="CP.DATA"):
     return d0, D.read_deck(path)
 
 
-def test_corner_point_grid_without_faults(tmp_path):
+def test_corner_point_grid(tmp_path):
     """COORD / ZCORN ingest (opmgpu/deck.py::_corner_point; opm-grid's geometry restated, no reference vectors): the corner-point form of a
     block-centred grid gives the block-centred transmissibilities, pore volumes and depths; a grid dipping along x keeps its volume and
-    lowers the transmissibility of the tilted faces' neighbours consistently; a fault is refused."""
+    lowers the transmissibility of the tilted faces' neighbours consistently; across a fault the cells are connected through the
+    overlaps of their faces (areas and centroids checked analytically); gaps between layers are refused."""
     d0, d1 = _corner_point_deck(tmp_path)
     g0, g1 = d0.grid(), d1.grid()
     assert np.array_equal(g0.conn_cells, g1.conn_cells)
@@ -202,10 +203,72 @@ def test_corner_point_grid_without_faults(tmp_path):
     assert np.all(g2.trans[:nxf] < g0.trans[:nxf]) and np.allclose(g2.trans[:nxf], g0.trans[:nxf] / (1 + 0.05 ** 2), rtol=1e-12)
     assert np.allclose(g2.trans[nxf:], g0.trans[nxf:], rtol=1e-12)
 
-    def fault(coord, zcorn):        # the columns i >= 3 thrown down by 4 m
+    def fault(coord, zcorn):        # the columns i >= 3 thrown down by 4 m (layers are 10 m thick)
         z2 = zcorn.copy(); z2[:, :, :, :, 3:, :] += 4.0
         c2 = coord.copy(); c2[..., 5] += 4.0
         return c2, z2
     _, d3 = _corner_point_deck(tmp_path, fault, "FAULT.DATA")
-    with pytest.raises(ValueError, match="faults"):
-        d3.grid()
+    g3 = d3.grid()
+    # across the fault a cell meets its own layer over 6 m of its 10 m and the layer above it (on the downthrown side) over 4 m; the
+    # half-transmissibilities see the overlap's area and its centroid: K A_ov (dx/2) / ((dx/2)^2 + dz_c^2) with dz_c = 2 m resp. 3 m
+    t0 = {tuple(c): t for c, t in zip(g0.conn_cells.tolist(), g0.trans)}
+    t3 = {tuple(c): t for c, t in zip(g3.conn_cells.tolist(), g3.trans)}
+    cell = lambda i, j, k: i + 6 * (j + 5 * k)          # noqa: E731
+    for j in range(5):
+        for k in range(3):
+            same = t3[(cell(2, j, k), cell(3, j, k))]
+            assert same == pytest.approx(t0[(cell(2, j, k), cell(3, j, k))] * 0.6 * 2500.0 / 2504.0, rel=1e-12)
+            if k >= 1:
+                up = t3[(cell(2, j, k), cell(3, j, k - 1))]
+                assert up == pytest.approx(t0[(cell(2, j, k), cell(3, j, k))] * 0.4 * 2500.0 / 2509.0, rel=1e-12)
+            assert (cell(2, j, k), cell(3, j, k + 1)) not in t3
+    # everything away from the fault is untouched
+    for (a, b), t in t0.items():
+        if not (a % 6 == 2 and b % 6 == 3):
+            assert t3[(a, b)] == pytest.approx(t, rel=1e-12)
+    assert len(t3) == len(t0) + 5 * 2
+    assert np.allclose(g3.pv, g0.pv, rtol=1e-12)
+
+    def gap(coord, zcorn):          # layer 2 detached from layer 1
+        z2 = zcorn.copy(); z2[2:] += 1.0
+        c2 = coord.copy(); c2[..., 5] += 1.0
+        return c2, z2
+    _, d4 = _corner_point_deck(tmp_path, gap, "GAP.DATA")
+    with pytest.raises(ValueError, match="gaps between layers"):
+        d4.grid()
+
+
+def test_scissor_fault_overlaps_tile_the_face(tmp_path):
+    """a fault whose throw changes sign along the fault plane (the top / bottom edges of the two sides CROSS): the overlaps of one cell's
+    face with the cells of the other side are polygons with crossing points as corners; together they tile the face exactly"""
+    from opmgpu import deck as D
+
+    def scissor(coord, zcorn):
+        nz, _, ny, _, nx, _ = zcorn.shape
+        ycorner = np.zeros((ny, 2))
+        for ys in (0, 1):
+            ycorner[:, ys] = coord[ys:ys + ny, 0, 1]
+        shift = 6.0 * (ycorner / coord[-1, 0, 1] - 0.5)                  # -3 m at y = 0 ... +3 m at y = Ly
+        z2 = zcorn.copy(); z2[:, :, :, :, 3:, :] += shift[None, None, :, :, None, None]
+        c2 = coord.copy(); c2[..., 2] -= 4.0; c2[..., 5] += 4.0
+        return c2, z2
+    _, d = _corner_point_deck(tmp_path, scissor, "SCISSOR.DATA")
+    g = d.grid()
+    cp = d._corner_point()
+    P = cp["P"]
+    assert cp["fault_x"][:, 2].all() and not cp["fault_x"][:, [0, 1, 3, 4]].any()
+    for j in range(5):
+        FA = np.array([[P[1, j, 2, tb, ys, 1] for ys in (0, 1)] for tb in (0, 1)])            # the middle layer: covered by the other side's stack
+        area = 0.0
+        pieces = 0
+        for kb in range(3):
+            FB = np.array([[P[kb, j, 3, tb, ys, 0] for ys in (0, 1)] for tb in (0, 1)])
+            ov = D.Deck._face_overlap(FA, FB)
+            if ov is not None:
+                area += np.linalg.norm(ov[0]); pieces += 1
+        assert area == pytest.approx(100.0 * 10.0, rel=1e-12), (j, area)
+        assert pieces >= 2
+    # in the middle row (j = 2) the throw changes sign inside the cell: the middle layer touches all three layers of the other side
+    conn = {tuple(c) for c in g.conn_cells.tolist()}
+    cell = lambda i, j, k: i + 6 * (j + 5 * k)          # noqa: E731
+    assert all((cell(2, 2, 1), cell(3, 2, kb)) in conn for kb in range(3))
