@@ -138,3 +138,37 @@ def test_restarted_device_run_reproduces_the_full_run(gpu_lib, tmp_path):
     s2.close()
     assert [r["days"] for r in r2] == [r["days"] for r in r1[1:]] and [r["substeps"] for r in r2] == [r["substeps"] for r in r1[1:]]
     assert not eclio.compare(full, part, abs_tol=2e-1, rel_tol=4e-5, by_seqnum=True, summary=False)
+
+
+def test_faulted_corner_point_deck_device_vs_oracle(gpu_lib, oracle, tmp_path):
+    """the SCHEDULE deck as a corner-point grid with a 4 m fault (connections through face overlaps, tests/test_deck_ingest.py): the device
+    run and the oracle run through the report-step driver agree at the reference's strict regression tolerances"""
+    from test_deck_ingest import _corner_point_deck
+    from util import OracleBackend
+
+    def fault(coord, zcorn):
+        z2 = zcorn.copy(); z2[:, :, :, :, 3:, :] += 4.0
+        c2 = coord.copy(); c2[..., 5] += 4.0
+        return c2, z2
+    _corner_point_deck(tmp_path, fault, "FAULT.DATA")
+    path = str(tmp_path / "FAULT.DATA")
+    tight = dict(linear_solver_reduction=1e-9, linear_solver_maxiter=600, tolerance_wells=1e-7)
+    base_d, base_o = str(tmp_path / "DEV"), str(tmp_path / "ORC")
+    sim = Simulator(path, params=capi.default_params(use_cpr=1, **tight), output_base=base_d)
+    assert sim.grid.nconn == 6 * 5 * 3 * 3 - (5 * 3 + 6 * 3 + 6 * 5) + 5 * 2          # the block grid's faces + the fault's extra overlaps
+    sim.model.max_single_precision_days = 0.0
+    rd = sim.run()
+    sim.close()
+
+    def oracle_model(grid, tables, params):
+        return OracleBackend(oracle, grid, tables, params)
+
+    def host_wells(model, wl, ws):
+        if model.wells is None or list(model.wells[1]) != list(wl.arrays()[1]):
+            model.wells = wl.arrays()
+            model.rowptr, model.col = oracle.pattern(model.grid, *model.wells)
+        return W.WellCoupledModel(model, W.StandardWellsHost(wl, model.grid.z, model.tab.surface_density[0], tolerance_wells=1e-7), ws)
+    so = Simulator(path, params=capi.default_params(**tight), output_base=base_o, model_factory=oracle_model, well_model_factory=host_wells)
+    ro = so.run()
+    assert [r["substeps"] for r in rd] == [r["substeps"] for r in ro] and [r["newton"] for r in rd] == [r["newton"] for r in ro]
+    assert not eclio.compare(base_d, base_o, abs_tol=2e-2, rel_tol=1e-5)
