@@ -3,6 +3,7 @@ keywords a standard-well black-oil run needs:
 
   WELSPECS  name group I J ref-depth preferred-phase            COMPDAT  name I J K1 K2 OPEN|SHUT satnum CF diameter Kh skin D dir
   WCONPROD  name OPEN|SHUT mode ORAT WRAT GRAT LRAT RESV BHP THP VFP ALQ     WCONINJE  name phase OPEN|SHUT mode RATE RESV BHP THP VFP
+  WELOPEN   name OPEN|SHUT|STOP [I J K]                            WELTARG  name ORAT|WRAT|GRAT|LRAT|BHP|THP|RATE value
   DATES / TSTEP (report steps), START (RUNSPEC)
 
 Every report step gets a `Wells` object (opmgpu/wells.py) the way WellsManager builds opm-core's `Wells` struct: one control per limit
@@ -10,7 +11,7 @@ the deck gives, the deck's control mode is the initial current control, the othe
 updateWellControls switches to (StandardWells_impl.hpp:709-800).  Producer rate targets are negative (flow into the wellbore).
 A defaulted connection factor is Peaceman's for a vertical well in a block-centred cell (WellsManager::createWellsFromSpecs ->
 computeWellIndices, opm-core, external: restated from the published formula).  METRIC units.
-Not read: groups (GCONPROD ...), WELTARG / WCONHIST, multi-segment wells, horizontal completions (dir X / Y), RESV control values
+Not read: groups (GCONPROD ...), WCONHIST, multi-segment wells, horizontal completions (dir X / Y), RESV control values
 (the reservoir-volume rate coefficients come from RateConverter; a RESV mode is rejected).
 """
 import datetime
@@ -94,6 +95,37 @@ class Schedule:
                     lim = {"RATE": _get(r, 4), "RESV": _get(r, 5), "BHP": _get(r, 6, 6895.0), "THP": _get(r, 7), "VFP": int(_get(r, 8, 0) or 0)}
                     for wn in self._match(specs, str(r[0])):
                         specs[wn].control = ("INJ", str(r[1]).upper(), str(_get(r, 2, "OPEN")).upper() == "OPEN", str(_get(r, 3, "")).upper(), lim)
+            elif name == "WELOPEN":          # name OPEN|SHUT|STOP [I J K C1 C2]: the whole well, or the completions that match (defaults / 0 = any)
+                for r in recs:
+                    if not r:
+                        continue
+                    status = str(_get(r, 1, "OPEN")).upper()
+                    sel = [int(_get(r, q, 0) or 0) for q in (2, 3, 4)]
+                    for wn in self._match(specs, str(r[0])):
+                        ws = specs[wn]
+                        if any(v > 0 for v in sel):
+                            ws.completions = [(ci, cj, ck, status == "OPEN" if all(v <= 0 or v - 1 == c for v, c in zip(sel, (ci, cj, ck))) else op, cf, dia, kh, sk)
+                                              for (ci, cj, ck, op, cf, dia, kh, sk) in ws.completions]
+                        elif ws.control is not None:
+                            c = list(ws.control)
+                            c[2 if c[0] == "INJ" else 1] = status == "OPEN"          # STOP (shut above the formation) is treated as SHUT: no crossflow model
+                            ws.control = tuple(c)
+            elif name == "WELTARG":          # name control value: one limit of the current WCONPROD / WCONINJE record changed
+                for r in recs:
+                    if not r:
+                        continue
+                    key, val = str(r[1]).upper(), float(r[2])
+                    for wn in self._match(specs, str(r[0])):
+                        ws = specs[wn]
+                        if ws.control is None:
+                            raise ValueError("WELTARG %s before WCONPROD / WCONINJE" % wn)
+                        lim = dict(ws.control[-1])
+                        if ws.control[0] == "INJ" and key in ("ORAT", "WRAT", "GRAT"):
+                            key = "RATE"
+                        if key not in lim:
+                            raise ValueError("WELTARG %s: control %s is not supported" % (wn, key))
+                        lim[key] = val
+                        ws.control = ws.control[:-1] + (lim,)
             elif name == "DATES":
                 for r in recs:
                     if not r:

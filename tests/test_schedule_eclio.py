@@ -128,3 +128,29 @@ def test_restarted_run_reproduces_the_full_run(tmp_path):
     s3.model.prepareStep(1.0, s3.state0)
     s3.run()
     assert eclio.compare(full, wrong, abs_tol=2e-1, rel_tol=4e-5, by_seqnum=True, summary=False)
+
+
+def test_welopen_and_weltarg(tmp_path):
+    """WELOPEN shuts / reopens a well or single completions, WELTARG changes one limit of the current control record"""
+    from opmgpu import deck as deckmod, schedule as schedmod, wells as W
+    src = open(DECK).read()
+    a = src.index("DATES")
+    extra = ("WELOPEN\n 'PROD2' 'SHUT' /\n 'INJ' 'SHUT' 0 0 3 /\n/\nWELTARG\n 'PROD1' 'ORAT' 90 /\n 'INJ' 'BHP' 300 /\n/\n")
+    path = os.path.join(str(tmp_path), "WELOPEN.DATA")
+    open(path, "w").write(src[:a] + extra + src[a:])
+    d = deckmod.read_deck(path)
+    grid = d.grid()
+    nx, ny, nz = d.dims
+    n = nx * ny * nz
+    dx, dy, dz = d._cell_sizes()
+    kx = d.array("PERMX", n)
+    sch = schedmod.Schedule(d, grid, perm_md=(kx, d.array("PERMY", n, kx)), dz=dz.ravel(), dxdy=(dx.ravel(), dy.ravel()), ntg=np.ones(n))
+    w0 = sch.wells(0)
+    assert list(w0.name) == ["INJ", "PROD1"]                                  # PROD2 is shut from the first report step on
+    inj = list(w0.name).index("INJ")
+    assert w0.connpos[inj + 1] - w0.connpos[inj] == 2                         # its completion in layer 3 is shut
+    p1 = list(w0.name).index("PROD1")
+    tgt = [c for c in w0.controls[p1] if c[0] == W.SURFACE_RATE][0]
+    assert tgt[1] == pytest.approx(-90.0 / 86400.0)
+    bhp = [c for c in w0.controls[inj] if c[0] == W.BHP][0]
+    assert bhp[1] == pytest.approx(300e5)
