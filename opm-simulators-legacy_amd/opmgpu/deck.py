@@ -4,7 +4,7 @@ What `flow_legacy` gets from opm-parser + `DerivedGeology` (opm/autodiff/GeoProp
 (opm/autodiff/BlackoilPropsAdFromDeck.cpp:60-240), restricted to what the device path consumes:
 
   RUNSPEC   DIMENS TABDIMS OIL WATER GAS DISGAS VAPOIL METRIC ENDSCALE
-  GRID      DX DY DZ / DXV DYV DZV, TOPS (+BOX for the top layer) or DEPTHZ (flat) -- or COORD / ZCORN (corner-point, no faults) --, PORO PERMX PERMY PERMZ NTG ACTNUM
+  GRID      DX DY DZ / DXV DYV DZV, TOPS (+BOX for the top layer) or DEPTHZ (flat) -- or COORD / ZCORN (corner-point, no faults) --, PORO PERMX PERMY PERMZ NTG ACTNUM MINPV, FAULTS + MULTFLT
             MULTX MULTY MULTZ MULTX- MULTY- MULTZ- MULTPV NNC
   PROPS     SWOF SGOF PVTO PVDO PVCDO PVTG PVDG PVTW DENSITY ROCK ROCKTAB VAPPARS SCALECRS (NO and YES) EHYSTR
             SWL SWCR SWU SOWCR SGL SGCR SGU SOGCR  KRW KRO KRG PCW PCG  ISWL ISWCR ISWU ISOWCR ISGL ISGCR ISGU ISOGCR
@@ -337,6 +337,31 @@ class Deck:
         dx = axis("DX", "DXV", nx, (1, 1, nx)); dy = axis("DY", "DYV", ny, (1, ny, 1)); dz = axis("DZ", "DZV", nz, (nz, 1, 1))
         return dx, dy, dz
 
+    def _face_multipliers(self):
+        """MULTX / MULTX- / ... arrays combined with the fault multipliers: FAULTS (name I1 I2 J1 J2 K1 K2 face) names sets of cell faces,
+        MULTFLT (name factor) multiplies the transmissibility of every connection through them (regular faces and the overlaps of a
+        faulted corner-point pillar pair alike).  {"X": per-cell factor of its X+ face, "X-": of its X- face, ...}"""
+        nx, ny, nz = self.dims
+        n = nx * ny * nz
+        out = {}
+        for key in ("X", "X-", "Y", "Y-", "Z", "Z-"):
+            a = self.array("MULT" + key, n)
+            out[key] = np.ones(n) if a is None else np.where(np.isnan(a), 1.0, a)
+        if self.has("FAULTS") and self.has("MULTFLT"):
+            fac = {}
+            for r in self.records("MULTFLT"):
+                if r:
+                    fac[str(r[0]).upper()] = fac.get(str(r[0]).upper(), 1.0) * float(r[1])
+            idx = np.arange(n).reshape(nz, ny, nx)
+            for r in self.records("FAULTS"):
+                if not r or str(r[0]).upper() not in fac:
+                    continue
+                i1, i2, j1, j2, k1, k2 = (int(v) for v in r[1:7])
+                face = str(r[7]).upper().replace("I", "X").replace("J", "Y").replace("K", "Z")
+                cells = idx[k1 - 1:k2, j1 - 1:j2, i1 - 1:i2].ravel()
+                out[face][cells] *= fac[str(r[0]).upper()]
+        return out
+
     def grid(self, gravity=decks.GRAVITY):
         """GridData of the active cells: connections x- then y- then z-normal faces (grid face order), then the NNCs."""
         nx, ny, nz = self.dims
@@ -366,7 +391,8 @@ class Deck:
         act = self.array("ACTNUM", n, np.ones(n)) > 0
         vol = cp["vol"].ravel() if cp is not None else (dx * dy * dz).ravel()
         pv = poro * ntg * multpv * vol
-        act &= pv > 0.0                                            # MINPV-free: cells without pore volume are inactive
+        minpv = float(self.records("MINPV")[0][0]) if self.has("MINPV") and self.records("MINPV")[0] else 0.0
+        act &= (pv > 0.0) & (pv >= minpv)                          # MINPV: cells below it are inactive (no PINCH connection across them)
         idx = np.arange(n).reshape(nz, ny, nx)
         dxr, dyr, dzr = dx.ravel(), dy.ravel(), dz.ravel()
 
@@ -384,6 +410,7 @@ class Deck:
                 t = t * np.where(np.isnan(mult_minus[b]), 1.0, mult_minus[b])  # MULTX-: the face towards -x of that cell
             return np.stack([a, b], 1), t
         ayz, axz, axy = dyr * dzr, dxr * dzr, dxr * dyr
+        fm = self._face_multipliers()
         if cp is not None:
             # tpfa_htrans_compute (opm-core, restated): hT = |c . K n| / (c . c) with c = face centroid - cell centroid, n = the face's area
             # vector, K the diagonal permeability tensor; NTG on the horizontal faces (DerivedGeology, GeoProps.hpp:121-159)
@@ -409,21 +436,20 @@ class Deck:
                 if mult_minus is not None:
                     t = t * np.where(np.isnan(mult_minus[b]), 1.0, mult_minus[b])
                 return np.stack([a, b], 1), t
-            cx, tx = cp_faces(idx[:, :, :-1], idx[:, :, 1:], "x+", "x-", True, self.array("MULTX", n), self.array("MULTX-", n))
-            cy, ty = cp_faces(idx[:, :-1, :], idx[:, 1:, :], "y+", "y-", True, self.array("MULTY", n), self.array("MULTY-", n))
-            cz, tz = cp_faces(idx[:-1, :, :], idx[1:, :, :], "z+", "z-", False, self.array("MULTZ", n), self.array("MULTZ-", n))
+            cx, tx = cp_faces(idx[:, :, :-1], idx[:, :, 1:], "x+", "x-", True, fm["X"], fm["X-"])
+            cy, ty = cp_faces(idx[:, :-1, :], idx[:, 1:, :], "y+", "y-", True, fm["Y"], fm["Y-"])
+            cz, tz = cp_faces(idx[:-1, :, :], idx[1:, :, :], "z+", "z-", False, fm["Z"], fm["Z-"])
             # faulted column pairs: their layer-to-layer faces do not coincide; the connections come from the face overlaps instead
             tx = np.where(np.broadcast_to(cp["fault_x"][None], (nz,) + cp["fault_x"].shape).ravel(), 0.0, tx)
             ty = np.where(np.broadcast_to(cp["fault_y"][None], (nz,) + cp["fault_y"].shape).ravel(), 0.0, ty)
-            fc = (self._fault_connections(cp, perm, ntg, self.array("MULTX", n), self.array("MULTX-", n), "x") +
-                  self._fault_connections(cp, perm, ntg, self.array("MULTY", n), self.array("MULTY-", n), "y"))
+            fc = (self._fault_connections(cp, perm, ntg, fm["X"], fm["X-"], "x") + self._fault_connections(cp, perm, ntg, fm["Y"], fm["Y-"], "y"))
             if fc:
                 cz = np.concatenate([cz, np.array([[a, b] for a, b, _ in fc], dtype=cz.dtype)])
                 tz = np.concatenate([tz, np.array([t for _, _, t in fc])])
         else:
-            cx, tx = faces(idx[:, :, :-1], idx[:, :, 1:], kx, ayz, ayz, dxr, dxr, True, self.array("MULTX", n), self.array("MULTX-", n))
-            cy, ty = faces(idx[:, :-1, :], idx[:, 1:, :], ky, axz, axz, dyr, dyr, True, self.array("MULTY", n), self.array("MULTY-", n))
-            cz, tz = faces(idx[:-1, :, :], idx[1:, :, :], kz, axy, axy, dzr, dzr, False, self.array("MULTZ", n), self.array("MULTZ-", n))
+            cx, tx = faces(idx[:, :, :-1], idx[:, :, 1:], kx, ayz, ayz, dxr, dxr, True, fm["X"], fm["X-"])
+            cy, ty = faces(idx[:, :-1, :], idx[:, 1:, :], ky, axz, axz, dyr, dyr, True, fm["Y"], fm["Y-"])
+            cz, tz = faces(idx[:-1, :, :], idx[1:, :, :], kz, axy, axy, dzr, dzr, False, fm["Z"], fm["Z-"])
         conn = np.concatenate([cx, cy, cz]); trans = np.concatenate([tx, ty, tz])
         if self.has("NNC"):
             for r in self.records("NNC"):

@@ -272,3 +272,44 @@ def test_scissor_fault_overlaps_tile_the_face(tmp_path):
     conn = {tuple(c) for c in g.conn_cells.tolist()}
     cell = lambda i, j, k: i + 6 * (j + 5 * k)          # noqa: E731
     assert all((cell(2, 2, 1), cell(3, 2, kb)) in conn for kb in range(3))
+
+
+def test_fault_multipliers_and_minpv(tmp_path):
+    """FAULTS + MULTFLT scale every connection through the named faces -- the regular ones of a block-centred grid and the overlaps across a
+    corner-point fault alike; MINPV deactivates small cells"""
+    from opmgpu import deck as D
+    src = open(os.path.join(os.path.dirname(__file__), "golden", "decks", "SCHEDULE_SMALL.DATA")).read()
+    a = src.index("PORO")
+    flt = "FAULTS\n 'F1' 3 3 1 5 1 3 'X' /\n 'F2' 1 6 2 2 1 1 'Y' /\n/\nMULTFLT\n 'F1' 0.1 /\n 'F2' 0.5 /\n/\n"
+    path = os.path.join(str(tmp_path), "FLT.DATA")
+    open(path, "w").write(src[:a] + flt + src[a:])
+    g0 = D.read_deck(os.path.join(os.path.dirname(__file__), "golden", "decks", "SCHEDULE_SMALL.DATA")).grid()
+    g1 = D.read_deck(path).grid()
+    t0 = {tuple(c): t for c, t in zip(g0.conn_cells.tolist(), g0.trans)}
+    t1 = {tuple(c): t for c, t in zip(g1.conn_cells.tolist(), g1.trans)}
+    cell = lambda i, j, k: i + 6 * (j + 5 * k)          # noqa: E731
+    for (x, y), t in t0.items():
+        f = 1.0
+        if x % 6 == 2 and y == x + 1:
+            f = 0.1                                     # the X+ faces of the cells with I = 3
+        if (x // 6) % 5 == 1 and y == x + 6 and x // 30 == 0:
+            f = 0.5                                     # the Y+ faces of row J = 2 in the top layer
+        assert t1[(x, y)] == pytest.approx(f * t, rel=1e-13)
+
+    def fault(coord, zcorn):
+        z2 = zcorn.copy(); z2[:, :, :, :, 3:, :] += 4.0
+        c2 = coord.copy(); c2[..., 5] += 4.0
+        return c2, z2
+    _, d2 = _corner_point_deck(tmp_path, fault, "F.DATA")
+    txt = open(os.path.join(str(tmp_path), "F.DATA")).read()
+    b = txt.index("PORO")
+    open(os.path.join(str(tmp_path), "F2.DATA"), "w").write(txt[:b] + "FAULTS\n 'F1' 3 3 1 5 1 3 'X' /\n/\nMULTFLT\n 'F1' 0.1 /\n/\nMINPV\n 1 /\n" + txt[b:])
+    g2, g3 = d2.grid(), D.read_deck(os.path.join(str(tmp_path), "F2.DATA")).grid()
+    t2 = {tuple(c): t for c, t in zip(g2.conn_cells.tolist(), g2.trans)}
+    t3 = {tuple(c): t for c, t in zip(g3.conn_cells.tolist(), g3.trans)}
+    assert set(t2) == set(t3)
+    for (x, y), t in t2.items():
+        assert t3[(x, y)] == pytest.approx((0.1 if (x % 6 == 2 and y % 6 == 3) else 1.0) * t, rel=1e-13)
+    # MINPV above every pore volume: nothing is left
+    open(os.path.join(str(tmp_path), "F3.DATA"), "w").write(txt[:b] + "MINPV\n 1e9 /\n" + txt[b:])
+    assert D.read_deck(os.path.join(str(tmp_path), "F3.DATA")).grid().nc == 0
