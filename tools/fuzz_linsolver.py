@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.join(ROOT, "opm-simulators-legacy_amd")); sys.path.in
 import numpy as np
 import torch  # noqa: F401
 from opmgpu import capi, decks
-from opmgpu.model import GpuNewtonIteration
+from opmgpu.model import GpuNewtonIteration, ISTLError
 from oracle import oracle as orc
 from util import bsr_to_scipy, random_block_matrix, rel_err
 
@@ -57,7 +57,17 @@ for case in range(ncases):
             if not single or dominance >= 1.0:
                 note("ilu_" + tag, rel_err(lu, luo))
                 note("apply_" + tag, rel_err(s.ilu0_apply(x), orc.ilu0_apply(rowptr, col, luo, x, position=pos, relax=0.9, single=single)))
-            xs = s.computeNewtonIncrement(rowptr, col, val, b, single)
+            try:
+                xs = s.computeNewtonIncrement(rowptr, col, val, b, single)
+            except ISTLError as e:
+                # a Krylov breakdown (rho or omega ~ 0) on a random, weakly dominant matrix: legitimate only if the oracle's BiCGStab
+                # on the same system does not converge either (or, in f32, where the two round differently on ill-conditioned pivots)
+                prm = capi.default_params(linear_solver_reduction=1e-4 if single else 1e-10, linear_solver_maxiter=400)
+                st_o, _, it_o, red_o, _ = orc.bicgstab(rowptr, col, val, b, prm, position=pos, single=single)
+                print("case %d %s dominance %.2f: %s; oracle status %d its %d reduction %.1e" % (seed0 + case, tag, dominance, e, st_o, it_o, red_o), flush=True)
+                note(("breakdown_" if st_o != 0 or (single and dominance < 1.0) else "breakdown_only_on_gpu_") + tag, 1.0)
+                s.close()
+                continue
             if s.reduction < (1e-4 if single else 1e-10):          # converged by its own (recurrence) residual: the true one must agree
                 A = bsr_to_scipy(rowptr, col, val)
                 note("solve_" + tag, np.linalg.norm(A @ xs - b) / np.linalg.norm(b))
@@ -65,7 +75,7 @@ for case in range(ncases):
                 note("unconverged_" + tag, 1.0)
             s.close()
 lim = {"f64": 1e-12, "f32": 1e-4}
-bad = {k: v for k, v in worst.items() if (k.startswith("solve") and v > (5e-3 if k.endswith("f32") else 1e-9)) or (k[:4] in ("spmv", "ilu_", "appl") and v > lim[k[-3:]])}
+bad = {k: v for k, v in worst.items() if k.startswith("breakdown_only") or (k.startswith("solve") and v > (5e-3 if k.endswith("f32") else 1e-9)) or (k[:4] in ("spmv", "ilu_", "appl") and v > lim[k[-3:]])}
 print("cases", ncases, "worst", {k: "%.1e" % v for k, v in sorted(worst.items())}, flush=True)
 if bad:
     print("VIOLATIONS", bad); sys.exit(1)
