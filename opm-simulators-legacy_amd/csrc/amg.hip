@@ -118,35 +118,49 @@ void to_sell(HostCsr& C, std::vector<int32_t>& slice_ptr, std::vector<int32_t>& 
 } // namespace
 
 // ---------------------------------------------------------------- device kernels
-template <class S>
-__global__ __launch_bounds__(kBlock) void k_amg_galerkin(int nce, const int32_t* __restrict__ cptr, const int32_t* __restrict__ cidx,
-                                                         const int32_t* __restrict__ cdev, const S* __restrict__ fine, S* __restrict__ coarse)
+constexpr int galerkin_unroll(int lpe) { return lpe == 1 ? 8 : (lpe <= 8 ? 2 : 1); }
+// Galerkin sums: coarse device slot e = sum of the fine entries cidx[cptr[e] .. cptr[e+1]) in a fixed order (deterministic).  The
+// work list is in the coarse level's SELL order (setup()): a wavefront's lanes are 64 neighbouring coarse rows at the same position of
+// the row -- all diagonal entries (~33 contributions at 100^3) or all off-diagonal ones (~4) --, so they loop equally often, and
+// the stores are contiguous.  (In csr order every ~13th lane was a diagonal and each wave ran at its pace, with a scattered
+// 4-byte store per thread: 79 us for level 0 -> 1, whose lists are 56 MB.)  LPE lanes share one entry (strided, butterfly-summed);
+// a diagonal entry also writes the coarse level's inverse diagonal (cdiag[e] = its row, else -1): one launch less per level.
+// What remains (PMC, level 0 -> 1 at 100^3: 459 MB fetched for 60 MB of lists and values): the gathers.  Level 0 is SELL-64 in the ILU's
+// two-colour row order, so the ~9 rows of an aggregate lie in ~7 row ranges and each of a row's entries in another 128-byte line; a
+// gather instruction touches 23 lines on average (measured on the dumped lists) and the fine values cost 35 of the kernel's 60 us.
+template <class S, int LPE>
+__global__ __launch_bounds__(kBlock) void k_amg_galerkin(int xm, int nce, const int32_t* __restrict__ cptr, const int32_t* __restrict__ cidx,
+                                                         const int32_t* __restrict__ cdiag,
+                                                         const S* __restrict__ fine, S* __restrict__ coarse, S* __restrict__ dinv_coarse)
 {
-    const int e = blockIdx.x * kBlock + threadIdx.x;
-    if (e >= nce) return;
+    constexpr int U = galerkin_unroll(LPE);
+    // XCD-contiguous chunks (common.hpp): the ~13 positions of one coarse slice gather from the SAME fine rows and are 13 consecutive
+    // wavefronts = 3-4 workgroups; dealt round-robin they land in 3-4 different L2s and every fine line is fetched that often
+    // (PMC at 100^3, level 0 -> 1: 459 MB fetched for 60 MB of lists and values, L2 hit rate 0.42)
+    const int nchunks = (int)(((long)nce * LPE + kBlock - 1) / kBlock);
+    const int ch = xcd_first(nchunks, xm);
+    if (ch >= xcd_end(nchunks, xm)) return;
+    const int t = ch * kBlock + threadIdx.x, e = t / LPE, l = t % LPE;
+    const bool live = e < nce;
     double s = 0.0;
-    const int q0 = cptr[e], q1 = cptr[e + 1];
-    for (int q = q0; q < q1; q += 8) {          // fixed order; index loads, then gathers, of a batch in flight together
-        int id[8]; S v[8];
+    const int q0 = live ? cptr[e] : 0, q1 = live ? cptr[e + 1] : 0;
+    for (int q = q0 + l; q < q1; q += U * LPE) {          // index loads, then gathers, of a batch in flight together
+        int id[U]; S v[U];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) id[u] = q + u < q1 ? cidx[q + u] : -1;
+        for (int u = 0; u < U; ++u) id[u] = q + u * LPE < q1 ? cidx[q + u * LPE] : -1;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = id[u] >= 0 ? fine[id[u]] : S(0);
+        for (int u = 0; u < U; ++u) v[u] = id[u] >= 0 ? fine[id[u]] : S(0);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s += double(v[u]);
+        for (int u = 0; u < U; ++u) s += double(v[u]);
     }
-    coarse[cdev[e]] = S(s);
-}
-template <class S>
-__global__ __launch_bounds__(kBlock) void k_amg_galerkin_wave(int nce, const int32_t* __restrict__ cptr, const int32_t* __restrict__ cidx,
-                                                              const int32_t* __restrict__ cdev, const S* __restrict__ fine, S* __restrict__ coarse)
-{
-    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
-    if (e >= nce) return;
-    double s = 0.0;
-    for (int q = cptr[e] + l; q < cptr[e + 1]; q += 64) s += double(fine[cidx[q]]);
-    s = wave_sum(s);                       // fixed lane order: deterministic
-    if (l == 0) coarse[cdev[e]] = S(s);
+#pragma unroll
+    for (int off = LPE / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (live && l == 0) {
+        const S c = S(s);
+        coarse[e] = c;
+        const int r = cdiag[e];
+        if (r >= 0) dinv_coarse[r] = c != S(0) ? S(1) / c : S(0);
+    }
 }
 template <class S>
 __global__ __launch_bounds__(kBlock) void k_amg_dinv(int n, const int32_t* __restrict__ diag_entry, const S* __restrict__ val, S* __restrict__ dinv)
@@ -454,10 +468,21 @@ __global__ __launch_bounds__(kBlock) void k_dense_apply(int n, const double* __r
 }
 
 // ---------------------------------------------------------------- host driver
+// lanes per coarse entry of the Galerkin kernel: one thread per entry on the big levels (millions of entries with ~5 contributions), 8
+// on the small ones (10^5 entries with tens to hundreds: too few threads otherwise).  A/B: OPMGPU_AMG_GALERKIN_LPE=big,small[,threshold]
+static int galerkin_lanes(int nce)
+{
+    static int big = 1, small = 8, below = 400000, parsed = 0;
+    if (!parsed) { parsed = 1; if (const char* e = std::getenv("OPMGPU_AMG_GALERKIN_LPE")) std::sscanf(e, "%d,%d,%d", &big, &small, &below); }
+    const int v = nce > below ? big : small;
+    return (v == 1 || v == 8 || v == 16) ? v : 64;
+}
 template <class S>
 void AmgHierarchy<S>::setup(const Plan& P, const int32_t* d_slice_ptr, const int32_t* d_col, const std::vector<double>& ap_host, const AmgBorderSpec* border)
 {
-    levels.clear(); level_sizes.clear(); coarse_dev.clear();
+    if (inv_stream) { OPMGPU_HIP(hipStreamSynchronize(inv_stream)); inv_pending = false; }       // dense_inv is re-allocated below
+    levels.clear(); level_sizes.clear();
+    if (const char* e = std::getenv("OPMGPU_AMG_INV_OVERLAP")) inv_overlap = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_AMG_OMEGA")) omega = std::atof(e);
     if (const char* e = std::getenv("OPMGPU_AMG_PDAMP")) { pdamp = std::atof(e); pdamp0 = pdamp; pdamp_user = true; }
     if (const char* e = std::getenv("OPMGPU_AMG_PDAMP0")) { pdamp0 = std::atof(e); pdamp_user = true; }
@@ -544,19 +569,26 @@ void AmgHierarchy<S>::setup(const Plan& P, const int32_t* d_slice_ptr, const int
         for (int e = 0; e < nce; ++e) cptr[e + 1] += cptr[e];
         { std::vector<int32_t> fill(cptr.begin(), cptr.end() - 1); for (size_t s = 0; s < A.col.size(); ++s) cidx[fill[cof[s]]++] = A.dev[s]; }
         L->agg.upload(agg, stream); L->agg_ptr.upload(aptr, stream); L->agg_rows.upload(arows, stream);
-        L->contrib_ptr.upload(cptr, stream); L->contrib_idx.upload(cidx, stream);
-        L->n_coarse = na; L->nentries_coarse = nce;
+        // work list of k_amg_galerkin, indexed by the coarse level's DEVICE slot (SELL-64: slice, position in the row, lane): a wavefront
+        // covers 64 neighbouring coarse rows at the same position, and coarsen() puts the diagonal first, so its lanes loop equally often
+        // and its stores are one contiguous line; padding slots have empty lists (they get 0).  The order of the sum inside an entry is
+        // the csr order of the fine entries, as before.
+        const int lpe = galerkin_lanes(nce);
+        std::vector<int32_t> cptr2(nent + 1, 0), cidx2(cidx.size()), cdiag2(nent, -1);
+        for (int e = 0; e < nce; ++e) cptr2[C.dev[e] + 1] = cptr[e + 1] - cptr[e];
+        for (int d = 0; d < nent; ++d) cptr2[d + 1] += cptr2[d];
+        for (int r = 0; r < C.n; ++r)
+            for (int e = C.rowptr[r]; e < C.rowptr[r + 1]; ++e) {
+                std::copy(cidx.begin() + cptr[e], cidx.begin() + cptr[e + 1], cidx2.begin() + cptr2[C.dev[e]]);
+                if (C.col[e] == r) cdiag2[C.dev[e]] = r;
+            }
+        L->contrib_ptr.upload(cptr2, stream); L->contrib_idx.upload(cidx2, stream); L->contrib_diag.upload(cdiag2, stream);
+        L->n_coarse = na; L->nentries_coarse = nent; L->galerkin_lpe = lpe;
         std::unique_ptr<AmgLevel<S>> Lc(new AmgLevel<S>());
         Lc->n = na; Lc->nslices = (na + 63) / 64; Lc->nentries = nent;
         Lc->own_slice_ptr.upload(sp, stream); Lc->own_col.upload(scol, stream);
         Lc->slice_ptr = Lc->own_slice_ptr.p; Lc->col = Lc->own_col.p;
         Lc->diag_entry.upload(dent, stream);
-        // stash coarse device-entry ids on the FINE level (used by k_amg_galerkin)
-        {
-            DevArray<int32_t>* cdev = new DevArray<int32_t>();
-            cdev->upload(C.dev, stream);
-            coarse_dev.emplace_back(cdev);
-        }
         levels.push_back(std::move(L));
         L = std::move(Lc);
         A = std::move(C);
@@ -574,26 +606,50 @@ void AmgHierarchy<S>::setup(const Plan& P, const int32_t* d_slice_ptr, const int
 template <class S>
 void AmgHierarchy<S>::galerkin(bool coarse_levels)
 {
+    // the inverse diagonal of level 0 here; those of the coarse levels are written by the Galerkin kernel that produces their operator
+    AmgLevel<S>& F0 = *levels[0];
+    hipLaunchKernelGGL((k_amg_dinv<S>), dim3(grid_for(F0.ntot())), dim3(kBlock), 0, stream, F0.ntot(), F0.diag_entry.p, F0.val.p, F0.dinv.p);
+    if (!coarse_levels) return;           // (experiment OPMGPU_AMG_LAG_COARSE) level 0 follows the matrix, the coarse operators lag
     for (size_t l = 0; l + 1 < levels.size(); ++l) {
         AmgLevel<S>& F = *levels[l]; AmgLevel<S>& C = *levels[l + 1];
-        hipLaunchKernelGGL((k_amg_dinv<S>), dim3(grid_for(F.ntot())), dim3(kBlock), 0, stream, F.ntot(), F.diag_entry.p, F.val.p, F.dinv.p);
-        if (!coarse_levels) return;           // (experiment OPMGPU_AMG_LAG_COARSE) level 0 follows the matrix, the coarse operators lag
-        static const int wave_below = std::getenv("OPMGPU_AMG_GALERKIN_WAVE") ? std::atoi(std::getenv("OPMGPU_AMG_GALERKIN_WAVE")) : 400000;
-        if (F.nentries_coarse > wave_below)
-            hipLaunchKernelGGL((k_amg_galerkin<S>), dim3(grid_for(F.nentries_coarse)), dim3(kBlock), 0, stream, F.nentries_coarse,
-                               F.contrib_ptr.p, F.contrib_idx.p, coarse_dev[l]->p, F.val.p, C.val.p);
-        else
-            hipLaunchKernelGGL((k_amg_galerkin_wave<S>), dim3((F.nentries_coarse + 3) / 4), dim3(kBlock), 0, stream, F.nentries_coarse,
-                               F.contrib_ptr.p, F.contrib_idx.p, coarse_dev[l]->p, F.val.p, C.val.p);
+        const int nce = F.nentries_coarse;
+#define OPMGPU_GALERKIN(LPE) hipLaunchKernelGGL((k_amg_galerkin<S, LPE>), dim3(grid8_for(long(nce) * LPE)), dim3(kBlock), 0, stream, xcd_mode(), nce, \
+                               F.contrib_ptr.p, F.contrib_idx.p, F.contrib_diag.p, F.val.p, C.val.p, C.dinv.p)
+        switch (F.galerkin_lpe) {
+            case 1: OPMGPU_GALERKIN(1); break;
+            case 8: OPMGPU_GALERKIN(8); break;
+            case 16: OPMGPU_GALERKIN(16); break;
+            default: OPMGPU_GALERKIN(64); break;
+        }
+#undef OPMGPU_GALERKIN
     }
     AmgLevel<S>& B = *levels.back();
-    hipLaunchKernelGGL((k_amg_dinv<S>), dim3(grid_for(B.n)), dim3(kBlock), 0, stream, B.n, B.diag_entry.p, B.val.p, B.dinv.p);
     if (n_coarsest <= kDenseMax) {
+        // the explicit inverse of the coarsest operator (one workgroup, ~50 us) on a side stream: the first cycle needs it only at the
+        // bottom of its down leg, so the inversion runs behind the right-hand side set-up and the down leg (join_inverse())
+        if (!inv_stream) {
+            OPMGPU_HIP(hipStreamCreateWithFlags(&inv_stream, hipStreamNonBlocking));
+            for (auto& e : ev_inv) OPMGPU_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        hipStream_t q = stream;
+        if (inv_overlap) {
+            OPMGPU_HIP(hipEventRecord(ev_inv[0], stream));
+            OPMGPU_HIP(hipStreamWaitEvent(inv_stream, ev_inv[0], 0));
+            q = inv_stream;
+        }
         int lg = 0; while ((1 << lg) < B.n) ++lg;
-        if (B.n <= 64) hipLaunchKernelGGL((k_dense_invert<S, 4>), dim3(1), dim3(1024), size_t(2) * B.n * B.n * sizeof(double), stream, B.n, lg, B.slice_ptr, B.col, B.val.p, dense_inv.p);
-        else hipLaunchKernelGGL((k_dense_invert<S, 12>), dim3(1), dim3(1024), size_t(2) * B.n * B.n * sizeof(double), stream, B.n, lg, B.slice_ptr, B.col, B.val.p, dense_inv.p);
+        if (B.n <= 64) hipLaunchKernelGGL((k_dense_invert<S, 4>), dim3(1), dim3(1024), size_t(2) * B.n * B.n * sizeof(double), q, B.n, lg, B.slice_ptr, B.col, B.val.p, dense_inv.p);
+        else hipLaunchKernelGGL((k_dense_invert<S, 12>), dim3(1), dim3(1024), size_t(2) * B.n * B.n * sizeof(double), q, B.n, lg, B.slice_ptr, B.col, B.val.p, dense_inv.p);
         OPMGPU_HIP(hipGetLastError());
+        if (inv_overlap) { OPMGPU_HIP(hipEventRecord(ev_inv[1], inv_stream)); inv_pending = true; }
     }
+}
+template <class S>
+void AmgHierarchy<S>::join_inverse()
+{
+    if (!inv_pending) return;
+    OPMGPU_HIP(hipStreamWaitEvent(stream, ev_inv[1], 0));
+    inv_pending = false;
 }
 
 constexpr int kSubLanes = 8;
@@ -672,6 +728,7 @@ void AmgHierarchy<S>::vcycle(const SolveCtl* ctl, bool level0_presmoothed)
     }
     AmgLevel<S>& B = *levels.back();
     if (n_coarsest <= kDenseMax) {
+        join_inverse();
         hipLaunchKernelGGL((k_dense_apply<S>), dim3((B.n + 3) / 4), dim3(kBlock), 0, stream, B.n, dense_inv.p, B.b.p, B.x.p, ctl);
     } else {        // coarsening stalled above the dense limit: a few Jacobi sweeps stand in for the coarse solve
         hipLaunchKernelGGL((k_amg_smooth0<S>), dim3(grid_for(B.n)), dim3(kBlock), 0, stream, B.n, om, B.dinv.p, B.b.p, B.x.p, ctl);
@@ -733,6 +790,7 @@ void AmgHierarchy<S>::vcycle_graph(const SolveCtl* ctl, bool level0_presmoothed)
 {
     const bool even = (npost % 2 == 0) && (npost0 % 2 == 0) && npre == 1;
     if (!use_graph || !even) { vcycle(ctl, level0_presmoothed); return; }
+    join_inverse();          // an event of another stream cannot be waited for inside a capture
     // the captured launches carry the smoother / correction constants as baked-in kernel arguments: they are part of the cache key
     const double key[6] = { pdamp0, pdamp, omega0(), double(npost), double(npost0), double(npre) };
     bool same = graph_exec && graph_ctl == ctl && graph_pre == level0_presmoothed;

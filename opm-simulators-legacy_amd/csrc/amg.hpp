@@ -36,8 +36,9 @@ struct AmgLevel {
     // transfer to the next coarser level
     DevArray<int32_t> agg;                      // [n] coarse index of every row
     DevArray<int32_t> agg_ptr, agg_rows;        // rows of every aggregate (restriction, fixed order)
-    DevArray<int32_t> contrib_ptr, contrib_idx; // fine entries summed into every coarse entry (Galerkin)
-    int n_coarse = 0, nentries_coarse = 0;
+    DevArray<int32_t> contrib_ptr, contrib_idx; // fine entries summed into every coarse entry (Galerkin), entries sorted by trip count
+    DevArray<int32_t> contrib_diag;             // per (sorted) coarse entry: its row if it is the diagonal one, else -1
+    int n_coarse = 0, nentries_coarse = 0, galerkin_lpe = 1;
     // Level 0 only -- BORDERED operator [A_p Bc; Cr Dw]: one extra unknown per well (its bhp) that couples the well's perforated cells
     // like the reference's explicit Schur complement does, without filling the borrowed block-plan structure with a clique per well.
     // Vectors of a bordered level have n + nw entries (well k at index n + k); the border values live behind the SELL values:
@@ -63,7 +64,12 @@ template <class S>
 class AmgHierarchy {
 public:
     explicit AmgHierarchy(hipStream_t s) : stream(s) {}
-    ~AmgHierarchy() { if (graph_exec) (void)hipGraphExecDestroy(graph_exec); }
+    ~AmgHierarchy()
+    {
+        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        for (auto e : ev_inv) if (e) (void)hipEventDestroy(e);
+        if (inv_stream) (void)hipStreamDestroy(inv_stream);
+    }
     AmgHierarchy(const AmgHierarchy&) = delete;
     AmgHierarchy& operator=(const AmgHierarchy&) = delete;
     // structure from the block plan + the level-0 pressure values (host copy, entry-indexed); builds all levels
@@ -82,8 +88,12 @@ public:
     double graph_key[6] = { 0, 0, 0, 0, 0, 0 };
     bool graph_pre = false, use_graph = false;
     std::vector<std::unique_ptr<AmgLevel<S>>> levels;
-    std::vector<std::unique_ptr<DevArray<int32_t>>> coarse_dev;   // per fine level: device entry id of every coarse csr entry
     DevArray<double> dense_inv;      // coarsest: explicit inverse (double), n_c x n_c
+    // the inversion runs on inv_stream behind the work that follows galerkin(); the first user of dense_inv joins it
+    hipStream_t inv_stream = nullptr;
+    hipEvent_t ev_inv[2] = { nullptr, nullptr };
+    bool inv_pending = false, inv_overlap = true;
+    void join_inverse();
     int n_coarsest = 0;
     std::vector<int> level_sizes;
     hipStream_t stream;

@@ -1248,6 +1248,7 @@ template <> float* BlackoilDevice::deriv_planes<float>()
 // of the whole matrix and half of the assembly's write traffic.  The host-well path adds f64 blocks, so it keeps the double matrix.
 void BlackoilDevice::assemble(double dt, bool initial)
 {
+    well_words_valid = false;
     last_dt = dt;
     has_rhs_extra = false;
     if (initial) { d_dx_old.zero(stream); ls.new_step_hint = true; }       // first matrix of a time step: coarse AMG operators are rebuilt
@@ -1307,7 +1308,13 @@ int BlackoilDevice::convergence(double dt, double* B3, double* CNV3, double* MB3
     hipLaunchKernelGGL(k_conv_final, dim3(13), dim3(kBlock), 0, stream, g, d_red.p + 16, d_red.p);
     ls.kt.end(KT_CONV, kt_a);
     if (ls.comm) { ls.comm->allreduce_sum(d_red.p, 7, stream); ls.comm->allreduce_max(d_red.p + 7, 6, stream); }
-    std::memcpy(h_red, ls.fetch_words(d_red.p, 26), 13 * sizeof(double));          // (polled host-mapped copy: no stream synchronisation)
+    // (polled host-mapped copy: no stream synchronisation); the device wells' residuals and error flags come along for well_convergence()
+    const void *we = nullptr, *wf = nullptr; int nwe = 0;
+    const bool with_wells = !ls.comm && well_words_sources(we, nwe, wf) && 26 + nwe + 1 <= LinSolver::kPubWords;
+    const uint32_t* h = with_wells ? ls.fetch_words(d_red.p, 26, we, nwe, wf, 1) : ls.fetch_words(d_red.p, 26);
+    std::memcpy(h_red, h, 13 * sizeof(double));
+    well_words_valid = with_wells;
+    if (with_wells) well_words.assign(h + 26, h + 26 + nwe + 1);
     bool conv = true; int status = OPMGPU_OK;
     const double ncg = ls.comm ? double(ls.comm->n_owned_global) : double(nc);
     const double pvs = ls.comm ? pvsum_global : pvsum;
@@ -1591,6 +1598,9 @@ void BlackoilDevice::get_sat_oil_max(double* v)
 
 void BlackoilDevice::stabilize_update(int relax_type, double omega)
 {
+    // dampening by 1 changes nothing, and the previous increment (dx_old) is only ever read by the SOR form: no launch then.  (A run
+    // uses one relaxation type throughout -- NonlinearSolver's parameter --, so SOR never meets a dx_old that was skipped here.)
+    if (relax_type != OPMGPU_RELAX_SOR && omega == 1.0) return;
     const long n = 3 * long(ls.plan.nbp);
     if (device_wells) wells_stabilize(relax_type == OPMGPU_RELAX_SOR ? 1 : 0, omega);      // the well part first: it is recovered from the UNRELAXED dx
     hipLaunchKernelGGL(k_stabilize, dim3(unsigned((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, n, relax_type == OPMGPU_RELAX_SOR ? 1 : 0, omega,

@@ -66,6 +66,11 @@ public:
     int well_state_set(const double* bhp, const double* qs, const double* perf_press, const double* perf_rates);
     int well_state_get(double* bhp, double* qs, double* perf_press, double* perf_rates);
     int well_convergence(double* flux3, double* ctrl);
+    // the well residuals ride on convergence()'s read-back (one host round trip instead of two per Newton iteration); valid until the
+    // next assembly
+    bool well_words_sources(const void*& e, int& ne, const void*& f) const;
+    std::vector<uint32_t> well_words;
+    bool well_words_valid = false;
     bool has_device_wells() const;        // a device well model is attached (on this or, in a multi-rank run, on any rank)
     int set_vfp_tables(int n, const opmgpu_vfp_table* tabs);
     int well_controls_set(const int32_t* current, const double* thp);

@@ -1867,27 +1867,29 @@ void LinSolver::wait_tick(int tick)
     OPMGPU_HIP(hipStreamSynchronize(stream));
 }
 
-__global__ __launch_bounds__(kBlock) void k_fetch_words(const uint32_t* __restrict__ s0, int n0, const uint32_t* __restrict__ s1, int n1, uint32_t* __restrict__ dst,
-                                                        int* __restrict__ tick_ptr, int tick)
+__global__ __launch_bounds__(kBlock) void k_fetch_words(const uint32_t* __restrict__ s0, int n0, const uint32_t* __restrict__ s1, int n1, const uint32_t* __restrict__ s2, int n2,
+                                                        uint32_t* __restrict__ dst, int* __restrict__ tick_ptr, int tick)
 {
     for (int i = threadIdx.x; i < n0; i += kBlock) dst[i] = s0[i];
     for (int i = threadIdx.x; i < n1; i += kBlock) dst[n0 + i] = s1[i];
+    for (int i = threadIdx.x; i < n2; i += kBlock) dst[n0 + n1 + i] = s2[i];
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) { __threadfence_system(); *(volatile int*)tick_ptr = tick; }
 }
-const uint32_t* LinSolver::fetch_words(const void* src0, int nwords0, const void* src1, int nwords1)
+const uint32_t* LinSolver::fetch_words(const void* src0, int nwords0, const void* src1, int nwords1, const void* src2, int nwords2)
 {
-    if (nwords0 + nwords1 > kPubWords) throw HipError(OPMGPU_EINVAL, "fetch_words: too many words");
+    if (nwords0 + nwords1 + nwords2 > kPubWords) throw HipError(OPMGPU_EINVAL, "fetch_words: too many words");
     if (!poll_status) {
         if (nwords0) OPMGPU_HIP(hipMemcpyAsync(h_pub, src0, size_t(nwords0) * 4, hipMemcpyDeviceToHost, stream));
         if (nwords1) OPMGPU_HIP(hipMemcpyAsync(h_pub + nwords0, src1, size_t(nwords1) * 4, hipMemcpyDeviceToHost, stream));
+        if (nwords2) OPMGPU_HIP(hipMemcpyAsync(h_pub + nwords0 + nwords1, src2, size_t(nwords2) * 4, hipMemcpyDeviceToHost, stream));
         OPMGPU_HIP(hipStreamSynchronize(stream));
         return h_pub;
     }
     const int tick = ++tick_seq;
-    hipLaunchKernelGGL(k_fetch_words, dim3(1), dim3(kBlock), 0, stream, static_cast<const uint32_t*>(src0), nwords0, static_cast<const uint32_t*>(src1), nwords1, h_pub_dev,
-                       h_tick_dev, tick);
+    hipLaunchKernelGGL(k_fetch_words, dim3(1), dim3(kBlock), 0, stream, static_cast<const uint32_t*>(src0), nwords0, static_cast<const uint32_t*>(src1), nwords1,
+                       static_cast<const uint32_t*>(src2), nwords2, h_pub_dev, h_tick_dev, tick);
     wait_tick(tick);
     return h_pub;
 }
@@ -2315,11 +2317,17 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
     // defect sets `done` on the device, the iteration's kernels then return at once and its status check reports 0 iterations
     int j = 1;
     bool stop = false;
+    // the next iteration's product is enqueued BEFORE the host waits for this iteration's verdict (v_{i+1} is complete once k_gm_normalize
+    // ran; if the verdict is "converged" the product's kernels see `done` and return): the device starts on it while the host is still
+    // reading the status word and enqueueing the rest -- otherwise ~12 us of idle device per iteration.  A/B: OPMGPU_GMRES_SPECULATE=0
+    static const bool speculate = !(std::getenv("OPMGPU_GMRES_SPECULATE") && std::atoi(std::getenv("OPMGPU_GMRES_SPECULATE")) == 0);
     while (j <= maxit && !stop) {
         int i = 0;
+        bool product_enqueued = false;
         for (; i < m && j <= maxit && !stop; ++i, ++j) {
             hipEvent_t kt_a = kt.begin();
-            product(V(i), w.v.p, (const SolveCtl*)d_ctl);
+            if (!product_enqueued) product(V(i), w.v.p, (const SolveCtl*)d_ctl);
+            product_enqueued = false;
             kt.end(KT_SPMV1, kt_a);
             precond(w.v.p, w.t.p);                                     // w = M^-1 A v_i
             kt_a = kt.begin();
@@ -2341,6 +2349,12 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
             const int tick = ++tick_seq;
             hipLaunchKernelGGL(k_gm_givens, dim3(1), dim3(1), 0, stream, i, m, j, g, d_ctl, h_ctl_dev, poll_status ? h_tick_dev : (int*)nullptr, tick);
             kt.end(KT_VECTOR, kt_a);
+            if (speculate && i + 1 < m && j + 1 <= maxit) {
+                kt_a = kt.begin();
+                product(V(i + 1), w.v.p, (const SolveCtl*)d_ctl);
+                kt.end(KT_SPMV1, kt_a);
+                product_enqueued = true;
+            }
             wait_tick(tick);
             if (h_ctl->done) stop = true;
         }

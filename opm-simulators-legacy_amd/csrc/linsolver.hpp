@@ -183,7 +183,7 @@ public:
     void wait_tick(int tick);
     // Small device results to the host without hipStreamSynchronize's interrupt round trip: one workgroup copies up to two word ranges
     // into a host-mapped buffer and writes the tick word the host spins on (wait_tick).  Returns the host copy (valid until the next call).
-    const uint32_t* fetch_words(const void* src0, int nwords0, const void* src1 = nullptr, int nwords1 = 0);
+    const uint32_t* fetch_words(const void* src0, int nwords0, const void* src1 = nullptr, int nwords1 = 0, const void* src2 = nullptr, int nwords2 = 0);
     uint32_t* h_pub = nullptr;     // host-mapped
     uint32_t* h_pub_dev = nullptr;
     static constexpr int kPubWords = 8192;

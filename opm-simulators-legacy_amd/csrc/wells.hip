@@ -1011,6 +1011,13 @@ void BlackoilDevice::wells_assemble(bool initial)
 // well part of getConvergence (BlackoilModelBase_impl.hpp:1769-1779): max |flux equation| per phase, max |control equation|
 bool BlackoilDevice::has_device_wells() const { return wd != nullptr || ls.run_has_wells; }
 
+bool BlackoilDevice::well_words_sources(const void*& e, int& ne, const void*& f) const
+{
+    if (!wd) return false;
+    e = wd->wellE.p; ne = 8 * wd->nw; f = wd->flags.p + WF_ERR;
+    return true;
+}
+
 int BlackoilDevice::well_convergence(double* flux3, double* ctrl)
 {
     if (!wd && !ls.comm) return OPMGPU_EINVAL;
@@ -1019,7 +1026,11 @@ int BlackoilDevice::well_convergence(double* flux3, double* ctrl)
     if (wd) {
         WellsDev& W = *wd;
         int32_t fl = 0;
-        if (8 * W.nw + 1 <= LinSolver::kPubWords) {
+        if (well_words_valid && int(well_words.size()) == 8 * W.nw + 1) {            // read back by convergence() after this assembly
+            std::memcpy(W.h_pinned, well_words.data(), 4 * size_t(W.nw) * sizeof(double));
+            std::memcpy(&fl, well_words.data() + 8 * W.nw, sizeof(int32_t));
+            well_words_valid = false;
+        } else if (8 * W.nw + 1 <= LinSolver::kPubWords) {
             const uint32_t* h = ls.fetch_words(W.wellE.p, 8 * W.nw, W.flags.p + WF_ERR, 1);
             std::memcpy(W.h_pinned, h, 4 * size_t(W.nw) * sizeof(double));
             std::memcpy(&fl, h + 8 * W.nw, sizeof(int32_t));
