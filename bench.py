@@ -61,11 +61,12 @@ def main():
     ap.add_argument("--ordering", choices=["multicolor", "natural"], default="multicolor")
     ap.add_argument("--solver", choices=["cpr", "ilu0"], default="cpr",
                     help="cpr: AMG pressure stage + ILU0 (reference solver_approach=cpr); ilu0: reference default solver_approach=interleaved")
-    ap.add_argument("--krylov", choices=["auto", "bicgstab", "gmres"], default="auto",
+    ap.add_argument("--krylov", choices=["auto", "bicgstab", "gmres", "fgmres"], default="auto",
                     help="gmres: the reference's newton_use_gmres option (restarted GMRES(40), left-preconditioned; single GPU only).  auto: gmres "
                          "under CPR on the deck with wells (measured: 3.75 preconditioner applications per Newton iteration against BiCGStab's 4.1 "
                          "iterations = 9.5 applications; on the SPE10-like deck BiCGStab does not converge within 50 iterations), bicgstab otherwise "
-                         "(well-free deck: 1.75 iterations against GMRES's 3.95) -- the other method runs as a same-run variant")
+                         "(well-free deck: 1.75 iterations against GMRES's 3.95) -- the other method runs as a same-run variant; fgmres: the flexible "
+                         "(right-preconditioned) form, not a reference solver, measured slower (4.95 columns against 3.65)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N > 1: weak = every GPU keeps an nx x ny x nz slab (global deck nx x ny x nz*N, sized for 288 GB/GPU); strong = the fixed nx x ny x nz deck is cut into N slabs")
     ap.add_argument("--deck", choices=["cart", "spe10like"], default="cart", help="spe10like: 60 x 220 x 85 cells, sigma_lnK = 2.5 (BASELINE configs[3]); implies its own dimensions")
@@ -119,7 +120,7 @@ def main():
     use_wells = args.wells == "fivespot" and not (use_dist and (args.scaling == "strong" or args.deck == "spe10like"))
     if args.krylov == "auto":
         args.krylov = "gmres" if (use_wells and args.solver == "cpr") else "bicgstab"
-    prm = capi.default_params(ilu_ordering=ordering, use_cpr=int(args.solver == "cpr"), newton_use_gmres=int(args.krylov == "gmres"))
+    prm = capi.default_params(ilu_ordering=ordering, use_cpr=int(args.solver == "cpr"), newton_use_gmres={"gmres": 1, "fgmres": 2}.get(args.krylov, 0))
 
     def make_deck():
         if args.deck == "spe10like":
@@ -344,7 +345,7 @@ def main():
                                                                      args.nz * (world if (world > 1 and args.scaling == "weak" and args.deck == "cart") else 1),
                                                                      "_fivespot" if use_wells else ""),
                        "cells": nc_global, "cells_per_gpu": info["n_owned"], "nnzb_rank0": nnzb,
-                       "dt_days": args.dt_days, "linear_solver": ("cpr(amg V-cycle + ilu0)" if prm.use_cpr else "ilu0") + (" + gmres(40)" if prm.newton_use_gmres else " + bicgstab"), "ilu0_ordering": args.ordering,
+                       "dt_days": args.dt_days, "linear_solver": ("cpr(amg V-cycle + ilu0)" if prm.use_cpr else "ilu0") + ({1: " + gmres(40)", 2: " + flexible gmres(40)"}.get(prm.newton_use_gmres, " + bicgstab")), "ilu0_ordering": args.ordering,
                        "linear_iterations_per_newton": res["lin"], "time_steps_completed": res["steps_done"], "time_steps_not_converged": res["steps_not_converged"], "time_steps_chopped": res["chopped"],
                        "spin_up_time_steps": args.spin_up, "nonlinear_solver": "reference NonlinearSolver (max_iter 10, update stabilisation on)",
                        "tables": "tests/satfuncStandard.DATA PROPS (reference's own test deck)", "wells": wells_txt,

@@ -1219,9 +1219,10 @@ template <class MS> void BlackoilDevice::assemble_kernels(double dt, bool initia
     const Plan& P = ls.plan;
     const double* sc = prm.matbalscale;
     MS* pd = deriv_planes<MS>();
-    // CPR on a system without wells: k_flux also writes the weights of the pressure equation
+    // CPR: k_flux also writes the weights of the pressure equation (the device well model redoes those of its perforated cells after
+    // its diagonal contributions, wells_assemble; explicit host well cliques change off-diagonal blocks: the solver's own pass then)
     MS* wout = nullptr;
-    if (prm.use_cpr && nperf == 0 && ls.cpr_weight_mode == 0 && ls.emulate_ranks <= 1) { ls.ensure_work<MS>(); ls.work<MS>().cprw.alloc(3 * size_t(P.nbp)); wout = ls.work<MS>().cprw.p; }
+    if (prm.use_cpr && (nperf == 0 || device_wells) && ls.cpr_weight_mode == 0 && ls.emulate_ranks <= 1) { ls.ensure_work<MS>(); ls.work<MS>().cprw.alloc(3 * size_t(P.nbp)); wout = ls.work<MS>().cprw.p; }
     hipEvent_t kt_a = ls.kt.begin();
     hipLaunchKernelGGL((k_cell_props<MS>), dim3(grid_for(nc)), dim3(kBlock), tab_lds_bytes(), stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_pv.p,
                        d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, 1.0 / dt, int(initial), sc[0], sc[1], sc[2],

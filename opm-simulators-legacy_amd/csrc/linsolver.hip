@@ -716,6 +716,21 @@ __global__ __launch_bounds__(kBlock) void k_cpr_weights(int nb, int nbp, const i
     cpr_row_weights<S>(row & 63, slice_ptr[row >> 6], rowlen[row], nlower[row], tpos, A, mode, ww);
     w[row] = ww[0]; w[nbp + row] = ww[1]; w[2 * long(nbp) + row] = ww[2];
 }
+// the same for a list of rows: the assembly kernel wrote the weights of every row from the reservoir equations, the device well model then
+// changed the diagonal blocks of its perforated cells -- their weights are redone from the final matrix (off-diagonal blocks, and with
+// them every other row's column sums, are untouched by the wells)
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_cpr_weights_rows(int nrows, const int32_t* __restrict__ rows, int nbp, const int32_t* __restrict__ slice_ptr,
+                                                             const int16_t* __restrict__ rowlen, const int16_t* __restrict__ nlower, const int32_t* __restrict__ tpos,
+                                                             const S* __restrict__ A, S* __restrict__ w, int mode)
+{
+    const int q = blockIdx.x * kBlock + threadIdx.x;
+    if (q >= nrows) return;
+    const int row = rows[q];
+    S ww[3];
+    cpr_row_weights<S>(row & 63, slice_ptr[row >> 6], rowlen[row], nlower[row], tpos, A, mode, ww);
+    w[row] = ww[0]; w[nbp + row] = ww[1]; w[2 * long(nbp) + row] = ww[2];
+}
 // A_p(i,j) = sum over the selected equations of A_ij[eq][pressure]; one thread per row (padding slots included: value 0)
 template <class S>
 __global__ __launch_bounds__(kBlock) void k_extract_pressure(int nb, int nbp, const int32_t* __restrict__ slice_ptr, const S* __restrict__ w,
@@ -1594,6 +1609,13 @@ template <class S> void LinSolver::coarse_begin()
     if (!emulated) w.csT.alloc(size_t(cs_slots.n) * plan.nbp);
 }
 
+template <class S> void LinSolver::cpr_reweigh_rows(const int32_t* d_rows, int nrows)
+{
+    if (nrows <= 0 || !weights_from_assembly) return;
+    hipLaunchKernelGGL((k_cpr_weights_rows<S>), dim3(grid_for(nrows)), dim3(kBlock), 0, stream, nrows, d_rows, plan.nbp, dp.slice_ptr.p, dp.rowlen.p, dp.nlower.p,
+                       dp.tpos.p, matrix<S>(), work<S>().cprw.p, cpr_weight_mode);
+}
+
 template <class S> void LinSolver::cpr_prepare()
 {
     SolverWork<S>& w = work<S>();
@@ -1636,6 +1658,9 @@ template <class S> void LinSolver::cpr_prepare()
                                dp.nlower.p, dp.tpos.p, (const int32_t*)nullptr, (const int8_t*)nullptr, matrix<S>(), w.cprw.p,
                                w.amg->levels[0]->val.p, (double*)nullptr, (S*)nullptr);
         }
+        // the factorisation (HBM-bound, on its own stream) next to the Galerkin chain (gather- and latency-bound) rather than next to
+        // this row pass (HBM-bound too): see solve_loaded / OPMGPU_FACTOR_AFTER_ROWS
+        if (factor_deferred) { factor_deferred = false; factor_async<S>(); }
         // Coarse operators (levels >= 1 and the coarsest inverse, 0.18 of the 0.27 ms set-up) follow the first TWO matrices of a time
         // step (the first update moves the state most; the second solve is also the reference for the guard below): level 0 (weights,
         // A_p, its Jacobi diagonal) is rebuilt for every matrix, the coarse-grid corrections of the Newton iterations 3.. of a step
@@ -1909,6 +1934,7 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
     const bool cpr = prm.use_cpr != 0;                   // multi-GPU: rank-local (additive Schwarz) AMG + block-Jacobi ILU0
     lag_allowed = prm.linear_solver_reduction >= 1e-4;
     if (cpr) cpr_prepare<S>();
+    if (factor_deferred) { factor_deferred = false; factor_async<S>(); }
     if (cpr && !w.amg->npost0_user) w.amg->npost0 = 2;            // post-sweeps on level 0: 2 under BiCGStab, 1 under GMRES (see gmres)
     const bool closed = closed_form_level0 && emulate_ranks <= 1;
     const int8_t* lightmask = nullptr;
@@ -2273,10 +2299,17 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
     static const bool gm_lag = std::getenv("OPMGPU_GMRES_LAG") && std::atoi(std::getenv("OPMGPU_GMRES_LAG")) != 0;
     lag_allowed = gm_lag && prm.linear_solver_reduction >= 1e-4;
     if (cpr) cpr_prepare<S>();
+    if (factor_deferred) { factor_deferred = false; factor_async<S>(); }
     // one post-smoothing sweep on level 0 instead of two: measured over nine decks with wells +1..+5 % under GMRES (the same iteration
     // counts within 0.1, a cheaper cycle), -7..0 % under BiCGStab on the well-free decks (profiles/r02_amg_sweep_gmres.log)
     if (cpr && !w.amg->npost0_user) w.amg->npost0 = 1;
     w.kry.alloc(size_t(m + 1) * n);
+    // newton_use_gmres = 2: flexible (right-preconditioned) GMRES -- z_i = M^-1 v_i is KEPT, w = A z_i is orthogonalised, x += sum y_i z_i.
+    // Not the reference's solver: Dune's RestartedGMResSolver (value 1) applies M from the left, which costs one application more per
+    // solve (M^-1 b before the first column; a CPR solve has ~4 columns) and stops on the PRECONDITIONED residual; this form stops on the
+    // true residual, the criterion of the reference's default BiCGStab.  One more basis of m vectors in memory.
+    const bool flex = prm.newton_use_gmres == 2;
+    if (flex) w.kryz.alloc(size_t(m) * n);
     gmbuf.alloc(size_t(m + 1) * m + (m + 1) + 3 * m + 8);
     gmbuf.zero(stream);
     GmState g; g.H = gmbuf.p; g.s = g.H + size_t(m + 1) * m; g.cs = g.s + (m + 1); g.sn = g.cs + m; g.y = g.sn + m;
@@ -2302,17 +2335,18 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
     };
     auto V = [&](int k) { return w.kry.p + size_t(k) * n; };
     auto precond = [&](const S* d, S* out) { if (cpr) cpr_apply<S>(d, out, prm.ilu_relaxation, d_ctl); else ilu_apply<S>(d, out, prm.ilu_relaxation, d_ctl); };
-    auto normalize_start = [&](int first) {          // v0 = M^-1 defect (in w.t), then v0 /= ||v0||, s[0] = ||v0||
-        dot(w.t.p, w.t.p);
+    auto Z = [&](int k) { return w.kryz.p + size_t(k) * n; };
+    auto normalize_start = [&](const S* src, int first) {          // v0 = src / ||src||, s[0] = ||src||  (src = M^-1 defect, flexible: the defect)
+        dot(src, src);
         hipLaunchKernelGGL((k_gm_normalize<S>), dim3(gv), dim3(kBlock), 0, stream, n, -1, first, prm.linear_solver_reduction, dot_arr, dot_np,
-                           g.H, g.s, (const S*)w.t.p, V(0), d_ctl, h_ctl_dev);
+                           g.H, g.s, src, V(0), d_ctl, h_ctl_dev);
         hipLaunchKernelGGL(k_gm_reset_s, dim3(1), dim3(1), 0, stream, m, g);
     };
     // x0 = 0: defect = b
     w.x.zero(stream);
     hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(1), 0, stream, d_ctl, h_ctl_dev, prm.linear_solver_reduction);
-    precond(w.b.p, w.t.p);
-    normalize_start(1);
+    if (flex) normalize_start((const S*)w.b.p, 1);
+    else { precond(w.b.p, w.t.p); normalize_start((const S*)w.t.p, 1); }
     // no synchronisation here: the first iteration is enqueued behind the set-up (factorisation, hierarchy, first application); a zero
     // defect sets `done` on the device, the iteration's kernels then return at once and its status check reports 0 iterations
     int j = 1;
@@ -2325,11 +2359,19 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
         int i = 0;
         bool product_enqueued = false;
         for (; i < m && j <= maxit && !stop; ++i, ++j) {
-            hipEvent_t kt_a = kt.begin();
-            if (!product_enqueued) product(V(i), w.v.p, (const SolveCtl*)d_ctl);
-            product_enqueued = false;
-            kt.end(KT_SPMV1, kt_a);
-            precond(w.v.p, w.t.p);                                     // w = M^-1 A v_i
+            hipEvent_t kt_a;
+            if (flex) {
+                precond(V(i), Z(i));                                   // z_i = M^-1 v_i
+                kt_a = kt.begin();
+                product(Z(i), w.t.p, (const SolveCtl*)d_ctl);          // w = A z_i
+                kt.end(KT_SPMV1, kt_a);
+            } else {
+                kt_a = kt.begin();
+                if (!product_enqueued) product(V(i), w.v.p, (const SolveCtl*)d_ctl);
+                product_enqueued = false;
+                kt.end(KT_SPMV1, kt_a);
+                precond(w.v.p, w.t.p);                                 // w = M^-1 A v_i
+            }
             kt_a = kt.begin();
             // modified Gram-Schmidt, each step's update fused with the next step's projection (k_gm_axpy_dot)
             dot((const S*)V(0), (const S*)w.t.p);
@@ -2349,7 +2391,7 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
             const int tick = ++tick_seq;
             hipLaunchKernelGGL(k_gm_givens, dim3(1), dim3(1), 0, stream, i, m, j, g, d_ctl, h_ctl_dev, poll_status ? h_tick_dev : (int*)nullptr, tick);
             kt.end(KT_VECTOR, kt_a);
-            if (speculate && i + 1 < m && j + 1 <= maxit) {
+            if (speculate && !flex && i + 1 < m && j + 1 <= maxit) {
                 kt_a = kt.begin();
                 product(V(i + 1), w.v.p, (const SolveCtl*)d_ctl);
                 kt.end(KT_SPMV1, kt_a);
@@ -2362,12 +2404,12 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
         if (h_ctl->done && h_ctl->iters == 0) break;                   // zero defect: x = 0 is the solution, no column was built
         // x += sum_a y_a v_a with R y = s   (i columns were completed)
         hipLaunchKernelGGL(k_gm_solve_y, dim3(1), dim3(1), 0, stream, i, m, g);
-        hipLaunchKernelGGL((k_gm_update_x<S>), dim3(gv), dim3(kBlock), 0, stream, n, i, (const double*)g.y, (const S*)w.kry.p, w.x.p);
+        hipLaunchKernelGGL((k_gm_update_x<S>), dim3(gv), dim3(kBlock), 0, stream, n, i, (const double*)g.y, flex ? (const S*)w.kryz.p : (const S*)w.kry.p, w.x.p);
         if (!stop && j <= maxit) {                                     // restart from the true defect
             product(w.x.p, w.v.p, (const SolveCtl*)nullptr);
             hipLaunchKernelGGL((k_gm_defect<S>), dim3(gv), dim3(kBlock), 0, stream, n, (const S*)w.b.p, (const S*)w.v.p, w.r.p);
-            precond(w.r.p, w.t.p);
-            normalize_start(0);
+            if (flex) normalize_start((const S*)w.r.p, 0);
+            else { precond(w.r.p, w.t.p); normalize_start((const S*)w.t.p, 0); }
         }
     }
     // the status block is current (the last iteration's tick was waited for); what is still in flight (the combination of the basis
@@ -2509,6 +2551,7 @@ double LinSolver::time_kernel(int kernel, int reps, int single_precision)
     template void LinSolver::spmv<S>(const S*, S*);                                      \
     template void LinSolver::spmv_at<S>(const S*, S*, const S*, const int32_t*);        \
     template void LinSolver::cpr_prepare<S>();                                           \
+    template void LinSolver::cpr_reweigh_rows<S>(const int32_t*, int);                   \
     template const S* LinSolver::pre_matrix<S>();                                        \
     template void LinSolver::coarse_setup<S>(bool);                                      \
     template void LinSolver::coarse_begin<S>();                                          \

@@ -83,6 +83,7 @@ struct SolverWork {
     DevArray<S> Apre;   // OPMGPU_EMULATE_RANKS: matrix copy without the blocks across the emulated cuts
     DevArray<S> r, rt, p, v, t, y, x, b, z, hx;  // z: scratch of the CPR second stage; hx: halo staging of x_p (multi-GPU)
     DevArray<S> kry;                             // GMRES: Krylov basis, (restart + 1) vectors
+    DevArray<S> kryz;                            // flexible GMRES: the preconditioned basis z_i = M^-1 v_i, restart vectors
     DevArray<S> csT;                             // coarse space: per row, sum of its pressure entries towards each neighbour slot
     DevArray<S> cxc;                             // coarse-space part of the pressure correction (constant per subdomain)
     DevArray<S> cprw;                            // [3][nbp] per-cell weights of the pressure equation (formEllipticSystem)
@@ -139,6 +140,7 @@ public:
     template <class S> void spmv_at(const S* x, S* y, const S* val, const int32_t* col);    // the same operator on another copy of the matrix arrays
     // CPR (solver_approach=cpr): build / refresh the pressure AMG for the current matrix; two-stage apply
     template <class S> void cpr_prepare();
+    template <class S> void cpr_reweigh_rows(const int32_t* d_rows, int nrows);   // weights of these rows again, from the current matrix
     void drop_hierarchies();            // the wells changed: the bordered pressure hierarchy is rebuilt from the next matrix
     template <class S> void cpr_apply(const S* d, S* v, double relax, const SolveCtl* ctl, const double* cr_given = nullptr);
     // coarse-correction factors of the pressure cycle chosen for THIS matrix on the first right-hand side it sees (see cpr_tune)
@@ -218,6 +220,7 @@ public:
     // ILU0 factorisation on a second stream next to the set-up of the pressure stage (both only read the matrix); the first ILU0
     // application joins.  A/B: OPMGPU_FACTOR_OVERLAP
     bool factor_overlap = true, factor_pending = false;
+    bool factor_deferred = false;        // factor_async() is started by cpr_prepare() behind its pass over the matrix
     hipStream_t factor_stream = nullptr;
     hipEvent_t ev_factor[2] = { nullptr, nullptr };
     template <class S> void factor_async();

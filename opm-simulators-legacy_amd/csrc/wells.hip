@@ -1004,6 +1004,7 @@ void BlackoilDevice::wells_assemble(bool initial)
     else
         hipLaunchKernelGGL((k_well_assemble<double, false>), dim3(W.nw), dim3(kBlock), 0, stream, A, ls.dp.slice_ptr.p, ls.dp.nlower.p, sc[0], sc[1], sc[2], d_R.p,
                            ls.matrix_d(), d_rhs_extra.p, W.flags.p);
+    if (ls.matrix_is_float) ls.cpr_reweigh_rows<float>(W.perf_row.p, int(W.h_cells.size())); else ls.cpr_reweigh_rows<double>(W.perf_row.p, int(W.h_cells.size()));
     has_rhs_extra = true;
     W.dy_valid = false;
 }

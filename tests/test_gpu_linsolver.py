@@ -288,6 +288,40 @@ def test_gmres_option(gpu_lib, oracle, single):
     s.close()
 
 
+@pytest.mark.parametrize("single", [False, True])
+def test_flexible_gmres_stops_on_the_true_residual(gpu_lib, oracle, single):
+    """newton_use_gmres = 2 (not a reference solver): right-preconditioned GMRES with the preconditioned basis kept.
+    Its stopping quantity is the TRUE residual (the criterion of the reference's default BiCGStab), so ||b - A x|| <= reduction ||b||
+    must hold for what comes back; ILU0 and CPR as the preconditioner, a restart shorter than the iteration count."""
+    grid = decks.cartesian_grid(12, 10, 8, lognormal_sigma=0.8)
+    tab = decks.satfunc_standard_tables()
+    st = decks.initial_state(grid, tab, perturb=0.01)
+    prm0 = capi.default_params()
+    scale = np.asarray(prm0.matbalscale[:])
+    rowptr, col = oracle.pattern(grid)
+    nc = grid.nc
+    r, val, _, _ = oracle.assemble(grid, tab, 5 * decks.DAY, st, rowptr, col, scale=tuple(scale))
+    b = np.ascontiguousarray((r * np.repeat(scale, nc)).reshape(3, nc).T).ravel()
+    A = bsr_to_scipy(rowptr, col, val)
+    red = 1e-4 if single else 1e-6
+    slack = 20.0 if single else 1.0 + 1e-6           # float: the recurrence residual and the true one drift apart by rounding
+    for kw in (dict(ilu_ordering=capi.ORDER_NATURAL), dict(ilu_ordering=capi.ORDER_NATURAL, linear_solver_restart=12), dict(use_cpr=1)):
+        s = GpuNewtonIteration(capi.default_params(newton_use_gmres=2, linear_solver_reduction=red, linear_solver_maxiter=400, **kw))
+        try:
+            x = s.computeNewtonIncrement(rowptr, col, val, b, single)
+        except LinearSolverProblem:
+            pytest.fail("no convergence with %r after %d iterations, reduction %.2e" % (kw, s.iterations(), s.reduction))
+        assert s.reduction < red
+        assert np.linalg.norm(b - A @ x) <= slack * red * np.linalg.norm(b), kw
+        if "linear_solver_restart" in kw:
+            assert s.iterations() > 12                       # the restart path ran
+        s.close()
+    s = GpuNewtonIteration(capi.default_params(newton_use_gmres=2, linear_solver_reduction=1e-12, linear_solver_maxiter=3))
+    with pytest.raises(LinearSolverProblem):
+        s.computeNewtonIncrement(rowptr, col, val, b, single)
+    s.close()
+
+
 def test_global_coarse_space_restores_convergence_of_decomposed_preconditioner(gpu_lib, monkeypatch):
     """The CPR pressure stage's global coarse space (one unknown per subdomain).  OPMGPU_EMULATE_RANKS builds the preconditioner
     as a 4-rank run would (no coupling across the cuts in the ILU0's and the AMG's matrix): without the coarse space the
