@@ -1,5 +1,6 @@
 // amg.hip -- plain-aggregation AMG for the CPR pressure stage (see amg.hpp).
 #include "amg.hpp"
+#include <functional>
 
 #include <string>
 #include <utility>
@@ -357,10 +358,22 @@ __global__ __launch_bounds__(kBlock) void k_amg_row_sub(int n, const int32_t* __
     double acc = 0.0;
     if (live) {
         const int base = slice_ptr[row >> 6], width = slice_ptr[(row >> 6) + 1] - base, lane = row & 63;
-        for (int k = l; k < width; k += LPR) {
-            const long e = long(base + k) * 64 + lane;
-            const int j = col[e];
-            acc += double(val[e]) * double(xf(j));
+        // predicated batches of 4 slots per lane: all (column, value) loads of a batch are issued before the first gather -- the plain
+        // loop is a chain of dependent round trips (column -> x) per slot, and these levels are bound by exactly that latency
+        for (int k0 = l; k0 < width; k0 += 4 * LPR) {
+            int jj[4]; S vv[4], xx[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + u * LPR;
+                const bool ok = k < width;
+                const long e = long(base + (ok ? k : 0)) * 64 + lane;
+                jj[u] = ok ? col[e] : -1;
+                vv[u] = ok ? val[e] : S(0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xx[u] = jj[u] >= 0 ? S(xf(jj[u])) : S(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += double(vv[u]) * double(xx[u]);
         }
     }
 #pragma unroll
@@ -604,12 +617,13 @@ void AmgHierarchy<S>::setup(const Plan& P, const int32_t* d_slice_ptr, const int
 }
 
 template <class S>
-void AmgHierarchy<S>::galerkin(bool coarse_levels)
+void AmgHierarchy<S>::galerkin(bool coarse_levels, const std::function<void()>& after_level0)
 {
     // the inverse diagonal of level 0 here; those of the coarse levels are written by the Galerkin kernel that produces their operator
     AmgLevel<S>& F0 = *levels[0];
     hipLaunchKernelGGL((k_amg_dinv<S>), dim3(grid_for(F0.ntot())), dim3(kBlock), 0, stream, F0.ntot(), F0.diag_entry.p, F0.val.p, F0.dinv.p);
-    if (!coarse_levels) return;           // (experiment OPMGPU_AMG_LAG_COARSE) level 0 follows the matrix, the coarse operators lag
+    if (!coarse_levels) { if (after_level0) after_level0(); return; }           // level 0 follows the matrix, the coarse operators lag
+    if (levels.size() < 2 && after_level0) after_level0();
     for (size_t l = 0; l + 1 < levels.size(); ++l) {
         AmgLevel<S>& F = *levels[l]; AmgLevel<S>& C = *levels[l + 1];
         const int nce = F.nentries_coarse;
@@ -622,6 +636,7 @@ void AmgHierarchy<S>::galerkin(bool coarse_levels)
             default: OPMGPU_GALERKIN(64); break;
         }
 #undef OPMGPU_GALERKIN
+        if (l == 0 && after_level0) after_level0();          // the bandwidth-heavy part of the chain is enqueued: see LinSolver::cpr_prepare
     }
     AmgLevel<S>& B = *levels.back();
     if (n_coarsest <= kDenseMax) {

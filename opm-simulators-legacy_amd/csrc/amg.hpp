@@ -14,6 +14,7 @@
 #ifndef OPMGPU_AMG_HPP
 #define OPMGPU_AMG_HPP
 
+#include <functional>
 #include <memory>
 #include <vector>
 
@@ -77,7 +78,8 @@ public:
     int border_nw() const { return levels.empty() ? 0 : levels[0]->nw; }
     bool ready() const { return !levels.empty(); }
     // numeric phase for a new matrix: level-0 values are already in levels[0].val
-    void galerkin(bool coarse_levels = true);
+    // after_level0: called once the level 0 -> 1 sums are enqueued (or at once when there is nothing of the kind)
+    void galerkin(bool coarse_levels = true, const std::function<void()>& after_level0 = {});
     // x0 = Vcycle(b0) with b0 in levels[0].b; result in levels[0].x
     // level0_presmoothed: levels[0].x already holds omega D^-1 b (the caller's kernel did the first sweep)
     void vcycle(const SolveCtl* ctl, bool level0_presmoothed = false);

@@ -1080,7 +1080,12 @@ template <class S> int LinSolver::factor(bool wait)
 template <class S> void LinSolver::factor_async()
 {
     if (!factor_stream) {
-        OPMGPU_HIP(hipStreamCreateWithFlags(&factor_stream, hipStreamNonBlocking));
+        // lowest priority: the factorisation is needed only by the first ILU0 sweep (behind the hierarchy set-up AND the first V-cycle),
+        // the Galerkin chain next to it is the critical path -- the dispatcher should give that one the free slots first
+        static const bool low = !(std::getenv("OPMGPU_FACTOR_PRIORITY") && std::atoi(std::getenv("OPMGPU_FACTOR_PRIORITY")) == 0);
+        int least = 0, greatest = 0;
+        OPMGPU_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        OPMGPU_HIP(hipStreamCreateWithPriority(&factor_stream, hipStreamNonBlocking, low ? least : greatest));
         for (auto& e : ev_factor) OPMGPU_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     OPMGPU_HIP(hipEventRecord(ev_factor[0], stream));
@@ -1658,9 +1663,6 @@ template <class S> void LinSolver::cpr_prepare()
                                dp.nlower.p, dp.tpos.p, (const int32_t*)nullptr, (const int8_t*)nullptr, matrix<S>(), w.cprw.p,
                                w.amg->levels[0]->val.p, (double*)nullptr, (S*)nullptr);
         }
-        // the factorisation (HBM-bound, on its own stream) next to the Galerkin chain (gather- and latency-bound) rather than next to
-        // this row pass (HBM-bound too): see solve_loaded / OPMGPU_FACTOR_AFTER_ROWS
-        if (factor_deferred) { factor_deferred = false; factor_async<S>(); }
         // Coarse operators (levels >= 1 and the coarsest inverse, 0.18 of the 0.27 ms set-up) follow the first TWO matrices of a time
         // step (the first update moves the state most; the second solve is also the reference for the guard below): level 0 (weights,
         // A_p, its Jacobi diagonal) is rebuilt for every matrix, the coarse-grid corrections of the Newton iterations 3.. of a step
@@ -1689,7 +1691,10 @@ template <class S> void LinSolver::cpr_prepare()
         refreshed = refresh;
         if (w.amg->border_nw() > 0)
             hipLaunchKernelGGL((k_cpr_border<S>), dim3(lowrank.nw), dim3(kBlock), 0, stream, lowrank, plan.nbp, (const S*)w.cprw.p, w.amg->levels[0]->val.p + w.amg->levels[0]->nentries);
-        w.amg->galerkin(refresh);
+        // The factorisation (HBM-bound, 140 us, on its own stream) is needed by the first ILU0 sweep only, i.e. behind the hierarchy set-up
+        // AND the first V-cycle.  It starts when the level 0 -> 1 Galerkin sums are done -- the one bandwidth-heavy kernel of the chain,
+        // which it would slow from 60 to 100 us -- and runs next to the small levels' sums and the first cycle (latency-bound launches).
+        w.amg->galerkin(refresh, [&] { if (factor_deferred) { factor_deferred = false; factor_async<S>(); } });
         if (coarse_nsub >= 1) coarse_setup<S>(true);
         return;
     }
