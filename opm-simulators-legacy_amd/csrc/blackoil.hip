@@ -860,6 +860,8 @@ BlackoilDevice::~BlackoilDevice()
     wells_free();
     vfp_free();
     if (h_red) (void)hipHostFree(h_red);
+    for (auto e : ev_well) if (e) (void)hipEventDestroy(e);
+    if (well_stream) (void)hipStreamDestroy(well_stream);
 }
 
 void BlackoilDevice::upload_tables(const opmgpu_tables* t)
@@ -1267,8 +1269,10 @@ void BlackoilDevice::assemble(double dt, bool initial)
         average_b(B);
         for (int a = 0; a < 3; ++a) prm.matbalscale[a] = B[a];
     }
+    const bool forked = wells_prologue_async(initial);
     if (ls.matrix_is_float) assemble_kernels<float>(dt, initial, ls.matrix_f());
     else assemble_kernels<double>(dt, initial, ls.matrix_d());
+    if (forked) OPMGPU_HIP(hipStreamWaitEvent(stream, ev_well[1], 0));
     KtScope kts(ls.kt, KT_WELLS);
     wells_assemble(initial);
 }

@@ -92,6 +92,13 @@ private:
     void upload_tables(const opmgpu_tables* t);
     void perf_props_device();
     void wells_assemble(bool initial);
+    // the part of wells_assemble() that reads only the state (perforation properties, updateWellControls): on Newton iterations after the
+    // first it runs on a side stream next to the reservoir assembly (returns true; wells_assemble() then starts behind it)
+    bool wells_prologue_async(bool initial);
+    void wells_prologue();
+    hipStream_t well_stream = nullptr;
+    hipEvent_t ev_well[2] = { nullptr, nullptr };
+    bool well_prologue_done = false;
     void wells_update(double relax, bool dx_from_host);
     void wells_stabilize(int sor, double omega);
     void wells_connection_pressures(const int32_t* gate);

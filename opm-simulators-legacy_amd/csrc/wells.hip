@@ -950,6 +950,38 @@ void BlackoilDevice::wells_connection_pressures(const int32_t* gate)
 }
 
 // called by assemble() after the reservoir kernels; the well part of BlackoilModelBase::assemble in the reference's order (:757-840)
+void BlackoilDevice::wells_prologue()
+{
+    WellsDev& W = *wd;
+    perf_props_device();
+    WellArgs A = args_of(W, vfp, ls.plan.nbp, d_perf.p, gravity);
+    if (W.vfp_active) wells_connection_pressures(nullptr);        // VFP: densities for the hydrostatic correction, every assembly (:771-776)
+    hipLaunchKernelGGL(k_well_controls, dim3((W.nw + 63) / 64), dim3(64), 0, stream, W.nw, A, W.flags.p);        // updateWellControls (:785)
+}
+// Newton iterations after the first of a time step: the prologue needs the state only, the reservoir assembly (0.36 ms) does not touch what
+// it writes (d_perf, the wells' control state) -- so it runs beside it on its own stream instead of 35 us behind it.  Not on the first
+// iteration (the pre-solve that follows needs the assembly's 1/b sums anyway) and not with THP controls (connection pressures in between).
+bool BlackoilDevice::wells_prologue_async(bool initial)
+{
+    static const bool on = !(std::getenv("OPMGPU_WELL_PROLOGUE_ASYNC") && std::atoi(std::getenv("OPMGPU_WELL_PROLOGUE_ASYNC")) == 0);
+    well_prologue_done = false;
+    if (!on || !wd || initial || wd->vfp_active) return false;
+    if (!well_stream) {
+        OPMGPU_HIP(hipStreamCreateWithFlags(&well_stream, hipStreamNonBlocking));
+        for (auto& e : ev_well) OPMGPU_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    OPMGPU_HIP(hipEventRecord(ev_well[0], stream));               // the state the previous update left
+    OPMGPU_HIP(hipStreamWaitEvent(well_stream, ev_well[0], 0));
+    std::swap(stream, well_stream);
+    const bool timing = ls.kt.on; ls.kt.on = false;               // (event brackets belong to the main stream)
+    wells_prologue();
+    ls.kt.on = timing;
+    std::swap(stream, well_stream);
+    OPMGPU_HIP(hipEventRecord(ev_well[1], well_stream));
+    well_prologue_done = true;
+    return true;
+}
+
 void BlackoilDevice::wells_assemble(bool initial)
 {
     if (!wd) {
@@ -959,11 +991,9 @@ void BlackoilDevice::wells_assemble(bool initial)
     }
     WellsDev& W = *wd;
     const Plan& P = ls.plan;
-    perf_props_device();
+    if (!well_prologue_done) wells_prologue();
+    well_prologue_done = false;
     WellArgs A = args_of(W, vfp, P.nbp, d_perf.p, gravity);
-    const int g = (W.nw + 63) / 64;
-    if (W.vfp_active) wells_connection_pressures(nullptr);        // VFP: densities for the hydrostatic correction, every assembly (:771-776)
-    hipLaunchKernelGGL(k_well_controls, dim3(g), dim3(64), 0, stream, W.nw, A, W.flags.p);        // updateWellControls (:785)
     const double* sc = prm.matbalscale;
     if (initial) {
         wells_connection_pressures(nullptr);      // once per time step from the explicit state (:797-805)

@@ -287,3 +287,40 @@ def test_one_call_newton_iteration_equals_the_call_by_call_sequence(gpu_lib, wit
     # iterations of a step must be consecutive from 0
     assert lib.opmgpu_nonlinear_iteration(gm.ctx, gm.dt, 1, 1, C.byref(ctl), C.byref(conv), C.byref(lin), None, None) == capi.EINVAL
     gm.close()
+
+
+@pytest.mark.parametrize("single", [False, True])
+def test_cpr_weights_with_device_wells_follow_the_final_matrix(gpu_lib, single):
+    """With device wells the assembly kernel writes the CPR weights of every row from the reservoir equations and the well model redoes the
+    rows of its perforated cells after adding its diagonal terms (k_cpr_weights_rows).  What the solver then uses must be
+    formEllipticSystem's rule (NewtonIterationUtilities.cpp:212-252, as in test_cpr_pressure_equation_weights) applied to the FINAL matrix."""
+    grid, tab, st, wl = _setup()
+    gm = GpuBlackoilModel(grid, tab, capi.default_params(use_cpr=1))
+    md = W.DeviceWellModel(gm, wl, W.WellState(wl, st.p))
+    md.prepareStep(150 * decks.DAY, st)          # long enough to need several Newton iterations
+    checked = 0
+    for it in range(4):                     # from the second iteration on the well prologue runs on its side stream
+        conv, _ = md.nonlinearIteration(it, single_precision=single)
+        if conv and it >= 1:
+            break                           # converged: no solve, nothing to check
+        checked += 1
+        # after the iteration: the matrix of THIS iteration is still resident, so are the weights of its solve
+        rowptr, col, val = gm.jacobian()
+        nb = rowptr.size - 1
+        rows = np.repeat(np.arange(nb), np.diff(rowptr))
+        diag = rows == col
+        v3 = val.reshape(-1, 3, 3)
+        expect = np.zeros((3, nb))
+        for eq in range(3):
+            dj = np.abs(v3[diag, eq, 0])[np.argsort(rows[diag])]
+            colsum = np.zeros(nb)
+            np.add.at(colsum, col, np.abs(v3[:, eq, 0]))
+            with np.errstate(divide="ignore", invalid="ignore"):
+                expect[eq] = (dj / (colsum - dj) > 0.01)
+        expect[1, expect.sum(0) == 0] = 1.0
+        w = np.zeros(3 * nb)
+        assert gm.lib.opmgpu_get_cpr_weights(gm.ctx, capi.dptr(w)) == capi.OK
+        bad = np.flatnonzero((w.reshape(3, nb) != expect).any(0))
+        assert bad.size == 0, (it, bad[:10], w.reshape(3, nb)[:, bad[:4]], expect[:, bad[:4]], sorted(set(wl.arrays()[1].tolist()) & set(bad.tolist())))
+    assert checked >= 2
+    gm.close()
