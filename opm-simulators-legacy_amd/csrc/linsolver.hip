@@ -2205,6 +2205,62 @@ __global__ __launch_bounds__(kBlock) void k_gm_axpy_dot(long n, int nbp, const i
     block_sum<1>(acc, sm);
     if (threadIdx.x == 0) parts_out[blockIdx.x] = acc[0];
 }
+// ---- decomposed runs: classical Gram-Schmidt.  Modified Gram-Schmidt (dune's, above) projects on v_0 .. v_i one after the other and
+// needs an all-reduce per projection -- i + 2 sequential ones in column i, ~13 us each over RCCL.  Here all projections of a column are
+// taken from the SAME w (one kernel, one all-reduce of i + 1 scalars), then subtracted together, then the norm of what is left (a second
+// all-reduce): 2 per column.  A different rounding path than the reference's -- used only where the preconditioner is decomposed anyway;
+// one GPU keeps dune's order (parity with the oracle's restatement).  The columns of a CPR solve are few (~4), so the weaker
+// orthogonality of the classical form does not show (OPMGPU_GMRES_CGS=0: modified Gram-Schmidt also when decomposed).
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_gm_multidot(long n, int nbp, const int8_t* __restrict__ mask, int cnt, const S* __restrict__ kry, const S* __restrict__ w,
+                                                        double* __restrict__ parts, const SolveCtl* __restrict__ ctl)
+{
+    __shared__ double sm[32];
+    if (ctl->done) return;
+    for (int k0 = 0; k0 < cnt; k0 += 8) {
+        double acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        const int nk = cnt - k0 < 8 ? cnt - k0 : 8;
+        for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) {
+            if (!mask[i % nbp]) continue;
+            const double wi = double(w[i]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (u < nk) acc[u] += wi * double(kry[long(k0 + u) * n + i]);
+        }
+        block_sum<8>(acc, sm);
+        if (threadIdx.x == 0) for (int u = 0; u < nk; ++u) parts[long(k0 + u) * gridDim.x + blockIdx.x] = acc[u];
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_sum_partials_multi(const double* __restrict__ parts, int np, double* __restrict__ out, const SolveCtl* __restrict__ ctl)
+{
+    __shared__ double sm[12];
+    if (ctl->done) return;
+    const double* const arr[1] = { parts + long(blockIdx.x) * np };
+    double s[1];
+    reduce_partials<1>(arr, np, s, sm);
+    if (threadIdx.x == 0) out[blockIdx.x] = s[0];
+}
+// w -= sum_k h_k v_k with the all-reduced h; column i of H; partial sums of the owned part of ||w||^2
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_gm_cgs_update(long n, int nbp, const int8_t* __restrict__ mask, int cnt, int m, int col, const double* __restrict__ h,
+                                                          double* __restrict__ H, const S* __restrict__ kry, S* __restrict__ w, double* __restrict__ parts_out,
+                                                          const SolveCtl* __restrict__ ctl)
+{
+    __shared__ double sm[8];
+    __shared__ S hs[64];
+    if (ctl->done) return;
+    for (int k = threadIdx.x; k < cnt; k += kBlock) { hs[k] = S(h[k]); if (blockIdx.x == 0) H[k * m + col] = h[k]; }
+    __syncthreads();
+    double acc[1] = { 0.0 };
+    for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) {
+        S v = w[i];
+        for (int k = 0; k < cnt; ++k) v -= hs[k] * kry[long(k) * n + i];
+        w[i] = v;
+        if (mask[i % nbp]) acc[0] += double(v) * double(v);
+    }
+    block_sum<1>(acc, sm);
+    if (threadIdx.x == 0) parts_out[blockIdx.x] = acc[0];
+}
 // vout = w / ||w|| with ||w||^2 in parts; slot >= 0: H[slot] = ||w|| (breakdown flag if ~0); slot < 0: the restart normalisation,
 // s[0] = ||w|| and, at the very first one (first != 0), the convergence threshold
 template <class S>
@@ -2315,7 +2371,8 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
     SolveResult res;
     // multi-GPU: the basis vector is halo-exchanged before every product (ghost rows of the product are zero, like in bicgstab), the
     // projections are owner-masked dot products whose partial arrays are collapsed and all-reduced before the axpy reads them: one small
-    // all-reduce per projection + one for the norm (j + 2 in iteration j of a cycle; a CPR solve takes ~4 iterations).  Every rank sees
+    // all-reduce per projection + one for the norm with dune's modified Gram-Schmidt (j + 2 in iteration j of a cycle), two per iteration with
+    // the classical form that decomposed runs use by default (k_gm_multidot; a CPR solve takes ~4 iterations).  Every rank sees
     // the same Hessenberg matrix, so the Givens / convergence decisions and the final combination are identical everywhere, and the
     // ghost entries of x are the owners' entries bit for bit (they are the same combination of exchanged basis vectors).
     const int8_t* mask = comm ? comm->owner_mask() : nullptr;
@@ -2340,6 +2397,9 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
     // solve (M^-1 b before the first column; a CPR solve has ~4 columns) and stops on the PRECONDITIONED residual; this form stops on the
     // true residual, the criterion of the reference's default BiCGStab.  One more basis of m vectors in memory.
     const bool flex = prm.newton_use_gmres == 2;
+    static const bool cgs_on = !(std::getenv("OPMGPU_GMRES_CGS") && std::atoi(std::getenv("OPMGPU_GMRES_CGS")) == 0);
+    const bool cgs = comm != nullptr && cgs_on && m <= 63;
+    if (cgs) cgs_parts.alloc(size_t(m + 1) * gv + size_t(m + 1));
     if (flex) w.kryz.alloc(size_t(m) * n);
     gmbuf.alloc(size_t(m + 1) * m + (m + 1) + 3 * m + 8);
     gmbuf.zero(stream);
@@ -2408,6 +2468,18 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
                 precond(w.v.p, w.t.p);                                 // w = M^-1 A v_i
             }
             kt_a = kt.begin();
+            if (cgs) {
+                // decomposed: classical Gram-Schmidt, two all-reduces per column (k_gm_multidot)
+                const int cnt = i + 1;
+                hipLaunchKernelGGL((k_gm_multidot<S>), dim3(gv), dim3(kBlock), 0, stream, n, plan.nbp, mask, cnt, (const S*)w.kry.p, (const S*)w.t.p, cgs_parts.p, (const SolveCtl*)d_ctl);
+                hipLaunchKernelGGL(k_sum_partials_multi, dim3(cnt), dim3(kBlock), 0, stream, (const double*)cgs_parts.p, gv, cgs_parts.p + size_t(m + 1) * gv, (const SolveCtl*)d_ctl);
+                comm->allreduce_sum(cgs_parts.p + size_t(m + 1) * gv, cnt, stream);
+                hipLaunchKernelGGL((k_gm_cgs_update<S>), dim3(gv), dim3(kBlock), 0, stream, n, plan.nbp, mask, cnt, m, i, (const double*)(cgs_parts.p + size_t(m + 1) * gv), g.H,
+                                   (const S*)w.kry.p, w.t.p, parts, (const SolveCtl*)d_ctl);
+                hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(kBlock), 0, stream, (const double*)parts, (const double*)nullptr, gv, red1);
+                comm->allreduce_sum(red1, 1, stream);
+                dot_arr = red1; dot_np = 1;
+            } else {
             // modified Gram-Schmidt, each step's update fused with the next step's projection (k_gm_axpy_dot)
             dot((const S*)V(0), (const S*)w.t.p);
             for (int k = 0; k <= i; ++k) {
@@ -2420,6 +2492,7 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
                     comm->allreduce_sum(red1, 1, stream);
                     dot_arr = red1; dot_np = 1;
                 }
+            }
             }
             hipLaunchKernelGGL((k_gm_normalize<S>), dim3(gv), dim3(kBlock), 0, stream, n, (i + 1) * m + i, 0, 0.0, dot_arr, dot_np, g.H, g.s,
                                (const S*)w.t.p, V(i + 1), d_ctl, h_ctl_dev);

@@ -220,6 +220,7 @@ public:
     // ILU0 factorisation on a second stream next to the set-up of the pressure stage (both only read the matrix); the first ILU0
     // application joins.  A/B: OPMGPU_FACTOR_OVERLAP
     bool factor_overlap = true, factor_pending = false;
+    DevArray<double> cgs_parts;          // decomposed GMRES, classical Gram-Schmidt: (restart + 1) partial arrays + their all-reduced sums
     bool factor_deferred = false;        // factor_async() is started by cpr_prepare() behind its pass over the matrix
     hipStream_t factor_stream = nullptr;
     hipEvent_t ev_factor[2] = { nullptr, nullptr };
