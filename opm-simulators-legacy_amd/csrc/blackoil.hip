@@ -850,7 +850,7 @@ BlackoilDevice::BlackoilDevice(hipStream_t s, LinSolver& ls_, const opmgpu_grid*
     pvsum = 0.0;
     for (int c = 0; c < nc; ++c) pvsum += h_pv[c];
     upload_tables(t);
-    OPMGPU_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_red), 16 * sizeof(double)));
+    OPMGPU_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_red), 32 * sizeof(double)));
     h_well_connpos.assign(1, 0);
     rebuild_structure();
 }
@@ -1023,7 +1023,7 @@ void BlackoilDevice::rebuild_structure()
     d_binv.alloc(3 * size_t(nbp)); d_binv.zero(stream);
     d_dx.alloc(3 * size_t(nbp)); d_dx.zero(stream);
     d_dx_old.alloc(3 * size_t(nbp)); d_dx_old.zero(stream);
-    d_red.alloc(13 * size_t(kMaxRedBlocks) + 16);
+    d_red.alloc(13 * size_t(kMaxRedBlocks) + kRedPart);
     OPMGPU_HIP(hipStreamSynchronize(stream));
     has_dx = false; has_saved = false;
     d_somax.alloc(nbp); d_somax.zero(stream);
@@ -1251,7 +1251,7 @@ template <> float* BlackoilDevice::deriv_planes<float>()
 // of the whole matrix and half of the assembly's write traffic.  The host-well path adds f64 blocks, so it keeps the double matrix.
 void BlackoilDevice::assemble(double dt, bool initial)
 {
-    well_words_valid = false;
+    well_words_valid = false; well_red_valid = false;
     last_dt = dt;
     has_rhs_extra = false;
     if (initial) { d_dx_old.zero(stream); ls.new_step_hint = true; }       // first matrix of a time step: coarse AMG operators are rebuilt
@@ -1309,15 +1309,20 @@ int BlackoilDevice::convergence(double dt, double* B3, double* CNV3, double* MB3
     const int g = std::min(grid_for(nc), kMaxRedBlocks);
     const int8_t* mask = ls.comm ? ls.comm->owner_mask() : nullptr;
     hipEvent_t kt_a = ls.kt.begin();
-    hipLaunchKernelGGL(k_conv_partial, dim3(g), dim3(kBlock), 0, stream, nc, P.nbp, d_R.p, d_binv.p, d_pv.p, mask, d_red.p + 16);
-    hipLaunchKernelGGL(k_conv_final, dim3(13), dim3(kBlock), 0, stream, g, d_red.p + 16, d_red.p);
+    hipLaunchKernelGGL(k_conv_partial, dim3(g), dim3(kBlock), 0, stream, nc, P.nbp, d_R.p, d_binv.p, d_pv.p, mask, d_red.p + kRedPart);
+    hipLaunchKernelGGL(k_conv_final, dim3(13), dim3(kBlock), 0, stream, g, d_red.p + kRedPart, d_red.p);
     ls.kt.end(KT_CONV, kt_a);
-    if (ls.comm) { ls.comm->allreduce_sum(d_red.p, 7, stream); ls.comm->allreduce_max(d_red.p + 7, 6, stream); }
+    // decomposed run with device wells somewhere: their convergence maxima (flux equations, control equation, error marks) ride on the same
+    // max-all-reduce in the slots 13..18 -- well_convergence() then needs neither its own all-reduce nor a stream synchronisation
+    const bool wells_ride = ls.comm && has_device_wells();
+    if (wells_ride) well_conv_pack(d_red.p + 13);
+    if (ls.comm) { ls.comm->allreduce_sum(d_red.p, 7, stream); ls.comm->allreduce_max(d_red.p + 7, wells_ride ? 12 : 6, stream); }
     // (polled host-mapped copy: no stream synchronisation); the device wells' residuals and error flags come along for well_convergence()
     const void *we = nullptr, *wf = nullptr; int nwe = 0;
     const bool with_wells = !ls.comm && well_words_sources(we, nwe, wf) && 26 + nwe + 1 <= LinSolver::kPubWords;
-    const uint32_t* h = with_wells ? ls.fetch_words(d_red.p, 26, we, nwe, wf, 1) : ls.fetch_words(d_red.p, 26);
-    std::memcpy(h_red, h, 13 * sizeof(double));
+    const uint32_t* h = with_wells ? ls.fetch_words(d_red.p, 26, we, nwe, wf, 1) : ls.fetch_words(d_red.p, wells_ride ? 38 : 26);
+    std::memcpy(h_red, h, (wells_ride ? 19 : 13) * sizeof(double));
+    well_red_valid = wells_ride;
     well_words_valid = with_wells;
     if (with_wells) well_words.assign(h + 26, h + 26 + nwe + 1);
     bool conv = true; int status = OPMGPU_OK;
@@ -1402,8 +1407,8 @@ double BlackoilDevice::relative_change()
     const int g = std::min(grid_for(nc), kMaxRedBlocks);
     const int8_t* mask = ls.comm ? ls.comm->owner_mask() : nullptr;
     hipLaunchKernelGGL(k_relchange_partial, dim3(g), dim3(kBlock), 0, stream, nc, d_p.p, d_sw.p, d_so.p, d_sg.p, d_saved.p, d_saved.p + nbp,
-                       d_saved.p + 2 * nbp, d_saved.p + 3 * nbp, mask, d_red.p + 16);
-    hipLaunchKernelGGL(k_sum2_final, dim3(1), dim3(kBlock), 0, stream, g, d_red.p + 16, d_red.p);
+                       d_saved.p + 2 * nbp, d_saved.p + 3 * nbp, mask, d_red.p + kRedPart);
+    hipLaunchKernelGGL(k_sum2_final, dim3(1), dim3(kBlock), 0, stream, g, d_red.p + kRedPart, d_red.p);
     if (ls.comm) ls.comm->allreduce_sum(d_red.p, 2, stream);
     OPMGPU_HIP(hipMemcpyAsync(h_red, d_red.p, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
     OPMGPU_HIP(hipStreamSynchronize(stream));

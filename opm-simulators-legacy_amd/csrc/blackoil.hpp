@@ -23,6 +23,8 @@ enum {
     PL_COUNT = 37
 };
 
+constexpr int kRedPart = 32;        // d_red: [0, 32) results, per-workgroup partials behind them
+
 class BlackoilDevice {
 public:
     BlackoilDevice(hipStream_t s, LinSolver& ls, const opmgpu_grid* g, const opmgpu_tables* t, const opmgpu_params* prm);
@@ -71,6 +73,9 @@ public:
     bool well_words_sources(const void*& e, int& ne, const void*& f) const;
     std::vector<uint32_t> well_words;
     bool well_words_valid = false;
+    // decomposed runs: the wells' six convergence numbers, max-all-reduced with the cells' (h_red[13..18] after convergence())
+    void well_conv_pack(double* d_out6);
+    bool well_red_valid = false;
     bool has_device_wells() const;        // a device well model is attached (on this or, in a multi-rank run, on any rank)
     int set_vfp_tables(int n, const opmgpu_vfp_table* tabs);
     int well_controls_set(const int32_t* current, const double* thp);

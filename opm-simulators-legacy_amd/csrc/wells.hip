@@ -986,7 +986,7 @@ void BlackoilDevice::wells_assemble(bool initial)
 {
     if (!wd) {
         // multi-GPU run with wells on OTHER ranks: the pre-solve's B_avg is a global mean -- take part in its all-reduce
-        if (initial && prm.solve_welleq_initially && ls.comm && ls.run_has_wells) binv_sums_device(d_red.p, d_red.p + 16);
+        if (initial && prm.solve_welleq_initially && ls.comm && ls.run_has_wells) binv_sums_device(d_red.p, d_red.p + kRedPart);
         return;
     }
     WellsDev& W = *wd;
@@ -1042,6 +1042,34 @@ void BlackoilDevice::wells_assemble(bool initial)
 // well part of getConvergence (BlackoilModelBase_impl.hpp:1769-1779): max |flux equation| per phase, max |control equation|
 bool BlackoilDevice::has_device_wells() const { return wd != nullptr || ls.run_has_wells; }
 
+// max |flux equation| per phase, max |control equation|, NaN / failure mark, singular mark of this rank's wells (zeros without wells); the
+// error word is consumed (reset) here, like well_convergence() does on the host path
+__global__ __launch_bounds__(kBlock) void k_well_conv_pack(int nw, const double* __restrict__ wellE, int32_t* __restrict__ flags, double* __restrict__ out)
+{
+    __shared__ double sm[4][6];
+    double m[6] = { 0, 0, 0, 0, 0, 0 };
+    for (int w = threadIdx.x; w < nw; w += kBlock)
+        for (int k = 0; k < 4; ++k) { const double e = fabs(wellE[4 * w + k]); if (!(e == e)) m[4] = 1.0; else m[k] = fmax(m[k], e); }
+    for (int k = 0; k < 6; ++k) {
+        double v = m[k];
+        for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 6; ++k) out[k] = fmax(fmax(sm[0][k], sm[1][k]), fmax(sm[2][k], sm[3][k]));
+        const int32_t fl = flags ? flags[0] : 0;
+        if (fl & (4 | 8 | 16)) out[4] = 1.0;
+        if (fl & 2) out[5] = 1.0;
+        if (fl) flags[0] = 0;
+    }
+}
+void BlackoilDevice::well_conv_pack(double* d_out6)
+{
+    if (wd) hipLaunchKernelGGL(k_well_conv_pack, dim3(1), dim3(kBlock), 0, stream, wd->nw, (const double*)wd->wellE.p, wd->flags.p + WF_ERR, d_out6);
+    else OPMGPU_HIP(hipMemsetAsync(d_out6, 0, 6 * sizeof(double), stream));
+}
+
 bool BlackoilDevice::well_words_sources(const void*& e, int& ne, const void*& f) const
 {
     if (!wd) return false;
@@ -1054,6 +1082,15 @@ int BlackoilDevice::well_convergence(double* flux3, double* ctrl)
     if (!wd && !ls.comm) return OPMGPU_EINVAL;
     double f[3] = { 0, 0, 0 }, c = 0.0;
     bool bad = false, singular = false;
+    if (ls.comm && well_red_valid) {            // all-reduced with the cells' maxima by convergence() after this assembly
+        well_red_valid = false;
+        for (int a = 0; a < 3; ++a) f[a] = h_red[13 + a];
+        c = h_red[16]; bad = h_red[17] != 0.0; singular = h_red[18] != 0.0;
+        if (flux3) for (int a = 0; a < 3; ++a) flux3[a] = f[a];
+        if (ctrl) *ctrl = c;
+        if (singular) return OPMGPU_ESINGULAR;
+        return bad ? OPMGPU_ENUMERICAL : OPMGPU_OK;
+    }
     if (wd) {
         WellsDev& W = *wd;
         int32_t fl = 0;
