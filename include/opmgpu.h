@@ -320,6 +320,19 @@ int opmgpu_save_state(opmgpu_ctx* ctx);
 int opmgpu_restore_state(opmgpu_ctx* ctx);
 int opmgpu_relative_change(opmgpu_ctx* ctx, double* value);
 
+/* BlackoilModelBase::computeFluidInPlace (BlackoilModelBase_impl.hpp:2263-2445; called by SimulatorBase_impl.hpp:207, :278 and
+ * AdaptiveTimeStepping_impl.hpp:322) for the RESIDENT state: per cell fip[phase] = pv_mult * b_phase * s_phase * pv (b at the phase
+ * pressures and the cell's phase condition), dissolved gas rs * fip[oil], vaporised oil rv * fip[gas], summed per region together with
+ * the pore volume and the hydrocarbon-pore-volume weighted average pressure.
+ *   fipnum    [nc] region of every cell in the caller's cell order, 1-based, 0 = in no region (the reference's fipnum[c] - 1 == -1);
+ *             NULL = one region of all cells
+ *   values    [nregions][7]: water, oil, gas, dissolved gas, vaporised oil, pore volume, weighted pressure (SimulatorData::FipId,
+ *             BlackoilModelEnums.hpp:53-61)
+ *   fip_cells [7][nc] or NULL: the per-cell arrays of SimulatorData::fip (getFIPData()), caller's cell order
+ * The per-cell evaluation runs on the device, the region loops on the host in the reference's cell order.  Not in decomposed runs
+ * (OPMGPU_EINVAL). */
+int opmgpu_compute_fluid_in_place(opmgpu_ctx* ctx, const int32_t* fipnum, int nregions, double* fip_cells, double* values);
+
 /* Maximum historical oil saturation per cell (BlackoilPropsAdFromDeck::satOilMax_, used by VAPPARS).
  * set: explicit values (nc, caller order; restart).  update: soMax = max(soMax, so of the resident state) --
  * what SimulatorBase_impl.hpp:192 does at the start of every report step (updateSatOilMax, :933-945).

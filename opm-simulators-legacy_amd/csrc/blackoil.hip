@@ -190,6 +190,7 @@ __device__ __forceinline__ void rocktab_eval(const double* __restrict__ x, const
 struct CellEval {
     V4 pw, pg, rs, rv, sw, so, sg;
     V4 b[3], mob[3], rho[3], accum[3];
+    V4 pvm;              // pore-volume multiplier (poroMult)
 };
 
 // SolutionState + ReservoirResidualQuant of one cell (BlackoilModelBase_impl.hpp:614-751, 1484-1497, 2009-2027)
@@ -327,6 +328,7 @@ __device__ void eval_cell(const opmgpu_tables& T, const EpsD& E, double so_max, 
         const double cp = T.rock_comp * (p - T.rock_pref);
         pvm = mk(1.0 + cp + 0.5 * cp * cp, T.rock_comp + cp * T.rock_comp, 0, 0);
     }
+    q.pvm = pvm;
     const V4 aw = vmul(vmul(pvm, q.b[0]), W);
     const V4 ao = vmul(vmul(pvm, q.b[1]), so);
     const V4 ag = vmul(vmul(pvm, q.b[2]), sg);
@@ -729,6 +731,35 @@ __global__ __launch_bounds__(kBlock) void k_perf_props(int nperf, opmgpu_tables 
     double* o = out + long(i) * OPMGPU_PERF_K;
 #pragma unroll
     for (int k = 0; k < 9; ++k) { o[4 * k] = list[k].v; o[4 * k + 1] = list[k].p; o[4 * k + 2] = list[k].w; o[4 * k + 3] = list[k].x; }
+}
+
+// computeFluidInPlace, the per-cell part (BlackoilModelBase_impl.hpp:2263-2296): fip[phase] = ((pv_mult * b_phase) * s_phase) * pv with b at the
+// phase pressures and the cell's phase condition, dissolved gas = rs * fip[oil], vaporised oil = rv * fip[gas]; plus what the region
+// loops need of the state (pore volume, pressure, so + sg).  Output in the CALLER's cell order: out[q * nc + nat[row]], q = 0..7.
+__global__ __launch_bounds__(kBlock) void k_fip_cells(int nc, opmgpu_tables T, const int32_t* __restrict__ nat, const int32_t* __restrict__ pvtnum,
+                                                      const int32_t* __restrict__ satnum, const double* __restrict__ pv, const double* __restrict__ p,
+                                                      const double* __restrict__ sw, const double* __restrict__ so_, const double* __restrict__ sg, const double* __restrict__ rs,
+                                                      const double* __restrict__ rv, const int8_t* __restrict__ hc, const double* __restrict__ eps,
+                                                      const double* __restrict__ eps_u0, const double* __restrict__ somax, long nbp,
+                                                      double* __restrict__ out, HystArgs hy)
+{
+    const int c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= nc) return;
+    CellEval q;
+    EpsD E, EI;
+    HystD H;
+    eps_load(eps, eps_u0, nbp, c, satnum[c], E);
+    hyst_load(hy.imbnum, hy.hist, nbp, c, H);
+    if (H.on) eps_load(hy.ieps, hy.iureg, nbp, c, H.ireg, EI);
+    eval_cell(T, E, somax[c], pvtnum[c], satnum[c], p[c], sw[c], sg[c], rs[c], rv[c], hc[c], q, H, &EI);
+    const long n = nat[c];
+    const double so = so_[c], sgv = sg[c], swv = sw[c];          // the state's saturations, as the reference takes them
+    const double fw = ((q.pvm.v * q.b[0].v) * swv) * pv[c];
+    const double fo = ((q.pvm.v * q.b[1].v) * so) * pv[c];
+    const double fg = ((q.pvm.v * q.b[2].v) * sgv) * pv[c];
+    out[0 * long(nc) + n] = fw; out[1 * long(nc) + n] = fo; out[2 * long(nc) + n] = fg;
+    out[3 * long(nc) + n] = rs[c] * fo; out[4 * long(nc) + n] = rv[c] * fg;
+    out[5 * long(nc) + n] = pv[c]; out[6 * long(nc) + n] = p[c]; out[7 * long(nc) + n] = so + sgv;
 }
 
 // computePropertiesForWellConnectionPressures (StandardWells_impl.hpp:218-296): b_w, b_o, b_g, rsSat, rvSat of the perforated cells at
@@ -1615,6 +1646,44 @@ void BlackoilDevice::stabilize_update(int relax_type, double omega)
     if (device_wells) wells_stabilize(relax_type == OPMGPU_RELAX_SOR ? 1 : 0, omega);      // the well part first: it is recovered from the UNRELAXED dx
     hipLaunchKernelGGL(k_stabilize, dim3(unsigned((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, n, relax_type == OPMGPU_RELAX_SOR ? 1 : 0, omega,
                        d_dx.p, d_dx_old.p);
+}
+
+// computeFluidInPlace (BlackoilModelBase_impl.hpp:2263-2445, the serial branch): per-cell volumes on the device, the region sums on the host
+// in cell order like the reference's loops (an output path: once per sub-step / report step).  fipnum: region per cell in the caller's
+// order, 0 = in no region, nullptr = one region of all cells; values: [dims][7]; fip_cells (optional): [7][nc] like SimulatorData::fip.
+void BlackoilDevice::fluid_in_place(const int32_t* fipnum, int dims, double* fip_cells, double* values)
+{
+    if (ls.comm) throw HipError(OPMGPU_EINVAL, "computeFluidInPlace: not available in decomposed runs (owner-masked sums + all-reduce are not restated)");
+    const Plan& P = ls.plan;
+    DevArray<double> dout; dout.alloc(size_t(8) * nc);
+    hipLaunchKernelGGL(k_fip_cells, dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, dt_, ls.dp.nat.p, d_pvtnum.p, d_satnum.p, d_pv.p,
+                       d_p.p, d_sw.p, d_so.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, eps_planes(), d_eps_u0.p, d_somax.p, long(P.nbp), dout.p, hyst_args());
+    std::vector<double> h(size_t(8) * nc);
+    dout.download(h.data(), h.size(), stream);
+    OPMGPU_HIP(hipStreamSynchronize(stream));
+    const double *pvol = h.data() + size_t(5) * nc, *pres_c = h.data() + size_t(6) * nc, *hyd = h.data() + size_t(7) * nc;
+    for (int i = 0; i < dims * 7; ++i) values[i] = 0.0;
+    auto region = [&](int c) { return fipnum ? fipnum[c] - 1 : 0; };
+    for (int ph = 0; ph < 5; ++ph)                       // phases, then the rs / rv volumes (:2312-2332)
+        for (int c = 0; c < nc; ++c) { const int r = region(c); if (r != -1) values[r * 7 + ph] += h[size_t(ph) * nc + c]; }
+    std::vector<double> hcpv(dims, 0.0), pres(dims, 0.0);
+    for (int c = 0; c < nc; ++c) { const int r = region(c); if (r != -1) { hcpv[r] += pvol[c] * hyd[c]; pres[r] += pvol[c] * pres_c[c]; } }
+    std::vector<double> fpv(nc, 0.0), fwp(nc, 0.0);
+    for (int c = 0; c < nc; ++c) {
+        const int r = region(c);
+        if (r == -1) continue;
+        fpv[c] = pvol[c];
+        // hydrocarbon-pore-volume weighted average pressure; a region without hydrocarbons: as the reference writes it (:2356-2360)
+        if (hcpv[r] != 0) fwp[c] = pvol[c] * pres_c[c] * hyd[c] / hcpv[r];
+        else fwp[c] = pres[r] / pvol[c];
+        values[r * 7 + 5] += fpv[c];
+        values[r * 7 + 6] += fwp[c];
+    }
+    if (fip_cells) {
+        std::copy(h.begin(), h.begin() + size_t(5) * nc, fip_cells);
+        std::copy(fpv.begin(), fpv.end(), fip_cells + size_t(5) * nc);
+        std::copy(fwp.begin(), fwp.end(), fip_cells + size_t(6) * nc);
+    }
 }
 
 void BlackoilDevice::get_residual(double* r)

@@ -33,6 +33,7 @@ public:
     int set_wells(int nw, const int32_t* connpos, const int32_t* cells);
     void set_state(const double* p, const double* sat, const double* rs, const double* rv, const int8_t* hc);
     void get_state(double* p, double* sat, double* rs, double* rv, int8_t* hc);
+    void fluid_in_place(const int32_t* fipnum, int dims, double* fip_cells, double* values);      // computeFluidInPlace (:2263-2445)
     void assemble(double dt, bool initial);
     template <class MS> void assemble_kernels(double dt, bool initial, MS* A, bool props_only = false);
     bool assemble_single = false;      // precision of the coming solve (opmgpu_set_solve_precision)

@@ -393,6 +393,14 @@ int opmgpu_restore_state(opmgpu_ctx* c)
     if (!c->model->has_saved) return fail(c, OPMGPU_EINVAL, "no saved state (opmgpu_save_state; a well re-plan discards it)");
     return guarded(c, [&]() { c->model->restore_state(); return OPMGPU_OK; });
 }
+int opmgpu_compute_fluid_in_place(opmgpu_ctx* c, const int32_t* fipnum, int nregions, double* fip_cells, double* values)
+{
+    if (!c || !c->model || !values || nregions < 1) return OPMGPU_EINVAL;
+    if (!c->model->has_state) return fail(c, OPMGPU_EINVAL, "no reservoir state on the device");
+    if (fipnum) for (int i = 0; i < c->model->nc; ++i) if (fipnum[i] < 0 || fipnum[i] > nregions) return fail(c, OPMGPU_EINVAL, "fipnum outside [0, nregions]");
+    return guarded(c, [&]() { c->model->fluid_in_place(fipnum, nregions, fip_cells, values); return int(OPMGPU_OK); });
+}
+
 int opmgpu_relative_change(opmgpu_ctx* c, double* value)
 {
     if (!c || !c->model || !value) return OPMGPU_EINVAL;

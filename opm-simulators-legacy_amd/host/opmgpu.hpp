@@ -199,6 +199,18 @@ public:
     void saveState() { throw_on_status(ctx_, opmgpu_save_state(ctx_)); }
     void restoreState() { throw_on_status(ctx_, opmgpu_restore_state(ctx_)); }
     double relativeChange() { double v = 0.0; throw_on_status(ctx_, opmgpu_relative_change(ctx_, &v)); return v; }
+    /// BlackoilModelBase::computeFluidInPlace(state, fipnum) (:2263-2445) for the resident state: values[region][7]
+    std::vector<std::vector<double>> computeFluidInPlace(const std::vector<int>& fipnum)
+    {
+        int dims = 1;
+        for (int f : fipnum) dims = std::max(dims, f);
+        std::vector<int32_t> fn(fipnum.begin(), fipnum.end());
+        std::vector<double> flat(std::size_t(dims) * 7, 0.0);
+        throw_on_status(ctx_, opmgpu_compute_fluid_in_place(ctx_, fn.empty() ? nullptr : fn.data(), dims, nullptr, flat.data()));
+        std::vector<std::vector<double>> values(dims, std::vector<double>(7));
+        for (int r = 0; r < dims; ++r) for (int k = 0; k < 7; ++k) values[r][k] = flat[std::size_t(r) * 7 + k];
+        return values;
+    }
     void setStepLength(double dt) { dt_ = dt; }
     double relaxation() const { return current_relaxation_; }
     void setUseUpdateStabilization(bool on) { use_update_stabilization_ = on; }

@@ -164,6 +164,7 @@ SIGNATURES = {
     "opmgpu_save_state": (C.c_int, [C.c_void_p]),
     "opmgpu_restore_state": (C.c_int, [C.c_void_p]),
     "opmgpu_relative_change": (C.c_int, [C.c_void_p, _dp]),
+    "opmgpu_compute_fluid_in_place": (C.c_int, [C.c_void_p, _ip, C.c_int, _dp, _dp]),
     "opmgpu_set_sat_oil_max": (C.c_int, [C.c_void_p, _dp]),
     "opmgpu_update_sat_oil_max": (C.c_int, [C.c_void_p]),
     "opmgpu_get_sat_oil_max": (C.c_int, [C.c_void_p, _dp]),

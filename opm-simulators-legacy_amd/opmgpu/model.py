@@ -208,6 +208,17 @@ class GpuBlackoilModel:
     def restoreState(self):
         self._chk(self.lib.opmgpu_restore_state(self.ctx))
 
+    def computeFluidInPlace(self, fipnum=None, cells=False):
+        """BlackoilModelBase::computeFluidInPlace (BlackoilModelBase_impl.hpp:2263-2445) for the resident state: values[region][7]
+        (water, oil, gas, dissolved gas, vaporised oil, pore volume, hydrocarbon-pv weighted pressure); cells=True also returns the
+        per-cell arrays [7][nc] (SimulatorData::fip)."""
+        fn = None if fipnum is None else capi.i32(fipnum)
+        dims = 1 if fn is None else max(1, int(fn.max()))
+        values = np.zeros((dims, 7))
+        fc = np.zeros((7, self.nc)) if cells else None
+        self._chk(self.lib.opmgpu_compute_fluid_in_place(self.ctx, capi.iptr(fn), dims, capi.dptr(fc), capi.dptr(values)))
+        return (values, fc) if cells else values
+
     def relativeChange(self):
         """BlackoilModelBase::relativeChange(saved, resident) (BlackoilModelBase_impl.hpp:1595-1631)."""
         v = C.c_double(0.0)

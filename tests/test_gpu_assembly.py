@@ -582,3 +582,64 @@ def test_update_equations_scaling(gpu_lib, oracle, single):
     m._chk(m.lib.opmgpu_get_matbalscale(m.ctx, capi.dptr(got)))
     assert np.array_equal(got, [1.1169, 1.0031, 0.0031])
     m.close()
+
+
+def test_compute_fluid_in_place(gpu_lib, oracle):
+    """BlackoilModelBase::computeFluidInPlace (BlackoilModelBase_impl.hpp:2263-2445, serial branch) for the resident state against a numpy
+    restatement on the oracle's cell properties: fip[phase] = pv_mult b s pv per cell, rs / rv volumes, and per region the sums, the pore
+    volume and the hydrocarbon-pore-volume weighted pressure -- with cells outside every region (fipnum 0) and a region without
+    hydrocarbons (the reference's pres / pv branch, :2358-2360)."""
+    tab = decks.satfunc_standard_tables()
+    grid = decks.cartesian_grid(7, 6, 5, lognormal_sigma=0.6, seed=3)
+    st = decks.random_state(grid, tab, seed=11)
+    nc = grid.nc
+    water = np.arange(nc) < 12                       # region 1: water only
+    st.sat[water] = [1.0, 0.0, 0.0]
+    rng = np.random.default_rng(4)
+    fipnum = rng.choice([0, 2, 3], nc).astype(np.int32)
+    fipnum[water] = 1
+    m = GpuBlackoilModel(grid, tab, capi.default_params())
+    m.prepareStep(1 * decks.DAY, st)
+    values, cells = m.computeFluidInPlace(fipnum, cells=True)
+    # numpy restatement
+    props = oracle.cell_props(grid, tab, st)
+    nm = oracle.PROP_NAMES
+    b = [props[:, nm.index("b_" + a), 0] for a in "wog"]
+    assert tab.rocktab_n == 0
+    cp = tab.rock_comp * (st.p - tab.rock_pref)
+    pvm = 1.0 + cp + 0.5 * cp * cp
+    pv = np.asarray(grid.pv)
+    fip = np.zeros((7, nc))
+    for a in range(3):
+        fip[a] = ((pvm * b[a]) * st.sat[:, a]) * pv
+    fip[3], fip[4] = st.rs * fip[1], st.rv * fip[2]
+    dims = int(fipnum.max())
+    expect = np.zeros((dims, 7))
+    hyd = st.sat[:, 1] + st.sat[:, 2]
+    hcpv, pres = np.zeros(dims), np.zeros(dims)
+    for c in range(nc):
+        r = fipnum[c] - 1
+        if r == -1:
+            continue
+        expect[r, :5] += fip[:5, c]
+        hcpv[r] += pv[c] * hyd[c]
+        pres[r] += pv[c] * st.p[c]
+    for c in range(nc):
+        r = fipnum[c] - 1
+        if r == -1:
+            continue
+        fip[5, c] = pv[c]
+        fip[6, c] = pv[c] * st.p[c] * hyd[c] / hcpv[r] if hcpv[r] != 0 else pres[r] / pv[c]
+        expect[r, 5] += fip[5, c]
+        expect[r, 6] += fip[6, c]
+    assert hcpv[0] == 0.0 and (hcpv[1:] > 0).all() and (fipnum == 0).any()
+    assert np.allclose(values, expect, rtol=1e-11, atol=0.0), (values, expect)
+    assert np.allclose(cells, fip, rtol=1e-11, atol=1e-300)
+    # one region of all cells
+    v1 = m.computeFluidInPlace()
+    assert v1.shape == (1, 7) and np.allclose(v1[0, :5], fip[:5].sum(1), rtol=1e-11) and np.isclose(v1[0, 5], pv.sum(), rtol=1e-13)
+    # regions outside the declared range are refused
+    import ctypes as C
+    out = np.zeros((2, 7))
+    assert m.lib.opmgpu_compute_fluid_in_place(m.ctx, capi.iptr(fipnum), 2, None, capi.dptr(out)) == capi.EINVAL
+    m.close()
