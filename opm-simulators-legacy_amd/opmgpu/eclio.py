@@ -192,7 +192,8 @@ class EclOutput:
     def _write_smspec(self, well_names):
         """vectors: TIME, YEARS, field rates, then per well WBHP WOPR WWPR WGPR WWIR WGIR (positive rates, per day)"""
         kws, wgn, nums, units = ["TIME", "YEARS"], [":+:+:+:+", ":+:+:+:+"], [0, 0], ["DAYS", "YEARS"]
-        for k, u in (("FOPR", "SM3/DAY"), ("FWPR", "SM3/DAY"), ("FGPR", "SM3/DAY"), ("FWIR", "SM3/DAY"), ("FGIR", "SM3/DAY")):
+        for k, u in (("FOPR", "SM3/DAY"), ("FWPR", "SM3/DAY"), ("FGPR", "SM3/DAY"), ("FWIR", "SM3/DAY"), ("FGIR", "SM3/DAY"),
+                     ("FOIP", "SM3"), ("FWIP", "SM3"), ("FGIP", "SM3"), ("FPR", "BARSA")):          # in place + average pressure: computeFluidInPlace
             kws.append(k); wgn.append(":+:+:+:+"); nums.append(0); units.append(u)
         for w in well_names:
             for k, u in (("WBHP", "BARSA"), ("WOPR", "SM3/DAY"), ("WWPR", "SM3/DAY"), ("WGPR", "SM3/DAY"), ("WWIR", "SM3/DAY"), ("WGIR", "SM3/DAY")):
@@ -209,8 +210,10 @@ class EclOutput:
             write_array(f, "STARTDAT", "INTE", [self.start.day, self.start.month, self.start.year, 0, 0, 0])
         self._smspec_written = True
 
-    def write_summary(self, elapsed_days, wells, well_state, new_report_step=False):
-        """one ministep: wells = opmgpu.wells.Wells (names, types), well_state = its WellState (bhp [Pa], qs [m3/s], w-o-g, production < 0)"""
+    def write_summary(self, elapsed_days, wells, well_state, new_report_step=False, fip=None):
+        """one ministep: wells = opmgpu.wells.Wells (names, types), well_state = its WellState (bhp [Pa], qs [m3/s], w-o-g, production < 0);
+        fip = computeFluidInPlace's row of the whole field (water, oil, gas, dissolved gas, vaporised oil, pore volume, hydrocarbon-pv
+        weighted pressure [Pa]) or None"""
         names = list(wells.name)
         if not self._smspec_written:
             self._write_smspec(names)
@@ -220,6 +223,10 @@ class EclOutput:
         row = {("TIME", ":+:+:+:+"): elapsed_days, ("YEARS", ":+:+:+:+"): elapsed_days / 365.25,
                ("FOPR", ":+:+:+:+"): prod[:, 1].sum(), ("FWPR", ":+:+:+:+"): prod[:, 0].sum(), ("FGPR", ":+:+:+:+"): prod[:, 2].sum(),
                ("FWIR", ":+:+:+:+"): inj[:, 0].sum(), ("FGIR", ":+:+:+:+"): inj[:, 2].sum()}
+        if fip is not None:
+            f7 = np.asarray(fip, float).reshape(-1)
+            row[("FWIP", ":+:+:+:+")], row[("FOIP", ":+:+:+:+")], row[("FGIP", ":+:+:+:+")] = f7[0], f7[1] + f7[4], f7[2] + f7[3]
+            row[("FPR", ":+:+:+:+")] = f7[6] / BAR
         for w, n in enumerate(names):
             row[("WBHP", n)] = well_state.bhp[w] / BAR
             row[("WOPR", n)], row[("WWPR", n)], row[("WGPR", n)] = prod[w, 1], prod[w, 0], prod[w, 2]

@@ -138,7 +138,9 @@ class Simulator:
                 self.out.write_restart(t / DAY, gm.getState(), extra=extra, wells=wl if wl.nw > 0 else None, well_state=ws if wl.nw > 0 else None,
                                        next_step_days=self.ats.suggested_next_timestep / DAY)
                 if wl.nw > 0:
-                    self.out.write_summary(t / DAY, wl, ws, new_report_step=True)
+                    # field totals in place and the hydrocarbon-pv weighted pressure (SimulatorBase_impl.hpp:278: COIP at every report step)
+                    fip = gm.computeFluidInPlace()[0] if hasattr(gm, "computeFluidInPlace") else None
+                    self.out.write_summary(t / DAY, wl, ws, new_report_step=True, fip=fip)
             prev_ws, prev_names = (ws.copy(), list(wl.name)) if wl.nw > 0 else (None, None)
         return self.reports
 

@@ -60,6 +60,36 @@ class OracleBackend:
                                                                    scale=tuple(self.scale), accum0=self.acc0)
         self.rhs_extra = np.zeros(3 * self.nc)
 
+    def computeFluidInPlace(self, fipnum=None, cells=False):
+        """numpy restatement of BlackoilModelBase::computeFluidInPlace (BlackoilModelBase_impl.hpp:2263-2366) on the oracle's cell properties"""
+        import numpy as np
+        st, nc = self.st, self.grid.nc
+        props = self.orc.cell_props(self.grid, self.tab, st)
+        nm = self.orc.PROP_NAMES
+        assert self.tab.rocktab_n == 0
+        cp = self.tab.rock_comp * (st.p - self.tab.rock_pref)
+        pvm = 1.0 + cp + 0.5 * cp * cp
+        pv = np.asarray(self.grid.pv)
+        fip = np.zeros((7, nc))
+        for a, ph in enumerate("wog"):
+            fip[a] = ((pvm * props[:, nm.index("b_" + ph), 0]) * st.sat[:, a]) * pv
+        fip[3], fip[4] = st.rs * fip[1], st.rv * fip[2]
+        fn = np.ones(nc, np.int32) if fipnum is None else np.asarray(fipnum, np.int32)
+        dims = max(1, int(fn.max()))
+        values, hcpv, pres = np.zeros((dims, 7)), np.zeros(dims), np.zeros(dims)
+        hyd = st.sat[:, 1] + st.sat[:, 2]
+        for c in range(nc):
+            r = fn[c] - 1
+            if r != -1:
+                values[r, :5] += fip[:5, c]; hcpv[r] += pv[c] * hyd[c]; pres[r] += pv[c] * st.p[c]
+        for c in range(nc):
+            r = fn[c] - 1
+            if r != -1:
+                fip[5, c] = pv[c]
+                fip[6, c] = pv[c] * st.p[c] * hyd[c] / hcpv[r] if hcpv[r] != 0 else pres[r] / pv[c]
+                values[r, 5] += fip[5, c]; values[r, 6] += fip[6, c]
+        return (values, fip) if cells else values
+
     def perfProps(self, nperf):
         props = self.orc.cell_props(self.grid, self.tab, self.st)[self.wells[1]]
         names = self.orc.PROP_NAMES
