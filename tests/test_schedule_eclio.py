@@ -154,3 +154,71 @@ def test_welopen_and_weltarg(tmp_path):
     assert tgt[1] == pytest.approx(-90.0 / 86400.0)
     bhp = [c for c in w0.controls[inj] if c[0] == W.BHP][0]
     assert bhp[1] == pytest.approx(300e5)
+
+
+def test_fluid_in_place_restatement_and_summary_vectors(tmp_path):
+    """The numpy restatement of computeFluidInPlace that checks the device (tests/util.py::OracleBackend.computeFluidInPlace) against
+    independent facts: its per-cell water volume equals the oracle's accumulation term x pore volume (the term the assembly parity tests
+    pin), region sums add up to the one-region sums, the weighted pressure is a pressure of the region; and on the summary of a run through
+    the report-step driver: the change of FOIP / FWIP between two report steps equals what the wells produced / injected in between
+    (implicit Euler: rates at the END of each ministep x its length, to the Newton tolerance)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import oracle
+    from opmgpu import capi, decks, eclio, wells as W
+    from opmgpu.simulator import Simulator
+    from util import OracleBackend
+    oracle.build()
+    tab = decks.satfunc_standard_tables()
+    grid = decks.cartesian_grid(6, 5, 4, lognormal_sigma=0.4, seed=2)
+    st = decks.random_state(grid, tab, seed=9)
+    ob = OracleBackend(oracle, grid, tab, capi.default_params())
+    ob.prepareStep(1 * decks.DAY, st)
+    nc = grid.nc
+    fipnum = np.random.default_rng(1).integers(0, 4, nc).astype(np.int32)
+    values, cells = ob.computeFluidInPlace(fipnum, cells=True)
+    props = oracle.cell_props(grid, tab, st)
+    nm = oracle.PROP_NAMES
+    assert np.allclose(cells[0], props[:, nm.index("accum_w"), 0] * grid.pv, rtol=1e-13)
+    # oil + vaporised oil and gas + dissolved gas are the other two accumulation terms -- with the MODEL's rs / rv (saturated values where
+    # the phase condition says so); computeFluidInPlace itself multiplies by the STATE's arrays (x.gasoilratio(), x.rv(), :2275-2276, :2294-2295)
+    mrs, mrv = props[:, nm.index("rs"), 0], props[:, nm.index("rv"), 0]
+    assert np.allclose(cells[1] + mrv * cells[2], props[:, nm.index("accum_o"), 0] * grid.pv, rtol=1e-12)
+    assert np.allclose(cells[2] + mrs * cells[1], props[:, nm.index("accum_g"), 0] * grid.pv, rtol=1e-12)
+    assert np.array_equal(cells[3], st.rs * cells[1]) and np.array_equal(cells[4], st.rv * cells[2])
+    inside = fipnum > 0
+    one = ob.computeFluidInPlace(np.where(inside, 1, 0).astype(np.int32))
+    assert np.allclose(values[:, :6].sum(0), one[0, :6], rtol=1e-12)
+    for r in range(values.shape[0]):
+        pr = st.p[fipnum == r + 1]
+        assert pr.min() <= values[r, 6] <= pr.max()
+
+    def oracle_model(g, t, params):
+        return OracleBackend(oracle, g, t, params)
+
+    def host_wells(model, wl, ws):
+        if model.wells is None or list(model.wells[1]) != list(wl.arrays()[1]):
+            model.wells = wl.arrays()
+            model.rowptr, model.col = oracle.pattern(model.grid, *model.wells)
+        return W.WellCoupledModel(model, W.StandardWellsHost(wl, model.grid.z, model.tab.surface_density[0], tolerance_wells=1e-9), ws)
+
+    base = str(tmp_path / "FIP")
+    prm = capi.default_params(linear_solver_reduction=1e-10, linear_solver_maxiter=600, tolerance_mb=1e-10, tolerance_cnv=1e-7, tolerance_wells=1e-9)
+    sim = Simulator(DECK, params=prm, output_base=base, model_factory=oracle_model, well_model_factory=host_wells)
+    reps = sim.run()
+    sp = {a[0]: a[2] for a in eclio.read_arrays(base + ".SMSPEC")}
+    kws = list(sp["KEYWORDS"])
+    rows = [a[2] for a in eclio.read_arrays(base + ".UNSMRY") if a[0] == "PARAMS"]
+    col = lambda k: np.array([r[kws.index(k)] for r in rows], float)          # noqa: E731  (field vectors come first: unique keywords)
+    foip, fwip, fpr, t = col("FOIP"), col("FWIP"), col("FPR"), col("TIME")
+    assert (np.diff(foip) < 0).all() and (np.diff(fwip) > 0).all() and (fpr > 50).all() and (fpr < 600).all()
+    # material balance between report steps with ONE ministep in between (rates of the end of the step, implicit Euler)
+    checked = 0
+    for i in range(1, len(rows)):
+        if reps[i]["substeps"] != 1:
+            continue
+        checked += 1
+        dt = t[i] - t[i - 1]
+        assert fwip[i] - fwip[i - 1] == pytest.approx((col("FWIR")[i] - col("FWPR")[i]) * dt, rel=2e-4)
+        assert foip[i - 1] - foip[i] == pytest.approx(col("FOPR")[i] * dt, rel=2e-4)
+    assert checked >= 1          # (the summary stores 4-byte reals: the differences carry ~2e-5 relative noise)
