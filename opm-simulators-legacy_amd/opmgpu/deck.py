@@ -10,7 +10,7 @@ What `flow_legacy` gets from opm-parser + `DerivedGeology` (opm/autodiff/GeoProp
             SWL SWCR SWU SOWCR SGL SGCR SGU SOGCR  KRW KRO KRG PCW PCG  ISWL ISWCR ISWU ISOWCR ISGL ISGCR ISGU ISOGCR
             (SATOPTS HYSTER in RUNSPEC switches the hysteresis on; EHYSTR item 2 = 0 and item 5 = KR -- Carlson, relative permeabilities
             only -- is the model the device implements)
-  REGIONS   PVTNUM SATNUM IMBNUM
+  REGIONS   PVTNUM SATNUM IMBNUM FIPNUM (fluid-in-place regions of computeFluidInPlace; 1-based in the deck and in `fipnum()`)
   SOLUTION  PRESSURE SWAT SGAS RS RV (explicit initial state; EQUIL is outside the hot path)
 
 Block-centred Cartesian geometry only (corner-point COORD/ZCORN needs opm-grid's processing, out of scope).  TPFA
@@ -485,6 +485,16 @@ class Deck:
         g.active_index = newid
         self._grid = g
         return g
+
+    def fipnum(self):
+        """FIPNUM of the active cells, 1-based as computeFluidInPlace takes it (0 = in no region); None without the keyword -- the
+        reference then reports the whole field as one region (SimulatorBase_impl.hpp:140-150)."""
+        if not self.has("FIPNUM"):
+            return None
+        nx, ny, nz = self.dims
+        self.grid()                                   # (fixes the set of active cells)
+        full = self.array("FIPNUM", nx * ny * nz)[self.active]
+        return np.where(np.isnan(full), 0, full).astype(np.int32)
 
     def hysteresis(self):
         """SATOPTS HYSTER with the EHYSTR model the device implements (item 2 = 0: Carlson / drainage for the wetting phase, item 5 = KR)"""

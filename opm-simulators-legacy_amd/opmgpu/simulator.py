@@ -51,6 +51,7 @@ class Simulator:
         if getattr(self, "_restart_dtnx", None) is not None:
             self.ats.suggested_next_timestep = self._restart_dtnx
         self.vfp_tables = vfp_tables
+        self.fipnum = self.deck.fipnum()             # REGIONS FIPNUM (None: the field is one region)
         self.out = None
         if output_base:
             porv = np.zeros(n); porv[self.deck.active] = self.grid.pv
@@ -128,6 +129,8 @@ class Simulator:
                 ws = model.pull_well_state()
             self.reports.append({"step": step, "days": t / DAY, "substeps": len(rep["substeps"]), "newton": rep["newton_iterations"],
                                  "linear": rep["linear_iterations"], "failed": len(rep["failed"])})
+            if hasattr(gm, "computeFluidInPlace"):      # COIP of SimulatorBase_impl.hpp:278: values[region][7] at the end of every report step
+                self.reports[-1]["fip"] = gm.computeFluidInPlace(self.fipnum)
             if self.out:
                 extra = {}
                 if hasattr(gm, "satOilMax") and self.tables.vap1 + self.tables.vap2 > 0:

@@ -222,3 +222,45 @@ def test_fluid_in_place_restatement_and_summary_vectors(tmp_path):
         assert fwip[i] - fwip[i - 1] == pytest.approx((col("FWIR")[i] - col("FWPR")[i]) * dt, rel=2e-4)
         assert foip[i - 1] - foip[i] == pytest.approx(col("FOPR")[i] * dt, rel=2e-4)
     assert checked >= 1          # (the summary stores 4-byte reals: the differences carry ~2e-5 relative noise)
+
+
+def test_fipnum_regions_reach_the_report_steps(tmp_path):
+    """REGIONS FIPNUM -> Deck.fipnum() -> the report-step driver's computeFluidInPlace(fipnum) (SimulatorBase_impl.hpp:278): one row of seven
+    numbers per region at the end of every report step; the regions' volumes add up to the field's, cells with FIPNUM 0 belong to none."""
+    import re
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import oracle
+    from opmgpu import capi, deck as deckmod, wells as W
+    from opmgpu.simulator import Simulator
+    from util import OracleBackend
+    oracle.build()
+    text = open(DECK).read()
+    nx, ny, nz = (int(v) for v in re.search(r"DIMENS\s+(\d+)\s+(\d+)\s+(\d+)", text).groups())
+    n = nx * ny * nz
+    n1 = n // 3
+    path = str(tmp_path / "FIPNUM.DATA")
+    open(path, "w").write(text.replace("SOLUTION\n", "REGIONS\nFIPNUM\n %d*1 %d*2 4*0 /\n\nSOLUTION\n" % (n1, n - n1 - 4), 1))
+    d = deckmod.read_deck(path)
+    fn = d.fipnum()
+    assert fn.shape == (n,) and (fn[:n1] == 1).all() and (fn[-4:] == 0).all() and fn.max() == 2
+    assert deckmod.read_deck(DECK).fipnum() is None
+
+    def oracle_model(g, t, params):
+        return OracleBackend(oracle, g, t, params)
+
+    def host_wells(model, wl, ws):
+        if model.wells is None or list(model.wells[1]) != list(wl.arrays()[1]):
+            model.wells = wl.arrays()
+            model.rowptr, model.col = oracle.pattern(model.grid, *model.wells)
+        return W.WellCoupledModel(model, W.StandardWellsHost(wl, model.grid.z, model.tab.surface_density[0]), ws)
+
+    sim = Simulator(path, params=capi.default_params(linear_solver_reduction=1e-8, linear_solver_maxiter=400), model_factory=oracle_model,
+                    well_model_factory=host_wells)
+    reps = sim.run(max_steps=2)
+    for r in reps:
+        assert r["fip"].shape == (2, 7) and (r["fip"][:, :2] > 0).all() and (r["fip"][:, 2] >= 0).all() and (r["fip"][:, 3] > 0).all()      # (no free gas in this deck)
+    field, cells = sim.model.computeFluidInPlace(None, cells=True)
+    last = reps[-1]["fip"]
+    assert np.allclose(last[:, :6].sum(0), field[0, :6] - cells[:6, -4:].sum(1), rtol=1e-12)      # the four cells outside every region
+    assert last[:, 6].min() > 50e5 and last[:, 6].max() < 600e5
