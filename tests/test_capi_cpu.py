@@ -37,6 +37,12 @@ def test_default_params_match_reference(lib):
     # BlackoilModelParameters.cpp:76-102, BlackoilModelBase_impl.hpp:139
     assert (p.dp_max_rel, p.ds_max, p.tolerance_mb, p.tolerance_cnv) == (0.3, 0.2, 1e-5, 1e-2)
     assert list(p.matbalscale) == [1.1169, 1.0031, 0.0031]
+    # linear-solver defaults the reference tree itself holds: the CPR plug-in's (NewtonIterationBlackoilCPR.cpp:59-64: gmres off,
+    # reduction 1e-2, maxiter 50, restart 40, convergence failures not ignored).  The interleaved solver's maxiter 150 and ILU relaxation 0.9
+    # live in NewtonIterationBlackoilInterleavedParameters (a header outside the tree): recalled, not checkable here.
+    c = capi.default_params(use_cpr=1)
+    assert (c.newton_use_gmres, c.linear_solver_reduction, c.linear_solver_maxiter, c.linear_solver_restart, c.ignore_convergence_failure) == (0, 1e-2, 50, 40, 0)
+    assert (p.linear_solver_reduction, p.linear_solver_maxiter, p.linear_solver_restart, p.newton_use_gmres) == (1e-2, 150, 40, 0)
 
 
 @pytest.mark.skipif(capi.load().opmgpu_device_count() > 0, reason="a GPU is present")
