@@ -102,3 +102,22 @@ def test_gives_up_after_solver_restart_max():
     with pytest.raises(NumericalIssue, match="cutting timestep 4 times"):
         a.step(0.0, 10 * DAY, FakeSolver(), m)
     assert a.failed_substeps == 5
+
+
+def test_defaults_are_the_references():
+    """The host mirrors' defaults against the lines of the reference that set them: NonlinearSolver::SolverParameters::reset
+    (NonlinearSolver_impl.hpp:183-188) and AdaptiveTimeStepping's parameter defaults (AdaptiveTimeStepping_impl.hpp:101-112, :123-147)."""
+    from opmgpu import capi
+    from opmgpu.model import NonlinearSolver
+    ns = NonlinearSolver()
+    assert (ns.relax_type, ns.relax_max, ns.relax_increment, ns.relax_rel_tol, ns.max_iter, ns.min_iter) == (capi.RELAX_DAMPEN, 0.5, 0.1, 0.2, 10, 1)
+    a = ts.AdaptiveTimeStepping()
+    assert (a.restart_factor, a.growth_factor, a.max_growth, a.solver_restart_max) == (0.33, 2.0, 3.0, 10)
+    assert a.max_time_step == 365.0 * ts.DAY and a.suggested_next_timestep == 1.0 * ts.DAY
+    assert a.full_timestep_initially is False and a.timestep_after_event == -1.0 * ts.DAY
+    assert isinstance(a.control, ts.PIDTimeStepControl) and a.control.tol == 1e-1 and not a.use_newton_iteration
+    assert ts.AdaptiveTimeStepping(control="pid+iteration").control.target_iterations == 30
+    b = ts.AdaptiveTimeStepping(control="pid+newtoniteration")
+    assert b.control.target_iterations == 8 and b.use_newton_iteration
+    c = ts.AdaptiveTimeStepping(control="iterationcount").control
+    assert (c.target_iterations, c.decayrate, c.growthrate) == (30, 0.75, 1.25)
