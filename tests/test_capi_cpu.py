@@ -36,6 +36,12 @@ def test_default_params_match_reference(lib):
         assert (list(a) == list(b)) if name == "matbalscale" else (a == b), name
     # BlackoilModelParameters.cpp:76-102, BlackoilModelBase_impl.hpp:139
     assert (p.dp_max_rel, p.ds_max, p.tolerance_mb, p.tolerance_cnv) == (0.3, 0.2, 1e-5, 1e-2)
+    # every model parameter of BlackoilModelParameters::reset (BlackoilModelParameters.cpp:76-102) that has a field in opmgpu_params
+    assert (p.dr_max_rel, p.dbhp_max_rel, p.max_residual_allowed, p.tolerance_wells, p.tolerance_well_control) == (1.0e9, 1.0, 1e7, 1.0e-4, 1.0e-7)
+    assert (p.solve_welleq_initially, p.update_equations_scaling) == (1, 0)
+    from opmgpu.model import GpuBlackoilModel
+    import inspect
+    assert "max_single_precision_days = 20.0" in inspect.getsource(GpuBlackoilModel.__init__)      # maxSinglePrecisionTimeStep_ (:95)
     assert list(p.matbalscale) == [1.1169, 1.0031, 0.0031]
     # linear-solver defaults the reference tree itself holds: the CPR plug-in's (NewtonIterationBlackoilCPR.cpp:59-64: gmres off,
     # reduction 1e-2, maxiter 50, restart 40, convergence failures not ignored).  The interleaved solver's maxiter 150 and ILU relaxation 0.9
