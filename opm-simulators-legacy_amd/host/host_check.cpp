@@ -154,6 +154,17 @@ int main()
             if (!conv) { std::printf("host_check: FAILED, the one-call Newton loop did not converge in %d iterations\n", it); return 1; }
             std::printf("host_check: one-call Newton loop: 2-day step converged in %d iterations\n", it);
         }
+        // computeFluidInPlace for the resident state, the field as one region (SimulatorBase_impl.hpp:278)
+        {
+            const std::vector<int> whole_field;
+            const auto fip = model.computeFluidInPlace(whole_field);
+            if (fip.size() != 1 || fip[0].size() != 7 || !(fip[0][0] > 0.0) || !(fip[0][1] > 0.0) || !(fip[0][5] > 0.0) || !(fip[0][6] > 1e5)) {
+                std::printf("host_check: FAILED, fluids in place: %zu regions\n", fip.size());
+                return 1;
+            }
+            std::printf("host_check: fluids in place: water %.5g, oil %.5g, free gas %.5g sm3, pore volume %.5g m3, hydrocarbon-pv weighted pressure %.1f bar\n",
+                        fip[0][0], fip[0][1], fip[0][2], fip[0][5], fip[0][6] / 1e5);
+        }
         std::printf("host_check: report step of 20 d in %zu sub-steps (first %.2f d, last %.2f d), %d failed, next suggestion %.2f d\n",
                     ats.substeps.size(), ats.substeps.front() / 86400.0, ats.substeps.back() / 86400.0, ats.failed_substeps,
                     ats.suggested_next_timestep / 86400.0);
