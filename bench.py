@@ -1,20 +1,35 @@
 #!/usr/bin/env python3
-"""bench.py -- Mcell-updates/s per Newton step (assembly + solve) on MI355X, with the SpMV roofline, a per-kernel table and the
+"""bench.py -- Mcell-updates/s per Newton step (assembly+solve) on MI355X, with the SpMV roofline, a per-kernel table and the
 CPU baseline timed beside it.
 
 Workload (BASELINE.json configs[2]): the synthetic 100x100x100 three-phase deck WITH its 5-spot (one rate-controlled water
 injector + four BHP producers, full columns, device well model incl. control switching and the explicit well pre-solve).  A "step" is
-one Newton iteration of the fully-implicit black-oil model: assemble (reservoir + wells) -> getConvergence -> solveJacobianSystem
-(CPR: AMG V-cycle on the pressure system + block-ILU0, BiCGStab; float because dt < 20 d exactly as the reference switches) ->
+one Newton iteration of the fully-implicit black-oil model: assemble (reservoir + wells) -> getConvergence -> solveJacobianSystem ->
 updateState, state resident in HBM.  Time steps follow each other like in the simulator (NonlinearSolver with the reference's update
 stabilisation); the synthetic initial state is far from equilibrium, so two time steps pass before anything is timed (deck set-up).
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+Which solver the headline runs, and in which arithmetic:
+  * the reference's DEFAULT is solver_approach=interleaved: block-ILU0 + BiCGStab, in float when dt < 20 d and in double otherwise
+    (BlackoilModelBase_impl.hpp:284, NewtonIterationBlackoilInterleaved.cpp:478-480) -> same_run_variants.reference_default_solver_ilu0*;
+  * the headline is the fastest configuration the reference itself can be SWITCHED to: solver_approach=cpr (CPR: AMG pressure stage +
+    ILU0) with newton_use_gmres (NewtonIterationBlackoilCPR.cpp:61-64, 148-165).  That plug-in computes in DOUBLE whatever dt is
+    (NewtonIterationBlackoilCPR.cpp:117-140 never reads singlePrecision), so the headline is an f64 assembly + f64 solve;
+  * the float CPR solve round 2 reported as its headline is a combination the reference cannot run: it stays as the variant
+    cpr_f32_gmres_with_wells and carries no like-for-like claim.
+`value` is the cell count over the MEDIAN duration of the timed Newton iterations that include a linear solve -- a
+converged call skips solveJacobianSystem + updateState (BlackoilModelBase_impl.hpp:277-281) and is not a Newton iteration of the
+reference's count; `value_all_calls_mean` = cells / (wall time of the K timed calls / K) is kept beside it, `ms_per_step` is that wall
+time per call.  The per-call durations, phase times and iteration counts all come from the K timed calls themselves (events recorded on
+the library's stream without a synchronisation inside the region: opmgpu_iteration_marks).
+
+    python bench.py --gpus N --steps K --warmup W
+(N > 1: one rank per GPU under torch.distributed.run; launched without WORLD_SIZE the script starts that launcher itself as a child process)
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -31,16 +46,20 @@ def spmv_bytes(nb, nnzb, S):
     return nnzb * (9 * S + 4) + (nb + 1) * 4 + 2 * nb * 3 * S
 
 
+def assembly_bytes(nb, nnzb, nconn, S):
+    """state 41 + statics 24 + accum0 24 + connection data (nconn / nc) * 16 + residual 24 per cell, + the Jacobian write"""
+    return nb * (41 + 24 + 24 + (nconn / nb) * 16 + 24) + nnzb * 9 * S
+
+
 def algorithmic_bytes(nb, nnzb, nconn, S, n_scalar_nnz):
     """algorithmic HBM bytes per launch (group) of every kernel class the in-situ timers bracket.
     S = scalar size of the matrix / solver vectors (4: float solve, 8: double)."""
-    per_cell_asm = 41 + 24 + 24 + (nconn / nb) * 16 + 24          # SURVEY 8d: state, statics, accum0, connection data, residual
     return {
-        # SURVEY 8d counts the assembly as ONE pass (state in, Jacobian out); the two kernels also exchange the 37 face-input
-        # planes (80 + 27 S bytes per cell written by cell_props, read by flux): listed as `exchange_bytes`
-        "assembly(cell_props+flux)": nb * per_cell_asm + nnzb * 9 * S,
-        "cell_props": nb * (49 + 16 + 24 + 24 + 24 + 9 * S + 80 + 27 * S),
-        "flux": nb * (8 + 24 + 24 + 9 * S + 3 * S + 80 + 27 * S) + nnzb * (8 + 9 * S) + 2 * nconn * 16,
+        "assembly(cell_props+flux)": assembly_bytes(nb, nnzb, nconn, S),
+        # the two passes of the assembly by themselves (DESIGN.md section 4): the value pass reads the state and writes the ten value planes
+        # the neighbours need; the flux pass reads state + statics + values of the row and of its neighbours and writes the Jacobian
+        "cell_props": nb * (49 + 16 + 24 + 80 + 24),
+        "flux": nb * (49 + 16 + 24 + 24 + 8 + 24 + 12) + nnzb * (80 + 4 + 9 * S) + (nnzb - nb) * 16,
         "spmv_fused_dot1": spmv_bytes(nb, nnzb, S) + nb * 3 * S, "spmv_fused_dot2": spmv_bytes(nb, nnzb, S) + nb * 3 * S,
         "ilu0_apply": nnzb * (9 * S + 4) + nb * 3 * S * 3,
         "ilu0_factor": 2 * nnzb * 9 * S + nnzb * 4,
@@ -49,7 +68,29 @@ def algorithmic_bytes(nb, nnzb, nconn, S, n_scalar_nnz):
     }
 
 
-def main():
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start `python -m torch.distributed.run --nproc-per-node N
+    bench.py ...` as a CHILD process -- before this process has imported torch or touched the GPU --, relay its JSON line and exit with its
+    code.  (Never an exec: a process that has initialised the GPU must not replace itself, and a child keeps this one free of HIP.)"""
+    port = int(os.environ.get("MASTER_PORT", "0")) or (29500 + os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["OPMGPU_BENCH_CHILD"] = "1"
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    for l in proc.stdout.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if proc.returncode != 0 or len(lines) != 1:
+        print("bench.py: the %d-rank child run failed (exit code %d, %d JSON lines)" % (args.gpus, proc.returncode, len(lines)), file=sys.stderr)
+        raise SystemExit(proc.returncode or 1)
+    print(lines[0])
+    raise SystemExit(0)
+
+
+def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -61,25 +102,36 @@ def main():
     ap.add_argument("--ordering", choices=["multicolor", "natural"], default="multicolor")
     ap.add_argument("--solver", choices=["cpr", "ilu0"], default="cpr",
                     help="cpr: AMG pressure stage + ILU0 (reference solver_approach=cpr); ilu0: reference default solver_approach=interleaved")
+    ap.add_argument("--precision", choices=["reference", "f32", "f64"], default="reference",
+                    help="arithmetic of the linear solve and of the Jacobian.  reference: what the reference's plug-in of --solver computes in -- cpr: double "
+                         "always (NewtonIterationBlackoilCPR.cpp:117-140); ilu0: float when dt < 20 d, else double (BlackoilModelBase_impl.hpp:284)")
     ap.add_argument("--krylov", choices=["auto", "bicgstab", "gmres", "fgmres"], default="auto",
-                    help="gmres: the reference's newton_use_gmres option (restarted GMRES(40), left-preconditioned; single GPU only).  auto: gmres "
-                         "under CPR on the deck with wells (measured: 3.75 preconditioner applications per Newton iteration against BiCGStab's 4.1 "
-                         "iterations = 9.5 applications; on the SPE10-like deck BiCGStab does not converge within 50 iterations), bicgstab otherwise "
-                         "(well-free deck: 1.75 iterations against GMRES's 3.95) -- the other method runs as a same-run variant; fgmres: the flexible "
-                         "(right-preconditioned) form, not a reference solver, measured slower (4.95 columns against 3.65)")
+                    help="gmres: the reference's newton_use_gmres option (restarted GMRES(40), left-preconditioned).  auto: gmres under CPR on the deck with "
+                         "wells (3.75 preconditioner applications per Newton iteration against BiCGStab's 4.1 iterations = 9.5 applications), bicgstab "
+                         "otherwise -- the other method runs as a same-run variant; fgmres: the flexible (right-preconditioned) form, not a reference solver")
+    ap.add_argument("--no-verify", action="store_true", help="GMRES without the true-residual check (opmgpu_params.gmres_verify_residual = 0: exactly dune's stopping rule)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="N > 1: weak = every GPU keeps an nx x ny x nz slab (global deck nx x ny x nz*N, sized for 288 GB/GPU); strong = the fixed nx x ny x nz deck is cut into N slabs")
+                    help="N > 1: weak = every GPU keeps an nx x ny x nz slab with its own 5-spot (global deck nx x ny x nz*N); strong = the fixed nx x ny x nz deck "
+                         "is cut into N slabs along j, which keeps its vertical wells whole")
     ap.add_argument("--deck", choices=["cart", "spe10like"], default="cart", help="spe10like: 60 x 220 x 85 cells, sigma_lnK = 2.5 (BASELINE configs[3]); implies its own dimensions")
     ap.add_argument("--wells", choices=["none", "fivespot"], default="fivespot",
-                    help="fivespot (default, SURVEY 8d): 1 rate-controlled water injector + 4 BHP producers, full columns, device well model; single GPU only")
+                    help="fivespot (default, SURVEY 8d): 1 rate-controlled water injector + 4 BHP producers, full columns, device well model")
     ap.add_argument("--rate", type=float, default=1000.0, help="injection rate of the 5-spot, m3/day")
     ap.add_argument("--spin-up", type=int, default=2, help="time steps that pass before the measurement (deck set-up, untimed)")
     ap.add_argument("--only-main", action="store_true", help="skip the same-run variants, the roofline micro-runs and the per-kernel pass (profiling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="take the domain-decomposition code path (torch.distributed + RCCL communicator) even with one rank")
     ap.add_argument("--cpu-threads", type=int, default=1)
-    ap.add_argument("--call-by-call", action="store_true", help="drive every Newton iteration through the seven single C calls instead of opmgpu_nonlinear_iteration")
-    args = ap.parse_args()
+    ap.add_argument("--call-by-call", action="store_true", help="drive every Newton iteration through the seven single C calls instead of opmgpu_nonlinear_iteration "
+                                                                 "(no per-call marks then: value falls back to the mean over all calls)")
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args, argv)                 # does not return
 
     import numpy as np
     import torch
@@ -91,7 +143,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d (or without a launcher)" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     # rehearsal on ONE GPU (OPMGPU_COMM_TRANSPORT=shm): every rank on cuda:0, the test library's shared-memory transport instead of
@@ -113,31 +165,47 @@ def main():
         args.nx, args.ny, args.nz = 60, 220, 85
     ordering = capi.ORDER_MULTICOLOR if args.ordering == "multicolor" else capi.ORDER_NATURAL
     tab = decks.satfunc_standard_tables()
-    dt = args.dt_days * decks.DAY
-    single = dt < 20 * decks.DAY            # BlackoilModelBase_impl.hpp:284
-    # multi-GPU, weak scaling: one 5-spot per rank's slab (a well lives on one rank), i.e. N copies of the one-GPU workload stacked along k;
-    # strong scaling cuts the fixed deck along k through its wells, which the device well model does not support: well-free deck there
-    use_wells = args.wells == "fivespot" and not (use_dist and (args.scaling == "strong" or args.deck == "spe10like"))
+    dt_main = args.dt_days * decks.DAY
+
+    def reference_single(solver, dt):
+        """the arithmetic the reference's plug-in computes in: CPR is double throughout (NewtonIterationBlackoilCPR.cpp:117-140), the
+        interleaved solver follows residual_.singlePrecision = dt < 20 d (BlackoilModelBase_impl.hpp:284)"""
+        return False if solver == "cpr" else dt < 20 * decks.DAY
+
+    single_main = {"reference": reference_single(args.solver, dt_main), "f32": True, "f64": False}[args.precision]
+    # multi-GPU: every well lives on one rank.  Weak scaling: one 5-spot per rank's slab of nz layers (N copies of the one-GPU workload stacked
+    # along k); strong scaling and the SPE10-like deck: slabs of whole j-rows, which keeps the deck's own vertical wells whole
+    use_wells = args.wells == "fivespot"
     if args.krylov == "auto":
         args.krylov = "gmres" if (use_wells and args.solver == "cpr") else "bicgstab"
-    prm = capi.default_params(ilu_ordering=ordering, use_cpr=int(args.solver == "cpr"), newton_use_gmres={"gmres": 1, "fgmres": 2}.get(args.krylov, 0))
+    verify = 0 if args.no_verify else 1
+
+    def make_params(solver=args.solver, krylov=args.krylov):
+        return capi.default_params(ilu_ordering=ordering, use_cpr=int(solver == "cpr"), newton_use_gmres={"gmres": 1, "fgmres": 2}.get(krylov, 0),
+                                   gmres_verify_residual=verify if krylov == "gmres" else 0)
+
+    prm = make_params()
+    spe10_spec = (200.0, 380.0)
 
     def make_deck():
         if args.deck == "spe10like":
             g = decks.cartesian_grid(60, 220, 85, dx=6.096, dy=3.048, dz=0.6096, tops=3657.6, lognormal_sigma=2.5, seed=10)
             s = decks.initial_state(g, tab, p_ref=413.0 * decks.BAR, z_ref=3657.6, perturb=1e-4, seed=10, gas_cap_fraction=0.0, gas_only_fraction=0.0)
-            return g, s, (200.0, 380.0)
+            return g, s, spe10_spec
         g = decks.cartesian_grid(args.nx, args.ny, args.nz, lognormal_sigma=0.5, seed=12345)
         return g, decks.initial_state(g, tab, perturb=0.002, seed=12345), (args.rate, 150.0)
 
     if use_dist:
         from opmgpu import partition
-        nz_global = args.nz * world if args.scaling == "weak" else args.nz
         if args.deck == "spe10like":
-            model, grid, st, info = partition.build_distributed_model(60, 220, 85, tab, prm, rank, world, local_rank, deck="spe10like")
+            wells_fn = (lambda g: W.five_spot(g, rate_m3_per_day=spe10_spec[0], bhp_prod_bar=spe10_spec[1])) if use_wells else None
+            model, grid, st, info = partition.build_distributed_model(60, 220, 85, tab, prm, rank, world, local_rank, deck="spe10like", wells_fn=wells_fn)
+        elif args.scaling == "strong":
+            wells_fn = (lambda g: W.five_spot(g, rate_m3_per_day=args.rate, bhp_prod_bar=150.0)) if use_wells else None
+            model, grid, st, info = partition.build_distributed_model(args.nx, args.ny, args.nz, tab, prm, rank, world, local_rank, wells_fn=wells_fn, axis=1)
         else:
             wells_fn = (lambda g: W.five_spot(g, rate_m3_per_day=args.rate, bhp_prod_bar=150.0, slabs=world)) if use_wells else None
-            model, grid, st, info = partition.build_distributed_model(args.nx, args.ny, nz_global, tab, prm, rank, world, local_rank, wells_fn=wells_fn)
+            model, grid, st, info = partition.build_distributed_model(args.nx, args.ny, args.nz * world, tab, prm, rank, world, local_rank, wells_fn=wells_fn)
         well_spec = None
     else:
         grid, st, well_spec = make_deck()
@@ -163,7 +231,7 @@ def main():
 
     ns = NonlinearSolver()                  # reference defaults: max_iter 10, min_iter 1, dampening on detected oscillation
 
-    def newton_iterations(model, n, state):
+    def newton_iterations(model, n, state, dt, single):
         """n Newton iterations; time steps follow each other like in the simulator.  A step that has not converged after the
         reference's max_iter is restarted from the current state.  A Newton iteration that ends in one of the conditions the reference's
         time stepper catches (NumericalIssue, LinearSolverProblem, ISTLError: AdaptiveTimeStepping_impl.hpp:244-281) is handled the way it
@@ -193,77 +261,117 @@ def main():
         state["it"] = it
         return lin, steps_done, failed
 
-    def timed_run(core, wells_on, kernel_table=False):
+    def timed_run(core, wells_on, dt, single, kernel_table=False):
         """deck set-up (spin-up time steps) -> W warm-up Newton iterations -> barrier -> exactly K timed Newton iterations -> barrier"""
         model = with_wells(core, wells_on)
         model.prepareStep(dt, st)
         model.saveState()
         state = {"it": 0, "dt": dt, "chopped": 0}
         done = 0
-        while done < args.spin_up:              # set-up: let the synthetic initial state relax for `spin_up` time steps
-            _, d, _ = newton_iterations(model, 1, state)
-            done += d
-        newton_iterations(model, args.warmup, state)
+        guard = 0
+        while done < args.spin_up and guard < 40 * max(1, args.spin_up):          # set-up: let the synthetic initial state relax for `spin_up` time steps
+            _, d, _ = newton_iterations(model, 1, state, dt, single)
+            done += d; guard += 1
+        newton_iterations(model, args.warmup, state, dt, single)
+        marks = GpuBlackoilModel.fused_iteration
         barrier()
+        if marks:
+            core._chk(core.lib.opmgpu_iteration_marks(core.ctx, 1))
         t0 = time.perf_counter()
         lin_total = steps_done = failed = 0
         for _ in range(args.steps):
-            l, d, f = newton_iterations(model, 1, state)
+            l, d, f = newton_iterations(model, 1, state, dt, single)
             lin_total += l; steps_done += d; failed += f
         barrier()
         elapsed = time.perf_counter() - t0
-        # phase breakdown: the NEXT K Newton iterations of the same run (asking for the phase times waits for the iteration's last kernel,
-        # a bubble that does not belong in the timed region); every rank does the same
-        t_asm = t_sol = t_upd = 0.0
-        for _ in range(args.steps):
-            newton_iterations(model, 1, state)
-            a, s, u = core.timings()
-            t_asm += a; t_sol += s; t_upd += u
+        out = {"lin": lin_total, "steps_done": steps_done, "steps_not_converged": failed, "chopped": state["chopped"]}
+        solving_ms = None
+        if marks:
+            K = args.steps
+            ms, sol, lit, ph = np.zeros(K), np.zeros(K, np.int32), np.zeros(K, np.int32), np.zeros((K, 3))
+            n = C.c_int(0)
+            core._chk(core.lib.opmgpu_iteration_marks_get(core.ctx, K, capi.dptr(ms), capi.iptr(sol), capi.iptr(lit), capi.dptr(ph), C.byref(n)))
+            core._chk(core.lib.opmgpu_iteration_marks(core.ctx, 0))
+            n = min(n.value, K)              # (a call that ended in an exception left its mark too; chopped restarts make no call)
+            ms, sol, lit, ph = ms[:n], sol[:n].astype(bool), lit[:n], ph[:n]
+            out["calls"] = {"ms": [round(float(x), 4) for x in ms], "solved": [int(x) for x in sol], "linear_iterations": [int(x) for x in lit]}
+            if sol.any():
+                solving_ms = float(np.median(ms[sol]))
+                out["n_solving"] = int(sol.sum())
+                out["lin_per_solving"] = float(lit[sol].mean())
+                out["breakdown"] = {"assemble": float(np.median(ph[sol, 0])), "linear_solve": float(np.median(ph[sol, 1])), "update": float(np.median(ph[sol, 2])),
+                                    "basis": "medians over the %d timed calls that include a solve; the phases are device time between events on the library's stream, "
+                                             "the call's remainder is the host's decisions between them" % int(sol.sum())}
+                if (~sol).any():
+                    out["non_solving_ms_median"] = float(np.median(ms[~sol]))
         if use_dist:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+            tt = torch.tensor([elapsed, solving_ms if solving_ms is not None else -1.0], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            elapsed = float(tt.item())
-        out = {"elapsed": elapsed, "lin": lin_total / args.steps, "steps_done": steps_done, "steps_not_converged": failed, "chopped": state["chopped"],
-               "breakdown": {"assemble": t_asm / args.steps, "linear_solve": t_sol / args.steps, "update": t_upd / args.steps}}
+            elapsed = float(tt[0].item())
+            if solving_ms is not None:
+                solving_ms = float(tt[1].item())
+        out["elapsed"], out["solving_ms"] = elapsed, solving_ms
         if kernel_table:
-            # per-kernel pass: the NEXT K Newton iterations of the same run with the in-situ event brackets on (not part of `value`)
+            # per-kernel pass: the NEXT K Newton iterations of the same run with the in-situ event brackets on (not part of `value`: the
+            # brackets cost time); its own iteration counts are reported with it
             core._chk(core.lib.opmgpu_kernel_timing(core.ctx, 1))
-            newton_iterations(model, args.steps, state)
+            core._chk(core.lib.opmgpu_iteration_marks(core.ctx, 1))
+            newton_iterations(model, args.steps, state, dt, single)
             tot, cnt = np.zeros(len(capi.KT_NAMES)), np.zeros(len(capi.KT_NAMES), np.int64)
             core._chk(core.lib.opmgpu_kernel_timing_get(core.ctx, capi.dptr(tot), cnt.ctypes.data_as(C.POINTER(C.c_int64))))
             core._chk(core.lib.opmgpu_kernel_timing(core.ctx, 0))
-            out["kt"] = (tot, cnt)
+            K = args.steps
+            sol, lit, n = np.zeros(K, np.int32), np.zeros(K, np.int32), C.c_int(0)
+            core._chk(core.lib.opmgpu_iteration_marks_get(core.ctx, K, None, capi.iptr(sol), capi.iptr(lit), None, C.byref(n)))
+            core._chk(core.lib.opmgpu_iteration_marks(core.ctx, 0))
+            n = min(n.value, K)
+            out["kt"] = (tot, cnt, n, int(sol[:n].sum()), int(lit[:n].sum()))
         return out
 
-    def summary(r):
-        return {"value": nc_global / (r["elapsed"] / args.steps) / 1e6, "ms_per_step": 1e3 * r["elapsed"] / args.steps,
-                "linear_iterations_per_newton": r["lin"], "time_steps_completed": r["steps_done"], "time_steps_not_converged": r["steps_not_converged"],
-                "time_steps_chopped": r["chopped"], "breakdown_ms_per_step": r["breakdown"]}
+    def summary(r, dt, single, note=None):
+        ms_mean = 1e3 * r["elapsed"] / args.steps
+        ms = r["solving_ms"] if r["solving_ms"] is not None else ms_mean
+        s = {"value": nc_global / (ms * 1e-3) / 1e6, "ms_per_solving_iteration_median": r["solving_ms"], "value_all_calls_mean": nc_global / (ms_mean * 1e-3) / 1e6,
+             "ms_per_step": ms_mean, "dt_days": dt / decks.DAY, "arithmetic": "f64 assembly + %s Jacobian and linear solve" % ("f32" if single else "f64"),
+             "solving_iterations": r.get("n_solving"), "linear_iterations_per_solving_iteration": r.get("lin_per_solving"),
+             "time_steps_completed": r["steps_done"], "time_steps_not_converged": r["steps_not_converged"], "time_steps_chopped": r["chopped"],
+             "breakdown_ms_per_solving_iteration": r.get("breakdown")}
+        if note:
+            s["note"] = note
+        return s
 
     # ---- timed region: exactly K Newton iterations of the headline workload ----
     extras = rank == 0 and not use_dist and not args.only_main
-    res = timed_run(model, use_wells, kernel_table=extras)
-    ms_per_step = 1e3 * res["elapsed"] / args.steps
-    value = nc_global / (res["elapsed"] / args.steps) / 1e6
+    res = timed_run(model, use_wells, dt_main, single_main, kernel_table=extras)
+    main_sum = summary(res, dt_main, single_main)
 
-    # same-run variants, equal weight: the reference-default linear solver (ILU0 + BiCGStab: what the CPU baseline runs), and the well-free deck
+    # same-run variants: the reference's default solver, the other arithmetic / Krylov method, the well-free deck, and dt = 30 d (the
+    # double branch of the reference's precision switch, BlackoilModelBase_impl.hpp:284)
     variants = {}
+    wtag = "_with_wells" if use_wells else ""
     if extras:
-        if prm.use_cpr:
-            m0 = GpuBlackoilModel(grid, tab, capi.default_params(ilu_ordering=ordering, use_cpr=0), device=local_rank)
-            variants["reference_default_solver_ilu0" + ("_with_wells" if use_wells else "")] = summary(timed_run(m0, use_wells)); m0.close()
-        if use_wells:
-            m1 = GpuBlackoilModel(grid, tab, capi.default_params(ilu_ordering=ordering, use_cpr=prm.use_cpr), device=local_rank)    # BiCGStab (the auto rule)
-            variants["without_wells"] = summary(timed_run(m1, False)); m1.close()
-        if prm.use_cpr and not use_dist:
-            # the reference's other Krylov method under the same preconditioner (NewtonIterationBlackoilCPR.cpp:61-64, newton_use_gmres)
-            other = 0 if prm.newton_use_gmres else 1
-            m2 = GpuBlackoilModel(grid, tab, capi.default_params(ilu_ordering=ordering, use_cpr=1, newton_use_gmres=other), device=local_rank)
+        def variant(name, solver, krylov, dt, single, wells_on=use_wells, note=None):
+            m = GpuBlackoilModel(grid, tab, make_params(solver, krylov), device=local_rank)
             try:
-                variants["cpr_" + ("gmres" if other else "bicgstab") + ("_with_wells" if use_wells else "")] = summary(timed_run(m2, use_wells))
-            except Exception as e:          # e.g. BiCGStab running out of iterations on the SPE10-like deck: say so instead of dying
-                variants["cpr_" + ("gmres" if other else "bicgstab") + ("_with_wells" if use_wells else "")] = {"failed": repr(e)}
-            m2.close()
+                variants[name] = summary(timed_run(m, wells_on, dt, single), dt, single, note)
+            except Exception as e:          # e.g. a Krylov method running out of iterations: say so instead of dying
+                variants[name] = {"failed": repr(e)}
+            m.close()
+
+        dt30 = 30.0 * decks.DAY
+        variant("reference_default_solver_ilu0" + wtag, "ilu0", "bicgstab", dt_main, reference_single("ilu0", dt_main),
+                note="solver_approach=interleaved, the reference's DEFAULT: block-ILU0 + BiCGStab, float because dt < 20 d")
+        if args.solver == "cpr":
+            other = "bicgstab" if args.krylov != "bicgstab" else "gmres"
+            variant("cpr_f64_%s%s" % (other, wtag), "cpr", other, dt_main, False,
+                    note="solver_approach=cpr in the reference's own arithmetic (double) with its %s Krylov method" % ("default" if other == "bicgstab" else "newton_use_gmres"))
+            variant("cpr_f32_%s%s" % (args.krylov, wtag), "cpr", args.krylov, dt_main, True,
+                    note="NOT a configuration the reference can run (its CPR plug-in is double-only, NewtonIterationBlackoilCPR.cpp:117-140): round 2's headline, kept for continuity")
+        if use_wells:
+            variant("without_wells", args.solver, "bicgstab" if args.solver == "cpr" else args.krylov, dt_main, single_main, wells_on=False)
+        if abs(args.dt_days - 30.0) > 1e-9:
+            variant("dt30_f64_ilu0" + wtag, "ilu0", "bicgstab", dt30, False, note="dt >= 20 d: the reference's default solver switches to double (BlackoilModelBase_impl.hpp:284)")
+            variant("dt30_f64_cpr_%s%s" % (args.krylov, wtag), "cpr", args.krylov, dt30, False)
 
     out = None
     if rank == 0:
@@ -288,27 +396,31 @@ def main():
                 nbytes = spmv_bytes(nb, nnzb, sb)
                 roof[name] = {"bound": "hbm", "achieved": nbytes / (ms_cold * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": nbytes / (ms_cold * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                              "traffic": None,        # PMC counters need rocprofv3 (separate passes): profiles/r02_pmc_*.json, never pasted here
+                              "traffic": None,        # PMC counters need rocprofv3 (separate passes): profiles/r03_*_pmc_summary.json, never pasted here
                               "kernel": "k_spmv<%s,0>" % ("float" if sp else "double"), "ms_per_launch": ms_cold, "algorithmic_bytes": nbytes,
                               "operands": "matrix rotating over 4 copies (%.0f MB each): HBM-resident" % ((nnzb * (9 * sb + 4)) / 1e6),
                               "cache_resident_replay": {"ms_per_launch": ms_warm, "achieved": nbytes / (ms_warm * 1e-3) / 1e9, "frac": nbytes / (ms_warm * 1e-3) / 1e9 / HBM_PEAK_GBS},
                               "ilu0_apply_ms": ms_ilu, "stream_copy_GBs": 2 * nnzb * 9 * sb / (ms_copy * 1e-3) / 1e9}
                 s.close()
                 del val
-        main_roof = roof.get("f32" if single else "f64")
+        main_roof = roof.get("f32" if single_main else "f64")
 
         kernel_table = None
         if "kt" in res:
-            tot, cnt = res["kt"]
-            S = 4 if single else 8
+            tot, cnt, n_calls, n_solving, lin_sum = res["kt"]
+            S = 4 if single_main else 8
             ab = algorithmic_bytes(nb, nnzb, grid.nconn, S, nnzb)
-            kernel_table = {"note": "HIP-event brackets on the launch stream around every launch (group) of a class during %d real Newton iterations right after the timed ones; "
-                                    "algorithmic bytes per launch: DESIGN.md section 4; frac = achieved / %.0f GB/s" % (args.steps, HBM_PEAK_GBS), "classes": {}}
+            nsol = max(1, n_solving)
+            kernel_table = {"note": "HIP-event brackets on the launch stream around every launch (group) of a class during the %d Newton iterations right after the timed "
+                                    "ones (the brackets cost time: a separate pass).  THIS pass: %d calls, %d of them with a solve, %.2f linear iterations per solving "
+                                    "iteration.  ms_per_newton = class total / calls; algorithmic bytes per launch: DESIGN.md section 4; frac = achieved / %.0f GB/s"
+                                    % (args.steps, n_calls, n_solving, lin_sum / nsol, HBM_PEAK_GBS),
+                            "calls": n_calls, "solving_iterations": n_solving, "linear_iterations_per_solving_iteration": lin_sum / nsol, "classes": {}}
             for i, name in enumerate(capi.KT_NAMES):
                 if cnt[i] == 0:
                     continue
                 ms = tot[i] / cnt[i]
-                e = {"ms_per_newton": tot[i] / args.steps, "launches_per_newton": cnt[i] / args.steps, "ms_per_launch": ms}
+                e = {"ms_per_newton": tot[i] / max(1, n_calls), "launches_per_newton": cnt[i] / max(1, n_calls), "ms_per_launch": ms}
                 if ab.get(name):
                     e.update({"algorithmic_bytes": int(ab[name]), "achieved_GBs": ab[name] / (ms * 1e-3) / 1e9, "frac": ab[name] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
                 kernel_table["classes"][name] = e
@@ -316,13 +428,15 @@ def main():
                 ms = tot[0] / cnt[0] + tot[1] / cnt[1]
                 b = ab["assembly(cell_props+flux)"]
                 kernel_table["classes"]["assembly(cell_props+flux)"] = {"ms_per_launch": ms, "algorithmic_bytes": int(b), "achieved_GBs": b / (ms * 1e-3) / 1e9,
-                                                                      "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "exchange_bytes": int(nb * (80 + 27 * S) * 2)}
-            kernel_table["sum_ms_per_newton"] = float(tot.sum() / args.steps)
+                                                                      "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                                      "note": "SURVEY 8d counts the assembly as ONE pass (state in, Jacobian out): both kernels' time against those bytes"}
+            kernel_table["sum_ms_per_newton"] = float(tot.sum() / max(1, n_calls))
 
         cpu = cpu_all = None
         if not args.no_cpu_baseline and not use_dist:
             wl = make_wells() if use_wells else None
-            cpu = cpu_baseline(grid, tab, st, wl, prm, dt, single, threads=args.cpu_threads)
+            cpu_single = reference_single("ilu0", dt_main)          # the port runs the reference's DEFAULT solver in the reference's arithmetic for it
+            cpu = cpu_baseline(grid, tab, st, wl, prm, dt_main, cpu_single, threads=args.cpu_threads)
             # the same port with its OpenMP-able loops (assembly, SpMV, vector updates; the ILU sweeps stay sequential like the
             # reference's) on this job's host cores -- the reference itself caps OpenMP at 4 threads (FlowMain.hpp:269-271)
             try:
@@ -331,26 +445,46 @@ def main():
                 ncores = os.cpu_count() or 1
             ncores = min(ncores, 16)             # a one-GPU box shares its host: 16 cores is this job's share
             if ncores > args.cpu_threads:
-                cpu_all = cpu_baseline(grid, tab, st, wl, prm, dt, single, threads=ncores, budget_s=8.0, max_newton=2)
+                cpu_all = cpu_baseline(grid, tab, st, wl, prm, dt_main, cpu_single, threads=ncores, budget_s=8.0, max_newton=2)
 
-        wells_txt = ("5-spot: 1 rate-controlled water injector (%.0f m3/d, BHP limit off) + 4 BHP producers (%.0f bar), %d perforations each, device well model "
-                     "(rank-7 operator per well, control switching + well pre-solve on the device)%s" %
-                     (((well_spec[0], well_spec[1]) if well_spec else (args.rate, 150.0)) + (args.nz, "" if world == 1 else "; one such 5-spot per rank's slab (%d wells)" % (5 * world)))) if use_wells else "none"
+        if use_wells:
+            spec = well_spec if well_spec else (spe10_spec if args.deck == "spe10like" else (args.rate, 150.0))
+            per = args.nz
+            wells_txt = ("5-spot: 1 rate-controlled water injector (%.0f m3/d, BHP limit off) + 4 BHP producers (%.0f bar), %d perforations each, device well model "
+                         "(rank-7 operator per well, control switching + well pre-solve on the device)%s" %
+                         (spec[0], spec[1], per, "" if world == 1 else ("; one such 5-spot per rank's slab (%d wells)" % (5 * world) if (args.scaling == "weak" and args.deck == "cart")
+                                                                         else "; the deck is cut along j, every well on one rank")))
+        else:
+            wells_txt = "none"
+        weak = world > 1 and args.scaling == "weak" and args.deck == "cart"
+        lin_name = ("cpr(amg V-cycle + ilu0)" if prm.use_cpr else "ilu0") + ({1: " + gmres(40)", 2: " + flexible gmres(40)"}.get(prm.newton_use_gmres, " + bicgstab"))
         out = {
-            "metric": "Mcell-updates/sec per Newton step (assembly+solve)", "value": value, "unit": "Mcell-updates/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "metric": "Mcell-updates/sec per Newton step (assembly+solve)", "value": main_sum["value"], "unit": "Mcell-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_sum["ms_per_step"],
             "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
-            "dtype": "f64 assembly + %s linear solve" % ("f32" if single else "f64"), "data": "synthetic",
-            "config": {"workload": "%s%dx%dx%d_3phase_blackoil%s" % ("spe10like_" if args.deck == "spe10like" else "cart", args.nx, args.ny,
-                                                                     args.nz * (world if (world > 1 and args.scaling == "weak" and args.deck == "cart") else 1),
+            "dtype": "f32" if single_main else "f64", "data": "synthetic",
+            "value_basis": ("cells / median duration of the %d timed Newton iterations that include a linear solve (SURVEY 8d M1)" % res["n_solving"]) if res["solving_ms"] is not None
+                           else "cells / mean duration of the timed calls (no per-call marks in this mode)",
+            "ms_per_solving_iteration_median": main_sum["ms_per_solving_iteration_median"], "value_all_calls_mean": main_sum["value_all_calls_mean"],
+            "config": {"workload": "%s%dx%dx%d_3phase_blackoil%s" % ("spe10like_" if args.deck == "spe10like" else "cart", args.nx, args.ny, args.nz * (world if weak else 1),
                                                                      "_fivespot" if use_wells else ""),
                        "cells": nc_global, "cells_per_gpu": info["n_owned"], "nnzb_rank0": nnzb,
-                       "dt_days": args.dt_days, "linear_solver": ("cpr(amg V-cycle + ilu0)" if prm.use_cpr else "ilu0") + ({1: " + gmres(40)", 2: " + flexible gmres(40)"}.get(prm.newton_use_gmres, " + bicgstab")), "ilu0_ordering": args.ordering,
-                       "linear_iterations_per_newton": res["lin"], "time_steps_completed": res["steps_done"], "time_steps_not_converged": res["steps_not_converged"], "time_steps_chopped": res["chopped"],
+                       "dt_days": args.dt_days, "linear_solver": lin_name, "ilu0_ordering": args.ordering,
+                       "arithmetic": main_sum["arithmetic"],
+                       "gmres_true_residual_check": bool(prm.gmres_verify_residual),
+                       "reference_equivalence": ("reference-option-equivalent: solver_approach=cpr + newton_use_gmres in double, the arithmetic of the reference's CPR plug-in "
+                                                 "(NewtonIterationBlackoilCPR.cpp:61-64, 117-140)" if (prm.use_cpr and not single_main) else
+                                                 "reference default (solver_approach=interleaved)" if (not prm.use_cpr and single_main == reference_single("ilu0", dt_main) and not prm.newton_use_gmres) else
+                                                 "NOT a configuration the reference can run as is (see the docstring of bench.py)"),
+                       "reference_default_variant": "same_run_variants.reference_default_solver_ilu0" + wtag,
+                       "solving_iterations": res.get("n_solving"), "linear_iterations_per_solving_iteration": res.get("lin_per_solving"),
+                       "time_steps_completed": res["steps_done"], "time_steps_not_converged": res["steps_not_converged"], "time_steps_chopped": res["chopped"],
                        "spin_up_time_steps": args.spin_up, "nonlinear_solver": "reference NonlinearSolver (max_iter 10, update stabilisation on)",
                        "tables": "tests/satfuncStandard.DATA PROPS (reference's own test deck)", "wells": wells_txt,
                        "parallelism": "1 GPU" if world == 1 else "domain decomposition x%d, RCCL halo" % world},
-            "breakdown_ms_per_step": res["breakdown"],
+            "timed_calls": res.get("calls"),
+            "non_solving_call_ms_median": res.get("non_solving_ms_median"),
+            "breakdown_ms_per_step": res.get("breakdown"),
             "same_run_variants": variants,
             "roofline": main_roof, "roofline_f64_spmv": roof.get("f64"), "roofline_f32_spmv": roof.get("f32"),
             "kernel_table": kernel_table,
@@ -369,7 +503,6 @@ def cpu_baseline(grid, tab, st, wl, prm, dt, single, threads=1, budget_s=15.0, m
     Schur complement, natural-order block-ILU0, BiCGStab, same precision switch, same update) timed on the host cores for a bounded
     sample: the first Newton iterations of the SAME deck (wells included) from the SAME initial state (at least one, until the time
     budget is used)."""
-    import numpy as np
     from oracle import oracle as orc
     from opmgpu import capi, wells as W
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -391,8 +524,9 @@ def cpu_baseline(grid, tab, st, wl, prm, dt, single, threads=1, budget_s=15.0, m
         tot += time.perf_counter() - t1
         its += 1; lin.append(l)
     return {"value": its * grid.nc / tot / 1e6, "unit": "Mcell-updates/s", "cores": threads, "kind": "port",
-            "sample": "first %d Newton iterations of the same deck%s and initial state: assembly + %snatural-order ILU0/BiCGStab %s (linear its %s) + update, %.2f s"
-                      % (its, " with its 5-spot (host well model, explicit Schur complement)" if wl is not None else "", "", "f32" if single else "f64", lin, tot),
+            "sample": "first %d Newton iterations of the same deck%s and initial state: assembly + natural-order ILU0/BiCGStab %s (the reference's default "
+                      "solver_approach=interleaved; linear its %s) + update, %.2f s"
+                      % (its, " with its 5-spot (host well model, explicit Schur complement)" if wl is not None else "", "f32" if single else "f64", lin, tot),
             "newton_iterations": its, "linear_iterations": lin}
 
 

@@ -154,6 +154,17 @@ typedef struct opmgpu_params {
     int32_t update_equations_scaling; /* 0; 1: matbalscale[a] = mean over the cells of 1 / b_a of the state being assembled
                                          (BlackoilModelBase::updateEquationsScaling, BlackoilModelBase_impl.hpp:909, :919-947); the values in
                                          use are read back with opmgpu_get_matbalscale */
+    int32_t gmres_verify_residual;  /* 0 = Dune::RestartedGMResSolver as it is (ISTLSolver.hpp:257-264): the iteration stops when the
+                                         PRECONDITIONED residual || M^-1 (b - A x) || has fallen by linear_solver_reduction;
+                                       1 = before such a solve is reported converged the TRUE residual b - A x is formed (one product) and the
+                                           iteration continues from it, with a lowered threshold, until || b - A x || <= reduction || b || -- the
+                                           statement the reference's default BiCGStab makes; the reported reduction is then the true one.
+                                           Not a reference option; costs one SpMV per solve; left-preconditioned GMRES only */
+    int32_t cpr_reference_transform; /* 0 = CPR as DESIGN.md 4b describes it (only the pressure stage sees the combined equation);
+                                        1 = the reference's formulation for comparability (NewtonIterationUtilities.cpp:253-287,
+                                            NewtonIterationBlackoilCPR.cpp:117-131): the WHOLE system is row-transformed by L (per cell: its
+                                            first equation is replaced by the sum of the dominant equations), the pressure row scaled by
+                                            200 bar, and the Krylov method iterates on (and measures) L A x = L b */
 } opmgpu_params;
 
 void opmgpu_default_params(opmgpu_params* p);
@@ -414,6 +425,16 @@ int opmgpu_kernel_timing(opmgpu_ctx* ctx, int enable);
 int opmgpu_kernel_timing_get(opmgpu_ctx* ctx, double* total_ms, int64_t* launches);
 /* elapsed device milliseconds of the last assemble / solve / update_state call. */
 int opmgpu_last_timings(opmgpu_ctx* ctx, double* assemble_ms, double* solve_ms, double* update_ms);
+/* Per-call timing of opmgpu_nonlinear_iteration WITHOUT a synchronisation inside the timed calls (the median over the Newton
+ * iterations that include a linear solve).  After opmgpu_iteration_marks(ctx, 1) every call records one event on the library's stream when
+ * it has enqueued its last kernel, and one event pair around each of its phases; opmgpu_iteration_marks_get waits for the last recorded
+ * event and returns for the first max_calls calls since the switch-on: call_ms[i] = device time from the end of call i - 1 (the switch-on
+ * for i = 0) to the end of call i -- the host round trips of an iteration serialise consecutive calls, so this is the iteration's wall
+ * time --, solved[i] = 1 if the call ran solveJacobianSystem + updateState (a converged call does not: BlackoilModelBase_impl.hpp:277-281),
+ * linear_iterations[i], phase_ms[3 i + {0, 1, 2}] = assemble / solve / update (0 where the phase did not run).  Any output may be NULL;
+ * *n_calls = calls recorded.  opmgpu_iteration_marks(ctx, 0) switches off and frees the events. */
+int opmgpu_iteration_marks(opmgpu_ctx* ctx, int enable);
+int opmgpu_iteration_marks_get(opmgpu_ctx* ctx, int max_calls, double* call_ms, int32_t* solved, int32_t* linear_iterations, double* phase_ms, int* n_calls);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-GPU (domain decomposition with a one-cell halo; mirrors owner/overlap of

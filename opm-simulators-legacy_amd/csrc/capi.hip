@@ -4,6 +4,7 @@
 // shim maps back to the exception flow_legacy's time stepper expects.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <array>
 #include <memory>
@@ -35,6 +36,18 @@ struct opmgpu_ctx {
     // opmgpu_nonlinear_iteration: residual_norms_history_ / current_relaxation_ of BlackoilModelBase (:244-247, :300-315)
     std::vector<std::array<double, 3>> norm_history;
     double relaxation = 1.0;
+    // opmgpu_iteration_marks: one event at the end of every opmgpu_nonlinear_iteration call and one pair per phase, kept per call (nothing
+    // is synchronised while the marks are on; opmgpu_iteration_marks_get resolves them afterwards)
+    struct IterMark { hipEvent_t end = nullptr; hipEvent_t ph[3][2] = { { nullptr, nullptr }, { nullptr, nullptr }, { nullptr, nullptr } }; int solved = 0, lin = 0, status = 0; };
+    bool marks_on = false;
+    hipEvent_t mark_start = nullptr;
+    std::vector<IterMark> marks;
+    IterMark* cur_mark = nullptr;
+    void marks_clear() {
+        for (IterMark& m : marks) { if (m.end) (void)hipEventDestroy(m.end); for (auto& pr : m.ph) for (auto& e : pr) if (e) (void)hipEventDestroy(e); }
+        marks.clear(); cur_mark = nullptr;
+        if (mark_start) { (void)hipEventDestroy(mark_start); mark_start = nullptr; }
+    }
 };
 
 namespace {
@@ -72,8 +85,22 @@ int make_ctx(opmgpu_ctx** out, int device, const opmgpu_params* params)
 enum { PH_ASSEMBLE = 0, PH_SOLVE = 1, PH_UPDATE = 2 };
 struct Timed {
     opmgpu_ctx* c; int ph;
-    Timed(opmgpu_ctx* c_, int phase) : c(c_), ph(phase) { c->ev_pending[ph] = false; (void)hipEventRecord(c->evp[ph][0], c->stream); }
-    ~Timed() { (void)hipEventRecord(c->evp[ph][1], c->stream); c->ev_pending[ph] = true; }
+    hipEvent_t e1 = nullptr;
+    Timed(opmgpu_ctx* c_, int phase) : c(c_), ph(phase) {
+        if (c->cur_mark) {                  // iteration marks: this call's own event pair (resolved by opmgpu_iteration_marks_get)
+            hipEvent_t e0 = nullptr;
+            if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+                // a phase that runs twice in one call (never today) keeps its last pair
+                for (auto& e : c->cur_mark->ph[ph]) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+                c->cur_mark->ph[ph][0] = e0; c->cur_mark->ph[ph][1] = e1;
+                (void)hipEventRecord(e0, c->stream);
+                return;
+            }
+            e1 = nullptr;
+        }
+        c->ev_pending[ph] = false; (void)hipEventRecord(c->evp[ph][0], c->stream);
+    }
+    ~Timed() { if (e1) { (void)hipEventRecord(e1, c->stream); return; } (void)hipEventRecord(c->evp[ph][1], c->stream); c->ev_pending[ph] = true; }
 };
 
 template <class S> int solve_loaded(opmgpu_ctx* c, bool matrix_changed, SolveResult& res)
@@ -120,7 +147,7 @@ void opmgpu_default_params(opmgpu_params* p)
     p->linear_solver_reduction = 1e-2; p->linear_solver_maxiter = 150;                    // FlowLinearSolverParameters
     p->ilu_relaxation = 0.9; p->ilu_ordering = OPMGPU_ORDER_MULTICOLOR; p->ignore_convergence_failure = 0; p->use_cpr = 0;
     p->newton_use_gmres = 0; p->linear_solver_restart = 40;                                // NewtonIterationBlackoilCPR.cpp:61-64
-    p->solve_welleq_initially = 1; p->tolerance_wells = 1e-4; p->tolerance_well_control = 1e-7; p->dbhp_max_rel = 1.0; p->update_equations_scaling = 0;   // BlackoilModelParameters.cpp:80-96
+    p->solve_welleq_initially = 1; p->tolerance_wells = 1e-4; p->tolerance_well_control = 1e-7; p->dbhp_max_rel = 1.0; p->update_equations_scaling = 0; p->gmres_verify_residual = 0; p->cpr_reference_transform = 0;   // BlackoilModelParameters.cpp:80-96
 }
 
 int opmgpu_create_solver(opmgpu_ctx** ctx, int device, const opmgpu_params* params) { return make_ctx(ctx, device, params); }
@@ -142,6 +169,7 @@ void opmgpu_destroy(opmgpu_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->model.reset(); c->ls.reset(); c->comm.reset();
+    c->marks_clear();
     for (auto& pr : c->evp) for (auto& e : pr) if (e) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -329,10 +357,63 @@ int opmgpu_well_convergence(opmgpu_ctx* c, double* flux3, double* ctrl)
     return guarded(c, [&]() { return c->model->well_convergence(flux3, ctrl); });
 }
 
+static int nonlinear_iteration_body(opmgpu_ctx* c, double dt, int iteration, int single_precision, const opmgpu_newton_ctl* ctl, int* converged,
+                                    int* linear_iterations, double* linf3, double* relaxation, int* solved);
+
 int opmgpu_nonlinear_iteration(opmgpu_ctx* c, double dt, int iteration, int single_precision, const opmgpu_newton_ctl* ctl, int* converged,
                                int* linear_iterations, double* linf3, double* relaxation)
 {
     if (!c || !c->model || !ctl || !converged || iteration < 0) return OPMGPU_EINVAL;
+    int solved = 0, lin = 0;
+    if (!c->marks_on) return nonlinear_iteration_body(c, dt, iteration, single_precision, ctl, converged, linear_iterations ? linear_iterations : &lin, linf3, relaxation, &solved);
+    if (hipSetDevice(c->device) != hipSuccess) return fail(c, OPMGPU_ENODEVICE, "hipSetDevice failed");
+    if (!c->mark_start) { if (hipEventCreate(&c->mark_start) != hipSuccess) return OPMGPU_ENODEVICE; (void)hipEventRecord(c->mark_start, c->stream); }
+    c->marks.emplace_back();
+    c->cur_mark = &c->marks.back();
+    if (!linear_iterations) linear_iterations = &lin;
+    const int st = nonlinear_iteration_body(c, dt, iteration, single_precision, ctl, converged, linear_iterations, linf3, relaxation, &solved);
+    opmgpu_ctx::IterMark& m = c->marks.back();
+    m.solved = solved; m.lin = *linear_iterations; m.status = st;
+    if (hipEventCreate(&m.end) == hipSuccess) (void)hipEventRecord(m.end, c->stream);
+    c->cur_mark = nullptr;
+    return st;
+}
+
+int opmgpu_iteration_marks(opmgpu_ctx* c, int enable)
+{
+    if (!c) return OPMGPU_EINVAL;
+    if (hipSetDevice(c->device) != hipSuccess) return fail(c, OPMGPU_ENODEVICE, "hipSetDevice failed");
+    c->marks_clear();
+    c->marks_on = enable != 0;
+    return OPMGPU_OK;
+}
+
+int opmgpu_iteration_marks_get(opmgpu_ctx* c, int max_calls, double* call_ms, int32_t* solved, int32_t* linear_iterations, double* phase_ms, int* n_calls)
+{
+    if (!c || !n_calls || max_calls < 0) return OPMGPU_EINVAL;
+    if (hipSetDevice(c->device) != hipSuccess) return fail(c, OPMGPU_ENODEVICE, "hipSetDevice failed");
+    const int n = std::min<int>(max_calls, int(c->marks.size()));
+    *n_calls = int(c->marks.size());
+    if (n > 0 && c->marks[n - 1].end && hipEventSynchronize(c->marks[n - 1].end) != hipSuccess) return fail(c, OPMGPU_ENODEVICE, "hipEventSynchronize failed");
+    hipEvent_t prev = c->mark_start;
+    for (int i = 0; i < n; ++i) {
+        const opmgpu_ctx::IterMark& m = c->marks[i];
+        float ms = 0.f;
+        if (call_ms) { call_ms[i] = (prev && m.end && hipEventElapsedTime(&ms, prev, m.end) == hipSuccess) ? double(ms) : -1.0; }
+        if (solved) solved[i] = m.solved;
+        if (linear_iterations) linear_iterations[i] = m.lin;
+        if (phase_ms) for (int ph = 0; ph < 3; ++ph) {
+            float pm = 0.f;
+            phase_ms[3 * i + ph] = (m.ph[ph][0] && m.ph[ph][1] && hipEventSynchronize(m.ph[ph][1]) == hipSuccess && hipEventElapsedTime(&pm, m.ph[ph][0], m.ph[ph][1]) == hipSuccess) ? double(pm) : 0.0;
+        }
+        if (m.end) prev = m.end;
+    }
+    return OPMGPU_OK;
+}
+
+static int nonlinear_iteration_body(opmgpu_ctx* c, double dt, int iteration, int single_precision, const opmgpu_newton_ctl* ctl, int* converged,
+                                    int* linear_iterations, double* linf3, double* relaxation, int* solved)
+{
     if (iteration == 0) { c->norm_history.clear(); c->relaxation = 1.0; }
     if (int(c->norm_history.size()) != iteration) return fail(c, OPMGPU_EINVAL, "opmgpu_nonlinear_iteration: iterations of a time step must be consecutive from 0");
     *converged = 0;
@@ -357,6 +438,7 @@ int opmgpu_nonlinear_iteration(opmgpu_ctx* c, double dt, int iteration, int sing
     *converged = conv;
     if (!conv || iteration < ctl->min_iter) {
         int its = 0;
+        *solved = 1;
         st = opmgpu_solve(c, single_precision, nullptr, &its, nullptr);
         if (linear_iterations) *linear_iterations = its;
         if (st != OPMGPU_OK) return st;

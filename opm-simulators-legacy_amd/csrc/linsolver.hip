@@ -2365,6 +2365,42 @@ __global__ __launch_bounds__(kBlock) void k_gm_defect(long n, const S* __restric
     for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) out[i] = b[i] - ax[i];
 }
 __global__ void k_gm_reset_s(int m, GmState g) { for (int i = 1; i < m + 1; ++i) g.s[i] = 0.0; }
+// opmgpu_params.gmres_verify_residual: left-preconditioned GMRES stops on || M^-1 (b - A x) ||; before the solve is reported as converged
+// the TRUE defect r = b - A x is formed (the vector a restart would start from anyway) together with the owned parts of ||r||^2 and ||b||^2
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_gm_defect_norms(long n, int nbp, const int8_t* __restrict__ mask, const S* __restrict__ b, const S* __restrict__ ax,
+                                                            S* __restrict__ out, double* __restrict__ parts_r, double* __restrict__ parts_b)
+{
+    __shared__ double sm[8];
+    double acc[2] = { 0.0, 0.0 };
+    for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) {
+        const S bi = b[i], r = bi - ax[i];
+        out[i] = r;
+        if (!mask || mask[i % nbp]) { acc[0] += double(r) * double(r); acc[1] += double(bi) * double(bi); }
+    }
+    block_sum<2>(acc, sm);
+    if (threadIdx.x == 0) { parts_r[blockIdx.x] = acc[0]; parts_b[blockIdx.x] = acc[1]; }
+}
+// verdict of the check: ||r|| <= reduction ||b|| keeps `done`; otherwise the iteration goes on from r with the threshold on the
+// preconditioned residual lowered by the factor the true residual missed its target by (and a safety factor of 2).  vr[0] = ||r||^2 / ||b||^2.
+__global__ __launch_bounds__(kBlock) void k_gm_verify(const double* __restrict__ parts_r, const double* __restrict__ parts_b, int np, double red, double* __restrict__ vr,
+                                                      SolveCtl* __restrict__ ctl, SolveCtl* __restrict__ hst, int* __restrict__ tick_ptr, int tick)
+{
+    __shared__ double sm[12];
+    const double* const arr[2] = { parts_r, parts_b };
+    double s[2];
+    reduce_partials<2>(arr, np, s, sm);
+    if (threadIdx.x == 0) {
+        const double ratio2 = s[1] > 0.0 ? s[0] / s[1] : 0.0;
+        vr[0] = ratio2;
+        if (ratio2 == ratio2 && ratio2 > red * red) {
+            ctl->done = 0;
+            ctl->thresh2 = ctl->norm2 * (red * red / ratio2) * 0.25;
+        } else if (ratio2 == ratio2) ctl->norm2 = ratio2 * ctl->norm0_2;      // the reported reduction is then the TRUE one (what BiCGStab's means)
+        publish(ctl, hst);
+        if (tick_ptr) { __threadfence_system(); *(volatile int*)tick_ptr = tick; }
+    }
+}
 
 template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
 {
@@ -2397,6 +2433,10 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
     // solve (M^-1 b before the first column; a CPR solve has ~4 columns) and stops on the PRECONDITIONED residual; this form stops on the
     // true residual, the criterion of the reference's default BiCGStab.  One more basis of m vectors in memory.
     const bool flex = prm.newton_use_gmres == 2;
+    // gmres_verify_residual: the flexible form measures the true residual itself
+    const bool verify = prm.gmres_verify_residual != 0 && !flex;
+    bool verified = false;
+    int verify_rounds = 0;
     static const bool cgs_on = !(std::getenv("OPMGPU_GMRES_CGS") && std::atoi(std::getenv("OPMGPU_GMRES_CGS")) == 0);
     const bool cgs = comm != nullptr && cgs_on && m <= 63;
     if (cgs) cgs_parts.alloc(size_t(m + 1) * gv + size_t(m + 1));
@@ -2513,9 +2553,29 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
         // x += sum_a y_a v_a with R y = s   (i columns were completed)
         hipLaunchKernelGGL(k_gm_solve_y, dim3(1), dim3(1), 0, stream, i, m, g);
         hipLaunchKernelGGL((k_gm_update_x<S>), dim3(gv), dim3(kBlock), 0, stream, n, i, (const double*)g.y, flex ? (const S*)w.kryz.p : (const S*)w.kry.p, w.x.p);
-        if (!stop && j <= maxit) {                                     // restart from the true defect
+        bool have_defect = false;
+        if (stop && verify && h_ctl->done && h_ctl->flag == 0) {
+            // the preconditioned residual met the threshold: does the true one?  (one product + one pass; the defect is the restart vector)
             product(w.x.p, w.v.p, (const SolveCtl*)nullptr);
-            hipLaunchKernelGGL((k_gm_defect<S>), dim3(gv), dim3(kBlock), 0, stream, n, (const S*)w.b.p, (const S*)w.v.p, w.r.p);
+            hipLaunchKernelGGL((k_gm_defect_norms<S>), dim3(gv), dim3(kBlock), 0, stream, n, plan.nbp, mask, (const S*)w.b.p, (const S*)w.v.p, w.r.p, parts, parts2);
+            const double* pr = parts; const double* pb = parts2; int np_v = gv;
+            if (comm) {
+                hipLaunchKernelGGL((k_sum_partials<2>), dim3(1), dim3(kBlock), 0, stream, (const double*)parts, (const double*)parts2, gv, red1);
+                comm->allreduce_sum(red1, 2, stream);
+                pr = red1; pb = red1 + 1; np_v = 1;
+            }
+            const int tick = ++tick_seq;
+            hipLaunchKernelGGL(k_gm_verify, dim3(1), dim3(kBlock), 0, stream, pr, pb, np_v, prm.linear_solver_reduction, g.y + m, d_ctl, h_ctl_dev,
+                               poll_status ? h_tick_dev : (int*)nullptr, tick);
+            wait_tick(tick);
+            verified = true;
+            if (!h_ctl->done) { stop = false; have_defect = true; ++verify_rounds; }
+        }
+        if (!stop && j <= maxit) {                                     // restart from the true defect
+            if (!have_defect) {
+                product(w.x.p, w.v.p, (const SolveCtl*)nullptr);
+                hipLaunchKernelGGL((k_gm_defect<S>), dim3(gv), dim3(kBlock), 0, stream, n, (const S*)w.b.p, (const S*)w.v.p, w.r.p);
+            }
             if (flex) normalize_start((const S*)w.r.p, 0);
             else { precond(w.r.p, w.t.p); normalize_start((const S*)w.t.p, 0); }
         }
@@ -2528,6 +2588,8 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
     res.converged = h_ctl->done && h_ctl->flag == 0;
     res.iterations = (h_ctl->done && h_ctl->flag == 0) ? h_ctl->iters : j - 1;
     res.reduction = norm0 > 0 ? norm / norm0 : 0.0;
+    (void)verified;
+    last_verify_rounds = verify_rounds;
     if (h_ctl->flag != 0 || !(norm0 == norm0)) res.status = OPMGPU_EBREAKDOWN;
     else if (!res.converged && !prm.ignore_convergence_failure) res.status = OPMGPU_ELINSOLVE;
     last_its = res.iterations;              // the back-off of the lag policy, as at the end of bicgstab (see cpr_prepare)

@@ -206,6 +206,7 @@ public:
     bool new_step_hint = true;     // set by the caller for the first matrix of a time step (and for every external matrix)
     bool refreshed = true;         // the current solve runs on freshly built coarse operators
     int last_its = 0, its_ref = 0; // iterations of the last solve / of the solve right after the last refresh
+    int last_verify_rounds = 0;    // GMRES with gmres_verify_residual: how often the true residual sent the last solve back to work
     bool weights_from_assembly = false;   // cprw of the current matrix was written by the assembly kernel (k_flux), not by k_cpr_weights
     bool lu_copy_upper = false;    // factor(): also store the U entries that equal A's (diagnostic read-back of the factors)
     bool lag_allowed = true, force_refresh = false;

@@ -641,6 +641,83 @@ __global__ __launch_bounds__(kBlock) void k_well_presolve_fused(int nw, WellArgs
     }
 }
 
+__global__ void k_well_flag_or(int32_t* f, int bits) { atomicOr(f, bits); }
+// Fallback of the fused pre-solve: its counter barrier needs all nw workgroups resident together, which the launch guarantees only against
+// the kernel's own occupancy (fused_presolve_capacity) -- other streams' and other processes' kernels give their slots back, but slowly enough
+// under co-tenancy (several ranks rehearsing on one GPU) for a workgroup's bounded spin to give up (error bit 16).  That is a SCHEDULING
+// condition, not a numerical one: this kernel, launched right behind the fused one, does nothing unless bit 16 is up; then it clears the
+// bit, restores the well state the pre-solve started from and runs the whole loop (the same arithmetic: assemble every well, one decision
+// from all residuals, update every well) inside ONE workgroup, wells one after the other.  Slow, correct, and never a NumericalIssue.
+__global__ __launch_bounds__(kBlock) void k_well_presolve_serial(int nw, int np, WellArgs A, const int32_t* __restrict__ slice_ptr, const int16_t* __restrict__ nlower,
+                                                                 const double* __restrict__ bsums, double ncells, double tol_wells, double tol_ctrl,
+                                                                 double max_resid, double dbhp_max_rel, int max_it, int32_t* __restrict__ flags,
+                                                                 const double* __restrict__ snap, const int32_t* __restrict__ isnap, double* __restrict__ Ebuf /* [nw][4] */)
+{
+    const int tid = threadIdx.x;
+    __shared__ int go, decision;
+    if (tid == 0) go = (flags[WF_ERR] & 16) ? 1 : 0;
+    __syncthreads();
+    if (!go) return;
+    // back to the state the pre-solve started from (layout of snap: k_well_snapshot)
+    {
+        double* parts[4] = { A.wstate, A.thp, A.perf_rates, A.perf_press };
+        const int len[4] = { 4 * nw, nw, 3 * np, np };
+        int off = 0;
+        for (int k = 0; k < 4; ++k) { for (int i = tid; i < len[k]; i += kBlock) parts[k][i] = snap[off + i]; off += len[k]; }
+        for (int i = tid; i < nw; i += kBlock) A.current[i] = isnap[i];
+        if (tid == 0) { atomicAnd(&flags[WF_ERR], ~16); flags[WF_DONE] = 0; flags[WF_CONV] = 0; flags[WF_ITS] = 0; }
+    }
+    __threadfence();
+    __syncthreads();
+    for (int it = 0;; ) {
+        for (int w = 0; w < nw; ++w) {
+            well_assemble_dev<double, true>(A, w, slice_ptr, nlower, 1.0, 1.0, 1.0, nullptr, (double*)nullptr, nullptr, flags, Ebuf + 4 * size_t(w), false);
+            __threadfence();
+            __syncthreads();
+        }
+        if (tid < 64) {
+            double mx[4] = { 0, 0, 0, 0 }; int bad = 0;
+            for (int v = tid; v < nw; v += 64) for (int k = 0; k < 4; ++k) { const double e = fabs(Ebuf[4 * v + k]); if (!(e == e)) bad = 1; mx[k] = fmax(mx[k], e); }
+            for (int k = 0; k < 4; ++k) mx[k] = wave_max(mx[k]);
+            bad = __any(bad);
+            if (tid == 0) {
+                bool conv = true, toolarge = false;
+                for (int a = 0; a < 3; ++a) { const double wf = (bsums[a] / ncells) * mx[a]; conv = conv && wf < tol_wells; toolarge = toolarge || wf > max_resid || !(wf == wf); }
+                conv = conv && mx[3] < tol_ctrl;
+                decision = (bad || toolarge) ? 2 : (conv ? 1 : 0);
+            }
+        }
+        __syncthreads();
+        const int dec = decision;
+        if (dec != 0) {
+            if (tid == 0) { if (dec == 2) atomicOr(&flags[WF_ERR], 8); flags[WF_CONV] = dec == 1 ? 1 : 0; flags[WF_ITS] = it; flags[WF_DONE] = 1; }
+            return;
+        }
+        ++it;
+        for (int w = tid; w < nw; w += kBlock) {
+            const double* Di = A.Dinv + 16 * w;
+            double dy[4];
+            for (int k = 0; k < 4; ++k) { dy[k] = 0.0; for (int c = 0; c < 4; ++c) dy[k] += Di[4 * k + c] * Ebuf[4 * w + c]; }
+            well_apply_increment(A, w, dy, dbhp_max_rel);
+            if (!well_update_controls(A, w)) atomicOr(&flags[WF_ERR], 4);
+        }
+        __threadfence();
+        __syncthreads();
+        if (it >= max_it) { if (tid == 0) { flags[WF_CONV] = 0; flags[WF_ITS] = it; flags[WF_DONE] = 1; } return; }
+    }
+}
+// how many workgroups of the fused pre-solve the device holds at once (occupancy query x compute units, halved as a margin for the side
+// streams that run next to it): the fused path is taken only for nw up to this
+static int fused_presolve_capacity()
+{
+    static int cap = -1;
+    if (cap >= 0) return cap;
+    int dev = 0, ncu = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k_well_presolve_fused), kBlock, 0) != hipSuccess) return cap = 0;
+    return cap = std::max(0, (ncu * per_cu) / 2);
+}
+
 // one step of the pre-solve loop (BlackoilModelBase_impl.hpp:1063-1097), ONE workgroup for all wells: getWellConvergence over all
 // wells (B_avg * max |flux eq| < tolerance_wells, max |control eq| < tolerance_well_control); if not converged every well takes the
 // Newton update dy = D^-1 E of its own 4x4 system (the well equations of different wells are independent while the reservoir is
@@ -1008,13 +1085,23 @@ void BlackoilDevice::wells_assemble(bool initial)
             binv_sums_device(W.bsums.p, W.bscratch.p);
             const double ncg = ls.comm ? double(ls.comm->n_owned_global) : double(nc);
             const int max_it = 15;
-            static const bool fused_ok = !(std::getenv("OPMGPU_WELL_PRESOLVE_FUSED") && std::atoi(std::getenv("OPMGPU_WELL_PRESOLVE_FUSED")) == 0);
-            if (W.nw <= kFusedWells && fused_ok) {
-                // one launch: one workgroup per well, counter barrier per iteration (all nw <= 256 workgroups are resident together)
+            // OPMGPU_WELL_PRESOLVE_FUSED: 1 (default) one launch with a counter barrier; 0 two launches per iteration; 2 (tests) the serial
+            // fallback that takes over when the fused kernel's barrier gives up.  Read per call: once per time step.
+            const char* fenv = std::getenv("OPMGPU_WELL_PRESOLVE_FUSED");
+            const int fmode = fenv ? std::atoi(fenv) : 1;
+            if (fmode != 0 && W.nw <= std::min(kFusedWells, fused_presolve_capacity())) {
+                // one launch: one workgroup per well, counter barrier per iteration -- all nw workgroups fit the device together
+                // (fused_presolve_capacity: the kernel's occupancy x compute units, with a margin)
                 W.presolve_sync.alloc(4 + 8 * size_t(W.nw)); W.presolve_sync.zero(stream);
+                if (fmode == 2) hipLaunchKernelGGL(k_well_flag_or, dim3(1), dim3(1), 0, stream, W.flags.p + WF_ERR, 16);
+                else
                 hipLaunchKernelGGL(k_well_presolve_fused, dim3(W.nw), dim3(kBlock), 0, stream, W.nw, A, ls.dp.slice_ptr.p, ls.dp.nlower.p, (const double*)W.bsums.p, ncg,
                                    prm.tolerance_wells, prm.tolerance_well_control, prm.max_residual_allowed, prm.dbhp_max_rel, max_it, W.flags.p,
                                    reinterpret_cast<int32_t*>(W.presolve_sync.p), W.presolve_sync.p + 4);
+                // does nothing unless the barrier gave up (error bit 16): then the loop once more from the snapshot, in one workgroup
+                hipLaunchKernelGGL(k_well_presolve_serial, dim3(1), dim3(kBlock), 0, stream, W.nw, np, A, ls.dp.slice_ptr.p, ls.dp.nlower.p, (const double*)W.bsums.p, ncg,
+                                   prm.tolerance_wells, prm.tolerance_well_control, prm.max_residual_allowed, prm.dbhp_max_rel, max_it, W.flags.p,
+                                   (const double*)W.snap.p, (const int32_t*)W.isnap.p, W.presolve_sync.p + 4);
             } else
             for (int it = 0; it <= max_it; ++it) {
                 hipLaunchKernelGGL((k_well_assemble<double, true>), dim3(W.nw), dim3(kBlock), 0, stream, A, ls.dp.slice_ptr.p, ls.dp.nlower.p, sc[0], sc[1], sc[2],

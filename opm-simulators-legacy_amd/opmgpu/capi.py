@@ -83,7 +83,8 @@ class Params(C.Structure):
                 ("ignore_convergence_failure", C.c_int32), ("use_cpr", C.c_int32),
                 ("newton_use_gmres", C.c_int32), ("linear_solver_restart", C.c_int32),
                 ("solve_welleq_initially", C.c_int32), ("tolerance_wells", C.c_double), ("tolerance_well_control", C.c_double),
-                ("dbhp_max_rel", C.c_double), ("update_equations_scaling", C.c_int32)]
+                ("dbhp_max_rel", C.c_double), ("update_equations_scaling", C.c_int32),
+                ("gmres_verify_residual", C.c_int32), ("cpr_reference_transform", C.c_int32)]
 
 
 def default_params(**over):
@@ -97,6 +98,7 @@ def default_params(**over):
     p.newton_use_gmres, p.linear_solver_restart = 0, 40
     p.solve_welleq_initially, p.tolerance_wells, p.tolerance_well_control, p.dbhp_max_rel = 1, 1e-4, 1e-7, 1.0
     p.update_equations_scaling = 0
+    p.gmres_verify_residual, p.cpr_reference_transform = 0, 0
     for k, v in over.items():
         if k == "matbalscale":
             p.matbalscale[:] = list(v)
@@ -181,6 +183,8 @@ SIGNATURES = {
     "opmgpu_get_jacobian_bsr": (C.c_int, [C.c_void_p, _ip, _ip, _dp]),
     "opmgpu_time_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp]),
     "opmgpu_last_timings": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
+    "opmgpu_iteration_marks": (C.c_int, [C.c_void_p, C.c_int]),
+    "opmgpu_iteration_marks_get": (C.c_int, [C.c_void_p, C.c_int, _dp, _ip, _ip, _dp, C.POINTER(C.c_int)]),
     "opmgpu_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "opmgpu_kernel_timing_get": (C.c_int, [C.c_void_p, _dp, C.POINTER(C.c_int64)]),
     "opmgpu_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),

@@ -140,10 +140,12 @@ def make_unique_id():
     return bytes(buf)
 
 
-def build_distributed_model(nx, ny, nz, tables, params, rank, world, local_rank, lognormal_sigma=0.5, seed=12345, perturb=0.002, deck="cart", wells_fn=None):
+def build_distributed_model(nx, ny, nz, tables, params, rank, world, local_rank, lognormal_sigma=0.5, seed=12345, perturb=0.002, deck="cart", wells_fn=None, axis=2):
     """Every rank builds the same global synthetic deck, keeps its slab (+ghosts) and joins the RCCL communicator.
     The unique id travels through torch.distributed (backend nccl = RCCL).  deck = "spe10like": BASELINE configs[3], the 60 x 220 x 85
-    deck with sigma_lnK = 2.5 cut along j (27-28 rows of 60 x 85 cells per GPU at N = 8: strong scaling by construction)."""
+    deck with sigma_lnK = 2.5 cut along j (27-28 rows of 60 x 85 cells per GPU at N = 8: strong scaling by construction).  axis: the
+    direction the Cartesian deck is cut along (2 = slabs of k-layers; 1 = slabs of whole j-rows, which keeps vertical wells on one rank --
+    the strong-scaling leg and the SPE10-like deck carry their wells that way)."""
     import torch
     import torch.distributed as dist
     from . import decks
@@ -155,7 +157,7 @@ def build_distributed_model(nx, ny, nz, tables, params, rank, world, local_rank,
     else:
         grid = decks.cartesian_grid(nx, ny, nz, lognormal_sigma=lognormal_sigma, seed=seed)
         st = decks.initial_state(grid, tables, perturb=perturb, seed=seed)
-        part = slab_partition(grid, world)
+        part = slab_partition(grid, world, axis=axis)
     dom = LocalDomain(grid, part, rank)
     model = GpuBlackoilModel(dom.grid, tables, params, device=local_rank)
     dev = torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else torch.device("cpu")      # gloo: one-GPU rehearsal

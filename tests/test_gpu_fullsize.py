@@ -194,16 +194,23 @@ def _perforated_diag_mask(rowptr, col, cells):
     return (rows == col) & perf[rows]
 
 
-def _lockstep_parity(gpu_lib, oracle, grid, tab, st, dt, wl, niter=2, cpr=1, reduction=1e-10, maxiter=2000, tol_p=1e-6, tol_s=1e-6):
-    """Newton iterations 0..niter-1 of one time step, GPU (device wells, CPR or ILU0, f64 solve) and oracle (+ host well model with
+def _lockstep_parity(gpu_lib, oracle, grid, tab, st, dt, wl, niter=2, cpr=1, reduction=1e-10, maxiter=2000, tol_p=1e-6, tol_s=1e-6,
+                     single=False, gmres=0, oracle_reduction=None, tol_jac=1e-11, tol_op=1e-9):
+    """Newton iterations 0..niter-1 of one time step, GPU (device wells, CPR or ILU0) and oracle (+ host well model with
     the explicit Schur complement) side by side.  Every assembly is compared at rounding level; after every update the two states are
     compared at the linear tolerance and the oracle then CONTINUES FROM THE GPU's state, so the next assembly is again a rounding-level
-    comparison (a free-running comparison is test_*_newton_count below)."""
+    comparison (a free-running comparison is test_*_newton_count below).
+
+    single / gmres select the configuration bench.py TIMES: the Jacobian written as float, the float CPR solve, restarted GMRES(40)
+    (newton_use_gmres) with the true-residual check bench.py runs with; the oracle side stays the f64 reference solve at
+    `oracle_reduction`, the residual (always f64) stays a rounding-level comparison, the float Jacobian / operator are compared at float
+    rounding level (tol_jac / tol_op) and the updated states at the float tolerances of DESIGN.md section 5."""
     from opmgpu import wells as W
     from util import OracleBackend, rel_err
     oracle.set_threads(16)
-    prm_g = capi.default_params(linear_solver_reduction=reduction, linear_solver_maxiter=maxiter, use_cpr=cpr)
-    prm_o = capi.default_params(linear_solver_reduction=reduction, linear_solver_maxiter=4 * maxiter)
+    prm_g = capi.default_params(linear_solver_reduction=reduction, linear_solver_maxiter=maxiter, use_cpr=cpr, newton_use_gmres=gmres,
+                                gmres_verify_residual=1 if gmres == 1 else 0)
+    prm_o = capi.default_params(linear_solver_reduction=oracle_reduction or reduction, linear_solver_maxiter=4 * maxiter)
     nc = grid.nc
     gm = GpuBlackoilModel(grid, tab, prm_g)
     rowptr0, col0 = oracle.pattern(grid)
@@ -220,7 +227,7 @@ def _lockstep_parity(gpu_lib, oracle, grid, tab, st, dt, wl, niter=2, cpr=1, red
     rng = np.random.default_rng(5)
     for it in range(niter):
         # ---- assembly ----
-        gm.setSolvePrecision(False)
+        gm.setSolvePrecision(single)
         gm.assemble(it == 0)
         mo.assemble(it == 0)            # with wells: control switching, reservoir, [connection pressures + well pre-solve], well terms
         val_res = None
@@ -234,16 +241,16 @@ def _lockstep_parity(gpu_lib, oracle, grid, tab, st, dt, wl, niter=2, cpr=1, red
         assert np.array_equal(gr, rowptr0) and np.array_equal(gc, col0)
         assert rel_err(gm.residual(), ob.r) < 1e-11, (it, rel_err(gm.residual(), ob.r))
         if wl is None:
-            assert rel_err(gv, ob.val) < 1e-11, it
+            assert rel_err(gv, ob.val) < tol_jac, it
         else:
             keep = ~diag_perf
-            assert rel_err(gv[keep], val_res[keep]) < 1e-11, it
+            assert rel_err(gv[keep], val_res[keep]) < tol_jac, (it, rel_err(gv[keep], val_res[keep]))
             # the coupled operator (matrix + factored rank-7 Schur complement per well) against the oracle's explicit clique matrix
             for _ in range(2):
                 x3 = rng.standard_normal(3 * nc) * np.tile([1e5, 1e-2, 1e-2], nc)
                 yo = oracle.spmv(ob.rowptr, ob.col, ob.val, x3)
                 yg = gm.spmv(x3)
-                assert rel_err(yg, yo) < 1e-9, (it, rel_err(yg, yo))
+                assert rel_err(yg, yo) < tol_op, (it, rel_err(yg, yo))
         del gv, val_res
         # ---- convergence scalars ----
         cg = gm.getConvergence(); co = ob.getConvergence()
@@ -254,7 +261,8 @@ def _lockstep_parity(gpu_lib, oracle, grid, tab, st, dt, wl, niter=2, cpr=1, red
             assert md.well_ctrl_residual == pytest.approx(mo.wh.well_ctrl_residual, rel=1e-7, abs=1e-14)
         assert cg == co
         # ---- solve + update ----
-        gm.solveJacobianSystem(single_precision=False)
+        gm.solveJacobianSystem(single_precision=single)
+        assert gm.linear_reduction <= reduction, (it, gm.linear_reduction)        # with gmres_verify_residual: the TRUE residual's reduction
         gm.updateState()
         ob.solveJacobianSystem(single_precision=False)
         if wl is not None:
@@ -264,12 +272,13 @@ def _lockstep_parity(gpu_lib, oracle, grid, tab, st, dt, wl, niter=2, cpr=1, red
         assert np.array_equal(a.hc, b.hc), it
         assert np.abs(a.p - b.p).max() <= tol_p * np.abs(b.p).max(), (it, np.abs(a.p - b.p).max() / np.abs(b.p).max())
         assert np.abs(a.sat - b.sat).max() <= tol_s, (it, np.abs(a.sat - b.sat).max())
-        assert np.abs(a.rs - b.rs).max() <= 1e-5 * max(np.abs(b.rs).max(), 1.0) and np.abs(a.rv - b.rv).max() <= 1e-5 * max(np.abs(b.rv).max(), 1e-3)
+        tol_r = max(1e-5, tol_s)
+        assert np.abs(a.rs - b.rs).max() <= tol_r * max(np.abs(b.rs).max(), 1.0) and np.abs(a.rv - b.rv).max() <= tol_r * max(np.abs(b.rv).max(), 1e-3)
         ob.st = a.copy()                                 # lockstep: the oracle continues from the device state
         if wl is not None:
             ws = md.pull_well_state()
-            assert np.allclose(ws.bhp, mo.ws.bhp, rtol=1e-6), (it, ws.bhp, mo.ws.bhp)
-            assert np.allclose(ws.qs, mo.ws.qs, rtol=1e-5, atol=1e-8 * np.abs(mo.ws.qs).max()), it
+            assert np.allclose(ws.bhp, mo.ws.bhp, rtol=max(1e-6, tol_p)), (it, ws.bhp, mo.ws.bhp)
+            assert np.allclose(ws.qs, mo.ws.qs, rtol=max(1e-5, 10 * tol_p), atol=max(1e-8, tol_p) * np.abs(mo.ws.qs).max()), it
             mo.ws.assign(ws)
     gm.close()
 
@@ -331,7 +340,7 @@ def _spin_up(grid, tab, st, wl, dt, nsteps=2):
     return out, ws
 
 
-def _check_newton_count(gpu_lib, oracle, grid, tab, st, dt, wl, solvers=(0, 1), reduction=1e-6, spin_up=2):
+def _check_newton_count(gpu_lib, oracle, grid, tab, st, dt, wl, solvers=(0, 1), reduction=1e-6, spin_up=2, oracle_gmres=True):
     """One whole time step with the reference's NonlinearSolver (update stabilisation on) and the reference's Newton tolerances
     (MB 1e-5, CNV 1e-2, wells 1e-4 / 1e-7), free-running on both sides from the same spun-up state.  The linear solves are double
     precision to a 1e-6 reduction on BOTH sides: at the default 1e-2 an inexact-Newton path depends on the preconditioner (measured:
@@ -343,20 +352,33 @@ def _check_newton_count(gpu_lib, oracle, grid, tab, st, dt, wl, solvers=(0, 1), 
     oracle.set_threads(16)
     st1, ws1 = _spin_up(grid, tab, st, wl, dt, spin_up) if spin_up else (st, None)
     lin = dict(linear_solver_reduction=reduction, linear_solver_maxiter=3000)
-    ob = OracleBackend(oracle, grid, tab, capi.default_params(**lin), wells=None if wl is None else wl.arrays())
-    if wl is None:
-        mo = _OracleModel(ob)
-    else:
-        wso = W.WellState(wl, st1.p)
-        if ws1 is not None:
-            wso.assign(ws1)
-        mo = W.WellCoupledModel(ob, W.StandardWellsHost(wl, grid.z, tab.surface_density[0]), wso)
-    n_oracle = _run_time_step(mo, dt, st1, False, NonlinearSolver())
-    b = ob.getState()
-    assert n_oracle <= 15, n_oracle
+
+    def oracle_step(gmres):
+        """the oracle's time step with ITS restatement of the same Krylov method (BiCGStab, or Dune::RestartedGMResSolver: oracle.cpp gmres_t)"""
+        ob = OracleBackend(oracle, grid, tab, capi.default_params(newton_use_gmres=gmres, **lin), wells=None if wl is None else wl.arrays())
+        if wl is None:
+            mo = _OracleModel(ob)
+        else:
+            wso = W.WellState(wl, st1.p)
+            if ws1 is not None:
+                wso.assign(ws1)
+            mo = W.WellCoupledModel(ob, W.StandardWellsHost(wl, grid.z, tab.surface_density[0]), wso)
+        n = _run_time_step(mo, dt, st1, False, NonlinearSolver())
+        assert n <= 15, n
+        return n, ob.getState()
+
+    oracle_runs = {}
     for code in solvers:          # bit 0: CPR instead of ILU0; bit 1: restarted GMRES instead of BiCGStab (newton_use_gmres)
         cpr = code & 1
-        gm = GpuBlackoilModel(grid, tab, capi.default_params(use_cpr=cpr, newton_use_gmres=code >> 1, **lin))
+        gmres = code >> 1
+        okey = gmres if oracle_gmres else 0
+        if okey not in oracle_runs:
+            oracle_runs[okey] = oracle_step(okey)
+        n_oracle, b = oracle_runs[okey]
+        # device GMRES against the oracle's GMRES: both stop on their preconditioned residual like dune's.  Where the oracle's
+        # ILU0-preconditioned GMRES(40) is not affordable (1 M cells), the device checks the TRUE residual (gmres_verify_residual, as
+        # bench.py runs it), which is the statement the oracle's BiCGStab makes -- the same 1e-4 state tolerance in both cases.
+        gm = GpuBlackoilModel(grid, tab, capi.default_params(use_cpr=cpr, newton_use_gmres=gmres, gmres_verify_residual=int(gmres == 1 and not oracle_gmres), **lin))
         if wl is None:
             md = gm
         else:
@@ -369,10 +391,8 @@ def _check_newton_count(gpu_lib, oracle, grid, tab, st, dt, wl, solvers=(0, 1), 
         gm.close()
         assert n_gpu == n_oracle, (code, n_gpu, n_oracle)
         assert np.array_equal(a.hc, b.hc)
-        # left-preconditioned GMRES stops on the PRECONDITIONED residual (as dune's does): its 1e-6 is a looser statement about the true
-        # residual than BiCGStab's, so the converged states sit further from the oracle's (BiCGStab) ones
-        tol = 1e-3 if code >> 1 else 1e-4
-        assert np.abs(a.p - b.p).max() <= tol * np.abs(b.p).max() and np.abs(a.sat - b.sat).max() <= tol, code
+        tol = 1e-4
+        assert np.abs(a.p - b.p).max() <= tol * np.abs(b.p).max() and np.abs(a.sat - b.sat).max() <= tol, (code, np.abs(a.p - b.p).max() / np.abs(b.p).max(), np.abs(a.sat - b.sat).max())
 
 
 def _cart100(rate=1000.0, perturb=0.002):
@@ -417,9 +437,27 @@ def _spe9_like():
                                          inj_rate_m3_per_day=800.0, prod_bhp_bar=150.0, prod_oil_rate_m3_per_day=60.0)
 
 
+def _cart60():
+    """the bench deck's recipe at 60^3 = 216 k cells: the size at which the ORACLE's ILU0-preconditioned GMRES(40) is still affordable (at 1 M
+    cells one 1e-6 solve takes it 211 iterations / 50 s on 8 cores), so that device GMRES and oracle GMRES can run whole time steps side by side"""
+    grid = decks.cartesian_grid(60, 60, 60, lognormal_sigma=0.5, seed=12345)
+    tab = decks.satfunc_standard_tables()
+    st = decks.initial_state(grid, tab, perturb=0.002, seed=12345)
+    from opmgpu import wells as W
+    return grid, tab, st, W.five_spot(grid, rate_m3_per_day=300.0, bhp_prod_bar=150.0)
+
+
 DECKS = {"cart100": (_cart100, 5.0), "spe10like": (_spe10_like, 2.0), "nornelike": (_norne_like, 3.0), "spe9like": (_spe9_like, 3.0)}
+COUNT_DECKS = dict(DECKS, cart60=(_cart60, 5.0))
 LOCKSTEP_KW = {"spe10like": dict(reduction=1e-8, tol_p=1e-5, tol_s=1e-5)}        # sigma_lnK = 2.5: a 1e-10 reduction is below what BiCGStab attains in f64
-COUNT_KW = {"cart100": dict(solvers=(1, 3)), "spe10like": dict(solvers=(1,)), "nornelike": dict(spin_up=0, solvers=(0, 1, 3)), "spe9like": dict(spin_up=0, solvers=(0, 1, 2, 3))}     # multicolour ILU0 alone needs ~1000 iterations for 1e-6 at 1 M cells
+# the configuration bench.py times (VERDICT r2 item 1): float Jacobian + float CPR solve + GMRES(40) + device wells.  A float solve attains
+# ~1e-5 on the true residual; the state tolerances are DESIGN section 5's float ones (p 2e-5 relative, s 2e-5 absolute)
+TIMED_KW = {"cart100": dict(single=True, gmres=1, reduction=1e-5, oracle_reduction=1e-10, maxiter=200, tol_p=2e-5, tol_s=2e-5, tol_jac=5e-7, tol_op=2e-5),
+            "spe10like": dict(single=True, gmres=1, reduction=1e-5, oracle_reduction=1e-8, maxiter=200, tol_p=2e-5, tol_s=2e-5, tol_jac=5e-7, tol_op=2e-5)}
+# solvers: bit 0 = CPR, bit 1 = GMRES.  Multicolour ILU0 alone needs ~1000 iterations for 1e-6 at 1 M cells.  GMRES legs run against the
+# oracle's own GMRES restatement, except at 1 M cells (cart100: too slow on the host, see _cart60) where the device verifies the true residual
+COUNT_KW = {"cart100": dict(solvers=(1, 3), oracle_gmres=False), "cart60": dict(solvers=(1, 3)), "spe10like": dict(solvers=(1,)),
+            "nornelike": dict(spin_up=0, solvers=(0, 1, 3)), "spe9like": dict(spin_up=0, solvers=(0, 1, 2, 3))}
 
 
 @pytest.mark.parametrize("name", list(DECKS))
@@ -429,8 +467,16 @@ def test_fullsize_lockstep_parity(gpu_lib, oracle, name):
     _lockstep_parity(gpu_lib, oracle, grid, tab, st, dt_days * decks.DAY, wl, **LOCKSTEP_KW.get(name, {}))
 
 
-@pytest.mark.parametrize("name", list(DECKS))
-def test_fullsize_newton_count(gpu_lib, oracle, name):
+@pytest.mark.parametrize("name", list(TIMED_KW))
+def test_fullsize_lockstep_parity_of_the_timed_configuration(gpu_lib, oracle, name):
+    """float Jacobian + float CPR + GMRES(40) + device wells -- what bench.py's headline number runs -- in lockstep with the oracle"""
     make, dt_days = DECKS[name]
+    grid, tab, st, wl = make()
+    _lockstep_parity(gpu_lib, oracle, grid, tab, st, dt_days * decks.DAY, wl, **TIMED_KW[name])
+
+
+@pytest.mark.parametrize("name", list(COUNT_DECKS))
+def test_fullsize_newton_count(gpu_lib, oracle, name):
+    make, dt_days = COUNT_DECKS[name]
     grid, tab, st, wl = make()
     _check_newton_count(gpu_lib, oracle, grid, tab, st, dt_days * decks.DAY, wl, **COUNT_KW.get(name, {}))

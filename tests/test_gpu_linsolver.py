@@ -322,6 +322,44 @@ def test_flexible_gmres_stops_on_the_true_residual(gpu_lib, oracle, single):
     s.close()
 
 
+@pytest.mark.parametrize("single", [False, True])
+def test_gmres_true_residual_check(gpu_lib, oracle, single):
+    """opmgpu_params.gmres_verify_residual: Dune's left-preconditioned GMRES stops on ||M^-1 (b - A x)||; with the check the solve is only
+    reported converged when ||b - A x|| <= reduction ||b|| holds as well (the statement the reference's default BiCGStab makes), the
+    iteration continuing from the true defect otherwise, and the reported reduction is the true one.  Without the check the same solver
+    leaves a larger true residual on the heterogeneous deck (which is what chopped a time step of the 200^3 bench deck in round 2)."""
+    grid = decks.cartesian_grid(12, 22, 17, dx=6.096, dy=3.048, dz=0.6096, tops=3657.6, lognormal_sigma=2.5, seed=10)
+    tab = decks.satfunc_standard_tables()
+    st = decks.initial_state(grid, tab, p_ref=413.0 * decks.BAR, z_ref=3657.6, perturb=0.005, seed=10)
+    prm0 = capi.default_params()
+    scale = np.asarray(prm0.matbalscale[:])
+    rowptr, col = oracle.pattern(grid)
+    nc = grid.nc
+    r, val, _, _ = oracle.assemble(grid, tab, 2 * decks.DAY, st, rowptr, col, scale=tuple(scale))
+    b = np.ascontiguousarray((r * np.repeat(scale, nc)).reshape(3, nc).T).ravel()
+    A = bsr_to_scipy(rowptr, col, val)
+    red = 1e-4 if single else 1e-6
+    slack = 3.0 if single else 1.0 + 1e-6            # float: x is rounded to 24 bits after the check measured it in the solve's precision
+    true_res = {}
+    for kw in (dict(), dict(use_cpr=1), dict(linear_solver_restart=6)):
+        for verify in (0, 1):
+            s = GpuNewtonIteration(capi.default_params(newton_use_gmres=1, gmres_verify_residual=verify, linear_solver_reduction=red, linear_solver_maxiter=600, **kw))
+            x = s.computeNewtonIncrement(rowptr, col, val, b, single)
+            true_res[verify] = np.linalg.norm(b - A @ x) / np.linalg.norm(b)
+            assert s.reduction < red
+            if verify:
+                assert true_res[1] <= slack * red, (kw, true_res)
+                assert s.reduction == pytest.approx(true_res[1], rel=0.5 if single else 1e-3), kw      # the reported number IS the true reduction
+            its = s.iterations()
+            s.close()
+        assert true_res[1] <= true_res[0] * (1 + 1e-6), (kw, true_res)
+    # a right-hand side of zero is converged at once with or without the check
+    s = GpuNewtonIteration(capi.default_params(newton_use_gmres=1, gmres_verify_residual=1))
+    x = s.computeNewtonIncrement(rowptr, col, val, np.zeros_like(b), single)
+    assert np.all(x == 0) and s.iterations() == 0
+    s.close()
+
+
 def test_global_coarse_space_restores_convergence_of_decomposed_preconditioner(gpu_lib, monkeypatch):
     """The CPR pressure stage's global coarse space (one unknown per subdomain).  OPMGPU_EMULATE_RANKS builds the preconditioner
     as a 4-rank run would (no coupling across the cuts in the ILU0's and the AMG's matrix): without the coarse space the

@@ -217,6 +217,34 @@ def test_device_well_controls_match_host(gpu_lib, oracle, case, cpr):
     gm.close()
 
 
+@pytest.mark.parametrize("case", ["presolve_switch", "prod_rate_limit", "thp"])
+def test_well_presolve_forms_agree(gpu_lib, monkeypatch, case):
+    """solveWellEq on the device in its three forms -- one fused launch with a counter barrier per iteration (default), two launches per
+    iteration (OPMGPU_WELL_PRESOLVE_FUSED=0) and the single-workgroup fallback that takes over when the fused kernel's barrier gives up
+    (forced by OPMGPU_WELL_PRESOLVE_FUSED=2; ADVICE r2: a scheduling condition must not surface as a NumericalIssue) -- must give the same
+    pre-solve iteration count, the same control switches and the same well state, bit for bit."""
+    from test_wells_host import _limits_setup
+    kw = {"presolve_switch": dict(inj_bhp_limit_bar=255.0), "prod_rate_limit": dict(inj_bhp_limit_bar=600.0, prod_rate_limit=150.0),
+          "thp": dict(inj_bhp_limit_bar=600.0, thp=True)}[case]
+    grid, tab, st, wl, tables = _limits_setup(**kw)
+    out = {}
+    for mode in ("1", "0", "2"):
+        monkeypatch.setenv("OPMGPU_WELL_PRESOLVE_FUSED", mode)
+        gm = GpuBlackoilModel(grid, tab, capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=500))
+        md = W.DeviceWellModel(gm, wl, W.WellState(wl, st.p), vfp_tables=tables)
+        md.prepareStep(5 * decks.DAY, st)
+        conv, _ = md.nonlinearIteration(0, single_precision=False)
+        ws = md.pull_well_state()
+        assert md.presolve_converged and md.presolve_iterations >= 1
+        out[mode] = (md.presolve_iterations, ws.current.copy(), ws.bhp.copy(), ws.qs.copy(), ws.thp.copy(), gm.getState())
+        gm.close()
+    for mode in ("0", "2"):
+        a, b = out["1"], out[mode]
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]), (mode, a[0], b[0])
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]), mode
+        assert np.array_equal(a[5].p, b[5].p) and np.array_equal(a[5].sat, b[5].sat), mode
+
+
 def test_stabilized_update_relaxes_the_well_increment_too(gpu_lib, oracle):
     """NonlinearSolver::stabilizeNonlinearUpdate acts on the WHOLE increment (NonlinearSolver_impl.hpp:260-301): with device wells the
     recovered (q_s, bhp) increment is relaxed with the reservoir part -- device vs host well model with a forced relaxation of 0.6."""
