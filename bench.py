@@ -109,7 +109,9 @@ def parse_args(argv):
                     help="gmres: the reference's newton_use_gmres option (restarted GMRES(40), left-preconditioned).  auto: gmres under CPR on the deck with "
                          "wells (3.75 preconditioner applications per Newton iteration against BiCGStab's 4.1 iterations = 9.5 applications), bicgstab "
                          "otherwise -- the other method runs as a same-run variant; fgmres: the flexible (right-preconditioned) form, not a reference solver")
-    ap.add_argument("--no-verify", action="store_true", help="GMRES without the true-residual check (opmgpu_params.gmres_verify_residual = 0: exactly dune's stopping rule)")
+    ap.add_argument("--verify", action="store_true",
+                    help="GMRES with the true-residual check (opmgpu_params.gmres_verify_residual = 1; not a reference option).  Default: exactly dune's stopping rule, the "
+                         "PRECONDITIONED residual -- what the reference's newton_use_gmres does; the check runs as the variant cpr_f64_gmres_verified*")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N > 1: weak = every GPU keeps an nx x ny x nz slab with its own 5-spot (global deck nx x ny x nz*N); strong = the fixed nx x ny x nz deck "
                          "is cut into N slabs along j, which keeps its vertical wells whole")
@@ -178,9 +180,9 @@ def main(argv=None):
     use_wells = args.wells == "fivespot"
     if args.krylov == "auto":
         args.krylov = "gmres" if (use_wells and args.solver == "cpr") else "bicgstab"
-    verify = 0 if args.no_verify else 1
+    verify = 1 if args.verify else 0
 
-    def make_params(solver=args.solver, krylov=args.krylov):
+    def make_params(solver=args.solver, krylov=args.krylov, verify=verify):
         return capi.default_params(ilu_ordering=ordering, use_cpr=int(solver == "cpr"), newton_use_gmres={"gmres": 1, "fgmres": 2}.get(krylov, 0),
                                    gmres_verify_residual=verify if krylov == "gmres" else 0)
 
@@ -350,8 +352,8 @@ def main(argv=None):
     variants = {}
     wtag = "_with_wells" if use_wells else ""
     if extras:
-        def variant(name, solver, krylov, dt, single, wells_on=use_wells, note=None):
-            m = GpuBlackoilModel(grid, tab, make_params(solver, krylov), device=local_rank)
+        def variant(name, solver, krylov, dt, single, wells_on=use_wells, note=None, verify=verify):
+            m = GpuBlackoilModel(grid, tab, make_params(solver, krylov, verify), device=local_rank)
             try:
                 variants[name] = summary(timed_run(m, wells_on, dt, single), dt, single, note)
             except Exception as e:          # e.g. a Krylov method running out of iterations: say so instead of dying
@@ -365,6 +367,10 @@ def main(argv=None):
             other = "bicgstab" if args.krylov != "bicgstab" else "gmres"
             variant("cpr_f64_%s%s" % (other, wtag), "cpr", other, dt_main, False,
                     note="solver_approach=cpr in the reference's own arithmetic (double) with its %s Krylov method" % ("default" if other == "bicgstab" else "newton_use_gmres"))
+            if args.krylov == "gmres":
+                variant("cpr_f64_gmres_verified%s" % wtag, "cpr", "gmres", dt_main, False, verify=1 - verify,
+                        note="the same solver %s the true-residual check (gmres_verify_residual): the solve is converged only when || b - A x || <= reduction || b || "
+                             "too -- BiCGStab's statement; left-preconditioned GMRES by itself stops on || M^-1 (b - A x) ||" % ("WITH" if not verify else "WITHOUT"))
             variant("cpr_f32_%s%s" % (args.krylov, wtag), "cpr", args.krylov, dt_main, True,
                     note="NOT a configuration the reference can run (its CPR plug-in is double-only, NewtonIterationBlackoilCPR.cpp:117-140): round 2's headline, kept for continuity")
         if use_wells:

@@ -340,8 +340,10 @@ int opmgpu_relative_change(opmgpu_ctx* ctx, double* value);
  *   values    [nregions][7]: water, oil, gas, dissolved gas, vaporised oil, pore volume, weighted pressure (SimulatorData::FipId,
  *             BlackoilModelEnums.hpp:53-61)
  *   fip_cells [7][nc] or NULL: the per-cell arrays of SimulatorData::fip (getFIPData()), caller's cell order
- * The per-cell evaluation runs on the device, the region loops on the host in the reference's cell order.  Not in decomposed runs
- * (OPMGPU_EINVAL). */
+ * The per-cell evaluation runs on the device, the region loops on the host in the reference's cell order.  Decomposed runs (the
+ * reference's parallel branch, :2369-2446): a COLLECTIVE call; every rank passes the fipnum of its local cells (ghost cells included --
+ * only owned cells are counted) and the GLOBAL number of regions, the sums are taken over the owned cells and all-reduced, every rank
+ * receives the global values (fip_cells: this rank's cells, zeros in the pv / weighted-pressure rows of its ghosts). */
 int opmgpu_compute_fluid_in_place(opmgpu_ctx* ctx, const int32_t* fipnum, int nregions, double* fip_cells, double* values);
 
 /* Maximum historical oil saturation per cell (BlackoilPropsAdFromDeck::satOilMax_, used by VAPPARS).

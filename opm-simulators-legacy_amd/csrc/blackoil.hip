@@ -2,17 +2,21 @@
 //
 // Two kernels per assembly, both one-thread-per-cell over the solver's internal (level-major)
 // numbering so that every per-cell plane access of a wavefront is one contiguous segment:
-//   k_cell_props : state -> PVT / relperm / pc with d/d(P,Sw,Xvar); writes the 37 "face input"
-//                  planes, the accumulation part of the residual and of the diagonal block.
-//   k_flux       : per row, walks the row's SELL slots; for every connection recomputes the TPFA
-//                  flux from both cells' planes (each face is evaluated from both sides: 2x the
-//                  flops, zero atomics, each Jacobian block written exactly once, coalesced).
+//   k_cell_values   : state -> PVT / relperm / pc VALUES; writes the ten value planes a cell's
+//                     neighbours need of it (phase pressures, densities, b * mobility, rs, rv).
+//   k_assemble_rows : per row: eval_cell again for the row's OWN derivatives, accumulation term,
+//                     then the row's SELL slots: every connection's TPFA flux from the neighbour's
+//                     values, its derivative with respect to the row's own variables into the
+//                     row's diagonal block and, negated, into the TRANSPOSED entry (neighbour, row)
+//                     (each face is evaluated from both sides: 2x the flops, zero atomics, each
+//                     Jacobian block written exactly once).
 // Algorithmic HBM bytes per cell are given in DESIGN.md; the Jacobian write dominates.
 #include "blackoil.hpp"
 
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <limits>
 
 namespace opmgpu {
 
@@ -187,6 +191,98 @@ __device__ __forceinline__ void rocktab_eval(const double* __restrict__ x, const
     f = y[i] + df * (xv - x[i]);
 }
 
+// Device-internal companions of the tables: the slope (y[i+1] - y[i]) / (x[i+1] - x[i]) of every segment of every 1-D table, formed once
+// on the host by the same IEEE division the kernels used to repeat per cell and per table (an f64 division is ~12 quarter-rate-class
+// instructions on gfx950 and eval_cell made ~50 of them; it runs twice per cell and assembly now, and it is VALU-bound: 3 800 static
+// instructions in its value-only form).  Arrays are as long as their table (the last entry of a table is unused).
+// (struct TabX / DevTables: blackoil.hpp)
+
+// The hot kernels take the tables with every pointer field holding a WORD OFFSET into the blob and resolve them here against the blob's
+// copy in LDS (LDS = true: the workgroup stages it first) or against the blob itself.  With the base a compile-time choice every table
+// access of the LDS instantiation is a ds_read at a 32-bit offset (the round-2 form rebased generic pointers at run time: flat loads
+// with 64-bit address arithmetic, 284 v_lshl_add_u64 in the value-only kernel).
+template <bool LDS>
+__device__ __forceinline__ void resolve_tables(DevTables& D, const double* __restrict__ blob, int words, double* lds)
+{
+    const double* base = blob;
+    if constexpr (LDS) {
+        for (int i = threadIdx.x; i < words; i += blockDim.x) lds[i] = blob[i];
+        __syncthreads();
+        base = lds;
+    }
+    auto rd = [&](const double*& p) { p = base + reinterpret_cast<size_t>(p); };
+    auto ri = [&](const int32_t*& p) { p = reinterpret_cast<const int32_t*>(base + reinterpret_cast<size_t>(p)); };
+    opmgpu_tables& T = D.t; TabX& X = D.x;
+    rd(T.surface_density); rd(T.pvtw);
+    ri(T.oil_node_ptr); rd(T.oil_rs); rd(T.oil_psat); rd(T.oil_invb_sat); rd(T.oil_invbmu_sat);
+    ri(T.oil_col_ptr); rd(T.oil_col_p); rd(T.oil_col_invb); rd(T.oil_col_invbmu);
+    ri(T.gas_node_ptr); rd(T.gas_pg); rd(T.gas_rvsat); rd(T.gas_invb_sat); rd(T.gas_invbmu_sat);
+    ri(T.gas_col_ptr); rd(T.gas_col_rv); rd(T.gas_col_invb); rd(T.gas_col_invbmu);
+    ri(T.swof_ptr); rd(T.swof_sw); rd(T.swof_krw); rd(T.swof_krow); rd(T.swof_pcow);
+    ri(T.sgof_ptr); rd(T.sgof_sg); rd(T.sgof_krg); rd(T.sgof_krog); rd(T.sgof_pcgo);
+    rd(T.rocktab_p); rd(T.rocktab_pvmult); rd(T.rocktab_transmult);
+    rd(X.swof_dkrw); rd(X.swof_dkrow); rd(X.swof_dpcow); rd(X.sgof_dkrg); rd(X.sgof_dkrog); rd(X.sgof_dpcgo);
+    rd(X.oil_drs); rd(X.oil_dinvb_sat); rd(X.oil_dinvbmu_sat); rd(X.oil_col_dinvb); rd(X.oil_col_dinvbmu);
+    rd(X.gas_drvsat); rd(X.gas_dinvb_sat); rd(X.gas_dinvbmu_sat); rd(X.gas_col_dinvb); rd(X.gas_col_dinvbmu);
+}
+
+// saturation table with the segment's slope tabulated: the segment search (sat_eval's rule) and the evaluation are separate so that
+// curves over the same abscissa share one search.  clamp: -1 / +1 = constant extrapolation below / above the table.
+template <bool RIGHT>
+__device__ __forceinline__ int sat_seg(const double* __restrict__ x, int n, double xv, int& clamp)
+{
+    clamp = (xv <= x[0]) ? -1 : ((xv >= x[n - 1]) ? 1 : 0);
+    int i = 0;
+    for (int k = 1; k < n - 1; ++k) i += (RIGHT ? (x[k] <= xv) : (x[k] < xv)) ? 1 : 0;
+    return i;
+}
+__device__ __forceinline__ void sat_at(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ dy, int n, int i, int clamp, double xv,
+                                       double& f, double& df)
+{
+    if (clamp < 0) { f = y[0]; df = 0.0; return; }
+    if (clamp > 0) { f = y[n - 1]; df = 0.0; return; }
+    df = dy[i];
+    f = y[i] + df * (xv - x[i]);
+}
+template <bool RIGHT>
+__device__ __forceinline__ void sat_curve_s(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ dy, int n, double sv, const EpsD& e, int c,
+                                            double& f, double& df)
+{
+    int cl;
+    if (!e.on) { const int i = sat_seg<RIGHT>(x, n, sv, cl); sat_at(x, y, dy, n, i, cl, sv, f, df); return; }
+    double slope;
+    const double su = eps_map(e, c, sv, slope);
+    const int i = sat_seg<RIGHT>(x, n, su, cl);
+    sat_at(x, y, dy, n, i, cl, su, f, df);
+    f *= e.v[c]; df *= slope * e.v[c];
+}
+__device__ __forceinline__ void lin_at(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ dy, int i, double xv, double& f, double& df)
+{
+    df = dy[i];
+    f = y[i] + df * (xv - x[i]);
+}
+// UniformXTabulated2DFunction::eval for TWO functions over the same columns (1/B and 1/(B mu)): node segment i given, column searches shared
+__device__ __forceinline__ void pvt2_pair(const double* __restrict__ xs, int i, const int32_t* __restrict__ cp, const double* __restrict__ cy,
+                                          const double* __restrict__ cv1, const double* __restrict__ dcv1, const double* __restrict__ cv2, const double* __restrict__ dcv2,
+                                          double xv, double yv, double& f1, double& dfx1, double& dfy1, double& f2, double& dfx2, double& dfy2)
+{
+    const double ih = 1.0 / (xs[i + 1] - xs[i]);
+    const double alpha = (xv - xs[i]) * ih, oma = 1.0 - alpha;
+    const int c0 = cp[i], c1 = cp[i + 1];
+    const int j0 = pvt_seg(cy + c0, c1 - c0, yv), j1 = pvt_seg(cy + c1, cp[i + 2] - c1, yv);
+    double s1, d1, s2, d2;
+    lin_at(cy + c0, cv1 + c0, dcv1 + c0, j0, yv, s1, d1); lin_at(cy + c1, cv1 + c1, dcv1 + c1, j1, yv, s2, d2);
+    f1 = s1 * oma + s2 * alpha; dfx1 = (s2 - s1) * ih; dfy1 = d1 * oma + d2 * alpha;
+    lin_at(cy + c0, cv2 + c0, dcv2 + c0, j0, yv, s1, d1); lin_at(cy + c1, cv2 + c1, dcv2 + c1, j1, yv, s2, d2);
+    f2 = s1 * oma + s2 * alpha; dfx2 = (s2 - s1) * ih; dfy2 = d1 * oma + d2 * alpha;
+}
+// a / b with ONE division (the reciprocal), value and derivatives
+__device__ __forceinline__ V4 vdiv1(const V4& a, const V4& b)
+{
+    const double ib = 1.0 / b.v, q = a.v * ib;
+    return mk(q, (a.p - q * b.p) * ib, (a.w - q * b.w) * ib, (a.x - q * b.x) * ib);
+}
+
 struct CellEval {
     V4 pw, pg, rs, rv, sw, so, sg;
     V4 b[3], mob[3], rho[3], accum[3];
@@ -194,16 +290,17 @@ struct CellEval {
 };
 
 // SolutionState + ReservoirResidualQuant of one cell (BlackoilModelBase_impl.hpp:614-751, 1484-1497, 2009-2027)
-__device__ void eval_cell(const opmgpu_tables& T, const EpsD& E, double so_max, int preg, int sreg, double p, double sw_, double sg_, double rs_, double rv_, int hc,
+__device__ void eval_cell(const DevTables& DT, const EpsD& E, double so_max, int preg, int sreg, double p, double sw_, double sg_, double rs_, double rv_, int hc,
                           CellEval& q, const HystD& H = HystD{ false, 0, 2.0, 2.0, 0.0, 0.0 }, const EpsD* EI = nullptr)
 {
+    const opmgpu_tables& T = DT.t; const TabX& X = DT.x;
     const bool isSg = hc == OPMGPU_HC_GAS_AND_OIL, isRs = hc == OPMGPU_HC_OIL_ONLY, isRv = hc == OPMGPU_HC_GAS_ONLY;
     const bool freeOil = isSg || isRs, freeGas = isSg || isRv;
     const V4 P = mk(p, 1, 0, 0), W = mk(sw_, 0, 1, 0);
-    const V4 X = mk(isRs ? rs_ : (isRv ? rv_ : sg_), 0, 0, 1);
+    const V4 Xv = mk(isRs ? rs_ : (isRv ? rv_ : sg_), 0, 0, 1);
     // sg = isSg*X + isRv*(1 - W);  so = 1 - W - sg
     V4 sg = mk(0, 0, 0, 0);
-    if (isSg) sg = X;
+    if (isSg) sg = Xv;
     else if (isRv) sg = mk(1.0 - sw_, 0, -1, 0);
     const V4 so = mk((1.0 - sw_) - sg.v, 0, -1.0 - sg.w, -sg.x);
     q.sw = W; q.so = so; q.sg = sg;
@@ -212,17 +309,34 @@ __device__ void eval_cell(const opmgpu_tables& T, const EpsD& E, double so_max, 
     const int ga = T.sgof_ptr[sreg], ng = T.sgof_ptr[sreg + 1] - ga;
     const double* xsw = T.swof_sw + wa; const double* xsg = T.sgof_sg + ga;
     double f, df;
-    sat_curve<false>(xsw, T.swof_pcow + wa, nw, sw_, E, EC_PCOW, f, df);
-    q.pw = mk(p - f, 1, -df, 0);
-    sat_curve<true>(xsg, T.sgof_pcgo + ga, ng, sg.v, E, EC_PCGO, f, df);
-    q.pg = mk(p + f, 1, df * sg.w, df * sg.x);
-    sat_curve<false>(xsw, T.swof_krw + wa, nw, sw_, E, EC_KRW, f, df);
-    const V4 krw = mk(f, 0, df, 0);
-    if (H.on && (1.0 - sg.v) > H.mdc_go) {       // gas on its (shifted) imbibition curve: krn_imb(Sw + delta) = krg_imb(Sg - delta)
+    V4 krw, krg;
+    const bool gas_imb = H.on && (1.0 - sg.v) > H.mdc_go;        // gas on its (shifted) imbibition curve: krn_imb(Sw + delta) = krg_imb(Sg - delta)
+    if (!E.on) {
+        // no end-point scaling: pcow and krw share the segment of Sw, pcgo and krg the segment of Sg
+        int cw, cg;
+        const int iw = sat_seg<false>(xsw, nw, sw_, cw);
+        sat_at(xsw, T.swof_pcow + wa, X.swof_dpcow + wa, nw, iw, cw, sw_, f, df);
+        q.pw = mk(p - f, 1, -df, 0);
+        sat_at(xsw, T.swof_krw + wa, X.swof_dkrw + wa, nw, iw, cw, sw_, f, df);
+        krw = mk(f, 0, df, 0);
+        const int ig = sat_seg<true>(xsg, ng, sg.v, cg);
+        sat_at(xsg, T.sgof_pcgo + ga, X.sgof_dpcgo + ga, ng, ig, cg, sg.v, f, df);
+        q.pg = mk(p + f, 1, df * sg.w, df * sg.x);
+        if (!gas_imb) { sat_at(xsg, T.sgof_krg + ga, X.sgof_dkrg + ga, ng, ig, cg, sg.v, f, df); krg = vchain(f, df, sg); }
+    } else {
+        sat_curve_s<false>(xsw, T.swof_pcow + wa, X.swof_dpcow + wa, nw, sw_, E, EC_PCOW, f, df);
+        q.pw = mk(p - f, 1, -df, 0);
+        sat_curve_s<true>(xsg, T.sgof_pcgo + ga, X.sgof_dpcgo + ga, ng, sg.v, E, EC_PCGO, f, df);
+        q.pg = mk(p + f, 1, df * sg.w, df * sg.x);
+        sat_curve_s<false>(xsw, T.swof_krw + wa, X.swof_dkrw + wa, nw, sw_, E, EC_KRW, f, df);
+        krw = mk(f, 0, df, 0);
+        if (!gas_imb) { sat_curve_s<true>(xsg, T.sgof_krg + ga, X.sgof_dkrg + ga, ng, sg.v, E, EC_KRG, f, df); krg = vchain(f, df, sg); }
+    }
+    if (gas_imb) {
         const int gi = T.sgof_ptr[H.ireg];
-        sat_curve<true>(T.sgof_sg + gi, T.sgof_krg + gi, T.sgof_ptr[H.ireg + 1] - gi, sg.v - H.d_go, *EI, EC_KRG, f, df);
-    } else sat_curve<true>(xsg, T.sgof_krg + ga, ng, sg.v, E, EC_KRG, f, df);
-    const V4 krg = vchain(f, df, sg);
+        sat_curve_s<true>(T.sgof_sg + gi, T.sgof_krg + gi, X.sgof_dkrg + gi, T.sgof_ptr[H.ireg + 1] - gi, sg.v - H.d_go, *EI, EC_KRG, f, df);
+        krg = vchain(f, df, sg);
+    }
     V4 kro;
     {   // EclDefaultMaterial::krn
         // connate water of the three-phase law: the cell's scaled SWL; a set without horizontal scaling (s0 = u0 = 0, k = 1) has the table's
@@ -232,16 +346,19 @@ __device__ void eval_cell(const opmgpu_tables& T, const EpsD& E, double so_max, 
         const V4 swow = vadd(sg, swp);
         if (H.on && swow.v > H.mdc_ow) {         // oil against water on its (shifted) imbibition curve
             const int wi = T.swof_ptr[H.ireg];
-            sat_curve<false>(T.swof_sw + wi, T.swof_krow + wi, T.swof_ptr[H.ireg + 1] - wi, swow.v + H.d_ow, *EI, EC_KROW, f, df);
-        } else sat_curve<false>(xsw, T.swof_krow + wa, nw, swow.v, E, EC_KROW, f, df);
+            sat_curve_s<false>(T.swof_sw + wi, T.swof_krow + wi, X.swof_dkrow + wi, T.swof_ptr[H.ireg + 1] - wi, swow.v + H.d_ow, *EI, EC_KROW, f, df);
+        } else sat_curve_s<false>(xsw, T.swof_krow + wa, X.swof_dkrow + wa, nw, swow.v, E, EC_KROW, f, df);
         const V4 kow = vchain(f, df, swow);
         const V4 sgeq = mk(swow.v - swco, swow.p, swow.w, swow.x);
+        int cl;
         if (E.on) {     // krog is tabulated against the oil saturation 1 - Swco_table - Sg; the scaling acts on that axis
             double slope;
             const double so_u = eps_map(E, EC_KROG, 1.0 - swow.v, slope);
-            sat_eval<true>(xsg, T.sgof_krog + ga, ng, 1.0 - xsw[0] - so_u, f, df);
+            const double sgu = 1.0 - xsw[0] - so_u;
+            const int i = sat_seg<true>(xsg, ng, sgu, cl);
+            sat_at(xsg, T.sgof_krog + ga, X.sgof_dkrog + ga, ng, i, cl, sgu, f, df);
             f *= E.v[EC_KROG]; df *= slope * E.v[EC_KROG];
-        } else sat_eval<true>(xsg, T.sgof_krog + ga, ng, sgeq.v, f, df);
+        } else { const int i = sat_seg<true>(xsg, ng, sgeq.v, cl); sat_at(xsg, T.sgof_krog + ga, X.sgof_dkrog + ga, ng, i, cl, sgeq.v, f, df); }
         const V4 kgo = vchain(f, df, sgeq);
         const double eps = 1e-5;
         const V4 den = sgeq;                                    // Sw_ow - Swco
@@ -254,60 +371,64 @@ __device__ void eval_cell(const opmgpu_tables& T, const EpsD& E, double so_max, 
                 const V4 oma = mk(1.0 - al.v, -al.p, -al.w, -al.x);
                 kro = vadd(vmul(k2, al), vmul(k1, oma));
             } else kro = k2;
-        } else kro = vdiv(num, den);
+        } else kro = vdiv1(num, den);
     }
-    // rs / rv
-    rs_sat_d(T, preg, p, f, df);
-    V4 rsSat = mk(f, df, 0, 0);
+    // rs / rv (saturated curves over the nodes' pressures: the node segment of p is shared with the saturated oil PVT below, that of
+    // p_g with the saturated gas PVT)
+    const int oa = T.oil_node_ptr[preg], on = T.oil_node_ptr[preg + 1] - oa;
+    const int gna = T.gas_node_ptr[preg], gn = T.gas_node_ptr[preg + 1] - gna;
+    const int ip = pvt_seg(T.oil_psat + oa, on, p);
+    const int ipg = pvt_seg(T.gas_pg + gna, gn, q.pg.v);
+    V4 rsSat = mk(0, 0, 0, 0), rvSat = mk(0, 0, 0, 0);
+    if (T.has_disgas) { lin_at(T.oil_psat + oa, T.oil_rs + oa, X.oil_drs + oa, ip, p, f, df); rsSat = mk(f, df, 0, 0); }
     if (T.vap2 > 0.0) { vap_factor(T.vap2, so.v, so_max, f, df); rsSat = vmul(vchain(f, df, so), rsSat); }
-    q.rs = (T.has_disgas && isRs) ? X : rsSat;
-    rv_sat_d(T, preg, q.pg.v, f, df);
-    V4 rvSat = vchain(f, df, q.pg);
+    q.rs = (T.has_disgas && isRs) ? Xv : rsSat;
+    if (T.has_vapoil) { lin_at(T.gas_pg + gna, T.gas_rvsat + gna, X.gas_drvsat + gna, ipg, q.pg.v, f, df); rvSat = vchain(f, df, q.pg); }
     if (T.vap1 > 0.0) { vap_factor(T.vap1, so.v, so_max, f, df); rvSat = vmul(vchain(f, df, so), rvSat); }
-    q.rv = (T.has_vapoil && isRv) ? X : rvSat;
+    q.rv = (T.has_vapoil && isRv) ? Xv : rvSat;
     // water PVT (ConstantCompressibilityWaterPvt)
     V4 mu[3];
     {
         const double* w = T.pvtw + 5 * preg;
+        const double iw1 = 1.0 / w[1];
         const double Xc = w[2] * (q.pw.v - w[0]);
-        const double bw = (1.0 + Xc * (1.0 + Xc / 2.0)) / w[1];
-        const double dbw = w[2] * (1.0 + Xc) / w[1];
+        const double bw = (1.0 + Xc * (1.0 + Xc / 2.0)) * iw1;
+        const double dbw = w[2] * (1.0 + Xc) * iw1;
         q.b[0] = vchain(bw, dbw, q.pw);
         const double c = w[2] - w[4];
         const double Y = c * (q.pw.v - w[0]);
-        const double den = 1.0 + Y * (1.0 + Y / 2.0);
+        const double den = 1.0 + Y * (1.0 + Y / 2.0), iden = 1.0 / den;
         const double BM = w[3] * w[1];
-        mu[0] = vchain(BM * bw / den, BM * (dbw * den - bw * c * (1.0 + Y)) / (den * den), q.pw);
+        mu[0] = vchain(BM * bw * iden, BM * (dbw * den - bw * c * (1.0 + Y)) * (iden * iden), q.pw);
     }
     // oil PVT (LiveOilPvt; saturated branch when free gas is present or no DISGAS)
     {
-        const int a = T.oil_node_ptr[preg], nn = T.oil_node_ptr[preg + 1] - a;
         double ib, dibp, dibr = 0.0, ibm, dibmp, dibmr = 0.0;
         if (freeGas || !T.has_disgas) {
-            pvt1(T.oil_psat + a, T.oil_invb_sat + a, nn, p, ib, dibp);
-            pvt1(T.oil_psat + a, T.oil_invbmu_sat + a, nn, p, ibm, dibmp);
+            lin_at(T.oil_psat + oa, T.oil_invb_sat + oa, X.oil_dinvb_sat + oa, ip, p, ib, dibp);
+            lin_at(T.oil_psat + oa, T.oil_invbmu_sat + oa, X.oil_dinvbmu_sat + oa, ip, p, ibm, dibmp);
         } else {
-            pvt2(T.oil_rs + a, nn, T.oil_col_ptr + a, T.oil_col_p, T.oil_col_invb, q.rs.v, p, ib, dibr, dibp);
-            pvt2(T.oil_rs + a, nn, T.oil_col_ptr + a, T.oil_col_p, T.oil_col_invbmu, q.rs.v, p, ibm, dibmr, dibmp);
+            const int ir = pvt_seg(T.oil_rs + oa, on, q.rs.v);
+            pvt2_pair(T.oil_rs + oa, ir, T.oil_col_ptr + oa, T.oil_col_p, T.oil_col_invb, X.oil_col_dinvb, T.oil_col_invbmu, X.oil_col_dinvbmu,
+                      q.rs.v, p, ib, dibr, dibp, ibm, dibmr, dibmp);
         }
         q.b[1] = vchain2(ib, dibp, P, dibr, q.rs);
-        const double m = ib / ibm;
-        mu[1] = vchain2(m, (dibp - m * dibmp) / ibm, P, (dibr - m * dibmr) / ibm, q.rs);
+        const double r = 1.0 / ibm, m = ib * r;
+        mu[1] = vchain2(m, (dibp - m * dibmp) * r, P, (dibr - m * dibmr) * r, q.rs);
     }
     // gas PVT (WetGasPvt; saturated branch when free oil is present or no VAPOIL)
     {
-        const int a = T.gas_node_ptr[preg], nn = T.gas_node_ptr[preg + 1] - a;
         double ib, dibp, dibr = 0.0, ibm, dibmp, dibmr = 0.0;
         if (freeOil || !T.has_vapoil) {
-            pvt1(T.gas_pg + a, T.gas_invb_sat + a, nn, q.pg.v, ib, dibp);
-            pvt1(T.gas_pg + a, T.gas_invbmu_sat + a, nn, q.pg.v, ibm, dibmp);
+            lin_at(T.gas_pg + gna, T.gas_invb_sat + gna, X.gas_dinvb_sat + gna, ipg, q.pg.v, ib, dibp);
+            lin_at(T.gas_pg + gna, T.gas_invbmu_sat + gna, X.gas_dinvbmu_sat + gna, ipg, q.pg.v, ibm, dibmp);
         } else {
-            pvt2(T.gas_pg + a, nn, T.gas_col_ptr + a, T.gas_col_rv, T.gas_col_invb, q.pg.v, q.rv.v, ib, dibp, dibr);
-            pvt2(T.gas_pg + a, nn, T.gas_col_ptr + a, T.gas_col_rv, T.gas_col_invbmu, q.pg.v, q.rv.v, ibm, dibmp, dibmr);
+            pvt2_pair(T.gas_pg + gna, ipg, T.gas_col_ptr + gna, T.gas_col_rv, T.gas_col_invb, X.gas_col_dinvb, T.gas_col_invbmu, X.gas_col_dinvbmu,
+                      q.pg.v, q.rv.v, ib, dibp, dibr, ibm, dibmp, dibmr);
         }
         q.b[2] = vchain2(ib, dibp, q.pg, dibr, q.rv);
-        const double m = ib / ibm;
-        mu[2] = vchain2(m, (dibp - m * dibmp) / ibm, q.pg, (dibr - m * dibmr) / ibm, q.rv);
+        const double r = 1.0 / ibm, m = ib * r;
+        mu[2] = vchain2(m, (dibp - m * dibmp) * r, q.pg, (dibr - m * dibmr) * r, q.rv);
     }
     // densities, mobilities (tr_mult == 1: no ROCKTAB)
     const double* rhos = T.surface_density + 3 * preg;
@@ -320,9 +441,9 @@ __device__ void eval_cell(const opmgpu_tables& T, const EpsD& E, double so_max, 
         rocktab_eval(T.rocktab_p, T.rocktab_pvmult, T.rocktab_n, p, f, df); pvm = mk(f, df, 0, 0);
         rocktab_eval(T.rocktab_p, T.rocktab_transmult, T.rocktab_n, p, f, df);
         const V4 trm = mk(f, df, 0, 0);
-        q.mob[0] = vdiv(vmul(trm, krw), mu[0]); q.mob[1] = vdiv(vmul(trm, kro), mu[1]); q.mob[2] = vdiv(vmul(trm, krg), mu[2]);
+        q.mob[0] = vdiv1(vmul(trm, krw), mu[0]); q.mob[1] = vdiv1(vmul(trm, kro), mu[1]); q.mob[2] = vdiv1(vmul(trm, krg), mu[2]);
     } else {
-        q.mob[0] = vdiv(krw, mu[0]); q.mob[1] = vdiv(kro, mu[1]); q.mob[2] = vdiv(krg, mu[2]);
+        q.mob[0] = vdiv1(krw, mu[0]); q.mob[1] = vdiv1(kro, mu[1]); q.mob[2] = vdiv1(krg, mu[2]);
     }
     if (T.rocktab_n == 0 && T.rock_comp != 0.0) {
         const double cp = T.rock_comp * (p - T.rock_pref);
@@ -340,31 +461,25 @@ __device__ void eval_cell(const opmgpu_tables& T, const EpsD& E, double so_max, 
 // ------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------
-// Face-input planes: the VALUE planes (pressures, densities, b*mobility, rs, rv: they enter the residual) are always double; the
-// DERIVATIVE planes (they enter only the Jacobian) are stored in the Jacobian's precision PS -- a float Jacobian (assemble_single)
-// rounds its entries to 24 bits anyway, and k_flux is bound by the bytes of the seven cell records it reads per row
-// (PMC: 1.34 GB fetched per launch at 100^3 against 0.48 GB of distinct lines, 50 % L2 hit rate).
-template <class PS>
-__device__ __forceinline__ void st4(double* __restrict__ props, PS* __restrict__ pd, int plane, long nbp, int row, const V4& a)
-{
-    props[long(plane) * nbp + row] = a.v; pd[long(plane + 1) * nbp + row] = PS(a.p);
-    pd[long(plane + 2) * nbp + row] = PS(a.w); pd[long(plane + 3) * nbp + row] = PS(a.x);
-}
-
-template <class MS>
-__global__ __launch_bounds__(kBlock) void k_cell_props(int nb, int nbp, opmgpu_tables T, const int32_t* __restrict__ pvtnum,
-                                                       const int32_t* __restrict__ satnum, const double* __restrict__ pv,
-                                                       const double* __restrict__ p, const double* __restrict__ sw, const double* __restrict__ sg,
-                                                       const double* __restrict__ rs, const double* __restrict__ rv, const int8_t* __restrict__ hc,
-                                                       double inv_dt, int initial, double s0, double s1, double s2,
-                                                       const int32_t* __restrict__ slice_ptr, const int16_t* __restrict__ nlower,
-                                                       const double* __restrict__ eps, const double* __restrict__ eps_u0,
-                                                       const double* __restrict__ somax,
-                                                       double* __restrict__ props, MS* __restrict__ pd, double* __restrict__ accum0, double* __restrict__ R,
-                                                       double* __restrict__ binv, MS* __restrict__ A, const double* __restrict__ tab_blob, int tab_words, HystArgs hy)
+// What a row needs of its NEIGHBOURS are ten VALUES per cell -- the phase pressures p_w and p_g (p_o is the state's pressure), the three
+// densities, the three b * mobility products, rs and rv -- and nothing else: a row computes the derivatives of each of its connections'
+// fluxes with respect to its OWN variables only, from the derivatives eval_cell gives it for its own cell, and writes them twice -- into
+// its own diagonal block, and (negated) into the block (neighbour, row) of the NEIGHBOUR's matrix row, which is exactly that entry:
+// dR_j / d x_i = -(dR_i / d x_i)|this connection.  Every block is still written by exactly one thread and every residual entry by its own
+// row (no atomics), but the 27 derivative planes round 2 exchanged between its two kernels (written once, read ~2.8 times: 1.37 GB of
+// HBM traffic for 0.41 GB of algorithmic bytes at 100^3, PMC in profiles/r02_w_pmc_summary.json) no longer exist.
+//   k_cell_values : state -> the ten value planes (+ 1 / b for getConvergence)                                  [pass 1, all cells]
+//   k_assemble_rows: state -> own derivatives (eval_cell again: arithmetic is free next to the bytes), accumulation term, TPFA fluxes
+//                    from the neighbours' value planes, residual, diagonal block, transposed off-diagonal blocks, CPR weights  [pass 2]
+template <bool LDS>
+__global__ __launch_bounds__(kBlock) void k_cell_values(int nb, int nbp, DevTables D, const int32_t* __restrict__ pvtnum, const int32_t* __restrict__ satnum,
+                                                        const double* __restrict__ p, const double* __restrict__ sw, const double* __restrict__ sg,
+                                                        const double* __restrict__ rs, const double* __restrict__ rv, const int8_t* __restrict__ hc,
+                                                        const double* __restrict__ eps, const double* __restrict__ eps_u0, const double* __restrict__ somax,
+                                                        double* __restrict__ vals, double* __restrict__ binv, const double* __restrict__ tab_blob, int tab_words, HystArgs hy)
 {
     extern __shared__ double tab_lds[];
-    stage_tables(T, tab_blob, tab_words, tab_lds);
+    resolve_tables<LDS>(D, tab_blob, tab_words, tab_lds);
     const int row = blockIdx.x * kBlock + threadIdx.x;
     if (row >= nb) return;
     CellEval q;
@@ -373,193 +488,189 @@ __global__ __launch_bounds__(kBlock) void k_cell_props(int nb, int nbp, opmgpu_t
     eps_load(eps, eps_u0, nbp, row, satnum[row], E);
     hyst_load(hy.imbnum, hy.hist, nbp, row, H);
     if (H.on) eps_load(hy.ieps, hy.iureg, nbp, row, H.ireg, EI);
-    eval_cell(T, E, somax[row], pvtnum[row], satnum[row], p[row], sw[row], sg[row], rs[row], rv[row], hc[row], q, H, &EI);
-    props[long(PL_PW) * nbp + row] = q.pw.v; props[long(PL_PG) * nbp + row] = q.pg.v;
-    pd[long(PL_DPW_W) * nbp + row] = MS(q.pw.w); pd[long(PL_DPG_W) * nbp + row] = MS(q.pg.w); pd[long(PL_DPG_X) * nbp + row] = MS(q.pg.x);
+    eval_cell(D, E, somax[row], pvtnum[row], satnum[row], p[row], sw[row], sg[row], rs[row], rv[row], hc[row], q, H, &EI);
+    vals[long(VP_PW) * nbp + row] = q.pw.v; vals[long(VP_PG) * nbp + row] = q.pg.v;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        st4(props, pd, PL_RHO + 4 * a, nbp, row, q.rho[a]);
-        st4(props, pd, PL_U + 4 * a, nbp, row, vmul(q.b[a], q.mob[a]));
+        vals[long(VP_RHO + a) * nbp + row] = q.rho[a].v;
+        vals[long(VP_U + a) * nbp + row] = q.b[a].v * q.mob[a].v;
         binv[long(a) * nbp + row] = 1.0 / q.b[a].v;
     }
-    st4(props, pd, PL_RS, nbp, row, q.rs); st4(props, pd, PL_RV, nbp, row, q.rv);
-    // accumulation term pvdt * (accum1 - accum0) and its diagonal-block contribution
-    const double pvdt = pv[row] * inv_dt;
-    const double scale[3] = { s0, s1, s2 };
-    MS* d = A + long(slice_ptr[row >> 6] + nlower[row]) * 576 + (row & 63);
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        if (initial) accum0[long(a) * nbp + row] = q.accum[a].v;
-        const double a0 = initial ? q.accum[a].v : accum0[long(a) * nbp + row];
-        R[long(a) * nbp + row] = pvdt * (q.accum[a].v - a0);
-        d[(3 * a) * 64] = MS(scale[a] * pvdt * q.accum[a].p);
-        d[(3 * a + 1) * 64] = MS(scale[a] * pvdt * q.accum[a].w);
-        d[(3 * a + 2) * 64] = MS(scale[a] * pvdt * q.accum[a].x);
-    }
+    vals[long(VP_RS) * nbp + row] = q.rs.v; vals[long(VP_RV) * nbp + row] = q.rv.v;
 }
 
-struct PhaseIn { double p, dpw, dpx, rho, drp, drw, drx; };    // dp/dP == 1 for every phase
-
-template <class PS>
-__device__ __forceinline__ PhaseIn load_phase(const double* __restrict__ props, const PS* __restrict__ pd, const double* __restrict__ pstate, long nbp, int c, int a)
+// computeAccum / assembleMassBalanceEq / computeMassFlux / applyThresholdPressures / UpwindSelector (BlackoilModelBase_impl.hpp:709-751, 845-913,
+// 1484-1545, AutoDiffHelpers.hpp:204-221; rs / rv cross terms :889-906, div = ngrad^T), one thread per row.
+// Per SELL entry of a row: the neighbour's row (col), the connection's transmissibility with the row's SIDE of the connection in its sign
+// bit (+: the row is c1, ngrad coefficient +1; NaN: not a connection -- the fill of an explicit well clique), g (z_c1 - z_c2), the
+// threshold pressure, and the index of the transposed entry (tpos).  All four are read coalesced at known addresses: the only dependent
+// loads of the loop are the neighbour's values.
+template <class MS, int WAVES, bool LDS>
+__global__ __launch_bounds__(kBlock, WAVES) void k_assemble_rows(int xm, int nb, int nbp, DevTables DT, const int32_t* __restrict__ pvtnum, const int32_t* __restrict__ satnum,
+                                                          const double* __restrict__ pv, const double* __restrict__ p, const double* __restrict__ sw,
+                                                          const double* __restrict__ sg, const double* __restrict__ rs, const double* __restrict__ rv,
+                                                          const int8_t* __restrict__ hc, double inv_dt, int initial, double s0, double s1, double s2,
+                                                          const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col, const int16_t* __restrict__ rowlen,
+                                                          const int16_t* __restrict__ nlower, const int32_t* __restrict__ tpos, const double* __restrict__ tr_e,
+                                                          const double* __restrict__ gdz_e, const double* __restrict__ thp_e,
+                                                          const double* __restrict__ eps, const double* __restrict__ eps_u0, const double* __restrict__ somax,
+                                                          const double* __restrict__ vals, double* __restrict__ accum0, const int8_t* __restrict__ mask,
+                                                          double* __restrict__ R, MS* __restrict__ A, MS* __restrict__ wout, const int32_t* __restrict__ chunk_perm,
+                                                          const double* __restrict__ tab_blob, int tab_words, HystArgs hy)
 {
-    PhaseIn r;
-    if (a == 0) { r.p = props[long(PL_PW) * nbp + c]; r.dpw = double(pd[long(PL_DPW_W) * nbp + c]); r.dpx = 0.0; }
-    else if (a == 1) { r.p = pstate[c]; r.dpw = 0.0; r.dpx = 0.0; }
-    else { r.p = props[long(PL_PG) * nbp + c]; r.dpw = double(pd[long(PL_DPG_W) * nbp + c]); r.dpx = double(pd[long(PL_DPG_X) * nbp + c]); }
-    const long o = long(PL_RHO + 4 * a) * nbp + c;
-    r.rho = props[o]; r.drp = double(pd[o + nbp]); r.drw = double(pd[o + 2 * nbp]); r.drx = double(pd[o + 3 * nbp]);
-    return r;
-}
-template <class PS>
-__device__ __forceinline__ V4 load4(const double* __restrict__ props, const PS* __restrict__ pd, int plane, long nbp, int c)
-{
-    const long o = long(plane) * nbp + c;
-    return mk(props[o], double(pd[o + nbp]), double(pd[o + 2 * nbp]), double(pd[o + 3 * nbp]));
-}
-
-// TPFA flux residual + 3x3 Jacobian blocks, one thread per row
-// (computeMassFlux :1484-1512, applyThresholdPressures :1518-1545, UpwindSelector AutoDiffHelpers.hpp:204-221,
-//  rs/rv cross terms :889-906, div = ngrad^T)
-template <class MS>
-__global__ __launch_bounds__(kBlock) void k_flux(int xm, int nb, int nbp, const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col,
-                                                 const int16_t* __restrict__ rowlen, const int16_t* __restrict__ nlower,
-                                                 const int32_t* __restrict__ conn_code, const double* __restrict__ trans,
-                                                 const double* __restrict__ gdz, const double* __restrict__ thpres,
-                                                 const double* __restrict__ pstate, const double* __restrict__ props, const MS* __restrict__ pd,
-                                                 double s0, double s1, double s2, const int8_t* __restrict__ mask,
-                                                 double* __restrict__ R, MS* __restrict__ A, MS* __restrict__ wout, const int32_t* __restrict__ chunk_perm)
-{
+    extern __shared__ double tab_lds[];
     const int nchunks = (nb + kBlock - 1) / kBlock;
     const int lch = xcd_first(nchunks, xm);
-    if (lch >= xcd_end(nchunks, xm)) return;
+    if (lch >= xcd_end(nchunks, xm)) return;               // (uniform over the workgroup)
+    resolve_tables<LDS>(DT, tab_blob, tab_words, tab_lds);
     const int ch = chunk_perm[lch];
     const int row = ch * kBlock + threadIdx.x;
     if (row >= nb) return;
     const int base = slice_ptr[row >> 6], lane = row & 63, nl = nlower[row], len = rowlen[row];
-    if (mask && !mask[row]) {
-        // ghost row (multi-GPU): identity block, zero residual -- the owner rank assembles the real equation
-        for (int k = 0; k < len; ++k) {
-            MS* bptr = A + long(base + k) * 576 + lane;
-#pragma unroll
-            for (int q = 0; q < 9; ++q) bptr[q * 64] = (k == nl && (q == 0 || q == 4 || q == 8)) ? MS(1) : MS(0);
-        }
-        R[row] = 0.0; R[nbp + row] = 0.0; R[2 * long(nbp) + row] = 0.0;
-        if (wout) { wout[row] = MS(1); wout[nbp + row] = MS(0); wout[2 * long(nbp) + row] = MS(0); }      // identity row: its pressure entry
-        return;
+    const bool ghost = mask && !mask[row];                 // multi-GPU: a ghost row is an identity row with zero residual -- the owner rank
+                                                           // assembles the real equation; its thread still writes the blocks (owned row, ghost column)
+    // ---- the row's own cell: values from the planes (bit for bit what the neighbours read), derivatives from eval_cell ----
+    CellEval q;
+    {
+        EpsD E, EI;
+        HystD H;
+        eps_load(eps, eps_u0, nbp, row, satnum[row], E);
+        hyst_load(hy.imbnum, hy.hist, nbp, row, H);
+        if (H.on) eps_load(hy.ieps, hy.iureg, nbp, row, H.ireg, EI);
+        eval_cell(DT, E, somax[row], pvtnum[row], satnum[row], p[row], sw[row], sg[row], rs[row], rv[row], hc[row], q, H, &EI);
     }
     const double scale[3] = { s0, s1, s2 };
-    // CPR weights (formEllipticSystem, see k_cpr_weights): column sums of |dR_j[eq]/dp_i| over the rows j != i.  The block (j, i) is
-    // the other side's view of THIS connection -- minus this row's own-variable derivative of the same flux -- so the sums come for
-    // free here and the pressure stage needs no transposed gathers (systems without wells; k_cpr_weights stays for everything else)
+    double op[3], orho[3], oU[3];                          // own values
+    double dP[3][3], dRho[3][3], dU[3][3];                 // own derivatives d/d(P, Sw, Xvar) of phase pressure, density, b * mobility
+    op[0] = vals[long(VP_PW) * nbp + row]; op[1] = p[row]; op[2] = vals[long(VP_PG) * nbp + row];
+    dP[0][0] = 1.0; dP[0][1] = q.pw.w; dP[0][2] = 0.0;
+    dP[1][0] = 1.0; dP[1][1] = 0.0; dP[1][2] = 0.0;
+    dP[2][0] = 1.0; dP[2][1] = q.pg.w; dP[2][2] = q.pg.x;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        orho[a] = vals[long(VP_RHO + a) * nbp + row]; oU[a] = vals[long(VP_U + a) * nbp + row];
+        const V4 u = vmul(q.b[a], q.mob[a]);
+        dRho[a][0] = q.rho[a].p; dRho[a][1] = q.rho[a].w; dRho[a][2] = q.rho[a].x;
+        dU[a][0] = u.p; dU[a][1] = u.w; dU[a][2] = u.x;
+    }
+    const double oRs = vals[long(VP_RS) * nbp + row], oRv = vals[long(VP_RV) * nbp + row];
+    const double dRs[3] = { q.rs.p, q.rs.w, q.rs.x }, dRv[3] = { q.rv.p, q.rv.w, q.rv.x };
+    // ---- accumulation term pvdt * (accum1 - accum0) and its part of the diagonal block ----
+    const double pvdt = pv[row] * inv_dt;
+    double Rl[3], D[9];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (initial) accum0[long(a) * nbp + row] = q.accum[a].v;
+        const double a0 = initial ? q.accum[a].v : accum0[long(a) * nbp + row];
+        Rl[a] = pvdt * (q.accum[a].v - a0);
+        D[3 * a] = scale[a] * pvdt * q.accum[a].p; D[3 * a + 1] = scale[a] * pvdt * q.accum[a].w; D[3 * a + 2] = scale[a] * pvdt * q.accum[a].x;
+    }
+    // CPR weights (formEllipticSystem, see k_cpr_weights): column sums of |dR_j[eq]/dp_i| over the rows j != i -- the blocks (j, i) this
+    // row writes itself, so the sums come for free (systems without explicit well cliques; k_cpr_weights stays for everything else)
     double sod[3] = { 0.0, 0.0, 0.0 };
-    double Rl[3] = { R[row], R[nbp + row], R[2 * long(nbp) + row] };
-    double D[9];
-    MS* dptr = A + long(base + nl) * 576 + lane;
-#pragma unroll
-    for (int q = 0; q < 9; ++q) D[q] = double(dptr[q * 64]);
-    // the row's own cell record is loaded ONCE and kept in registers: with both sides of every connection re-loaded per
-    // neighbour (the first version) the own planes fell out of the 32 KB L1 between neighbours and 4.8 KB per row went through
-    // the L2 (PMC: 18 % L2 hit rate) instead of the 2.1 KB the seven records need
-    PhaseIn own[3];
-    V4 ownU[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) { own[a] = load_phase(props, pd, pstate, nbp, row, a); ownU[a] = load4(props, pd, PL_U + 4 * a, nbp, row); }
-    const V4 ownRs = load4(props, pd, PL_RS, nbp, row), ownRv = load4(props, pd, PL_RV, nbp, row);
-    // The loop is a chain of dependent loads (connection code -> neighbour index -> neighbour record -> upwind-dependent planes) at
-    // 2 waves per SIMD (212 VGPRs), i.e. latency bound: the code/index of the NEXT connection are fetched while this one is
-    // computed, and all upwind-dependent loads of a connection (U of three phases, rs, rv) are issued together after the three
-    // potential differences, not one phase at a time.  (Forcing 3 waves per SIMD spills 200 B per lane: 265 -> 490 us.)
     int k0 = (nl == 0) ? 1 : 0;
-    int code_n = 0, nbr_n = 0;
-    if (k0 < len) { const long e0 = long(base + k0) * 64 + lane; code_n = __builtin_nontemporal_load(&conn_code[e0]); nbr_n = __builtin_nontemporal_load(&col[e0]); }
+    int nbr_n = 0, tp_n = 0; double T_n = 0.0, g_n = 0.0, th_n = 0.0;
+    if (k0 < len) {
+        const long e0 = long(base + k0) * 64 + lane;
+        nbr_n = __builtin_nontemporal_load(&col[e0]); tp_n = __builtin_nontemporal_load(&tpos[e0]);
+        T_n = __builtin_nontemporal_load(&tr_e[e0]); g_n = __builtin_nontemporal_load(&gdz_e[e0]);
+        if (thp_e) th_n = __builtin_nontemporal_load(&thp_e[e0]);
+    }
     for (int k = k0; k < len; ) {
-        const int code = code_n, nbr = nbr_n;
+        const int nbr = nbr_n, tp = tp_n; const double Te = T_n, g = g_n, thp = th_n;
         const int kn = (k + 1 == nl) ? k + 2 : k + 1;
-        if (kn < len) { const long en = long(base + kn) * 64 + lane; code_n = __builtin_nontemporal_load(&conn_code[en]); nbr_n = __builtin_nontemporal_load(&col[en]); }
+        if (kn < len) {           // the next entry's words are in flight while this one is computed
+            const long en = long(base + kn) * 64 + lane;
+            nbr_n = __builtin_nontemporal_load(&col[en]); tp_n = __builtin_nontemporal_load(&tpos[en]);
+            T_n = __builtin_nontemporal_load(&tr_e[en]); g_n = __builtin_nontemporal_load(&gdz_e[en]);
+            if (thp_e) th_n = __builtin_nontemporal_load(&thp_e[en]);
+        }
         MS* bptr = A + long(base + k) * 576 + lane;
         k = kn;
-        if (code < 0) {          // pure well fill: the host adds the Schur block later
+        if (Te != Te) {          // pure well fill: the host adds the Schur block later
 #pragma unroll
-            for (int q = 0; q < 9; ++q) bptr[q * 64] = MS(0);
+            for (int c = 0; c < 9; ++c) bptr[c * 64] = MS(0);
             continue;
         }
-        const int conn = code >> 1, side = code & 1;       // side 0: this row is c1 (ngrad +1), side 1: it is c2
-        const double Tf = trans[conn], g = gdz[conn];
-        const double thp = thpres ? thpres[conn] : 0.0;
-        // F[a], dF/d(c1 vars), dF/d(c2 vars)
-        double F[3], dF1[3][3], dF2[3][3], d1[3][3], d2[3][3], Tdh[3];
-        int up[3];
-        PhaseIn qn[3];
+        const int side = __builtin_signbit(Te) ? 1 : 0;     // side 0: this row is c1 (ngrad +1), side 1: it is c2
+        const double Tf = fabs(Te);
+        // neighbour values that every connection needs: phase pressures and densities
+        double np_[3], nrho[3];
+        np_[0] = vals[long(VP_PW) * nbp + nbr]; np_[1] = p[nbr]; np_[2] = vals[long(VP_PG) * nbp + nbr];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) qn[a] = load_phase(props, pd, pstate, nbp, nbr, a);
+        for (int a = 0; a < 3; ++a) nrho[a] = vals[long(VP_RHO + a) * nbp + nbr];
+        double Tdh[3], ddh[3][3];
+        bool own_up[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const PhaseIn q1 = side ? qn[a] : own[a];
-            const PhaseIn q2 = side ? own[a] : qn[a];
-            double dh = (q1.p - q2.p) - g * (0.5 * q1.rho + 0.5 * q2.rho);
+            const double p1 = side ? np_[a] : op[a], p2 = side ? op[a] : np_[a];
+            const double r1 = side ? nrho[a] : orho[a], r2 = side ? orho[a] : nrho[a];
+            double dh = (p1 - p2) - g * (0.5 * r1 + 0.5 * r2);
             double keep = 1.0;
-            if (thpres) {
+            if (thp_e) {
                 keep = (fabs(dh) >= thp) ? 1.0 : 0.0;
                 const double sg_ = (dh > 0.0) ? 1.0 : ((dh < 0.0) ? -1.0 : 0.0);
                 dh = keep * (dh - sg_ * thp);
             }
-            const double hg = 0.5 * g;
-            d1[a][0] = keep * (1.0 - hg * q1.drp); d1[a][1] = keep * (q1.dpw - hg * q1.drw); d1[a][2] = keep * (q1.dpx - hg * q1.drx);
-            d2[a][0] = keep * (-1.0 - hg * q2.drp); d2[a][1] = keep * (-q2.dpw - hg * q2.drw); d2[a][2] = keep * (-q2.dpx - hg * q2.drx);
-            up[a] = (dh >= 0.0) ? 0 : 1;
+            const double hg = 0.5 * g, sp = side ? -1.0 : 1.0;          // d dh / d(own variables): own is c1 (+) or c2 (-) in the pressure difference
+#pragma unroll
+            for (int v = 0; v < 3; ++v) ddh[a][v] = keep * (sp * dP[a][v] - hg * dRho[a][v]);
+            own_up[a] = ((dh >= 0.0) ? 0 : 1) == side;                   // upwind cell = c1 if dh >= 0 else c2
             Tdh[a] = Tf * dh;
         }
-        // upwind-dependent planes of the neighbour, one batch
-        V4 U[3] = { ownU[0], ownU[1], ownU[2] };
-        V4 rsu = ownRs, rvu = ownRv;
+        // upwind-dependent values of the neighbour, one batch
+        double Uv[3] = { oU[0], oU[1], oU[2] }, rsu = oRs, rvu = oRv;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) if (up[a] != side) U[a] = load4(props, pd, PL_U + 4 * a, nbp, nbr);          // the upwind cell is the neighbour
-        if (up[1] != side) rsu = load4(props, pd, PL_RS, nbp, nbr);
-        if (up[2] != side) rvu = load4(props, pd, PL_RV, nbp, nbr);
+        for (int a = 0; a < 3; ++a) if (!own_up[a]) Uv[a] = vals[long(VP_U + a) * nbp + nbr];
+        if (!own_up[1]) rsu = vals[long(VP_RS) * nbp + nbr];
+        if (!own_up[2]) rvu = vals[long(VP_RV) * nbp + nbr];
+        double F[3], dF[3][3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            F[a] = U[a].v * Tdh[a];
-            const double dU[3] = { U[a].p, U[a].w, U[a].x };
+            F[a] = Uv[a] * Tdh[a];
 #pragma unroll
-            for (int v = 0; v < 3; ++v) {
-                dF1[a][v] = U[a].v * (Tf * d1[a][v]) + (up[a] == 0 ? dU[v] * Tdh[a] : 0.0);
-                dF2[a][v] = U[a].v * (Tf * d2[a][v]) + (up[a] == 1 ? dU[v] * Tdh[a] : 0.0);
-            }
+            for (int v = 0; v < 3; ++v) dF[a][v] = Uv[a] * (Tf * ddh[a][v]) + (own_up[a] ? dU[a][v] * Tdh[a] : 0.0);
         }
         // G_o = F_o + rv_up(g) F_g ; G_g = F_g + rs_up(o) F_o
-        const double drs[3] = { rsu.p, rsu.w, rsu.x }, drv[3] = { rvu.p, rvu.w, rvu.x };
-        double G[3] = { F[0], F[1] + rvu.v * F[2], F[2] + rsu.v * F[1] };
-        double dG1[3][3], dG2[3][3];
+        const double G[3] = { F[0], F[1] + rvu * F[2], F[2] + rsu * F[1] };
+        double dG[3][3];
 #pragma unroll
         for (int v = 0; v < 3; ++v) {
-            dG1[0][v] = dF1[0][v]; dG2[0][v] = dF2[0][v];
-            dG1[1][v] = dF1[1][v] + rvu.v * dF1[2][v] + (up[2] == 0 ? drv[v] * F[2] : 0.0);
-            dG2[1][v] = dF2[1][v] + rvu.v * dF2[2][v] + (up[2] == 1 ? drv[v] * F[2] : 0.0);
-            dG1[2][v] = dF1[2][v] + rsu.v * dF1[1][v] + (up[1] == 0 ? drs[v] * F[1] : 0.0);
-            dG2[2][v] = dF2[2][v] + rsu.v * dF2[1][v] + (up[1] == 1 ? drs[v] * F[1] : 0.0);
+            dG[0][v] = dF[0][v];
+            dG[1][v] = dF[1][v] + rvu * dF[2][v] + (own_up[2] ? dRv[v] * F[2] : 0.0);
+            dG[2][v] = dF[2][v] + rsu * dF[1][v] + (own_up[1] ? dRs[v] * F[1] : 0.0);
         }
         const double s = side ? -1.0 : 1.0;
+        // the neighbour's row sees this flux with the opposite sign: block (nbr, row) = -s scale dG / d(own); zero where that row is a ghost's
+        const bool nbr_ghost = mask && !mask[nbr];
+        MS* tptr = A + long(tp >> 6) * 576 + (tp & 63);
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             Rl[a] += s * G[a];
 #pragma unroll
             for (int v = 0; v < 3; ++v) {
-                const double own = side ? dG2[a][v] : dG1[a][v];
-                const double oth = side ? dG1[a][v] : dG2[a][v];
-                if (v == 0) sod[a] += fabs(scale[a] * own);
-                D[3 * a + v] += s * scale[a] * own;
-                __builtin_nontemporal_store(MS(s * scale[a] * oth), &bptr[(3 * a + v) * 64]);
+                const double own = s * scale[a] * dG[a][v];
+                if (v == 0) sod[a] += fabs(own);
+                D[3 * a + v] += own;
+                __builtin_nontemporal_store(nbr_ghost ? MS(0) : MS(-own), &tptr[(3 * a + v) * 64]);
             }
         }
     }
+    MS* dptr = A + long(base + nl) * 576 + lane;
+    if (ghost) {
 #pragma unroll
-    for (int q = 0; q < 9; ++q) __builtin_nontemporal_store(MS(D[q]), &dptr[q * 64]);
+        for (int c = 0; c < 9; ++c) dptr[c * 64] = (c == 0 || c == 4 || c == 8) ? MS(1) : MS(0);
+        R[row] = 0.0; R[nbp + row] = 0.0; R[2 * long(nbp) + row] = 0.0;
+        if (wout) { wout[row] = MS(1); wout[nbp + row] = MS(0); wout[2 * long(nbp) + row] = MS(0); }      // identity row: its pressure entry
+        return;
+    }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) __builtin_nontemporal_store(MS(D[c]), &dptr[c * 64]);
     if (wout) {
-        const bool sw = fabs(D[0]) / sod[0] > 0.01, sg = fabs(D[6]) / sod[2] > 0.01;       // NaN (0/0) compares false like the reference's Eigen cast
-        bool so = fabs(D[3]) / sod[1] > 0.01;
-        if (!so && !sw && !sg) so = true;
-        wout[row] = sw ? MS(1) : MS(0); wout[nbp + row] = so ? MS(1) : MS(0); wout[2 * long(nbp) + row] = sg ? MS(1) : MS(0);
+        const bool w_ = fabs(D[0]) / sod[0] > 0.01, g_ = fabs(D[6]) / sod[2] > 0.01;       // NaN (0/0) compares false like the reference's Eigen cast
+        bool o_ = fabs(D[3]) / sod[1] > 0.01;
+        if (!o_ && !w_ && !g_) o_ = true;
+        wout[row] = w_ ? MS(1) : MS(0); wout[nbp + row] = o_ ? MS(1) : MS(0); wout[2 * long(nbp) + row] = g_ ? MS(1) : MS(0);
     }
     R[row] = Rl[0]; R[nbp + row] = Rl[1]; R[2 * long(nbp) + row] = Rl[2];
 }
@@ -710,7 +821,7 @@ __global__ __launch_bounds__(kBlock) void k_gather_perf3(int nperf, int nbp, con
 }
 
 // per-perforation properties for the host well model (extractWellPerfProperties)
-__global__ __launch_bounds__(kBlock) void k_perf_props(int nperf, opmgpu_tables T, const int32_t* __restrict__ cells, const int32_t* __restrict__ pvtnum,
+__global__ __launch_bounds__(kBlock) void k_perf_props(int nperf, DevTables T, const int32_t* __restrict__ cells, const int32_t* __restrict__ pvtnum,
                                                        const int32_t* __restrict__ satnum, const double* __restrict__ p, const double* __restrict__ sw,
                                                        const double* __restrict__ sg, const double* __restrict__ rs, const double* __restrict__ rv,
                                                        const int8_t* __restrict__ hc, const double* __restrict__ eps,
@@ -736,7 +847,7 @@ __global__ __launch_bounds__(kBlock) void k_perf_props(int nperf, opmgpu_tables 
 // computeFluidInPlace, the per-cell part (BlackoilModelBase_impl.hpp:2263-2296): fip[phase] = ((pv_mult * b_phase) * s_phase) * pv with b at the
 // phase pressures and the cell's phase condition, dissolved gas = rs * fip[oil], vaporised oil = rv * fip[gas]; plus what the region
 // loops need of the state (pore volume, pressure, so + sg).  Output in the CALLER's cell order: out[q * nc + nat[row]], q = 0..7.
-__global__ __launch_bounds__(kBlock) void k_fip_cells(int nc, opmgpu_tables T, const int32_t* __restrict__ nat, const int32_t* __restrict__ pvtnum,
+__global__ __launch_bounds__(kBlock) void k_fip_cells(int nc, DevTables T, const int32_t* __restrict__ nat, const int32_t* __restrict__ pvtnum,
                                                       const int32_t* __restrict__ satnum, const double* __restrict__ pv, const double* __restrict__ p,
                                                       const double* __restrict__ sw, const double* __restrict__ so_, const double* __restrict__ sg, const double* __restrict__ rs,
                                                       const double* __restrict__ rv, const int8_t* __restrict__ hc, const double* __restrict__ eps,
@@ -937,8 +1048,49 @@ void BlackoilDevice::upload_tables(const opmgpu_tables* t)
         dt_.rocktab_p = upd(t->rocktab_p, t->rocktab_n); dt_.rocktab_pvmult = upd(t->rocktab_pvmult, t->rocktab_n);
         dt_.rocktab_transmult = upd(t->rocktab_transmult, t->rocktab_n);
     }
+    // slopes of every 1-D table (TabX): (y[i+1] - y[i]) / (x[i+1] - x[i]) per segment, segments never cross the tables of a CSR-style array
+    auto slopes = [&](const double* x, const double* y, const int32_t* ptr, int ntab) -> const double* {
+        const int n = ptr[ntab];
+        std::vector<double> d(size_t(std::max(n, 1)), 0.0);
+        for (int t_ = 0; t_ < ntab; ++t_)
+            for (int i = ptr[t_]; i + 1 < ptr[t_ + 1]; ++i) d[i] = (y[i + 1] - y[i]) / (x[i + 1] - x[i]);
+        return upd(d.data(), size_t(n));
+    };
+    dx_.swof_dkrw = slopes(t->swof_sw, t->swof_krw, t->swof_ptr, ns); dx_.swof_dkrow = slopes(t->swof_sw, t->swof_krow, t->swof_ptr, ns);
+    dx_.swof_dpcow = slopes(t->swof_sw, t->swof_pcow, t->swof_ptr, ns);
+    dx_.sgof_dkrg = slopes(t->sgof_sg, t->sgof_krg, t->sgof_ptr, ns); dx_.sgof_dkrog = slopes(t->sgof_sg, t->sgof_krog, t->sgof_ptr, ns);
+    dx_.sgof_dpcgo = slopes(t->sgof_sg, t->sgof_pcgo, t->sgof_ptr, ns);
+    dx_.oil_drs = slopes(t->oil_psat, t->oil_rs, t->oil_node_ptr, np); dx_.oil_dinvb_sat = slopes(t->oil_psat, t->oil_invb_sat, t->oil_node_ptr, np);
+    dx_.oil_dinvbmu_sat = slopes(t->oil_psat, t->oil_invbmu_sat, t->oil_node_ptr, np);
+    dx_.oil_col_dinvb = slopes(t->oil_col_p, t->oil_col_invb, t->oil_col_ptr, non); dx_.oil_col_dinvbmu = slopes(t->oil_col_p, t->oil_col_invbmu, t->oil_col_ptr, non);
+    dx_.gas_drvsat = slopes(t->gas_pg, t->gas_rvsat, t->gas_node_ptr, np); dx_.gas_dinvb_sat = slopes(t->gas_pg, t->gas_invb_sat, t->gas_node_ptr, np);
+    dx_.gas_dinvbmu_sat = slopes(t->gas_pg, t->gas_invbmu_sat, t->gas_node_ptr, np);
+    dx_.gas_col_dinvb = slopes(t->gas_col_rv, t->gas_col_invb, t->gas_col_ptr, ngn); dx_.gas_col_dinvbmu = slopes(t->gas_col_rv, t->gas_col_invbmu, t->gas_col_ptr, ngn);
     d_tab.upload(blob, stream);
     tab_words = int(blob.size());
+    {
+        // offset form for the kernels that resolve the tables against the blob's LDS copy (resolve_tables): pointer fields = word offsets
+        dto_.t = dt_; dto_.x = dx_;
+        auto offd = [&](const double*& p) { p = reinterpret_cast<const double*>(p ? reinterpret_cast<size_t>(p) - 1 : size_t(0)); };
+        auto offi = [&](const int32_t*& p) { p = reinterpret_cast<const int32_t*>(p ? reinterpret_cast<size_t>(p) - 1 : size_t(0)); };
+        opmgpu_tables& o = dto_.t;
+        offd(o.surface_density); offd(o.pvtw);
+        offi(o.oil_node_ptr); offd(o.oil_rs); offd(o.oil_psat); offd(o.oil_invb_sat); offd(o.oil_invbmu_sat);
+        offi(o.oil_col_ptr); offd(o.oil_col_p); offd(o.oil_col_invb); offd(o.oil_col_invbmu);
+        offi(o.gas_node_ptr); offd(o.gas_pg); offd(o.gas_rvsat); offd(o.gas_invb_sat); offd(o.gas_invbmu_sat);
+        offi(o.gas_col_ptr); offd(o.gas_col_rv); offd(o.gas_col_invb); offd(o.gas_col_invbmu);
+        offi(o.swof_ptr); offd(o.swof_sw); offd(o.swof_krw); offd(o.swof_krow); offd(o.swof_pcow);
+        offi(o.sgof_ptr); offd(o.sgof_sg); offd(o.sgof_krg); offd(o.sgof_krog); offd(o.sgof_pcgo);
+        if (t->rocktab_n > 0) { offd(o.rocktab_p); offd(o.rocktab_pvmult); offd(o.rocktab_transmult); }
+        else { o.rocktab_p = nullptr; o.rocktab_pvmult = nullptr; o.rocktab_transmult = nullptr; }
+        const double** xs[] = { &dto_.x.swof_dkrw, &dto_.x.swof_dkrow, &dto_.x.swof_dpcow, &dto_.x.sgof_dkrg, &dto_.x.sgof_dkrog, &dto_.x.sgof_dpcgo, &dto_.x.oil_drs,
+                                &dto_.x.oil_dinvb_sat, &dto_.x.oil_dinvbmu_sat, &dto_.x.oil_col_dinvb, &dto_.x.oil_col_dinvbmu, &dto_.x.gas_drvsat, &dto_.x.gas_dinvb_sat,
+                                &dto_.x.gas_dinvbmu_sat, &dto_.x.gas_col_dinvb, &dto_.x.gas_col_dinvbmu };
+        const double** xg[] = { &dx_.swof_dkrw, &dx_.swof_dkrow, &dx_.swof_dpcow, &dx_.sgof_dkrg, &dx_.sgof_dkrog, &dx_.sgof_dpcgo, &dx_.oil_drs,
+                                &dx_.oil_dinvb_sat, &dx_.oil_dinvbmu_sat, &dx_.oil_col_dinvb, &dx_.oil_col_dinvbmu, &dx_.gas_drvsat, &dx_.gas_dinvb_sat,
+                                &dx_.gas_dinvbmu_sat, &dx_.gas_col_dinvb, &dx_.gas_col_dinvbmu };
+        for (size_t k = 0; k < sizeof(xs) / sizeof(xs[0]); ++k) { offd(*xs[k]); *xg[k] = d_tab.p + (reinterpret_cast<size_t>(*xg[k]) - 1); }
+    }
     {
         auto fixd = [&](const double*& p) { if (p) p = d_tab.p + (reinterpret_cast<size_t>(p) - 1); };
         auto fixi = [&](const int32_t*& p) { if (p) p = reinterpret_cast<const int32_t*>(d_tab.p + (reinterpret_cast<size_t>(p) - 1)); };
@@ -992,9 +1144,24 @@ void BlackoilDevice::rebuild_structure()
     if (st2 != OPMGPU_OK) throw HipError(st2, "sparsity plan failed");
     const Plan& P = ls.plan;
     const int nbp = P.nbp;
-    std::vector<int32_t> ccode(P.nentries, -2);
-    for (int b = 0; b < P.nnzb; ++b) ccode[P.entry_of_block[b]] = code[b];
-    d_conn_code.upload(ccode, stream);
+    // per SELL entry: transmissibility with the row's side of the connection in the sign bit (NaN: well fill, 0: diagonal / padding),
+    // g (z_c1 - z_c2) of the connection, its threshold pressure (k_assemble_rows reads them coalesced next to the column index)
+    {
+        const double nan = std::numeric_limits<double>::quiet_NaN();
+        std::vector<double> te(P.nentries, 0.0), ge(P.nentries, 0.0), he;
+        if (use_thpres) he.assign(P.nentries, 0.0);
+        for (int b = 0; b < P.nnzb; ++b) {
+            const int e = P.entry_of_block[b], c = code[b];
+            if (c >= 0) {
+                const int f = c >> 1;
+                te[e] = std::copysign(h_trans[f], (c & 1) ? -1.0 : 1.0);
+                ge[e] = gravity * (h_z[h_conn[2 * f]] - h_z[h_conn[2 * f + 1]]);
+                if (use_thpres) he[e] = h_thpres[f];
+            } else if (c == -2) te[e] = nan;
+        }
+        d_tr_e.upload(te, stream); d_gdz_e.upload(ge, stream);
+        if (use_thpres) d_thp_e.upload(he, stream);
+    }
     std::vector<double> pvi(nbp, 1.0); std::vector<int32_t> pn(nbp, 0), sn(nbp, 0);
     for (int r = 0; r < nc; ++r) { pvi[r] = h_pv[P.nat[r]]; pn[r] = h_pvtnum[P.nat[r]]; sn[r] = h_satnum[P.nat[r]]; }
     d_pv.upload(pvi, stream); d_pvtnum.upload(pn, stream); d_satnum.upload(sn, stream);
@@ -1034,12 +1201,6 @@ void BlackoilDevice::rebuild_structure()
             d_hist.upload(hp, stream);
         }
     }
-    std::vector<double> gdz(std::max(nconn, 1), 0.0);
-    for (int f = 0; f < nconn; ++f) gdz[f] = gravity * (h_z[h_conn[2 * f]] - h_z[h_conn[2 * f + 1]]);
-    d_gdz.upload(gdz, stream);
-    std::vector<double> tr(h_trans); if (tr.empty()) tr.push_back(0.0);
-    d_trans.upload(tr, stream);
-    if (use_thpres) d_thpres.upload(h_thpres, stream);
     std::vector<int32_t> pc(std::max<size_t>(h_well_cells.size(), 1), 0);
     for (size_t i = 0; i < h_well_cells.size(); ++i) pc[i] = P.pos[h_well_cells[i]];
     d_perf_cells.upload(pc, stream);
@@ -1048,7 +1209,7 @@ void BlackoilDevice::rebuild_structure()
     DevArray<double>* planes[] = { &d_p, &d_sw, &d_so, &d_sg, &d_rs, &d_rv };
     for (DevArray<double>* a : planes) { a->alloc(nbp); a->zero(stream); }
     d_hc.alloc(nbp); d_hc.zero(stream);
-    d_props.alloc(size_t(PL_COUNT) * nbp); d_props.zero(stream);
+    d_vals.alloc(size_t(VP_COUNT) * nbp); d_vals.zero(stream);
     d_accum0.alloc(3 * size_t(nbp)); d_accum0.zero(stream);
     d_R.alloc(3 * size_t(nbp)); d_R.zero(stream);
     d_binv.alloc(3 * size_t(nbp)); d_binv.zero(stream);
@@ -1247,35 +1408,37 @@ void BlackoilDevice::get_state(double* p, double* sat, double* rs, double* rv, i
     }
 }
 
+void BlackoilDevice::launch_cell_values()
+{
+    const Plan& P = ls.plan;
+    auto kern = tab_lds_words() > 0 ? k_cell_values<true> : k_cell_values<false>;
+    hipLaunchKernelGGL(kern, dim3(grid_for(nc)), dim3(kBlock), tab_lds_bytes(), stream, nc, P.nbp, dto_, d_pvtnum.p, d_satnum.p,
+                       d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, eps_planes(), d_eps_u0.p, d_somax.p, d_vals.p, d_binv.p,
+                       (const double*)d_tab.p, tab_lds_words(), hyst_args());
+}
 template <class MS> void BlackoilDevice::assemble_kernels(double dt, bool initial, MS* A, bool props_only)
 {
     const Plan& P = ls.plan;
     const double* sc = prm.matbalscale;
-    MS* pd = deriv_planes<MS>();
-    // CPR: k_flux also writes the weights of the pressure equation (the device well model redoes those of its perforated cells after
+    // CPR: k_assemble_rows also writes the weights of the pressure equation (the device well model redoes those of its perforated cells after
     // its diagonal contributions, wells_assemble; explicit host well cliques change off-diagonal blocks: the solver's own pass then)
     MS* wout = nullptr;
     if (prm.use_cpr && (nperf == 0 || device_wells) && ls.cpr_weight_mode == 0 && ls.emulate_ranks <= 1) { ls.ensure_work<MS>(); ls.work<MS>().cprw.alloc(3 * size_t(P.nbp)); wout = ls.work<MS>().cprw.p; }
     hipEvent_t kt_a = ls.kt.begin();
-    hipLaunchKernelGGL((k_cell_props<MS>), dim3(grid_for(nc)), dim3(kBlock), tab_lds_bytes(), stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_pv.p,
-                       d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, 1.0 / dt, int(initial), sc[0], sc[1], sc[2],
-                       ls.dp.slice_ptr.p, ls.dp.nlower.p, eps_planes(), d_eps_u0.p, d_somax.p, d_props.p, pd, d_accum0.p, d_R.p, d_binv.p, A,
-                       (const double*)d_tab.p, tab_lds_words(), hyst_args());
+    launch_cell_values();
     ls.kt.end(KT_CELL_PROPS, kt_a);
     if (props_only) return;
     KtScope kts(ls.kt, KT_FLUX);
-    hipLaunchKernelGGL((k_flux<MS>), dim3(grid8_for(nc)), dim3(kBlock), 0, stream, xcd_mode(), nc, P.nbp, ls.dp.slice_ptr.p, ls.dp.col.p, ls.dp.rowlen.p,
-                       ls.dp.nlower.p, d_conn_code.p, d_trans.p, d_gdz.p, use_thpres ? d_thpres.p : (const double*)nullptr,
-                       d_p.p, d_props.p, (const MS*)pd, sc[0], sc[1], sc[2], ls.comm ? ls.comm->owner_mask() : (const int8_t*)nullptr, d_R.p, A, wout,
-                       (const int32_t*)ls.dp.flux_perm.p);
+    // OPMGPU_ASM_WAVES=3: the variant compiled for 3 waves per SIMD (168 VGPRs, 12 spilled) instead of 2 (175 VGPRs, none): A/B knob
+    static const int waves = std::getenv("OPMGPU_ASM_WAVES") ? std::atoi(std::getenv("OPMGPU_ASM_WAVES")) : 2;
+    const bool lds = tab_lds_words() > 0;
+    auto kern = waves == 3 ? (lds ? k_assemble_rows<MS, 3, true> : k_assemble_rows<MS, 3, false>) : (lds ? k_assemble_rows<MS, 2, true> : k_assemble_rows<MS, 2, false>);
+    hipLaunchKernelGGL(kern, dim3(grid8_for(nc)), dim3(kBlock), tab_lds_bytes(), stream, xcd_mode(), nc, P.nbp, dto_, d_pvtnum.p, d_satnum.p, d_pv.p,
+                       d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, 1.0 / dt, int(initial), sc[0], sc[1], sc[2],
+                       ls.dp.slice_ptr.p, ls.dp.col.p, ls.dp.rowlen.p, ls.dp.nlower.p, ls.dp.tpos.p, d_tr_e.p, d_gdz_e.p, use_thpres ? d_thp_e.p : (const double*)nullptr,
+                       eps_planes(), d_eps_u0.p, d_somax.p, (const double*)d_vals.p, d_accum0.p, ls.comm ? ls.comm->owner_mask() : (const int8_t*)nullptr, d_R.p, A, wout,
+                       (const int32_t*)ls.dp.flux_perm.p, (const double*)d_tab.p, tab_lds_words(), hyst_args());
     ls.weights_from_assembly = wout != nullptr;
-}
-// derivative planes in the Jacobian's precision: the double ones live in d_props itself, the float ones in their own buffer
-template <> double* BlackoilDevice::deriv_planes<double>() { return d_props.p; }
-template <> float* BlackoilDevice::deriv_planes<float>()
-{
-    if (!d_props_f.p) { d_props_f.alloc(size_t(PL_COUNT) * ls.plan.nbp); d_props_f.zero(stream); }
-    return d_props_f.p;
 }
 
 // The Jacobian is written in the precision of the coming solve (opmgpu_set_solve_precision): float saves the f64 -> f32 copy
@@ -1310,17 +1473,11 @@ void BlackoilDevice::assemble(double dt, bool initial)
 
 double BlackoilDevice::time_assemble(int reps, int props_only)
 {
-    const Plan& P = ls.plan;
-    const double* sc = prm.matbalscale;
     const double dt = last_dt > 0 ? last_dt : 86400.0;
     hipEvent_t e0, e1;
     OPMGPU_HIP(hipEventCreate(&e0)); OPMGPU_HIP(hipEventCreate(&e1));
     auto launch = [&]() {
-        if (props_only)
-            hipLaunchKernelGGL((k_cell_props<double>), dim3(grid_for(nc)), dim3(kBlock), tab_lds_bytes(), stream, nc, P.nbp, dt_, d_pvtnum.p, d_satnum.p, d_pv.p,
-                               d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, 1.0 / dt, 0, sc[0], sc[1], sc[2],
-                               ls.dp.slice_ptr.p, ls.dp.nlower.p, eps_planes(), d_eps_u0.p, d_somax.p, d_props.p, d_props.p, d_accum0.p, d_R.p, d_binv.p, ls.matrix_d(),
-                               (const double*)d_tab.p, tab_lds_words(), hyst_args());
+        if (props_only) launch_cell_values();
         else assemble(dt, false);
     };
     launch();
@@ -1465,7 +1622,7 @@ void BlackoilDevice::attach_comm(CommBase* c, int n_owned)
 void BlackoilDevice::perf_props_device()
 {
     if (nperf == 0) return;
-    hipLaunchKernelGGL(k_perf_props, dim3(grid_for(nperf)), dim3(kBlock), 0, stream, nperf, dt_, d_perf_cells.p, d_pvtnum.p, d_satnum.p,
+    hipLaunchKernelGGL(k_perf_props, dim3(grid_for(nperf)), dim3(kBlock), 0, stream, nperf, DevTables{ dt_, dx_ }, d_perf_cells.p, d_pvtnum.p, d_satnum.p,
                        d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, eps_planes(), d_eps_u0.p, d_somax.p, long(ls.plan.nbp), d_perf.p, hyst_args());
 }
 
@@ -1510,7 +1667,7 @@ void BlackoilDevice::average_b(double* B3)
 void BlackoilDevice::perf_props(double* out)
 {
     if (nperf == 0) return;
-    hipLaunchKernelGGL(k_perf_props, dim3(grid_for(nperf)), dim3(kBlock), 0, stream, nperf, dt_, d_perf_cells.p, d_pvtnum.p, d_satnum.p,
+    hipLaunchKernelGGL(k_perf_props, dim3(grid_for(nperf)), dim3(kBlock), 0, stream, nperf, DevTables{ dt_, dx_ }, d_perf_cells.p, d_pvtnum.p, d_satnum.p,
                        d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, eps_planes(), d_eps_u0.p, d_somax.p, long(ls.plan.nbp), d_perf.p, hyst_args());
     OPMGPU_HIP(hipMemcpyAsync(out, d_perf.p, size_t(nperf) * OPMGPU_PERF_K * sizeof(double), hipMemcpyDeviceToHost, stream));
     OPMGPU_HIP(hipStreamSynchronize(stream));
@@ -1648,28 +1805,49 @@ void BlackoilDevice::stabilize_update(int relax_type, double omega)
                        d_dx.p, d_dx_old.p);
 }
 
-// computeFluidInPlace (BlackoilModelBase_impl.hpp:2263-2445, the serial branch): per-cell volumes on the device, the region sums on the host
+// computeFluidInPlace (BlackoilModelBase_impl.hpp:2263-2445, serial and parallel branch): per-cell volumes on the device, the region sums on the host
 // in cell order like the reference's loops (an output path: once per sub-step / report step).  fipnum: region per cell in the caller's
 // order, 0 = in no region, nullptr = one region of all cells; values: [dims][7]; fip_cells (optional): [7][nc] like SimulatorData::fip.
 void BlackoilDevice::fluid_in_place(const int32_t* fipnum, int dims, double* fip_cells, double* values)
 {
-    if (ls.comm) throw HipError(OPMGPU_EINVAL, "computeFluidInPlace: not available in decomposed runs (owner-masked sums + all-reduce are not restated)");
     const Plan& P = ls.plan;
     DevArray<double> dout; dout.alloc(size_t(8) * nc);
-    hipLaunchKernelGGL(k_fip_cells, dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, dt_, ls.dp.nat.p, d_pvtnum.p, d_satnum.p, d_pv.p,
+    hipLaunchKernelGGL(k_fip_cells, dim3(grid_for(nc)), dim3(kBlock), 0, stream, nc, DevTables{ dt_, dx_ }, ls.dp.nat.p, d_pvtnum.p, d_satnum.p, d_pv.p,
                        d_p.p, d_sw.p, d_so.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, eps_planes(), d_eps_u0.p, d_somax.p, long(P.nbp), dout.p, hyst_args());
     std::vector<double> h(size_t(8) * nc);
     dout.download(h.data(), h.size(), stream);
     OPMGPU_HIP(hipStreamSynchronize(stream));
     const double *pvol = h.data() + size_t(5) * nc, *pres_c = h.data() + size_t(6) * nc, *hyd = h.data() + size_t(7) * nc;
+    // decomposed runs (the reference's parallel branch, :2369-2446): every rank sums over the cells it OWNS (caller cells [0, n_owned)),
+    // the regions' hydrocarbon pore volumes / pressure sums and finally the region values are summed over the ranks; `dims` must be the
+    // GLOBAL number of regions on every rank (the reference takes comm.max of the local maxima; here the buffer is the caller's)
+    const int n_own = ls.comm ? n_owned_cells : nc;
+    DevArray<double> dsum;
+    auto allsum = [&](double* v, int n) {
+        if (!ls.comm || n <= 0) return;
+        dsum.upload(v, size_t(n), stream);
+        ls.comm->allreduce_sum(dsum.p, n, stream);
+        dsum.download(v, size_t(n), stream);
+        OPMGPU_HIP(hipStreamSynchronize(stream));
+    };
+    if (ls.comm) {
+        double dmax = double(dims);
+        dsum.upload(&dmax, 1, stream);
+        ls.comm->allreduce_max(dsum.p, 1, stream);
+        dsum.download(&dmax, 1, stream);
+        OPMGPU_HIP(hipStreamSynchronize(stream));
+        if (int(dmax + 0.5) != dims) throw HipError(OPMGPU_EINVAL, "computeFluidInPlace: pass the GLOBAL number of regions on every rank of a decomposed run");
+    }
     for (int i = 0; i < dims * 7; ++i) values[i] = 0.0;
     auto region = [&](int c) { return fipnum ? fipnum[c] - 1 : 0; };
     for (int ph = 0; ph < 5; ++ph)                       // phases, then the rs / rv volumes (:2312-2332)
-        for (int c = 0; c < nc; ++c) { const int r = region(c); if (r != -1) values[r * 7 + ph] += h[size_t(ph) * nc + c]; }
-    std::vector<double> hcpv(dims, 0.0), pres(dims, 0.0);
-    for (int c = 0; c < nc; ++c) { const int r = region(c); if (r != -1) { hcpv[r] += pvol[c] * hyd[c]; pres[r] += pvol[c] * pres_c[c]; } }
+        for (int c = 0; c < n_own; ++c) { const int r = region(c); if (r != -1) values[r * 7 + ph] += h[size_t(ph) * nc + c]; }
+    std::vector<double> hp(2 * size_t(dims), 0.0);       // hydrocarbon pore volume | pv-weighted pressure sum, per region
+    double* hcpv = hp.data(); double* pres = hp.data() + dims;
+    for (int c = 0; c < n_own; ++c) { const int r = region(c); if (r != -1) { hcpv[r] += pvol[c] * hyd[c]; pres[r] += pvol[c] * pres_c[c]; } }
+    allsum(hp.data(), 2 * dims);                         // comm.sum(hcpv), comm.sum(pres)
     std::vector<double> fpv(nc, 0.0), fwp(nc, 0.0);
-    for (int c = 0; c < nc; ++c) {
+    for (int c = 0; c < n_own; ++c) {
         const int r = region(c);
         if (r == -1) continue;
         fpv[c] = pvol[c];
@@ -1679,6 +1857,7 @@ void BlackoilDevice::fluid_in_place(const int32_t* fipnum, int dims, double* fip
         values[r * 7 + 5] += fpv[c];
         values[r * 7 + 6] += fwp[c];
     }
+    allsum(values, dims * 7);                            // one sum for all regions (the reference loops comm.sum over the regions)
     if (fip_cells) {
         std::copy(h.begin(), h.begin() + size_t(5) * nc, fip_cells);
         std::copy(fpv.begin(), fpv.end(), fip_cells + size_t(5) * nc);

@@ -13,15 +13,17 @@
 namespace opmgpu {
 
 struct HystArgs;
-
-// per-cell planes handed from the property kernel to the flux kernel (doubles, stride nbp)
-enum {
-    PL_PW = 0, PL_PG, PL_DPW_W, PL_DPG_W, PL_DPG_X,
-    PL_RHO = 5,      // + 4*phase + {0: value, 1: d/dP, 2: d/dSw, 3: d/dXvar}
-    PL_U = 17,       // b*mob, same sub-layout
-    PL_RS = 29, PL_RV = 33,
-    PL_COUNT = 37
+struct TabX {
+    const double *swof_dkrw, *swof_dkrow, *swof_dpcow, *sgof_dkrg, *sgof_dkrog, *sgof_dpcgo;
+    const double *oil_drs, *oil_dinvb_sat, *oil_dinvbmu_sat, *oil_col_dinvb, *oil_col_dinvbmu;
+    const double *gas_drvsat, *gas_dinvb_sat, *gas_dinvbmu_sat, *gas_col_dinvb, *gas_col_dinvbmu;
 };
+struct DevTables { opmgpu_tables t; TabX x; };
+
+// per-cell VALUE planes a row's neighbours read (doubles, stride nbp): phase pressures p_w, p_g (p_o is the state's pressure), the
+// densities, b * mobility, rs, rv.  No derivative plane exists: a row differentiates its connections with respect to its own
+// variables only and writes the neighbour's off-diagonal block itself (k_assemble_rows).
+enum { VP_PW = 0, VP_PG = 1, VP_RHO = 2 /* + phase */, VP_U = 5 /* + phase */, VP_RS = 8, VP_RV = 9, VP_COUNT = 10 };
 
 constexpr int kRedPart = 32;        // d_red: [0, 32) results, per-workgroup partials behind them
 
@@ -139,21 +141,22 @@ private:
     const double* eps_planes() const { return use_eps ? d_eps.p : nullptr; }
     // device: tables
     opmgpu_tables dt_;                       // same struct, device pointers
+    TabX dx_;                                // per-segment slopes of the 1-D tables (device pointers into the same blob)
+    DevTables dto_;                          // tables + slopes with WORD OFFSETS into the blob in the pointer fields (resolve_tables)
     DevArray<double> d_tab;                  // all table arrays in one blob of 8-byte words (staged in LDS by the property kernels)
     int tab_words = 0;
     static constexpr int kTabLdsMaxBytes = 24 * 1024;     // 6 workgroups x 24 KiB fit the 160 KiB LDS of a CU: no occupancy lost
     int tab_lds_words() const { return tab_words * 8 <= kTabLdsMaxBytes ? tab_words : 0; }
     size_t tab_lds_bytes() const { return size_t(tab_lds_words()) * 8; }
     // device: static per-cell / per-connection (internal numbering for cells)
-    DevArray<double> d_pv, d_trans, d_gdz, d_thpres;
-    DevArray<int32_t> d_pvtnum, d_satnum, d_conn_code, d_perf_cells;
+    DevArray<double> d_pv, d_tr_e, d_gdz_e, d_thp_e;      // per SELL entry: +-transmissibility (sign = side, NaN = well fill), g dz, threshold pressure
+    DevArray<int32_t> d_pvtnum, d_satnum, d_perf_cells;
     // device: state (internal numbering)
     DevArray<double> d_p, d_sw, d_so, d_sg, d_rs, d_rv;
     DevArray<int8_t> d_hc;
     // device: work
-    DevArray<float> d_props_f;      // derivative planes of a float Jacobian (see st4 in blackoil.hip)
-    template <class MS> MS* deriv_planes();
-    DevArray<double> d_props, d_accum0, d_R, d_binv, d_dx, d_dx_old, d_red, d_perf, d_rhs_extra;
+    void launch_cell_values();
+    DevArray<double> d_vals, d_accum0, d_R, d_binv, d_dx, d_dx_old, d_red, d_perf, d_rhs_extra;
     double* h_red = nullptr;
     std::vector<double> hbuf;
     std::vector<int8_t> hbuf8;

@@ -2547,35 +2547,39 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
             }
             wait_tick(tick);
             if (h_ctl->done) stop = true;
+            if (stop && verify && h_ctl->flag == 0 && h_ctl->iters > 0) {
+                // gmres_verify_residual: the preconditioned residual met the threshold -- does the true one?  The candidate x + V y of the
+                // i + 1 completed columns goes into a scratch vector (x itself is only updated when the cycle ends), one product, one pass
+                // for || b - A xt ||^2 and || b ||^2.  If it misses the target, `done` is taken back, the threshold on the preconditioned
+                // residual is lowered in proportion, and the SAME cycle goes on with its next column: the Krylov space is kept.
+                const int cnt = i + 1;
+                hipLaunchKernelGGL(k_gm_solve_y, dim3(1), dim3(1), 0, stream, cnt, m, g);
+                OPMGPU_HIP(hipMemcpyAsync(w.y.p, w.x.p, size_t(n) * sizeof(S), hipMemcpyDeviceToDevice, stream));
+                hipLaunchKernelGGL((k_gm_update_x<S>), dim3(gv), dim3(kBlock), 0, stream, n, cnt, (const double*)g.y, (const S*)w.kry.p, w.y.p);
+                product(w.y.p, w.p.p, (const SolveCtl*)nullptr);
+                hipLaunchKernelGGL((k_gm_defect_norms<S>), dim3(gv), dim3(kBlock), 0, stream, n, plan.nbp, mask, (const S*)w.b.p, (const S*)w.p.p, w.r.p, parts, parts2);
+                const double* pr = parts; const double* pb = parts2; int np_v = gv;
+                if (comm) {
+                    hipLaunchKernelGGL((k_sum_partials<2>), dim3(1), dim3(kBlock), 0, stream, (const double*)parts, (const double*)parts2, gv, red1);
+                    comm->allreduce_sum(red1, 2, stream);
+                    pr = red1; pb = red1 + 1; np_v = 1;
+                }
+                const int vtick = ++tick_seq;
+                hipLaunchKernelGGL(k_gm_verify, dim3(1), dim3(kBlock), 0, stream, pr, pb, np_v, prm.linear_solver_reduction, g.y + m, d_ctl, h_ctl_dev,
+                                   poll_status ? h_tick_dev : (int*)nullptr, vtick);
+                wait_tick(vtick);
+                verified = true;
+                if (!h_ctl->done) { stop = false; ++verify_rounds; }
+            }
         }
         if (h_ctl->flag != 0) break;                                   // breakdown: dune throws, no update
         if (h_ctl->done && h_ctl->iters == 0) break;                   // zero defect: x = 0 is the solution, no column was built
         // x += sum_a y_a v_a with R y = s   (i columns were completed)
         hipLaunchKernelGGL(k_gm_solve_y, dim3(1), dim3(1), 0, stream, i, m, g);
         hipLaunchKernelGGL((k_gm_update_x<S>), dim3(gv), dim3(kBlock), 0, stream, n, i, (const double*)g.y, flex ? (const S*)w.kryz.p : (const S*)w.kry.p, w.x.p);
-        bool have_defect = false;
-        if (stop && verify && h_ctl->done && h_ctl->flag == 0) {
-            // the preconditioned residual met the threshold: does the true one?  (one product + one pass; the defect is the restart vector)
-            product(w.x.p, w.v.p, (const SolveCtl*)nullptr);
-            hipLaunchKernelGGL((k_gm_defect_norms<S>), dim3(gv), dim3(kBlock), 0, stream, n, plan.nbp, mask, (const S*)w.b.p, (const S*)w.v.p, w.r.p, parts, parts2);
-            const double* pr = parts; const double* pb = parts2; int np_v = gv;
-            if (comm) {
-                hipLaunchKernelGGL((k_sum_partials<2>), dim3(1), dim3(kBlock), 0, stream, (const double*)parts, (const double*)parts2, gv, red1);
-                comm->allreduce_sum(red1, 2, stream);
-                pr = red1; pb = red1 + 1; np_v = 1;
-            }
-            const int tick = ++tick_seq;
-            hipLaunchKernelGGL(k_gm_verify, dim3(1), dim3(kBlock), 0, stream, pr, pb, np_v, prm.linear_solver_reduction, g.y + m, d_ctl, h_ctl_dev,
-                               poll_status ? h_tick_dev : (int*)nullptr, tick);
-            wait_tick(tick);
-            verified = true;
-            if (!h_ctl->done) { stop = false; have_defect = true; ++verify_rounds; }
-        }
         if (!stop && j <= maxit) {                                     // restart from the true defect
-            if (!have_defect) {
-                product(w.x.p, w.v.p, (const SolveCtl*)nullptr);
-                hipLaunchKernelGGL((k_gm_defect<S>), dim3(gv), dim3(kBlock), 0, stream, n, (const S*)w.b.p, (const S*)w.v.p, w.r.p);
-            }
+            product(w.x.p, w.v.p, (const SolveCtl*)nullptr);
+            hipLaunchKernelGGL((k_gm_defect<S>), dim3(gv), dim3(kBlock), 0, stream, n, (const S*)w.b.p, (const S*)w.v.p, w.r.p);
             if (flex) normalize_start((const S*)w.r.p, 0);
             else { precond(w.r.p, w.t.p); normalize_start((const S*)w.t.p, 0); }
         }

@@ -208,12 +208,13 @@ class GpuBlackoilModel:
     def restoreState(self):
         self._chk(self.lib.opmgpu_restore_state(self.ctx))
 
-    def computeFluidInPlace(self, fipnum=None, cells=False):
+    def computeFluidInPlace(self, fipnum=None, cells=False, nregions=None):
         """BlackoilModelBase::computeFluidInPlace (BlackoilModelBase_impl.hpp:2263-2445) for the resident state: values[region][7]
         (water, oil, gas, dissolved gas, vaporised oil, pore volume, hydrocarbon-pv weighted pressure); cells=True also returns the
-        per-cell arrays [7][nc] (SimulatorData::fip)."""
+        per-cell arrays [7][nc] (SimulatorData::fip).  Decomposed runs: collective; every rank passes the fipnum of its local cells
+        (ghosts included, they are not counted) and the GLOBAL number of regions, and receives the global sums."""
         fn = None if fipnum is None else capi.i32(fipnum)
-        dims = 1 if fn is None else max(1, int(fn.max()))
+        dims = nregions if nregions is not None else (1 if fn is None else max(1, int(fn.max())))
         values = np.zeros((dims, 7))
         fc = np.zeros((7, self.nc)) if cells else None
         self._chk(self.lib.opmgpu_compute_fluid_in_place(self.ctx, capi.iptr(fn), dims, capi.dptr(fc), capi.dptr(values)))

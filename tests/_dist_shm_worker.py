@@ -88,7 +88,13 @@ def run(cfg, rank, world, uid, out):
             hist.append([bool(conv), int(lin)])
     s = model.getState()
     n = owned_global.size
-    np.savez(out, ids=owned_global, p=s.p[:n], sat=s.sat[:n], hc=s.hc[:n], hist=np.array(hist, dtype=np.int64))
+    # computeFluidInPlace on the decomposed state: three regions by global cell index (+ region 0 = "in no region" for every 7th cell),
+    # the fipnum of this rank's cells incl. its ghosts (which must not be counted twice)
+    gids = np.arange(grid.nc) if world == 1 else dom.global_of_local
+    fipnum = (1 + (gids * 3) // grid.nc).astype(np.int32)
+    fipnum[gids % 7 == 3] = 0
+    fip = model.computeFluidInPlace(fipnum, nregions=3)
+    np.savez(out, ids=owned_global, p=s.p[:n], sat=s.sat[:n], hc=s.hc[:n], hist=np.array(hist, dtype=np.int64), fip=fip)
     model.close()
 
 

@@ -37,7 +37,7 @@ def test_bench_line_contract(gpu_lib):
     b = d["breakdown_ms_per_step"]
     assert b["assemble"] + b["linear_solve"] + b["update"] <= d["ms_per_solving_iteration_median"] * 1.02
     # the headline is the reference-runnable configuration: CPR in double (NewtonIterationBlackoilCPR.cpp:117-140) with newton_use_gmres
-    assert d["dtype"] == "f64" and d["config"]["linear_solver"] == "cpr(amg V-cycle + ilu0) + gmres(40)" and d["config"]["gmres_true_residual_check"] is True
+    assert d["dtype"] == "f64" and d["config"]["linear_solver"] == "cpr(amg V-cycle + ilu0) + gmres(40)" and d["config"]["gmres_true_residual_check"] is False
     assert d["config"]["workload"].startswith("cart24x24x12") and d["config"]["workload"].endswith("_fivespot") and "model" not in d["config"]
     assert d["config"]["time_steps_not_converged"] == 0
     r = d["roofline"]
@@ -46,7 +46,7 @@ def test_bench_line_contract(gpu_lib):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
     v = d["same_run_variants"]
-    assert {"reference_default_solver_ilu0_with_wells", "without_wells", "cpr_f64_bicgstab_with_wells", "cpr_f32_gmres_with_wells", "dt30_f64_ilu0_with_wells",
+    assert {"reference_default_solver_ilu0_with_wells", "without_wells", "cpr_f64_bicgstab_with_wells", "cpr_f64_gmres_verified_with_wells", "cpr_f32_gmres_with_wells", "dt30_f64_ilu0_with_wells",
             "dt30_f64_cpr_gmres_with_wells"} <= set(v)
     assert all("failed" not in x for x in v.values()), v
     assert "f32" in v["reference_default_solver_ilu0_with_wells"]["arithmetic"] and "f64 Jacobian" in v["dt30_f64_ilu0_with_wells"]["arithmetic"]

@@ -60,7 +60,9 @@ def _launch(cfg, world, tmp, extra_env=None):
     hists = [q["hist"] for q in parts]
     for h in hists[1:]:
         assert np.array_equal(h, hists[0])                           # converged flags and iteration counts are collective results
-    return p, sat, hc, hists[0]
+    for q in parts[1:]:
+        assert np.array_equal(q["fip"], parts[0]["fip"])             # computeFluidInPlace is collective: every rank holds the global sums
+    return p, sat, hc, hists[0], parts[0]["fip"]
 
 
 CASES = {
@@ -105,6 +107,9 @@ def test_decomposed_runs_walk_the_single_domain_newton_path(gpu_lib, case):
             assert np.abs(got[0] - ref[0]).max() <= tol * np.abs(ref[0]).max(), (case, world)
             assert np.abs(got[1] - ref[1]).max() <= tol, (case, world)
             assert np.array_equal(got[3][:, 0], ref[3][:, 0]), (case, world)      # same convergence decisions
+            # computeFluidInPlace of the decomposed state (owner-masked region sums + all-reduce, BlackoilModelBase_impl.hpp:2369-2446) against
+            # the single-domain run's: the states agree to `tol`, the sums are taken in another order
+            assert got[4].shape == (3, 7) and np.allclose(got[4], ref[4], rtol=max(tol, 1e-9) * 10, atol=0), (case, world, got[4], ref[4])
 
 
 def test_coarse_space_restrictions_ride_on_the_scalar_all_reduces(gpu_lib):

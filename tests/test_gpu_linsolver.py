@@ -338,13 +338,16 @@ def test_gmres_true_residual_check(gpu_lib, oracle, single):
     r, val, _, _ = oracle.assemble(grid, tab, 2 * decks.DAY, st, rowptr, col, scale=tuple(scale))
     b = np.ascontiguousarray((r * np.repeat(scale, nc)).reshape(3, nc).T).ravel()
     A = bsr_to_scipy(rowptr, col, val)
-    red = 1e-4 if single else 1e-6
+    red = 1e-3 if single else 1e-5
     slack = 3.0 if single else 1.0 + 1e-6            # float: x is rounded to 24 bits after the check measured it in the solve's precision
     true_res = {}
-    for kw in (dict(), dict(use_cpr=1), dict(linear_solver_restart=6)):
+    for kw in (dict(ilu_ordering=capi.ORDER_NATURAL), dict(use_cpr=1), dict(use_cpr=1, linear_solver_restart=5)):
         for verify in (0, 1):
-            s = GpuNewtonIteration(capi.default_params(newton_use_gmres=1, gmres_verify_residual=verify, linear_solver_reduction=red, linear_solver_maxiter=600, **kw))
-            x = s.computeNewtonIncrement(rowptr, col, val, b, single)
+            s = GpuNewtonIteration(capi.default_params(newton_use_gmres=1, gmres_verify_residual=verify, linear_solver_reduction=red, linear_solver_maxiter=1500, **kw))
+            try:
+                x = s.computeNewtonIncrement(rowptr, col, val, b, single)
+            except LinearSolverProblem:
+                pytest.fail("no convergence with %r, verify %d, after %d iterations, reduction %.2e" % (kw, verify, s.iterations(), s.reduction))
             true_res[verify] = np.linalg.norm(b - A @ x) / np.linalg.norm(b)
             assert s.reduction < red
             if verify:
