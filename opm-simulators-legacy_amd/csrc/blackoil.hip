@@ -1429,8 +1429,9 @@ template <class MS> void BlackoilDevice::assemble_kernels(double dt, bool initia
     ls.kt.end(KT_CELL_PROPS, kt_a);
     if (props_only) return;
     KtScope kts(ls.kt, KT_FLUX);
-    // OPMGPU_ASM_WAVES=3: the variant compiled for 3 waves per SIMD (168 VGPRs, 12 spilled) instead of 2 (175 VGPRs, none): A/B knob
-    static const int waves = std::getenv("OPMGPU_ASM_WAVES") ? std::atoi(std::getenv("OPMGPU_ASM_WAVES")) : 2;
+    // compiled for 3 waves per SIMD (168 VGPRs, 14 spilled; default) or for 2 (173 VGPRs, none; OPMGPU_ASM_WAVES=2).  Measured at 100^3
+    // (profiles/r03_asm_waves_ab.log): 0.232 against 0.240 ms with a double Jacobian, 0.181 against 0.206 ms with a float one
+    static const int waves = std::getenv("OPMGPU_ASM_WAVES") ? std::atoi(std::getenv("OPMGPU_ASM_WAVES")) : 3;
     const bool lds = tab_lds_words() > 0;
     auto kern = waves == 3 ? (lds ? k_assemble_rows<MS, 3, true> : k_assemble_rows<MS, 3, false>) : (lds ? k_assemble_rows<MS, 2, true> : k_assemble_rows<MS, 2, false>);
     hipLaunchKernelGGL(kern, dim3(grid8_for(nc)), dim3(kBlock), tab_lds_bytes(), stream, xcd_mode(), nc, P.nbp, dto_, d_pvtnum.p, d_satnum.p, d_pv.p,
@@ -1461,7 +1462,7 @@ void BlackoilDevice::assemble(double dt, bool initial)
         else assemble_kernels<double>(dt, initial, ls.matrix_d(), true);
         double B[3];
         average_b(B);
-        for (int a = 0; a < 3; ++a) prm.matbalscale[a] = B[a];
+        for (int a = 0; a < 3; ++a) { prm.matbalscale[a] = B[a]; ls.lowrank.scale[a] = B[a]; }      // the wells' bordered pressure column is built from the same factors (k_cpr_border)
     }
     const bool forked = wells_prologue_async(initial);
     if (ls.matrix_is_float) assemble_kernels<float>(dt, initial, ls.matrix_f());

@@ -443,16 +443,17 @@ static int nonlinear_iteration_body(opmgpu_ctx* c, double dt, int iteration, int
         if (linear_iterations) *linear_iterations = its;
         if (st != OPMGPU_OK) return st;
         if (ctl->use_update_stabilization) {
-            // detectOscillations (NonlinearSolver_impl.hpp:221-257): only the three mass-balance norms take part
+            // the oscillation rule of NonlinearSolver_impl.hpp:221-257 (only the three mass-balance norms take part): a phase swings when its
+            // norm is back within relax_rel_tol of its value two iterations ago but not of last iteration's; two swinging phases oscillate
             bool oscillate = false;
             if (iteration >= 2) {
-                const auto &F0 = c->norm_history[iteration], &F1 = c->norm_history[iteration - 1], &F2 = c->norm_history[iteration - 2];
-                int n_osc = 0;
-                for (int p = 0; p < 3; ++p) {
-                    const double d1 = std::fabs((F0[p] - F2[p]) / F0[p]), d2 = std::fabs((F0[p] - F1[p]) / F0[p]);
-                    n_osc += (d1 < ctl->relax_rel_tol) && (ctl->relax_rel_tol < d2);
+                const auto &now = c->norm_history[iteration], &last = c->norm_history[iteration - 1], &before = c->norm_history[iteration - 2];
+                int swinging = 0;
+                for (int ph = 0; ph < 3; ++ph) {
+                    const double to_before = std::fabs((now[ph] - before[ph]) / now[ph]), to_last = std::fabs((now[ph] - last[ph]) / now[ph]);
+                    if (to_before < ctl->relax_rel_tol && ctl->relax_rel_tol < to_last) ++swinging;
                 }
-                oscillate = n_osc > 1;
+                oscillate = swinging >= 2;
             }
             if (oscillate) c->relaxation = std::max(c->relaxation - ctl->relax_increment, ctl->relax_max);
             st = opmgpu_stabilize_update(c, ctl->relax_type, c->relaxation);

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/opmgpu.h"
@@ -85,6 +86,16 @@ struct KtScope {        // RAII bracket
     KernelTimers& kt; int id; hipEvent_t a;
     KtScope(KernelTimers& k, int i) : kt(k), id(i), a(k.begin()) {}
     ~KtScope() { try { kt.end(id, a); } catch (...) {} }
+};
+
+// Work redirected to a side stream by swapping the stream member (and the in-situ timers off meanwhile): swapped back on every exit path,
+// also when the redirected code throws -- otherwise every later call of the context would run on the side stream without its event ordering
+struct StreamSwapGuard {
+    hipStream_t& a; hipStream_t& b; bool& timing; bool saved;
+    StreamSwapGuard(hipStream_t& main_, hipStream_t& side_, bool& timing_on) : a(main_), b(side_), timing(timing_on), saved(timing_on) { std::swap(a, b); timing = false; }
+    ~StreamSwapGuard() { std::swap(a, b); timing = saved; }
+    StreamSwapGuard(const StreamSwapGuard&) = delete;
+    StreamSwapGuard& operator=(const StreamSwapGuard&) = delete;
 };
 
 constexpr int kBlock = 256;          // 4 wavefronts = 4 SELL slices per workgroup

@@ -1116,11 +1116,10 @@ template <class S> void LinSolver::factor_async()
     }
     OPMGPU_HIP(hipEventRecord(ev_factor[0], stream));
     OPMGPU_HIP(hipStreamWaitEvent(factor_stream, ev_factor[0], 0));
-    std::swap(stream, factor_stream);
-    const bool timing = kt.on; kt.on = false;            // (event brackets belong to the main stream)
-    (void)factor<S>(false);
-    kt.on = timing;
-    std::swap(stream, factor_stream);
+    {
+        StreamSwapGuard g(stream, factor_stream, kt.on);  // (event brackets belong to the main stream); restored also if factor() throws
+        (void)factor<S>(false);
+    }
     OPMGPU_HIP(hipEventRecord(ev_factor[1], factor_stream));
     factor_pending = true;
 }

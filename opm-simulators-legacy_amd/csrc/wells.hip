@@ -1049,11 +1049,10 @@ bool BlackoilDevice::wells_prologue_async(bool initial)
     }
     OPMGPU_HIP(hipEventRecord(ev_well[0], stream));               // the state the previous update left
     OPMGPU_HIP(hipStreamWaitEvent(well_stream, ev_well[0], 0));
-    std::swap(stream, well_stream);
-    const bool timing = ls.kt.on; ls.kt.on = false;               // (event brackets belong to the main stream)
-    wells_prologue();
-    ls.kt.on = timing;
-    std::swap(stream, well_stream);
+    {
+        StreamSwapGuard g(stream, well_stream, ls.kt.on);          // (event brackets belong to the main stream); restored also if the prologue throws
+        wells_prologue();
+    }
     OPMGPU_HIP(hipEventRecord(ev_well[1], well_stream));
     well_prologue_done = true;
     return true;

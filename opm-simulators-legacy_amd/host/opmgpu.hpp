@@ -241,20 +241,26 @@ struct NonlinearSolverGpu {
     double relaxIncrement() const { return relax_increment; }
     double relaxRelTol() const { return relax_rel_tol; }
 
-    /// detectOscillations (:221-257): two of the three phase residual norms return to their value of two iterations ago
-    void detectOscillations(const std::vector<std::array<double, 3>>& residual_history, int it, bool& oscillate, bool& stagnate) const
+    /// The rule of NonlinearSolver::detectOscillations (NonlinearSolver_impl.hpp:221-257) in this library's words.  A phase's residual norm
+    /// "swings" when this iteration's value is back within relax_rel_tol of where it stood TWO iterations ago while it differs by more
+    /// than that from LAST iteration's; the update oscillates when at least two of the three phases swing.  It stagnates when no phase's
+    /// norm moved by more than 0.1 % between the two previous iterations.  All differences are relative (to the newest value for the
+    /// swing test, to the oldest for the stagnation test).
+    void detectOscillations(const std::vector<std::array<double, 3>>& norms, int it, bool& oscillate, bool& stagnate) const
     {
-        if (it < 2) { oscillate = false; stagnate = false; return; }
-        stagnate = true;
-        int oscillatePhase = 0;
-        const auto &F0 = residual_history[it], &F1 = residual_history[it - 1], &F2 = residual_history[it - 2];
-        for (int p = 0; p < 3; ++p) {
-            const double d1 = std::abs((F0[p] - F2[p]) / F0[p]);
-            const double d2 = std::abs((F0[p] - F1[p]) / F0[p]);
-            oscillatePhase += (d1 < relax_rel_tol) && (relax_rel_tol < d2);
-            stagnate = stagnate && !(std::abs((F1[p] - F2[p]) / F2[p]) > 1.0e-3);
+        oscillate = false; stagnate = false;
+        if (it < 2) return;
+        const std::array<double, 3>&now = norms[it], &last = norms[it - 1], &before = norms[it - 2];
+        int swinging = 0;
+        bool any_moved = false;
+        for (int ph = 0; ph < 3; ++ph) {
+            const double to_before = std::abs((now[ph] - before[ph]) / now[ph]);
+            const double to_last = std::abs((now[ph] - last[ph]) / now[ph]);
+            if (to_before < relax_rel_tol && relax_rel_tol < to_last) ++swinging;
+            if (std::abs((last[ph] - before[ph]) / before[ph]) > 1.0e-3) any_moved = true;
         }
-        oscillate = oscillatePhase > 1;
+        oscillate = swinging >= 2;
+        stagnate = !any_moved;
     }
 
     int step(BlackoilModelGpu& model) const

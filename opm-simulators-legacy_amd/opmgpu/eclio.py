@@ -8,7 +8,7 @@ published file format: Fortran sequential records (4-byte big-endian length befo
 (8-char keyword, int32 count, 4-char type INTE / REAL / DOUB / LOGI / CHAR / MESS) followed by its data in blocks of at most 1000
 elements (105 for CHAR), all big-endian.  Units METRIC (pressure in bar, rates per day, volumes in m3).  No reference vectors for
 the FILE FORMAT exist in /root/reference (EclipseIO is external): checked here by a reader written against the same description
-(tests/test_eclio.py) -- parity unpinned.
+(tests/test_schedule_eclio.py; one byte-level known answer of the record layout there is independent of that reader) -- parity unpinned.
 """
 import datetime
 import struct
@@ -42,7 +42,7 @@ def write_array(f, name, typ, data):
 
 
 def read_arrays(path):
-    """[(keyword, type, numpy array)] of a unified file (the checker of tests/test_eclio.py; also handy for diffs)"""
+    """[(keyword, type, numpy array)] of a unified file (the checker of tests/test_schedule_eclio.py; also handy for diffs)"""
     out = []
     with open(path, "rb") as f:
         blob = f.read()
@@ -78,10 +78,11 @@ def read_arrays(path):
     return out
 
 
-def _intehead(dims, nactive, date, nwells=0, ncwmax=0, report=0):
+def _intehead(dims, nactive, date, nwells=0, ncwmax=0):
     """INTEHEAD (411 entries; the ones readers look at): [2] units (1 METRIC), [8..10] NX NY NZ, [11] NACTIV, [14] phase indicator
-    (7 = oil + water + gas), [16] NWELLS, [17] NCWMAX, [24..27] NIWELZ NSWELZ NXWELZ NZWELZ, [32..34] NICONZ NSCONZ NXCONZ,
-    [64..66] day month year, [94] simulator (100 = ECLIPSE 100 conventions), [206..208] hour minute microsecond"""
+    (7 = oil + water + gas), [16] NWELLS, [17] NCWMAX (most completions of a well), [24..27] NIWELZ NSWELZ NXWELZ NZWELZ,
+    [32..34] NICONZ NSCONZ NXCONZ, [64..66] day month year, [94] simulator (100 = ECLIPSE 100 conventions).  (The report step number is
+    the SEQNUM keyword's, not an INTEHEAD entry.)"""
     ih = np.zeros(411, np.int32)
     ih[2] = 1
     ih[8], ih[9], ih[10], ih[11] = dims[0], dims[1], dims[2], nactive
@@ -167,7 +168,9 @@ class EclOutput:
         date = self.start + datetime.timedelta(days=self.elapsed)
         with open(self.base + ".UNRST", "ab") as f:
             write_array(f, "SEQNUM", "INTE", [self.report])
-            write_array(f, "INTEHEAD", "INTE", _intehead(self.dims, self.nactive, date, report=self.report))
+            nw = wells.nw if wells is not None else 0
+            ncw = max((wells.connpos[w + 1] - wells.connpos[w] for w in range(nw)), default=0)
+            write_array(f, "INTEHEAD", "INTE", _intehead(self.dims, self.nactive, date, nwells=nw, ncwmax=ncw))
             write_array(f, "LOGIHEAD", "LOGI", np.zeros(121, bool))
             dh = np.zeros(229); dh[0] = self.elapsed
             write_array(f, "DOUBHEAD", "DOUB", dh)

@@ -378,19 +378,22 @@ class NonlinearSolver:
         self.max_iter, self.min_iter = max_iter, min_iter               # SolverParameters::reset (:183-192)
         self.relax_type, self.relax_max, self.relax_increment, self.relax_rel_tol = relax_type, relax_max, relax_increment, relax_rel_tol
 
-    def detectOscillations(self, residual_history, it):
-        """(:221-257) -> (oscillate, stagnate); only the three mass-balance norms take part."""
+    def detectOscillations(self, norms, it):
+        """The rule of NonlinearSolver::detectOscillations (:221-257) -> (oscillate, stagnate); only the three mass-balance norms take part.
+        A phase "swings" when its norm is back within relax_rel_tol (relative to the newest value) of its value two iterations ago but not
+        of last iteration's; two swinging phases = oscillation.  Stagnation = no phase moved by more than 0.1 % between the two previous
+        iterations."""
         if it < 2:
             return False, False
-        F0, F1, F2 = residual_history[it], residual_history[it - 1], residual_history[it - 2]
-        stagnate, n_osc = True, 0
+        now, last, before = norms[it], norms[it - 1], norms[it - 2]
+        swinging, any_moved = 0, False
         with np.errstate(divide="ignore", invalid="ignore"):
-            for p in range(3):
-                d1 = abs(np.float64(F0[p] - F2[p]) / F0[p])
-                d2 = abs(np.float64(F0[p] - F1[p]) / F0[p])
-                n_osc += int((d1 < self.relax_rel_tol) and (self.relax_rel_tol < d2))
-                stagnate = stagnate and not (abs(np.float64(F1[p] - F2[p]) / F2[p]) > 1.0e-3)
-        return n_osc > 1, stagnate
+            for ph in range(3):
+                to_before = abs(np.float64(now[ph] - before[ph]) / now[ph])
+                to_last = abs(np.float64(now[ph] - last[ph]) / now[ph])
+                swinging += int(to_before < self.relax_rel_tol < to_last)
+                any_moved = any_moved or bool(abs(np.float64(last[ph] - before[ph]) / before[ph]) > 1.0e-3)
+        return swinging >= 2, not any_moved
 
     def step(self, model, single_precision=None):
         """(:119-174). Returns (newton_iterations, linear_iterations); raises TooManyIterations."""

@@ -87,7 +87,7 @@ class LocalDomain:
                 continue
             ctrls = wells.controls[w]
             out.add_well(wells.name[w], wells.type[w], wells.depth_ref[w], g2l[cells], wells.WI[wells.connpos[w]:wells.connpos[w + 1]],
-                         wells.comp_frac[w], ctrls[0], allow_cf=wells.allow_cf[w], limits=ctrls[1:])
+                         wells.comp_frac[w], ctrls[0], allow_cf=wells.allow_cf[w], limits=ctrls[1:], current=wells.current0[w])
             self.well_index.append(w)
         return out
 

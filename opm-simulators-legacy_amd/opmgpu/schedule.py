@@ -204,6 +204,9 @@ class Schedule:
                 wtype = W.PRODUCER
             if mode not in ctrls:
                 raise ValueError("well %s: control mode %r has no target in the deck" % (name, mode))
-            current = ctrls.pop(mode)
-            out.add_well(name, wtype, ref, cells, wi, comp, current, limits=list(ctrls.values()))
+            # WellsManager's fixed order (ORAT, WRAT, GRAT, LRAT, [RESV], BHP, THP; injectors RATE, [RESV], BHP, THP) with the deck's
+            # control mode as the index of the current control: updateWellControls switches to the FIRST broken constraint, so the
+            # order decides which one wins when two are broken (and the index goes into the restart file)
+            order = list(ctrls.values())
+            out.add_well(name, wtype, ref, cells, wi, comp, order[0], limits=order[1:], current=list(ctrls).index(mode))
         return out

@@ -54,6 +54,10 @@ class Simulator:
         self.fipnum = self.deck.fipnum()             # REGIONS FIPNUM (None: the field is one region)
         self.out = None
         if output_base:
+            # EclOutput truncates BASE.UNRST / .UNSMRY: a restarted run writing over the files it was just started from would destroy the full run's
+            import os
+            if restart is not None and os.path.abspath(output_base) == os.path.abspath(restart[0]):
+                raise ValueError("output_base %r is the restart source: choose another base name for the restarted run's files" % output_base)
             porv = np.zeros(n); porv[self.deck.active] = self.grid.pv
             tops = self.deck.array("TOPS")[:nx * ny] if self.deck.has("TOPS") and self.deck.array("TOPS").size >= nx * ny else None
             cz = (self.deck.array("COORD"), self.deck.array("ZCORN")) if self.deck.has("ZCORN") else None

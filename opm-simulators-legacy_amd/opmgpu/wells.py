@@ -86,20 +86,29 @@ class Wells:
     def __init__(self):
         self.type, self.depth_ref, self.comp_frac, self.allow_cf = [], [], [], []
         self.connpos, self.cells, self.WI = [0], [], []
-        self.ctrl_type, self.ctrl_target, self.ctrl_distr = [], [], []        # control 0 of each well = its initial current control
+        self.ctrl_type, self.ctrl_target, self.ctrl_distr = [], [], []        # the initial CURRENT control of each well (controls[w][current0[w]])
+        self.current0 = []
         self.controls = []                                                     # all controls of each well (WellControls), control 0 first
         self.name = []
 
-    def add_well(self, name, wtype, depth_ref, cells, WI, comp_frac, control, allow_cf=True, limits=()):
-        """`control` is the well's initial current control; `limits` are its other controls -- inequality constraints that
-        updateWellControls switches to when broken (e.g. a BHP limit on a rate-controlled well)."""
+    def add_well(self, name, wtype, depth_ref, cells, WI, comp_frac, control, allow_cf=True, limits=(), current=0):
+        """The well's controls are [control] + limits IN THAT ORDER; `current` is the index of its initial current control in that list
+        (default: `control`), the others are inequality constraints that updateWellControls switches to when broken (e.g. a BHP limit
+        on a rate-controlled well).  The order matters: updateWellControls switches to the FIRST broken constraint
+        (StandardWells_impl.hpp:709-780), and WellsManager keeps a fixed order (ORAT, WRAT, GRAT, LRAT, RESV, BHP, THP) with the current
+        control as an index into it -- opmgpu/schedule.py builds its wells that way."""
         self.name.append(name); self.type.append(wtype); self.depth_ref.append(float(depth_ref))
         self.comp_frac.append(np.asarray(comp_frac, float)); self.allow_cf.append(bool(allow_cf))
         self.cells += [int(c) for c in cells]; self.WI += [float(w) for w in np.broadcast_to(WI, (len(cells),))]
         self.connpos.append(len(self.cells))
-        self.ctrl_type.append(control[0]); self.ctrl_target.append(float(control[1]))
-        self.ctrl_distr.append(np.asarray(control[2] if len(control) > 2 and control[2] is not None else (0, 0, 0), float))
-        self.controls.append([_ctrl(control)] + [_ctrl(c) for c in limits])
+        ctrls = [_ctrl(control)] + [_ctrl(c) for c in limits]
+        if not 0 <= current < len(ctrls):
+            raise ValueError("well %s: current control %d out of range" % (name, current))
+        cur = ctrls[current]
+        self.ctrl_type.append(cur[0]); self.ctrl_target.append(float(cur[1]))
+        self.ctrl_distr.append(np.asarray(cur[2], float))
+        self.controls.append(ctrls)
+        self.current0.append(int(current))
         return self
 
     def control_arrays(self):
@@ -135,7 +144,7 @@ class WellState:
         nw = wells.nw
         self.bhp, self.qs = np.zeros(nw), np.zeros((nw, 3))
         self.perf_press = np.zeros(wells.nperf); self.perf_rates = np.zeros((wells.nperf, 3))
-        self.current = np.zeros(nw, np.int32)          # currentControls(): index into the well's controls
+        self.current = np.asarray(getattr(wells, "current0", None) or np.zeros(nw), np.int32).copy()          # currentControls(): index into the well's controls
         self.thp = np.zeros(nw)
         for w in range(nw):
             p0 = cell_pressure[wells.cells[wells.connpos[w]]]

@@ -264,3 +264,40 @@ def test_fipnum_regions_reach_the_report_steps(tmp_path):
     last = reps[-1]["fip"]
     assert np.allclose(last[:, :6].sum(0), field[0, :6] - cells[:6, -4:].sum(1), rtol=1e-12)      # the four cells outside every region
     assert last[:, 6].min() > 50e5 and last[:, 6].max() < 600e5
+
+
+def test_record_layout_known_answer(tmp_path):
+    """Byte-level known answer of the file format, independent of eclio.read_arrays: Fortran sequential records with 4-byte
+    big-endian length markers, a 16-byte header record (8-char keyword, int32 count, 4-char type), data in blocks of at most 1000
+    elements (105 for CHAR), everything big-endian -- parsed here with struct only."""
+    import struct
+    path = tmp_path / "X.BIN"
+    vals = np.arange(2500, dtype=np.float32) * 0.5
+    names = ["W%05d" % i for i in range(106)]
+    with open(path, "wb") as f:
+        eclio.write_array(f, "PRESSURE", "REAL", vals)
+        eclio.write_array(f, "WGNAMES", "CHAR", names)
+        eclio.write_array(f, "INTEHEAD", "INTE", [7, -3])
+    raw = open(path, "rb").read()
+    pos = 0
+
+    def record():
+        nonlocal pos
+        n, = struct.unpack(">i", raw[pos:pos + 4]); body = raw[pos + 4:pos + 4 + n]; tail, = struct.unpack(">i", raw[pos + 4 + n:pos + 8 + n])
+        assert tail == n
+        pos += 8 + n
+        return body
+
+    h = record()
+    assert len(h) == 16 and h[:8] == b"PRESSURE" and struct.unpack(">i", h[8:12])[0] == 2500 and h[12:] == b"REAL"
+    blocks = [record() for _ in range(3)]
+    assert [len(b) for b in blocks] == [4000, 4000, 2000]
+    got = np.frombuffer(b"".join(blocks), dtype=">f4")
+    assert np.array_equal(got, vals) and struct.unpack(">f", blocks[1][:4])[0] == 500.0
+    h = record()
+    assert h[:8] == b"WGNAMES " and struct.unpack(">i", h[8:12])[0] == 106 and h[12:] == b"CHAR"
+    blocks = [record() for _ in range(2)]
+    assert [len(b) for b in blocks] == [105 * 8, 8] and blocks[0][:8] == b"W00000  " and blocks[1] == b"W00105  "
+    h = record()
+    assert h[:8] == b"INTEHEAD" and struct.unpack(">i", h[8:12])[0] == 2 and h[12:] == b"INTE"
+    assert struct.unpack(">ii", record()) == (7, -3) and pos == len(raw)

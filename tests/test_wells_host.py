@@ -261,3 +261,37 @@ def test_thp_controlled_producer(oracle):
     assert ws.bhp[1] == pytest.approx(want, rel=1e-7)
     assert ws.thp[1] == pytest.approx(30 * decks.BAR, rel=1e-5)
     assert 150 * decks.BAR < ws.bhp[1] < 250 * decks.BAR and ws.qs[1, 1] < 0
+
+
+def test_first_broken_constraint_wins_in_wellsmanagers_order(tmp_path):
+    """updateWellControls switches to the FIRST broken constraint (StandardWells_impl.hpp:709-780), so the order of a well's controls
+    decides which one wins when two are broken.  WellsManager keeps a fixed order (ORAT, WRAT, GRAT, LRAT, RESV, BHP, THP) and stores the
+    current control as an index into it; opmgpu/schedule.py builds its wells the same way: a producer on BHP control with a
+    WRAT and an ORAT limit both broken goes to ORAT (index 0), not to whichever limit the deck happens to list last."""
+    from opmgpu import deck as deckmod, schedule
+    src = open(os.path.join(GOLD, "decks", "SCHEDULE_SMALL.DATA")).read()
+    # PROD1: current control BHP (index 2 of ORAT, WRAT, BHP), limits ORAT 150 and WRAT 20
+    src = src.replace(" 'PROD1' 'OPEN' 'ORAT' 150 4* 180 /", " 'PROD1' 'OPEN' 'BHP' 150 20 3* 180 /", 1)
+    path = tmp_path / "TWO_LIMITS.DATA"
+    path.write_text(src)
+    d = deckmod.read_deck(str(path))
+    g = d.grid()
+    n = g.nc
+    dx, dy, dz = d._cell_sizes()
+    s = schedule.Schedule(d, g, perm_md=(d.array("PERMX", n), d.array("PERMY", n)), dz=dz.ravel(), dxdy=(dx.ravel(), dy.ravel()), ntg=np.ones(n))
+    wl = s.wells(0)
+    w = wl.name.index("PROD1")
+    types = [(c[0], tuple(c[2])) for c in wl.controls[w]]
+    assert types == [(W.SURFACE_RATE, (0.0, 1.0, 0.0)), (W.SURFACE_RATE, (1.0, 0.0, 0.0)), (W.BHP, (0.0, 0.0, 0.0))]      # ORAT, WRAT, BHP
+    assert wl.current0[w] == 2 and wl.ctrl_type[w] == W.BHP and wl.ctrl_target[w] == pytest.approx(180e5)
+    ws = W.WellState(wl, np.full(g.nc, 250e5))
+    assert ws.current[w] == 2 and ws.bhp[w] == pytest.approx(180e5)
+    # the well produces far more oil AND water than its limits allow: both rate constraints are broken
+    ws.qs[w] = [-100.0 / 86400.0, -400.0 / 86400.0, 0.0]
+    wh = W.StandardWellsHost(wl, g.z, d.tables().surface_density[0])
+    switched = wh.update_well_controls(ws)
+    mine = [x for x in switched if x[0] == w]
+    assert mine[0] == (w, 2, 0)                  # ORAT (first in the fixed order) wins the first switch, not WRAT
+    # ... its target becomes the oil rate; the water limit is still broken then, so the loop goes on to WRAT and rests there
+    assert mine[1:] == [(w, 0, 1)] and ws.current[w] == 1
+    assert ws.qs[w, 1] == pytest.approx(-150.0 / 86400.0) and ws.qs[w, 0] == pytest.approx(-20.0 / 86400.0)
