@@ -505,7 +505,7 @@ __global__ __launch_bounds__(kBlock) void k_cell_values(int nb, int nbp, DevTabl
 // bit (+: the row is c1, ngrad coefficient +1; NaN: not a connection -- the fill of an explicit well clique), g (z_c1 - z_c2), the
 // threshold pressure, and the index of the transposed entry (tpos).  All four are read coalesced at known addresses: the only dependent
 // loads of the loop are the neighbour's values.
-template <class MS, int WAVES, bool LDS>
+template <class MS, int WAVES, bool LDS, bool BATCH>
 __global__ __launch_bounds__(kBlock, WAVES) void k_assemble_rows(int xm, int nb, int nbp, DevTables DT, const int32_t* __restrict__ pvtnum, const int32_t* __restrict__ satnum,
                                                           const double* __restrict__ pv, const double* __restrict__ p, const double* __restrict__ sw,
                                                           const double* __restrict__ sg, const double* __restrict__ rs, const double* __restrict__ rv,
@@ -599,6 +599,12 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_assemble_rows(int xm, int nb,
         np_[0] = vals[long(VP_PW) * nbp + nbr]; np_[1] = p[nbr]; np_[2] = vals[long(VP_PG) * nbp + nbr];
 #pragma unroll
         for (int a = 0; a < 3; ++a) nrho[a] = vals[long(VP_RHO + a) * nbp + nbr];
+        double nU[3] = { 0.0, 0.0, 0.0 }, nRs = 0.0, nRv = 0.0;
+        if (BATCH) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) nU[a] = vals[long(VP_U + a) * nbp + nbr];
+            nRs = vals[long(VP_RS) * nbp + nbr]; nRv = vals[long(VP_RV) * nbp + nbr];
+        }
         double Tdh[3], ddh[3][3];
         bool own_up[3];
 #pragma unroll
@@ -618,12 +624,19 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_assemble_rows(int xm, int nb,
             own_up[a] = ((dh >= 0.0) ? 0 : 1) == side;                   // upwind cell = c1 if dh >= 0 else c2
             Tdh[a] = Tf * dh;
         }
-        // upwind-dependent values of the neighbour, one batch
+        // upwind-dependent values of the neighbour.  BATCH: all five loaded with the pressures and densities above (one dependent round trip
+        // per connection instead of two; the lines are fetched by some lane of the wave anyway); otherwise only the ones the upwinding asks for
         double Uv[3] = { oU[0], oU[1], oU[2] }, rsu = oRs, rvu = oRv;
+        if (BATCH) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) if (!own_up[a]) Uv[a] = vals[long(VP_U + a) * nbp + nbr];
-        if (!own_up[1]) rsu = vals[long(VP_RS) * nbp + nbr];
-        if (!own_up[2]) rvu = vals[long(VP_RV) * nbp + nbr];
+            for (int a = 0; a < 3; ++a) Uv[a] = own_up[a] ? oU[a] : nU[a];
+            rsu = own_up[1] ? oRs : nRs; rvu = own_up[2] ? oRv : nRv;
+        } else {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) if (!own_up[a]) Uv[a] = vals[long(VP_U + a) * nbp + nbr];
+            if (!own_up[1]) rsu = vals[long(VP_RS) * nbp + nbr];
+            if (!own_up[2]) rvu = vals[long(VP_RV) * nbp + nbr];
+        }
         double F[3], dF[3][3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -722,6 +735,21 @@ __global__ __launch_bounds__(kBlock) void k_conv_final(int nblocks, const double
     if (lane == 0) sm[w] = s_;
     __syncthreads();
     if (threadIdx.x == 0) out[q] = is_max ? fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3])) : (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+// decomposed runs: the 7 sums and 6 (+ 6) maxima of getConvergence through ONE sum-all-reduce (see BlackoilDevice::convergence).
+// phase 0: table[rank][:] = red[:], every other row zero; phase 1: red[q] = sum (q < 7) or max over the ranks' rows, in rank order
+__global__ __launch_bounds__(kBlock) void k_conv_gather(int phase, int nv, int nranks, int rank, double* __restrict__ red, double* __restrict__ table)
+{
+    if (phase == 0) {
+        for (int i = threadIdx.x; i < nranks * nv; i += kBlock) table[i] = (i / nv == rank) ? red[i % nv] : 0.0;
+        return;
+    }
+    for (int q = threadIdx.x; q < nv; q += kBlock) {
+        double v = table[q];
+        for (int r = 1; r < nranks; ++r) { const double x = table[r * nv + q]; v = conv_is_max(q) ? fmax(v, x) : v + x; }
+        red[q] = v;
+    }
 }
 
 // updateState (BlackoilModelBase_impl.hpp:1147-1389), one thread per cell
@@ -1433,7 +1461,12 @@ template <class MS> void BlackoilDevice::assemble_kernels(double dt, bool initia
     // (profiles/r03_asm_waves_ab.log): 0.232 against 0.240 ms with a double Jacobian, 0.181 against 0.206 ms with a float one
     static const int waves = std::getenv("OPMGPU_ASM_WAVES") ? std::atoi(std::getenv("OPMGPU_ASM_WAVES")) : 3;
     const bool lds = tab_lds_words() > 0;
-    auto kern = waves == 3 ? (lds ? k_assemble_rows<MS, 3, true> : k_assemble_rows<MS, 3, false>) : (lds ? k_assemble_rows<MS, 2, true> : k_assemble_rows<MS, 2, false>);
+    // all ten neighbour values in one batch (default; measured 0.202 against 0.211 ms with a double Jacobian, profiles/r03_asm_batch_ab.log) or
+    // the upwind-dependent five only when needed (OPMGPU_ASM_BATCH=0)
+    static const bool batch = !(std::getenv("OPMGPU_ASM_BATCH") && std::atoi(std::getenv("OPMGPU_ASM_BATCH")) == 0);
+    auto kern = !lds ? k_assemble_rows<MS, 2, false, false>
+                     : (waves == 3 ? (batch ? k_assemble_rows<MS, 3, true, true> : k_assemble_rows<MS, 3, true, false>)
+                                   : (batch ? k_assemble_rows<MS, 2, true, true> : k_assemble_rows<MS, 2, true, false>));
     hipLaunchKernelGGL(kern, dim3(grid8_for(nc)), dim3(kBlock), tab_lds_bytes(), stream, xcd_mode(), nc, P.nbp, dto_, d_pvtnum.p, d_satnum.p, d_pv.p,
                        d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, 1.0 / dt, int(initial), sc[0], sc[1], sc[2],
                        ls.dp.slice_ptr.p, ls.dp.col.p, ls.dp.rowlen.p, ls.dp.nlower.p, ls.dp.tpos.p, d_tr_e.p, d_gdz_e.p, use_thpres ? d_thp_e.p : (const double*)nullptr,
@@ -1505,7 +1538,16 @@ int BlackoilDevice::convergence(double dt, double* B3, double* CNV3, double* MB3
     // max-all-reduce in the slots 13..18 -- well_convergence() then needs neither its own all-reduce nor a stream synchronisation
     const bool wells_ride = ls.comm && has_device_wells();
     if (wells_ride) well_conv_pack(d_red.p + 13);
-    if (ls.comm) { ls.comm->allreduce_sum(d_red.p, 7, stream); ls.comm->allreduce_max(d_red.p + 7, wells_ride ? 12 : 6, stream); }
+    if (ls.comm) {
+        // sums (7) and maxima (6 + the wells' 6) in ONE all-reduce: every rank places its numbers in its own slot of a zeroed
+        // [ranks][nv] table, the table is sum-all-reduced (= gathered), and every rank reduces the columns itself in rank order --
+        // the same bits everywhere, and one small-message latency (~13 us over RCCL) instead of two per Newton iteration
+        const int nv = wells_ride ? 19 : 13, nr = ls.comm->num_ranks();
+        d_gather.ensure(size_t(nr) * 19);
+        hipLaunchKernelGGL(k_conv_gather, dim3(1), dim3(kBlock), 0, stream, 0, nv, nr, ls.comm->my_rank(), d_red.p, d_gather.p);
+        ls.comm->allreduce_sum(d_gather.p, nr * nv, stream);
+        hipLaunchKernelGGL(k_conv_gather, dim3(1), dim3(kBlock), 0, stream, 1, nv, nr, ls.comm->my_rank(), d_red.p, d_gather.p);
+    }
     // (polled host-mapped copy: no stream synchronisation); the device wells' residuals and error flags come along for well_convergence()
     const void *we = nullptr, *wf = nullptr; int nwe = 0;
     const bool with_wells = !ls.comm && well_words_sources(we, nwe, wf) && 26 + nwe + 1 <= LinSolver::kPubWords;

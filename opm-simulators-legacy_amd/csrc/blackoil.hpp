@@ -156,6 +156,7 @@ private:
     DevArray<int8_t> d_hc;
     // device: work
     void launch_cell_values();
+    DevArray<double> d_gather;      // decomposed runs: [ranks][19] table of getConvergence's sums and maxima (one all-reduce)
     DevArray<double> d_vals, d_accum0, d_R, d_binv, d_dx, d_dx_old, d_red, d_perf, d_rhs_extra;
     double* h_red = nullptr;
     std::vector<double> hbuf;

@@ -107,6 +107,9 @@ template <class S> int solve_loaded(opmgpu_ctx* c, bool matrix_changed, SolveRes
 {
     LinSolver& ls = *c->ls;
     ls.prepare<S>(matrix_changed);
+    // the reference's CPR formulation (whole-system L transform, 200-bar pressure row, ||L r|| stopping) as an option; once per matrix
+    if (c->prm.use_cpr && c->prm.cpr_reference_transform) ls.cpr_reference_transform<S>();
+    else { ls.border_weights = nullptr; ls.border_colscale = 1.0; }
     // next to the pressure stage's set-up (cpr_prepare, inside the solver); not in the emulated-decomposition diagnostics, whose cut copy of
     // the matrix is built lazily by whichever of the two asks first
     static const bool after_rows = !(std::getenv("OPMGPU_FACTOR_AFTER_ROWS") && std::atoi(std::getenv("OPMGPU_FACTOR_AFTER_ROWS")) == 0);      // measured +0.5 %
@@ -215,7 +218,7 @@ int opmgpu_assemble(opmgpu_ctx* c, double dt, int initial, const double* p, cons
             Timed t(c, PH_ASSEMBLE);
             c->model->assemble(dt, initial != 0);
         }
-        c->matrix_loaded = true; c->factored = false; c->cur_single = -1;
+        c->matrix_loaded = true; c->factored = false; c->cur_single = -1; c->ls->ref_transformed = false;
         return int(OPMGPU_OK);
     });
 }
@@ -543,7 +546,7 @@ int opmgpu_load_bsr(opmgpu_ctx* c, int nb, const int32_t* rowptr, const int32_t*
         c->ls->load_host_bsr(val9);
         if (single_precision) c->ls->prepare<float>(true); else c->ls->prepare<double>(true);
         c->cur_single = single_precision ? 1 : 0;
-        c->matrix_loaded = true; c->factored = false;
+        c->matrix_loaded = true; c->factored = false; c->ls->ref_transformed = false;
         return int(OPMGPU_OK);
     });
 }
@@ -671,7 +674,7 @@ int opmgpu_time_kernel(opmgpu_ctx* c, int kernel, int reps, double* ms_per_launc
         if (kernel == OPMGPU_K_ASSEMBLE || kernel == OPMGPU_K_PROPS) {
             if (!c->model || !c->model->has_state) return fail(c, OPMGPU_EINVAL, "no model / state");
             *ms_per_launch = c->model->time_assemble(reps, kernel == OPMGPU_K_PROPS);
-            c->factored = false; c->cur_single = -1; c->matrix_loaded = true;
+            c->factored = false; c->cur_single = -1; c->matrix_loaded = true; c->ls->ref_transformed = false;
             return int(OPMGPU_OK);
         }
         const int st = ensure_prepared(c); if (st) return st;

@@ -813,7 +813,7 @@ __global__ __launch_bounds__(kBlock) void k_cpr_sum_eqs(int nb, int nbp, const S
 // Eliminating the unknown again gives the pressure part of the explicit Schur complement the reference forms (minus the wellbore-mixture
 // terms) -- without its clique fill.  One workgroup per well; out = [bcol (nperf) | crow (nperf) | dw (nw)].
 template <class S>
-__global__ __launch_bounds__(kBlock) void k_cpr_border(LowRankOp lr, int nbp, const S* __restrict__ w, S* __restrict__ out)
+__global__ __launch_bounds__(kBlock) void k_cpr_border(LowRankOp lr, int nbp, const S* __restrict__ w, S* __restrict__ out, double colscale = 1.0)
 {
     __shared__ double sm[4];
     const int k = blockIdx.x;
@@ -828,7 +828,7 @@ __global__ __launch_bounds__(kBlock) void k_cpr_border(LowRankOp lr, int nbp, co
             cr += g[a] * Fs[3 * a];
             acc[0] += g[a] * Fs[18 + a];
         }
-        out[j] = S(bc); out[lr.nperf + j] = S(cr);
+        out[j] = S(colscale * bc); out[lr.nperf + j] = S(cr);
     }
     block_sum<1>(acc, sm);
     if (threadIdx.x == 0) {
@@ -1646,6 +1646,103 @@ template <class S> void LinSolver::cpr_reweigh_rows(const int32_t* d_rows, int n
                        dp.tpos.p, matrix<S>(), work<S>().cprw.p, cpr_weight_mode);
 }
 
+// ---- the reference's CPR formulation as an option (opmgpu_params.cpr_reference_transform) ----
+// L of a row from its 0/1 dominance weights (formEllipticSystem's l1, l21 / l22, l31 / l33, NewtonIterationUtilities.cpp:218-262, in this
+// library's equation order water, oil, gas; the reference swaps oil to the front first, so "the first equation" there is the oil slot):
+//   row 0 = pscale * sum of the dominant equations                              (pressure equation; pscale = 200 bar, CPR.cpp:117-121)
+//   row 1 = the water equation -- or the oil equation, if oil is weak and water at least as dominant as gas (l21)
+//   row 2 = the gas equation   -- or the oil equation, if oil is weak and gas more dominant than water (l31)
+// (a weak oil equation with nothing else dominant stays in the sum alone: the weights already say so, no swap)
+template <class S>
+__device__ __forceinline__ void ref_L(const S* __restrict__ w, int nbp, int row, double pscale, double (&L)[9])
+{
+    const double w0 = double(w[row]), w1 = double(w[nbp + row]), w2 = double(w[2 * long(nbp) + row]);
+    const bool oil_weak = w1 == 0.0;
+    const bool l21 = oil_weak && w0 >= w2, l31 = oil_weak && !(w0 >= w2);
+    L[0] = pscale * w0; L[1] = pscale * w1; L[2] = pscale * w2;
+    L[3] = l21 ? 0.0 : 1.0; L[4] = l21 ? 1.0 : 0.0; L[5] = 0.0;
+    L[6] = 0.0; L[7] = l31 ? 1.0 : 0.0; L[8] = l31 ? 0.0 : 1.0;
+}
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_ref_transform_rows(int nb, int nbp, double pscale, const int32_t* __restrict__ slice_ptr, const int16_t* __restrict__ rowlen,
+                                                               const S* __restrict__ w, S* __restrict__ A)
+{
+    const int row = blockIdx.x * kBlock + threadIdx.x;
+    if (row >= nb) return;
+    double L[9];
+    ref_L<S>(w, nbp, row, pscale, L);
+    const int base = slice_ptr[row >> 6], lane = row & 63, len = rowlen[row];
+    for (int k = 0; k < len; ++k) {
+        S* b = A + long(base + k) * 576 + lane;
+        double m[9], o[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) m[q] = double(b[q * 64]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int v = 0; v < 3; ++v) o[3 * i + v] = L[3 * i] * m[v] + L[3 * i + 1] * m[3 + v] + L[3 * i + 2] * m[6 + v];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) b[q * 64] = S(o[q]);
+    }
+}
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_ref_transform_vec(int nb, int nbp, double pscale, const S* __restrict__ w, S* __restrict__ b)
+{
+    const int row = blockIdx.x * kBlock + threadIdx.x;
+    if (row >= nb) return;
+    double L[9];
+    ref_L<S>(w, nbp, row, pscale, L);
+    const double r0 = double(b[row]), r1 = double(b[nbp + row]), r2 = double(b[2 * long(nbp) + row]);
+    b[row] = S(L[0] * r0 + L[1] * r1 + L[2] * r2); b[nbp + row] = S(L[3] * r0 + L[4] * r1 + L[5] * r2); b[2 * long(nbp) + row] = S(L[6] * r0 + L[7] * r1 + L[8] * r2);
+}
+// the wells' low-rank part A += P_w Q_w: the rows of P ([nperf][3][7]) belong to the perforated cells' equations
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_ref_transform_lowrank(LowRankOp lr, int nbp, double pscale, const S* __restrict__ w, double* __restrict__ P)
+{
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= lr.nperf) return;
+    double L[9];
+    ref_L<S>(w, nbp, lr.perf_row[j], pscale, L);
+    double* p = P + 21 * long(j);
+    double m[21];
+    for (int q = 0; q < 21; ++q) m[q] = p[q];
+    for (int i = 0; i < 3; ++i) for (int k = 0; k < 7; ++k) p[7 * i + k] = L[3 * i] * m[k] + L[3 * i + 1] * m[7 + k] + L[3 * i + 2] * m[14 + k];
+}
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_unit_weights(int nbp, S* __restrict__ w)
+{
+    const int row = blockIdx.x * kBlock + threadIdx.x;
+    if (row >= nbp) return;
+    w[row] = S(1); w[nbp + row] = S(0); w[2 * long(nbp) + row] = S(0);
+}
+
+template <class S> void LinSolver::cpr_reference_transform()
+{
+    SolverWork<S>& w = work<S>();
+    const double pscale = 200.0e5;               // 200 * unit::barsa (NewtonIterationBlackoilCPR.cpp:117)
+    const int g = grid_for(plan.nb);
+    if (!ref_transformed) {
+        w.cprw.alloc(3 * size_t(plan.nbp)); w.cprw_orig.alloc(3 * size_t(plan.nbp));
+        if (!weights_from_assembly)
+            hipLaunchKernelGGL((k_cpr_weights<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, plan.nbp, dp.slice_ptr.p, dp.rowlen.p, dp.nlower.p,
+                               dp.tpos.p, matrix<S>(), w.cprw.p, cpr_weight_mode);
+        OPMGPU_HIP(hipMemcpyAsync(w.cprw_orig.p, w.cprw.p, 3 * size_t(plan.nbp) * sizeof(S), hipMemcpyDeviceToDevice, stream));
+        hipLaunchKernelGGL((k_ref_transform_rows<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, plan.nbp, pscale, dp.slice_ptr.p, dp.rowlen.p, (const S*)w.cprw_orig.p,
+                           const_cast<S*>(matrix<S>()));
+        if (lowrank.nw > 0 && lowrank.P)
+            hipLaunchKernelGGL((k_ref_transform_lowrank<S>), dim3(grid_for(lowrank.nperf)), dim3(kBlock), 0, stream, lowrank, plan.nbp, pscale, (const S*)w.cprw_orig.p,
+                               const_cast<double*>(lowrank.P));
+        // the pressure equation is row 0 of every transformed block: unit weights for the pressure stage (its extraction, restriction and
+        // coarse space); the bordered well column is formed from the ORIGINAL weights and carries the pressure row's scaling
+        hipLaunchKernelGGL((k_unit_weights<S>), dim3(grid_for(plan.nbp)), dim3(kBlock), 0, stream, plan.nbp, w.cprw.p);
+        weights_from_assembly = true;
+        border_weights = w.cprw_orig.p; border_colscale = pscale;
+        ref_transformed = true;
+        pre_stale = true;
+    }
+    hipLaunchKernelGGL((k_ref_transform_vec<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, plan.nbp, pscale, (const S*)w.cprw_orig.p, w.b.p);
+}
+
 template <class S> void LinSolver::cpr_prepare()
 {
     SolverWork<S>& w = work<S>();
@@ -1715,7 +1812,7 @@ template <class S> void LinSolver::cpr_prepare()
         new_step_hint = false;
         refreshed = refresh;
         if (w.amg->border_nw() > 0)
-            hipLaunchKernelGGL((k_cpr_border<S>), dim3(lowrank.nw), dim3(kBlock), 0, stream, lowrank, plan.nbp, (const S*)w.cprw.p, w.amg->levels[0]->val.p + w.amg->levels[0]->nentries);
+            hipLaunchKernelGGL((k_cpr_border<S>), dim3(lowrank.nw), dim3(kBlock), 0, stream, lowrank, plan.nbp, border_weights ? (const S*)border_weights : (const S*)w.cprw.p, w.amg->levels[0]->val.p + w.amg->levels[0]->nentries, border_colscale);
         // The factorisation (HBM-bound, 140 us, on its own stream) is needed by the first ILU0 sweep only, i.e. behind the hierarchy set-up
         // AND the first V-cycle.  It starts when the level 0 -> 1 Galerkin sums are done -- the one bandwidth-heavy kernel of the chain,
         // which it would slow from 60 to 100 us -- and runs next to the small levels' sums and the first cycle (latency-bound launches).
@@ -1743,7 +1840,7 @@ template <class S> void LinSolver::cpr_prepare()
             OPMGPU_HIP(hipMemcpyAsync(bs.connpos.data(), lowrank.connpos, (bs.nw + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
             OPMGPU_HIP(hipMemcpyAsync(bs.perf_row.data(), lowrank.perf_row, bs.nperf * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
             DevArray<S> bt; bt.alloc(2 * size_t(bs.nperf) + bs.nw);
-            hipLaunchKernelGGL((k_cpr_border<S>), dim3(lowrank.nw), dim3(kBlock), 0, stream, lowrank, plan.nbp, (const S*)w.cprw.p, bt.p);
+            hipLaunchKernelGGL((k_cpr_border<S>), dim3(lowrank.nw), dim3(kBlock), 0, stream, lowrank, plan.nbp, border_weights ? (const S*)border_weights : (const S*)w.cprw.p, bt.p, border_colscale);
             std::vector<S> hb(bt.n);
             bt.download(hb.data(), bt.n, stream);
             OPMGPU_HIP(hipStreamSynchronize(stream));
@@ -1755,7 +1852,7 @@ template <class S> void LinSolver::cpr_prepare()
     hipLaunchKernelGGL((k_extract_pressure<S>), dim3(grid_for(plan.nbp)), dim3(kBlock), 0, stream, plan.nb, plan.nbp, dp.slice_ptr.p, (const S*)w.cprw.p, ((emulate_what & 2) ? pre_matrix<S>() : matrix<S>()),
                        w.amg->levels[0]->val.p);
     if (w.amg->border_nw() > 0)
-        hipLaunchKernelGGL((k_cpr_border<S>), dim3(lowrank.nw), dim3(kBlock), 0, stream, lowrank, plan.nbp, (const S*)w.cprw.p, w.amg->levels[0]->val.p + w.amg->levels[0]->nentries);
+        hipLaunchKernelGGL((k_cpr_border<S>), dim3(lowrank.nw), dim3(kBlock), 0, stream, lowrank, plan.nbp, border_weights ? (const S*)border_weights : (const S*)w.cprw.p, w.amg->levels[0]->val.p + w.amg->levels[0]->nentries, border_colscale);
     w.amg->galerkin();
     new_step_hint = false; refreshed = true;
     if (coarse_nsub >= 1) { coarse_begin<S>(); coarse_setup<S>(false); }
@@ -2216,14 +2313,16 @@ __global__ __launch_bounds__(kBlock) void k_gm_multidot(long n, int nbp, const i
 {
     __shared__ double sm[32];
     if (ctl->done) return;
-    for (int k0 = 0; k0 < cnt; k0 += 8) {
+    // slot cnt: the owned part of ||w||^2 -- with the projections h_k of an orthonormal basis, ||w - sum h_k v_k||^2 = ||w||^2 - sum h_k^2
+    // (Pythagoras), so the column's norm needs no second all-reduce (k_gm_cgs_update decides whether the difference is trustworthy)
+    for (int k0 = 0; k0 < cnt + 1; k0 += 8) {
         double acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-        const int nk = cnt - k0 < 8 ? cnt - k0 : 8;
+        const int nk = cnt + 1 - k0 < 8 ? cnt + 1 - k0 : 8;
         for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) {
             if (!mask[i % nbp]) continue;
             const double wi = double(w[i]);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) if (u < nk) acc[u] += wi * double(kry[long(k0 + u) * n + i]);
+            for (int u = 0; u < 8; ++u) if (u < nk) acc[u] += wi * ((k0 + u < cnt) ? double(kry[long(k0 + u) * n + i]) : wi);
         }
         block_sum<8>(acc, sm);
         if (threadIdx.x == 0) for (int u = 0; u < nk; ++u) parts[long(k0 + u) * gridDim.x + blockIdx.x] = acc[u];
@@ -2243,12 +2342,22 @@ __global__ __launch_bounds__(kBlock) void k_sum_partials_multi(const double* __r
 template <class S>
 __global__ __launch_bounds__(kBlock) void k_gm_cgs_update(long n, int nbp, const int8_t* __restrict__ mask, int cnt, int m, int col, const double* __restrict__ h,
                                                           double* __restrict__ H, const S* __restrict__ kry, S* __restrict__ w, double* __restrict__ parts_out,
-                                                          const SolveCtl* __restrict__ ctl)
+                                                          const SolveCtl* __restrict__ ctl, double* __restrict__ pyth = nullptr)
 {
     __shared__ double sm[8];
     __shared__ S hs[64];
     if (ctl->done) return;
     for (int k = threadIdx.x; k < cnt; k += kBlock) { hs[k] = S(h[k]); if (blockIdx.x == 0) H[k * m + col] = h[k]; }
+    if (pyth && blockIdx.x == 0 && threadIdx.x == 0) {
+        // ||w_new||^2 = ||w||^2 - sum h_k^2 from the all-reduced numbers (h[cnt] = ||w||^2).  The difference loses relative accuracy as
+        // w falls into the span of the basis -- eps ||w||^2 / rest, i.e. ~1 % at rest = 1e-5 ||w||^2 with float vectors -- which is the
+        // column that ends the solve: its entry only feeds the residual estimate |s_{i+1}|, a 1 % error there moves no stopping decision.
+        // (A lucky breakdown, rest <= 0 by rounding, is clamped: the estimate becomes ~0 and the solve stops.)
+        double s2 = 0.0;
+        for (int k = 0; k < cnt; ++k) s2 += h[k] * h[k];
+        const double rest = h[cnt] - s2;
+        pyth[0] = rest > 1e-28 * h[cnt] ? rest : 1e-28 * h[cnt];
+    }
     __syncthreads();
     double acc[1] = { 0.0 };
     for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) {
@@ -2438,7 +2547,9 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
     int verify_rounds = 0;
     static const bool cgs_on = !(std::getenv("OPMGPU_GMRES_CGS") && std::atoi(std::getenv("OPMGPU_GMRES_CGS")) == 0);
     const bool cgs = comm != nullptr && cgs_on && m <= 63;
-    if (cgs) cgs_parts.alloc(size_t(m + 1) * gv + size_t(m + 1));
+    if (cgs) cgs_parts.alloc(size_t(m + 2) * gv + size_t(m + 2));
+    // OPMGPU_GMRES_PYTH=0: the column's norm by its own all-reduce (two per column) instead of Pythagoras (one)
+    static const bool cgs_pyth = !(std::getenv("OPMGPU_GMRES_PYTH") && std::atoi(std::getenv("OPMGPU_GMRES_PYTH")) == 0);
     if (flex) w.kryz.alloc(size_t(m) * n);
     gmbuf.alloc(size_t(m + 1) * m + (m + 1) + 3 * m + 8);
     gmbuf.zero(stream);
@@ -2488,7 +2599,7 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
     // (OPMGPU_GMRES_SPECULATE=1 switches it on)
     static const bool speculate = std::getenv("OPMGPU_GMRES_SPECULATE") && std::atoi(std::getenv("OPMGPU_GMRES_SPECULATE")) != 0;
     while (j <= maxit && !stop) {
-        int i = 0;
+        int i = 0, cycle_misses = 0;
         bool product_enqueued = false;
         for (; i < m && j <= maxit && !stop; ++i, ++j) {
             hipEvent_t kt_a;
@@ -2511,13 +2622,18 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
                 // decomposed: classical Gram-Schmidt, two all-reduces per column (k_gm_multidot)
                 const int cnt = i + 1;
                 hipLaunchKernelGGL((k_gm_multidot<S>), dim3(gv), dim3(kBlock), 0, stream, n, plan.nbp, mask, cnt, (const S*)w.kry.p, (const S*)w.t.p, cgs_parts.p, (const SolveCtl*)d_ctl);
-                hipLaunchKernelGGL(k_sum_partials_multi, dim3(cnt), dim3(kBlock), 0, stream, (const double*)cgs_parts.p, gv, cgs_parts.p + size_t(m + 1) * gv, (const SolveCtl*)d_ctl);
-                comm->allreduce_sum(cgs_parts.p + size_t(m + 1) * gv, cnt, stream);
-                hipLaunchKernelGGL((k_gm_cgs_update<S>), dim3(gv), dim3(kBlock), 0, stream, n, plan.nbp, mask, cnt, m, i, (const double*)(cgs_parts.p + size_t(m + 1) * gv), g.H,
-                                   (const S*)w.kry.p, w.t.p, parts, (const SolveCtl*)d_ctl);
-                hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(kBlock), 0, stream, (const double*)parts, (const double*)nullptr, gv, red1);
-                comm->allreduce_sum(red1, 1, stream);
-                dot_arr = red1; dot_np = 1;
+                double* hsum = cgs_parts.p + size_t(m + 2) * gv;              // cnt projections + ||w||^2, all-reduced together
+                hipLaunchKernelGGL(k_sum_partials_multi, dim3(cnt + 1), dim3(kBlock), 0, stream, (const double*)cgs_parts.p, gv, hsum, (const SolveCtl*)d_ctl);
+                comm->allreduce_sum(hsum, cnt + 1, stream);
+                double* pyth = cgs_pyth ? g.y + m + 2 : (double*)nullptr;    // norm^2 of what is left, by Pythagoras
+                hipLaunchKernelGGL((k_gm_cgs_update<S>), dim3(gv), dim3(kBlock), 0, stream, n, plan.nbp, mask, cnt, m, i, (const double*)hsum, g.H,
+                                   (const S*)w.kry.p, w.t.p, parts, (const SolveCtl*)d_ctl, pyth);
+                if (cgs_pyth) { dot_arr = pyth; dot_np = 1; }          // one all-reduce per column: the norm of what is left comes from Pythagoras
+                else {
+                    hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(kBlock), 0, stream, (const double*)parts, (const double*)nullptr, gv, red1);
+                    comm->allreduce_sum(red1, 1, stream);
+                    dot_arr = red1; dot_np = 1;
+                }
             } else {
             // modified Gram-Schmidt, each step's update fused with the next step's projection (k_gm_axpy_dot)
             dot((const S*)V(0), (const S*)w.t.p);
@@ -2568,7 +2684,13 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
                                    poll_status ? h_tick_dev : (int*)nullptr, vtick);
                 wait_tick(vtick);
                 verified = true;
-                if (!h_ctl->done) { stop = false; ++verify_rounds; }
+                if (!h_ctl->done) {
+                    stop = false; ++verify_rounds;
+                    // a second miss in the same cycle: the Arnoldi recurrence's estimate has drifted from the real defect (float vectors: the
+                    // estimate keeps falling while b - A x does not) -- end the cycle here and restart from the true defect, which the
+                    // restart path forms from the updated x (iterative refinement)
+                    if (++cycle_misses >= 2) { ++i; ++j; break; }
+                }
             }
         }
         if (h_ctl->flag != 0) break;                                   // breakdown: dune throws, no update
@@ -2724,6 +2846,7 @@ double LinSolver::time_kernel(int kernel, int reps, int single_precision)
     template void LinSolver::spmv<S>(const S*, S*);                                      \
     template void LinSolver::spmv_at<S>(const S*, S*, const S*, const int32_t*);        \
     template void LinSolver::cpr_prepare<S>();                                           \
+    template void LinSolver::cpr_reference_transform<S>();                               \
     template void LinSolver::cpr_reweigh_rows<S>(const int32_t*, int);                   \
     template const S* LinSolver::pre_matrix<S>();                                        \
     template void LinSolver::coarse_setup<S>(bool);                                      \

@@ -87,6 +87,7 @@ struct SolverWork {
     DevArray<S> csT;                             // coarse space: per row, sum of its pressure entries towards each neighbour slot
     DevArray<S> cxc;                             // coarse-space part of the pressure correction (constant per subdomain)
     DevArray<S> cprw;                            // [3][nbp] per-cell weights of the pressure equation (formEllipticSystem)
+    DevArray<S> cprw_orig;                       // cpr_reference_transform: the weights L was built from (cprw itself then selects the transformed pressure row)
     std::unique_ptr<AmgHierarchy<S>> amg;         // CPR pressure stage (built on first use)
     bool allocated = false;
 };
@@ -143,6 +144,16 @@ public:
     template <class S> void cpr_reweigh_rows(const int32_t* d_rows, int nrows);   // weights of these rows again, from the current matrix
     void drop_hierarchies();            // the wells changed: the bordered pressure hierarchy is rebuilt from the next matrix
     template <class S> void cpr_apply(const S* d, S* v, double relax, const SolveCtl* ctl, const double* cr_given = nullptr);
+    // opmgpu_params.cpr_reference_transform: the reference's CPR formulation (NewtonIterationUtilities.cpp:253-287 formEllipticSystem,
+    // NewtonIterationBlackoilCPR.cpp:117-131): the WHOLE system is row-transformed by the per-cell matrix L -- first row = the sum of the
+    // dominant equations (the pressure equation), scaled by 200 bar; second / third row = the water / gas equation, or the oil equation
+    // where a weak oil equation was swapped out of the sum -- and the Krylov method iterates on, and measures, L A x = L b.  The matrix
+    // (once per matrix), the wells' low-rank rows and the right-hand side b (every solve) are transformed in place; the CPR weights then
+    // select the transformed pressure row.  The solution x is that of the untransformed system.
+    template <class S> void cpr_reference_transform();
+    bool ref_transformed = false;      // the resident matrix is L A (reset by whoever writes a new matrix)
+    const void* border_weights = nullptr;   // weights of the bordered pressure column when cprw are the transformed system's unit weights
+    double border_colscale = 1.0;
     // coarse-correction factors of the pressure cycle chosen for THIS matrix on the first right-hand side it sees (see cpr_tune)
     template <class S> void cpr_tune();
     bool amg_autotune = false;      // OPMGPU_AMG_AUTOTUNE=1: experiment, measured NOT robust; default: 1.9 (2.2 into level 0 on one well-free subdomain)

@@ -466,9 +466,10 @@ TIMED_KW = {"cart100_f64": ("cart100", dict(gmres=1, reduction=1e-10, maxiter=40
             "spe10like_f64": ("spe10like", dict(gmres=1, reduction=1e-11, oracle_reduction=1e-8, maxiter=800, tol_p=1e-5, tol_s=1e-5)),
             "cart100_f32": ("cart100", dict(single=True, gmres=1, verify=1, reduction=1e-5, oracle_reduction=1e-10, maxiter=200, tol_p=2e-5, tol_s=1e-4, tol_jac=5e-7, tol_op=2e-5))}
 # solvers: bit 0 = CPR, bit 1 = GMRES.  Multicolour ILU0 alone needs ~1000 iterations for 1e-6 at 1 M cells.  GMRES legs run against the
-# oracle's own GMRES restatement, except at 1 M cells (cart100: too slow on the host, see _cart60) where the device verifies the true residual
+# oracle's own GMRES restatement (both at 1e-7), except at 1 M cells (cart100: too slow on the host, see _cart60) and on the Norne-like grid
+# (isolated cells: restarted GMRES(40) stalls on its preconditioned residual near 1e-7 there), where the device verifies the true residual instead
 COUNT_KW = {"cart100": dict(solvers=(1, 3), oracle_gmres=False), "cart60": dict(solvers=(1, 3)), "spe10like": dict(solvers=(1,)),
-            "nornelike": dict(spin_up=0, solvers=(0, 1, 3)), "spe9like": dict(spin_up=0, solvers=(0, 1, 2, 3))}
+            "nornelike": dict(spin_up=0, solvers=(0, 1, 3), oracle_gmres=False), "spe9like": dict(spin_up=0, solvers=(0, 1, 2, 3))}
 
 
 @pytest.mark.parametrize("name", list(DECKS))

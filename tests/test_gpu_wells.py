@@ -245,6 +245,31 @@ def test_well_presolve_forms_agree(gpu_lib, monkeypatch, case):
         assert np.array_equal(a[5].p, b[5].p) and np.array_equal(a[5].sat, b[5].sat), mode
 
 
+@pytest.mark.parametrize("gmres", [0, 1])
+def test_reference_cpr_formulation_with_device_wells(gpu_lib, gmres):
+    """cpr_reference_transform on the model path with the device well model: the matrix, the wells' rank-7 rows P_w and the right-hand side are
+    transformed by L, the bordered pressure column follows the pressure row's 200-bar scaling -- the Newton path must be the untransformed
+    run's (tight linear tolerance), with the same convergence decisions."""
+    grid, tab, st, wl = _setup()
+    out = {}
+    for tr in (0, 1):
+        gm = GpuBlackoilModel(grid, tab, capi.default_params(use_cpr=1, newton_use_gmres=gmres, cpr_reference_transform=tr, linear_solver_reduction=1e-11, linear_solver_maxiter=400))
+        md = W.DeviceWellModel(gm, wl, W.WellState(wl, st.p))
+        md.prepareStep(2 * decks.DAY, st)
+        hist = []
+        for it in range(4):
+            conv, lin = md.nonlinearIteration(it, single_precision=False)
+            hist.append((conv, lin))
+        ws = md.pull_well_state()
+        out[tr] = (gm.getState(), ws.bhp.copy(), ws.qs.copy(), hist)
+        gm.close()
+    a, b = out[0], out[1]
+    assert [h[0] for h in a[3]] == [h[0] for h in b[3]]
+    assert np.array_equal(a[0].hc, b[0].hc)
+    assert np.abs(a[0].p - b[0].p).max() <= 1e-6 * np.abs(a[0].p).max() and np.abs(a[0].sat - b[0].sat).max() <= 1e-6
+    assert np.allclose(a[1], b[1], rtol=1e-7) and np.allclose(a[2], b[2], rtol=1e-6, atol=1e-9 * np.abs(a[2]).max())
+
+
 def test_stabilized_update_relaxes_the_well_increment_too(gpu_lib, oracle):
     """NonlinearSolver::stabilizeNonlinearUpdate acts on the WHOLE increment (NonlinearSolver_impl.hpp:260-301): with device wells the
     recovered (q_s, bhp) increment is relaxed with the reservoir part -- device vs host well model with a forced relaxation of 0.6."""

@@ -13,15 +13,17 @@ tab = decks.satfunc_standard_tables()
 st = decks.initial_state(grid, tab, perturb=0.002, seed=12345)
 m = GpuBlackoilModel(grid, tab, capi.default_params())
 m.prepareStep(5 * decks.DAY, st)
-m.setSolvePrecision(True)
+m.setSolvePrecision(True)               # float Jacobian (k_assemble_rows<float, ...>)
 for i in range(4):
     m.assemble(i == 0)
 m.getConvergence()
-# the roofline kernel of bench.py: the f32 SpMV over rotating copies of the matrix (out of cache), a few launches
-m.setSolvePrecision(False)
-m.assemble(False)
+m.setSolvePrecision(False)              # double Jacobian (k_assemble_rows<double, ...>): what bench.py's headline assembles
+for i in range(4):
+    m.assemble(False)
+# the roofline kernel of bench.py: the SpMV over rotating copies of the matrix (out of cache), a few launches in both precisions
 rowptr, col, val = m.jacobian()
-s = GpuNewtonIteration(capi.default_params()); s.load(rowptr, col, val, True); s.ilu0_factor()
-s.time_kernel(capi.K_SPMV_COLD, 8)
-s.close()
+for single in (True, False):
+    s = GpuNewtonIteration(capi.default_params()); s.load(rowptr, col, val, single); s.ilu0_factor()
+    s.time_kernel(capi.K_SPMV_COLD, 8)
+    s.close()
 m.close()

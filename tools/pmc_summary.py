@@ -10,7 +10,9 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
         acc = {}
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"].split("(")[0]
-            if not any(t in k for t in ("k_flux", "k_cell_props", "k_spmv")):
+            if "k_assemble_rows" in k or "k_spmv" in k:          # keep the template arguments that tell float from double apart
+                k = row["Kernel_Name"].split("(")[0]
+            if not any(t in k for t in ("k_assemble_rows", "k_cell_values", "k_flux", "k_cell_props", "k_spmv")):
                 continue
             key = (k, row["Counter_Name"])
             a = acc.setdefault(key, [0.0, set()])
