@@ -360,7 +360,6 @@ def main(argv=None):
                 variants[name] = {"failed": repr(e)}
             m.close()
 
-        dt30 = 30.0 * decks.DAY
         variant("reference_default_solver_ilu0" + wtag, "ilu0", "bicgstab", dt_main, reference_single("ilu0", dt_main),
                 note="solver_approach=interleaved, the reference's DEFAULT: block-ILU0 + BiCGStab, float because dt < 20 d")
         if args.solver == "cpr":
@@ -375,9 +374,16 @@ def main(argv=None):
                     note="NOT a configuration the reference can run (its CPR plug-in is double-only, NewtonIterationBlackoilCPR.cpp:117-140): round 2's headline, kept for continuity")
         if use_wells:
             variant("without_wells", args.solver, "bicgstab" if args.solver == "cpr" else args.krylov, dt_main, single_main, wells_on=False)
-        if abs(args.dt_days - 30.0) > 1e-9:
-            variant("dt30_f64_ilu0" + wtag, "ilu0", "bicgstab", dt30, False, note="dt >= 20 d: the reference's default solver switches to double (BlackoilModelBase_impl.hpp:284)")
-            variant("dt30_f64_cpr_%s%s" % (args.krylov, wtag), "cpr", args.krylov, dt30, False)
+        # SURVEY 8d's dt sweep (1, 5, 20, 30 d; covers the float / double switch of the reference's default solver at 20 d): the main run and the
+        # variant above are the dt = --dt-days legs, here the others, for the reference-default solver and for the headline's
+        for days in (1.0, 20.0, 30.0):
+            if abs(args.dt_days - days) < 1e-9:
+                continue
+            dts = days * decks.DAY
+            sp = reference_single("ilu0", dts)
+            variant("dt%d_%s_ilu0%s" % (days, "f32" if sp else "f64", wtag), "ilu0", "bicgstab", dts, sp,
+                    note="the reference's default solver at dt = %g d: %s (BlackoilModelBase_impl.hpp:284)" % (days, "float, dt < 20 d" if sp else "double, dt >= 20 d"))
+            variant("dt%d_f64_cpr_%s%s" % (days, args.krylov, wtag), "cpr", args.krylov, dts, False)
 
     out = None
     if rank == 0:

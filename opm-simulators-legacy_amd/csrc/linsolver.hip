@@ -2548,8 +2548,12 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
     static const bool cgs_on = !(std::getenv("OPMGPU_GMRES_CGS") && std::atoi(std::getenv("OPMGPU_GMRES_CGS")) == 0);
     const bool cgs = comm != nullptr && cgs_on && m <= 63;
     if (cgs) cgs_parts.alloc(size_t(m + 2) * gv + size_t(m + 2));
-    // OPMGPU_GMRES_PYTH=0: the column's norm by its own all-reduce (two per column) instead of Pythagoras (one)
-    static const bool cgs_pyth = !(std::getenv("OPMGPU_GMRES_PYTH") && std::atoi(std::getenv("OPMGPU_GMRES_PYTH")) == 0);
+    // The column's norm by Pythagoras (one all-reduce per column) -- for the loose reductions of Newton solves only (>= 1e-4, a handful of
+    // columns): the identity needs an orthonormal basis, and classical Gram-Schmidt loses orthogonality as the columns add up -- at a
+    // 1e-10 reduction (~20 columns) the decomposed runs left the single-domain Newton path with it (tests/test_gpu_dist_shm.py, cpr_gmres),
+    // with the explicit norm (a second all-reduce) they do not.  OPMGPU_GMRES_PYTH=0: always the explicit norm.
+    static const bool cgs_pyth_env = !(std::getenv("OPMGPU_GMRES_PYTH") && std::atoi(std::getenv("OPMGPU_GMRES_PYTH")) == 0);
+    const bool cgs_pyth = cgs_pyth_env && prm.linear_solver_reduction >= 1e-4;
     if (flex) w.kryz.alloc(size_t(m) * n);
     gmbuf.alloc(size_t(m + 1) * m + (m + 1) + 3 * m + 8);
     gmbuf.zero(stream);
@@ -2686,10 +2690,11 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
                 verified = true;
                 if (!h_ctl->done) {
                     stop = false; ++verify_rounds;
-                    // a second miss in the same cycle: the Arnoldi recurrence's estimate has drifted from the real defect (float vectors: the
-                    // estimate keeps falling while b - A x does not) -- end the cycle here and restart from the true defect, which the
-                    // restart path forms from the updated x (iterative refinement)
-                    if (++cycle_misses >= 2) { ++i; ++j; break; }
+                    // a second miss in the same cycle (the first already with float vectors, whose Arnoldi estimate keeps falling while
+                    // b - A x does not: measured on the 1 M-cell deck, in-cycle continuation never reached 1e-5 there): the recurrence's
+                    // estimate has drifted from the real defect -- end the cycle here and restart from the true defect, which the restart
+                    // path forms from the updated x (iterative refinement)
+                    if (++cycle_misses >= (sizeof(S) == 4 ? 1 : 2)) { ++i; ++j; break; }      // (float vectors: refine at the first miss)
                 }
             }
         }
