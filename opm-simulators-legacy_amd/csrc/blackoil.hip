@@ -488,7 +488,7 @@ __global__ __launch_bounds__(kBlock) void k_cell_values(int nb, int nbp, DevTabl
     eps_load(eps, eps_u0, nbp, row, satnum[row], E);
     hyst_load(hy.imbnum, hy.hist, nbp, row, H);
     if (H.on) eps_load(hy.ieps, hy.iureg, nbp, row, H.ireg, EI);
-    eval_cell(D, E, somax[row], pvtnum[row], satnum[row], p[row], sw[row], sg[row], rs[row], rv[row], hc[row], q, H, &EI);
+    eval_cell(D, E, (D.t.vap1 > 0.0 || D.t.vap2 > 0.0) ? somax[row] : 0.0, pvtnum[row], satnum[row], p[row], sw[row], sg[row], rs[row], rv[row], hc[row], q, H, &EI);
     vals[long(VP_PW) * nbp + row] = q.pw.v; vals[long(VP_PG) * nbp + row] = q.pg.v;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -537,11 +537,14 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_assemble_rows(int xm, int nb,
         eps_load(eps, eps_u0, nbp, row, satnum[row], E);
         hyst_load(hy.imbnum, hy.hist, nbp, row, H);
         if (H.on) eps_load(hy.ieps, hy.iureg, nbp, row, H.ireg, EI);
-        eval_cell(DT, E, somax[row], pvtnum[row], satnum[row], p[row], sw[row], sg[row], rs[row], rv[row], hc[row], q, H, &EI);
+        eval_cell(DT, E, (DT.t.vap1 > 0.0 || DT.t.vap2 > 0.0) ? somax[row] : 0.0, pvtnum[row], satnum[row], p[row], sw[row], sg[row], rs[row], rv[row], hc[row], q, H, &EI);
     }
     const double scale[3] = { s0, s1, s2 };
     double op[3], orho[3], oU[3];                          // own values
     double dP[3][3], dRho[3][3], dU[3][3];                 // own derivatives d/d(P, Sw, Xvar) of phase pressure, density, b * mobility
+    // (the row's own VALUES are read from the planes pass 1 wrote -- bit for bit what the neighbours see of this cell.  Taking them from this
+    // kernel's own eval_cell instead saves 80 B per cell and was measured SLOWER, 0.239 against 0.202 ms: the values then stay live in
+    // registers across the whole evaluation and the loop spills more; profiles/r03_asm_ownvals_ab.log)
     op[0] = vals[long(VP_PW) * nbp + row]; op[1] = p[row]; op[2] = vals[long(VP_PG) * nbp + row];
     dP[0][0] = 1.0; dP[0][1] = q.pw.w; dP[0][2] = 0.0;
     dP[1][0] = 1.0; dP[1][1] = 0.0; dP[1][2] = 0.0;

@@ -106,6 +106,7 @@ struct Timed {
 template <class S> int solve_loaded(opmgpu_ctx* c, bool matrix_changed, SolveResult& res)
 {
     LinSolver& ls = *c->ls;
+    ls.wb_relax = c->prm.ilu_relaxation;
     ls.prepare<S>(matrix_changed);
     // the reference's CPR formulation (whole-system L transform, 200-bar pressure row, ||L r|| stopping) as an option; once per matrix
     if (c->prm.use_cpr && c->prm.cpr_reference_transform) ls.cpr_reference_transform<S>();

@@ -959,6 +959,7 @@ LinSolver::LinSolver(hipStream_t s) : stream(s)
     OPMGPU_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
     OPMGPU_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
     if (const char* e = std::getenv("OPMGPU_CLOSED")) closed_form_level0 = std::atoi(e) != 0;
+    if (const char* e = std::getenv("OPMGPU_WELL_WOODBURY")) well_woodbury = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_CPR_SPECULATE")) cpr_speculate = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_CPR_WEIGHTS")) cpr_weight_mode = std::atoi(e);
     if (const char* e = std::getenv("OPMGPU_AMG_LAG")) amg_lag = std::atoi(e);
@@ -1085,6 +1086,94 @@ template <class S> const S* LinSolver::pre_matrix()
     return w.Apre.p;
 }
 
+// ---- the wells in stage 2: local Woodbury correction of the ILU0 application (linsolver.hpp) ----
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_wb_setup(LowRankOp lr, const int32_t* __restrict__ slice_ptr, const int16_t* __restrict__ nlower,
+                                                     const S* __restrict__ lu, double relax, double* __restrict__ Y, double* __restrict__ Ginv)
+{
+    __shared__ double sm[28];
+    __shared__ double G[49];
+    const int w = blockIdx.x, tid = threadIdx.x;
+    double acc[49];
+#pragma unroll
+    for (int q = 0; q < 49; ++q) acc[q] = 0.0;
+    for (int j = lr.connpos[w] + tid; j < lr.connpos[w + 1]; j += kBlock) {
+        const int row = lr.perf_row[j];
+        const S* __restrict__ d = lu + vidx(slice_ptr[row >> 6] + nlower[row], row & 63);       // the ILU0's inverted diagonal block, row-major planes
+        double Di[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) Di[q] = double(d[q * 64]);
+        const double* __restrict__ P = lr.P + 21 * long(j);
+        const double* __restrict__ Q = lr.Q + 21 * long(j);
+        double y[21];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int k = 0; k < 7; ++k) y[7 * a + k] = relax * (Di[3 * a] * P[k] + Di[3 * a + 1] * P[7 + k] + Di[3 * a + 2] * P[14 + k]);
+#pragma unroll
+        for (int q = 0; q < 21; ++q) Y[21 * long(j) + q] = y[q];
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+#pragma unroll
+            for (int l = 0; l < 7; ++l) acc[7 * k + l] += Q[3 * k] * y[l] + Q[3 * k + 1] * y[7 + l] + Q[3 * k + 2] * y[14 + l];
+    }
+    for (int k = 0; k < 7; ++k) {
+        double part[7];
+#pragma unroll
+        for (int l = 0; l < 7; ++l) part[l] = acc[7 * k + l];
+        __syncthreads();
+        block_sum<7>(part, sm);
+        if (tid == 0) for (int l = 0; l < 7; ++l) G[7 * k + l] = part[l] + (k == l ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // Gauss-Jordan with partial pivoting on [G | I]; a singular G switches the correction of this well off (zero inverse)
+        double M[7][14];
+        for (int r = 0; r < 7; ++r) for (int c = 0; c < 7; ++c) { M[r][c] = G[7 * r + c]; M[r][7 + c] = r == c ? 1.0 : 0.0; }
+        bool ok = true;
+        for (int c = 0; c < 7 && ok; ++c) {
+            int pr = c; double best = fabs(M[c][c]);
+            for (int r = c + 1; r < 7; ++r) if (fabs(M[r][c]) > best) { best = fabs(M[r][c]); pr = r; }
+            if (!(best > 1e-300)) { ok = false; break; }
+            if (pr != c) for (int q = 0; q < 14; ++q) { const double tmp = M[c][q]; M[c][q] = M[pr][q]; M[pr][q] = tmp; }
+            const double ip = 1.0 / M[c][c];
+            for (int q = 0; q < 14; ++q) M[c][q] *= ip;
+            for (int r = 0; r < 7; ++r) if (r != c) { const double f = M[r][c]; if (f != 0.0) for (int q = 0; q < 14; ++q) M[r][q] -= f * M[c][q]; }
+        }
+        for (int r = 0; r < 7; ++r) for (int c = 0; c < 7; ++c) { const double v = ok ? M[r][7 + c] : 0.0; Ginv[49 * long(w) + 7 * r + c] = (v == v) ? v : 0.0; }
+    }
+}
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_wb_apply(LowRankOp lr, int nbp, const double* __restrict__ Y, const double* __restrict__ Ginv, S* __restrict__ v,
+                                                     const SolveCtl* __restrict__ ctl)
+{
+    __shared__ double sm[28];
+    __shared__ double ts[7], ss[7];
+    if (ctl && ctl->done) return;
+    const int w = blockIdx.x, tid = threadIdx.x;
+    double acc[7] = { 0, 0, 0, 0, 0, 0, 0 };
+    for (int j = lr.connpos[w] + tid; j < lr.connpos[w + 1]; j += kBlock) {
+        const int row = lr.perf_row[j];
+        const double x0 = double(v[row]), x1 = double(v[nbp + row]), x2 = double(v[2 * long(nbp) + row]);
+        const double* __restrict__ Q = lr.Q + 21 * long(j);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) acc[k] += Q[3 * k] * x0 + Q[3 * k + 1] * x1 + Q[3 * k + 2] * x2;
+    }
+    block_sum<7>(acc, sm);
+    if (tid == 0) for (int k = 0; k < 7; ++k) ts[k] = acc[k];
+    __syncthreads();
+    if (tid < 7) { double s = 0.0; for (int l = 0; l < 7; ++l) s += Ginv[49 * long(w) + 7 * tid + l] * ts[l]; ss[tid] = s; }
+    __syncthreads();
+    for (int j = lr.connpos[w] + tid; j < lr.connpos[w + 1]; j += kBlock) {
+        const int row = lr.perf_row[j];
+        const double* __restrict__ y = Y + 21 * long(j);
+        double d0 = 0.0, d1 = 0.0, d2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) { d0 += y[k] * ss[k]; d1 += y[7 + k] * ss[k]; d2 += y[14 + k] * ss[k]; }
+        v[row] -= S(d0); v[nbp + row] -= S(d1); v[2 * long(nbp) + row] -= S(d2);
+    }
+}
+
 template <class S> int LinSolver::factor(bool wait)
 {
     SolverWork<S>& w = work<S>();
@@ -1096,6 +1185,12 @@ template <class S> int LinSolver::factor(bool wait)
         hipLaunchKernelGGL((k_ilu_factor<S>), dim3(grid_for(hi - lo)), dim3(kBlock), 0, stream, lo, hi, dp.slice_ptr.p, dp.col.p,
                            dp.nlower.p, dp.trip_ptr.p, dp.trip_l.p, dp.trip_u.p, dp.trip_t.p, ((emulate_what & 1) ? pre_matrix<S>() : matrix<S>()), dp.rowlen.p, w.LU.p, flags.p,
                            (const int8_t*)dp.simple.p, int(lu_copy_upper));
+    }
+    if (well_woodbury && lowrank.nw > 0 && lowrank.P && !comm) {
+        // the wells' Woodbury data of this factorisation (same stream: ordered behind it, covered by join_factor like the factors)
+        wb_buf.ensure(size_t(21) * lowrank.nperf + size_t(49) * lowrank.nw);
+        hipLaunchKernelGGL((k_wb_setup<S>), dim3(lowrank.nw), dim3(kBlock), 0, stream, lowrank, dp.slice_ptr.p, dp.nlower.p, (const S*)w.LU.p, wb_relax,
+                           wb_buf.p, wb_buf.p + size_t(21) * lowrank.nperf);
     }
     OPMGPU_HIP(hipMemcpyAsync(h_flags, flags.p, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     if (!wait) return OPMGPU_OK;          // the caller reads factor_status() after its next synchronisation (no pipeline bubble per solve)
@@ -1994,6 +2089,9 @@ template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, con
     kt.end(KT_CPR_OTHER, kt_a);
     ilu_apply<S>(w.z.p, v, relax, ctl);
     kt_a = kt.begin();
+    if (well_woodbury && wb_active && lowrank.nw > 0 && lowrank.P && !comm && wb_buf.p)
+        hipLaunchKernelGGL((k_wb_apply<S>), dim3(lowrank.nw), dim3(kBlock), 0, stream, lowrank, plan.nbp, (const double*)wb_buf.p,
+                           (const double*)(wb_buf.p + size_t(21) * lowrank.nperf), v, ctl);
     hipLaunchKernelGGL((k_cpr_add_p<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, xp, v, ctl);
     kt.end(KT_CPR_OTHER, kt_a);
 }
@@ -2050,6 +2148,7 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
 {
     SolverWork<S>& w = work<S>();
     SolveResult res;
+    wb_active = false;             // (the wells' Woodbury correction of stage 2 runs under GMRES only: the closed-form rows below assume the plain ILU0)
     const long n = long(3) * plan.nbp;
     const int gv = std::min(grid_for(n), kMaxPart);            // vector kernels (also the number of their partials)
     const int gs = std::min(grid8_for(plan.nb), kMaxPart);     // reducing SpMV launches (multiple of 8: XCD-aware chunking)
@@ -2319,7 +2418,7 @@ __global__ __launch_bounds__(kBlock) void k_gm_multidot(long n, int nbp, const i
         double acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
         const int nk = cnt + 1 - k0 < 8 ? cnt + 1 - k0 : 8;
         for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < n; i += long(gridDim.x) * kBlock) {
-            if (!mask[i % nbp]) continue;
+            if (mask && !mask[i % nbp]) continue;
             const double wi = double(w[i]);
 #pragma unroll
             for (int u = 0; u < 8; ++u) if (u < nk) acc[u] += wi * ((k0 + u < cnt) ? double(kry[long(k0 + u) * n + i]) : wi);
@@ -2364,7 +2463,7 @@ __global__ __launch_bounds__(kBlock) void k_gm_cgs_update(long n, int nbp, const
         S v = w[i];
         for (int k = 0; k < cnt; ++k) v -= hs[k] * kry[long(k) * n + i];
         w[i] = v;
-        if (mask[i % nbp]) acc[0] += double(v) * double(v);
+        if (!mask || mask[i % nbp]) acc[0] += double(v) * double(v);
     }
     block_sum<1>(acc, sm);
     if (threadIdx.x == 0) parts_out[blockIdx.x] = acc[0];
@@ -2541,12 +2640,16 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
     // solve (M^-1 b before the first column; a CPR solve has ~4 columns) and stops on the PRECONDITIONED residual; this form stops on the
     // true residual, the criterion of the reference's default BiCGStab.  One more basis of m vectors in memory.
     const bool flex = prm.newton_use_gmres == 2;
+    wb_active = true;
     // gmres_verify_residual: the flexible form measures the true residual itself
     const bool verify = prm.gmres_verify_residual != 0 && !flex;
     bool verified = false;
     int verify_rounds = 0;
     static const bool cgs_on = !(std::getenv("OPMGPU_GMRES_CGS") && std::atoi(std::getenv("OPMGPU_GMRES_CGS")) == 0);
-    const bool cgs = comm != nullptr && cgs_on && m <= 63;
+    // OPMGPU_GMRES_CGS=2 (experiment): the classical form on ONE GPU too (fewer passes over the basis per column; a different rounding
+    // path than dune's modified Gram-Schmidt, which one GPU keeps by default)
+    static const bool cgs_single = std::getenv("OPMGPU_GMRES_CGS") && std::atoi(std::getenv("OPMGPU_GMRES_CGS")) == 2;
+    const bool cgs = (comm != nullptr || cgs_single) && cgs_on && m <= 63;
     if (cgs) cgs_parts.alloc(size_t(m + 2) * gv + size_t(m + 2));
     // The column's norm by Pythagoras (one all-reduce per column) -- for the loose reductions of Newton solves only (>= 1e-4, a handful of
     // columns): the identity needs an orthonormal basis, and classical Gram-Schmidt loses orthogonality as the columns add up -- at a
@@ -2628,11 +2731,12 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
                 hipLaunchKernelGGL((k_gm_multidot<S>), dim3(gv), dim3(kBlock), 0, stream, n, plan.nbp, mask, cnt, (const S*)w.kry.p, (const S*)w.t.p, cgs_parts.p, (const SolveCtl*)d_ctl);
                 double* hsum = cgs_parts.p + size_t(m + 2) * gv;              // cnt projections + ||w||^2, all-reduced together
                 hipLaunchKernelGGL(k_sum_partials_multi, dim3(cnt + 1), dim3(kBlock), 0, stream, (const double*)cgs_parts.p, gv, hsum, (const SolveCtl*)d_ctl);
-                comm->allreduce_sum(hsum, cnt + 1, stream);
+                if (comm) comm->allreduce_sum(hsum, cnt + 1, stream);
                 double* pyth = cgs_pyth ? g.y + m + 2 : (double*)nullptr;    // norm^2 of what is left, by Pythagoras
                 hipLaunchKernelGGL((k_gm_cgs_update<S>), dim3(gv), dim3(kBlock), 0, stream, n, plan.nbp, mask, cnt, m, i, (const double*)hsum, g.H,
                                    (const S*)w.kry.p, w.t.p, parts, (const SolveCtl*)d_ctl, pyth);
                 if (cgs_pyth) { dot_arr = pyth; dot_np = 1; }          // one all-reduce per column: the norm of what is left comes from Pythagoras
+                else if (!comm) { dot_arr = parts; dot_np = gv; }
                 else {
                     hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(kBlock), 0, stream, (const double*)parts, (const double*)nullptr, gv, red1);
                     comm->allreduce_sum(red1, 1, stream);

@@ -209,6 +209,14 @@ public:
     DevArray<int8_t> light_ok;     // multi-GPU: rows that keep the closed form (owned, no ghost neighbour)
     const CommBase* light_ok_for = nullptr;
     template <class S> void lowrank_reduce(const S* x, const SolveCtl* ctl);
+    // Stage 2 of the CPR preconditioner sees the wells: the ILU0 is of A, the operator is A + sum_w P_w Q_w.  Woodbury with
+    // the block-diagonal of the ILU0 standing in for its inverse on the (few) perforated rows:
+    //   (M + P Q)^-1 ~ M^-1 - Y (I + Q Y)^-1 Q M^-1,   Y = omega D^-1 P   (D^-1: the ILU0's inverted diagonal blocks of the perforated rows)
+    // Y and the 7 x 7 inverses are formed behind every factorisation (k_wb_setup), one launch per application applies the correction
+    // (k_wb_apply).  Under GMRES only (BiCGStab's closed-form rows assume x = M^-1 p with the plain ILU0).  OPMGPU_WELL_WOODBURY=1.
+    DevArray<double> wb_buf;       // [nperf][3][7] Y | [nw][49] inverses
+    bool well_woodbury = false, wb_active = false;
+    double wb_relax = 0.9;         // the ILU0's relaxation factor (omega above), set by the caller before the factorisation
     bool closed_form_level0 = true; // k_spmv shortcut on level-0 rows (A/B switch: OPMGPU_CLOSED=0)
     bool cpr_halo_xp = true;        // multi-GPU CPR: halo-exchange the pressure correction before stage 2 (A/B: OPMGPU_CPR_HALO_XP=0)
     int amg_lag = 1, amg_age = 0;   // A/B: OPMGPU_AMG_LAG

@@ -78,10 +78,19 @@ CASES = {
     "cpr_gmres_wells": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=500, use_cpr=1, newton_use_gmres=1), wells=True, single=False),
     "ilu0_gmres": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=1500, newton_use_gmres=1), wells=False, single=False),
     "cpr_f32_default_tolerance": dict(params=dict(use_cpr=1), wells=False, single=True),
+
     # a 30-day report step through the adaptive sub-stepping loop, first sub-step too long for 3 Newton iterations: chopped and redone
     "cpr_adaptive_substeps": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=500, use_cpr=1), wells=False, single=False,
                                   ats=dict(first_days=30.0, report_days=30.0, max_iter=3)),
 }
+
+
+# the bench's decomposed configuration: GMRES at the default 1e-2 reduction in double, wells on -- classical Gram-Schmidt with the column's
+# norm by Pythagoras (ONE all-reduce per column; only taken at loose reductions, linsolver.hip).  Not one of the CASES above: dune's GMRES
+# stops on the PRECONDITIONED residual, and at 1e-2 that leaves several per cent of error in the pressure LEVEL of this deck (measured: 5 % after
+# four Newton iterations, single domain against 2 ranks) -- a comparison across decompositions says nothing at that tolerance.  It is run
+# decomposed with and without the Pythagorean norm instead (test_collective_operations_per_newton_iteration).
+GMRES_DEFAULT_TOLERANCE = dict(params=dict(use_cpr=1, newton_use_gmres=1), wells=True, single=False)
 
 
 @pytest.mark.parametrize("case", sorted(CASES))
@@ -133,3 +142,28 @@ def test_coarse_space_restrictions_ride_on_the_scalar_all_reduces(gpu_lib):
     # two all-reduces less per BiCGStab iteration (the iteration that converges at its half step has made one of them only)
     assert c0[0] - c1[0] >= 2 * lin - 2 * len(its0) and c0[0] - c1[0] <= 2 * lin + 2 * len(its0), (c0, c1, lin)
     assert c1[1] == c0[1] or abs(c1[1] - c0[1]) <= 4 * np.abs(its1 - its0).sum()     # the halo exchanges are untouched
+
+
+def test_collective_operations_per_newton_iteration(gpu_lib):
+    """How many collective operations (all-reduces + halo exchanges, counted by the test transport) one Newton iteration of the bench's
+    decomposed configuration costs -- CPR + GMRES at the default reduction, device wells, 2 ranks -- with the round-3 mergers (getConvergence's
+    sums and maxima in one all-reduce; the Gram-Schmidt column norm by Pythagoras) and without the second one.  Every operation is a
+    small-message latency (~13 us over RCCL at 1 M cells per rank): the count is the cost model of DESIGN section 7."""
+    cfg = dict(nx=10, ny=9, nz=16, sigma=0.7, seed=21, perturb=0.004, dt_days=3.0, newton=4, rate=30.0 / 86400.0, **GMRES_DEFAULT_TOLERANCE)
+    res = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for pyth in (1, 0):
+            stats = os.path.join(tmp, "stats%d" % pyth)
+            got = _launch(cfg, 2, tmp, {"OPMGPU_GMRES_PYTH": str(pyth), "OPMGPU_SHM_STATS": stats})
+            calls = [tuple(int(x) for x in open("%s.%d" % (stats, r)).read().split()) for r in range(2)]
+            assert len(set(calls)) == 1                               # every rank made the same collective calls
+            res[pyth] = (got, calls[0])
+    (g1, c1), (g0, c0) = res[1], res[0]
+    newton = len(g1[3])
+    lin1, lin0 = int(g1[3][:, 1].sum()), int(g0[3][:, 1].sum())
+    per1, per0 = sum(c1[:2]) / newton, sum(c0[:2]) / newton
+    print("collective operations per Newton iteration: %.1f with the Pythagorean norm (%d all-reduces + %d exchanges, %d columns over %d iterations), %.1f without (%d + %d, %d columns)"
+          % (per1, c1[0], c1[1], lin1, newton, per0, c0[0], c0[1], lin0))
+    assert abs(lin1 - lin0) <= 2                                      # the same Krylov process
+    assert c0[0] - c1[0] >= lin1 - 2                                  # one all-reduce less per column
+    assert np.abs(g1[0] - g0[0]).max() <= 2e-3 * np.abs(g0[0]).max()

@@ -464,7 +464,7 @@ LOCKSTEP_KW = {"spe10like": dict(reduction=1e-8, tol_p=1e-5, tol_s=1e-5)}       
 TIMED_KW = {"cart100_f64": ("cart100", dict(gmres=1, reduction=1e-10, maxiter=400)),
             # (sigma_lnK = 2.5: dune's rule stops on the PRECONDITIONED residual, which at 1e-8 left 7e-4 in the saturations here: 1e-11)
             "spe10like_f64": ("spe10like", dict(gmres=1, reduction=1e-11, oracle_reduction=1e-8, maxiter=800, tol_p=1e-5, tol_s=1e-5)),
-            "cart100_f32": ("cart100", dict(single=True, gmres=1, verify=1, reduction=1e-5, oracle_reduction=1e-10, maxiter=200, tol_p=2e-5, tol_s=1e-4, tol_jac=5e-7, tol_op=2e-5))}
+            "cart100_f32": ("cart100", dict(single=True, gmres=1, verify=1, reduction=1e-5, oracle_reduction=1e-10, maxiter=1000, tol_p=2e-5, tol_s=1e-4, tol_jac=5e-7, tol_op=2e-5))}
 # solvers: bit 0 = CPR, bit 1 = GMRES.  Multicolour ILU0 alone needs ~1000 iterations for 1e-6 at 1 M cells.  GMRES legs run against the
 # oracle's own GMRES restatement, both at 1e-7 -- except at 1 M cells (cart100: too slow on the host, see _cart60; the device verifies the true
 # residual there) and on the Norne-like grid: with its isolated cells restarted GMRES(40) stalls near 1e-7 on either side (and does not reach a
