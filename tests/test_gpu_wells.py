@@ -377,3 +377,32 @@ def test_cpr_weights_with_device_wells_follow_the_final_matrix(gpu_lib, single):
         assert bad.size == 0, (it, bad[:10], w.reshape(3, nb)[:, bad[:4]], expect[:, bad[:4]], sorted(set(wl.arrays()[1].tolist()) & set(bad.tolist())))
     assert checked >= 2
     gm.close()
+
+
+def test_update_equations_scaling_with_device_wells_and_cpr(gpu_lib):
+    """updateEquationsScaling (default off) with the device well model under CPR: the wells' bordered pressure column, the CPR
+    weights and the matrix must all carry the factors of THIS assembly -- the run with the option walks the Newton path of the run without it
+    (a row scaling changes no solution; tight linear tolerance), and its factors are the means of 1 / b of the assembled state."""
+    grid, tab, st, wl = _setup()
+    out = {}
+    for ues in (0, 1):
+        gm = GpuBlackoilModel(grid, tab, capi.default_params(use_cpr=1, update_equations_scaling=ues, linear_solver_reduction=1e-11, linear_solver_maxiter=400))
+        md = W.DeviceWellModel(gm, wl, W.WellState(wl, st.p))
+        md.prepareStep(2 * decks.DAY, st)
+        hist, scales = [], []
+        for it in range(4):
+            conv, lin = md.nonlinearIteration(it, single_precision=False)
+            got = np.zeros(3)
+            gm._chk(gm.lib.opmgpu_get_matbalscale(gm.ctx, capi.dptr(got)))
+            hist.append((conv, lin)); scales.append(got.copy())
+        ws = md.pull_well_state()
+        out[ues] = (gm.getState(), ws.bhp.copy(), ws.qs.copy(), hist, scales)
+        gm.close()
+    a, b = out[0], out[1]
+    assert all(np.array_equal(s, [1.1169, 1.0031, 0.0031]) for s in a[4])
+    assert all(0.5 < s[0] < 1.5 and 0.5 < s[1] < 2.0 and 0.0 < s[2] < 0.1 for s in b[4]) and not np.array_equal(b[4][0], b[4][-1])     # mean 1 / b, moving with the state
+    assert [h[0] for h in a[3]] == [h[0] for h in b[3]]
+    assert max(h[1] for h in b[3]) <= 2 * max(h[1] for h in a[3]) + 2          # the preconditioner stays consistent: no blow-up of the iteration counts
+    assert np.array_equal(a[0].hc, b[0].hc)
+    assert np.abs(a[0].p - b[0].p).max() <= 1e-6 * np.abs(a[0].p).max() and np.abs(a[0].sat - b[0].sat).max() <= 1e-6
+    assert np.allclose(a[1], b[1], rtol=1e-7) and np.allclose(a[2], b[2], rtol=1e-6, atol=1e-9 * np.abs(a[2]).max())
