@@ -135,6 +135,12 @@ def main(argv=None):
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args, argv)                 # does not return
 
+    # everything a library prints on the way (RCCL's version banner at communicator creation, gloo's connection notes, ...) goes to stderr:
+    # file descriptor 1 carries exactly ONE line, the JSON line at the end
+    sys.stdout.flush()
+    saved_stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -506,8 +512,11 @@ def main(argv=None):
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(saved_stdout_fd, 1)
+    os.close(saved_stdout_fd)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
 
 
 def cpu_baseline(grid, tab, st, wl, prm, dt, single, threads=1, budget_s=15.0, max_newton=4):
