@@ -312,6 +312,9 @@ int opmgpu_well_state_get(opmgpu_ctx* ctx, double* bhp, double* qs, double* perf
  * get also reports the iteration count and outcome of the last explicit well pre-solve (solveWellEq). */
 int opmgpu_well_controls_set(opmgpu_ctx* ctx, const int32_t* current, const double* thp);
 int opmgpu_well_controls_get(opmgpu_ctx* ctx, int32_t* current, double* thp, int32_t* presolve_iterations, int32_t* presolve_converged);
+/* well_controls_iset_target / well_controls_iset_distr for ALL controls (order of opmgpu_set_device_wells; either pointer may be NULL = keep):
+ * what SimulatorBase::computeRESV does to the RESERVOIR_RATE controls once per report step (SimulatorBase_impl.hpp:551-553). */
+int opmgpu_well_controls_set_targets(opmgpu_ctx* ctx, const double* ctrl_target, const double* ctrl_distr);
 /* computePropertiesForWellConnectionPressures (StandardWells_impl.hpp:218-296) for the HOST well model: b_w, b_o, b_g, rsSat, rvSat
  * of the perforated cells (opmgpu_set_wells order) evaluated at the given pressures with the cells' own rs / rv / phase condition /
  * oil saturation.  out[nperf*5]. */
@@ -330,6 +333,16 @@ int opmgpu_well_convergence(opmgpu_ctx* ctx, double* flux_residual3, double* con
 int opmgpu_save_state(opmgpu_ctx* ctx);
 int opmgpu_restore_state(opmgpu_ctx* ctx);
 int opmgpu_relative_change(opmgpu_ctx* ctx, double* value);
+
+/* RateConverter::SurfaceToReservoirVoidage (RateConverterLegacy.hpp:407-770), the two halves SimulatorBase::computeRESV
+ * (SimulatorBase_impl.hpp:476-553) and computeWellVoidageRates (BlackoilModelBase_impl.hpp:2490-2534) call:
+ * defineState -> calcAverages (:718-768): per region the SUMS of p, rs, rv of the RESIDENT state over the cells and their number,
+ *   sums[nregions][4]; region[nc] in the caller's cell order with values 0 .. nregions-1, NULL = one region of all cells (what
+ *   SimulatorBase builds, SimulatorBase_impl.hpp:66).  Collective in decomposed runs (owned cells, summed over the ranks: the is_parallel
+ *   branch).  The division -- and the reference's habit of NOT clearing rs / rv between calls (:733-737) -- stay with the caller's mirror.
+ * calcCoeff (:495-548): coeff[n][3] (water, oil, gas) with q_rT = sum_p coeff[p] q_s[p] at n given (p, rs, rv) points; pvt_region NULL = 0. */
+int opmgpu_region_state_sums(opmgpu_ctx* ctx, const int32_t* region, int nregions, double* sums);
+int opmgpu_voidage_coefficients(opmgpu_ctx* ctx, int n, const double* p, const double* rs, const double* rv, const int32_t* pvt_region, double* coeff);
 
 /* BlackoilModelBase::computeFluidInPlace (BlackoilModelBase_impl.hpp:2263-2445; called by SimulatorBase_impl.hpp:207, :278 and
  * AdaptiveTimeStepping_impl.hpp:322) for the RESIDENT state: per cell fip[phase] = pv_mult * b_phase * s_phase * pv (b at the phase

@@ -945,6 +945,50 @@ __global__ __launch_bounds__(kBlock) void k_perf_pvt(int nperf, opmgpu_tables T,
     o[4] = f;
 }
 
+// RateConverter::SurfaceToReservoirVoidage::calcCoeff (RateConverterLegacy.hpp:495-548): coefficients c with q_rT = sum_p c[p] q_s[p] at a
+// region's average state (p, rs, rv) -- b_w(p), the UNDERSATURATED b_o(p, rs) and b_g(p, rv) (FluidSystem::oilPvt().inverseFormationVolumeFactor(
+// region, T, p, Rs): the tables are evaluated at the given ratios whatever the saturated curve says), detR = 1 - rs rv.
+__global__ __launch_bounds__(kBlock) void k_voidage_coeff(int n, opmgpu_tables T, const double* __restrict__ press, const double* __restrict__ rs_,
+                                                          const double* __restrict__ rv_, const int32_t* __restrict__ pvtreg, double* __restrict__ coeff)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int preg = pvtreg ? pvtreg[i] : 0;
+    const double p = press[i], rs = rs_[i], rv = rv_[i];
+    double f, df, d2, bw, bo, bg;
+    {
+        const double* w = T.pvtw + 5 * preg;
+        const double Xc = w[2] * (p - w[0]);
+        bw = (1.0 + Xc * (1.0 + Xc / 2.0)) / w[1];
+    }
+    {
+        const int a = T.oil_node_ptr[preg], nn = T.oil_node_ptr[preg + 1] - a;
+        if (!T.has_disgas) pvt1(T.oil_psat + a, T.oil_invb_sat + a, nn, p, f, df);
+        else pvt2(T.oil_rs + a, nn, T.oil_col_ptr + a, T.oil_col_p, T.oil_col_invb, rs, p, f, d2, df);
+        bo = f;
+    }
+    {
+        const int a = T.gas_node_ptr[preg], nn = T.gas_node_ptr[preg + 1] - a;
+        if (!T.has_vapoil) pvt1(T.gas_pg + a, T.gas_invb_sat + a, nn, p, f, df);
+        else pvt2(T.gas_pg + a, nn, T.gas_col_ptr + a, T.gas_col_rv, T.gas_col_invb, p, rv, f, df, d2);
+        bg = f;
+    }
+    const double detR = 1.0 - (rs * rv);
+    double cw = 0.0, co = 0.0, cg = 0.0;
+    cw = 1.0 / bw;                                  // q[w]_r = q[w]_s / bw
+    {
+        const double den = bo * detR;               // q[o]_r = 1/(bo (1 - rs rv)) (q[o]_s - rv q[g]_s)
+        co += 1.0 / den;
+        cg -= rv / den;
+    }
+    {
+        const double den = bg * detR;               // q[g]_r = 1/(bg (1 - rs rv)) (q[g]_s - rs q[o]_s)
+        cg += 1.0 / den;
+        co -= rs / den;
+    }
+    coeff[3 * long(i) + 0] = cw; coeff[3 * long(i) + 1] = co; coeff[3 * long(i) + 2] = cg;
+}
+
 __global__ __launch_bounds__(kBlock) void k_add_well_resid(int nperf, int nbp, const int32_t* __restrict__ cells, const double* __restrict__ delta, double* __restrict__ R)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -1909,6 +1953,47 @@ void BlackoilDevice::fluid_in_place(const int32_t* fipnum, int dims, double* fip
         std::copy(fpv.begin(), fpv.end(), fip_cells + size_t(5) * nc);
         std::copy(fwp.begin(), fwp.end(), fip_cells + size_t(6) * nc);
     }
+}
+
+// RateConverter::SurfaceToReservoirVoidage::calcAverages (RateConverterLegacy.hpp:718-768), the sums only: per region sum of p, rs, rv over the
+// cells and their number, in cell order like the reference's loop; decomposed runs: over the OWNED cells, then summed over the ranks (its
+// is_parallel branch).  region: per cell in the caller's order, values 0 .. nregions-1 (nullptr = one region: what SimulatorBase builds,
+// SimulatorBase_impl.hpp:66).  sums: [nregions][4] = sum p, sum rs, sum rv, n.  An output-cadence path (once per report step).
+void BlackoilDevice::region_state_sums(const int32_t* region, int nregions, double* sums)
+{
+    std::vector<double> p(nc), sat(3 * size_t(nc)), rs(nc), rv(nc);
+    std::vector<int8_t> hc(nc);
+    get_state(p.data(), sat.data(), rs.data(), rv.data(), hc.data());
+    const int n_own = ls.comm ? n_owned_cells : nc;
+    for (int i = 0; i < 4 * nregions; ++i) sums[i] = 0.0;
+    for (int c = 0; c < n_own; ++c) {
+        const int r = region ? region[c] : 0;
+        if (r < 0 || r >= nregions) throw HipError(OPMGPU_EINVAL, "region_state_sums: region index out of range");
+        sums[4 * r + 0] += p[c]; sums[4 * r + 1] += rs[c]; sums[4 * r + 2] += rv[c]; sums[4 * r + 3] += 1.0;
+    }
+    if (ls.comm) {
+        DevArray<double> d;
+        d.upload(sums, size_t(4) * nregions, stream);
+        ls.comm->allreduce_sum(d.p, 4 * nregions, stream);
+        d.download(sums, size_t(4) * nregions, stream);
+        OPMGPU_HIP(hipStreamSynchronize(stream));
+    }
+}
+
+void BlackoilDevice::voidage_coefficients(int n, const double* p, const double* rs, const double* rv, const int32_t* pvtreg, double* coeff)
+{
+    if (n <= 0) return;
+    if (pvtreg) for (int i = 0; i < n; ++i) if (pvtreg[i] < 0 || pvtreg[i] >= dt_.n_pvt_regions) throw HipError(OPMGPU_EINVAL, "voidage_coefficients: PVT region out of range");
+    DevArray<double> din, dout; DevArray<int32_t> dreg;
+    std::vector<double> h(3 * size_t(n));
+    std::copy(p, p + n, h.begin()); std::copy(rs, rs + n, h.begin() + n); std::copy(rv, rv + n, h.begin() + 2 * size_t(n));
+    din.upload(h.data(), h.size(), stream);
+    if (pvtreg) dreg.upload(pvtreg, size_t(n), stream);
+    dout.alloc(3 * size_t(n));
+    hipLaunchKernelGGL(k_voidage_coeff, dim3(grid_for(n)), dim3(kBlock), 0, stream, n, dt_, din.p, din.p + n, din.p + 2 * size_t(n),
+                       pvtreg ? (const int32_t*)dreg.p : (const int32_t*)nullptr, dout.p);
+    dout.download(coeff, 3 * size_t(n), stream);
+    OPMGPU_HIP(hipStreamSynchronize(stream));
 }
 
 void BlackoilDevice::get_residual(double* r)

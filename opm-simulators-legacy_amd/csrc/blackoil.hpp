@@ -36,6 +36,8 @@ public:
     void set_state(const double* p, const double* sat, const double* rs, const double* rv, const int8_t* hc);
     void get_state(double* p, double* sat, double* rs, double* rv, int8_t* hc);
     void fluid_in_place(const int32_t* fipnum, int dims, double* fip_cells, double* values);      // computeFluidInPlace (:2263-2445)
+    void region_state_sums(const int32_t* region, int nregions, double* sums);                   // RateConverter calcAverages (RateConverterLegacy.hpp:718-768)
+    void voidage_coefficients(int n, const double* p, const double* rs, const double* rv, const int32_t* pvtreg, double* coeff);   // calcCoeff (:495-548)
     void assemble(double dt, bool initial);
     template <class MS> void assemble_kernels(double dt, bool initial, MS* A, bool props_only = false);
     bool assemble_single = false;      // precision of the coming solve (opmgpu_set_solve_precision)
@@ -82,6 +84,7 @@ public:
     bool has_device_wells() const;        // a device well model is attached (on this or, in a multi-rank run, on any rank)
     int set_vfp_tables(int n, const opmgpu_vfp_table* tabs);
     int well_controls_set(const int32_t* current, const double* thp);
+    int well_controls_set_targets(const double* target, const double* distr);
     int well_controls_get(int32_t* current, double* thp, int32_t* pre_its, int32_t* pre_conv);
     void wells_recover();                                   // recoverVariable: well part of the increment from the resident dx
     bool device_wells = false;

@@ -340,6 +340,11 @@ int opmgpu_well_controls_set(opmgpu_ctx* c, const int32_t* current, const double
     if (!c || !c->model) return OPMGPU_EINVAL;
     return guarded(c, [&]() { return c->model->well_controls_set(current, thp); });
 }
+int opmgpu_well_controls_set_targets(opmgpu_ctx* c, const double* target, const double* distr)
+{
+    if (!c || !c->model || (!target && !distr)) return OPMGPU_EINVAL;
+    return guarded(c, [&]() { return c->model->well_controls_set_targets(target, distr); });
+}
 int opmgpu_well_controls_get(opmgpu_ctx* c, int32_t* current, double* thp, int32_t* pre_its, int32_t* pre_conv)
 {
     if (!c || !c->model) return OPMGPU_EINVAL;
@@ -486,6 +491,18 @@ int opmgpu_compute_fluid_in_place(opmgpu_ctx* c, const int32_t* fipnum, int nreg
     if (!c->model->has_state) return fail(c, OPMGPU_EINVAL, "no reservoir state on the device");
     if (fipnum) for (int i = 0; i < c->model->nc; ++i) if (fipnum[i] < 0 || fipnum[i] > nregions) return fail(c, OPMGPU_EINVAL, "fipnum outside [0, nregions]");
     return guarded(c, [&]() { c->model->fluid_in_place(fipnum, nregions, fip_cells, values); return int(OPMGPU_OK); });
+}
+
+int opmgpu_region_state_sums(opmgpu_ctx* c, const int32_t* region, int nregions, double* sums)
+{
+    if (!c || !c->model || !sums || nregions < 1) return OPMGPU_EINVAL;
+    if (!c->model->has_state) return fail(c, OPMGPU_EINVAL, "no reservoir state on the device");
+    return guarded(c, [&]() { c->model->region_state_sums(region, nregions, sums); return int(OPMGPU_OK); });
+}
+int opmgpu_voidage_coefficients(opmgpu_ctx* c, int n, const double* p, const double* rs, const double* rv, const int32_t* pvt_region, double* coeff)
+{
+    if (!c || !c->model || n < 0 || (n > 0 && (!p || !rs || !rv || !coeff))) return OPMGPU_EINVAL;
+    return guarded(c, [&]() { c->model->voidage_coefficients(n, p, rs, rv, pvt_region, coeff); return int(OPMGPU_OK); });
 }
 
 int opmgpu_relative_change(opmgpu_ctx* c, double* value)

@@ -17,7 +17,8 @@
 //   solveWellEq (explicit well pre-solve, default on) BlackoilModelBase_impl.hpp:1018-1133          (k_well_assemble<PRE> + k_well_presolve_step)
 //   THP control through VFP tables                   :655-700, :895-960; VFPProd/InjPropertiesLegacy.cpp   (vfp_* below)
 //   PVT at the average well-block pressure           :218-296                                       (k_well_avg_press + k_perf_pvt)
-// Not restated: group controls / guide rates, RESERVOIR_RATE conversion coefficients, efficiency factors.
+//   RESERVOIR_RATE conversion coefficients          RateConverterLegacy.hpp:495-548, :718-768        (k_voidage_coeff, region_state_sums in blackoil.hip)
+// Not restated: group controls / guide rates, efficiency factors.
 #include "blackoil.hpp"
 
 #include <algorithm>
@@ -1278,6 +1279,17 @@ int BlackoilDevice::well_controls_set(const int32_t* current, const double* thp)
         W.current.upload(current, size_t(W.nw), stream);
     }
     if (thp) W.thp.upload(thp, size_t(W.nw), stream);
+    OPMGPU_HIP(hipStreamSynchronize(stream));
+    return OPMGPU_OK;
+}
+// well_controls_iset_target / well_controls_iset_distr of every control at once (what SimulatorBase::computeRESV does to the RESERVOIR_RATE
+// controls once per report step, SimulatorBase_impl.hpp:551-553): target[nctrl] and / or distr[nctrl][3] in the order of opmgpu_set_device_wells
+int BlackoilDevice::well_controls_set_targets(const double* target, const double* distr)
+{
+    if (!wd) return OPMGPU_EINVAL;
+    WellsDev& W = *wd;
+    if (target) W.ctrl_target.upload(target, size_t(W.nctrl), stream);
+    if (distr) W.ctrl_distr.upload(distr, 3 * size_t(W.nctrl), stream);
     OPMGPU_HIP(hipStreamSynchronize(stream));
     return OPMGPU_OK;
 }

@@ -165,6 +165,20 @@ int main()
             std::printf("host_check: fluids in place: water %.5g, oil %.5g, free gas %.5g sm3, pore volume %.5g m3, hydrocarbon-pv weighted pressure %.1f bar\n",
                         fip[0][0], fip[0][1], fip[0][2], fip[0][5], fip[0][6] / 1e5);
         }
+        // RateConverter of SimulatorBase::computeRESV on the resident state: one region, the coefficients of the top PVT region
+        {
+            opmgpu::SurfaceToReservoirVoidageGpu cvrt(model.handle());
+            cvrt.defineState();
+            double distr[3] = { 0.0, 0.0, 0.0 };
+            cvrt.calcCoeff(0, 0, distr);
+            const auto& a = cvrt.attributes(0);
+            if (!(a.pressure > 1e5) || !(distr[0] > 0.9 && distr[0] < 1.1) || !(distr[1] > 0.0) || !(distr[2] > 0.0)) {
+                std::printf("host_check: FAILED, voidage coefficients %g %g %g at %g Pa\n", distr[0], distr[1], distr[2], a.pressure);
+                return 1;
+            }
+            std::printf("host_check: RESV coefficients at the field's average state (%.1f bar, rs %.3g, rv %.3g): %.5g %.5g %.5g\n",
+                        a.pressure / 1e5, a.rs, a.rv, distr[0], distr[1], distr[2]);
+        }
         std::printf("host_check: report step of 20 d in %zu sub-steps (first %.2f d, last %.2f d), %d failed, next suggestion %.2f d\n",
                     ats.substeps.size(), ats.substeps.front() / 86400.0, ats.substeps.back() / 86400.0, ats.failed_substeps,
                     ats.suggested_next_timestep / 86400.0);

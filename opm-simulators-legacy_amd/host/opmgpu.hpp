@@ -230,6 +230,56 @@ private:
 };
 
 /// NonlinearSolver (NonlinearSolver_impl.hpp:119-301): step loop, oscillation detection, relaxation parameters
+/// RateConverter::SurfaceToReservoirVoidage (RateConverterLegacy.hpp:407-770) over the resident state: defineState takes the regions'
+/// sums from the library (collective in decomposed runs), calcCoeff evaluates the PVT tables on the device at the region's average state.
+/// `region` empty = one region 0 of all cells, what SimulatorBase builds (SimulatorBase_impl.hpp:66) and asks for (:548).
+class SurfaceToReservoirVoidageGpu {
+public:
+    SurfaceToReservoirVoidageGpu(opmgpu_ctx* ctx, const std::vector<int>& region = {}, int n_ranks = 1)
+        : ctx_(ctx), n_ranks_(n_ranks)
+    {
+        ids_ = region;
+        std::sort(ids_.begin(), ids_.end());
+        ids_.erase(std::unique(ids_.begin(), ids_.end()), ids_.end());
+        if (ids_.empty()) ids_.push_back(0);
+        index_.reserve(region.size());
+        for (int r : region) index_.push_back(int32_t(std::lower_bound(ids_.begin(), ids_.end(), r) - ids_.begin()));
+        attr_.assign(ids_.size(), Attributes{ 0.0, 0.0, 0.0 });          // Attributes(): all zero (:684-692)
+    }
+    /// calcAverages (:718-768).  p is cleared before the loop, rs and rv are NOT (:733-737): they start from the previous call's averages
+    /// (on every rank of a parallel run) -- restated as found.
+    void defineState()
+    {
+        std::vector<double> sums(4 * ids_.size(), 0.0);
+        throw_on_status(ctx_, opmgpu_region_state_sums(ctx_, index_.empty() ? nullptr : index_.data(), int(ids_.size()), sums.data()));
+        for (std::size_t k = 0; k < ids_.size(); ++k) {
+            const double n = sums[4 * k + 3];
+            attr_[k].pressure = sums[4 * k + 0] / n;
+            attr_[k].rs = (n_ranks_ * attr_[k].rs + sums[4 * k + 1]) / n;
+            attr_[k].rv = (n_ranks_ * attr_[k].rv + sums[4 * k + 2]) / n;
+        }
+    }
+    /// calcCoeff (:495-548): q_rT = sum_p coeff[p] q_s[p], phases water, oil, gas
+    template <class Coeff> void calcCoeff(int r, int pvtRegionIdx, Coeff& coeff) const
+    {
+        const std::size_t k = std::size_t(std::lower_bound(ids_.begin(), ids_.end(), r) - ids_.begin());
+        if (k >= ids_.size() || ids_[k] != r) throw std::invalid_argument("SurfaceToReservoirVoidageGpu::calcCoeff: unknown region");
+        const int32_t reg = pvtRegionIdx;
+        double c[3];
+        throw_on_status(ctx_, opmgpu_voidage_coefficients(ctx_, 1, &attr_[k].pressure, &attr_[k].rs, &attr_[k].rv, &reg, c));
+        for (int p = 0; p < 3; ++p) coeff[p] = c[p];
+    }
+    struct Attributes { double pressure, rs, rv; };
+    const Attributes& attributes(int r) const { return attr_[std::size_t(std::lower_bound(ids_.begin(), ids_.end(), r) - ids_.begin())]; }
+
+private:
+    opmgpu_ctx* ctx_;
+    int n_ranks_;
+    std::vector<int> ids_;
+    std::vector<int32_t> index_;
+    std::vector<Attributes> attr_;
+};
+
 struct NonlinearSolverGpu {
     int max_iter = 10, min_iter = 1;                                          // SolverParameters::reset (:183-192)
     int relax_type = OPMGPU_RELAX_DAMPEN;

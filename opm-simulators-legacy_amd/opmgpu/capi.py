@@ -166,6 +166,9 @@ SIGNATURES = {
     "opmgpu_save_state": (C.c_int, [C.c_void_p]),
     "opmgpu_restore_state": (C.c_int, [C.c_void_p]),
     "opmgpu_relative_change": (C.c_int, [C.c_void_p, _dp]),
+    "opmgpu_well_controls_set_targets": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "opmgpu_region_state_sums": (C.c_int, [C.c_void_p, _ip, C.c_int, _dp]),
+    "opmgpu_voidage_coefficients": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _ip, _dp]),
     "opmgpu_compute_fluid_in_place": (C.c_int, [C.c_void_p, _ip, C.c_int, _dp, _dp]),
     "opmgpu_set_sat_oil_max": (C.c_int, [C.c_void_p, _dp]),
     "opmgpu_update_sat_oil_max": (C.c_int, [C.c_void_p]),

@@ -11,8 +11,9 @@ the deck gives, the deck's control mode is the initial current control, the othe
 updateWellControls switches to (StandardWells_impl.hpp:709-800).  Producer rate targets are negative (flow into the wellbore).
 A defaulted connection factor is Peaceman's for a vertical well in a block-centred cell (WellsManager::createWellsFromSpecs ->
 computeWellIndices, opm-core, external: restated from the published formula).  METRIC units.
-Not read: groups (GCONPROD ...), WCONHIST, multi-segment wells, horizontal completions (dir X / Y), RESV control values
-(the reservoir-volume rate coefficients come from RateConverter; a RESV mode is rejected).
+Not read: groups (GCONPROD ...), WCONHIST, multi-segment wells, horizontal completions (dir X / Y).  A RESV target becomes a
+RESERVOIR_RATE control with distr {1, 1, 1}; opmgpu/rateconverter.py's computeRESV gives it the conversion coefficients once per report
+step (SimulatorBase_impl.hpp:196, :476-553).
 """
 import datetime
 
@@ -181,11 +182,13 @@ class Schedule:
                 ctrls = {}
                 if lim["RATE"] is not None:
                     ctrls["RATE"] = (W.SURFACE_RATE, lim["RATE"] / DAY, comp)
+                if lim["RESV"] is not None:          # distr {1, 1, 1} until SimulatorBase::computeRESV fills in the conversion coefficients
+                    ctrls["RESV"] = (W.RESERVOIR_RATE, lim["RESV"] / DAY, (1.0, 1.0, 1.0))
                 if lim["BHP"] is not None:
                     ctrls["BHP"] = (W.BHP, lim["BHP"] * BAR)
                 if lim["THP"] is not None and lim["VFP"] > 0:
                     ctrls["THP"] = (W.THP, lim["THP"] * BAR, None, lim["VFP"], 0.0)
-                if mode in ("RESV", "GRUP"):
+                if mode == "GRUP":
                     raise ValueError("WCONINJE %s: control mode %s is not supported" % (name, mode))
                 wtype = W.INJECTOR
             else:
@@ -195,11 +198,13 @@ class Schedule:
                 for key, distr in (("ORAT", (0.0, 1.0, 0.0)), ("WRAT", (1.0, 0.0, 0.0)), ("GRAT", (0.0, 0.0, 1.0)), ("LRAT", (1.0, 1.0, 0.0))):
                     if lim[key] is not None:
                         ctrls[key] = (W.SURFACE_RATE, -lim[key] / DAY, distr)
+                if lim["RESV"] is not None:
+                    ctrls["RESV"] = (W.RESERVOIR_RATE, -lim["RESV"] / DAY, (1.0, 1.0, 1.0))
                 if lim["BHP"] is not None:
                     ctrls["BHP"] = (W.BHP, lim["BHP"] * BAR)
                 if lim["THP"] is not None and lim["VFP"] > 0:
                     ctrls["THP"] = (W.THP, lim["THP"] * BAR, None, lim["VFP"], lim["ALQ"] or 0.0)
-                if mode in ("RESV", "GRUP", "CRAT"):
+                if mode in ("GRUP", "CRAT"):
                     raise ValueError("WCONPROD %s: control mode %s is not supported" % (name, mode))
                 wtype = W.PRODUCER
             if mode not in ctrls:

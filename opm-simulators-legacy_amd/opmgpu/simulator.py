@@ -120,6 +120,11 @@ class Simulator:
             if hasattr(gm, "updateSatOilMax"):
                 gm.updateSatOilMax()                      # SimulatorBase_impl.hpp:190-192
                 gm.updateHysteresis()
+            if wl.nw > 0 and hasattr(gm, "lib"):         # SimulatorBase_impl.hpp:196: computeRESV before the step's solver is built
+                from .rateconverter import SurfaceToReservoirVoidage, computeRESV
+                if getattr(self, "_rate_converter", None) is None:
+                    self._rate_converter = SurfaceToReservoirVoidage(gm)      # one region of all cells (:66), a member like rateConverter_
+                computeRESV(self._rate_converter, wl, pvtnum=getattr(self.grid, "pvtnum", None))
             if wl.nw == 0:
                 model = gm
             elif self.well_model_factory is not None:

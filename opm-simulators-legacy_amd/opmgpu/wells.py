@@ -16,8 +16,10 @@ terms go back through `addWellTerms` / `addWellRhs`, the perforated cells' incre
   THP control through VFP tables (opmgpu/vfp.py)   StandardWells_impl.hpp:655-700, :895-960
   computePropertiesForWellConnectionPressures (PVT at the average well-block pressure)   :218-296
 
-Not restated: group controls / guide rates (WellCollection), RESERVOIR_RATE conversion coefficients (a RESERVOIR_RATE control is
-treated like the reference's control equation treats it: a weighted rate sum with the given distribution), efficiency factors.
+  RESERVOIR_RATE controls: the control equation is the weighted rate sum with the control's distribution (:938-955); the distribution
+  comes from opmgpu/rateconverter.py (RateConverter::SurfaceToReservoirVoidage + SimulatorBase::computeRESV)
+
+Not restated: group controls / guide rates (WellCollection), efficiency factors.
 """
 import numpy as np
 

@@ -295,3 +295,26 @@ def test_first_broken_constraint_wins_in_wellsmanagers_order(tmp_path):
     # ... its target becomes the oil rate; the water limit is still broken then, so the loop goes on to WRAT and rests there
     assert mine[1:] == [(w, 0, 1)] and ws.current[w] == 1
     assert ws.qs[w, 1] == pytest.approx(-150.0 / 86400.0) and ws.qs[w, 0] == pytest.approx(-20.0 / 86400.0)
+
+
+def test_resv_mode_becomes_a_reservoir_rate_control(tmp_path):
+    """WCONPROD ... 'RESV': a RESERVOIR_RATE control in WellsManager's slot (after LRAT, before BHP) with distr {1, 1, 1} and a negative
+    target; SimulatorBase::computeRESV (opmgpu/rateconverter.py) overwrites the distr once per report step"""
+    from opmgpu import deck as deckmod, schedule
+    from opmgpu.rateconverter import resv_control
+    src = open(os.path.join(GOLD, "decks", "SCHEDULE_SMALL.DATA")).read()
+    src = src.replace(" 'PROD1' 'OPEN' 'ORAT' 150 4* 180 /", " 'PROD1' 'OPEN' 'RESV' 150 3* 400 180 /", 1)
+    path = tmp_path / "RESV.DATA"
+    path.write_text(src)
+    d = deckmod.read_deck(str(path))
+    g = d.grid()
+    n = g.nc
+    dx, dy, dz = d._cell_sizes()
+    s = schedule.Schedule(d, g, perm_md=(d.array("PERMX", n), d.array("PERMY", n)), dz=dz.ravel(), dxdy=(dx.ravel(), dy.ravel()), ntg=np.ones(n))
+    wl = s.wells(0)
+    w = wl.name.index("PROD1")
+    types = [c[0] for c in wl.controls[w]]
+    assert types == [W.SURFACE_RATE, W.RESERVOIR_RATE, W.BHP]                     # ORAT, RESV, BHP
+    assert resv_control(wl.controls[w]) == 1 and wl.current0[w] == 1
+    c = wl.controls[w][1]
+    assert c[1] == pytest.approx(-400.0 / 86400.0) and tuple(c[2]) == (1.0, 1.0, 1.0)
