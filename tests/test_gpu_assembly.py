@@ -366,7 +366,7 @@ def test_cpp_host_mirror_runs_a_time_step(gpu_lib):
     exe = os.path.join(os.path.dirname(capi.LIB_PATH), "host_check")
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "host_check: converged in" in out.stdout and "host_check: report step of 20 d in" in out.stdout and "one-call Newton loop" in out.stdout, out.stdout
+    assert "host_check: converged in" in out.stdout and "host_check: report step of 20 d in" in out.stdout and "one-call Newton loop" in out.stdout and "RESV coefficients" in out.stdout, out.stdout
     assert "host_check: fluids in place" in out.stdout, out.stdout          # BlackoilModelGpu::computeFluidInPlace
 
 
