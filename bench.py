@@ -6,7 +6,10 @@ Workload (BASELINE.json configs[2]): the synthetic 100x100x100 three-
 injector + four BHP producers, full columns, device well model incl. control switching and the explicit well pre-solve).  A "step" is
 one Newton iteration of the fully-implicit black-oil model: assemble (reservoir + wells) -> getConvergence -> solveJacobianSystem ->
 updateState, state resident in HBM.  Time steps follow each other like in the simulator (NonlinearSolver with the reference's update
-stabilisation); the synthetic initial state is far from equilibrium, so two time steps pass before anything is timed (deck set-up).
+stabilisation; a step the reference's time stepper would cut -- not converged within max_iter, or a caught solver / numerical
+condition -- restarts with 0.33 dt as in AdaptiveTimeStepping_impl.hpp:244-359).  The run starts like a simulation does, with a 1-day
+step that grows by at most 3 per step towards --dt-days (timestep.initial_timestep_in_days, :110); timing begins once two steps have
+passed and the step length has reached dt (deck set-up, untimed).
 
 Which solver the headline runs, and in which arithmetic:
   * the reference's DEFAULT is solver_approach=interleaved: block-ILU0 + BiCGStab, in float when dt < 20 d and in double otherwise

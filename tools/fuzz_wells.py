@@ -1,5 +1,6 @@
 """Randomised campaign for the device well model (csrc/wells.hip) against the CPU oracle driven by the host well model with the explicit
-Schur complement: random small decks, 1-4 wells with random type / control / perforations / crossflow flag, ILU0 or CPR, three Newton
+Schur complement: random small decks, 1-4 wells with random type / control (BHP, surface rate, or RESV: reservoir-volume rate with the
+coefficients of RateConverter / computeRESV, device against oracle restatement) / perforations / crossflow flag, ILU0 or CPR, three Newton
 iterations each: reservoir state, well state and well residuals must agree.      python tools/fuzz_wells.py [ncases] [seed0]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,7 +9,9 @@ import numpy as np
 import torch  # noqa: F401
 from opmgpu import capi, decks, wells as W
 from opmgpu.model import GpuBlackoilModel
+from opmgpu.rateconverter import SurfaceToReservoirVoidage, computeRESV
 from oracle import oracle as orc
+from oracle.rateconverter import SurfaceToReservoirVoidage as OracleVoidage
 from util import OracleBackend
 
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
@@ -31,13 +34,16 @@ for case in range(ncases):
         k0 = int(rng.integers(0, nz)); k1 = int(rng.integers(k0 + 1, nz + 1))
         cells = [int(cols[w]) + nx * ny * k for k in range(k0, k1)]
         inj = rng.random() < 0.5
+        resv = rng.random() < 0.3
         bhp_ctrl = rng.random() < 0.5 or (w == nw - 1 and not have_bhp)          # at least one pressure control anchors the box
         have_bhp = have_bhp or bhp_ctrl
         if inj:
-            ctrl = (W.BHP, float(rng.uniform(260, 300)) * decks.BAR) if bhp_ctrl else (W.SURFACE_RATE, float(rng.uniform(0.2, 1.0)) * pv_rate, (1.0, 0.0, 0.0))
+            ctrl = (W.BHP, float(rng.uniform(260, 300)) * decks.BAR) if bhp_ctrl else \
+                   (W.RESERVOIR_RATE, float(rng.uniform(0.2, 1.0)) * pv_rate, (1.0, 1.0, 1.0)) if resv else (W.SURFACE_RATE, float(rng.uniform(0.2, 1.0)) * pv_rate, (1.0, 0.0, 0.0))
             wl.add_well("I%d" % w, W.INJECTOR, grid.z[cells[0]], cells, WI, (1.0, 0.0, 0.0), ctrl, allow_cf=bool(rng.random() < 0.7))
         else:
-            ctrl = (W.BHP, float(rng.uniform(180, 240)) * decks.BAR) if bhp_ctrl else (W.SURFACE_RATE, -float(rng.uniform(0.2, 1.0)) * pv_rate, (0.0, 1.0, 0.0))
+            ctrl = (W.BHP, float(rng.uniform(180, 240)) * decks.BAR) if bhp_ctrl else \
+                   (W.RESERVOIR_RATE, -float(rng.uniform(0.2, 1.0)) * pv_rate, (1.0, 1.0, 1.0)) if resv else (W.SURFACE_RATE, -float(rng.uniform(0.2, 1.0)) * pv_rate, (0.0, 1.0, 0.0))
             wl.add_well("P%d" % w, W.PRODUCER, grid.z[cells[0]], cells, WI, (0.0, 1.0, 0.0), ctrl, allow_cf=bool(rng.random() < 0.7))
     cpr = int(rng.integers(0, 2))
     prm = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=800, use_cpr=cpr)
@@ -52,12 +58,18 @@ for case in range(ncases):
         def start_state():
             w0 = W.WellState(wl, st.p)
             for w_ in range(wl.nw):
-                if wl.ctrl_type[w_] == W.BHP:
+                if wl.ctrl_type[w_] in (W.BHP, W.RESERVOIR_RATE):          # neither control seeds the rates (updateWellStateWithTarget)
                     w0.qs[w_] = (1e-5 if wl.type[w_] == W.INJECTOR else -1e-5) * np.asarray(wl.comp_frac[w_])
             return w0
         md = W.DeviceWellModel(gm, wl, start_state())
         mo = W.WellCoupledModel(ob, W.StandardWellsHost(wl, grid.z, tab.surface_density[0]), start_state())
         md.prepareStep(dt, st); mo.prepareStep(dt, st)
+        # computeRESV (SimulatorBase_impl.hpp:476-553): the device's coefficients go into the shared controls, the oracle's restatement must agree
+        if computeRESV(SurfaceToReservoirVoidage(gm), wl, device_wells=md):
+            want = OracleVoidage(tab, np.zeros(grid.nc, int)).defineState(st.p, st.rs, st.rv).calcCoeff(0, 0)
+            for w_ in range(wl.nw):
+                if wl.controls[w_][0][0] == W.RESERVOIR_RATE:
+                    assert np.allclose(wl.controls[w_][0][2], want, rtol=1e-13, atol=0.0), (case, wl.controls[w_][0][2], want)
         for it in range(3):
             try:
                 co, _ = mo.nonlinearIteration(it, single_precision=False)
