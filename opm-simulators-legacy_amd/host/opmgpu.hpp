@@ -99,6 +99,7 @@ public:
     BlackoilModelGpu(const opmgpu_grid& grid, const opmgpu_tables& tables, const opmgpu_params* prm = nullptr, int device = 0)
     {
         nc_ = grid.nc;
+        use_cpr_ = prm && prm->use_cpr;
         const int st = opmgpu_create(&ctx_, device, &grid, &tables, prm);
         if (st != OPMGPU_OK) throw std::runtime_error("opmgpu_create failed (no GPU? there is no CPU fallback), status " + std::to_string(st));
     }
@@ -162,10 +163,13 @@ public:
         throw_on_status(ctx_, st);         // NumericalIssue on NaN / too large residual
         return r;
     }
-    /// solveJacobianSystem (:1139-1145); residual_.singlePrecision = dt < maxSinglePrecisionTimeStep (:284)
+    /// residual_.singlePrecision = dt < maxSinglePrecisionTimeStep (:284) is honoured by the interleaved solver only
+    /// (NewtonIterationBlackoilInterleaved.cpp:478-480); the CPR plug-in computes in double whatever it says (NewtonIterationBlackoilCPR.cpp:117-140)
+    bool referencePrecisionIsSingle() const { return !use_cpr_ && dt_ < max_single_precision_days_ * 86400.0; }
+    /// solveJacobianSystem (:1139-1145)
     void solveJacobianSystem()
     {
-        const int single = dt_ < max_single_precision_days_ * 86400.0 ? 1 : 0;
+        const int single = referencePrecisionIsSingle() ? 1 : 0;
         throw_on_status(ctx_, opmgpu_solve(ctx_, single, nullptr, &linear_iterations_, &linear_reduction_));
     }
     void updateState(double relax = 1.0) { throw_on_status(ctx_, opmgpu_update_state(ctx_, nullptr, relax)); }
@@ -177,7 +181,7 @@ public:
     bool nonlinearIteration(int iteration, const NonlinearSolverType& nonlinear_solver)
     {
         if (iteration == 0) { residual_norms_history_.clear(); current_relaxation_ = 1.0; }    // dx_old is zeroed by the initial assembly
-        throw_on_status(ctx_, opmgpu_set_solve_precision(ctx_, dt_ < max_single_precision_days_ * 86400.0 ? 1 : 0));   // :284, before the assembly
+        throw_on_status(ctx_, opmgpu_set_solve_precision(ctx_, referencePrecisionIsSingle() ? 1 : 0));   // :284, before the assembly
         assemble(iteration == 0);
         ConvergenceReport r = getConvergence();
         r.converged = wellsConverged(r) && r.converged;
@@ -220,6 +224,7 @@ public:
 private:
     opmgpu_ctx* ctx_ = nullptr;
     int nc_ = 0;
+    bool use_cpr_ = false;
     double dt_ = 0.0, max_single_precision_days_ = 20.0, linear_reduction_ = 0.0;
     int linear_iterations_ = 0;
     bool use_update_stabilization_ = true;              // BlackoilModelParameters.cpp:98

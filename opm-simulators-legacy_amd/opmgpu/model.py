@@ -188,9 +188,17 @@ class GpuBlackoilModel:
         self._chk(st)
         return bool(conv.value)
 
+    def referencePrecision(self):
+        """The arithmetic the reference's plug-in solves in: residual_.singlePrecision = dt < maxSinglePrecisionTimeStep_
+        (BlackoilModelBase_impl.hpp:284) is honoured by the interleaved solver only (NewtonIterationBlackoilInterleaved.cpp:478-480);
+        the CPR plug-in never reads it and computes in double (NewtonIterationBlackoilCPR.cpp:117-140)."""
+        if self.params.use_cpr:
+            return False
+        return self.dt < self.max_single_precision_days * 86400.0
+
     def solveJacobianSystem(self, want_dx=False, single_precision=None):
-        if single_precision is None:     # residual_.singlePrecision = dt < maxSinglePrecisionTimeStep_ (:284)
-            single_precision = self.dt < self.max_single_precision_days * 86400.0
+        if single_precision is None:
+            single_precision = self.referencePrecision()
         dx = np.zeros(3 * self.nc) if want_dx else None
         it, red = C.c_int(0), C.c_double(0)
         st = self.lib.opmgpu_solve(self.ctx, int(single_precision), capi.dptr(dx), C.byref(it), C.byref(red))
@@ -255,7 +263,7 @@ class GpuBlackoilModel:
         """residual_.singlePrecision = dt < maxSinglePrecisionTimeStep (:284), told to the device BEFORE the assembly so that
         the Jacobian is written in the solve's precision."""
         if single_precision is None:
-            single_precision = self.dt < self.max_single_precision_days * 86400.0
+            single_precision = self.referencePrecision()
         self._chk(self.lib.opmgpu_set_solve_precision(self.ctx, int(bool(single_precision))))
 
     def stabilizeUpdate(self, relax_type, omega):
@@ -291,7 +299,7 @@ class GpuBlackoilModel:
 
     def _fused_iteration(self, iteration, single_precision, ns):
         if single_precision is None:
-            single_precision = self.dt < self.max_single_precision_days * 86400.0
+            single_precision = self.referencePrecision()
         ctl = capi.NewtonCtl(int(ns.min_iter), int(self.use_update_stabilization), int(ns.relax_type), float(ns.relax_max), float(ns.relax_increment),
                              float(ns.relax_rel_tol))
         conv, lin, relax = C.c_int(0), C.c_int(0), C.c_double(1.0)

@@ -435,3 +435,19 @@ def test_global_coarse_space_restores_convergence_of_decomposed_preconditioner(g
     for s in (cut, fix, one):
         # same Newton path up to the linear tolerance (1e-6 on the residual, three iterations)
         assert np.abs(s.p - base.p).max() <= 1e-5 * np.abs(base.p).max() and np.abs(s.sat - base.sat).max() <= 3e-4
+
+
+@pytest.mark.gpu
+def test_default_precision_follows_the_reference_plugins(gpu_lib):
+    """residual_.singlePrecision = dt < 20 d (BlackoilModelBase_impl.hpp:284) reaches the interleaved solver only
+    (NewtonIterationBlackoilInterleaved.cpp:478-480); the CPR plug-in computes in double whatever it says (NewtonIterationBlackoilCPR.cpp:117-140).
+    The host mirror's default (single_precision=None) follows that."""
+    from opmgpu.model import GpuBlackoilModel
+    g = decks.cartesian_grid(4, 4, 3)
+    t = decks.satfunc_standard_tables()
+    st = decks.initial_state(g, t)
+    for use_cpr, dt_days, want in ((0, 1.0, True), (0, 19.9, True), (0, 20.0, False), (1, 1.0, False), (1, 30.0, False)):
+        m = GpuBlackoilModel(g, t, capi.default_params(use_cpr=use_cpr))
+        m.prepareStep(dt_days * decks.DAY, st)
+        assert m.referencePrecision() is want, (use_cpr, dt_days)
+        m.close()
