@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--reduction", type=float, default=1e-2)
     ap.add_argument("--newton", type=int, default=8)
     ap.add_argument("--dt-days", type=float, default=5.0)
+    ap.add_argument("--gmres", type=int, default=0, help="newton_use_gmres")
     args = ap.parse_args()
     from opmgpu import capi, decks, wells as W
     from opmgpu.model import GpuBlackoilModel
@@ -29,8 +30,8 @@ def main():
     st = decks.initial_state(grid, tab, perturb=0.002, seed=12345)
     wl = W.five_spot(grid, rate_m3_per_day=args.rate * (n / 100.0) ** 2, bhp_prod_bar=150.0)
     dt = args.dt_days * decks.DAY
-    for cpr in (1, 0):
-        prm = capi.default_params(use_cpr=cpr, linear_solver_reduction=args.reduction, linear_solver_maxiter=400)
+    for cpr in ((1,) if args.gmres else (1, 0)):
+        prm = capi.default_params(use_cpr=cpr, linear_solver_reduction=args.reduction, linear_solver_maxiter=400, newton_use_gmres=args.gmres)
         out = {}
         for kind in ("device", "host", "none"):
             if kind == "host":
