@@ -107,6 +107,7 @@ template <class S> int solve_loaded(opmgpu_ctx* c, bool matrix_changed, SolveRes
 {
     LinSolver& ls = *c->ls;
     ls.wb_relax = c->prm.ilu_relaxation;
+    if (c->prm.use_cpr) ls.correction_policy_choose();
     ls.prepare<S>(matrix_changed);
     // the reference's CPR formulation (whole-system L transform, 200-bar pressure row, ||L r|| stopping) as an option; once per matrix
     if (c->prm.use_cpr && c->prm.cpr_reference_transform) ls.cpr_reference_transform<S>();
@@ -117,6 +118,14 @@ template <class S> int solve_loaded(opmgpu_ctx* c, bool matrix_changed, SolveRes
     if (ls.factor_overlap && c->prm.use_cpr && ls.emulate_ranks <= 1) { if (after_rows) ls.factor_deferred = true; else ls.factor_async<S>(); }
     else (void)ls.factor<S>(false);      // status read below: the solver's own final synchronisation covers it
     res = c->prm.newton_use_gmres ? ls.gmres<S>(c->prm) : ls.bicgstab<S>(c->prm);
+    if (c->prm.use_cpr) ls.correction_policy_report(res.iterations, res.status == OPMGPU_OK);
+    if (res.status != OPMGPU_OK && c->prm.use_cpr && ls.corr_policy.active && ls.corr_policy.cur == 1 && ls.factor_status() == OPMGPU_OK) {
+        // the solve ran with the larger correction factor of the adaptive policy: once more with the conservative one before anything is reported
+        ls.corr_policy.cur = 0;
+        ls.work<S>().amg->pdamp0 = ls.work<S>().amg->pdamp = ls.corr_policy.arm[0];
+        res = c->prm.newton_use_gmres ? ls.gmres<S>(c->prm) : ls.bicgstab<S>(c->prm);
+        ls.correction_policy_report(res.iterations, res.status == OPMGPU_OK);
+    }
     if (res.status != OPMGPU_OK && c->prm.use_cpr && !ls.refreshed && ls.factor_status() == OPMGPU_OK) {
         // the solve ran on lagged coarse operators of the pressure hierarchy (LinSolver::cpr_prepare): once more on fresh ones
         ls.force_refresh = true; ls.lag_block = 8;

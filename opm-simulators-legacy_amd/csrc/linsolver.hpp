@@ -156,6 +156,20 @@ public:
     double border_colscale = 1.0;
     // coarse-correction factors of the pressure cycle chosen for THIS matrix on the first right-hand side it sees (see cpr_tune)
     template <class S> void cpr_tune();
+    // EXPERIMENT, off by default (OPMGPU_AMG_ADAPT=1): the scaling of the coarse-grid corrections chosen by what it does to the iteration
+    // counts -- two settings; the one whose recent solves needed fewer iterations is used, the other is tried again every `period`-th
+    // solve.  Preconditioner-only: every solve still meets its reduction; identical decisions on every rank (the counts are global).
+    // Measured (profiles/r03_probes.md): +20 % on the bench deck under GMRES, but the iteration count of one solve is too noisy a score
+    // (it follows the Newton iteration's index more than the setting): -8 % under BiCGStab, +18 % iterations at 200^3.  Not robust: off.
+    struct CorrectionPolicy {
+        bool on = false;
+        double arm[2] = { 1.9, 2.4 };
+        double avg[2] = { -1.0, -1.0 }; // running mean of the iterations per solve under each setting (< 0: not tried yet)
+        int solves = 0, cur = 0, period = 10;
+        bool active = false;            // set by cpr_prepare: this solve's factors come from the policy
+    } corr_policy;
+    void correction_policy_choose();
+    void correction_policy_report(int iterations, bool converged);
     bool amg_autotune = false;      // OPMGPU_AMG_AUTOTUNE=1: experiment, measured NOT robust; default: 1.9 (2.2 into level 0 on one well-free subdomain)
     // x0 = 0; rhs in work<S>().b; solution in work<S>().x
     template <class S> SolveResult bicgstab(const opmgpu_params& prm);

@@ -8,6 +8,30 @@ d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]
 print('%-70s value %6.1f  ms %.3f  its %.2f  chopped %s' % ('$*', d['value'], d['ms_per_solving_iteration_median'], d['config'].get('linear_iterations_per_solving_iteration') or 0, d['config'].get('time_steps_chopped')), flush=True)
 "
 }
+if [ "$1" = "adapt" ]; then       # the two-setting policy for the correction factor (OPMGPU_AMG_ADAPT), on against off
+  rund() {
+    tag="$1"; shift
+    python bench.py --only-main --no-cpu-baseline "$@" 2>/dev/null | python -c "
+import sys, json
+d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1])
+c=d['config']
+print('%-44s value %6.1f  ms %.3f  mean-all %6.1f its %.2f  chopped %s notconv %s' % ('$tag', d['value'], d['ms_per_solving_iteration_median'], d['value_all_calls_mean'], c.get('linear_iterations_per_solving_iteration') or 0, c.get('time_steps_chopped'), c.get('time_steps_not_converged')), flush=True)
+"
+  }
+  for ad in 1 0; do
+  export OPMGPU_AMG_ADAPT=$ad
+  rund "adapt=$ad cart100 (headline)"
+  rund "adapt=$ad cart100 steps 60" --steps 60
+  rund "adapt=$ad spe10like gmres" --deck spe10like
+  rund "adapt=$ad spe10like bicgstab" --deck spe10like --krylov bicgstab
+  rund "adapt=$ad 200^3" --nx 200 --ny 200 --nz 200
+  rund "adapt=$ad cart100 bicgstab" --krylov bicgstab
+  rund "adapt=$ad cart100 f32" --precision f32
+  rund "adapt=$ad cart100 dt1" --dt-days 1
+  rund "adapt=$ad 150^3" --nx 150 --ny 150 --nz 150
+done
+  exit 0
+fi
 if [ "$1" = "decks" ]; then       # the correction factor across decks and solver variants
   rund() {
     tag="$1"; shift
