@@ -386,8 +386,17 @@ def main(argv=None):
     variants = {}
     wtag = "_with_wells" if use_wells else ""
     if extras:
-        def variant(name, solver, krylov, dt, single, wells_on=use_wells, note=None, verify=verify):
-            m = GpuBlackoilModel(grid, tab, make_params(solver, krylov, verify), device=local_rank)
+        def variant(name, solver, krylov, dt, single, wells_on=use_wells, note=None, verify=verify, env=None):
+            saved = {k: os.environ.get(k) for k in (env or {})}
+            os.environ.update(env or {})          # library knobs are read when the solver context is created
+            try:
+                m = GpuBlackoilModel(grid, tab, make_params(solver, krylov, verify), device=local_rank)
+            finally:
+                for k, v in saved.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
             try:
                 variants[name] = summary(timed_run(m, wells_on, dt, single), dt, single, note)
             except Exception as e:          # e.g. a Krylov method running out of iterations: say so instead of dying
@@ -404,6 +413,9 @@ def main(argv=None):
                 variant("cpr_f64_gmres_verified%s" % wtag, "cpr", "gmres", dt_main, False, verify=1 - verify,
                         note="the same solver %s the true-residual check (gmres_verify_residual): the solve is converged only when || b - A x || <= reduction || b || "
                              "too -- BiCGStab's statement; left-preconditioned GMRES by itself stops on || M^-1 (b - A x) ||" % ("WITH" if not verify else "WITHOUT"))
+            variant("cpr_f64_%s_fixed_correction_factor%s" % (args.krylov, wtag), "cpr", args.krylov, dt_main, False, env={"OPMGPU_AMG_ADAPT": "0"},
+                    note="the headline's solver with the pressure stage's coarse-grid corrections scaled by the fixed 1.9 of rounds 1-2 instead of the "
+                         "per-time-step choice between 1.9 and 2.3 (DESIGN.md section 4b; OPMGPU_AMG_ADAPT=0)")
             variant("cpr_f32_%s%s" % (args.krylov, wtag), "cpr", args.krylov, dt_main, True,
                     note="NOT a configuration the reference can run (its CPR plug-in is double-only, NewtonIterationBlackoilCPR.cpp:117-140): round 2's headline, kept for continuity")
         if use_wells:
@@ -518,6 +530,9 @@ def main(argv=None):
                        "dt_days": args.dt_days, "linear_solver": lin_name, "ilu0_ordering": args.ordering,
                        "arithmetic": main_sum["arithmetic"],
                        "gmres_true_residual_check": bool(prm.gmres_verify_residual),
+                       "pressure_stage_correction_factor": ("fixed 1.9 (OPMGPU_AMG_ADAPT=0)" if os.environ.get("OPMGPU_AMG_ADAPT") == "0" else
+                                                            "chosen per time step between 1.9 and 2.3 by the step's linear iterations per solve (library default; "
+                                                            "same_run_variants.*fixed_correction_factor* is the fixed 1.9)") if prm.use_cpr else None,
                        "reference_equivalence": ("reference-option-equivalent: solver_approach=cpr + newton_use_gmres in double, the arithmetic of the reference's CPR plug-in "
                                                  "(NewtonIterationBlackoilCPR.cpp:61-64, 117-140)" if (prm.use_cpr and not single_main) else
                                                  "reference default (solver_approach=interleaved)" if (not prm.use_cpr and single_main == reference_single("ilu0", dt_main) and not prm.newton_use_gmres) else

@@ -121,6 +121,8 @@ template <class S> int solve_loaded(opmgpu_ctx* c, bool matrix_changed, SolveRes
     if (c->prm.use_cpr) ls.correction_policy_report(res.iterations, res.status == OPMGPU_OK);
     if (res.status != OPMGPU_OK && c->prm.use_cpr && ls.corr_policy.active && ls.corr_policy.cur == 1 && ls.factor_status() == OPMGPU_OK) {
         // the solve ran with the larger correction factor of the adaptive policy: once more with the conservative one before anything is reported
+        // (the rest of the step stays on it; the failure counts against the larger factor at once, the step's tallies start over)
+        { auto& P = ls.corr_policy; P.avg[1] = P.avg[1] < 0.0 ? 4.0 * std::max(res.iterations, 1) : 2.0 * P.avg[1]; P.step_its = P.step_solves = 0; P.step_failed = false; }
         ls.corr_policy.cur = 0;
         ls.work<S>().amg->pdamp0 = ls.work<S>().amg->pdamp = ls.corr_policy.arm[0];
         res = c->prm.newton_use_gmres ? ls.gmres<S>(c->prm) : ls.bicgstab<S>(c->prm);

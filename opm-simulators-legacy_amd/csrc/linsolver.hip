@@ -972,6 +972,7 @@ LinSolver::LinSolver(hipStream_t s) : stream(s)
     if (const char* e = std::getenv("OPMGPU_AMG_AUTOTUNE")) amg_autotune = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_AMG_ADAPT")) corr_policy.on = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_AMG_ADAPT_ARM")) corr_policy.arm[1] = std::atof(e);
+    if (const char* e = std::getenv("OPMGPU_AMG_ADAPT_MARGIN")) corr_policy.margin = std::atof(e);
     if (const char* e = std::getenv("OPMGPU_EMULATE_RANKS")) emulate_ranks = std::atoi(e);
     if (const char* e = std::getenv("OPMGPU_EMULATE_WHAT")) emulate_what = std::atoi(e);
     if (const char* e = std::getenv("OPMGPU_COARSE")) coarse_mode = std::atoi(e);
@@ -2011,21 +2012,26 @@ template <class S> void LinSolver::cpr_tune()
 void LinSolver::correction_policy_choose()
 {
     CorrectionPolicy& P = corr_policy;
-    if (!P.on) return;
+    if (!P.on || !new_step_hint) return;            // the setting changes at time-step boundaries only
+    if (P.step_solves >= 2 || P.step_failed) {      // score the step that has just ended
+        const double score = (P.step_failed ? 4.0 : 1.0) * double(P.step_its) / double(std::max(P.step_solves, 1));
+        P.avg[P.cur] = P.avg[P.cur] < 0.0 ? score : 0.5 * P.avg[P.cur] + 0.5 * score;
+        ++P.steps;
+    }
+    P.step_its = P.step_solves = 0; P.step_failed = false;
     if (P.avg[0] < 0.0) P.cur = 0;
     else if (P.avg[1] < 0.0) P.cur = 1;
     else {
-        const int best = P.avg[1] < P.avg[0] ? 1 : 0;            // ties: the conservative setting
-        P.cur = (P.solves % P.period == P.period - 1) ? 1 - best : best;
+        const int best = P.avg[1] < P.margin * P.avg[0] ? 1 : 0;
+        P.cur = (P.steps % P.period == P.period - 1) ? 1 - best : best;
     }
 }
 void LinSolver::correction_policy_report(int iterations, bool converged)
 {
     CorrectionPolicy& P = corr_policy;
     if (!P.on || !P.active) return;
-    const double its = converged ? double(iterations) : 4.0 * double(std::max(iterations, 1));       // a failed solve counts heavily against its setting
-    P.avg[P.cur] = P.avg[P.cur] < 0.0 ? its : 0.7 * P.avg[P.cur] + 0.3 * its;
-    ++P.solves;
+    P.step_its += iterations; ++P.step_solves;
+    if (!converged) P.step_failed = true;
 }
 
 // M^-1 d = [x_p;0;0] + ILU0^-1 (d - A [x_p;0;0]),  x_p = Vcycle(sum of the equations of d)

@@ -156,16 +156,20 @@ public:
     double border_colscale = 1.0;
     // coarse-correction factors of the pressure cycle chosen for THIS matrix on the first right-hand side it sees (see cpr_tune)
     template <class S> void cpr_tune();
-    // EXPERIMENT, off by default (OPMGPU_AMG_ADAPT=1): the scaling of the coarse-grid corrections chosen by what it does to the iteration
-    // counts -- two settings; the one whose recent solves needed fewer iterations is used, the other is tried again every `period`-th
-    // solve.  Preconditioner-only: every solve still meets its reduction; identical decisions on every rank (the counts are global).
-    // Measured (profiles/r03_probes.md): +20 % on the bench deck under GMRES, but the iteration count of one solve is too noisy a score
-    // (it follows the Newton iteration's index more than the setting): -8 % under BiCGStab, +18 % iterations at 200^3.  Not robust: off.
+    // The scaling of the coarse-grid corrections, chosen per TIME STEP by what it does to the iteration counts (DESIGN sections 4b, 11): two
+    // settings; a whole time step runs under one of them and is scored by its linear iterations per Newton iteration (one solve's count
+    // follows the Newton iteration's index more than the setting -- round 3's first, per-solve form of this policy was misled by that);
+    // the second setting is kept only while its steps need `margin` fewer iterations, and the setting not in use is tried again for one
+    // step in `period`.  Preconditioner-only: every solve still meets its reduction; the counts are global, so every rank of a decomposed
+    // run decides alike.  OPMGPU_AMG_ADAPT=0: the fixed 1.9.
     struct CorrectionPolicy {
-        bool on = false;
-        double arm[2] = { 1.9, 2.4 };
-        double avg[2] = { -1.0, -1.0 }; // running mean of the iterations per solve under each setting (< 0: not tried yet)
-        int solves = 0, cur = 0, period = 10;
+        bool on = true;
+        double arm[2] = { 1.9, 2.3 };
+        double avg[2] = { -1.0, -1.0 }; // running mean of (linear iterations / solve) of the steps run under each setting (< 0: none yet)
+        double margin = 0.93;
+        int cur = 0, steps = 0, period = 8;
+        int step_its = 0, step_solves = 0;
+        bool step_failed = false;
         bool active = false;            // set by cpr_prepare: this solve's factors come from the policy
     } corr_policy;
     void correction_policy_choose();

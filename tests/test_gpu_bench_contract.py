@@ -46,7 +46,7 @@ def test_bench_line_contract(gpu_lib):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
     v = d["same_run_variants"]
-    assert {"reference_default_solver_ilu0_with_wells", "without_wells", "cpr_f64_bicgstab_with_wells", "cpr_f64_gmres_verified_with_wells", "cpr_f32_gmres_with_wells", "dt30_f64_ilu0_with_wells",
+    assert {"reference_default_solver_ilu0_with_wells", "without_wells", "cpr_f64_bicgstab_with_wells", "cpr_f64_gmres_verified_with_wells", "cpr_f64_gmres_fixed_correction_factor_with_wells", "cpr_f32_gmres_with_wells", "dt30_f64_ilu0_with_wells",
             "dt30_f64_cpr_gmres_with_wells", "dt1_f32_ilu0_with_wells", "dt1_f64_cpr_gmres_with_wells", "dt20_f64_ilu0_with_wells", "dt20_f64_cpr_gmres_with_wells"} <= set(v)
     assert all("failed" not in x for x in v.values()), v
     assert "f32" in v["reference_default_solver_ilu0_with_wells"]["arithmetic"] and "reference's switch on the CURRENT step length" in v["dt30_f64_ilu0_with_wells"]["arithmetic"]
