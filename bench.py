@@ -18,7 +18,9 @@ Which solver the headline runs, and in which arithmetic:
     ILU0) with newton_use_gmres (NewtonIterationBlackoilCPR.cpp:61-64, 148-165).  That plug-in computes in DOUBLE whatever dt is
     (NewtonIterationBlackoilCPR.cpp:117-140 never reads singlePrecision), so the headline is an f64 assembly + f64 solve;
   * the float CPR solve round 2 reported as its headline is a combination the reference cannot run: it stays as the variant
-    cpr_f32_gmres_with_wells and carries no like-for-like claim.
+    cpr_f32_gmres_with_wells and carries no like-for-like claim;
+  * the library's pressure stage chooses the scaling of its coarse-grid corrections per time step (1.9 or 2.3, by the iteration counts the
+    two produce: DESIGN.md section 4b); same_run_variants.cpr_f64_gmres_fixed_correction_factor* runs the fixed 1.9 of rounds 1-2.
 `value` is the cell count over the MEDIAN duration of the timed Newton iterations that include a linear solve -- a
 converged call skips solveJacobianSystem + updateState (BlackoilModelBase_impl.hpp:277-281) and is not a Newton iteration of the
 reference's count; `value_all_calls_mean` = cells / (wall time of the K timed calls / K) is kept beside it, `ms_per_step` is that wall
