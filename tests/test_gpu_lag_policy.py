@@ -67,3 +67,49 @@ def test_failed_lagged_solve_is_retried_then_reported(gpu_lib):
         for it in range(4):
             m.nonlinearIteration(it, single_precision=True)
     m.close()
+
+
+def _run_correction_policy(adapt, arm, prm, steps=6, gmres=1):
+    """time steps of a small deck with wells under the per-time-step choice of the correction factor (OPMGPU_AMG_ADAPT) or the fixed 1.9"""
+    from opmgpu import wells as W
+    saved = {k: os.environ.get(k) for k in ("OPMGPU_AMG_ADAPT", "OPMGPU_AMG_ADAPT_ARM")}
+    os.environ["OPMGPU_AMG_ADAPT"] = str(adapt); os.environ["OPMGPU_AMG_ADAPT_ARM"] = str(arm)          # read when the solver context is created
+    try:
+        grid = decks.cartesian_grid(24, 20, 12, lognormal_sigma=0.8, seed=5)
+        tab = decks.satfunc_standard_tables()
+        st = decks.initial_state(grid, tab, perturb=0.004, seed=5)
+        wl = W.five_spot(grid, rate_m3_per_day=40.0, bhp_prod_bar=150.0)
+        gm = GpuBlackoilModel(grid, tab, prm)
+        m = W.DeviceWellModel(gm, wl, W.WellState(wl, st.p))
+        m.prepareStep(decks.DAY, st)
+        lin = newton = 0
+        ns = NonlinearSolver(max_iter=15)
+        for k in range(steps):
+            if k:
+                m.prepareStep(2 * decks.DAY)
+            it, l = ns.step(m)
+            lin += l; newton += it
+        out = gm.getState()
+        gm.close()
+        return out, lin, newton
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_correction_factor_policy_is_preconditioner_only(gpu_lib):
+    """LinSolver::CorrectionPolicy (DESIGN 4b / 11): choosing the scaling of the coarse-grid corrections per time step changes the iteration
+    counts, never the answer -- at a tight reduction the time steps end in the same state with the policy on (second setting 2.3, and an
+    absurd 6.0 that the policy must walk away from, a failed solve being repeated under 1.9) as with the fixed 1.9."""
+    prm = capi.default_params(use_cpr=1, newton_use_gmres=1, linear_solver_reduction=1e-9, linear_solver_maxiter=400)
+    ref, lin0, n0 = _run_correction_policy(0, 2.3, prm)
+    for arm in (2.3, 6.0):
+        out, lin, n = _run_correction_policy(1, arm, prm)
+        assert n == n0, (arm, n, n0)
+        assert np.array_equal(out.hc, ref.hc)
+        assert np.abs(out.p - ref.p).max() <= 1e-6 * np.abs(ref.p).max() and np.abs(out.sat - ref.sat).max() <= 1e-6, arm
+        if arm == 6.0:
+            assert lin <= 1.6 * lin0, (lin, lin0)          # the bad setting costs the steps it is tried on, not the run
