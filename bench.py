@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
-"""bench.py -- Mcell-updates/s per Newton step (assembly+solve) on MI355X, with the SpMV roofline, a per-kernel table and the
-CPU baseline timed beside it.
+"""bench.py -- Mcell-updates/s per Newton step (assembly+solve) on MI355X, with the SpMV roofline and the CPU baseline timed beside it.
+
+OUTPUT: stdout carries exactly ONE JSON line of < 4 KB (the driver keeps 8 KB of stdout): the contract keys, a short `config`, `roofline`,
+`cpu_baseline`, `per_time_step` and compact name -> number maps of the same-run variants and of the other BASELINE decks.  Everything
+else -- per-call durations, the full variant records, the kernel table, the prose notes -- goes to `bench_detail.json` beside this script
+(and to stderr when OPMGPU_BENCH_VERBOSE=1).
 
 Workload (BASELINE.json configs[2]): the synthetic 100x100x100 three-phase deck WITH its 5-spot (one rate-controlled water
 injector + four BHP producers, full columns, device well model incl. control switching and the explicit well pre-solve).  A "step" is
@@ -11,21 +15,23 @@ condition -- restarts with 0.33 dt as in AdaptiveTimeStepping_impl.hpp:244-359).
 step that grows by at most 3 per step towards --dt-days (timestep.initial_timestep_in_days, :110); timing begins once two steps have
 passed and the step length has reached dt (deck set-up, untimed).
 
-Which solver the headline runs, and in which arithmetic (VERDICT r2 items 4-5):
+Which solver the headline runs, and in which arithmetic:
   * the reference's DEFAULT is solver_approach=interleaved: block-ILU0 + BiCGStab, in float when dt < 20 d and in double otherwise
-    (BlackoilModelBase_impl.hpp:284, NewtonIterationBlackoilInterleaved.cpp:478-480) -> same_run_variants.reference_default_solver_ilu0*;
-  * the headline is the fastest configuration the reference itself can be SWITCHED to: solver_approach=cpr (CPR: AMG pressure stage +
-    ILU0) with newton_use_gmres (NewtonIterationBlackoilCPR.cpp:61-64, 148-165).  That plug-in computes in DOUBLE whatever dt is
-    (NewtonIterationBlackoilCPR.cpp:117-140 never reads singlePrecision), so the headline is an f64 assembly + f64 solve;
-  * the float CPR solve round 2 reported as its headline is a combination the reference cannot run: it stays as the variant
-    cpr_f32_gmres_with_wells and carries no like-for-like claim;
-  * the library's pressure stage chooses the scaling of its coarse-grid corrections per time step (1.9 or 2.3, by the iteration counts the
-    two produce: DESIGN.md section 4b); same_run_variants.cpr_f64_gmres_fixed_correction_factor* runs the fixed 1.9 of rounds 1-2.
-`value` is the cell count over the MEDIAN duration of the timed Newton iterations that include a linear solve -- a
+    (BlackoilModelBase_impl.hpp:284, NewtonIterationBlackoilInterleaved.cpp:478-480) -> variants.ref_default_ilu0*;
+  * the headline is solver_approach=cpr with cpr_use_amg=true and newton_use_gmres=true (NewtonIterationBlackoilCPR.hpp:59-63,
+    .cpp:61-64), in DOUBLE like that plug-in (.cpp:117-140 never reads singlePrecision), stage 2 relaxed by cpr_relax = 1.0 -- with ONE
+    difference, stated in config.reference_equivalence: the pressure stage is one AMG V-cycle per application (cpr_max_ell_iter = 0, a
+    library extension) where the reference's external CPRPreconditioner wraps its AMG in an inner BiCGStab;
+  * variants.cpr_ref_defaults is the CPR plug-in with ITS documented defaults (no AMG: ILU0-preconditioned inner BiCGStab on the
+    pressure system, BiCGStab outside), variants.cpr_amg_inner_bicgstab the AMG behind the inner BiCGStab;
+  * the float CPR solve is a combination the reference cannot run: kept as variants.cpr_f32_gmres, no like-for-like claim.
+`value` is the cell count over the MEDIAN duration of the K timed Newton iterations that include a linear solve -- a
 converged call skips solveJacobianSystem + updateState (BlackoilModelBase_impl.hpp:277-281) and is not a Newton iteration of the
-reference's count; `value_all_calls_mean` = cells / (wall time of the K timed calls / K) is kept beside it, `ms_per_step` is that wall
-time per call.  The per-call durations, phase times and iteration counts all come from the K timed calls themselves (events recorded on
-the library's stream without a synchronisation inside the region: opmgpu_iteration_marks).
+reference's count; `value_mean_solving` is the cell count over their MEAN, `ms_per_step` the wall time of the K calls / K.
+
+Per time step: a looser linear solve is cheaper per iteration and costs Newton iterations.  After the K timed calls
+the same run goes on to --stat-calls calls in all; over the whole converged time steps inside them `per_time_step` reports the Newton
+iterations per time step, the device ms per converged time step (chopped attempts included) and the ms per simulated day.
 
     python bench.py --gpus N --steps K --warmup W
 (N > 1: one rank per GPU under torch.distributed.run; launched without WORLD_SIZE the script starts that launcher itself as a child process)
@@ -106,17 +112,16 @@ def parse_args(argv):
     ap.add_argument("--dt-days", type=float, default=5.0)
     ap.add_argument("--ordering", choices=["multicolor", "natural"], default="multicolor")
     ap.add_argument("--solver", choices=["cpr", "ilu0"], default="cpr",
-                    help="cpr: AMG pressure stage + ILU0 (reference solver_approach=cpr); ilu0: reference default solver_approach=interleaved")
+                    help="cpr: AMG pressure stage + ILU0 (reference solver_approach=cpr cpr_use_amg=true); ilu0: reference default solver_approach=interleaved")
     ap.add_argument("--precision", choices=["reference", "f32", "f64"], default="reference",
                     help="arithmetic of the linear solve and of the Jacobian.  reference: what the reference's plug-in of --solver computes in -- cpr: double "
                          "always (NewtonIterationBlackoilCPR.cpp:117-140); ilu0: float when dt < 20 d, else double (BlackoilModelBase_impl.hpp:284)")
     ap.add_argument("--krylov", choices=["auto", "bicgstab", "gmres", "fgmres"], default="auto",
                     help="gmres: the reference's newton_use_gmres option (restarted GMRES(40), left-preconditioned).  auto: gmres under CPR on the deck with "
-                         "wells (3.75 preconditioner applications per Newton iteration against BiCGStab's 4.1 iterations = 9.5 applications), bicgstab "
-                         "otherwise -- the other method runs as a same-run variant; fgmres: the flexible (right-preconditioned) form, not a reference solver")
+                         "wells, bicgstab otherwise -- the other method runs as a same-run variant; fgmres: the flexible (right-preconditioned) form, not a reference solver")
     ap.add_argument("--verify", action="store_true",
                     help="GMRES with the true-residual check (opmgpu_params.gmres_verify_residual = 1; not a reference option).  Default: exactly dune's stopping rule, the "
-                         "PRECONDITIONED residual -- what the reference's newton_use_gmres does; the check runs as the variant cpr_f64_gmres_verified*")
+                         "PRECONDITIONED residual -- what the reference's newton_use_gmres does; the check runs as the variant cpr_f64_gmres_verified")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N > 1: weak = every GPU keeps an nx x ny x nz slab with its own 5-spot (global deck nx x ny x nz*N); strong = the fixed nx x ny x nz deck "
                          "is cut into N slabs along j, which keeps its vertical wells whole")
@@ -125,13 +130,41 @@ def parse_args(argv):
                     help="fivespot (default, SURVEY 8d): 1 rate-controlled water injector + 4 BHP producers, full columns, device well model")
     ap.add_argument("--rate", type=float, default=1000.0, help="injection rate of the 5-spot, m3/day")
     ap.add_argument("--spin-up", type=int, default=2, help="time steps that pass before the measurement (deck set-up, untimed)")
-    ap.add_argument("--only-main", action="store_true", help="skip the same-run variants, the roofline micro-runs and the per-kernel pass (profiling)")
+    ap.add_argument("--stat-calls", type=int, default=60, help="calls (the K timed ones included) the per-time-step statistics are taken over")
+    ap.add_argument("--only-main", action="store_true", help="skip the same-run variants, the other decks, the roofline micro-runs and the per-kernel pass (profiling)")
+    ap.add_argument("--no-other-decks", action="store_true", help="skip the SPE9-like / SPE10-like / Norne-like legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="take the domain-decomposition code path (torch.distributed + RCCL communicator) even with one rank")
     ap.add_argument("--cpu-threads", type=int, default=1)
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"), help="where the full record goes (the stdout line stays < 4 KB)")
     ap.add_argument("--call-by-call", action="store_true", help="drive every Newton iteration through the seven single C calls instead of opmgpu_nonlinear_iteration "
                                                                  "(no per-call marks then: value falls back to the mean over all calls)")
     return ap.parse_args(argv)
+
+
+MAX_LINE_BYTES = 4096          # the driver keeps 8 KB of stdout; a longer line reaches it without its head
+
+
+def per_time_step_stats(log, ms, solved, lin):
+    """Whole converged time steps inside a run of calls.  log[i] = (event, dt_seconds) of call i, event in {None, "step", "chop"}: "step"
+    = this call found the time step converged (the step is complete), "chop" = the attempt was given up (exception or max_iter: the state is
+    rolled back and the step restarts with 0.33 dt).  The window runs from the call after the first step boundary to the last completed
+    step, so that only whole steps -- their chopped attempts included -- are counted."""
+    n = min(len(log), len(ms))
+    bounds = [i for i in range(n) if log[i][0] in ("step", "chop")]
+    done = [i for i in range(n) if log[i][0] == "step"]
+    if not bounds or not done or done[-1] <= bounds[0]:
+        return None
+    lo, hi = bounds[0] + 1, done[-1]              # calls lo..hi inclusive
+    steps = [i for i in done if lo <= i <= hi]
+    if not steps:
+        return None
+    tot = float(sum(ms[lo:hi + 1]))
+    days = sum(log[i][1] for i in steps) / 86400.0
+    nsolve = int(sum(1 for i in range(lo, hi + 1) if solved[i]))
+    return {"time_steps": len(steps), "calls": hi - lo + 1, "chopped_attempts": sum(1 for i in range(lo, hi + 1) if log[i][0] == "chop"),
+            "newton_iterations_per_time_step": nsolve / len(steps), "linear_iterations_per_time_step": float(sum(lin[lo:hi + 1])) / len(steps),
+            "ms_per_converged_time_step": tot / len(steps), "simulated_days": days, "ms_per_simulated_day": tot / days if days > 0 else None}
 
 
 def main(argv=None):
@@ -149,7 +182,7 @@ def main(argv=None):
     import numpy as np
     import torch
     import torch.distributed as dist
-    from opmgpu import capi, decks, wells as W
+    from opmgpu import capi, decks, baseline_decks, wells as W
     from opmgpu.model import GpuBlackoilModel, GpuNewtonIteration, NonlinearSolver
 
     rank = int(os.environ.get("RANK", "0"))
@@ -183,31 +216,35 @@ def main(argv=None):
     def reference_single(solver, dt):
         """the arithmetic the reference's plug-in computes in: CPR is double throughout (NewtonIterationBlackoilCPR.cpp:117-140), the
         interleaved solver follows residual_.singlePrecision = dt < 20 d (BlackoilModelBase_impl.hpp:284)"""
-        return False if solver == "cpr" else dt < 20 * decks.DAY
+        return False if solver.startswith("cpr") else dt < 20 * decks.DAY
 
     single_main = {"reference": reference_single(args.solver, dt_main), "f32": True, "f64": False}[args.precision]
-    # multi-GPU: every well lives on one rank.  Weak scaling: one 5-spot per rank's slab of nz layers (N copies of the one-GPU workload stacked
-    # along k); strong scaling and the SPE10-like deck: slabs of whole j-rows, which keeps the deck's own vertical wells whole
     use_wells = args.wells == "fivespot"
     if args.krylov == "auto":
         args.krylov = "gmres" if (use_wells and args.solver == "cpr") else "bicgstab"
     verify = 1 if args.verify else 0
 
+    # solver names: "ilu0" = solver_approach=interleaved; "cpr" = the headline's pressure stage (cpr_use_amg=true, ONE V-cycle per application:
+    # cpr_max_ell_iter = 0); "cpr_ref" = the CPR plug-in's documented defaults (cpr_use_amg=false: ILU0-preconditioned inner BiCGStab on the
+    # pressure system, cpr_solver_tol / cpr_max_ell_iter at their defaults); "cpr_amg_inner" = cpr_use_amg=true behind that inner BiCGStab
+    CPR_KW = {"ilu0": dict(use_cpr=0), "cpr": dict(capi.CPR_AMG_VCYCLE), "cpr_ref": dict(use_cpr=1, cpr_use_amg=0), "cpr_amg_inner": dict(use_cpr=1, cpr_use_amg=1)}
+
     def make_params(solver=args.solver, krylov=args.krylov, verify=verify):
-        return capi.default_params(ilu_ordering=ordering, use_cpr=int(solver == "cpr"), newton_use_gmres={"gmres": 1, "fgmres": 2}.get(krylov, 0),
-                                   gmres_verify_residual=verify if krylov == "gmres" else 0)
+        return capi.default_params(ilu_ordering=ordering, newton_use_gmres={"gmres": 1, "fgmres": 2}.get(krylov, 0),
+                                   gmres_verify_residual=verify if krylov == "gmres" else 0, **CPR_KW[solver])
 
     prm = make_params()
     spe10_spec = (200.0, 380.0)
 
     def make_deck():
         if args.deck == "spe10like":
-            g = decks.cartesian_grid(60, 220, 85, dx=6.096, dy=3.048, dz=0.6096, tops=3657.6, lognormal_sigma=2.5, seed=10)
-            s = decks.initial_state(g, tab, p_ref=413.0 * decks.BAR, z_ref=3657.6, perturb=1e-4, seed=10, gas_cap_fraction=0.0, gas_only_fraction=0.0)
+            g, _, s, _ = baseline_decks.spe10_like()
             return g, s, spe10_spec
         g = decks.cartesian_grid(args.nx, args.ny, args.nz, lognormal_sigma=0.5, seed=12345)
         return g, decks.initial_state(g, tab, perturb=0.002, seed=12345), (args.rate, 150.0)
 
+    # multi-GPU: every well lives on one rank.  Weak scaling: one 5-spot per rank's slab of nz layers (N copies of the one-GPU workload stacked
+    # along k); strong scaling and the SPE10-like deck: slabs of whole j-rows, which keeps the deck's own vertical wells whole
     if use_dist:
         from opmgpu import partition
         if args.deck == "spe10like":
@@ -220,27 +257,18 @@ def main(argv=None):
             wells_fn = (lambda g: W.five_spot(g, rate_m3_per_day=args.rate, bhp_prod_bar=150.0, slabs=world)) if use_wells else None
             model, grid, st, info = partition.build_distributed_model(args.nx, args.ny, args.nz * world, tab, prm, rank, world, local_rank, wells_fn=wells_fn)
         well_spec = None
+        main_wells = info["wells"] if use_wells else None
     else:
         grid, st, well_spec = make_deck()
         model = GpuBlackoilModel(grid, tab, prm, device=local_rank)
         info = {"n_owned": grid.nc, "n_global": grid.nc}
+        main_wells = W.five_spot(grid, rate_m3_per_day=well_spec[0], bhp_prod_bar=well_spec[1]) if use_wells else None
     nc_global = info["n_global"]
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
-
-    def make_wells():
-        if use_dist:
-            return info["wells"]
-        return W.five_spot(grid, rate_m3_per_day=well_spec[0], bhp_prod_bar=well_spec[1])
-
-    def with_wells(core, on):
-        if not on:
-            return core
-        wl = make_wells()
-        return W.DeviceWellModel(core, wl, W.WellState(wl, st.p))
 
     ns = NonlinearSolver()                  # reference defaults: max_iter 10, min_iter 1, dampening on detected oscillation
 
@@ -250,10 +278,11 @@ def main(argv=None):
         that has not converged after the reference's max_iter (NonlinearSolver_impl.hpp:165 throws TooManyIterations, caught at :244), are
         handled the way it handles them: the state of the step's start is restored and the step restarts with 0.33 dt (:359); the step after a
         restart grows by at most 2 (:304), later ones by at most 3 (:300) back towards dt.  Such an iteration still counts as one of the n (its
-        work was done); `time_steps_chopped` reports how often it happened.  single = "reference": the default solver's switch on the CURRENT
-        step length (float below 20 d, BlackoilModelBase_impl.hpp:284), which a chopped step crosses."""
+        work was done).  single = "reference": the default solver's switch on the CURRENT step length (float below 20 d,
+        BlackoilModelBase_impl.hpp:284), which a chopped step crosses.  state["log"] gets one (event, dt) entry per call."""
         from opmgpu.model import NumericalIssue, LinearSolverProblem, ISTLError
         it, lin, steps_done, failed = state["it"], 0, 0, 0
+        log = state.setdefault("log", [])
 
         def chop():
             model.restoreState()
@@ -265,35 +294,43 @@ def main(argv=None):
         for _ in range(n):
             sp = (state["dt"] < 20 * decks.DAY) if single == "reference" else single
             state["calls_f32"] = state.get("calls_f32", 0) + int(bool(sp))
+            dt_now = state["dt"]
             try:
                 converged, l = model.nonlinearIteration(it, single_precision=sp, nonlinear_solver=ns)
             except (NumericalIssue, LinearSolverProblem, ISTLError):
+                log.append(("chop", dt_now))
                 chop()
                 it = 0
                 continue
             lin += l
             it += 1
             if converged and it > ns.min_iter:
+                log.append(("step", dt_now))
                 model.saveState()               # last_state of the time stepper
                 state["dt"] = min(dt, (2.0 if state.pop("restarted", False) else 3.0) * state["dt"])
                 model.prepareStep(state["dt"])  # next time step from the resident state
                 it = 0
                 steps_done += 1
             elif it > ns.max_iter:
+                log.append(("chop", dt_now))
                 failed += 1
                 chop()
                 it = 0
+            else:
+                log.append((None, dt_now))
         state["it"] = it
         return lin, steps_done, failed
 
-    def timed_run(core, wells_on, dt, single, kernel_table=False):
-        """deck set-up (spin-up time steps) -> W warm-up Newton iterations -> barrier -> exactly K timed Newton iterations -> barrier"""
-        model = with_wells(core, wells_on)
+    def timed_run(core, wells, st0, dt, single, nc, kernel_table=False, stat_calls=None):
+        """deck set-up (spin-up time steps) -> W warm-up Newton iterations -> barrier -> exactly K timed Newton iterations -> barrier ->
+        (statistics only) further calls up to stat_calls"""
+        model = core if wells is None else W.DeviceWellModel(core, wells, W.WellState(wells, st0.p))
+        stat_calls = max(args.steps, args.stat_calls if stat_calls is None else stat_calls)
         # set-up: the run starts the way the reference's time stepper starts one, with a first step of at most 1 d
         # (timestep.initial_timestep_in_days = 1, AdaptiveTimeStepping_impl.hpp:110) that grows by at most 3 per step towards dt; the measurement begins
         # once `spin_up` steps have passed AND the step length has reached dt
         dt0 = min(dt, decks.DAY)
-        model.prepareStep(dt0, st)
+        model.prepareStep(dt0, st0)
         model.saveState()
         state = {"it": 0, "dt": dt0, "chopped": 0}
         done = 0
@@ -303,6 +340,7 @@ def main(argv=None):
             done += d; guard += 1
         newton_iterations(model, args.warmup, state, dt, single)
         marks = GpuBlackoilModel.fused_iteration
+        state["log"] = []
         barrier()
         if marks:
             core._chk(core.lib.opmgpu_iteration_marks(core.ctx, 1))
@@ -315,33 +353,41 @@ def main(argv=None):
         barrier()
         elapsed = time.perf_counter() - t0
         out = {"lin": lin_total, "steps_done": steps_done, "steps_not_converged": failed, "chopped": state["chopped"], "chopped_timed": state["chopped"] - chopped_before,
-               "dt_end": state["dt"], "calls_f32": state.get("calls_f32", 0) - f32_before}
-        solving_ms = None
+               "dt_end": state["dt"], "calls_f32": state.get("calls_f32", 0) - f32_before, "nc": nc}
+        solving_ms = solving_mean = None
         if marks:
-            K = args.steps
-            ms, sol, lit, ph = np.zeros(K), np.zeros(K, np.int32), np.zeros(K, np.int32), np.zeros((K, 3))
+            # beyond the timed region: the same run goes on, for the per-time-step statistics only
+            newton_iterations(model, stat_calls - args.steps, state, dt, single)
+            K, T = args.steps, stat_calls
+            ms, sol, lit, ph = np.zeros(T), np.zeros(T, np.int32), np.zeros(T, np.int32), np.zeros((T, 3))
             n = C.c_int(0)
-            core._chk(core.lib.opmgpu_iteration_marks_get(core.ctx, K, capi.dptr(ms), capi.iptr(sol), capi.iptr(lit), capi.dptr(ph), C.byref(n)))
+            core._chk(core.lib.opmgpu_iteration_marks_get(core.ctx, T, capi.dptr(ms), capi.iptr(sol), capi.iptr(lit), capi.dptr(ph), C.byref(n)))
             core._chk(core.lib.opmgpu_iteration_marks(core.ctx, 0))
-            n = min(n.value, K)              # (a call that ended in an exception left its mark too; chopped restarts make no call)
+            n = min(n.value, T)              # (a call that ended in an exception left its mark too)
             ms, sol, lit, ph = ms[:n], sol[:n].astype(bool), lit[:n], ph[:n]
-            out["calls"] = {"ms": [round(float(x), 4) for x in ms], "solved": [int(x) for x in sol], "linear_iterations": [int(x) for x in lit]}
-            if sol.any():
-                solving_ms = float(np.median(ms[sol]))
-                out["n_solving"] = int(sol.sum())
-                out["lin_per_solving"] = float(lit[sol].mean())
-                out["breakdown"] = {"assemble": float(np.median(ph[sol, 0])), "linear_solve": float(np.median(ph[sol, 1])), "update": float(np.median(ph[sol, 2])),
+            kk = min(K, n)
+            out["calls"] = {"ms": [round(float(x), 4) for x in ms], "solved": [int(x) for x in sol], "linear_iterations": [int(x) for x in lit],
+                            "event": [e for e, _ in state["log"][:n]], "timed": kk}
+            if n == len(state["log"]):
+                out["per_time_step"] = per_time_step_stats(state["log"], ms, sol, lit)
+            if sol[:kk].any():
+                s = sol[:kk]
+                solving_ms, solving_mean = float(np.median(ms[:kk][s])), float(np.mean(ms[:kk][s]))
+                out["n_solving"] = int(s.sum())
+                out["lin_per_solving"] = float(lit[:kk][s].mean())
+                out["breakdown"] = {"assemble": float(np.median(ph[:kk][s, 0])), "linear_solve": float(np.median(ph[:kk][s, 1])), "update": float(np.median(ph[:kk][s, 2])),
                                     "basis": "medians over the %d timed calls that include a solve; the phases are device time between events on the library's stream, "
-                                             "the call's remainder is the host's decisions between them" % int(sol.sum())}
-                if (~sol).any():
-                    out["non_solving_ms_median"] = float(np.median(ms[~sol]))
+                                             "the call's remainder is the host's decisions between them" % int(s.sum())}
+                if (~s).any():
+                    out["non_solving_ms_median"] = float(np.median(ms[:kk][~s]))
         if use_dist:
-            tt = torch.tensor([elapsed, solving_ms if solving_ms is not None else -1.0], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+            tt = torch.tensor([elapsed, solving_ms if solving_ms is not None else -1.0, solving_mean if solving_mean is not None else -1.0], dtype=torch.float64,
+                              device="cpu" if rehearsal else "cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt[0].item())
             if solving_ms is not None:
-                solving_ms = float(tt[1].item())
-        out["elapsed"], out["solving_ms"] = elapsed, solving_ms
+                solving_ms, solving_mean = float(tt[1].item()), float(tt[2].item())
+        out["elapsed"], out["solving_ms"], out["solving_mean_ms"] = elapsed, solving_ms, solving_mean
         if kernel_table:
             # per-kernel pass: the NEXT K Newton iterations of the same run with the in-situ event brackets on (not part of `value`: the
             # brackets cost time); its own iteration counts are reported with it
@@ -360,17 +406,19 @@ def main(argv=None):
         return out
 
     def summary(r, dt, single, note=None):
+        nc = r["nc"]
         ms_mean = 1e3 * r["elapsed"] / args.steps
         ms = r["solving_ms"] if r["solving_ms"] is not None else ms_mean
-        s = {"value": nc_global / (ms * 1e-3) / 1e6, "ms_per_solving_iteration_median": r["solving_ms"], "value_all_calls_mean": nc_global / (ms_mean * 1e-3) / 1e6,
-             "ms_per_step": ms_mean, "dt_days": dt / decks.DAY,
+        s = {"value": nc / (ms * 1e-3) / 1e6, "ms_per_solving_iteration_median": r["solving_ms"], "ms_per_solving_iteration_mean": r["solving_mean_ms"],
+             "value_mean_solving": nc / (r["solving_mean_ms"] * 1e-3) / 1e6 if r["solving_mean_ms"] else None,
+             "value_all_calls_mean": nc / (ms_mean * 1e-3) / 1e6, "ms_per_step": ms_mean, "dt_days": dt / decks.DAY, "cells": nc,
              "arithmetic": ("f64 assembly; Jacobian and linear solve follow the reference's switch on the CURRENT step length (float below 20 d, which a chopped "
                             "step crosses): %d of the %d timed calls in float" % (r["calls_f32"], args.steps)) if single == "reference" else
                            "f64 assembly + %s Jacobian and linear solve" % ("f32" if single else "f64"),
              "solving_iterations": r.get("n_solving"), "linear_iterations_per_solving_iteration": r.get("lin_per_solving"),
              "time_steps_completed": r["steps_done"], "time_steps_not_converged": r["steps_not_converged"], "time_steps_chopped": r["chopped"],
              "time_steps_chopped_in_timed_region": r["chopped_timed"], "dt_days_at_end": r["dt_end"] / decks.DAY,
-             "breakdown_ms_per_solving_iteration": r.get("breakdown")}
+             "breakdown_ms_per_solving_iteration": r.get("breakdown"), "per_time_step": r.get("per_time_step"), "calls": r.get("calls")}
         if r["chopped_timed"]:
             s["caution"] = ("%d time step(s) of the timed region were cut (0.33 dt, the reference's rule): the timed iterations ran at a MIX of step lengths, "
                             "so this figure is not a dt = %g d figure" % (r["chopped_timed"], dt / decks.DAY))
@@ -380,19 +428,19 @@ def main(argv=None):
 
     # ---- timed region: exactly K Newton iterations of the headline workload ----
     extras = rank == 0 and not use_dist and not args.only_main
-    res = timed_run(model, use_wells, dt_main, single_main, kernel_table=extras)
+    res = timed_run(model, main_wells, st, dt_main, single_main, nc_global, kernel_table=extras)
     main_sum = summary(res, dt_main, single_main)
 
-    # same-run variants: the reference's default solver, the other arithmetic / Krylov method, the well-free deck, and dt = 30 d (the
-    # double branch of the reference's precision switch, BlackoilModelBase_impl.hpp:284)
-    variants = {}
-    wtag = "_with_wells" if use_wells else ""
+    # same-run variants: the reference's default solver, the CPR plug-in's documented defaults, the other arithmetic / Krylov method, the
+    # well-free deck, and SURVEY 8d's dt sweep (20 d is where the default solver's precision switches, BlackoilModelBase_impl.hpp:284)
+    variants, other_decks = {}, {}
     if extras:
-        def variant(name, solver, krylov, dt, single, wells_on=use_wells, note=None, verify=verify, env=None):
+        def variant(name, solver, krylov, dt, single, wells_on=use_wells, note=None, verify=verify, env=None, into=variants, deck=None):
             saved = {k: os.environ.get(k) for k in (env or {})}
             os.environ.update(env or {})          # library knobs are read when the solver context is created
+            g, t, s0, wl = deck if deck is not None else (grid, tab, st, main_wells)
             try:
-                m = GpuBlackoilModel(grid, tab, make_params(solver, krylov, verify), device=local_rank)
+                m = GpuBlackoilModel(g, t, make_params(solver, krylov, verify), device=local_rank)
             finally:
                 for k, v in saved.items():
                     if v is None:
@@ -400,40 +448,54 @@ def main(argv=None):
                     else:
                         os.environ[k] = v
             try:
-                variants[name] = summary(timed_run(m, wells_on, dt, single), dt, single, note)
+                into[name] = summary(timed_run(m, wl if wells_on else None, s0, dt, single, g.nc), dt, single, note)
             except Exception as e:          # e.g. a Krylov method running out of iterations: say so instead of dying
-                variants[name] = {"failed": repr(e)}
+                into[name] = {"failed": repr(e)}
             m.close()
 
-        variant("reference_default_solver_ilu0" + wtag, "ilu0", "bicgstab", dt_main, reference_single("ilu0", dt_main),
+        variant("ref_default_ilu0", "ilu0", "bicgstab", dt_main, reference_single("ilu0", dt_main),
                 note="solver_approach=interleaved, the reference's DEFAULT: block-ILU0 + BiCGStab, float because dt < 20 d")
         if args.solver == "cpr":
+            variant("cpr_ref_defaults", "cpr_ref", "bicgstab", dt_main, False,
+                    note="solver_approach=cpr with the plug-in's documented defaults (NewtonIterationBlackoilCPR.hpp:59-63): cpr_use_amg=false -- the pressure system "
+                         "by an ILU0-preconditioned inner BiCGStab (cpr_solver_tol 1e-2, at most 25 iterations: recollection of the external CPRPreconditioner) --, "
+                         "cpr_relax 1.0, BiCGStab outside, double")
+            variant("cpr_amg_inner_bicgstab", "cpr_amg_inner", args.krylov, dt_main, False,
+                    note="the headline's solver with the AMG behind the inner BiCGStab of the reference's CPRPreconditioner (cpr_max_ell_iter 25) instead of one V-cycle")
             other = "bicgstab" if args.krylov != "bicgstab" else "gmres"
-            variant("cpr_f64_%s%s" % (other, wtag), "cpr", other, dt_main, False,
-                    note="solver_approach=cpr in the reference's own arithmetic (double) with its %s Krylov method" % ("default" if other == "bicgstab" else "newton_use_gmres"))
+            variant("cpr_f64_%s" % other, "cpr", other, dt_main, False,
+                    note="solver_approach=cpr cpr_use_amg=true (one V-cycle) in double with the reference's %s Krylov method" % ("default" if other == "bicgstab" else "newton_use_gmres"))
             if args.krylov == "gmres":
-                variant("cpr_f64_gmres_verified%s" % wtag, "cpr", "gmres", dt_main, False, verify=1 - verify,
+                variant("cpr_f64_gmres_verified", "cpr", "gmres", dt_main, False, verify=1 - verify,
                         note="the same solver %s the true-residual check (gmres_verify_residual): the solve is converged only when || b - A x || <= reduction || b || "
                              "too -- BiCGStab's statement; left-preconditioned GMRES by itself stops on || M^-1 (b - A x) ||" % ("WITH" if not verify else "WITHOUT"))
-            variant("cpr_f64_%s_fixed_correction_factor%s" % (args.krylov, wtag), "cpr", args.krylov, dt_main, False, env={"OPMGPU_AMG_ADAPT": "0"},
-                    note="the headline's solver with the pressure stage's coarse-grid corrections scaled by the fixed 1.9 of rounds 1-2 instead of the "
+            variant("cpr_f64_%s_fixed_factor" % args.krylov, "cpr", args.krylov, dt_main, False, env={"OPMGPU_AMG_ADAPT": "0"},
+                    note="the headline's solver with the pressure stage's coarse-grid corrections scaled by the fixed 1.9 instead of the "
                          "per-time-step choice between 1.9 and 2.3 (DESIGN.md section 4b; OPMGPU_AMG_ADAPT=0)")
-            variant("cpr_f32_%s%s" % (args.krylov, wtag), "cpr", args.krylov, dt_main, True,
-                    note="NOT a configuration the reference can run (its CPR plug-in is double-only, NewtonIterationBlackoilCPR.cpp:117-140): round 2's headline, kept for continuity")
+            variant("cpr_f32_%s" % args.krylov, "cpr", args.krylov, dt_main, True,
+                    note="NOT a configuration the reference can run (its CPR plug-in is double-only, NewtonIterationBlackoilCPR.cpp:117-140): kept for continuity")
         if use_wells:
             variant("without_wells", args.solver, "bicgstab" if args.solver == "cpr" else args.krylov, dt_main, single_main, wells_on=False)
-        # SURVEY 8d's dt sweep (1, 5, 20, 30 d; covers the float / double switch of the reference's default solver at 20 d): the main run and the
-        # variant above are the dt = --dt-days legs, here the others, for the reference-default solver and for the headline's
         for days in (1.0, 20.0, 30.0):
             if abs(args.dt_days - days) < 1e-9:
                 continue
             dts = days * decks.DAY
             sp = reference_single("ilu0", dts)
-            variant("dt%d_%s_ilu0%s" % (days, "f32" if sp else "f64", wtag), "ilu0", "bicgstab", dts, sp if sp else "reference",
+            variant("dt%d_%s_ilu0" % (days, "f32" if sp else "f64"), "ilu0", "bicgstab", dts, sp if sp else "reference",
                     note="the reference's default solver at dt = %g d: %s (BlackoilModelBase_impl.hpp:284)" % (days, "float, dt < 20 d" if sp else "double, dt >= 20 d"))
-            variant("dt%d_f64_cpr_%s%s" % (days, args.krylov, wtag), "cpr", args.krylov, dts, False)
+            variant("dt%d_f64_cpr_%s" % (days, args.krylov), "cpr", args.krylov, dts, False)
+            if days >= 20.0 and args.krylov != "bicgstab":
+                variant("dt%d_f64_cpr_bicgstab" % days, "cpr", "bicgstab", dts, False)
+        # the other BASELINE decks on one GPU (north_star: "synthetic Cartesian and SPE decks"): headline solver + reference default each
+        if not args.no_other_decks and args.deck == "cart" and (args.nx, args.ny, args.nz) == (100, 100, 100):
+            for name in ("spe9like", "spe10like", "nornelike"):
+                dk = baseline_decks.make(name)
+                dts = baseline_decks.DT_DAYS[name] * decks.DAY
+                variant(name + "_cpr_%s" % args.krylov, "cpr", args.krylov, dts, False, deck=dk, into=other_decks)
+                variant(name + "_ref_default_ilu0", "ilu0", "bicgstab", dts, reference_single("ilu0", dts), deck=dk, into=other_decks)
+                del dk
 
-    out = None
+    out = detail = None
     if rank == 0:
         nb = grid.nc
         rowptr, col, _ = model.jacobian()
@@ -456,7 +518,7 @@ def main(argv=None):
                 nbytes = spmv_bytes(nb, nnzb, sb)
                 roof[name] = {"bound": "hbm", "achieved": nbytes / (ms_cold * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": nbytes / (ms_cold * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                              "traffic": None,        # PMC counters need rocprofv3 (separate passes): profiles/r03_*_pmc_summary.json, never pasted here
+                              "traffic": None,        # PMC counters need rocprofv3 (separate passes): profiles/r04_*_pmc_summary.json, never pasted here
                               "kernel": "k_spmv<%s,0>" % ("float" if sp else "double"), "ms_per_launch": ms_cold, "algorithmic_bytes": nbytes,
                               "operands": "matrix rotating over 4 copies (%.0f MB each): HBM-resident" % ((nnzb * (9 * sb + 4)) / 1e6),
                               "cache_resident_replay": {"ms_per_launch": ms_warm, "achieved": nbytes / (ms_warm * 1e-3) / 1e9, "frac": nbytes / (ms_warm * 1e-3) / 1e9 / HBM_PEAK_GBS},
@@ -494,9 +556,8 @@ def main(argv=None):
 
         cpu = cpu_all = None
         if not args.no_cpu_baseline and not use_dist:
-            wl = make_wells() if use_wells else None
             cpu_single = reference_single("ilu0", dt_main)          # the port runs the reference's DEFAULT solver in the reference's arithmetic for it
-            cpu = cpu_baseline(grid, tab, st, wl, prm, dt_main, cpu_single, threads=args.cpu_threads)
+            cpu = cpu_baseline(grid, tab, st, main_wells, prm, dt_main, cpu_single, threads=args.cpu_threads)
             # the same port with its OpenMP-able loops (assembly, SpMV, vector updates; the ILU sweeps stay sequential like the
             # reference's) on this job's host cores -- the reference itself caps OpenMP at 4 threads (FlowMain.hpp:269-271)
             try:
@@ -505,55 +566,91 @@ def main(argv=None):
                 ncores = os.cpu_count() or 1
             ncores = min(ncores, 16)             # a one-GPU box shares its host: 16 cores is this job's share
             if ncores > args.cpu_threads:
-                cpu_all = cpu_baseline(grid, tab, st, wl, prm, dt_main, cpu_single, threads=ncores, budget_s=8.0, max_newton=2)
+                cpu_all = cpu_baseline(grid, tab, st, main_wells, prm, dt_main, cpu_single, threads=ncores, budget_s=8.0, max_newton=2)
 
         if use_wells:
             spec = well_spec if well_spec else (spe10_spec if args.deck == "spe10like" else (args.rate, 150.0))
-            per = args.nz
-            wells_txt = ("5-spot: 1 rate-controlled water injector (%.0f m3/d, BHP limit off) + 4 BHP producers (%.0f bar), %d perforations each, device well model "
-                         "(rank-7 operator per well, control switching + well pre-solve on the device)%s" %
-                         (spec[0], spec[1], per, "" if world == 1 else ("; one such 5-spot per rank's slab (%d wells)" % (5 * world) if (args.scaling == "weak" and args.deck == "cart")
-                                                                         else "; the deck is cut along j, every well on one rank")))
+            wells_txt = ("5-spot on the device: 1 water injector (%.0f m3/d) + 4 BHP producers (%.0f bar), %d perforations each%s" %
+                         (spec[0], spec[1], args.nz, "" if world == 1 else ("; one 5-spot per rank's slab" if (args.scaling == "weak" and args.deck == "cart")
+                                                                            else "; cut along j, every well on one rank")))
         else:
             wells_txt = "none"
         weak = world > 1 and args.scaling == "weak" and args.deck == "cart"
-        lin_name = ("cpr(amg V-cycle + ilu0)" if prm.use_cpr else "ilu0") + ({1: " + gmres(40)", 2: " + flexible gmres(40)"}.get(prm.newton_use_gmres, " + bicgstab"))
+        kry = {1: "gmres(40)", 2: "flexible gmres(40)"}.get(prm.newton_use_gmres, "bicgstab")
+        if prm.use_cpr:
+            stage1 = ("amg" if prm.cpr_use_amg else "ilu0(A_p)") + (" V-cycle" if (prm.cpr_use_amg and prm.cpr_max_ell_iter == 0) else
+                                                                    " in %s(tol %g, <= %d)" % ("bicgstab" if prm.cpr_use_bicgstab else "cg", prm.cpr_solver_tol, prm.cpr_max_ell_iter))
+            lin_name = "cpr(%s + ilu0, relax %g) + %s" % (stage1, prm.cpr_relax, kry)
+        else:
+            lin_name = "ilu0(relax %g) + %s" % (prm.ilu_relaxation, kry)
+        if prm.use_cpr and not single_main and prm.newton_use_gmres != 2:
+            equiv = "solver_approach=cpr cpr_use_amg=%s%s cpr_relax=%g in double (NewtonIterationBlackoilCPR.hpp:59-63, .cpp:61-64,117-140)" % (
+                "true" if prm.cpr_use_amg else "false", " newton_use_gmres=true" if prm.newton_use_gmres else "", prm.cpr_relax)
+            if prm.cpr_use_amg and prm.cpr_max_ell_iter == 0:
+                equiv += ("; DIFFERS in the pressure stage: ONE AMG V-cycle per application (cpr_max_ell_iter=0, library extension) where the reference's external "
+                          "CPRPreconditioner runs an AMG-preconditioned inner BiCGStab -> variants.cpr_amg_inner_bicgstab")
+        elif not prm.use_cpr and single_main == reference_single("ilu0", dt_main) and not prm.newton_use_gmres:
+            equiv = "reference default (solver_approach=interleaved)"
+        else:
+            equiv = "NOT a configuration the reference can run as is (see the docstring of bench.py)"
+        pts = main_sum.get("per_time_step") or {}
+
+        def r3(x):
+            return None if x is None else round(float(x), 3)
+
+        def compact_variants(vs):
+            """name -> [Mcell-updates/s (median over solving calls), Newton iterations per time step, ms per converged time step, ms per simulated day]"""
+            o = {}
+            for k, v in vs.items():
+                if "failed" in v:
+                    o[k] = "failed"
+                    continue
+                p = v.get("per_time_step") or {}
+                o[k] = [round(v["value"], 1), r3(p.get("newton_iterations_per_time_step")), r3(p.get("ms_per_converged_time_step")), r3(p.get("ms_per_simulated_day"))]
+            return o
+
         out = {
-            "metric": "Mcell-updates/sec per Newton step (assembly+solve)", "value": main_sum["value"], "unit": "Mcell-updates/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_sum["ms_per_step"],
+            "metric": "Mcell-updates/sec per Newton step (assembly+solve)", "value": round(main_sum["value"], 3), "unit": "Mcell-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(main_sum["ms_per_step"], 4),
             "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
             "dtype": "f32" if single_main else "f64", "data": "synthetic",
-            "value_basis": ("cells / median duration of the %d timed Newton iterations that include a linear solve (SURVEY 8d M1)" % res["n_solving"]) if res["solving_ms"] is not None
-                           else "cells / mean duration of the timed calls (no per-call marks in this mode)",
-            "ms_per_solving_iteration_median": main_sum["ms_per_solving_iteration_median"], "value_all_calls_mean": main_sum["value_all_calls_mean"],
+            "value_basis": "cells / median ms of the timed Newton iterations that include a linear solve (SURVEY 8d M1)" if res["solving_ms"] is not None
+                           else "cells / mean ms of the timed calls (no per-call marks in this mode)",
+            "ms_per_solving_iteration_median": r3(main_sum["ms_per_solving_iteration_median"]),
+            "ms_per_solving_iteration_mean": r3(main_sum["ms_per_solving_iteration_mean"]),
+            "value_mean_solving": r3(main_sum["value_mean_solving"]), "value_all_calls_mean": r3(main_sum["value_all_calls_mean"]),
             "config": {"workload": "%s%dx%dx%d_3phase_blackoil%s" % ("spe10like_" if args.deck == "spe10like" else "cart", args.nx, args.ny, args.nz * (world if weak else 1),
                                                                      "_fivespot" if use_wells else ""),
-                       "cells": nc_global, "cells_per_gpu": info["n_owned"], "nnzb_rank0": nnzb,
-                       "dt_days": args.dt_days, "linear_solver": lin_name, "ilu0_ordering": args.ordering,
-                       "arithmetic": main_sum["arithmetic"],
-                       "gmres_true_residual_check": bool(prm.gmres_verify_residual),
-                       "pressure_stage_correction_factor": ("fixed 1.9 (OPMGPU_AMG_ADAPT=0)" if os.environ.get("OPMGPU_AMG_ADAPT") == "0" else
-                                                            "chosen per time step between 1.9 and 2.3 by the step's linear iterations per solve (library default; "
-                                                            "same_run_variants.*fixed_correction_factor* is the fixed 1.9)") if prm.use_cpr else None,
-                       "reference_equivalence": ("reference-option-equivalent: solver_approach=cpr + newton_use_gmres in double, the arithmetic of the reference's CPR plug-in "
-                                                 "(NewtonIterationBlackoilCPR.cpp:61-64, 117-140)" if (prm.use_cpr and not single_main) else
-                                                 "reference default (solver_approach=interleaved)" if (not prm.use_cpr and single_main == reference_single("ilu0", dt_main) and not prm.newton_use_gmres) else
-                                                 "NOT a configuration the reference can run as is (see the docstring of bench.py)"),
-                       "reference_default_variant": "same_run_variants.reference_default_solver_ilu0" + wtag,
-                       "solving_iterations": res.get("n_solving"), "linear_iterations_per_solving_iteration": res.get("lin_per_solving"),
-                       "time_steps_completed": res["steps_done"], "time_steps_not_converged": res["steps_not_converged"], "time_steps_chopped": res["chopped"],
-                       "time_steps_chopped_in_timed_region": res["chopped_timed"],
-                       "spin_up_time_steps": args.spin_up, "nonlinear_solver": "reference NonlinearSolver (max_iter 10, update stabilisation on)",
-                       "tables": "tests/satfuncStandard.DATA PROPS (reference's own test deck)", "wells": wells_txt,
-                       "parallelism": "1 GPU" if world == 1 else "domain decomposition x%d, RCCL halo" % world},
-            "timed_calls": res.get("calls"),
-            "non_solving_call_ms_median": res.get("non_solving_ms_median"),
-            "breakdown_ms_per_step": res.get("breakdown"),
-            "same_run_variants": variants,
-            "roofline": main_roof, "roofline_f64_spmv": roof.get("f64"), "roofline_f32_spmv": roof.get("f32"),
-            "kernel_table": kernel_table,
-            "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all,
+                       "cells": nc_global, "cells_per_gpu": info["n_owned"], "dt_days": args.dt_days, "linear_solver": lin_name,
+                       "arithmetic": main_sum["arithmetic"], "reference_equivalence": equiv,
+                       "solving_iterations": res.get("n_solving"), "linear_its_per_solve": r3(res.get("lin_per_solving")),
+                       "time_steps_completed": res["steps_done"], "time_steps_chopped": res["chopped_timed"], "time_steps_not_converged": res["steps_not_converged"],
+                       "wells": wells_txt, "parallelism": "1 GPU" if world == 1 else "domain decomposition x%d, RCCL halo" % world},
+            "per_time_step": {k: (r3(v) if isinstance(v, float) else v) for k, v in pts.items()} if pts else None,
+            "breakdown_ms": {k: r3(v) for k, v in (res.get("breakdown") or {}).items() if k != "basis"} or None,
+            "roofline": None if main_roof is None else {k: (round(v, 4) if isinstance(v, float) else v) for k, v in main_roof.items()
+                                                        if k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "ms_per_launch", "algorithmic_bytes")},
+            "cpu_baseline": None if cpu is None else {"value": round(cpu["value"], 4), "unit": cpu["unit"], "cores": cpu["cores"], "kind": cpu["kind"], "sample": cpu["sample"]},
+            "cpu_all_cores": None if cpu_all is None else {"value": round(cpu_all["value"], 4), "cores": cpu_all["cores"]},
+            "variants_columns": "[Mcell-updates/s, newton its per time step, ms per converged time step, ms per simulated day]",
+            "variants": compact_variants(variants),
+            "decks": compact_variants(other_decks),
+            "detail": os.path.basename(args.detail),
         }
+        # the line must reach the driver whole: shed the optional maps first, never the contract keys
+        for k in ("variants_columns", "cpu_all_cores", "breakdown_ms", "decks", "variants", "per_time_step"):
+            if len(json.dumps(out)) < MAX_LINE_BYTES:
+                break
+            out[k] = "see " + os.path.basename(args.detail)
+        assert len(json.dumps(out)) < MAX_LINE_BYTES, "bench line too long for the driver"
+        detail = {"line": out, "main": main_sum, "same_run_variants": variants, "other_decks": other_decks,
+                  "roofline_f64_spmv": roof.get("f64"), "roofline_f32_spmv": roof.get("f32"), "kernel_table": kernel_table,
+                  "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "nnzb_rank0": nnzb, "ilu0_ordering": args.ordering,
+                  "spin_up_time_steps": args.spin_up, "nonlinear_solver": "reference NonlinearSolver (max_iter 10, update stabilisation on)",
+                  "tables": "tests/satfuncStandard.DATA PROPS (reference's own test deck)",
+                  "pressure_stage_correction_factor": ("fixed 1.9 (OPMGPU_AMG_ADAPT=0)" if os.environ.get("OPMGPU_AMG_ADAPT") == "0" else
+                                                       "chosen per time step between 1.9 and 2.3 by the step's linear iterations per solve (library default)") if prm.use_cpr else None,
+                  "gmres_true_residual_check": bool(prm.gmres_verify_residual), "argv": argv}
     model.close()
     if use_dist:
         dist.barrier()
@@ -562,6 +659,13 @@ def main(argv=None):
     os.dup2(saved_stdout_fd, 1)
     os.close(saved_stdout_fd)
     if rank == 0:
+        try:
+            with open(args.detail, "w") as f:
+                json.dump(detail, f, indent=1)
+        except OSError as e:
+            print("bench.py: could not write %s: %r" % (args.detail, e), file=sys.stderr)
+        if os.environ.get("OPMGPU_BENCH_VERBOSE"):
+            print(json.dumps(detail), file=sys.stderr)
         print(json.dumps(out), flush=True)
 
 

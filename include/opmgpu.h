@@ -165,6 +165,21 @@ typedef struct opmgpu_params {
                                             NewtonIterationBlackoilCPR.cpp:117-131): the WHOLE system is row-transformed by L (per cell: its
                                             first equation is replaced by the sum of the dominant equations), the pressure row scaled by
                                             200 bar, and the Krylov method iterates on (and measures) L A x = L b */
+    /* --- the reference's CPR parameters (NewtonIterationBlackoilCPR.hpp:59-63 documents the first four with these defaults; they are read
+     *     by the external opm-simulators CPRPreconditioner, whose source is NOT under /root/reference) ------------------------------------ */
+    double cpr_relax;               /* 1.0: relaxation of the CPR preconditioner -- the ILU0 of stage 2 is built with it INSTEAD of
+                                       ilu_relaxation, and a value != 1 also scales the pressure correction of stage 1 */
+    int32_t cpr_ilu_n;              /* 0: fill-in level of stage 2's ILU(n).  Only 0 is built: > 0 -> OPMGPU_EINVAL at the first CPR solve */
+    int32_t cpr_use_amg;            /* 0 = the elliptic (pressure) part is preconditioned by a POINT ILU0 of A_p (the documented default),
+                                       1 = by one AMG V-cycle on A_p (amg.hip) */
+    int32_t cpr_use_bicgstab;       /* 1 = BiCGStab for the elliptic part, 0 = CG */
+    /* the elliptic part's inner Krylov solve.  Its stopping rule lives in the external CPRPreconditioner: the two values below are this
+     * library's RECOLLECTION of that file (cpr_solver_tol 1e-2, cpr_max_elliptic_iter 25), unpinned by anything in the container */
+    double cpr_solver_tol;          /* 1e-2: reduction of || b_p - A_p x_p || the inner solve stops at */
+    int32_t cpr_max_ell_iter;       /* 25: iteration limit of the inner solve (reaching it is NOT an error here: the outer method goes on with
+                                       what the inner one attained).  0 = library extension, no inner Krylov method at all: ONE application
+                                       of the elliptic preconditioner (with cpr_use_amg = 1: one V-cycle, its coarse-grid corrections scaled
+                                       as DESIGN.md section 4b describes) -- what bench.py's headline runs, and says so */
 } opmgpu_params;
 
 void opmgpu_default_params(opmgpu_params* p);

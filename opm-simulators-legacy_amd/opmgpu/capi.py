@@ -84,7 +84,14 @@ class Params(C.Structure):
                 ("newton_use_gmres", C.c_int32), ("linear_solver_restart", C.c_int32),
                 ("solve_welleq_initially", C.c_int32), ("tolerance_wells", C.c_double), ("tolerance_well_control", C.c_double),
                 ("dbhp_max_rel", C.c_double), ("update_equations_scaling", C.c_int32),
-                ("gmres_verify_residual", C.c_int32), ("cpr_reference_transform", C.c_int32)]
+                ("gmres_verify_residual", C.c_int32), ("cpr_reference_transform", C.c_int32),
+                ("cpr_relax", C.c_double), ("cpr_ilu_n", C.c_int32), ("cpr_use_amg", C.c_int32), ("cpr_use_bicgstab", C.c_int32),
+                ("cpr_solver_tol", C.c_double), ("cpr_max_ell_iter", C.c_int32)]
+
+
+# use_cpr = 1 with the pressure stage this library was built around: ONE AMG V-cycle per application (cpr_use_amg = 1 without the inner
+# Krylov solve the reference's external CPRPreconditioner wraps around it -- cpr_max_ell_iter = 0, a library extension; include/opmgpu.h)
+CPR_AMG_VCYCLE = dict(use_cpr=1, cpr_use_amg=1, cpr_max_ell_iter=0)
 
 
 def default_params(**over):
@@ -99,6 +106,8 @@ def default_params(**over):
     p.solve_welleq_initially, p.tolerance_wells, p.tolerance_well_control, p.dbhp_max_rel = 1, 1e-4, 1e-7, 1.0
     p.update_equations_scaling = 0
     p.gmres_verify_residual, p.cpr_reference_transform = 0, 0
+    p.cpr_relax, p.cpr_ilu_n, p.cpr_use_amg, p.cpr_use_bicgstab = 1.0, 0, 0, 1            # NewtonIterationBlackoilCPR.hpp:59-63
+    p.cpr_solver_tol, p.cpr_max_ell_iter = 1e-2, 25                                       # external CPRPreconditioner (recollection)
     for k, v in over.items():
         if k == "matbalscale":
             p.matbalscale[:] = list(v)

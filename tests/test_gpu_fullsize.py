@@ -402,56 +402,9 @@ def _check_newton_count(gpu_lib, oracle, grid, tab, st, dt, wl, solvers=(0, 1), 
         assert np.abs(a.p - b.p).max() <= tol * np.abs(b.p).max() and np.abs(a.sat - b.sat).max() <= tol, (code, np.abs(a.p - b.p).max() / np.abs(b.p).max(), np.abs(a.sat - b.sat).max())
 
 
-def _cart100(rate=1000.0, perturb=0.002):
-    grid = decks.cartesian_grid(100, 100, 100, lognormal_sigma=0.5, seed=12345)
-    tab = decks.satfunc_standard_tables()
-    st = decks.initial_state(grid, tab, perturb=perturb, seed=12345)
-    from opmgpu import wells as W
-    return grid, tab, st, W.five_spot(grid, rate_m3_per_day=rate, bhp_prod_bar=150.0)
+from opmgpu import baseline_decks as _bd          # the deck recipes live with the package: bench.py times the same ones
 
-
-def _spe10_like(rate=200.0, perturb=1e-4, bhp=380.0, gascap=0.0):
-    """SPE10 Model 2 dimensions and cell sizes (20 x 10 x 2 ft), channel-free lognormal permeability with sigma_lnK = 2.5 (the SPE10
-    permeability file is not available offline), 5-spot like the original: central water injector, four corner producers.  Like
-    SPE10 there is no gas cap (undersaturated oil everywhere); pore volumes are ~2 m3 per cell, so rates and drawdown are moderate."""
-    grid = decks.cartesian_grid(60, 220, 85, dx=6.096, dy=3.048, dz=0.6096, tops=3657.6, lognormal_sigma=2.5, seed=10)
-    tab = decks.satfunc_standard_tables()
-    st = decks.initial_state(grid, tab, p_ref=413.0 * decks.BAR, z_ref=3657.6, perturb=perturb, seed=10, gas_cap_fraction=gascap, gas_only_fraction=0.01 if gascap > 0 else 0.0)
-    from opmgpu import wells as W
-    return grid, tab, st, W.five_spot(grid, rate_m3_per_day=rate, bhp_prod_bar=bhp)
-
-
-def _norne_like():
-    """Norne's Cartesian box 46 x 112 x 22 with 60 % of the cells inactive (~45 k active), fault-style NNCs (5 % extra connections),
-    threshold pressures, 36 wells (4 water injectors, producers on BHP or oil-rate control)."""
-    rng = np.random.default_rng(44)
-    act = rng.random(46 * 112 * 22) > 0.6
-    grid = decks.cartesian_grid(46, 112, 22, dx=80.0, dy=80.0, dz=4.0, tops=2500.0, actnum=act, nnc_fraction=0.05, lognormal_sigma=1.0, thpres=0.02 * decks.BAR, seed=44)
-    tab = decks.satfunc_standard_tables()
-    st = decks.initial_state(grid, tab, p_ref=270.0 * decks.BAR, z_ref=2500.0, perturb=0.005, seed=44)
-    from opmgpu import wells as W
-    return grid, tab, st, W.column_wells(grid, 36, n_injectors=4, seed=44, inj_rate_m3_per_day=300.0, prod_bhp_bar=200.0, prod_oil_rate_m3_per_day=40.0)
-
-
-def _spe9_like():
-    """SPE9 dimensions (24 x 25 x 15, 300 ft cells), 26 wells: one water injector completed in layers 11-15 and 25 producers in
-    layers 2-4 (half on BHP, half on oil-rate control)."""
-    grid = decks.cartesian_grid(24, 25, 15, dx=91.44, dy=91.44, dz=6.0, tops=2743.0, lognormal_sigma=1.0, seed=9)
-    tab = decks.satfunc_standard_tables()
-    st = decks.initial_state(grid, tab, p_ref=248.0 * decks.BAR, z_ref=2743.0, perturb=0.005, seed=9)
-    from opmgpu import wells as W
-    return grid, tab, st, W.column_wells(grid, 26, n_injectors=1, seed=9, inj_layers=range(10, 15), prod_layers=range(1, 4),
-                                         inj_rate_m3_per_day=800.0, prod_bhp_bar=150.0, prod_oil_rate_m3_per_day=60.0)
-
-
-def _cart60():
-    """the bench deck's recipe at 60^3 = 216 k cells: the size at which the ORACLE's ILU0-preconditioned GMRES(40) is still affordable (at 1 M
-    cells one 1e-6 solve takes it 211 iterations / 50 s on 8 cores), so that device GMRES and oracle GMRES can run whole time steps side by side"""
-    grid = decks.cartesian_grid(60, 60, 60, lognormal_sigma=0.5, seed=12345)
-    tab = decks.satfunc_standard_tables()
-    st = decks.initial_state(grid, tab, perturb=0.002, seed=12345)
-    from opmgpu import wells as W
-    return grid, tab, st, W.five_spot(grid, rate_m3_per_day=300.0, bhp_prod_bar=150.0)
+_cart100, _spe10_like, _norne_like, _spe9_like, _cart60 = _bd.cart100, _bd.spe10_like, _bd.norne_like, _bd.spe9_like, _bd.cart60
 
 
 DECKS = {"cart100": (_cart100, 5.0), "spe10like": (_spe10_like, 2.0), "nornelike": (_norne_like, 3.0), "spe9like": (_spe9_like, 3.0)}
