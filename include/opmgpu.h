@@ -185,6 +185,9 @@ typedef struct opmgpu_params {
 void opmgpu_default_params(opmgpu_params* p);
 /* the equation scaling the last assembly used (== params.matbalscale unless update_equations_scaling) */
 int opmgpu_get_matbalscale(opmgpu_ctx* ctx, double* scale3);
+/* CPR with an inner Krylov method on the elliptic part (cpr_max_ell_iter > 0; the reference's external CPRPreconditioner::solveElliptic,
+ * reached from NewtonIterationBlackoilCPR.cpp:148-165): inner solves and inner iterations since the context was created */
+int opmgpu_cpr_elliptic_stats(opmgpu_ctx* ctx, int64_t* solves, int64_t* iterations);
 
 /* ------------------------------------------------------------------------------------------
  * B2 boundary: BlackoilModel hooks (BlackoilModelBase_impl.hpp:239-326: assemble ->
@@ -462,7 +465,8 @@ int opmgpu_last_timings(opmgpu_ctx* ctx, double* assemble_ms, double* solve_ms, 
  * for i = 0) to the end of call i -- the host round trips of an iteration serialise consecutive calls, so this is the iteration's wall
  * time --, solved[i] = 1 if the call ran solveJacobianSystem + updateState (a converged call does not: BlackoilModelBase_impl.hpp:277-281),
  * linear_iterations[i], phase_ms[3 i + {0, 1, 2}] = assemble / solve / update (0 where the phase did not run).  Any output may be NULL;
- * *n_calls = calls recorded.  opmgpu_iteration_marks(ctx, 0) switches off and frees the events. */
+ * *n_calls = calls made since the switch-on.  At most 16384 calls are recorded (later ones run unmarked and only count); the events are
+ * recycled through a pool that lives as long as the context.  opmgpu_iteration_marks(ctx, 0) switches off and returns the events to it. */
 int opmgpu_iteration_marks(opmgpu_ctx* ctx, int enable);
 int opmgpu_iteration_marks_get(opmgpu_ctx* ctx, int max_calls, double* call_ms, int32_t* solved, int32_t* linear_iterations, double* phase_ms, int* n_calls);
 

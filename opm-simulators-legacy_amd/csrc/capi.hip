@@ -43,10 +43,17 @@ struct opmgpu_ctx {
     hipEvent_t mark_start = nullptr;
     std::vector<IterMark> marks;
     IterMark* cur_mark = nullptr;
-    void marks_clear() {
-        for (IterMark& m : marks) { if (m.end) (void)hipEventDestroy(m.end); for (auto& pr : m.ph) for (auto& e : pr) if (e) (void)hipEventDestroy(e); }
-        marks.clear(); cur_mark = nullptr;
-        if (mark_start) { (void)hipEventDestroy(mark_start); mark_start = nullptr; }
+    // events of the marks are recycled through a pool (a caller that leaves the marks on for a long run does not create seven new events per
+    // call for ever), and the list is capped: beyond kMaxMarks calls the marks stop being recorded (n_calls of marks_get keeps counting)
+    static constexpr size_t kMaxMarks = 16384;
+    long marks_dropped = 0;
+    std::vector<hipEvent_t> mark_pool;
+    hipEvent_t mark_event() { if (!mark_pool.empty()) { hipEvent_t e = mark_pool.back(); mark_pool.pop_back(); return e; } hipEvent_t e = nullptr; return hipEventCreate(&e) == hipSuccess ? e : nullptr; }
+    void marks_clear(bool destroy = false) {
+        for (IterMark& m : marks) { if (m.end) mark_pool.push_back(m.end); for (auto& pr : m.ph) for (auto& e : pr) if (e) mark_pool.push_back(e); }
+        marks.clear(); cur_mark = nullptr; marks_dropped = 0;
+        if (mark_start) { mark_pool.push_back(mark_start); mark_start = nullptr; }
+        if (destroy) { for (hipEvent_t e : mark_pool) (void)hipEventDestroy(e); mark_pool.clear(); }
     }
 };
 
@@ -88,10 +95,11 @@ struct Timed {
     hipEvent_t e1 = nullptr;
     Timed(opmgpu_ctx* c_, int phase) : c(c_), ph(phase) {
         if (c->cur_mark) {                  // iteration marks: this call's own event pair (resolved by opmgpu_iteration_marks_get)
-            hipEvent_t e0 = nullptr;
-            if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+            hipEvent_t e0 = c->mark_event();
+            e1 = c->mark_event();
+            if (e0 && e1) {
                 // a phase that runs twice in one call (never today) keeps its last pair
-                for (auto& e : c->cur_mark->ph[ph]) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+                for (auto& e : c->cur_mark->ph[ph]) if (e) { c->mark_pool.push_back(e); e = nullptr; }
                 c->cur_mark->ph[ph][0] = e0; c->cur_mark->ph[ph][1] = e1;
                 (void)hipEventRecord(e0, c->stream);
                 return;
@@ -113,6 +121,10 @@ template <class S> int solve_loaded(opmgpu_ctx* c, bool matrix_changed, SolveRes
         if (prm.cpr_ilu_n != 0) return fail(c, OPMGPU_EINVAL, "cpr_ilu_n > 0 (ILU(n) with fill-in) is not built: only cpr_ilu_n = 0");
         if (!(prm.cpr_relax > 0.0) || !(prm.cpr_solver_tol > 0.0) || prm.cpr_max_ell_iter < 0) return fail(c, OPMGPU_EINVAL, "cpr_relax / cpr_solver_tol must be positive, cpr_max_ell_iter >= 0");
         prm.ilu_relaxation = prm.cpr_relax;
+        // the elliptic part (elliptic.inl): cpr_max_ell_iter = 0 is this library's one-V-cycle stage, which needs the AMG
+        if (prm.cpr_max_ell_iter == 0 && !prm.cpr_use_amg) return fail(c, OPMGPU_EINVAL, "cpr_max_ell_iter = 0 (one application, no inner Krylov method) needs cpr_use_amg = 1");
+        ls.ell.inner = prm.cpr_max_ell_iter > 0; ls.ell.use_amg = prm.cpr_use_amg != 0; ls.ell.bicgstab = prm.cpr_use_bicgstab != 0;
+        ls.ell.tol = prm.cpr_solver_tol; ls.ell.maxit = prm.cpr_max_ell_iter; ls.ell.relax = prm.cpr_relax;
     }
     ls.wb_relax = prm.ilu_relaxation;
     if (prm.use_cpr) ls.correction_policy_choose();
@@ -194,7 +206,7 @@ void opmgpu_destroy(opmgpu_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->model.reset(); c->ls.reset(); c->comm.reset();
-    c->marks_clear();
+    c->marks_clear(true);
     for (auto& pr : c->evp) for (auto& e : pr) if (e) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -243,6 +255,14 @@ int opmgpu_assemble(opmgpu_ctx* c, double dt, int initial, const double* p, cons
         c->matrix_loaded = true; c->factored = false; c->cur_single = -1; c->ls->ref_transformed = false;
         return int(OPMGPU_OK);
     });
+}
+
+int opmgpu_cpr_elliptic_stats(opmgpu_ctx* c, int64_t* solves, int64_t* iterations)
+{
+    if (!c || !c->ls) return OPMGPU_EINVAL;
+    if (solves) *solves = c->ls->ell_solves;
+    if (iterations) *iterations = c->ls->ell_iterations;
+    return OPMGPU_OK;
 }
 
 int opmgpu_get_matbalscale(opmgpu_ctx* c, double* scale3)
@@ -397,14 +417,19 @@ int opmgpu_nonlinear_iteration(opmgpu_ctx* c, double dt, int iteration, int sing
     int solved = 0, lin = 0;
     if (!c->marks_on) return nonlinear_iteration_body(c, dt, iteration, single_precision, ctl, converged, linear_iterations ? linear_iterations : &lin, linf3, relaxation, &solved);
     if (hipSetDevice(c->device) != hipSuccess) return fail(c, OPMGPU_ENODEVICE, "hipSetDevice failed");
-    if (!c->mark_start) { if (hipEventCreate(&c->mark_start) != hipSuccess) return OPMGPU_ENODEVICE; (void)hipEventRecord(c->mark_start, c->stream); }
+    if (c->marks.size() >= opmgpu_ctx::kMaxMarks) {      // the list is full: the call runs unmarked
+        ++c->marks_dropped;
+        return nonlinear_iteration_body(c, dt, iteration, single_precision, ctl, converged, linear_iterations ? linear_iterations : &lin, linf3, relaxation, &solved);
+    }
+    if (!c->mark_start) { c->mark_start = c->mark_event(); if (!c->mark_start) return OPMGPU_ENODEVICE; (void)hipEventRecord(c->mark_start, c->stream); }
     c->marks.emplace_back();
     c->cur_mark = &c->marks.back();
     if (!linear_iterations) linear_iterations = &lin;
     const int st = nonlinear_iteration_body(c, dt, iteration, single_precision, ctl, converged, linear_iterations, linf3, relaxation, &solved);
     opmgpu_ctx::IterMark& m = c->marks.back();
     m.solved = solved; m.lin = *linear_iterations; m.status = st;
-    if (hipEventCreate(&m.end) == hipSuccess) (void)hipEventRecord(m.end, c->stream);
+    m.end = c->mark_event();
+    if (m.end) (void)hipEventRecord(m.end, c->stream);
     c->cur_mark = nullptr;
     return st;
 }
@@ -423,7 +448,7 @@ int opmgpu_iteration_marks_get(opmgpu_ctx* c, int max_calls, double* call_ms, in
     if (!c || !n_calls || max_calls < 0) return OPMGPU_EINVAL;
     if (hipSetDevice(c->device) != hipSuccess) return fail(c, OPMGPU_ENODEVICE, "hipSetDevice failed");
     const int n = std::min<int>(max_calls, int(c->marks.size()));
-    *n_calls = int(c->marks.size());
+    *n_calls = int(c->marks.size() + c->marks_dropped);
     if (n > 0 && c->marks[n - 1].end && hipEventSynchronize(c->marks[n - 1].end) != hipSuccess) return fail(c, OPMGPU_ENODEVICE, "hipEventSynchronize failed");
     hipEvent_t prev = c->mark_start;
     for (int i = 0; i < n; ++i) {

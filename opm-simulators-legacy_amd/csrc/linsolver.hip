@@ -870,12 +870,13 @@ __global__ __launch_bounds__(kBlock) void k_amg_restore_x0(int n, S omega, const
     if (i < n) x[i] = omega * dinv[i] * b[i];
 }
 template <class S>
-__global__ __launch_bounds__(kBlock) void k_cpr_add_p(int nb, const S* __restrict__ xp, S* __restrict__ v, const SolveCtl* __restrict__ ctl)
+__global__ __launch_bounds__(kBlock) void k_cpr_add_p(int nb, const S* __restrict__ xp, S* __restrict__ v, const SolveCtl* __restrict__ ctl, S c)
 {
+    // c = cpr_relax: the reference's CPRPreconditioner scales the pressure part by it when it is not 1 (the ILU0 part carries it already)
     if (ctl && ctl->done) return;
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= nb) return;
-    v[i] += xp[i];
+    v[i] += c * xp[i];
 }
 
 // ---- layout conversion kernels ----
@@ -1861,6 +1862,7 @@ template <class S> void LinSolver::cpr_prepare()
     const bool single_ok = coarse_mode == 2 || (coarse_single_ok && lowrank.nw == 0);
     coarse_nsub = coarse_mode != 0 && (nsub >= 2 || single_ok) ? nsub : 0;
     if (coarse_nsub > 64) coarse_nsub = 0;        // table sizes of the kernels
+    if (ell.inner) coarse_nsub = 0;               // the inner Krylov method of the elliptic part works on A_p itself (rank-local when decomposed)
     // Scaling of the coarse-grid corrections: 1.9 in general; the correction into level 0 by 2.2 when ONE subdomain carries the coarse
     // space (one GPU, no wells) -- the global constant is then removed exactly for the whole domain and the hierarchy is global:
     // measured +4 % (100^3), +9 % (200^3), +7 % (300^3) throughput, 0 % on the sigma = 2 deck (2.2 on every level: better at 100^3 /
@@ -1923,7 +1925,8 @@ template <class S> void LinSolver::cpr_prepare()
         // The factorisation (HBM-bound, 140 us, on its own stream) is needed by the first ILU0 sweep only, i.e. behind the hierarchy set-up
         // AND the first V-cycle.  It starts when the level 0 -> 1 Galerkin sums are done -- the one bandwidth-heavy kernel of the chain,
         // which it would slow from 60 to 100 us -- and runs next to the small levels' sums and the first cycle (latency-bound launches).
-        w.amg->galerkin(refresh, [&] { if (factor_deferred) { factor_deferred = false; factor_async<S>(); } });
+        w.amg->galerkin(refresh && !(ell.inner && !ell.use_amg), [&] { if (factor_deferred) { factor_deferred = false; factor_async<S>(); } });
+        if (ell.inner && !ell.use_amg) elliptic_factor<S>();
         if (coarse_nsub >= 1) coarse_setup<S>(true);
         return;
     }
@@ -1961,6 +1964,7 @@ template <class S> void LinSolver::cpr_prepare()
     if (w.amg->border_nw() > 0)
         hipLaunchKernelGGL((k_cpr_border<S>), dim3(lowrank.nw), dim3(kBlock), 0, stream, lowrank, plan.nbp, border_weights ? (const S*)border_weights : (const S*)w.cprw.p, w.amg->levels[0]->val.p + w.amg->levels[0]->nentries, border_colscale);
     w.amg->galerkin();
+    if (ell.inner && !ell.use_amg) elliptic_factor<S>();
     new_step_hint = false; refreshed = true;
     if (coarse_nsub >= 1) { coarse_begin<S>(); coarse_setup<S>(false); }
 }
@@ -2034,7 +2038,9 @@ void LinSolver::correction_policy_report(int iterations, bool converged)
     if (!converged) P.step_failed = true;
 }
 
-// M^-1 d = [x_p;0;0] + ILU0^-1 (d - A [x_p;0;0]),  x_p = Vcycle(sum of the equations of d)
+#include "elliptic.inl"
+
+// M^-1 d = [x_p;0;0] + ILU0^-1 (d - A [x_p;0;0]),  x_p = Vcycle(sum of the equations of d) -- or the inner Krylov solve of elliptic.inl
 template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, const SolveCtl* ctl, const double* cr_given)
 {
     SolverWork<S>& w = work<S>();
@@ -2084,7 +2090,7 @@ template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, con
     }
     kt.end(KT_CPR_OTHER, kt_a);
     kt_a = kt.begin();
-    w.amg->vcycle_graph(ctl, true);
+    if (ell.inner) elliptic_solve<S>(); else w.amg->vcycle_graph(ctl, true);
     kt.end(KT_VCYCLE, kt_a);
     kt_a = kt.begin();
     const S* xp = L0.x.p;
@@ -2129,7 +2135,7 @@ template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, con
     if (well_woodbury && wb_active && lowrank.nw > 0 && lowrank.P && !comm && wb_buf.p)
         hipLaunchKernelGGL((k_wb_apply<S>), dim3(lowrank.nw), dim3(kBlock), 0, stream, lowrank, plan.nbp, (const double*)wb_buf.p,
                            (const double*)(wb_buf.p + size_t(21) * lowrank.nperf), v, ctl);
-    hipLaunchKernelGGL((k_cpr_add_p<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, xp, v, ctl);
+    hipLaunchKernelGGL((k_cpr_add_p<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, xp, v, ctl, S(relax));
     kt.end(KT_CPR_OTHER, kt_a);
 }
 
@@ -2199,7 +2205,8 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
     if (cpr) cpr_prepare<S>();
     if (factor_deferred) { factor_deferred = false; factor_async<S>(); }
     if (cpr && !w.amg->npost0_user) w.amg->npost0 = 2;            // post-sweeps on level 0: 2 under BiCGStab, 1 under GMRES (see gmres)
-    const bool closed = closed_form_level0 && emulate_ranks <= 1;
+    // (with cpr_relax != 1 the pressure part of M^-1 p is scaled, which the closed form does not cover)
+    const bool closed = closed_form_level0 && emulate_ranks <= 1 && !(cpr && prm.ilu_relaxation != 1.0);      // (under CPR the field holds cpr_relax: solve_loaded)
     const int8_t* lightmask = nullptr;
     const bool overlap = comm && halo_overlap;
     if (comm && (closed || overlap)) {

@@ -89,6 +89,8 @@ struct SolverWork {
     DevArray<S> cprw;                            // [3][nbp] per-cell weights of the pressure equation (formEllipticSystem)
     DevArray<S> cprw_orig;                       // cpr_reference_transform: the weights L was built from (cprw itself then selects the transformed pressure row)
     std::unique_ptr<AmgHierarchy<S>> amg;         // CPR pressure stage (built on first use)
+    DevArray<S> plu;                             // point ILU0 of the pressure matrix A_p (cpr_use_amg = 0, elliptic.inl)
+    DevArray<S> ellv;                            // work vectors of the elliptic part's inner Krylov method
     bool allocated = false;
 };
 
@@ -143,6 +145,14 @@ public:
     template <class S> void cpr_prepare();
     template <class S> void cpr_reweigh_rows(const int32_t* d_rows, int nrows);   // weights of these rows again, from the current matrix
     void drop_hierarchies();            // the wells changed: the bordered pressure hierarchy is rebuilt from the next matrix
+    // The elliptic part the way the reference's CPR plug-in documents it (NewtonIterationBlackoilCPR.hpp:59-63; elliptic.inl): an inner
+    // BiCGStab / CG on A_p, preconditioned by a point ILU0 of A_p (cpr_use_amg = 0) or by the AMG cycle.  inner = false (cpr_max_ell_iter
+    // = 0): one application of the AMG cycle, no inner method.  Set from opmgpu_params before every solve (capi.hip, solve_loaded).
+    struct EllipticCfg { bool inner = false, use_amg = true, bicgstab = true; double tol = 1e-2; int maxit = 25; double relax = 1.0; } ell;
+    long ell_solves = 0, ell_iterations = 0;     // inner solves / inner iterations since the context was created (opmgpu_cpr_elliptic_stats)
+    DevArray<double> ell_parts;
+    template <class S> void elliptic_factor();
+    template <class S> void elliptic_solve();
     template <class S> void cpr_apply(const S* d, S* v, double relax, const SolveCtl* ctl, const double* cr_given = nullptr);
     // opmgpu_params.cpr_reference_transform: the reference's CPR formulation (NewtonIterationUtilities.cpp:253-287 formEllipticSystem,
     // NewtonIterationBlackoilCPR.cpp:117-131): the WHOLE system is row-transformed by the per-cell matrix L -- first row = the sum of the

@@ -39,7 +39,7 @@ class Simulator:
         ky = self.deck.array("PERMY", n, kx)
         self.schedule = schedmod.Schedule(self.deck, self.grid, perm_md=(kx, ky), dz=dz.ravel(), dxdy=(dx.ravel(), dy.ravel()),
                                           ntg=self.deck.array("NTG", n, np.ones(n)))
-        self.params = params or capi.default_params(use_cpr=1)
+        self.params = params or capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1)
         self.well_model_factory = well_model_factory
         if model_factory is None:
             self.model = GpuBlackoilModel(self.grid, self.tables, self.params, device=device)

@@ -49,6 +49,12 @@ def test_default_params_match_reference(lib):
     c = capi.default_params(use_cpr=1)
     assert (c.newton_use_gmres, c.linear_solver_reduction, c.linear_solver_maxiter, c.linear_solver_restart, c.ignore_convergence_failure) == (0, 1e-2, 50, 40, 0)
     assert (p.linear_solver_reduction, p.linear_solver_maxiter, p.linear_solver_restart, p.newton_use_gmres) == (1e-2, 150, 40, 0)
+    # the CPR plug-in's own parameters with the defaults NewtonIterationBlackoilCPR.hpp:59-63 documents (relax 1.0, ILU(0), NO AMG, BiCGStab for
+    # the elliptic part); the inner solve's tolerance / iteration limit live in the external CPRPreconditioner: recalled, parameters here
+    assert (c.cpr_relax, c.cpr_ilu_n, c.cpr_use_amg, c.cpr_use_bicgstab) == (1.0, 0, 0, 1)
+    assert (c.cpr_solver_tol, c.cpr_max_ell_iter) == (1e-2, 25)
+    v = capi.default_params(**capi.CPR_AMG_VCYCLE)
+    assert (v.use_cpr, v.cpr_use_amg, v.cpr_max_ell_iter, v.linear_solver_maxiter) == (1, 1, 0, 50)
 
 
 @pytest.mark.skipif(capi.load().opmgpu_device_count() > 0, reason="a GPU is present")

@@ -51,7 +51,7 @@ def test_self_halo_reproduces_plain_grid(gpu_lib, oracle, single, cpr, monkeypat
     stA = decks.initial_state(gridA, tab, perturb=0.01)
     stB = decks.State(stA.p[src], stA.sat[src], stA.rs[src], stA.rv[src], stA.hc[src])
     red = 1e-4 if single else 1e-11
-    prm = capi.default_params(linear_solver_reduction=red, linear_solver_maxiter=400, use_cpr=cpr)
+    prm = capi.default_params(linear_solver_reduction=red, linear_solver_maxiter=400, cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=cpr)
     dt = 5 * decks.DAY
     n = gridA.nc
     A = GpuBlackoilModel(gridA, tab, prm)
@@ -121,7 +121,7 @@ def test_self_halo_with_device_wells(gpu_lib, cpr):
     prod = [22 + L * k for k in range(2, 5)]          # includes the top layer
     wl.add_well("INJ", W.INJECTOR, gridA.z[inj[0]], inj, WI, (1.0, 0.0, 0.0), (W.SURFACE_RATE, 20.0 / 86400.0, (1.0, 0.0, 0.0)))
     wl.add_well("PROD", W.PRODUCER, gridA.z[prod[0]], prod, WI, (0.0, 1.0, 0.0), (W.BHP, 150 * decks.BAR))
-    prm = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=500, use_cpr=cpr)
+    prm = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=500, cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=cpr)
     A = GpuBlackoilModel(gridA, tab, prm)
     B = GpuBlackoilModel(gridB, tab, prm)
     dom = _Dom()

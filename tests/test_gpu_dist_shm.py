@@ -68,19 +68,19 @@ def _launch(cfg, world, tmp, extra_env=None):
 CASES = {
     "ilu0": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=1500), wells=False, single=False),
     "ilu0_natural_order": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=1500, ilu_ordering=0), wells=False, single=False),
-    "cpr": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=500, use_cpr=1), wells=False, single=False),
+    "cpr": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=500, cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1), wells=False, single=False),
     # inactive cells + non-neighbour connections: contiguous index ranges as subdomains, ranks with more than two neighbours
-    "cpr_unstructured": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=800, use_cpr=1), wells=False, single=False, unstructured=True),
+    "cpr_unstructured": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=800, cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1), wells=False, single=False, unstructured=True),
     "ilu0_j_slabs": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=1500), wells=False, single=False, axis=1),
-    "cpr_wells": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=500, use_cpr=1), wells=True, single=False),
+    "cpr_wells": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=500, cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1), wells=True, single=False),
     # the reference's newton_use_gmres option decomposed: halo-exchanged basis vectors, owner-masked projections, one all-reduce each
-    "cpr_gmres": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=500, use_cpr=1, newton_use_gmres=1), wells=False, single=False),
-    "cpr_gmres_wells": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=500, use_cpr=1, newton_use_gmres=1), wells=True, single=False),
+    "cpr_gmres": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=500, cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1, newton_use_gmres=1), wells=False, single=False),
+    "cpr_gmres_wells": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=500, cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1, newton_use_gmres=1), wells=True, single=False),
     "ilu0_gmres": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=1500, newton_use_gmres=1), wells=False, single=False),
-    "cpr_f32_default_tolerance": dict(params=dict(use_cpr=1), wells=False, single=True),
+    "cpr_f32_default_tolerance": dict(params=dict(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1), wells=False, single=True),
 
     # a 30-day report step through the adaptive sub-stepping loop, first sub-step too long for 3 Newton iterations: chopped and redone
-    "cpr_adaptive_substeps": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=500, use_cpr=1), wells=False, single=False,
+    "cpr_adaptive_substeps": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=500, cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1), wells=False, single=False,
                                   ats=dict(first_days=30.0, report_days=30.0, max_iter=3)),
 }
 
@@ -90,7 +90,7 @@ CASES = {
 # stops on the PRECONDITIONED residual, and at 1e-2 that leaves several per cent of error in the pressure LEVEL of this deck (measured: 5 % after
 # four Newton iterations, single domain against 2 ranks) -- a comparison across decompositions says nothing at that tolerance.  It is run
 # decomposed with and without the Pythagorean norm instead (test_collective_operations_per_newton_iteration).
-GMRES_DEFAULT_TOLERANCE = dict(params=dict(use_cpr=1, newton_use_gmres=1), wells=True, single=False)
+GMRES_DEFAULT_TOLERANCE = dict(params=dict(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1, newton_use_gmres=1), wells=True, single=False)
 
 
 @pytest.mark.parametrize("case", sorted(CASES))

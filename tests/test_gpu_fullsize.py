@@ -164,7 +164,7 @@ def test_spe10_like_heterogeneity(gpu_lib, oracle):
     for cpr in (0, 1):
         # four orders of magnitude of contrast: the error of a solve is cond(A) x its residual reduction, and which side of the 1e-6
         # state tolerance a 1e-11 reduction lands on depends on the Krylov path (measured 0.9e-6 .. 1.1e-6) -- hence 1e-12
-        prm = capi.default_params(linear_solver_reduction=1e-12, linear_solver_maxiter=1500, use_cpr=cpr)
+        prm = capi.default_params(linear_solver_reduction=1e-12, linear_solver_maxiter=1500, cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=cpr)
         _newton_parity(gpu_lib, oracle, grid, tab, st, 2 * decks.DAY, prm)
 
 
@@ -179,7 +179,7 @@ def test_norne_like_unstructured(gpu_lib, oracle):
     rowptr, _ = oracle.pattern(grid)
     assert np.diff(rowptr).min() >= 1 and np.diff(rowptr).max() >= 8
     for cpr in (0, 1):
-        prm = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=1500, use_cpr=cpr)
+        prm = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=1500, cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=cpr)
         _newton_parity(gpu_lib, oracle, grid, tab, st, 3 * decks.DAY, prm)
 
 
@@ -208,7 +208,7 @@ def _lockstep_parity(gpu_lib, oracle, grid, tab, st, dt, wl, niter=2, cpr=1, red
     from opmgpu import wells as W
     from util import OracleBackend, rel_err
     oracle.set_threads(16)
-    prm_g = capi.default_params(linear_solver_reduction=reduction, linear_solver_maxiter=maxiter, use_cpr=cpr, newton_use_gmres=gmres, gmres_verify_residual=verify)
+    prm_g = capi.default_params(linear_solver_reduction=reduction, linear_solver_maxiter=maxiter, cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=cpr, newton_use_gmres=gmres, gmres_verify_residual=verify)
     prm_o = capi.default_params(linear_solver_reduction=oracle_reduction or reduction, linear_solver_maxiter=4 * maxiter)
     nc = grid.nc
     gm = GpuBlackoilModel(grid, tab, prm_g)
@@ -329,7 +329,7 @@ def _spin_up(grid, tab, st, wl, dt, nsteps=2):
     behaviour on the step after them.  Returns the state and well state at the end."""
     from opmgpu import wells as W
     from opmgpu.model import NonlinearSolver
-    gm = GpuBlackoilModel(grid, tab, capi.default_params(use_cpr=1))
+    gm = GpuBlackoilModel(grid, tab, capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1))
     md = gm if wl is None else W.DeviceWellModel(gm, wl, W.WellState(wl, st.p))
     ns = NonlinearSolver()
     cur = st
@@ -385,7 +385,7 @@ def _check_newton_count(gpu_lib, oracle, grid, tab, st, dt, wl, solvers=(0, 1), 
         # device GMRES against the oracle's GMRES: both stop on their preconditioned residual like dune's.  Where the oracle's
         # ILU0-preconditioned GMRES(40) is not affordable (1 M cells), the device checks the TRUE residual (gmres_verify_residual),
         # which is the statement the oracle's BiCGStab makes -- the same 1e-4 state tolerance in both cases.
-        gm = GpuBlackoilModel(grid, tab, capi.default_params(use_cpr=cpr, newton_use_gmres=gmres, gmres_verify_residual=int(gmres == 1 and not oracle_gmres), **lin_of(gmres)))
+        gm = GpuBlackoilModel(grid, tab, capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=cpr, newton_use_gmres=gmres, gmres_verify_residual=int(gmres == 1 and not oracle_gmres), **lin_of(gmres)))
         if wl is None:
             md = gm
         else:

@@ -37,7 +37,7 @@ def _run(policy, prm, steps=2):
 
 
 def test_lagged_coarse_operators_reach_the_same_state(gpu_lib):
-    prm = capi.default_params(use_cpr=1)
+    prm = capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1)
     fresh, lin0, n0 = _run(0, prm)
     lagged, lin1, n1 = _run(1, prm)
     # both paths stop at the Newton tolerances (CNV 1e-2, MB 1e-5) with linear solves of 1e-2: states agree to that level
@@ -51,7 +51,7 @@ def test_lagged_coarse_operators_reach_the_same_state(gpu_lib):
 def test_failed_lagged_solve_is_retried_then_reported(gpu_lib):
     # one BiCGStab iteration cannot reach 1e-3: every solve fails; from the third matrix of the step on the failing solve is a
     # lagged one and goes through the retry on fresh operators -- the error contract (ISTLSolver.hpp:358-368) must hold on that path
-    prm = capi.default_params(use_cpr=1, linear_solver_maxiter=1, linear_solver_reduction=1e-3, ignore_convergence_failure=1)
+    prm = capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1, linear_solver_maxiter=1, linear_solver_reduction=1e-3, ignore_convergence_failure=1)
     grid = decks.cartesian_grid(16, 12, 8, lognormal_sigma=0.8, seed=6)
     tab = decks.satfunc_standard_tables()
     st = decks.initial_state(grid, tab, perturb=0.004, seed=6)
@@ -60,7 +60,7 @@ def test_failed_lagged_solve_is_retried_then_reported(gpu_lib):
     for it in range(4):                        # ignore_convergence_failure: the truncated solves are accepted
         m.nonlinearIteration(it, single_precision=True)
     m.close()
-    prm = capi.default_params(use_cpr=1, linear_solver_maxiter=1, linear_solver_reduction=1e-3)
+    prm = capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1, linear_solver_maxiter=1, linear_solver_reduction=1e-3)
     m = GpuBlackoilModel(grid, tab, prm)
     m.prepareStep(4 * decks.DAY, st)
     with pytest.raises(LinearSolverProblem):
@@ -104,7 +104,7 @@ def test_correction_factor_policy_is_preconditioner_only(gpu_lib):
     """LinSolver::CorrectionPolicy (DESIGN 4b / 11): choosing the scaling of the coarse-grid corrections per time step changes the iteration
     counts, never the answer -- at a tight reduction the time steps end in the same state with the policy on (second setting 2.3, and an
     absurd 6.0 that the policy must walk away from, a failed solve being repeated under 1.9) as with the fixed 1.9."""
-    prm = capi.default_params(use_cpr=1, newton_use_gmres=1, linear_solver_reduction=1e-9, linear_solver_maxiter=400)
+    prm = capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1, newton_use_gmres=1, linear_solver_reduction=1e-9, linear_solver_maxiter=400)
     ref, lin0, n0 = _run_correction_policy(0, 2.3, prm)
     for arm in (2.3, 6.0):
         out, lin, n = _run_correction_policy(1, arm, prm)

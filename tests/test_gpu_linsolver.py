@@ -164,14 +164,14 @@ def test_cpr_amg_solve(gpu_lib, oracle, single):
     xe = spla.spsolve(A.tocsc(), b)
     its = {}
     for cpr in (0, 1):
-        s = GpuNewtonIteration(capi.default_params(use_cpr=cpr))
+        s = GpuNewtonIteration(capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=cpr))
         xs = s.computeNewtonIncrement(rowptr, col, val, b, single)
         its[cpr] = s.iterations()
         assert np.linalg.norm(A @ xs - b) <= 1.5e-2 * np.linalg.norm(b) and s.reduction < 1e-2
         s.close()
     assert its[1] * 3 <= its[0], its                      # CPR: at least 3x fewer iterations here
     red = 1e-5 if single else 1e-10
-    s = GpuNewtonIteration(capi.default_params(use_cpr=1, linear_solver_reduction=red, linear_solver_maxiter=200))
+    s = GpuNewtonIteration(capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1, linear_solver_reduction=red, linear_solver_maxiter=200))
     xs = s.computeNewtonIncrement(rowptr, col, val, b, single)
     if single:
         assert np.linalg.norm(A @ xs - b) <= 30 * red * np.linalg.norm(b)
@@ -184,7 +184,7 @@ def test_cpr_amg_solve(gpu_lib, oracle, single):
     # opt-in smoother of level 0: Gauss-Seidel by colour (OPMGPU_AMG_GS=1, read when the hierarchy is built): same contract
     os.environ["OPMGPU_AMG_GS"] = "1"; os.environ["OPMGPU_AMG_NPOST0"] = "1"
     try:
-        s = GpuNewtonIteration(capi.default_params(use_cpr=1, linear_solver_reduction=red, linear_solver_maxiter=200))
+        s = GpuNewtonIteration(capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1, linear_solver_reduction=red, linear_solver_maxiter=200))
         xg = s.computeNewtonIncrement(rowptr, col, val, b, single)
         assert s.iterations() <= its[0]
         if single:
@@ -232,7 +232,7 @@ def test_cpr_pressure_equation_weights(gpu_lib, oracle):
     expect[1, none] = 1.0
     assert none.any() and (expect[2] == 0).any() and ((expect[1] == 0) & (expect[0] == 1)).any()
     b = rng.standard_normal(3 * nb)
-    s = GpuNewtonIteration(capi.default_params(use_cpr=1, linear_solver_maxiter=400))
+    s = GpuNewtonIteration(capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1, linear_solver_maxiter=400))
     try:
         s.computeNewtonIncrement(rowptr, col, val, b, False)
     except LinearSolverProblem:
@@ -276,7 +276,7 @@ def test_gmres_option(gpu_lib, oracle, single):
         s.close()
     # CPR as the preconditioner of GMRES (NewtonIterationBlackoilCPR.hpp:116-119)
     red_c = 1e-5 if single else 1e-10
-    prm_c = capi.default_params(newton_use_gmres=1, use_cpr=1, linear_solver_reduction=red_c, linear_solver_maxiter=200)
+    prm_c = capi.default_params(newton_use_gmres=1, cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1, linear_solver_reduction=red_c, linear_solver_maxiter=200)
     s = GpuNewtonIteration(prm_c)
     xg = s.computeNewtonIncrement(rowptr, col, val, b, single)
     assert np.linalg.norm(xg - xe) <= (3e-3 if single else 1e-6) * np.linalg.norm(xe) and s.iterations() < 40
@@ -305,7 +305,7 @@ def test_flexible_gmres_stops_on_the_true_residual(gpu_lib, oracle, single):
     A = bsr_to_scipy(rowptr, col, val)
     red = 1e-4 if single else 1e-6
     slack = 20.0 if single else 1.0 + 1e-6           # float: the recurrence residual and the true one drift apart by rounding
-    for kw in (dict(ilu_ordering=capi.ORDER_NATURAL), dict(ilu_ordering=capi.ORDER_NATURAL, linear_solver_restart=12), dict(use_cpr=1)):
+    for kw in (dict(ilu_ordering=capi.ORDER_NATURAL), dict(ilu_ordering=capi.ORDER_NATURAL, linear_solver_restart=12), dict(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1)):
         s = GpuNewtonIteration(capi.default_params(newton_use_gmres=2, linear_solver_reduction=red, linear_solver_maxiter=400, **kw))
         try:
             x = s.computeNewtonIncrement(rowptr, col, val, b, single)
@@ -341,7 +341,7 @@ def test_gmres_true_residual_check(gpu_lib, oracle, single):
     red = 1e-3 if single else 1e-5
     slack = 3.0 if single else 1.0 + 1e-6            # float: x is rounded to 24 bits after the check measured it in the solve's precision
     true_res = {}
-    for kw in (dict(ilu_ordering=capi.ORDER_NATURAL), dict(use_cpr=1), dict(use_cpr=1, linear_solver_restart=5)):
+    for kw in (dict(ilu_ordering=capi.ORDER_NATURAL), dict(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1), dict(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1, linear_solver_restart=5)):
         for verify in (0, 1):
             s = GpuNewtonIteration(capi.default_params(newton_use_gmres=1, gmres_verify_residual=verify, linear_solver_reduction=red, linear_solver_maxiter=1500, **kw))
             try:
@@ -384,7 +384,7 @@ def test_reference_cpr_formulation_gives_the_same_solution(gpu_lib, oracle, gmre
     red = 1e-4 if single else 1e-11
     sol, its = {}, {}
     for tr in (0, 1):
-        s = GpuNewtonIteration(capi.default_params(use_cpr=1, newton_use_gmres=gmres, cpr_reference_transform=tr, linear_solver_reduction=red, linear_solver_maxiter=300))
+        s = GpuNewtonIteration(capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1, newton_use_gmres=gmres, cpr_reference_transform=tr, linear_solver_reduction=red, linear_solver_maxiter=300))
         sol[tr] = s.computeNewtonIncrement(rowptr, col, val, b, single)
         its[tr] = s.iterations()
         assert s.reduction < red and 1 <= its[tr] < 300, (tr, its)
@@ -411,7 +411,7 @@ def test_global_coarse_space_restores_convergence_of_decomposed_preconditioner(g
     def run(env):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        m = GpuBlackoilModel(grid, tab, capi.default_params(use_cpr=1, linear_solver_reduction=1e-6, linear_solver_maxiter=200))
+        m = GpuBlackoilModel(grid, tab, capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1, linear_solver_reduction=1e-6, linear_solver_maxiter=200))
         m.prepareStep(5 * decks.DAY, st)
         its = 0
         for it in range(3):
@@ -447,7 +447,7 @@ def test_default_precision_follows_the_reference_plugins(gpu_lib):
     t = decks.satfunc_standard_tables()
     st = decks.initial_state(g, t)
     for use_cpr, dt_days, want in ((0, 1.0, True), (0, 19.9, True), (0, 20.0, False), (1, 1.0, False), (1, 30.0, False)):
-        m = GpuBlackoilModel(g, t, capi.default_params(use_cpr=use_cpr))
+        m = GpuBlackoilModel(g, t, capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=use_cpr))
         m.prepareStep(dt_days * decks.DAY, st)
         assert m.referencePrecision() is want, (use_cpr, dt_days)
         m.close()

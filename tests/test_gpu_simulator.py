@@ -17,7 +17,7 @@ DECK = os.path.join(os.path.dirname(__file__), "golden", "decks", "SCHEDULE_SMAL
 
 def test_deck_with_schedule_runs_and_writes_eclipse_files(gpu_lib, oracle, tmp_path):
     base = str(tmp_path / "SCHED")
-    prm = capi.default_params(use_cpr=1, tolerance_mb=1e-9, tolerance_cnv=1e-5, tolerance_wells=1e-8, linear_solver_reduction=1e-6, linear_solver_maxiter=200)
+    prm = capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1, tolerance_mb=1e-9, tolerance_cnv=1e-5, tolerance_wells=1e-8, linear_solver_reduction=1e-6, linear_solver_maxiter=200)
     sim = Simulator(DECK, params=prm, output_base=base)
     names = oracle.PROP_NAMES
 
@@ -68,7 +68,7 @@ def test_equilibrated_deck_is_stationary_on_the_device(gpu_lib, tmp_path):
     d = deckmod.read_deck(path)
     tables, grid = d.tables(), d.grid()
     st = d.initial_state(tables)
-    prm = capi.default_params(use_cpr=0, tolerance_mb=1e-10, tolerance_cnv=1e-6, linear_solver_reduction=1e-8, linear_solver_maxiter=200)
+    prm = capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=0, tolerance_mb=1e-10, tolerance_cnv=1e-6, linear_solver_reduction=1e-8, linear_solver_maxiter=200)
     gm = GpuBlackoilModel(grid, tables, prm)
     gm.prepareStep(1.0 * decks.DAY, st)
     for it in range(12):
@@ -80,7 +80,7 @@ def test_equilibrated_deck_is_stationary_on_the_device(gpu_lib, tmp_path):
     assert np.abs(s1.p - st.p).max() < 0.05 * decks.BAR
     assert np.abs(s1.sat - st.sat).max() < 2e-3
     gm.close()
-    sim = Simulator(path, params=capi.default_params(use_cpr=1))
+    sim = Simulator(path, params=capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1))
     reps = sim.run(max_steps=1)
     assert reps[0]["days"] == 10.0 and reps[0]["failed"] == 0
     sim.close()
@@ -95,7 +95,7 @@ def test_device_run_against_oracle_run_with_the_regression_tolerances(gpu_lib, o
     from util import OracleBackend
     tight = dict(linear_solver_reduction=1e-9, linear_solver_maxiter=600, tolerance_wells=1e-7)
     base_d, base_o = str(tmp_path / "DEV"), str(tmp_path / "ORC")
-    sim = Simulator(DECK, params=capi.default_params(use_cpr=1, **tight), output_base=base_d)
+    sim = Simulator(DECK, params=capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1, **tight), output_base=base_d)
     sim.model.max_single_precision_days = 0.0            # double solves on the device too
     rd = sim.run()
     sim.close()
@@ -128,7 +128,7 @@ def test_device_run_against_oracle_run_with_the_regression_tolerances(gpu_lib, o
 def test_restarted_device_run_reproduces_the_full_run(gpu_lib, tmp_path):
     """tests/run-restart-regressionTest.sh on the device path: restart from report step 2 of the full run's UNRST (state, well state by
     name, the time stepper's suggestion), same criterion and tolerances (abs 2e-1, rel 4e-5, compareECLFiles.cmake:121-135)."""
-    prm = capi.default_params(use_cpr=1, linear_solver_reduction=1e-6, linear_solver_maxiter=200)
+    prm = capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1, linear_solver_reduction=1e-6, linear_solver_maxiter=200)
     full, part = str(tmp_path / "FULL"), str(tmp_path / "RESTARTED")
     s1 = Simulator(DECK, params=prm, output_base=full)
     r1 = s1.run()
@@ -154,7 +154,7 @@ def test_faulted_corner_point_deck_device_vs_oracle(gpu_lib, oracle, tmp_path):
     path = str(tmp_path / "FAULT.DATA")
     tight = dict(linear_solver_reduction=1e-9, linear_solver_maxiter=600, tolerance_wells=1e-7)
     base_d, base_o = str(tmp_path / "DEV"), str(tmp_path / "ORC")
-    sim = Simulator(path, params=capi.default_params(use_cpr=1, **tight), output_base=base_d)
+    sim = Simulator(path, params=capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1, **tight), output_base=base_d)
     assert sim.grid.nconn == 6 * 5 * 3 * 3 - (5 * 3 + 6 * 3 + 6 * 5) + 5 * 2          # the block grid's faces + the fault's extra overlaps
     sim.model.max_single_precision_days = 0.0
     rd = sim.run()

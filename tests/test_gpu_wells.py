@@ -47,7 +47,7 @@ def test_device_wells_match_host_wells_on_the_oracle(gpu_lib, oracle, cpr):
     """Wells ON THE DEVICE (csrc/wells.hip: factored Schur complement, rank-7 operator per well inside the SpMV) vs the CPU
     oracle driven by the host well model with the explicit Schur complement: same Newton path, same well state."""
     grid, tab, st, wl = _setup()
-    prm = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=500, use_cpr=cpr)
+    prm = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=500, cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=cpr)
     prm_o = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=500)
     dt = 2 * decks.DAY
     gm = GpuBlackoilModel(grid, tab, prm)
@@ -129,7 +129,7 @@ def test_waterflood_material_balance_through_adaptive_stepping(gpu_lib, oracle):
     from opmgpu.model import NonlinearSolver
     grid, tab, st, wl = _setup()
     # tight tolerances: the default ones (MB 1e-5 of the pore volume, wells 1e-4 m3/s) allow hundreds of m3 of imbalance per step
-    prm = capi.default_params(use_cpr=1, tolerance_mb=1e-10, tolerance_cnv=1e-6, linear_solver_reduction=1e-8, linear_solver_maxiter=300)
+    prm = capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1, tolerance_mb=1e-10, tolerance_cnv=1e-6, linear_solver_reduction=1e-8, linear_solver_maxiter=300)
     gm = GpuBlackoilModel(grid, tab, prm)
     model = W.DeviceWellModel(gm, wl, W.WellState(wl, st.p), tolerance_wells=1e-9, tolerance_well_control=1e-9)
     gm.setState(st)
@@ -175,7 +175,7 @@ def test_device_well_controls_match_host(gpu_lib, oracle, case, cpr):
     kw = {"bhp_limit_midstep": dict(inj_bhp_limit_bar=262.0), "presolve_switch": dict(inj_bhp_limit_bar=255.0),
           "prod_rate_limit": dict(inj_bhp_limit_bar=600.0, prod_rate_limit=150.0), "thp": dict(inj_bhp_limit_bar=600.0, thp=True)}[case]
     grid, tab, st, wl, tables = _limits_setup(**kw)
-    prm = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=500, use_cpr=cpr)
+    prm = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=500, cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=cpr)
     prm_o = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=500)
     dt = 5 * decks.DAY
     gm = GpuBlackoilModel(grid, tab, prm)
@@ -253,7 +253,7 @@ def test_reference_cpr_formulation_with_device_wells(gpu_lib, gmres):
     grid, tab, st, wl = _setup()
     out = {}
     for tr in (0, 1):
-        gm = GpuBlackoilModel(grid, tab, capi.default_params(use_cpr=1, newton_use_gmres=gmres, cpr_reference_transform=tr, linear_solver_reduction=1e-11, linear_solver_maxiter=400))
+        gm = GpuBlackoilModel(grid, tab, capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1, newton_use_gmres=gmres, cpr_reference_transform=tr, linear_solver_reduction=1e-11, linear_solver_maxiter=400))
         md = W.DeviceWellModel(gm, wl, W.WellState(wl, st.p))
         md.prepareStep(2 * decks.DAY, st)
         hist = []
@@ -268,6 +268,74 @@ def test_reference_cpr_formulation_with_device_wells(gpu_lib, gmres):
     assert np.array_equal(a[0].hc, b[0].hc)
     assert np.abs(a[0].p - b[0].p).max() <= 1e-6 * np.abs(a[0].p).max() and np.abs(a[0].sat - b[0].sat).max() <= 1e-6
     assert np.allclose(a[1], b[1], rtol=1e-7) and np.allclose(a[2], b[2], rtol=1e-6, atol=1e-9 * np.abs(a[2]).max())
+
+
+CPR_VARIANTS = {
+    # the reference CPR plug-in's documented defaults (NewtonIterationBlackoilCPR.hpp:59-63): no AMG -- the elliptic part by an ILU0-preconditioned
+    # inner BiCGStab --, relax 1.0
+    "reference_defaults": dict(use_cpr=1),
+    "ilu0_inner_cg": dict(use_cpr=1, cpr_use_bicgstab=0),
+    "amg_inner_bicgstab": dict(use_cpr=1, cpr_use_amg=1),
+    "amg_inner_cg": dict(use_cpr=1, cpr_use_amg=1, cpr_use_bicgstab=0),
+    "amg_vcycle_relax_0.9": dict(use_cpr=1, cpr_use_amg=1, cpr_max_ell_iter=0, cpr_relax=0.9),
+    "reference_defaults_relax_0.9_tight_inner": dict(use_cpr=1, cpr_relax=0.9, cpr_solver_tol=1e-4, cpr_max_ell_iter=60),
+}
+
+
+@pytest.mark.parametrize("gmres", [0, 1])
+def test_cpr_parameters_of_the_reference_give_the_same_newton_path(gpu_lib, gmres):
+    """cpr_relax / cpr_ilu_n / cpr_use_amg / cpr_use_bicgstab of NewtonIterationBlackoilCPR.hpp:59-63 (+ the inner solve's
+    cpr_solver_tol / cpr_max_ell_iter).  Every pressure stage is a PRECONDITIONER: with a tight outer tolerance the Newton path with device
+    wells (bordered pressure system) must be the one of the AMG V-cycle stage, whatever solves the elliptic part."""
+    import ctypes as C
+    grid, tab, st, wl = _setup()
+    out = {}
+    for name, kw in dict(base=dict(capi.CPR_AMG_VCYCLE), **CPR_VARIANTS).items():
+        gm = GpuBlackoilModel(grid, tab, capi.default_params(newton_use_gmres=gmres, linear_solver_reduction=1e-11, linear_solver_maxiter=400, **kw))
+        md = W.DeviceWellModel(gm, wl, W.WellState(wl, st.p))
+        md.prepareStep(2 * decks.DAY, st)
+        hist = []
+        for it in range(3):
+            conv, lin = md.nonlinearIteration(it, single_precision=False)
+            hist.append((conv, lin))
+        ws = md.pull_well_state()
+        solves, its = C.c_int64(0), C.c_int64(0)
+        gm._chk(gm.lib.opmgpu_cpr_elliptic_stats(gm.ctx, C.byref(solves), C.byref(its)))
+        out[name] = (gm.getState(), ws.bhp.copy(), ws.qs.copy(), hist, solves.value, its.value)
+        gm.close()
+    a = out["base"]
+    assert a[4] == 0 and a[5] == 0                                   # one V-cycle per application: no inner method
+    for name in CPR_VARIANTS:
+        b = out[name]
+        assert [h[0] for h in a[3]] == [h[0] for h in b[3]], name
+        assert np.array_equal(a[0].hc, b[0].hc), name
+        assert np.abs(a[0].p - b[0].p).max() <= 1e-6 * np.abs(a[0].p).max() and np.abs(a[0].sat - b[0].sat).max() <= 1e-6, name
+        assert np.allclose(a[1], b[1], rtol=1e-7) and np.allclose(a[2], b[2], rtol=1e-6, atol=1e-9 * np.abs(a[2]).max()), name
+        if "vcycle" in name:
+            assert b[4] == 0
+        else:
+            # one inner solve per preconditioner application, each within its iteration limit
+            limit = CPR_VARIANTS[name].get("cpr_max_ell_iter", 25)
+            assert b[4] >= sum(h[1] for h in b[3]) and 1 <= b[5] <= limit * b[4], (name, b[4], b[5])
+    # a better elliptic solve makes the outer method need fewer iterations: the inner-Krylov stages never need more than the single cycle
+    # plus a small margin, and the reference-default stage (ILU0) needs more inner iterations than the AMG one
+    lin = {k: sum(h[1] for h in v[3]) for k, v in out.items()}
+    assert lin["amg_inner_bicgstab"] <= lin["base"] + 2, lin
+    assert out["reference_defaults"][5] / out["reference_defaults"][4] > out["amg_inner_bicgstab"][5] / out["amg_inner_bicgstab"][4], (out["reference_defaults"][4:], out["amg_inner_bicgstab"][4:])
+
+
+def test_cpr_parameter_combinations_that_are_not_built_are_refused(gpu_lib):
+    """cpr_ilu_n > 0 (ILU(n) with fill-in) and the one-application stage without the AMG are errors at the first solve, not silent fallbacks"""
+    from opmgpu.model import LinearSolverProblem  # noqa: F401
+    grid, tab, st, _ = _setup()
+    for kw, text in ((dict(use_cpr=1, cpr_ilu_n=1), "cpr_ilu_n"), (dict(use_cpr=1, cpr_use_amg=0, cpr_max_ell_iter=0), "cpr_max_ell_iter"), (dict(use_cpr=1, cpr_relax=0.0), "cpr_relax")):
+        gm = GpuBlackoilModel(grid, tab, capi.default_params(**kw))
+        gm.prepareStep(2 * decks.DAY, st)
+        gm.assemble(True); gm.getConvergence()
+        with pytest.raises(Exception) as e:
+            gm.solveJacobianSystem(single_precision=False)
+        assert text in str(e.value), (kw, str(e.value))
+        gm.close()
 
 
 def test_stabilized_update_relaxes_the_well_increment_too(gpu_lib, oracle):
@@ -308,7 +376,7 @@ def test_one_call_newton_iteration_equals_the_call_by_call_sequence(gpu_lib, wit
     bit-identical reservoir and well states over a time step that needs relaxing."""
     from opmgpu.model import NonlinearSolver
     grid, tab, st, wl = _setup()
-    prm = capi.default_params(use_cpr=1)
+    prm = capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1)
     out = []
     for fused in (False, True):
         gm = GpuBlackoilModel(grid, tab, prm)
@@ -348,7 +416,7 @@ def test_cpr_weights_with_device_wells_follow_the_final_matrix(gpu_lib, single):
     rows of its perforated cells after adding its diagonal terms (k_cpr_weights_rows).  What the solver then uses must be
     formEllipticSystem's rule (NewtonIterationUtilities.cpp:212-252, as in test_cpr_pressure_equation_weights) applied to the FINAL matrix."""
     grid, tab, st, wl = _setup()
-    gm = GpuBlackoilModel(grid, tab, capi.default_params(use_cpr=1))
+    gm = GpuBlackoilModel(grid, tab, capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1))
     md = W.DeviceWellModel(gm, wl, W.WellState(wl, st.p))
     md.prepareStep(150 * decks.DAY, st)          # long enough to need several Newton iterations
     checked = 0
@@ -386,7 +454,7 @@ def test_update_equations_scaling_with_device_wells_and_cpr(gpu_lib):
     grid, tab, st, wl = _setup()
     out = {}
     for ues in (0, 1):
-        gm = GpuBlackoilModel(grid, tab, capi.default_params(use_cpr=1, update_equations_scaling=ues, linear_solver_reduction=1e-11, linear_solver_maxiter=400))
+        gm = GpuBlackoilModel(grid, tab, capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1, update_equations_scaling=ues, linear_solver_reduction=1e-11, linear_solver_maxiter=400))
         md = W.DeviceWellModel(gm, wl, W.WellState(wl, st.p))
         md.prepareStep(2 * decks.DAY, st)
         hist, scales = [], []

@@ -119,7 +119,7 @@ def test_device_wells_against_the_independent_well_model(gpu_lib, oracle, case, 
     from opmgpu.model import GpuBlackoilModel
     from oracle.wells import CoupledOracleModel
     grid, tab, st, make, start = _deck(case)
-    prm = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=500, use_cpr=cpr)
+    prm = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=500, cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=cpr)
     dt = 5 * decks.DAY
     wl_d, wl_i = make(), make()
     gm = GpuBlackoilModel(grid, tab, prm)
@@ -224,7 +224,7 @@ def test_random_wells_device_vs_independent(gpu_lib, oracle, seed):
     from opmgpu.model import GpuBlackoilModel
     from oracle.wells import CoupledOracleModel
     grid, tab, st, make, start, dt = _random_case(seed)
-    prm = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=800, use_cpr=seed % 2)
+    prm = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=800, cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=seed % 2)
     wl_d, wl_i = make(), make()
     gm = GpuBlackoilModel(grid, tab, prm)
     md = W.DeviceWellModel(gm, wl_d, start(wl_d))

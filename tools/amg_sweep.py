@@ -20,7 +20,7 @@ def child(n, steps, warmup, sigma=0.5):
     tab = decks.satfunc_standard_tables()
     st = decks.initial_state(grid, tab, perturb=0.002, seed=12345)
     dt = 5 * decks.DAY
-    m = GpuBlackoilModel(grid, tab, capi.default_params(use_cpr=1))
+    m = GpuBlackoilModel(grid, tab, capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1))
     m.prepareStep(dt, st)
     it, lin_total, t_sol, t_asm, t0, nsteps = 0, 0, 0.0, 0.0, None, 0
     for step in range(warmup + steps):

@@ -18,7 +18,7 @@ WI = 5.0 * float(np.median(gridA.trans))
 inj = [7 + L * k for k in range(0, 3)]; prod = [22 + L * k for k in range(2, 5)]
 wl.add_well("INJ", W.INJECTOR, gridA.z[inj[0]], inj, WI, (1.0, 0.0, 0.0), (W.SURFACE_RATE, 20.0 / 86400.0, (1.0, 0.0, 0.0)))
 wl.add_well("PROD", W.PRODUCER, gridA.z[prod[0]], prod, WI, (0.0, 1.0, 0.0), (W.BHP, 150 * decks.BAR))
-prm = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=500, use_cpr=cpr)
+prm = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=500, cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=cpr)
 A = GpuBlackoilModel(gridA, tab, prm); B = GpuBlackoilModel(gridB, tab, prm)
 dom = _Dom()
 for k, v in halo.items():

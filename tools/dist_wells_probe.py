@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join
 import numpy as np
 import test_gpu_dist_shm as T
 cfg = dict(nx=40, ny=40, nz=48, sigma=0.5, seed=21, perturb=0.002, dt_days=5.0, newton=6, rate=2000.0 / 86400.0,
-           params=dict(use_cpr=1), wells=True, single=True)
+           params=dict(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1), wells=True, single=True)
 for world in (1, 2, 4):
     for coarse, blocks in ((0, 1), (1, 1), (1, 4)):
         if world == 1 and (coarse, blocks) != (1, 1):

@@ -30,7 +30,7 @@ for case in range(ncases):
     if rng.random() < 0.3: grid = decks.with_endpoints(grid, decks.random_endpoints(grid, seed=int(seed0 + case)))
     st = decks.initial_state(grid, tab, perturb=float(rng.uniform(0.001, 0.01)), seed=int(seed0 + case))
     ordering = int(rng.integers(0, 2))
-    prm = capi.default_params(ilu_ordering=ordering, linear_solver_reduction=1e-12, linear_solver_maxiter=1000, use_cpr=int(rng.integers(0, 2)))   # the oracle side is always ILU0
+    prm = capi.default_params(ilu_ordering=ordering, linear_solver_reduction=1e-12, linear_solver_maxiter=1000, cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=int(rng.integers(0, 2)))   # the oracle side is always ILU0
     scale = np.asarray(prm.matbalscale[:])
     dt = float(rng.uniform(0.5, 10.0)) * decks.DAY
     nc = grid.nc

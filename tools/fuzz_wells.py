@@ -46,7 +46,7 @@ for case in range(ncases):
                    (W.RESERVOIR_RATE, -float(rng.uniform(0.2, 1.0)) * pv_rate, (1.0, 1.0, 1.0)) if resv else (W.SURFACE_RATE, -float(rng.uniform(0.2, 1.0)) * pv_rate, (0.0, 1.0, 0.0))
             wl.add_well("P%d" % w, W.PRODUCER, grid.z[cells[0]], cells, WI, (0.0, 1.0, 0.0), ctrl, allow_cf=bool(rng.random() < 0.7))
     cpr = int(rng.integers(0, 2))
-    prm = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=800, use_cpr=cpr)
+    prm = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=800, cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=cpr)
     prm_o = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=800)
     dt = float(rng.uniform(0.5, 5.0)) * decks.DAY
     gm = GpuBlackoilModel(grid, tab, prm)

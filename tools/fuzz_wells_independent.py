@@ -18,7 +18,7 @@ worst = {"p": 0.0, "sat": 0.0, "bhp": 0.0, "qs": 0.0}
 done = skipped = switches = knife = 0
 for case in range(ncases):
     grid, tab, st, make, start, dt = _random_case(seed0 + case)
-    prm = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=800, use_cpr=(seed0 + case) % 2)
+    prm = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=800, cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=(seed0 + case) % 2)
     wl_d, wl_i = make(), make()
     gm = GpuBlackoilModel(grid, tab, prm)
     try:

@@ -10,7 +10,7 @@ grid = decks.cartesian_grid(n, n, n, lognormal_sigma=0.5, seed=12345)
 tab = decks.satfunc_standard_tables()
 st = decks.initial_state(grid, tab, perturb=0.002, seed=12345)
 for gm in (0, 1):
-    prm = capi.default_params(use_cpr=1, newton_use_gmres=gm)
+    prm = capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1, newton_use_gmres=gm)
     m = GpuBlackoilModel(grid, tab, prm)
     m.setState(st)
     tot_it, tot_lin, t_acc, steps = 0, 0, 0.0, 0

@@ -8,7 +8,7 @@ red = float(sys.argv[1]); out = sys.argv[2]
 grid = decks.cartesian_grid(30, 30, 20, lognormal_sigma=1.5, seed=3)
 tab = decks.satfunc_standard_tables()
 st = decks.initial_state(grid, tab, perturb=0.01, seed=3)
-prm = capi.default_params(linear_solver_reduction=red, linear_solver_maxiter=500, use_cpr=1, ignore_convergence_failure=1)
+prm = capi.default_params(linear_solver_reduction=red, linear_solver_maxiter=500, cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1, ignore_convergence_failure=1)
 m = GpuBlackoilModel(grid, tab, prm)
 m.prepareStep(10 * decks.DAY, st)
 res = []

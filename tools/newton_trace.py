@@ -77,7 +77,7 @@ def main():
         print("%s: %d Newton iterations" % (label, it), flush=True)
 
     if args.side in ("gpu", "both"):
-        gm = GpuBlackoilModel(grid, tab, capi.default_params(use_cpr=args.cpr, linear_solver_reduction=args.reduction, linear_solver_maxiter=args.maxiter))
+        gm = GpuBlackoilModel(grid, tab, capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=args.cpr, linear_solver_reduction=args.reduction, linear_solver_maxiter=args.maxiter))
         md = gm if wl is None else W.DeviceWellModel(gm, wl, W.WellState(wl, st.p))
         run(md, gm, "gpu")
         gm.close()

@@ -11,7 +11,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 grid = decks.cartesian_grid(n, n, n, lognormal_sigma=0.5, seed=12345)
 tab = decks.satfunc_standard_tables()
 st = decks.initial_state(grid, tab, perturb=0.002, seed=12345)
-m = GpuBlackoilModel(grid, tab, capi.default_params(use_cpr=1, newton_use_gmres=1))
+m = GpuBlackoilModel(grid, tab, capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1, newton_use_gmres=1))
 m.prepareStep(5 * decks.DAY, st)
 for it in range(4):
     try:

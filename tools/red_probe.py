@@ -10,7 +10,7 @@ for sigma in (0.5, 2.0):
     tab = decks.satfunc_standard_tables()
     st = decks.initial_state(grid, tab, perturb=0.002, seed=12345)
     for k in (1, 2, 3):
-        prm = capi.default_params(use_cpr=1, linear_solver_maxiter=k, linear_solver_reduction=1e-30, ignore_convergence_failure=1)
+        prm = capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1, linear_solver_maxiter=k, linear_solver_reduction=1e-30, ignore_convergence_failure=1)
         m = GpuBlackoilModel(grid, tab, prm)
         m.prepareStep(5 * decks.DAY, st)
         reds = []

@@ -10,7 +10,7 @@ n = 100
 grid = decks.cartesian_grid(n, n, n, lognormal_sigma=0.5, seed=12345)
 tab = decks.satfunc_standard_tables()
 st = decks.initial_state(grid, tab, perturb=0.002, seed=12345)
-prm = capi.default_params(use_cpr=1)
+prm = capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1)
 m = GpuBlackoilModel(grid, tab, prm)
 if os.environ.get("PROBE_COMM", "1") == "1":
     part = np.zeros(grid.nc, dtype=np.int64)

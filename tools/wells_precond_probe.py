@@ -31,7 +31,7 @@ def main():
     wl = W.five_spot(grid, rate_m3_per_day=args.rate * (n / 100.0) ** 2, bhp_prod_bar=150.0)
     dt = args.dt_days * decks.DAY
     for cpr in ((1,) if args.gmres else (1, 0)):
-        prm = capi.default_params(use_cpr=cpr, linear_solver_reduction=args.reduction, linear_solver_maxiter=400, newton_use_gmres=args.gmres)
+        prm = capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=cpr, linear_solver_reduction=args.reduction, linear_solver_maxiter=400, newton_use_gmres=args.gmres)
         out = {}
         for kind in ("device", "host", "none"):
             if kind == "host":
