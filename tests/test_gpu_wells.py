@@ -291,7 +291,12 @@ def test_cpr_parameters_of_the_reference_give_the_same_newton_path(gpu_lib, gmre
     grid, tab, st, wl = _setup()
     out = {}
     for name, kw in dict(base=dict(capi.CPR_AMG_VCYCLE), **CPR_VARIANTS).items():
-        gm = GpuBlackoilModel(grid, tab, capi.default_params(newton_use_gmres=gmres, linear_solver_reduction=1e-11, linear_solver_maxiter=400, **kw))
+        # (an inner Krylov method makes the preconditioner a DIFFERENT operator in every application.  BiCGStab's recurrences hold for that --
+        # x and r are updated with the same vectors --, left-preconditioned GMRES's do not: its Arnoldi relation assumes one fixed M, and the
+        # residual it tracks then drifts from the real one (measured here: it reports 1e-11 with 6e-4 left in the pressures).  The
+        # reference's CPR + newton_use_gmres has that property by construction; here the true-residual check restarts the cycle from the
+        # real defect until it is met.)
+        gm = GpuBlackoilModel(grid, tab, capi.default_params(newton_use_gmres=gmres, gmres_verify_residual=gmres, linear_solver_reduction=1e-11, linear_solver_maxiter=400, **kw))
         md = W.DeviceWellModel(gm, wl, W.WellState(wl, st.p))
         md.prepareStep(2 * decks.DAY, st)
         hist = []
