@@ -558,8 +558,9 @@ def main(argv=None):
         if not args.no_cpu_baseline and not use_dist:
             cpu_single = reference_single("ilu0", dt_main)          # the port runs the reference's DEFAULT solver in the reference's arithmetic for it
             cpu = cpu_baseline(grid, tab, st, main_wells, prm, dt_main, cpu_single, threads=args.cpu_threads)
-            # the same port with its OpenMP-able loops (assembly, SpMV, vector updates; the ILU sweeps stay sequential like the
-            # reference's) on this job's host cores -- the reference itself caps OpenMP at 4 threads (FlowMain.hpp:269-271)
+            # the same port with its OpenMP loops (assembly, SpMV, vector updates, and since round 4 the ILU0 factorisation and sweeps by
+            # levels -- bit-identical to the sequential ones; the reference's own sweeps are sequential) on this job's host cores -- the
+            # reference itself caps OpenMP at 4 threads (FlowMain.hpp:269-271)
             try:
                 ncores = len(os.sched_getaffinity(0))
             except AttributeError:

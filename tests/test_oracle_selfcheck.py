@@ -139,3 +139,42 @@ def test_update_state_invariants(oracle):
     # zero increment keeps pressures and saturations
     same = oracle.update_state(grid, tab, prm, np.zeros(3 * nc), st)
     assert np.array_equal(same.p, st.p)
+
+
+def test_threads_do_not_change_a_bit(oracle):
+    """The checker's OpenMP paths are bit-reproducible and independent of the thread count: dot products are summed in
+    fixed blocks, the ILU0 factorisation and sweeps run by levels whose rows do exactly the sequential row's operations.  One thread keeps
+    the plain sequential sum (dune's SeqScalarProduct), so 1 vs n threads may differ in the dot products' rounding -- n vs m threads and
+    repeated runs must not, and the factors must be identical for every count."""
+    grid = decks.cartesian_grid(14, 12, 9, lognormal_sigma=1.5, seed=3)
+    tab = decks.satfunc_standard_tables()
+    st = decks.initial_state(grid, tab, perturb=0.01, seed=3)
+    prm = capi.default_params(linear_solver_reduction=1e-9, linear_solver_maxiter=300)
+    rowptr, col = oracle.pattern(grid)
+    r, val, _, _ = oracle.assemble(grid, tab, 10 * decks.DAY, st, rowptr, col, scale=tuple(prm.matbalscale))
+    nc = grid.nc
+    b = _eqmajor_to_interleaved(r * np.repeat(np.asarray(prm.matbalscale[:]), nc), nc)
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(nc).astype(np.int32)            # an arbitrary elimination order: many short levels
+    out = {}
+    try:
+        for nt in (1, 2, 5, 8, 8):
+            oracle.set_threads(nt)
+            for tag, pos in (("nat", None), ("perm", perm)):
+                stf, lu = oracle.ilu0(rowptr, col, val, position=pos)
+                sts, x, it, red, hist = oracle.bicgstab(rowptr, col, val, b, prm, position=pos, nhist=600)
+                assert stf == 0 and sts == 0
+                v = oracle.ilu0_apply(rowptr, col, lu, b, position=pos)
+                out.setdefault(tag, []).append((nt, lu, x, it, hist, v))
+    finally:
+        oracle.set_threads(1)
+    for tag, runs in out.items():
+        base = runs[0]
+        for nt, lu, x, it, hist, v in runs[1:]:
+            assert np.array_equal(lu, base[1]), (tag, nt)                       # factors: identical for every thread count
+            assert np.array_equal(v, base[5]), (tag, nt)
+        multi = [r_ for r_ in runs if r_[0] > 1]
+        for nt, lu, x, it, hist, v in multi[1:]:
+            assert it == multi[0][3] and np.array_equal(x, multi[0][2]) and np.array_equal(hist, multi[0][4]), (tag, nt)
+        # one thread against many: the same solve up to the dot products' rounding
+        assert abs(base[3] - multi[0][3]) <= 1 and np.abs(base[2] - multi[0][2]).max() <= 1e-6 * np.abs(base[2]).max(), tag
