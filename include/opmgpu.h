@@ -176,6 +176,12 @@ typedef struct opmgpu_params {
     /* the elliptic part's inner Krylov solve.  Its stopping rule lives in the external CPRPreconditioner: the two values below are this
      * library's RECOLLECTION of that file (cpr_solver_tol 1e-2, cpr_max_elliptic_iter 25), unpinned by anything in the container */
     double cpr_solver_tol;          /* 1e-2: reduction of || b_p - A_p x_p || the inner solve stops at */
+    double cpr_stage2_relax;        /* 1.0.  LIBRARY EXTENSION: an extra relaxation of the second stage ALONE,
+                                           M^-1 d = cpr_relax (x_p + cpr_stage2_relax ILU0^-1 (d - A x_p)).
+                                       cpr_relax by itself multiplies the whole preconditioner by a scalar (that is what the reference's
+                                       CPRPreconditioner::apply does with it, as recalled), which no Krylov method notices; damping stage 2
+                                       against the pressure correction is a different preconditioner -- rounds 1-3 of this library ran 0.9,
+                                       which is what the Norne-like deck (isolated cells) needs to reach 1e-10: tests/test_gpu_fullsize.py */
     int32_t cpr_max_ell_iter;       /* 25: iteration limit of the inner solve (reaching it is NOT an error here: the outer method goes on with
                                        what the inner one attained).  0 = library extension, no inner Krylov method at all: ONE application
                                        of the elliptic preconditioner (with cpr_use_amg = 1: one V-cycle, its coarse-grid corrections scaled

@@ -476,27 +476,39 @@ __global__ __launch_bounds__(kBlock) void k_cell_values(int nb, int nbp, DevTabl
                                                         const double* __restrict__ p, const double* __restrict__ sw, const double* __restrict__ sg,
                                                         const double* __restrict__ rs, const double* __restrict__ rv, const int8_t* __restrict__ hc,
                                                         const double* __restrict__ eps, const double* __restrict__ eps_u0, const double* __restrict__ somax,
-                                                        double* __restrict__ vals, double* __restrict__ binv, const double* __restrict__ tab_blob, int tab_words, HystArgs hy)
+                                                        double* __restrict__ vals, double* __restrict__ bpart, const int8_t* __restrict__ mask,
+                                                        const double* __restrict__ tab_blob, int tab_words, HystArgs hy)
 {
     extern __shared__ double tab_lds[];
+    __shared__ double bsm[12];
     resolve_tables<LDS>(D, tab_blob, tab_words, tab_lds);
     const int row = blockIdx.x * kBlock + threadIdx.x;
-    if (row >= nb) return;
-    CellEval q;
-    EpsD E, EI;
-    HystD H;
-    eps_load(eps, eps_u0, nbp, row, satnum[row], E);
-    hyst_load(hy.imbnum, hy.hist, nbp, row, H);
-    if (H.on) eps_load(hy.ieps, hy.iureg, nbp, row, H.ireg, EI);
-    eval_cell(D, E, (D.t.vap1 > 0.0 || D.t.vap2 > 0.0) ? somax[row] : 0.0, pvtnum[row], satnum[row], p[row], sw[row], sg[row], rs[row], rv[row], hc[row], q, H, &EI);
-    vals[long(VP_PW) * nbp + row] = q.pw.v; vals[long(VP_PG) * nbp + row] = q.pg.v;
+    double ib[3] = { 0.0, 0.0, 0.0 };
+    if (row < nb) {
+        CellEval q;
+        EpsD E, EI;
+        HystD H;
+        eps_load(eps, eps_u0, nbp, row, satnum[row], E);
+        hyst_load(hy.imbnum, hy.hist, nbp, row, H);
+        if (H.on) eps_load(hy.ieps, hy.iureg, nbp, row, H.ireg, EI);
+        eval_cell(D, E, (D.t.vap1 > 0.0 || D.t.vap2 > 0.0) ? somax[row] : 0.0, pvtnum[row], satnum[row], p[row], sw[row], sg[row], rs[row], rv[row], hc[row], q, H, &EI);
+        vals[long(VP_PW) * nbp + row] = q.pw.v; vals[long(VP_PG) * nbp + row] = q.pg.v;
+        const bool owned = !mask || mask[row];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        vals[long(VP_RHO + a) * nbp + row] = q.rho[a].v;
-        vals[long(VP_U + a) * nbp + row] = q.b[a].v * q.mob[a].v;
-        binv[long(a) * nbp + row] = 1.0 / q.b[a].v;
+        for (int a = 0; a < 3; ++a) {
+            vals[long(VP_RHO + a) * nbp + row] = q.rho[a].v;
+            vals[long(VP_U + a) * nbp + row] = q.b[a].v * q.mob[a].v;
+            if (owned) ib[a] = 1.0 / q.b[a].v;
+        }
+        vals[long(VP_RS) * nbp + row] = q.rs.v; vals[long(VP_RV) * nbp + row] = q.rv.v;
     }
-    vals[long(VP_RS) * nbp + row] = q.rs.v; vals[long(VP_RV) * nbp + row] = q.rv.v;
+    // getConvergence needs only the SUMS of 1 / b_a over the owned cells (B_avg, BlackoilModelBase_impl.hpp:1650-1660): one partial per
+    // workgroup here instead of three planes written now and read back by k_conv_partial (48 MB of traffic at 100^3)
+    block_sum<3>(ib, bsm);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) bpart[long(a) * gridDim.x + blockIdx.x] = ib[a];
+    }
 }
 
 // computeAccum / assembleMassBalanceEq / computeMassFlux / applyThresholdPressures / UpwindSelector (BlackoilModelBase_impl.hpp:709-751, 845-913,
@@ -511,8 +523,9 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_assemble_rows(int xm, int nb,
                                                           const double* __restrict__ sg, const double* __restrict__ rs, const double* __restrict__ rv,
                                                           const int8_t* __restrict__ hc, double inv_dt, int initial, double s0, double s1, double s2,
                                                           const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col, const int16_t* __restrict__ rowlen,
-                                                          const int16_t* __restrict__ nlower, const int32_t* __restrict__ tpos, const double* __restrict__ tr_e,
-                                                          const double* __restrict__ gdz_e, const double* __restrict__ thp_e,
+                                                          const int16_t* __restrict__ nlower, const int32_t* __restrict__ tpos, const uint8_t* __restrict__ tslot,
+                                                          const double* __restrict__ tr_e, const double* __restrict__ zc, double grav, const double* __restrict__ gdz_e,
+                                                          const double* __restrict__ thp_e,
                                                           const double* __restrict__ eps, const double* __restrict__ eps_u0, const double* __restrict__ somax,
                                                           const double* __restrict__ vals, double* __restrict__ accum0, const int8_t* __restrict__ mask,
                                                           double* __restrict__ R, MS* __restrict__ A, MS* __restrict__ wout, const int32_t* __restrict__ chunk_perm,
@@ -572,20 +585,29 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_assemble_rows(int xm, int nb,
     // row writes itself, so the sums come for free (systems without explicit well cliques; k_cpr_weights stays for everything else)
     double sod[3] = { 0.0, 0.0, 0.0 };
     int k0 = (nl == 0) ? 1 : 0;
-    int nbr_n = 0, tp_n = 0; double T_n = 0.0, g_n = 0.0, th_n = 0.0;
+    // per entry: the neighbour (4 B), the transmissibility with the side in its sign bit (8 B), the index of the transposed entry (4 B; as a
+    // one-byte slot of the neighbour's row it was measured slower, see assemble_kernels), the threshold pressure where the deck has one.
+    // g (z_c1 - z_c2) is formed from the depth plane: the neighbour's depth rides on the gather of its values (round 3 kept a per-entry
+    // word for it: 55 MB at 100^3 against ~16 MB now; 0.210 against 0.245 ms, profiles/r04_f_ab.log)
+    // (A/B: OPMGPU_ASM_TSLOT=0 keeps the 4-byte index, OPMGPU_ASM_GDZ=1 the per-entry g dz word: gdz_e != nullptr)
+    const double z_own = zc[row];
+    int nbr_n = 0, tp_n = 0; double T_n = 0.0, th_n = 0.0, g_n = 0.0;
     if (k0 < len) {
         const long e0 = long(base + k0) * 64 + lane;
-        nbr_n = __builtin_nontemporal_load(&col[e0]); tp_n = __builtin_nontemporal_load(&tpos[e0]);
-        T_n = __builtin_nontemporal_load(&tr_e[e0]); g_n = __builtin_nontemporal_load(&gdz_e[e0]);
+        nbr_n = __builtin_nontemporal_load(&col[e0]); tp_n = tslot ? int(__builtin_nontemporal_load(&tslot[e0])) : __builtin_nontemporal_load(&tpos[e0]);
+        T_n = __builtin_nontemporal_load(&tr_e[e0]);
+        if (gdz_e) g_n = __builtin_nontemporal_load(&gdz_e[e0]);
         if (thp_e) th_n = __builtin_nontemporal_load(&thp_e[e0]);
     }
     for (int k = k0; k < len; ) {
-        const int nbr = nbr_n, tp = tp_n; const double Te = T_n, g = g_n, thp = th_n;
+        const int nbr = nbr_n; const double Te = T_n, thp = th_n, g_e = g_n;
+        const int tp = tslot ? (slice_ptr[nbr >> 6] + tp_n) * 64 + (nbr & 63) : tp_n;
         const int kn = (k + 1 == nl) ? k + 2 : k + 1;
         if (kn < len) {           // the next entry's words are in flight while this one is computed
             const long en = long(base + kn) * 64 + lane;
-            nbr_n = __builtin_nontemporal_load(&col[en]); tp_n = __builtin_nontemporal_load(&tpos[en]);
-            T_n = __builtin_nontemporal_load(&tr_e[en]); g_n = __builtin_nontemporal_load(&gdz_e[en]);
+            nbr_n = __builtin_nontemporal_load(&col[en]); tp_n = tslot ? int(__builtin_nontemporal_load(&tslot[en])) : __builtin_nontemporal_load(&tpos[en]);
+            T_n = __builtin_nontemporal_load(&tr_e[en]);
+            if (gdz_e) g_n = __builtin_nontemporal_load(&gdz_e[en]);
             if (thp_e) th_n = __builtin_nontemporal_load(&thp_e[en]);
         }
         MS* bptr = A + long(base + k) * 576 + lane;
@@ -597,6 +619,8 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_assemble_rows(int xm, int nb,
         }
         const int side = __builtin_signbit(Te) ? 1 : 0;     // side 0: this row is c1 (ngrad +1), side 1: it is c2
         const double Tf = fabs(Te);
+        double g = g_e;
+        if (!gdz_e) { const double z_n = zc[nbr]; g = grav * (side ? z_n - z_own : z_own - z_n); }      // g (z_c1 - z_c2), the expression the host evaluates per entry otherwise
         // neighbour values that every connection needs: phase pressures and densities
         double np_[3], nrho[3];
         np_[0] = vals[long(VP_PW) * nbp + nbr]; np_[1] = p[nbr]; np_[2] = vals[long(VP_PG) * nbp + nbr];
@@ -694,7 +718,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_assemble_rows(int xm, int nb,
 // convergenceReduction (BlackoilModelBase_impl.hpp:1633-1714): per phase sum(1/b), sum R, non-finite flag (sums: slots 0..6),
 // max|R|/pv, max|R| (maxima: slots 7..12); owned rows only (multi-GPU: followed by an all-reduce of each group)
 __device__ __forceinline__ bool conv_is_max(int q) { return q >= 7; }
-__global__ __launch_bounds__(kBlock) void k_conv_partial(int nb, int nbp, const double* __restrict__ R, const double* __restrict__ binv,
+__global__ __launch_bounds__(kBlock) void k_conv_partial(int nb, int nbp, const double* __restrict__ R, const double* __restrict__ bpart, int nbpart,
                                                          const double* __restrict__ pv, const int8_t* __restrict__ mask, double* __restrict__ part)
 {
     __shared__ double sm[4];
@@ -702,13 +726,17 @@ __global__ __launch_bounds__(kBlock) void k_conv_partial(int nb, int nbp, const 
     double vals[13];
 #pragma unroll
     for (int q = 0; q < 13; ++q) vals[q] = 0.0;
+    // sums of 1 / b: the per-workgroup partials of k_cell_values (owned cells only), spread over this launch's threads in a fixed order
+    for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < nbpart; i += long(gridDim.x) * kBlock) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) vals[a] += bpart[long(a) * nbpart + i];
+    }
     for (long i = blockIdx.x * long(kBlock) + threadIdx.x; i < nb; i += long(gridDim.x) * kBlock) {
         if (mask && !mask[i]) continue;
         const double ipv = 1.0 / pv[i];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const double r = R[long(a) * nbp + i];
-            vals[a] += binv[long(a) * nbp + i];
             vals[3 + a] += r;
             vals[7 + a] = fmax(vals[7 + a], fabs(r) * ipv);
             vals[10 + a] = fmax(vals[10 + a], fabs(r));
@@ -1223,19 +1251,28 @@ void BlackoilDevice::rebuild_structure()
     // g (z_c1 - z_c2) of the connection, its threshold pressure (k_assemble_rows reads them coalesced next to the column index)
     {
         const double nan = std::numeric_limits<double>::quiet_NaN();
-        std::vector<double> te(P.nentries, 0.0), ge(P.nentries, 0.0), he;
+        std::vector<double> te(P.nentries, 0.0), he;
         if (use_thpres) he.assign(P.nentries, 0.0);
         for (int b = 0; b < P.nnzb; ++b) {
             const int e = P.entry_of_block[b], c = code[b];
             if (c >= 0) {
                 const int f = c >> 1;
                 te[e] = std::copysign(h_trans[f], (c & 1) ? -1.0 : 1.0);
-                ge[e] = gravity * (h_z[h_conn[2 * f]] - h_z[h_conn[2 * f + 1]]);
                 if (use_thpres) he[e] = h_thpres[f];
             } else if (c == -2) te[e] = nan;
         }
-        d_tr_e.upload(te, stream); d_gdz_e.upload(ge, stream);
+        d_tr_e.upload(te, stream);
         if (use_thpres) d_thp_e.upload(he, stream);
+        if (std::getenv("OPMGPU_ASM_GDZ") && std::atoi(std::getenv("OPMGPU_ASM_GDZ")) != 0) {      // A/B: g dz as a per-entry word (round 3's layout)
+            std::vector<double> ge(P.nentries, 0.0);
+            for (int b = 0; b < P.nnzb; ++b) { const int c = code[b]; if (c >= 0) ge[P.entry_of_block[b]] = gravity * (h_z[h_conn[2 * (c >> 1)]] - h_z[h_conn[2 * (c >> 1) + 1]]); }
+            d_gdz_e.upload(ge, stream);
+        } else d_gdz_e.release();
+        // cell depths in internal numbering: g (z_c1 - z_c2) of a connection is formed in the kernel (gravity * (z[c1] - z[c2]), the same
+        // expression the reference's geometry evaluates once per face)
+        std::vector<double> zi(P.nbp, 0.0);
+        for (int r = 0; r < nc; ++r) zi[r] = h_z[P.nat[r]];
+        d_zc.upload(zi, stream);
     }
     std::vector<double> pvi(nbp, 1.0); std::vector<int32_t> pn(nbp, 0), sn(nbp, 0);
     for (int r = 0; r < nc; ++r) { pvi[r] = h_pv[P.nat[r]]; pn[r] = h_pvtnum[P.nat[r]]; sn[r] = h_satnum[P.nat[r]]; }
@@ -1287,7 +1324,7 @@ void BlackoilDevice::rebuild_structure()
     d_vals.alloc(size_t(VP_COUNT) * nbp); d_vals.zero(stream);
     d_accum0.alloc(3 * size_t(nbp)); d_accum0.zero(stream);
     d_R.alloc(3 * size_t(nbp)); d_R.zero(stream);
-    d_binv.alloc(3 * size_t(nbp)); d_binv.zero(stream);
+    d_bpart.alloc(3 * size_t(grid_for(nc))); d_bpart.zero(stream);
     d_dx.alloc(3 * size_t(nbp)); d_dx.zero(stream);
     d_dx_old.alloc(3 * size_t(nbp)); d_dx_old.zero(stream);
     d_red.alloc(13 * size_t(kMaxRedBlocks) + kRedPart);
@@ -1488,8 +1525,8 @@ void BlackoilDevice::launch_cell_values()
     const Plan& P = ls.plan;
     auto kern = tab_lds_words() > 0 ? k_cell_values<true> : k_cell_values<false>;
     hipLaunchKernelGGL(kern, dim3(grid_for(nc)), dim3(kBlock), tab_lds_bytes(), stream, nc, P.nbp, dto_, d_pvtnum.p, d_satnum.p,
-                       d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, eps_planes(), d_eps_u0.p, d_somax.p, d_vals.p, d_binv.p,
-                       (const double*)d_tab.p, tab_lds_words(), hyst_args());
+                       d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, eps_planes(), d_eps_u0.p, d_somax.p, d_vals.p, d_bpart.p,
+                       ls.comm ? ls.comm->owner_mask() : (const int8_t*)nullptr, (const double*)d_tab.p, tab_lds_words(), hyst_args());
 }
 template <class MS> void BlackoilDevice::assemble_kernels(double dt, bool initial, MS* A, bool props_only)
 {
@@ -1511,12 +1548,16 @@ template <class MS> void BlackoilDevice::assemble_kernels(double dt, bool initia
     // all ten neighbour values in one batch (default; measured 0.202 against 0.211 ms with a double Jacobian, profiles/r03_asm_batch_ab.log) or
     // the upwind-dependent five only when needed (OPMGPU_ASM_BATCH=0)
     static const bool batch = !(std::getenv("OPMGPU_ASM_BATCH") && std::atoi(std::getenv("OPMGPU_ASM_BATCH")) == 0);
+    // the transposed entry as a one-byte slot (OPMGPU_ASM_TSLOT=1) saves 21 MB of the 90 MB entry stream and was measured SLOWER than the 4-byte index:
+    // 0.240 against 0.210 ms (the slice base of the neighbour's row is one more dependent load per connection; profiles/r04_f_ab.log) -- off
+    static const bool use_tslot = std::getenv("OPMGPU_ASM_TSLOT") && std::atoi(std::getenv("OPMGPU_ASM_TSLOT")) != 0;
     auto kern = !lds ? k_assemble_rows<MS, 2, false, false>
                      : (waves == 3 ? (batch ? k_assemble_rows<MS, 3, true, true> : k_assemble_rows<MS, 3, true, false>)
                                    : (batch ? k_assemble_rows<MS, 2, true, true> : k_assemble_rows<MS, 2, true, false>));
     hipLaunchKernelGGL(kern, dim3(grid8_for(nc)), dim3(kBlock), tab_lds_bytes(), stream, xcd_mode(), nc, P.nbp, dto_, d_pvtnum.p, d_satnum.p, d_pv.p,
                        d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, 1.0 / dt, int(initial), sc[0], sc[1], sc[2],
-                       ls.dp.slice_ptr.p, ls.dp.col.p, ls.dp.rowlen.p, ls.dp.nlower.p, ls.dp.tpos.p, d_tr_e.p, d_gdz_e.p, use_thpres ? d_thp_e.p : (const double*)nullptr,
+                       ls.dp.slice_ptr.p, ls.dp.col.p, ls.dp.rowlen.p, ls.dp.nlower.p, ls.dp.tpos.p, use_tslot ? (const uint8_t*)ls.dp.tslot.p : (const uint8_t*)nullptr, d_tr_e.p, (const double*)d_zc.p, gravity,
+                       (const double*)d_gdz_e.p, use_thpres ? d_thp_e.p : (const double*)nullptr,
                        eps_planes(), d_eps_u0.p, d_somax.p, (const double*)d_vals.p, d_accum0.p, ls.comm ? ls.comm->owner_mask() : (const int8_t*)nullptr, d_R.p, A, wout,
                        (const int32_t*)ls.dp.flux_perm.p, (const double*)d_tab.p, tab_lds_words(), hyst_args());
     ls.weights_from_assembly = wout != nullptr;
@@ -1537,7 +1578,7 @@ void BlackoilDevice::assemble(double dt, bool initial)
         // updateEquationsScaling (BlackoilModelBase_impl.hpp:919-947; default off): every equation scaled by the mean 1/b of its phase in the
         // state being assembled.  The reference sets it at the end of assemble() and its linear solver scales this assembly's system with
         // it; here the scaling is applied while the Jacobian is written, so the mean is taken first: one extra property pass (it fills
-        // d_binv), the three sums, then the assembly proper with the new factors (wells and right-hand side read prm.matbalscale too).
+        // d_bpart), the three sums, then the assembly proper with the new factors (wells and right-hand side read prm.matbalscale too).
         if (ls.matrix_is_float) assemble_kernels<float>(dt, initial, ls.matrix_f(), true);
         else assemble_kernels<double>(dt, initial, ls.matrix_d(), true);
         double B[3];
@@ -1548,8 +1589,17 @@ void BlackoilDevice::assemble(double dt, bool initial)
     if (ls.matrix_is_float) assemble_kernels<float>(dt, initial, ls.matrix_f());
     else assemble_kernels<double>(dt, initial, ls.matrix_d());
     if (forked) OPMGPU_HIP(hipStreamWaitEvent(stream, ev_well[1], 0));
-    KtScope kts(ls.kt, KT_WELLS);
-    wells_assemble(initial);
+    {
+        KtScope kts(ls.kt, KT_WELLS);
+        wells_assemble(initial);
+    }
+    // the matrix is final (the host well model, if any, adds its blocks later: not then): start its ILU0 factorisation now, see LinSolver::factor_early
+    ls.factor_early = 0;
+    if (ls.factor_early_on && ls.factor_overlap && prm.use_cpr && !prm.cpr_reference_transform && ls.emulate_ranks <= 1 && !host_wells) {
+        ls.wb_relax = prm.cpr_relax * prm.cpr_stage2_relax;
+        if (ls.matrix_is_float) { ls.ensure_work<float>(); ls.factor_async<float>(); ls.factor_early = 4; }
+        else { ls.ensure_work<double>(); ls.factor_async<double>(); ls.factor_early = 8; }
+    }
 }
 
 double BlackoilDevice::time_assemble(int reps, int props_only)
@@ -1578,7 +1628,7 @@ int BlackoilDevice::convergence(double dt, double* B3, double* CNV3, double* MB3
     const int g = std::min(grid_for(nc), kMaxRedBlocks);
     const int8_t* mask = ls.comm ? ls.comm->owner_mask() : nullptr;
     hipEvent_t kt_a = ls.kt.begin();
-    hipLaunchKernelGGL(k_conv_partial, dim3(g), dim3(kBlock), 0, stream, nc, P.nbp, d_R.p, d_binv.p, d_pv.p, mask, d_red.p + kRedPart);
+    hipLaunchKernelGGL(k_conv_partial, dim3(g), dim3(kBlock), 0, stream, nc, P.nbp, d_R.p, (const double*)d_bpart.p, grid_for(nc), d_pv.p, mask, d_red.p + kRedPart);
     hipLaunchKernelGGL(k_conv_final, dim3(13), dim3(kBlock), 0, stream, g, d_red.p + kRedPart, d_red.p);
     ls.kt.end(KT_CONV, kt_a);
     // decomposed run with device wells somewhere: their convergence maxima (flux equations, control equation, error marks) ride on the same
@@ -1738,7 +1788,7 @@ void BlackoilDevice::binv_sums_device(double* out13_dev, double* scratch_dev)
     const Plan& P = ls.plan;
     const int g = std::min(grid_for(nc), kMaxRedBlocks);
     const int8_t* mask = ls.comm ? ls.comm->owner_mask() : nullptr;
-    hipLaunchKernelGGL(k_conv_partial, dim3(g), dim3(kBlock), 0, stream, nc, P.nbp, d_R.p, d_binv.p, d_pv.p, mask, scratch_dev);
+    hipLaunchKernelGGL(k_conv_partial, dim3(g), dim3(kBlock), 0, stream, nc, P.nbp, d_R.p, (const double*)d_bpart.p, grid_for(nc), d_pv.p, mask, scratch_dev);
     hipLaunchKernelGGL(k_conv_final, dim3(13), dim3(kBlock), 0, stream, g, scratch_dev, out13_dev);
     if (ls.comm) ls.comm->allreduce_sum(out13_dev, 3, stream);
 }

@@ -152,7 +152,7 @@ private:
     int tab_lds_words() const { return tab_words * 8 <= kTabLdsMaxBytes ? tab_words : 0; }
     size_t tab_lds_bytes() const { return size_t(tab_lds_words()) * 8; }
     // device: static per-cell / per-connection (internal numbering for cells)
-    DevArray<double> d_pv, d_tr_e, d_gdz_e, d_thp_e;      // per SELL entry: +-transmissibility (sign = side, NaN = well fill), g dz, threshold pressure
+    DevArray<double> d_pv, d_tr_e, d_gdz_e, d_thp_e;      // per SELL entry: +-transmissibility (sign = side, NaN = well fill), threshold pressure; d_zc: cell depths (g dz is formed in the kernel)
     DevArray<int32_t> d_pvtnum, d_satnum, d_perf_cells;
     // device: state (internal numbering)
     DevArray<double> d_p, d_sw, d_so, d_sg, d_rs, d_rv;
@@ -160,7 +160,7 @@ private:
     // device: work
     void launch_cell_values();
     DevArray<double> d_gather;      // decomposed runs: [ranks][19] table of getConvergence's sums and maxima (one all-reduce)
-    DevArray<double> d_vals, d_accum0, d_R, d_binv, d_dx, d_dx_old, d_red, d_perf, d_rhs_extra;
+    DevArray<double> d_vals, d_accum0, d_R, d_bpart, d_zc, d_dx, d_dx_old, d_red, d_perf, d_rhs_extra;
     double* h_red = nullptr;
     std::vector<double> hbuf;
     std::vector<int8_t> hbuf8;

@@ -120,7 +120,8 @@ template <class S> int solve_loaded(opmgpu_ctx* c, bool matrix_changed, SolveRes
     if (prm.use_cpr) {
         if (prm.cpr_ilu_n != 0) return fail(c, OPMGPU_EINVAL, "cpr_ilu_n > 0 (ILU(n) with fill-in) is not built: only cpr_ilu_n = 0");
         if (!(prm.cpr_relax > 0.0) || !(prm.cpr_solver_tol > 0.0) || prm.cpr_max_ell_iter < 0) return fail(c, OPMGPU_EINVAL, "cpr_relax / cpr_solver_tol must be positive, cpr_max_ell_iter >= 0");
-        prm.ilu_relaxation = prm.cpr_relax;
+        if (!(prm.cpr_stage2_relax > 0.0)) return fail(c, OPMGPU_EINVAL, "cpr_stage2_relax must be positive");
+        prm.ilu_relaxation = prm.cpr_relax * prm.cpr_stage2_relax;
         // the elliptic part (elliptic.inl): cpr_max_ell_iter = 0 is this library's one-V-cycle stage, which needs the AMG
         if (prm.cpr_max_ell_iter == 0 && !prm.cpr_use_amg) return fail(c, OPMGPU_EINVAL, "cpr_max_ell_iter = 0 (one application, no inner Krylov method) needs cpr_use_amg = 1");
         ls.ell.inner = prm.cpr_max_ell_iter > 0; ls.ell.use_amg = prm.cpr_use_amg != 0; ls.ell.bicgstab = prm.cpr_use_bicgstab != 0;
@@ -135,9 +136,12 @@ template <class S> int solve_loaded(opmgpu_ctx* c, bool matrix_changed, SolveRes
     // next to the pressure stage's set-up (cpr_prepare, inside the solver); not in the emulated-decomposition diagnostics, whose cut copy of
     // the matrix is built lazily by whichever of the two asks first
     static const bool after_rows = !(std::getenv("OPMGPU_FACTOR_AFTER_ROWS") && std::atoi(std::getenv("OPMGPU_FACTOR_AFTER_ROWS")) == 0);      // measured +0.5 %
-    if (ls.factor_overlap && prm.use_cpr && ls.emulate_ranks <= 1) { if (after_rows) ls.factor_deferred = true; else ls.factor_async<S>(); }
+    const bool early = ls.factor_early == int(sizeof(S)) && matrix_changed && !prm.cpr_reference_transform;      // the model started it behind the assembly (LinSolver::factor_early)
+    ls.factor_early = 0;
+    if (early) { /* running on the factor stream already; the first ILU0 sweep joins it */ }
+    else if (ls.factor_overlap && prm.use_cpr && ls.emulate_ranks <= 1) { if (after_rows) ls.factor_deferred = true; else ls.factor_async<S>(); }
     else (void)ls.factor<S>(false);      // status read below: the solver's own final synchronisation covers it
-    res = prm.newton_use_gmres ? ls.gmres<S>(c->prm) : ls.bicgstab<S>(c->prm);
+    res = prm.newton_use_gmres ? ls.gmres<S>(prm) : ls.bicgstab<S>(prm);
     if (prm.use_cpr) ls.correction_policy_report(res.iterations, res.status == OPMGPU_OK);
     if (res.status != OPMGPU_OK && prm.use_cpr && ls.corr_policy.active && ls.corr_policy.cur == 1 && ls.factor_status() == OPMGPU_OK) {
         // the solve ran with the larger correction factor of the adaptive policy: once more with the conservative one before anything is reported
@@ -145,13 +149,13 @@ template <class S> int solve_loaded(opmgpu_ctx* c, bool matrix_changed, SolveRes
         { auto& P = ls.corr_policy; P.avg[1] = P.avg[1] < 0.0 ? 4.0 * std::max(res.iterations, 1) : 2.0 * P.avg[1]; P.step_its = P.step_solves = 0; P.step_failed = false; }
         ls.corr_policy.cur = 0;
         ls.work<S>().amg->pdamp0 = ls.work<S>().amg->pdamp = ls.corr_policy.arm[0];
-        res = prm.newton_use_gmres ? ls.gmres<S>(c->prm) : ls.bicgstab<S>(c->prm);
+        res = prm.newton_use_gmres ? ls.gmres<S>(prm) : ls.bicgstab<S>(prm);
         ls.correction_policy_report(res.iterations, res.status == OPMGPU_OK);
     }
     if (res.status != OPMGPU_OK && prm.use_cpr && !ls.refreshed && ls.factor_status() == OPMGPU_OK) {
         // the solve ran on lagged coarse operators of the pressure hierarchy (LinSolver::cpr_prepare): once more on fresh ones
         ls.force_refresh = true; ls.lag_block = 8;
-        res = prm.newton_use_gmres ? ls.gmres<S>(c->prm) : ls.bicgstab<S>(c->prm);
+        res = prm.newton_use_gmres ? ls.gmres<S>(prm) : ls.bicgstab<S>(prm);
     }
     if (ls.factor_status() != OPMGPU_OK) { c->factored = false; return fail(c, OPMGPU_ESINGULAR, "singular diagonal block in ILU0"); }
     c->factored = true;
@@ -184,7 +188,7 @@ void opmgpu_default_params(opmgpu_params* p)
     p->newton_use_gmres = 0; p->linear_solver_restart = 40;                                // NewtonIterationBlackoilCPR.cpp:61-64
     p->solve_welleq_initially = 1; p->tolerance_wells = 1e-4; p->tolerance_well_control = 1e-7; p->dbhp_max_rel = 1.0; p->update_equations_scaling = 0; p->gmres_verify_residual = 0; p->cpr_reference_transform = 0;   // BlackoilModelParameters.cpp:80-96
     p->cpr_relax = 1.0; p->cpr_ilu_n = 0; p->cpr_use_amg = 0; p->cpr_use_bicgstab = 1;       // NewtonIterationBlackoilCPR.hpp:59-63
-    p->cpr_solver_tol = 1e-2; p->cpr_max_ell_iter = 25;                                       // external CPRPreconditioner (recollection, see opmgpu.h)
+    p->cpr_solver_tol = 1e-2; p->cpr_stage2_relax = 1.0; p->cpr_max_ell_iter = 25;                                       // external CPRPreconditioner (recollection, see opmgpu.h)
 }
 
 int opmgpu_create_solver(opmgpu_ctx** ctx, int device, const opmgpu_params* params) { return make_ctx(ctx, device, params); }

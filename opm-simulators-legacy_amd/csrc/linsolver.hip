@@ -935,6 +935,19 @@ void DevPlan::upload(const Plan& P, hipStream_t s)
     trip_t.upload(P.trip_t.empty() ? one : P.trip_t, s);
     rowlen.upload(P.rowlen, s); nlower.upload(P.nlower, s); tpos.upload(P.tpos, s); simple.upload(P.simple, s);
     flux_perm.upload(P.flux_perm, s);
+    {
+        // the transposed entry by its slot: one byte per entry instead of tpos's four (the assembly kernel's per-entry stream)
+        bool fits = true;
+        std::vector<uint8_t> ts(P.nentries, 0);
+        for (int e = 0; e < P.nentries && fits; ++e) {
+            const int32_t tp = P.tpos[e];
+            if (tp < 0) continue;
+            const int j = P.sell_col[e];
+            const int slot = (tp >> 6) - P.slice_ptr[j >> 6];
+            if (slot < 0 || slot > 255 || (tp & 63) != (j & 63)) fits = false; else ts[e] = uint8_t(slot);
+        }
+        if (fits && P.nentries > 0) tslot.upload(ts, s); else tslot.release();
+    }
     level_ptr = P.level_ptr;
     OPMGPU_HIP(hipStreamSynchronize(s));      // the host vectors may go away
 }
@@ -969,6 +982,7 @@ LinSolver::LinSolver(hipStream_t s) : stream(s)
     if (const char* e = std::getenv("OPMGPU_CPR_HALO_XP")) cpr_halo_xp = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_HALO_OVERLAP")) halo_overlap = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_FACTOR_OVERLAP")) factor_overlap = std::atoi(e) != 0;
+    if (const char* e = std::getenv("OPMGPU_FACTOR_EARLY")) factor_early_on = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_CS_RECUR")) cs_recur = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_AMG_AUTOTUNE")) amg_autotune = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_AMG_ADAPT")) corr_policy.on = std::atoi(e) != 0;
@@ -2135,7 +2149,7 @@ template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, con
     if (well_woodbury && wb_active && lowrank.nw > 0 && lowrank.P && !comm && wb_buf.p)
         hipLaunchKernelGGL((k_wb_apply<S>), dim3(lowrank.nw), dim3(kBlock), 0, stream, lowrank, plan.nbp, (const double*)wb_buf.p,
                            (const double*)(wb_buf.p + size_t(21) * lowrank.nperf), v, ctl);
-    hipLaunchKernelGGL((k_cpr_add_p<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, xp, v, ctl, S(relax));
+    hipLaunchKernelGGL((k_cpr_add_p<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, xp, v, ctl, S(ell.relax));
     kt.end(KT_CPR_OTHER, kt_a);
 }
 
@@ -2206,7 +2220,7 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
     if (factor_deferred) { factor_deferred = false; factor_async<S>(); }
     if (cpr && !w.amg->npost0_user) w.amg->npost0 = 2;            // post-sweeps on level 0: 2 under BiCGStab, 1 under GMRES (see gmres)
     // (with cpr_relax != 1 the pressure part of M^-1 p is scaled, which the closed form does not cover)
-    const bool closed = closed_form_level0 && emulate_ranks <= 1 && !(cpr && prm.ilu_relaxation != 1.0);      // (under CPR the field holds cpr_relax: solve_loaded)
+    const bool closed = closed_form_level0 && emulate_ranks <= 1 && !(cpr && ell.relax != 1.0);      // (ell.relax = cpr_relax; under CPR prm.ilu_relaxation holds cpr_relax * cpr_stage2_relax: solve_loaded)
     const int8_t* lightmask = nullptr;
     const bool overlap = comm && halo_overlap;
     if (comm && (closed || overlap)) {

@@ -17,6 +17,7 @@ struct DevPlan {
     DevArray<int32_t> slice_ptr, col, src, entry_of_block, nat, pos, trip_ptr, trip_l, trip_u, trip_t, tpos, flux_perm;
     DevArray<int16_t> rowlen, nlower;
     DevArray<int8_t> simple;
+    DevArray<uint8_t> tslot;        // [nentries] SLOT of the transposed entry in the neighbour's row (tpos = (slice_ptr[col >> 6] + tslot) * 64 + (col & 63)); empty when a row has > 255 slots
     std::vector<int32_t> level_ptr;
     void upload(const Plan& P, hipStream_t s);
 };
@@ -268,6 +269,13 @@ public:
     // ILU0 factorisation on a second stream next to the set-up of the pressure stage (both only read the matrix); the first ILU0
     // application joins.  A/B: OPMGPU_FACTOR_OVERLAP
     bool factor_overlap = true, factor_pending = false;
+    // The ILU0 factorisation of a freshly ASSEMBLED matrix starts at the end of the assembly (behind the wells' diagonal contributions), on its
+    // own stream: it then runs next to getConvergence, the host's decision and the first pass of the pressure stage's set-up instead of next
+    // to the small levels' Galerkin sums, which it slowed from ~25 to ~200 us (profiles/r04_e trace).  A call that turns out converged has
+    // factorised for nothing (device time only; such a call is 0.5 ms against 2.8).  factor_early: set by the model when it has started the
+    // factorisation for the current matrix; solve_loaded then does not start another.  A/B: OPMGPU_FACTOR_EARLY=0
+    bool factor_early_on = true;
+    int factor_early = 0;          // 0 = not started; 4 / 8 = started for the float / double matrix
     DevArray<double> cgs_parts;          // decomposed GMRES, classical Gram-Schmidt: (restart + 1) partial arrays + their all-reduced sums
     bool factor_deferred = false;        // factor_async() is started by cpr_prepare() behind its pass over the matrix
     hipStream_t factor_stream = nullptr;

@@ -195,7 +195,7 @@ def _perforated_diag_mask(rowptr, col, cells):
 
 
 def _lockstep_parity(gpu_lib, oracle, grid, tab, st, dt, wl, niter=2, cpr=1, reduction=1e-10, maxiter=2000, tol_p=1e-6, tol_s=1e-6,
-                     single=False, gmres=0, verify=0, oracle_reduction=None, tol_jac=1e-11, tol_op=1e-9):
+                     single=False, gmres=0, verify=0, oracle_reduction=None, tol_jac=1e-11, tol_op=1e-9, stage2_relax=1.0):
     """Newton iterations 0..niter-1 of one time step, GPU (device wells, CPR or ILU0) and oracle (+ host well model with
     the explicit Schur complement) side by side.  Every assembly is compared at rounding level; after every update the two states are
     compared at the linear tolerance and the oracle then CONTINUES FROM THE GPU's state, so the next assembly is again a rounding-level
@@ -208,7 +208,8 @@ def _lockstep_parity(gpu_lib, oracle, grid, tab, st, dt, wl, niter=2, cpr=1, red
     from opmgpu import wells as W
     from util import OracleBackend, rel_err
     oracle.set_threads(16)
-    prm_g = capi.default_params(linear_solver_reduction=reduction, linear_solver_maxiter=maxiter, cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=cpr, newton_use_gmres=gmres, gmres_verify_residual=verify)
+    prm_g = capi.default_params(linear_solver_reduction=reduction, linear_solver_maxiter=maxiter, cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=cpr, newton_use_gmres=gmres, gmres_verify_residual=verify,
+                                cpr_stage2_relax=stage2_relax)
     prm_o = capi.default_params(linear_solver_reduction=oracle_reduction or reduction, linear_solver_maxiter=4 * maxiter)
     nc = grid.nc
     gm = GpuBlackoilModel(grid, tab, prm_g)
@@ -342,7 +343,7 @@ def _spin_up(grid, tab, st, wl, dt, nsteps=2):
     return out, ws
 
 
-def _check_newton_count(gpu_lib, oracle, grid, tab, st, dt, wl, solvers=(0, 1), reduction=1e-6, spin_up=2, oracle_gmres=True, gmres_reduction_factor=1e-1, gmres_tol=1e-4):
+def _check_newton_count(gpu_lib, oracle, grid, tab, st, dt, wl, solvers=(0, 1), reduction=1e-6, spin_up=2, oracle_gmres=True, gmres_reduction_factor=1e-1, gmres_tol=1e-4, stage2_relax=1.0):
     """One whole time step with the reference's NonlinearSolver (update stabilisation on) and the reference's Newton tolerances
     (MB 1e-5, CNV 1e-2, wells 1e-4 / 1e-7), free-running on both sides from the same spun-up state.  The linear solves are double
     precision to a 1e-6 reduction on BOTH sides: at the default 1e-2 an inexact-Newton path depends on the preconditioner (measured:
@@ -385,7 +386,8 @@ def _check_newton_count(gpu_lib, oracle, grid, tab, st, dt, wl, solvers=(0, 1), 
         # device GMRES against the oracle's GMRES: both stop on their preconditioned residual like dune's.  Where the oracle's
         # ILU0-preconditioned GMRES(40) is not affordable (1 M cells), the device checks the TRUE residual (gmres_verify_residual),
         # which is the statement the oracle's BiCGStab makes -- the same 1e-4 state tolerance in both cases.
-        gm = GpuBlackoilModel(grid, tab, capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=cpr, newton_use_gmres=gmres, gmres_verify_residual=int(gmres == 1 and not oracle_gmres), **lin_of(gmres)))
+        gm = GpuBlackoilModel(grid, tab, capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=cpr, newton_use_gmres=gmres, gmres_verify_residual=int(gmres == 1 and not oracle_gmres),
+                                                             cpr_stage2_relax=stage2_relax, **lin_of(gmres)))
         if wl is None:
             md = gm
         else:
@@ -411,7 +413,10 @@ DECKS = {"cart100": (_cart100, 5.0), "spe10like": (_spe10_like, 2.0), "nornelike
 COUNT_DECKS = dict(DECKS, cart60=(_cart60, 5.0))
 # (the two 1 M-cell decks walk their SECOND iteration in the timed configuration below -- same assembly and well comparisons, GMRES instead of
 # BiCGStab --, so the BiCGStab leg stops after the first there: the whole GPU suite has to stay well inside the box's time limit)
-LOCKSTEP_KW = {"cart100": dict(niter=1),
+# cpr_stage2_relax = 0.9 (library extension, include/opmgpu.h; what rounds 1-3 ran under the name ilu_relaxation): the Norne-like deck with its
+# isolated cells does not reach the tight reductions of these tests with the undamped second stage of the reference's cpr_relax = 1 (measured:
+# Convergence failure at 1e-10 / 1e-6), and the float solve of cart100_f32 then leaves 1.5e-2 in the saturations instead of 1.4e-3
+LOCKSTEP_KW = {"cart100": dict(niter=1), "nornelike": dict(stage2_relax=0.9),
                "spe10like": dict(niter=1, reduction=1e-8, tol_p=1e-5, tol_s=1e-5)}        # sigma_lnK = 2.5: a 1e-10 reduction is below what BiCGStab attains in f64
 # the configurations bench.py times, device wells everywhere:
 #   *_f64: CPR in double + GMRES(40) with dune's stopping rule -- the headline (the reference's CPR plug-in is double-only) -- at the f64 tolerances
@@ -427,14 +432,14 @@ LOCKSTEP_KW = {"cart100": dict(niter=1),
 TIMED_KW = {"cart100_f64": ("cart100", dict(gmres=1, reduction=1e-10, maxiter=400)),
             # (sigma_lnK = 2.5: dune's rule stops on the PRECONDITIONED residual, which at 1e-8 left 7e-4 in the saturations here: 1e-11)
             "spe10like_f64": ("spe10like", dict(gmres=1, reduction=1e-11, oracle_reduction=1e-8, maxiter=800, tol_p=1e-5, tol_s=1e-5)),
-            "cart100_f32": ("cart100", dict(single=True, gmres=1, reduction=1e-5, oracle_reduction=1e-10, maxiter=300, tol_p=1e-3, tol_s=5e-3, tol_jac=5e-7, tol_op=2e-5))}
+            "cart100_f32": ("cart100", dict(single=True, gmres=1, reduction=1e-5, oracle_reduction=1e-10, maxiter=300, tol_p=1e-3, tol_s=5e-3, tol_jac=5e-7, tol_op=2e-5, stage2_relax=0.9))}
 # solvers: bit 0 = CPR, bit 1 = GMRES.  Multicolour ILU0 alone needs ~1000 iterations for 1e-6 at 1 M cells.  GMRES legs run against the
 # oracle's own GMRES restatement, both at 1e-7 -- except at 1 M cells (cart100: too slow on the host, see _cart60; the device verifies the true
 # residual there) and on the Norne-like grid: with its isolated cells restarted GMRES(40) stalls near 1e-7 on either side (and does not reach a
 # verified 1e-6 either), so both sides stop at 1e-6 on their OWN preconditioned residuals -- CPR's and ILU0's, two different norms -- which
 # leaves the converged states 2e-4 apart (measured); the Newton counts must still be equal
 COUNT_KW = {"cart100": dict(solvers=(1, 3), oracle_gmres=False), "cart60": dict(solvers=(1, 3)), "spe10like": dict(solvers=(1,)),
-            "nornelike": dict(spin_up=0, solvers=(0, 1, 3), gmres_reduction_factor=1.0, gmres_tol=3e-4), "spe9like": dict(spin_up=0, solvers=(0, 1, 2, 3))}
+            "nornelike": dict(spin_up=0, solvers=(0, 1, 3), gmres_reduction_factor=1.0, gmres_tol=3e-4, stage2_relax=0.9), "spe9like": dict(spin_up=0, solvers=(0, 1, 2, 3))}
 
 
 @pytest.mark.parametrize("name", list(DECKS))

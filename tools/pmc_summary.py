@@ -3,7 +3,7 @@
 import csv, glob, json, os, sys
 out = sys.argv[1]
 res = {}
-for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
+for d in sorted(glob.glob(os.path.join(out, "pmc*_*"))):
     if not os.path.isdir(d):
         continue
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -12,8 +12,13 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
             k = row["Kernel_Name"].split("(")[0]
             if "k_assemble_rows" in k or "k_spmv" in k:          # keep the template arguments that tell float from double apart
                 k = row["Kernel_Name"].split("(")[0]
-            if not any(t in k for t in ("k_assemble_rows", "k_cell_values", "k_flux", "k_cell_props", "k_spmv")):
+            amg_pass = os.path.basename(d).startswith("pmcamg_")
+            wanted = ("k_amg_galerkin", "k_amg_row_sub", "k_cpr_rows", "k_dense_invert", "k_ilu_factor", "k_amg_residual", "k_cpr_sum_eqs", "k_cpr_presidual") if amg_pass else \
+                     ("k_assemble_rows", "k_cell_values", "k_flux", "k_cell_props", "k_spmv", "k_conv_partial")
+            if not any(t in k for t in wanted):
                 continue
+            if amg_pass:
+                k = row["Kernel_Name"].split("(")[0]
             key = (k, row["Counter_Name"])
             a = acc.setdefault(key, [0.0, set()])
             a[0] += float(row["Counter_Value"]); a[1].add(row["Dispatch_Id"])
