@@ -109,6 +109,13 @@ struct RcclComm::Transport {
     // per neighbour q: send sbytes[q] from sb + soff[q], receive rbytes[q] into rb + roff[q]
     virtual void exchange(const std::vector<int32_t>& neigh, const char* sb, const std::vector<int64_t>& soff, const std::vector<int64_t>& sbytes,
                           char* rb, const std::vector<int64_t>& roff, const std::vector<int64_t>& rbytes, hipStream_t s) = 0;
+    // the two at once (they are independent): one operation where the transport can fuse them
+    virtual void allreduce_exchange(double* d, int n, const std::vector<int32_t>& neigh, const char* sb, const std::vector<int64_t>& soff,
+                                    const std::vector<int64_t>& sbytes, char* rb, const std::vector<int64_t>& roff, const std::vector<int64_t>& rbytes, hipStream_t s)
+    {
+        allreduce(d, n, false, s);
+        exchange(neigh, sb, soff, sbytes, rb, roff, rbytes, s);
+    }
     virtual void check_async() {}
 };
 
@@ -134,6 +141,20 @@ struct RcclTransport : RcclComm::Transport {
         rccl_check(rc, "ncclSend / ncclRecv");
         rccl_check(rc_end, "ncclGroupEnd");
     }
+    void allreduce_exchange(double* d, int n, const std::vector<int32_t>& neigh, const char* sb, const std::vector<int64_t>& soff,
+                            const std::vector<int64_t>& sbytes, char* rb, const std::vector<int64_t>& roff, const std::vector<int64_t>& rbytes, hipStream_t s) override
+    {
+        // one group: RCCL launches the collective and the point-to-point transfers together (one launch latency instead of two)
+        rccl_check(g_rccl.GroupStart(), "ncclGroupStart");
+        int rc = g_rccl.AllReduce(d, d, size_t(n), ncclFloat64, ncclSum, comm, s);
+        for (size_t q = 0; q < neigh.size() && rc == ncclSuccess; ++q) {
+            if (sbytes[q]) rc = g_rccl.Send(sb + soff[q], size_t(sbytes[q]), ncclInt8, neigh[q], comm, s);
+            if (rc == ncclSuccess && rbytes[q]) rc = g_rccl.Recv(rb + roff[q], size_t(rbytes[q]), ncclInt8, neigh[q], comm, s);
+        }
+        const int rc_end = g_rccl.GroupEnd();
+        rccl_check(rc, "ncclAllReduce / ncclSend / ncclRecv");
+        rccl_check(rc_end, "ncclGroupEnd");
+    }
     void check_async() override
     {
         if (!g_rccl.CommGetAsyncError) return;
@@ -156,6 +177,13 @@ struct ExternalTransport : RcclComm::Transport {
     {
         if (t.exchange(t.self, int(neigh.size()), neigh.data(), sb, soff.data(), sbytes.data(), rb, roff.data(), rbytes.data(), s) != 0)
             throw HipError(OPMGPU_ECOMM, "external transport: neighbour exchange failed");
+    }
+    void allreduce_exchange(double* d, int n, const std::vector<int32_t>& neigh, const char* sb, const std::vector<int64_t>& soff,
+                            const std::vector<int64_t>& sbytes, char* rb, const std::vector<int64_t>& roff, const std::vector<int64_t>& rbytes, hipStream_t s) override
+    {
+        if (!t.allreduce_exchange) { allreduce(d, n, false, s); exchange(neigh, sb, soff, sbytes, rb, roff, rbytes, s); return; }
+        if (t.allreduce_exchange(t.self, d, n, int(neigh.size()), neigh.data(), sb, soff.data(), sbytes.data(), rb, roff.data(), rbytes.data(), s) != 0)
+            throw HipError(OPMGPU_ECOMM, "external transport: fused all-reduce + neighbour exchange failed");
     }
 };
 
@@ -237,7 +265,7 @@ void RcclComm::coarse_blocks_of_rows(const Plan& P, int m, hipStream_t s, std::v
     for (int c = n_owned; c < n_local; ++c) sub[P.pos[c]] = int32_t(h[P.pos[c]] + 0.5);
 }
 
-template <class S> void RcclComm::halo_t(S* v, hipStream_t s)
+template <class S> void RcclComm::halo_t(S* v, hipStream_t s, double* red, int nred)
 {
     const int ns = int(send_cells.size()), nr = int(recv_cells.size());
     S* sb = reinterpret_cast<S*>(sbuf.p); S* rb = reinterpret_cast<S*>(rbuf.p);
@@ -248,11 +276,14 @@ template <class S> void RcclComm::halo_t(S* v, hipStream_t s)
         soff[q] = int64_t(3) * send_ptr[q] * sizeof(S); sby[q] = int64_t(3) * (send_ptr[q + 1] - send_ptr[q]) * sizeof(S);
         roff[q] = int64_t(3) * recv_ptr[q] * sizeof(S); rby[q] = int64_t(3) * (recv_ptr[q + 1] - recv_ptr[q]) * sizeof(S);
     }
-    transport->exchange(neigh_rank, reinterpret_cast<const char*>(sb), soff, sby, reinterpret_cast<char*>(rb), roff, rby, s);
+    if (red) transport->allreduce_exchange(red, nred, neigh_rank, reinterpret_cast<const char*>(sb), soff, sby, reinterpret_cast<char*>(rb), roff, rby, s);
+    else transport->exchange(neigh_rank, reinterpret_cast<const char*>(sb), soff, sby, reinterpret_cast<char*>(rb), roff, rby, s);
     if (nr) hipLaunchKernelGGL((k_halo_unpack<S>), dim3(grid_for(nr)), dim3(kBlock), 0, s, nr, nbp, d_recv_rows.p, rb, v);
 }
 void RcclComm::halo_exchange_f(float* v, hipStream_t s) { halo_t<float>(v, s); }
 void RcclComm::halo_exchange_d(double* v, hipStream_t s) { halo_t<double>(v, s); }
+void RcclComm::allreduce_sum_halo_f(double* d, int n, float* v, hipStream_t s) { halo_t<float>(v, s, d, n); }
+void RcclComm::allreduce_sum_halo_d(double* d, int n, double* v, hipStream_t s) { halo_t<double>(v, s, d, n); }
 void RcclComm::allreduce_sum(double* d, int n, hipStream_t s) { transport->allreduce(d, n, false, s); }
 void RcclComm::allreduce_max(double* d, int n, hipStream_t s) { transport->allreduce(d, n, true, s); }
 void RcclComm::check_async() { if (transport) transport->check_async(); }

@@ -22,6 +22,8 @@ public:
     void halo_exchange_d(double* v, hipStream_t s) override;
     void allreduce_sum(double* dbuf, int n, hipStream_t s) override;
     void allreduce_max(double* dbuf, int n, hipStream_t s) override;
+    void allreduce_sum_halo_f(double* dbuf, int n, float* v, hipStream_t s) override;
+    void allreduce_sum_halo_d(double* dbuf, int n, double* v, hipStream_t s) override;
     const int8_t* owner_mask() const override { return d_mask.p; }
     int my_rank() const override { return rank; }
     int num_ranks() const override { return nranks; }
@@ -32,7 +34,7 @@ public:
     double pvsum_global = 0.0;
 
 private:
-    template <class S> void halo_t(S* v, hipStream_t s);
+    template <class S> void halo_t(S* v, hipStream_t s, double* red = nullptr, int nred = 0);
     Transport* transport = nullptr;
     std::vector<int32_t> neigh_rank, send_ptr, recv_ptr, send_cells, recv_cells;
     DevArray<int32_t> d_send_rows, d_recv_rows;

@@ -2156,6 +2156,8 @@ template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, con
 template <class S> static void halo(CommBase* c, S* v, hipStream_t s);
 template <> void halo<float>(CommBase* c, float* v, hipStream_t s) { c->halo_exchange_f(v, s); }
 template <> void halo<double>(CommBase* c, double* v, hipStream_t s) { c->halo_exchange_d(v, s); }
+static void allreduce_halo(CommBase* c, double* d, int n, float* v, hipStream_t s) { c->allreduce_sum_halo_f(d, n, v, s); }
+static void allreduce_halo(CommBase* c, double* d, int n, double* v, hipStream_t s) { c->allreduce_sum_halo_d(d, n, v, s); }
 
 // Wait for the status block of the check kernel just enqueued.  Spinning on a host-mapped word the kernel writes last sees the result
 // a few microseconds after the kernel retires; hipStreamSynchronize takes an interrupt round trip (~20 us of idle GPU per check).
@@ -2709,6 +2711,13 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
     static const bool cgs_single = std::getenv("OPMGPU_GMRES_CGS") && std::atoi(std::getenv("OPMGPU_GMRES_CGS")) == 2;
     const bool cgs = (comm != nullptr || cgs_single) && cgs_on && m <= 63;
     if (cgs) cgs_parts.alloc(size_t(m + 2) * gv + size_t(m + 2));
+    // Decomposed, classical Gram-Schmidt: the halo of the vector a column ends with travels WITH the all-reduce of its projections (one
+    // fused operation, CommBase::allreduce_sum_halo_*): w = M^-1 A v_i gets its ghost entries from the owners, the update w -= sum h_k v_k
+    // and the normalisation run over ghost rows too (the basis vectors' ghost entries are the owners' values by induction), so v_{i+1} needs
+    // no exchange of its own before the next product -- one latency per column less, and one at the start (the first vector's halo rides on
+    // the all-reduce of its norm).  A/B: OPMGPU_GMRES_FUSE_HALO=0
+    static const bool fuse_env = !(std::getenv("OPMGPU_GMRES_FUSE_HALO") && std::atoi(std::getenv("OPMGPU_GMRES_FUSE_HALO")) == 0);
+    const bool fuse_halo = comm != nullptr && cgs && fuse_env && !flex;
     // The column's norm by Pythagoras (one all-reduce per column) -- for the loose reductions of Newton solves only (>= 1e-4, a handful of
     // columns): the identity needs an orthonormal basis, and classical Gram-Schmidt loses orthogonality as the columns add up -- at a
     // 1e-10 reduction (~20 columns) the decomposed runs left the single-domain Newton path with it (tests/test_gpu_dist_shm.py, cpr_gmres),
@@ -2732,8 +2741,8 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
         comm->allreduce_sum(red1, 1, stream);
         dot_arr = red1; dot_np = 1;
     };
-    auto product = [&](S* vin, S* out, const SolveCtl* c) {          // out = A vin (vin's ghost entries refreshed first)
-        if (comm) halo<S>(comm, vin, stream);
+    auto product = [&](S* vin, S* out, const SolveCtl* c, bool exchange = true) {          // out = A vin (vin's ghost entries refreshed first unless they are current)
+        if (comm && exchange) halo<S>(comm, vin, stream);
         lowrank_reduce<S>(vin, c);
         hipLaunchKernelGGL((k_spmv<S, 0>), dim3(std::min(grid8_for(plan.nb), 4 * kMaxPart)), dim3(kBlock), 0, stream, xcd_mode(), plan.nb, plan.nbp,
                            dp.slice_ptr.p, dp.col.p, matrix<S>(), (const S*)vin, out, (const S*)nullptr, mask, c,
@@ -2742,7 +2751,13 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
     auto V = [&](int k) { return w.kry.p + size_t(k) * n; };
     auto precond = [&](const S* d, S* out) { if (cpr) cpr_apply<S>(d, out, prm.ilu_relaxation, d_ctl); else ilu_apply<S>(d, out, prm.ilu_relaxation, d_ctl); };
     auto Z = [&](int k) { return w.kryz.p + size_t(k) * n; };
-    auto normalize_start = [&](const S* src, int first) {          // v0 = src / ||src||, s[0] = ||src||  (src = M^-1 defect, flexible: the defect)
+    auto normalize_start = [&](S* src, int first) {          // v0 = src / ||src||, s[0] = ||src||  (src = M^-1 defect, flexible: the defect)
+        if (fuse_halo) {        // ||src||^2 over the owned rows and src's halo in one operation: v0 then carries the owners' ghost values
+            hipLaunchKernelGGL((k_dot_owned<S>), dim3(gv), dim3(kBlock), 0, stream, n, plan.nbp, mask, (const S*)src, (const S*)src, parts);
+            hipLaunchKernelGGL((k_sum_partials<1>), dim3(1), dim3(kBlock), 0, stream, (const double*)parts, (const double*)nullptr, gv, red1);
+            allreduce_halo(comm, red1, 1, src, stream);
+            dot_arr = red1; dot_np = 1;
+        } else
         dot(src, src);
         hipLaunchKernelGGL((k_gm_normalize<S>), dim3(gv), dim3(kBlock), 0, stream, n, -1, first, prm.linear_solver_reduction, dot_arr, dot_np,
                            g.H, g.s, src, V(0), d_ctl, h_ctl_dev);
@@ -2751,8 +2766,8 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
     // x0 = 0: defect = b
     w.x.zero(stream);
     hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(1), 0, stream, d_ctl, h_ctl_dev, prm.linear_solver_reduction);
-    if (flex) normalize_start((const S*)w.b.p, 1);
-    else { precond(w.b.p, w.t.p); normalize_start((const S*)w.t.p, 1); }
+    if (flex) normalize_start(w.b.p, 1);
+    else { precond(w.b.p, w.t.p); normalize_start(w.t.p, 1); }
     // no synchronisation here: the first iteration is enqueued behind the set-up (factorisation, hierarchy, first application); a zero
     // defect sets `done` on the device, the iteration's kernels then return at once and its status check reports 0 iterations
     int j = 1;
@@ -2776,7 +2791,7 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
             } else {
                 if (!product_enqueued) {
                     kt_a = kt.begin();
-                    product(V(i), w.v.p, (const SolveCtl*)d_ctl);
+                    product(V(i), w.v.p, (const SolveCtl*)d_ctl, !fuse_halo);
                     kt.end(KT_SPMV1, kt_a);
                 }
                 product_enqueued = false;
@@ -2789,7 +2804,7 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
                 hipLaunchKernelGGL((k_gm_multidot<S>), dim3(gv), dim3(kBlock), 0, stream, n, plan.nbp, mask, cnt, (const S*)w.kry.p, (const S*)w.t.p, cgs_parts.p, (const SolveCtl*)d_ctl);
                 double* hsum = cgs_parts.p + size_t(m + 2) * gv;              // cnt projections + ||w||^2, all-reduced together
                 hipLaunchKernelGGL(k_sum_partials_multi, dim3(cnt + 1), dim3(kBlock), 0, stream, (const double*)cgs_parts.p, gv, hsum, (const SolveCtl*)d_ctl);
-                if (comm) comm->allreduce_sum(hsum, cnt + 1, stream);
+                if (comm) { if (fuse_halo && !flex) allreduce_halo(comm, hsum, cnt + 1, w.t.p, stream); else comm->allreduce_sum(hsum, cnt + 1, stream); }
                 double* pyth = cgs_pyth ? g.y + m + 2 : (double*)nullptr;    // norm^2 of what is left, by Pythagoras
                 hipLaunchKernelGGL((k_gm_cgs_update<S>), dim3(gv), dim3(kBlock), 0, stream, n, plan.nbp, mask, cnt, m, i, (const double*)hsum, g.H,
                                    (const S*)w.kry.p, w.t.p, parts, (const SolveCtl*)d_ctl, pyth);
@@ -2822,7 +2837,7 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
             kt.end(KT_VECTOR, kt_a);
             if (speculate && !flex && i + 1 < m && j + 1 <= maxit) {
                 kt_a = kt.begin();
-                product(V(i + 1), w.v.p, (const SolveCtl*)d_ctl);
+                product(V(i + 1), w.v.p, (const SolveCtl*)d_ctl, !fuse_halo);
                 kt.end(KT_SPMV1, kt_a);
                 product_enqueued = true;
             }
@@ -2868,8 +2883,8 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
         if (!stop && j <= maxit) {                                     // restart from the true defect
             product(w.x.p, w.v.p, (const SolveCtl*)nullptr);
             hipLaunchKernelGGL((k_gm_defect<S>), dim3(gv), dim3(kBlock), 0, stream, n, (const S*)w.b.p, (const S*)w.v.p, w.r.p);
-            if (flex) normalize_start((const S*)w.r.p, 0);
-            else { precond(w.r.p, w.t.p); normalize_start((const S*)w.t.p, 0); }
+            if (flex) normalize_start(w.r.p, 0);
+            else { precond(w.r.p, w.t.p); normalize_start(w.t.p, 0); }
         }
     }
     // the status block is current (the last iteration's tick was waited for); what is still in flight (the combination of the basis

@@ -45,6 +45,9 @@ struct CommBase {
     virtual void halo_exchange_d(double* v, hipStream_t s) = 0;
     virtual void allreduce_sum(double* dbuf, int n, hipStream_t s) = 0;
     virtual void allreduce_max(double* dbuf, int n, hipStream_t s) = 0;
+    // an all-reduce (sum) and a halo exchange that do not depend on each other as ONE operation where the transport can (dist.hip)
+    virtual void allreduce_sum_halo_f(double* dbuf, int n, float* v, hipStream_t s) { allreduce_sum(dbuf, n, s); halo_exchange_f(v, s); }
+    virtual void allreduce_sum_halo_d(double* dbuf, int n, double* v, hipStream_t s) { allreduce_sum(dbuf, n, s); halo_exchange_d(v, s); }
     virtual const int8_t* owner_mask() const = 0;     // [nbp] internal numbering, 1 = owned
     virtual void check_async() {}          // asynchronous transport errors -> HipError(OPMGPU_ECOMM)
     virtual int my_rank() const = 0;

@@ -66,7 +66,7 @@ class VfpTable(C.Structure):
 
 class Transport(C.Structure):
     """opmgpu_transport: caller-supplied all-reduce / neighbour exchange (include/opmgpu.h)"""
-    _fields_ = [("self", C.c_void_p), ("allreduce", C.c_void_p), ("exchange", C.c_void_p), ("destroy", C.c_void_p)]
+    _fields_ = [("self", C.c_void_p), ("allreduce", C.c_void_p), ("exchange", C.c_void_p), ("destroy", C.c_void_p), ("allreduce_exchange", C.c_void_p)]
 
 
 class NewtonCtl(C.Structure):

@@ -80,13 +80,13 @@ struct Shm {
         }
         return true;
     }
-    long n_allreduce = 0, n_exchange = 0;
+    long n_allreduce = 0, n_exchange = 0, n_fused = 0;
     ~Shm()
     {
         // OPMGPU_SHM_STATS=<path prefix>: the number of collective calls of this rank (tests count the all-reduces of an iteration)
         if (const char* e = std::getenv("OPMGPU_SHM_STATS")) {
             const std::string f = std::string(e) + "." + std::to_string(rank);
-            if (FILE* fp = std::fopen(f.c_str(), "w")) { std::fprintf(fp, "%ld %ld\n", n_allreduce, n_exchange); std::fclose(fp); }
+            if (FILE* fp = std::fopen(f.c_str(), "w")) { std::fprintf(fp, "%ld %ld %ld\n", n_allreduce, n_exchange, n_fused); std::fclose(fp); }
         }
         if (hdr) munmap(hdr, bytes);
         if (rank == 0 && !name.empty()) (void)shm_unlink(name.c_str());
@@ -139,6 +139,17 @@ int shm_exchange(void* self, int nq, const int32_t* neigh, const void* sbuf, con
     return 0;
 }
 
+// the fused operation (opmgpu_transport::allreduce_exchange): here simply both, counted as ONE operation -- what it is over RCCL (one group)
+int shm_allreduce_exchange(void* self, double* d, int n, int nq, const int32_t* neigh, const void* sbuf, const int64_t* soff, const int64_t* scount, void* rbuf,
+                           const int64_t* roff, const int64_t* rcount, void* stream)
+{
+    Shm& m = *static_cast<Shm*>(self);
+    const int a = shm_allreduce(self, d, n, 0, stream);
+    const int b = a ? a : shm_exchange(self, nq, neigh, sbuf, soff, scount, rbuf, roff, rcount, stream);
+    --m.n_allreduce; if (!a) --m.n_exchange; ++m.n_fused;
+    return b;
+}
+
 void shm_destroy(void* self) { delete static_cast<Shm*>(self); }
 
 } // namespace
@@ -149,5 +160,6 @@ extern "C" int shm_transport_create(const char* segment_name, int rank, int nran
     Shm* m = new Shm();
     if (!m->open(segment_name, rank, nranks)) { delete m; return 1; }
     out->self = m; out->allreduce = &shm_allreduce; out->exchange = &shm_exchange; out->destroy = &shm_destroy;
+    out->allreduce_exchange = std::getenv("OPMGPU_SHM_NO_FUSED") ? nullptr : &shm_allreduce_exchange;
     return 0;
 }

@@ -161,9 +161,9 @@ def test_collective_operations_per_newton_iteration(gpu_lib):
     (g1, c1), (g0, c0) = res[1], res[0]
     newton = len(g1[3])
     lin1, lin0 = int(g1[3][:, 1].sum()), int(g0[3][:, 1].sum())
-    per1, per0 = sum(c1[:2]) / newton, sum(c0[:2]) / newton
-    print("collective operations per Newton iteration: %.1f with the Pythagorean norm (%d all-reduces + %d exchanges, %d columns over %d iterations), %.1f without (%d + %d, %d columns)"
-          % (per1, c1[0], c1[1], lin1, newton, per0, c0[0], c0[1], lin0))
+    per1, per0 = sum(c1) / newton, sum(c0) / newton                  # (all-reduces, exchanges, fused all-reduce + exchange operations)
+    print("collective operations per Newton iteration: %.1f with the Pythagorean norm (%d all-reduces + %d exchanges + %d fused, %d columns over %d iterations), %.1f without (%d + %d + %d, %d columns)"
+          % (per1, c1[0], c1[1], c1[2], lin1, newton, per0, c0[0], c0[1], c0[2], lin0))
     assert abs(lin1 - lin0) <= 2                                      # the same Krylov process
     assert c0[0] - c1[0] >= lin1 - 2                                  # one all-reduce less per column
     assert np.abs(g1[0] - g0[0]).max() <= 2e-3 * np.abs(g0[0]).max()
