@@ -842,6 +842,19 @@ __global__ __launch_bounds__(kBlock) void k_amg_sum_parts(int np, const double* 
     if (threadIdx.x == 0) out[0] = acc[0];
 }
 template <class S>
+void AmgHierarchy<S>::residual0(const SolveCtl* ctl)
+{
+    AmgLevel<S>& F = *levels[0];
+    const int g = grid_for(F.n);
+    Border<S> B;
+    if (F.nw) {
+        B.nw = F.nw; B.n = F.n; B.gcells = g; B.connpos = F.b_connpos; B.perf_row = F.b_perf_row; B.perf_of_row = F.b_perf_of_row; B.perf_well = F.b_perf_well;
+        B.bcol = F.val.p + F.nentries; B.crow = B.bcol + F.nperf; B.dw = B.crow + F.nperf;
+    }
+    hipLaunchKernelGGL((k_amg_residual<S, 0>), dim3(g + F.nw), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, F.x.p, S(omega), F.dinv.p, F.r.p, ctl,
+                       (const int32_t*)nullptr, (const S*)nullptr, S(0), B);
+}
+template <class S>
 void AmgHierarchy<S>::residual_norm2(double* d_out)
 {
     AmgLevel<S>& F = *levels[0];

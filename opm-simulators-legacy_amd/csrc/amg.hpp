@@ -109,6 +109,8 @@ public:
     bool tuned = false;           // the correction factors were chosen for this hierarchy (LinSolver::cpr_tune)
     // ||b - A x||^2 over level 0 (border rows included) into d_out[0]; two launches, fixed summation order
     void residual_norm2(double* d_out);
+    // levels[0].r = b - A x on level 0 (border rows included); one launch
+    void residual0(const SolveCtl* ctl);
     DevArray<double> tune_parts;
     // levels[0].b := A s for an algebraically smooth s (pseudo-random start, `sweeps` Jacobi sweeps on A s = 0): the kind of error the
     // coarse-grid correction of a cycle meets.  The caller's right-hand side is parked in tune_b until restore_rhs().

@@ -984,6 +984,7 @@ LinSolver::LinSolver(hipStream_t s) : stream(s)
     if (const char* e = std::getenv("OPMGPU_FACTOR_OVERLAP")) factor_overlap = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_FACTOR_EARLY")) factor_early_on = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_CS_RECUR")) cs_recur = std::atoi(e) != 0;
+    if (const char* e = std::getenv("OPMGPU_CS_FUSED")) cs_fused_env = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_AMG_AUTOTUNE")) amg_autotune = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_AMG_ADAPT")) corr_policy.on = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_AMG_ADAPT_ARM")) corr_policy.arm[1] = std::atof(e);
@@ -1385,6 +1386,20 @@ __global__ __launch_bounds__(kBlock) void k_cs_add(int nb, const S* __restrict__
     if (ctl && ctl->done) return;
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i < nb) out[i] = x[i] + xc[i];
+}
+
+// out[row] += (A_c^-1 cr)[sub[row]] on every local row, ghost rows included (their subdomain is their owner's): the additive form of
+// the coarse-space correction behind the cycle (LinSolver::cs_fused_post)
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_cs_add_post(int nb, int ns, const int32_t* __restrict__ sub, const double* __restrict__ inv, const double* __restrict__ cr,
+                                                        S* __restrict__ out, const SolveCtl* __restrict__ ctl)
+{
+    __shared__ double e[64];
+    if (ctl && ctl->done) return;
+    if (int(threadIdx.x) < ns) { double s_ = 0.0; for (int k = 0; k < ns; ++k) s_ += inv[threadIdx.x * ns + k] * cr[k]; e[threadIdx.x] = s_; }
+    __syncthreads();
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < nb) out[i] = S(double(out[i]) + e[sub[i]]);
 }
 
 // real multi-GPU (one subdomain per process): deterministic versions -- per-workgroup partials, re-reduced in a fixed order
@@ -2052,6 +2067,9 @@ void LinSolver::correction_policy_report(int iterations, bool converged)
     if (!converged) P.step_failed = true;
 }
 
+static void allreduce_halo(CommBase* c, double* d, int n, float* v, hipStream_t s);
+static void allreduce_halo(CommBase* c, double* d, int n, double* v, hipStream_t s);
+
 #include "elliptic.inl"
 
 // M^-1 d = [x_p;0;0] + ILU0^-1 (d - A [x_p;0;0]),  x_p = Vcycle(sum of the equations of d) -- or the inner Krylov solve of elliptic.inl
@@ -2061,7 +2079,8 @@ template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, con
     AmgLevel<S>& L0 = *w.amg->levels[0];
     const int g = grid_for(plan.nb);
     const bool coarse = coarse_nsub >= 1;
-    const bool fused_rsum = coarse && !(!comm && emulate_ranks > 1) && g <= kCsRowParts;       // real coarse space: restriction fused into the kernel below
+    const bool fused_post = coarse && cs_fused_post && comm && cpr_halo_xp && !cr_given;        // coarse correction behind the cycle (see linsolver.hpp)
+    const bool fused_rsum = coarse && !fused_post && !(!comm && emulate_ranks > 1) && g <= kCsRowParts;       // real coarse space: restriction fused into the kernel below
     hipEvent_t kt_a = kt.begin();
     double* const cs_parts = coarse ? cs_buf.p + size_t(2) * coarse_nsub * coarse_nsub + coarse_nsub : nullptr;   // own scratch (the BiCGStab partial arrays are live across an application)
     S* const xw = L0.nw > 0 ? L0.x.p + L0.n : (S*)nullptr;        // the wells' unknowns start from zero (their right-hand side is zero): k_cpr_sum_eqs clears them
@@ -2075,7 +2094,7 @@ template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, con
         hipLaunchKernelGGL((k_cpr_sum_eqs<S, 1>), dim3(g), dim3(kBlock), 0, stream, plan.nb, plan.nbp, d, (const S*)w.cprw.p, L0.b.p, S(w.amg->omega0()), (const S*)L0.dinv.p, L0.x.p, ctl,
                            comm ? comm->owner_mask() : (const int8_t*)nullptr, (const int8_t*)nullptr, cs_parts, xw, L0.nw);
     if (!w.amg->tuned) cpr_tune<S>();          // first right-hand side of this hierarchy: choose its correction factors
-    if (coarse) {
+    if (coarse && !fused_post) {
         const int ns = coarse_nsub;
         double* inv = cs_buf.p + ns * ns; double* cr = inv + ns * ns;
         const bool emulated = !comm && emulate_ranks > 1;
@@ -2116,7 +2135,26 @@ template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, con
     // ranks: 4.4 -> 11.5, OPMGPU_EMULATE_WHAT=7).  The exchange runs on the halo stream behind the rows that read no ghost (as in
     // bicgstab's products).
     bool exchange = false;
-    if (coarse) {
+    if (fused_post) {
+        // r = b - A_p x of the cycle's result, restricted over this rank's owned rows (its coarse unknowns); hx = x; the halo of hx and the
+        // restricted residual in ONE operation; then the subdomain constants on all rows, ghost rows included
+        const int ns = coarse_nsub;
+        double* inv = cs_buf.p + ns * ns; double* cr = inv + ns * ns;
+        w.amg->residual0(ctl);
+        AmgLevel<S>& F0 = *w.amg->levels[0];
+        const int gp = std::min(grid_for(plan.nb), kMaxPart);
+        if (cs_m > 1) {
+            hipLaunchKernelGGL((k_cs_rsum_blocks<S>), dim3(gp), dim3(kBlock), 0, stream, plan.nb, (const int8_t*)cs_blk.p, (const S*)F0.r.p, cs_parts, ctl);
+            hipLaunchKernelGGL(k_cs_place_cr, dim3(1), dim3(kBlock), 0, stream, gp, (const double*)cs_parts, ns, cs_m, comm->my_rank(), cr, ctl);
+        } else {
+            hipLaunchKernelGGL((k_cs_rsum<S>), dim3(gp), dim3(kBlock), 0, stream, plan.nb, comm->owner_mask(), (const S*)F0.r.p, cs_parts, ctl);
+            hipLaunchKernelGGL(k_cs_place, dim3(1), dim3(kBlock), 0, stream, gp, (const double*)cs_parts, ns, comm->my_rank(), cr, ctl);
+        }
+        OPMGPU_HIP(hipMemcpyAsync(w.hx.p, F0.x.p, size_t(plan.nb) * sizeof(S), hipMemcpyDeviceToDevice, stream));
+        allreduce_halo(comm, cr, ns, w.hx.p, stream);
+        hipLaunchKernelGGL((k_cs_add_post<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, ns, (const int32_t*)cs_sub.p, (const double*)inv, (const double*)cr, w.hx.p, ctl);
+        xp = w.hx.p;
+    } else if (coarse) {
         hipLaunchKernelGGL((k_cs_add<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, (const S*)L0.x.p, (const S*)w.cxc.p, w.hx.p, ctl);
         xp = w.hx.p;
         exchange = comm && cpr_halo_xp;
@@ -2208,6 +2246,7 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
     SolverWork<S>& w = work<S>();
     SolveResult res;
     wb_active = false;             // (the wells' Woodbury correction of stage 2 runs under GMRES only: the closed-form rows below assume the plain ILU0)
+    cs_fused_post = false;         // (BiCGStab carries the coarse space's restriction along its recurrences: no all-reduce to fuse)
     const long n = long(3) * plan.nbp;
     const int gv = std::min(grid_for(n), kMaxPart);            // vector kernels (also the number of their partials)
     const int gs = std::min(grid8_for(plan.nb), kMaxPart);     // reducing SpMV launches (multiple of 8: XCD-aware chunking)
@@ -2718,6 +2757,7 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
     // the all-reduce of its norm).  A/B: OPMGPU_GMRES_FUSE_HALO=0
     static const bool fuse_env = !(std::getenv("OPMGPU_GMRES_FUSE_HALO") && std::atoi(std::getenv("OPMGPU_GMRES_FUSE_HALO")) == 0);
     const bool fuse_halo = comm != nullptr && cgs && fuse_env && !flex;
+    cs_fused_post = fuse_halo && cs_fused_env;
     // The column's norm by Pythagoras (one all-reduce per column) -- for the loose reductions of Newton solves only (>= 1e-4, a handful of
     // columns): the identity needs an orthonormal basis, and classical Gram-Schmidt loses orthogonality as the columns add up -- at a
     // 1e-10 reduction (~20 columns) the decomposed runs left the single-domain Newton path with it (tests/test_gpu_dist_shm.py, cpr_gmres),

@@ -289,6 +289,15 @@ public:
     // carried by the BiCGStab recurrences (it is linear in the vector), so only <W_b, A y> has to be summed over the ranks -- together
     // with the scalar products the iteration all-reduces anyway: 3 all-reduces per iteration instead of 5.  A/B: OPMGPU_CS_RECUR=0.
     bool cs_recur = true;
+    // Decomposed GMRES (fused halo operations on): the coarse space's correction moves BEHIND the cycle -- x_p = x + P A_c^-1 R (b - A_p x)
+    // with x = Vcycle(b), still multiplicative -- so that its restricted residual is all-reduced TOGETHER with the halo exchange of x (one
+    // fused operation instead of an all-reduce before the cycle and an exchange after it); costs one residual pass over A_p per application.
+    // MEASURED, NOT ADOPTED (profiles/r04_j_dist_ab.log, r04_i_dist_ab.log): the correction behind the cycle leaves the jumps of the subdomain
+    // constants to stage 2 instead of letting the cycle smooth them -- 12 -> 18 columns on the 2-rank test deck (14.8 operations per Newton
+    // iteration against 15.8: the saved latencies are spent on extra columns), SPE10-like 23.4 -> 25.7 iterations per solve; the additive
+    // form x + P A_c^-1 R b (no residual pass) is unusable: 4 ranks 9.0 -> 13.9 iterations per solve with chopped time steps.
+    // Off by default; OPMGPU_CS_FUSED=1 switches it on for further work.  Set by gmres() per solve.
+    bool cs_fused_post = false, cs_fused_env = false;
     DevArray<double> cs_state;     // [2 ns]: restricted residual of p, of r
     hipStream_t halo_stream = nullptr;
     hipEvent_t ev_halo[2] = { nullptr, nullptr };
