@@ -159,7 +159,12 @@ typedef struct opmgpu_params {
                                        1 = before such a solve is reported converged the TRUE residual b - A x is formed (one product) and the
                                            iteration continues from it, with a lowered threshold, until || b - A x || <= reduction || b || -- the
                                            statement the reference's default BiCGStab makes; the reported reduction is then the true one.
-                                           Not a reference option; costs one SpMV per solve; left-preconditioned GMRES only */
+                                           Not a reference option; costs one SpMV per solve; left-preconditioned GMRES only.
+                                           LIMIT with a float solve (single_precision = 1): b - A x is then formed in float, so the verified
+                                           reduction cannot go below the rounding of that product (about 1e-6 x the conditioning of the
+                                           scaled system; on the 1 M-cell bench deck a verified 1e-5 is NOT reached within 1000 iterations
+                                           and the solve ends in OPMGPU_ELINSOLVE) -- ask a float solve for reductions >= 1e-3 with the
+                                           check, or solve in double (tests/test_gpu_linsolver.py::test_gmres_verify_with_float_vectors) */
     int32_t cpr_reference_transform; /* 0 = CPR as DESIGN.md 4b describes it (only the pressure stage sees the combined equation);
                                         1 = the reference's formulation for comparability (NewtonIterationUtilities.cpp:253-287,
                                             NewtonIterationBlackoilCPR.cpp:117-131): the WHOLE system is row-transformed by L (per cell: its
@@ -194,6 +199,10 @@ int opmgpu_get_matbalscale(opmgpu_ctx* ctx, double* scale3);
 /* CPR with an inner Krylov method on the elliptic part (cpr_max_ell_iter > 0; the reference's external CPRPreconditioner::solveElliptic,
  * reached from NewtonIterationBlackoilCPR.cpp:148-165): inner solves and inner iterations since the context was created */
 int opmgpu_cpr_elliptic_stats(opmgpu_ctx* ctx, int64_t* solves, int64_t* iterations);
+/* diagnostic: the scaling of the pressure cycle's coarse-grid corrections the LAST CPR solve ran with (into level 0 / below it; DESIGN.md
+ * section 4b: 1.9, or the per-time-step choice between 1.9 and 2.3 on matrices of the model's own assembly -- external matrices of the B1
+ * path keep 1.9).  OPMGPU_EINVAL before the first CPR solve. */
+int opmgpu_cpr_correction_factors(opmgpu_ctx* ctx, double* into_level0, double* below);
 
 /* ------------------------------------------------------------------------------------------
  * B2 boundary: BlackoilModel hooks (BlackoilModelBase_impl.hpp:239-326: assemble ->

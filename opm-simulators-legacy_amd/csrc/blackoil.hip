@@ -1572,6 +1572,7 @@ void BlackoilDevice::assemble(double dt, bool initial)
     has_rhs_extra = false;
     if (initial) { d_dx_old.zero(stream); ls.new_step_hint = true; }       // first matrix of a time step: coarse AMG operators are rebuilt
     const bool host_wells = nperf > 0 && !device_wells;
+    ls.corr_policy.external = false;           // a matrix of the model's own assembly: the correction-factor policy may score its time steps
     ls.coarse_single_ok = nperf == 0;          // no wells of either kind: the global constant is the near-null-space vector
     ls.matrix_is_float = assemble_single && !host_wells;
     if (prm.update_equations_scaling) {

@@ -269,6 +269,17 @@ int opmgpu_cpr_elliptic_stats(opmgpu_ctx* c, int64_t* solves, int64_t* iteration
     return OPMGPU_OK;
 }
 
+int opmgpu_cpr_correction_factors(opmgpu_ctx* c, double* into_level0, double* below)
+{
+    if (!c || !c->ls) return OPMGPU_EINVAL;
+    LinSolver& ls = *c->ls;
+    const bool f = c->cur_single == 1;
+    if (f ? !(ls.work<float>().amg && ls.work<float>().amg->ready()) : !(ls.work<double>().amg && ls.work<double>().amg->ready())) return OPMGPU_EINVAL;
+    if (into_level0) *into_level0 = f ? ls.work<float>().amg->pdamp0 : ls.work<double>().amg->pdamp0;
+    if (below) *below = f ? ls.work<float>().amg->pdamp : ls.work<double>().amg->pdamp;
+    return OPMGPU_OK;
+}
+
 int opmgpu_get_matbalscale(opmgpu_ctx* c, double* scale3)
 {
     if (!c || !c->model || !scale3) return OPMGPU_EINVAL;

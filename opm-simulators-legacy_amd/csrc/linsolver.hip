@@ -1047,6 +1047,9 @@ void LinSolver::load_host_bsr(const double* val9)
 {
     matrix_is_float = false; weights_from_assembly = false;
     new_step_hint = true;          // an external matrix: nothing is known about its relation to the previous one
+    // every external matrix is its own "time step" with a single solve, which the correction-factor policy never scores -- one failed
+    // solve would park it on the unscored larger factor for good: external matrices run the fixed first setting
+    corr_policy.external = true; corr_policy.cur = 0;
     stage.ensure(std::max(size_t(plan.nnzb) * 9, size_t(3) * plan.nbp));
     OPMGPU_HIP(hipMemcpyAsync(stage.p, val9, size_t(plan.nnzb) * 9 * sizeof(double), hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(k_bsr_to_sell, dim3(grid_for(plan.nentries)), dim3(kBlock), 0, stream, plan.nentries, dp.src.p, stage.p, Ad.p);
@@ -1903,7 +1906,7 @@ template <class S> void LinSolver::cpr_prepare()
     corr_policy.active = false;
     if (!w.amg->pdamp_user) {
         const bool global_constant = coarse_nsub == 1 && lowrank.nw == 0;
-        if (global_constant || !corr_policy.on || amg_autotune) {
+        if (global_constant || !corr_policy.on || corr_policy.external || amg_autotune) {
             if (!w.amg->tuned) { w.amg->pdamp0 = global_constant ? 2.2 : 1.9; w.amg->pdamp = 1.9; }       // (cpr_tune marks the hierarchy; with the autotune experiment it also chose the factors)
         } else { w.amg->pdamp0 = w.amg->pdamp = corr_policy.arm[corr_policy.cur]; corr_policy.active = true; }
     }
@@ -2045,7 +2048,7 @@ template <class S> void LinSolver::cpr_tune()
 void LinSolver::correction_policy_choose()
 {
     CorrectionPolicy& P = corr_policy;
-    if (!P.on || !new_step_hint) return;            // the setting changes at time-step boundaries only
+    if (!P.on || P.external || !new_step_hint) return;            // the setting changes at time-step boundaries only
     if (P.step_solves >= 2 || P.step_failed) {      // score the step that has just ended
         const double score = (P.step_failed ? 4.0 : 1.0) * double(P.step_its) / double(std::max(P.step_solves, 1));
         P.avg[P.cur] = P.avg[P.cur] < 0.0 ? score : 0.5 * P.avg[P.cur] + 0.5 * score;
@@ -2907,6 +2910,7 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
                 verified = true;
                 if (!h_ctl->done) {
                     stop = false; ++verify_rounds;
+                    product_enqueued = false;          // (OPMGPU_GMRES_SPECULATE: the next column's product was enqueued while `done` was up and returned at once)
                     // a second miss in the same cycle (the first already with float vectors, whose Arnoldi estimate keeps falling while
                     // b - A x does not: measured on the 1 M-cell deck, in-cycle continuation never reached 1e-5 there): the recurrence's
                     // estimate has drifted from the real defect -- end the cycle here and restart from the true defect, which the restart

@@ -185,6 +185,7 @@ public:
         int step_its = 0, step_solves = 0;
         bool step_failed = false;
         bool active = false;            // set by cpr_prepare: this solve's factors come from the policy
+        bool external = false;          // the current matrix came through load_host_bsr (B1): one solve per "time step", nothing to score -- fixed first setting
     } corr_policy;
     void correction_policy_choose();
     void correction_policy_report(int iterations, bool converged);

@@ -666,7 +666,7 @@ __global__ __launch_bounds__(kBlock) void k_well_presolve_serial(int nw, int np,
         int off = 0;
         for (int k = 0; k < 4; ++k) { for (int i = tid; i < len[k]; i += kBlock) parts[k][i] = snap[off + i]; off += len[k]; }
         for (int i = tid; i < nw; i += kBlock) A.current[i] = isnap[i];
-        if (tid == 0) { atomicAnd(&flags[WF_ERR], ~16); flags[WF_DONE] = 0; flags[WF_CONV] = 0; flags[WF_ITS] = 0; }
+        if (tid == 0) { flags[WF_ERR] = isnap[nw] & ~16; flags[WF_DONE] = 0; flags[WF_CONV] = 0; flags[WF_ITS] = 0; }     // the whole word as snapshot before the fused attempt
     }
     __threadfence();
     __syncthreads();
@@ -776,6 +776,9 @@ __global__ __launch_bounds__(kBlock) void k_well_snapshot(int nw, int np, WellAr
         off += len[k];
     }
     if (i < nw) { if (restore) A.current[i] = isnap[i]; else isnap[i] = A.current[i]; }
+    // the error word as it stood before the pre-solve (isnap[nw]): the serial fallback puts it back WHOLE -- a half-run fused attempt may have
+    // left control-switch / assembly bits behind that are not the pre-solve's verdict
+    if (!restore && i == 0) isnap[nw] = flags[WF_ERR];
 }
 
 // recoverVariable (NewtonIterationUtilities.cpp:134-184): dy = D^-1 (E - sum_j C_j dx_j) -- the well part of the Newton increment,
@@ -944,7 +947,7 @@ int BlackoilDevice::set_device_wells(const opmgpu_wells* s)
     W.ctrl_ptr.upload(W.h_ctrl_ptr, stream); W.ctrl_vfp.upload(vfp_idx, stream); W.thp_ctrl.upload(thp_ctrl, stream);
     upd(W.WI, s->WI, np); upd(W.comp_frac, s->comp_frac, 3 * size_t(nw)); upd(W.ctrl_target, s->ctrl_target, nct);
     upd(W.ctrl_distr, s->ctrl_distr, 3 * size_t(nct)); upd(W.ctrl_alq, s->ctrl_alq, nct); upd(W.depth_ref, s->depth_ref, nw);
-    W.current.alloc(nw); W.current.zero(stream); W.isnap.alloc(nw); W.isaved.alloc(nw);
+    W.current.alloc(nw); W.current.zero(stream); W.isnap.alloc(nw + 1); W.isaved.alloc(nw);
     W.thp.alloc(nw); W.thp.zero(stream);
     W.perf_dens.alloc(np); W.perf_dens.zero(stream); W.perf_pvt.alloc(5 * size_t(np)); W.avgp.alloc(np);
     W.ctrl_row.alloc(4 * size_t(nw)); W.ctrl_row.zero(stream);
@@ -1093,7 +1096,7 @@ void BlackoilDevice::wells_assemble(bool initial)
                 // one launch: one workgroup per well, counter barrier per iteration -- all nw workgroups fit the device together
                 // (fused_presolve_capacity: the kernel's occupancy x compute units, with a margin)
                 W.presolve_sync.alloc(4 + 8 * size_t(W.nw)); W.presolve_sync.zero(stream);
-                if (fmode == 2) hipLaunchKernelGGL(k_well_flag_or, dim3(1), dim3(1), 0, stream, W.flags.p + WF_ERR, 16);
+                if (fmode == 2) hipLaunchKernelGGL(k_well_flag_or, dim3(1), dim3(1), 0, stream, W.flags.p + WF_ERR, 16 | 4);      // (tests) the give-up bit AND a stray control bit of a half-run attempt: the fallback must wipe both
                 else
                 hipLaunchKernelGGL(k_well_presolve_fused, dim3(W.nw), dim3(kBlock), 0, stream, W.nw, A, ls.dp.slice_ptr.p, ls.dp.nlower.p, (const double*)W.bsums.p, ncg,
                                    prm.tolerance_wells, prm.tolerance_well_control, prm.max_residual_allowed, prm.dbhp_max_rel, max_it, W.flags.p,

@@ -150,8 +150,24 @@ def test_self_halo_with_device_wells(gpu_lib, cpr):
             # The fourth iteration of this deck solves a nearly singular system (the well residuals jump there: CNV 0.57 -> 1.9; the
             # pressure LEVEL is a near-null mode of it): two solves that both reach a 3e-12 residual on matrices that agree to rounding
             # -- the residuals of A and B differ by 2e-13 on states 3e-6 Pa apart (tools/debug_selfhalo.py) -- differ by 5e-6 in that
-            # mode, 90 Pa everywhere.  That is the conditioning of the system, not the decomposition: the comparison of the UPDATED
-            # states ends with the third iteration, the fourth is compared through its residual (state in) only.
+            # mode, 90 Pa everywhere.  That is the conditioning of the system, not the decomposition.  The fourth update is therefore
+            # compared with the level shift taken out -- and the shift itself must stay inside four times what was measured (ADVICE r3:
+            # round 3 stopped comparing here, which would have let a decomposition bug in the fourth update through).
+            shift = float(np.mean(sa.p - sb.p[:n]))
+            assert abs(shift) <= 2e-5 * np.abs(sa.p).max(), shift
+            assert np.array_equal(sa.hc, sb.hc[:n]), it
+            dp_ = np.abs((sa.p - shift) - sb.p[:n]).max() / np.abs(sa.p).max()
+            ds_ = np.abs(sa.sat - sb.sat[:n]).max()
+            db_ = np.abs((wa.bhp - shift) - wb.bhp).max() / np.abs(wa.bhp).max()
+            dq_ = np.abs(wa.qs - wb.qs).max() / np.abs(wa.qs).max()
+            print("self-halo wells, fourth update: level shift %.1f Pa, then p %.2e sat %.2e bhp %.2e qs %.2e" % (shift, dp_, ds_, db_, dq_))
+            # measured (gpurun r04_m): ILU0 + BiCGStab -- the decomposed ILU0 is a different preconditioner, hence a different Krylov path on this
+            # nearly singular system -- shift -105.7 Pa, then p 3.5e-5, sat 1.2e-3, bhp 6e-6, qs 8e-5; CPR: 1e-13 throughout (the same
+            # arithmetic on both sides).  The bounds are three times the measured values: a decomposition bug in the update shows as O(1).
+            if cpr:
+                assert abs(shift) <= 1e-6 * np.abs(sa.p).max() and dp_ <= 1e-9 and ds_ <= 1e-9 and db_ <= 1e-9 and dq_ <= 1e-9, (it, shift, dp_, ds_, db_, dq_)
+            else:
+                assert dp_ <= 1e-4 and ds_ <= 4e-3 and db_ <= 2e-5 and dq_ <= 3e-4, (it, shift, dp_, ds_, db_, dq_)
             break
         assert np.array_equal(sa.hc, sb.hc[:n]), it
         assert np.abs(sa.p - sb.p[:n]).max() <= 1e-6 * np.abs(sa.p).max() and np.abs(sa.sat - sb.sat[:n]).max() <= 1e-6, it

@@ -113,3 +113,42 @@ def test_correction_factor_policy_is_preconditioner_only(gpu_lib):
         assert np.abs(out.p - ref.p).max() <= 1e-6 * np.abs(ref.p).max() and np.abs(out.sat - ref.sat).max() <= 1e-6, arm
         if arm == 6.0:
             assert lin <= 1.6 * lin0, (lin, lin0)          # the bad setting costs the steps it is tried on, not the run
+
+
+def test_external_matrices_keep_the_fixed_correction_factor(gpu_lib):
+    """through the B1 path (opmgpu_solve_bsr: a matrix the reference's own assembly supplies) every solve is its own "time step",
+    which the correction-factor policy never scores -- a single failed solve used to park it on the unscored larger factor for good.
+    External matrices now run the fixed first setting (1.9): also after failed solves."""
+    import ctypes as C
+    from opmgpu.model import GpuNewtonIteration
+    grid = decks.cartesian_grid(12, 10, 8, lognormal_sigma=0.8, seed=3)
+    tab = decks.satfunc_standard_tables()
+    st = decks.initial_state(grid, tab, perturb=0.004, seed=3)
+    gm = GpuBlackoilModel(grid, tab, capi.default_params())
+    gm.prepareStep(2 * decks.DAY, st)
+    gm.assemble(True)
+    rowptr, col, val = gm.jacobian()
+    r = gm.residual()
+    gm.close()
+    nc = grid.nc
+    scale = np.asarray(capi.default_params().matbalscale[:])
+    b = np.ascontiguousarray((r * np.repeat(scale, nc)).reshape(3, nc).T).ravel()
+
+    def factors(s):
+        a, bb = np.zeros(1), np.zeros(1)
+        assert s.lib.opmgpu_cpr_correction_factors(s.ctx, capi.dptr(a), capi.dptr(bb)) == 0
+        return float(a[0]), float(bb[0])
+
+    # one iteration cannot reach 1e-8: every solve fails
+    s = GpuNewtonIteration(capi.default_params(newton_use_gmres=1, linear_solver_maxiter=1, linear_solver_reduction=1e-8, **capi.CPR_AMG_VCYCLE))
+    for k in range(4):
+        with pytest.raises(LinearSolverProblem):
+            s.computeNewtonIncrement(rowptr, col, val * (1.0 + 0.01 * k), b, False)
+        assert factors(s) == (1.9, 1.9), (k, factors(s))
+    s.close()
+    # and solves that converge stay there as well
+    s = GpuNewtonIteration(capi.default_params(newton_use_gmres=1, **capi.CPR_AMG_VCYCLE))
+    for k in range(12):
+        s.computeNewtonIncrement(rowptr, col, val * (1.0 + 0.01 * k), b, False)
+        assert factors(s) == (1.9, 1.9), (k, factors(s))
+    s.close()

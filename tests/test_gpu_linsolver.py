@@ -288,6 +288,39 @@ def test_gmres_option(gpu_lib, oracle, single):
     s.close()
 
 
+def test_gmres_verify_with_float_vectors(gpu_lib, oracle, monkeypatch):
+    """gmres_verify_residual with a FLOAT solve: the documented range -- reductions down to 1e-3 -- is met on the TRUE residual
+    (checked with an independent double product), also with the speculative product of the next column enqueued ahead of the verdict
+    (OPMGPU_GMRES_SPECULATE=1: a verify round that takes `done` back must not reuse a product that returned at once); beyond what float
+    rounding of b - A x allows the solve reports LinearSolverProblem instead of a wrong answer."""
+    grid = decks.cartesian_grid(12, 10, 8, lognormal_sigma=0.8)
+    tab = decks.satfunc_standard_tables()
+    st = decks.initial_state(grid, tab, perturb=0.01)
+    prm0 = capi.default_params()
+    scale = np.asarray(prm0.matbalscale[:])
+    rowptr, col = oracle.pattern(grid)
+    nc = grid.nc
+    r, val, _, _ = oracle.assemble(grid, tab, 5 * decks.DAY, st, rowptr, col, scale=tuple(scale))
+    b = np.ascontiguousarray((r * np.repeat(scale, nc)).reshape(3, nc).T).ravel()
+    A = bsr_to_scipy(rowptr, col, val)
+    for speculate in ("0", "1"):
+        monkeypatch.setenv("OPMGPU_GMRES_SPECULATE", speculate)
+        for kw in (dict(), dict(capi.CPR_AMG_VCYCLE)):
+            for red in (1e-2, 1e-3):
+                s = GpuNewtonIteration(capi.default_params(newton_use_gmres=1, gmres_verify_residual=1, linear_solver_reduction=red, linear_solver_maxiter=300, **kw))
+                x = s.computeNewtonIncrement(rowptr, col, val, b, True)
+                true_red = np.linalg.norm(b - A @ x) / np.linalg.norm(b)
+                assert true_red <= 1.05 * red, (speculate, kw, red, true_red)          # (5 %: the check itself is a float product)
+                assert s.reduction <= red
+                s.close()
+    monkeypatch.delenv("OPMGPU_GMRES_SPECULATE")
+    # far below float rounding: an error, never a silently unverified answer
+    s = GpuNewtonIteration(capi.default_params(newton_use_gmres=1, gmres_verify_residual=1, linear_solver_reduction=1e-12, linear_solver_maxiter=60))
+    with pytest.raises(LinearSolverProblem):
+        s.computeNewtonIncrement(rowptr, col, val, b, True)
+    s.close()
+
+
 @pytest.mark.parametrize("single", [False, True])
 def test_flexible_gmres_stops_on_the_true_residual(gpu_lib, oracle, single):
     """newton_use_gmres = 2 (not a reference solver): right-preconditioned GMRES with the preconditioned basis kept.
