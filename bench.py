@@ -227,7 +227,9 @@ def main(argv=None):
     # solver names: "ilu0" = solver_approach=interleaved; "cpr" = the headline's pressure stage (cpr_use_amg=true, ONE V-cycle per application:
     # cpr_max_ell_iter = 0); "cpr_ref" = the CPR plug-in's documented defaults (cpr_use_amg=false: ILU0-preconditioned inner BiCGStab on the
     # pressure system, cpr_solver_tol / cpr_max_ell_iter at their defaults); "cpr_amg_inner" = cpr_use_amg=true behind that inner BiCGStab
-    CPR_KW = {"ilu0": dict(use_cpr=0), "cpr": dict(capi.CPR_AMG_VCYCLE), "cpr_ref": dict(use_cpr=1, cpr_use_amg=0), "cpr_amg_inner": dict(use_cpr=1, cpr_use_amg=1)}
+    CPR_KW = {"ilu0": dict(use_cpr=0), "cpr": dict(capi.CPR_AMG_VCYCLE), "cpr_ref": dict(use_cpr=1, cpr_use_amg=0), "cpr_amg_inner": dict(use_cpr=1, cpr_use_amg=1),
+              # library extension (opmgpu_params.preconditioner_single): the headline's solver with its preconditioner in float, Krylov method in double
+              "cpr_mixed": dict(capi.CPR_AMG_VCYCLE, preconditioner_single=1)}
 
     def make_params(solver=args.solver, krylov=args.krylov, verify=verify):
         return capi.default_params(ilu_ordering=ordering, newton_use_gmres={"gmres": 1, "fgmres": 2}.get(krylov, 0),
@@ -472,6 +474,10 @@ def main(argv=None):
             variant("cpr_f64_%s_fixed_factor" % args.krylov, "cpr", args.krylov, dt_main, False, env={"OPMGPU_AMG_ADAPT": "0"},
                     note="the headline's solver with the pressure stage's coarse-grid corrections scaled by the fixed 1.9 instead of the "
                          "per-time-step choice between 1.9 and 2.3 (DESIGN.md section 4b; OPMGPU_AMG_ADAPT=0)")
+            for kry in sorted({args.krylov, "bicgstab"}):
+                variant("cpr_f64_%s_f32_precond" % kry, "cpr_mixed", kry, dt_main, False,
+                        note="library extension, not a reference option: the double solve (Krylov method, operator, residual, solution in double) with its whole "
+                             "preconditioner -- ILU0, pressure stage, stage-2 residual -- built and applied in float (opmgpu_params.preconditioner_single)")
             variant("cpr_f32_%s" % args.krylov, "cpr", args.krylov, dt_main, True,
                     note="NOT a configuration the reference can run (its CPR plug-in is double-only, NewtonIterationBlackoilCPR.cpp:117-140): kept for continuity")
         if use_wells:

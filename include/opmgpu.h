@@ -187,6 +187,13 @@ typedef struct opmgpu_params {
                                        CPRPreconditioner::apply does with it, as recalled), which no Krylov method notices; damping stage 2
                                        against the pressure correction is a different preconditioner -- rounds 1-3 of this library ran 0.9,
                                        which is what the Norne-like deck (isolated cells) needs to reach 1e-10: tests/test_gpu_fullsize.py */
+    int32_t preconditioner_single;  /* 0.  LIBRARY EXTENSION, 1 = mixed precision: a DOUBLE solve (single_precision = 0) builds and applies its
+                                       preconditioner -- the ILU0 factors and sweeps, under CPR also the pressure stage and the stage-2 residual --
+                                       in FLOAT; the Krylov method, its operator A, its residual and the solution stay double, so the solve meets
+                                       the same reduction on the same double system.  The preconditioner's bytes are half (the path is HBM-bound).
+                                       The reference's plug-ins have no such option: bench.py runs it as a variant, not as the headline.  Under
+                                       newton_use_gmres (left-preconditioned) reductions below ~1e-6 are out of reach of the recurrence's
+                                       residual estimate (a float M^-1 is not one fixed linear operator); BiCGStab is not limited */
     int32_t cpr_max_ell_iter;       /* 25: iteration limit of the inner solve (reaching it is NOT an error here: the outer method goes on with
                                        what the inner one attained).  0 = library extension, no inner Krylov method at all: ONE application
                                        of the elliptic preconditioner (with cpr_use_amg = 1: one V-cycle, its coarse-grid corrections scaled

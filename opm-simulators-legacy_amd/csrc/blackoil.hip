@@ -517,20 +517,21 @@ __global__ __launch_bounds__(kBlock) void k_cell_values(int nb, int nbp, DevTabl
 // bit (+: the row is c1, ngrad coefficient +1; NaN: not a connection -- the fill of an explicit well clique), g (z_c1 - z_c2), the
 // threshold pressure, and the index of the transposed entry (tpos).  All four are read coalesced at known addresses: the only dependent
 // loads of the loop are the neighbour's values.
-template <class MS, int WAVES, bool LDS, bool BATCH>
+template <class MS, int WAVES, bool LDS, bool BATCH, bool DUAL>
 __global__ __launch_bounds__(kBlock, WAVES) void k_assemble_rows(int xm, int nb, int nbp, DevTables DT, const int32_t* __restrict__ pvtnum, const int32_t* __restrict__ satnum,
                                                           const double* __restrict__ pv, const double* __restrict__ p, const double* __restrict__ sw,
                                                           const double* __restrict__ sg, const double* __restrict__ rs, const double* __restrict__ rv,
                                                           const int8_t* __restrict__ hc, double inv_dt, int initial, double s0, double s1, double s2,
                                                           const int32_t* __restrict__ slice_ptr, const int32_t* __restrict__ col, const int16_t* __restrict__ rowlen,
-                                                          const int16_t* __restrict__ nlower, const int32_t* __restrict__ tpos, const uint8_t* __restrict__ tslot,
-                                                          const double* __restrict__ tr_e, const double* __restrict__ zc, double grav, const double* __restrict__ gdz_e,
-                                                          const double* __restrict__ thp_e,
+                                                          const int16_t* __restrict__ nlower, const int32_t* __restrict__ tpos,
+                                                          const double* __restrict__ tr_e, const double* __restrict__ zc, double grav, const double* __restrict__ thp_e,
                                                           const double* __restrict__ eps, const double* __restrict__ eps_u0, const double* __restrict__ somax,
                                                           const double* __restrict__ vals, double* __restrict__ accum0, const int8_t* __restrict__ mask,
                                                           double* __restrict__ R, MS* __restrict__ A, MS* __restrict__ wout, const int32_t* __restrict__ chunk_perm,
-                                                          const double* __restrict__ tab_blob, int tab_words, HystArgs hy)
+                                                          const double* __restrict__ tab_blob, int tab_words, HystArgs hy, float* __restrict__ A32)
 {
+    // A32 != nullptr (mixed precision, opmgpu_params.preconditioner_single): every block is ALSO written as float into the preconditioner's
+    // copy of the matrix -- 250 MB more written here instead of a conversion pass that reads 500 MB and writes 250 MB before the solve
     extern __shared__ double tab_lds[];
     const int nchunks = (nb + kBlock - 1) / kBlock;
     const int lch = xcd_first(nchunks, xm);
@@ -586,41 +587,38 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_assemble_rows(int xm, int nb,
     double sod[3] = { 0.0, 0.0, 0.0 };
     int k0 = (nl == 0) ? 1 : 0;
     // per entry: the neighbour (4 B), the transmissibility with the side in its sign bit (8 B), the index of the transposed entry (4 B; as a
-    // one-byte slot of the neighbour's row it was measured slower, see assemble_kernels), the threshold pressure where the deck has one.
-    // g (z_c1 - z_c2) is formed from the depth plane: the neighbour's depth rides on the gather of its values (round 3 kept a per-entry
-    // word for it: 55 MB at 100^3 against ~16 MB now; 0.210 against 0.245 ms, profiles/r04_f_ab.log)
-    // (A/B: OPMGPU_ASM_TSLOT=0 keeps the 4-byte index, OPMGPU_ASM_GDZ=1 the per-entry g dz word: gdz_e != nullptr)
+    // one-byte slot of the neighbour's row it was measured slower: one more dependent load per connection, 0.240 against 0.210 ms), the
+    // threshold pressure where the deck has one.  g (z_c1 - z_c2) is formed from the depth plane: the neighbour's depth rides on the gather
+    // of its values (round 3 kept a per-entry word for it: 55 MB at 100^3 against ~16 MB now; 0.210 against 0.245 ms, profiles/r04_f_ab.log)
     const double z_own = zc[row];
-    int nbr_n = 0, tp_n = 0; double T_n = 0.0, th_n = 0.0, g_n = 0.0;
+    int nbr_n = 0, tp_n = 0; double T_n = 0.0, th_n = 0.0;
     if (k0 < len) {
         const long e0 = long(base + k0) * 64 + lane;
-        nbr_n = __builtin_nontemporal_load(&col[e0]); tp_n = tslot ? int(__builtin_nontemporal_load(&tslot[e0])) : __builtin_nontemporal_load(&tpos[e0]);
+        nbr_n = __builtin_nontemporal_load(&col[e0]); tp_n = __builtin_nontemporal_load(&tpos[e0]);
         T_n = __builtin_nontemporal_load(&tr_e[e0]);
-        if (gdz_e) g_n = __builtin_nontemporal_load(&gdz_e[e0]);
         if (thp_e) th_n = __builtin_nontemporal_load(&thp_e[e0]);
     }
     for (int k = k0; k < len; ) {
-        const int nbr = nbr_n; const double Te = T_n, thp = th_n, g_e = g_n;
-        const int tp = tslot ? (slice_ptr[nbr >> 6] + tp_n) * 64 + (nbr & 63) : tp_n;
+        const int nbr = nbr_n, tp = tp_n; const double Te = T_n, thp = th_n;
         const int kn = (k + 1 == nl) ? k + 2 : k + 1;
         if (kn < len) {           // the next entry's words are in flight while this one is computed
             const long en = long(base + kn) * 64 + lane;
-            nbr_n = __builtin_nontemporal_load(&col[en]); tp_n = tslot ? int(__builtin_nontemporal_load(&tslot[en])) : __builtin_nontemporal_load(&tpos[en]);
+            nbr_n = __builtin_nontemporal_load(&col[en]); tp_n = __builtin_nontemporal_load(&tpos[en]);
             T_n = __builtin_nontemporal_load(&tr_e[en]);
-            if (gdz_e) g_n = __builtin_nontemporal_load(&gdz_e[en]);
             if (thp_e) th_n = __builtin_nontemporal_load(&thp_e[en]);
         }
         MS* bptr = A + long(base + k) * 576 + lane;
+        float* bptr32 = DUAL ? A32 + long(base + k) * 576 + lane : nullptr;
         k = kn;
         if (Te != Te) {          // pure well fill: the host adds the Schur block later
 #pragma unroll
-            for (int c = 0; c < 9; ++c) bptr[c * 64] = MS(0);
+            for (int c = 0; c < 9; ++c) { bptr[c * 64] = MS(0); if (DUAL) bptr32[c * 64] = 0.f; }
             continue;
         }
         const int side = __builtin_signbit(Te) ? 1 : 0;     // side 0: this row is c1 (ngrad +1), side 1: it is c2
         const double Tf = fabs(Te);
-        double g = g_e;
-        if (!gdz_e) { const double z_n = zc[nbr]; g = grav * (side ? z_n - z_own : z_own - z_n); }      // g (z_c1 - z_c2), the expression the host evaluates per entry otherwise
+        const double z_n = zc[nbr];
+        const double g = grav * (side ? z_n - z_own : z_own - z_n);          // g (z_c1 - z_c2): the expression the host evaluated per entry in round 3
         // neighbour values that every connection needs: phase pressures and densities
         double np_[3], nrho[3];
         np_[0] = vals[long(VP_PW) * nbp + nbr]; np_[1] = p[nbr]; np_[2] = vals[long(VP_PG) * nbp + nbr];
@@ -684,6 +682,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_assemble_rows(int xm, int nb,
         // the neighbour's row sees this flux with the opposite sign: block (nbr, row) = -s scale dG / d(own); zero where that row is a ghost's
         const bool nbr_ghost = mask && !mask[nbr];
         MS* tptr = A + long(tp >> 6) * 576 + (tp & 63);
+        float* tptr32 = DUAL ? A32 + long(tp >> 6) * 576 + (tp & 63) : nullptr;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             Rl[a] += s * G[a];
@@ -693,19 +692,21 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_assemble_rows(int xm, int nb,
                 if (v == 0) sod[a] += fabs(own);
                 D[3 * a + v] += own;
                 __builtin_nontemporal_store(nbr_ghost ? MS(0) : MS(-own), &tptr[(3 * a + v) * 64]);
+                if (DUAL) __builtin_nontemporal_store(nbr_ghost ? 0.f : float(-own), &tptr32[(3 * a + v) * 64]);
             }
         }
     }
     MS* dptr = A + long(base + nl) * 576 + lane;
+    float* dptr32 = DUAL ? A32 + long(base + nl) * 576 + lane : nullptr;
     if (ghost) {
 #pragma unroll
-        for (int c = 0; c < 9; ++c) dptr[c * 64] = (c == 0 || c == 4 || c == 8) ? MS(1) : MS(0);
+        for (int c = 0; c < 9; ++c) { dptr[c * 64] = (c == 0 || c == 4 || c == 8) ? MS(1) : MS(0); if (DUAL) dptr32[c * 64] = (c == 0 || c == 4 || c == 8) ? 1.f : 0.f; }
         R[row] = 0.0; R[nbp + row] = 0.0; R[2 * long(nbp) + row] = 0.0;
         if (wout) { wout[row] = MS(1); wout[nbp + row] = MS(0); wout[2 * long(nbp) + row] = MS(0); }      // identity row: its pressure entry
         return;
     }
 #pragma unroll
-    for (int c = 0; c < 9; ++c) __builtin_nontemporal_store(MS(D[c]), &dptr[c * 64]);
+    for (int c = 0; c < 9; ++c) { __builtin_nontemporal_store(MS(D[c]), &dptr[c * 64]); if (DUAL) __builtin_nontemporal_store(float(D[c]), &dptr32[c * 64]); }
     if (wout) {
         const bool w_ = fabs(D[0]) / sod[0] > 0.01, g_ = fabs(D[6]) / sod[2] > 0.01;       // NaN (0/0) compares false like the reference's Eigen cast
         bool o_ = fabs(D[3]) / sod[1] > 0.01;
@@ -713,6 +714,19 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_assemble_rows(int xm, int nb,
         wout[row] = w_ ? MS(1) : MS(0); wout[nbp + row] = o_ ? MS(1) : MS(0); wout[2 * long(nbp) + row] = g_ ? MS(1) : MS(0);
     }
     R[row] = Rl[0]; R[nbp + row] = Rl[1]; R[2 * long(nbp) + row] = Rl[2];
+}
+
+// mixed precision: the device well model adds its own-cell derivatives to the DOUBLE diagonal blocks of the perforated cells after the
+// reservoir assembly; their float copies follow
+__global__ __launch_bounds__(kBlock) void k_refresh_f32_diag(int nperf, const int32_t* __restrict__ rows, const int32_t* __restrict__ slice_ptr,
+                                                            const int16_t* __restrict__ nlower, const double* __restrict__ A, float* __restrict__ A32)
+{
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= nperf) return;
+    const int row = rows[j];
+    const long e = long(slice_ptr[row >> 6] + nlower[row]) * 576 + (row & 63);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) A32[e + c * 64] = float(A[e + c * 64]);
 }
 
 // convergenceReduction (BlackoilModelBase_impl.hpp:1633-1714): per phase sum(1/b), sum R, non-finite flag (sums: slots 0..6),
@@ -1263,11 +1277,6 @@ void BlackoilDevice::rebuild_structure()
         }
         d_tr_e.upload(te, stream);
         if (use_thpres) d_thp_e.upload(he, stream);
-        if (std::getenv("OPMGPU_ASM_GDZ") && std::atoi(std::getenv("OPMGPU_ASM_GDZ")) != 0) {      // A/B: g dz as a per-entry word (round 3's layout)
-            std::vector<double> ge(P.nentries, 0.0);
-            for (int b = 0; b < P.nnzb; ++b) { const int c = code[b]; if (c >= 0) ge[P.entry_of_block[b]] = gravity * (h_z[h_conn[2 * (c >> 1)]] - h_z[h_conn[2 * (c >> 1) + 1]]); }
-            d_gdz_e.upload(ge, stream);
-        } else d_gdz_e.release();
         // cell depths in internal numbering: g (z_c1 - z_c2) of a connection is formed in the kernel (gravity * (z[c1] - z[c2]), the same
         // expression the reference's geometry evaluates once per face)
         std::vector<double> zi(P.nbp, 0.0);
@@ -1548,18 +1557,19 @@ template <class MS> void BlackoilDevice::assemble_kernels(double dt, bool initia
     // all ten neighbour values in one batch (default; measured 0.202 against 0.211 ms with a double Jacobian, profiles/r03_asm_batch_ab.log) or
     // the upwind-dependent five only when needed (OPMGPU_ASM_BATCH=0)
     static const bool batch = !(std::getenv("OPMGPU_ASM_BATCH") && std::atoi(std::getenv("OPMGPU_ASM_BATCH")) == 0);
-    // the transposed entry as a one-byte slot (OPMGPU_ASM_TSLOT=1) saves 21 MB of the 90 MB entry stream and was measured SLOWER than the 4-byte index:
-    // 0.240 against 0.210 ms (the slice base of the neighbour's row is one more dependent load per connection; profiles/r04_f_ab.log) -- off
-    static const bool use_tslot = std::getenv("OPMGPU_ASM_TSLOT") && std::atoi(std::getenv("OPMGPU_ASM_TSLOT")) != 0;
-    auto kern = !lds ? k_assemble_rows<MS, 2, false, false>
-                     : (waves == 3 ? (batch ? k_assemble_rows<MS, 3, true, true> : k_assemble_rows<MS, 3, true, false>)
-                                   : (batch ? k_assemble_rows<MS, 2, true, true> : k_assemble_rows<MS, 2, true, false>));
+    // mixed precision: the float copy of a DOUBLE Jacobian is written in the same pass (A/B: OPMGPU_MIXED_DUALWRITE=0 converts before the solve)
+    static const bool dual = !(std::getenv("OPMGPU_MIXED_DUALWRITE") && std::atoi(std::getenv("OPMGPU_MIXED_DUALWRITE")) == 0);
+    float* a32 = nullptr;
+    if (dual && sizeof(MS) == 8 && prm.preconditioner_single && !props_only && ls.emulate_ranks <= 1 && !(prm.use_cpr && prm.cpr_reference_transform)) { a32 = ls.matrix_f(); dual_written = true; }
+    auto kern = !lds ? k_assemble_rows<MS, 2, false, false, false>
+                     : (waves == 3 ? (batch ? k_assemble_rows<MS, 3, true, true, false> : k_assemble_rows<MS, 3, true, false, false>)
+                                   : (batch ? k_assemble_rows<MS, 2, true, true, false> : k_assemble_rows<MS, 2, true, false, false>));
+    if (a32) kern = lds ? k_assemble_rows<MS, 2, true, true, true> : k_assemble_rows<MS, 2, false, false, true>;      // (the dual-write variant: 2 waves per SIMD, no spills)
     hipLaunchKernelGGL(kern, dim3(grid8_for(nc)), dim3(kBlock), tab_lds_bytes(), stream, xcd_mode(), nc, P.nbp, dto_, d_pvtnum.p, d_satnum.p, d_pv.p,
                        d_p.p, d_sw.p, d_sg.p, d_rs.p, d_rv.p, d_hc.p, 1.0 / dt, int(initial), sc[0], sc[1], sc[2],
-                       ls.dp.slice_ptr.p, ls.dp.col.p, ls.dp.rowlen.p, ls.dp.nlower.p, ls.dp.tpos.p, use_tslot ? (const uint8_t*)ls.dp.tslot.p : (const uint8_t*)nullptr, d_tr_e.p, (const double*)d_zc.p, gravity,
-                       (const double*)d_gdz_e.p, use_thpres ? d_thp_e.p : (const double*)nullptr,
+                       ls.dp.slice_ptr.p, ls.dp.col.p, ls.dp.rowlen.p, ls.dp.nlower.p, ls.dp.tpos.p, d_tr_e.p, (const double*)d_zc.p, gravity, use_thpres ? d_thp_e.p : (const double*)nullptr,
                        eps_planes(), d_eps_u0.p, d_somax.p, (const double*)d_vals.p, d_accum0.p, ls.comm ? ls.comm->owner_mask() : (const int8_t*)nullptr, d_R.p, A, wout,
-                       (const int32_t*)ls.dp.flux_perm.p, (const double*)d_tab.p, tab_lds_words(), hyst_args());
+                       (const int32_t*)ls.dp.flux_perm.p, (const double*)d_tab.p, tab_lds_words(), hyst_args(), a32);
     ls.weights_from_assembly = wout != nullptr;
 }
 
@@ -1573,6 +1583,8 @@ void BlackoilDevice::assemble(double dt, bool initial)
     if (initial) { d_dx_old.zero(stream); ls.new_step_hint = true; }       // first matrix of a time step: coarse AMG operators are rebuilt
     const bool host_wells = nperf > 0 && !device_wells;
     ls.corr_policy.external = false;           // a matrix of the model's own assembly: the correction-factor policy may score its time steps
+    ls.float_copy_valid = false;               // (mixed precision: the float copy of the previous matrix is stale)
+    dual_written = false;
     ls.coarse_single_ok = nperf == 0;          // no wells of either kind: the global constant is the near-null-space vector
     ls.matrix_is_float = assemble_single && !host_wells;
     if (prm.update_equations_scaling) {
@@ -1598,7 +1610,14 @@ void BlackoilDevice::assemble(double dt, bool initial)
     ls.factor_early = 0;
     if (ls.factor_early_on && ls.factor_overlap && prm.use_cpr && !prm.cpr_reference_transform && ls.emulate_ranks <= 1 && !host_wells) {
         ls.wb_relax = prm.cpr_relax * prm.cpr_stage2_relax;
+        if (dual_written && !ls.matrix_is_float) {       // the float copy came with the assembly; the wells' diagonal contributions follow it
+            if (device_wells && nperf > 0)
+                hipLaunchKernelGGL(k_refresh_f32_diag, dim3(grid_for(nperf)), dim3(kBlock), 0, stream, nperf, (const int32_t*)d_perf_cells.p, ls.dp.slice_ptr.p, ls.dp.nlower.p,
+                                   (const double*)ls.matrix_d(), ls.matrix_f());
+            ls.float_copy_valid = true;
+        }
         if (ls.matrix_is_float) { ls.ensure_work<float>(); ls.factor_async<float>(); ls.factor_early = 4; }
+        else if (prm.preconditioner_single) { ls.mixed_prepare(true); ls.factor_async<float>(); ls.factor_early = 4; }      // mixed precision: the float copy, then its factors
         else { ls.ensure_work<double>(); ls.factor_async<double>(); ls.factor_early = 8; }
     }
 }

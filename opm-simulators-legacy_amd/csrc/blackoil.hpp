@@ -152,7 +152,8 @@ private:
     int tab_lds_words() const { return tab_words * 8 <= kTabLdsMaxBytes ? tab_words : 0; }
     size_t tab_lds_bytes() const { return size_t(tab_lds_words()) * 8; }
     // device: static per-cell / per-connection (internal numbering for cells)
-    DevArray<double> d_pv, d_tr_e, d_gdz_e, d_thp_e;      // per SELL entry: +-transmissibility (sign = side, NaN = well fill), threshold pressure; d_zc: cell depths (g dz is formed in the kernel)
+    bool dual_written = false;      // mixed precision: this assembly also wrote the float copy of its double Jacobian
+    DevArray<double> d_pv, d_tr_e, d_thp_e;      // per SELL entry: +-transmissibility (sign = side, NaN = well fill), threshold pressure; d_zc: cell depths (g dz is formed in the kernel)
     DevArray<int32_t> d_pvtnum, d_satnum, d_perf_cells;
     // device: state (internal numbering)
     DevArray<double> d_p, d_sw, d_so, d_sg, d_rs, d_rv;

@@ -129,17 +129,22 @@ template <class S> int solve_loaded(opmgpu_ctx* c, bool matrix_changed, SolveRes
     }
     ls.wb_relax = prm.ilu_relaxation;
     if (prm.use_cpr) ls.correction_policy_choose();
+    // mixed precision (preconditioner_single): a double solve with its preconditioner in the float work set; not with the in-place transform
+    const bool mixed = prm.preconditioner_single && sizeof(S) == 8 && !(prm.use_cpr && prm.cpr_reference_transform) && ls.emulate_ranks <= 1;
+    ls.mixed = mixed;
     ls.prepare<S>(matrix_changed);
+    if (mixed) ls.mixed_prepare(matrix_changed);
     // the reference's CPR formulation (whole-system L transform, 200-bar pressure row, ||L r|| stopping) as an option; once per matrix
     if (prm.use_cpr && prm.cpr_reference_transform) ls.cpr_reference_transform<S>();
     else { ls.border_weights = nullptr; ls.border_colscale = 1.0; }
     // next to the pressure stage's set-up (cpr_prepare, inside the solver); not in the emulated-decomposition diagnostics, whose cut copy of
     // the matrix is built lazily by whichever of the two asks first
     static const bool after_rows = !(std::getenv("OPMGPU_FACTOR_AFTER_ROWS") && std::atoi(std::getenv("OPMGPU_FACTOR_AFTER_ROWS")) == 0);      // measured +0.5 %
-    const bool early = ls.factor_early == int(sizeof(S)) && matrix_changed && !prm.cpr_reference_transform;      // the model started it behind the assembly (LinSolver::factor_early)
+    const bool early = ls.factor_early == (mixed ? 4 : int(sizeof(S))) && matrix_changed && !prm.cpr_reference_transform;      // the model started it behind the assembly (LinSolver::factor_early)
     ls.factor_early = 0;
     if (early) { /* running on the factor stream already; the first ILU0 sweep joins it */ }
-    else if (ls.factor_overlap && prm.use_cpr && ls.emulate_ranks <= 1) { if (after_rows) ls.factor_deferred = true; else ls.factor_async<S>(); }
+    else if (ls.factor_overlap && prm.use_cpr && ls.emulate_ranks <= 1) { if (after_rows) ls.factor_deferred = true; else if (mixed) ls.factor_async<float>(); else ls.factor_async<S>(); }
+    else if (mixed) (void)ls.factor<float>(false);
     else (void)ls.factor<S>(false);      // status read below: the solver's own final synchronisation covers it
     res = prm.newton_use_gmres ? ls.gmres<S>(prm) : ls.bicgstab<S>(prm);
     if (prm.use_cpr) ls.correction_policy_report(res.iterations, res.status == OPMGPU_OK);
@@ -148,7 +153,8 @@ template <class S> int solve_loaded(opmgpu_ctx* c, bool matrix_changed, SolveRes
         // (the rest of the step stays on it; the failure counts against the larger factor at once, the step's tallies start over)
         { auto& P = ls.corr_policy; P.avg[1] = P.avg[1] < 0.0 ? 4.0 * std::max(res.iterations, 1) : 2.0 * P.avg[1]; P.step_its = P.step_solves = 0; P.step_failed = false; }
         ls.corr_policy.cur = 0;
-        ls.work<S>().amg->pdamp0 = ls.work<S>().amg->pdamp = ls.corr_policy.arm[0];
+        if (mixed) ls.work<float>().amg->pdamp0 = ls.work<float>().amg->pdamp = ls.corr_policy.arm[0];
+        else ls.work<S>().amg->pdamp0 = ls.work<S>().amg->pdamp = ls.corr_policy.arm[0];
         res = prm.newton_use_gmres ? ls.gmres<S>(prm) : ls.bicgstab<S>(prm);
         ls.correction_policy_report(res.iterations, res.status == OPMGPU_OK);
     }
@@ -188,7 +194,7 @@ void opmgpu_default_params(opmgpu_params* p)
     p->newton_use_gmres = 0; p->linear_solver_restart = 40;                                // NewtonIterationBlackoilCPR.cpp:61-64
     p->solve_welleq_initially = 1; p->tolerance_wells = 1e-4; p->tolerance_well_control = 1e-7; p->dbhp_max_rel = 1.0; p->update_equations_scaling = 0; p->gmres_verify_residual = 0; p->cpr_reference_transform = 0;   // BlackoilModelParameters.cpp:80-96
     p->cpr_relax = 1.0; p->cpr_ilu_n = 0; p->cpr_use_amg = 0; p->cpr_use_bicgstab = 1;       // NewtonIterationBlackoilCPR.hpp:59-63
-    p->cpr_solver_tol = 1e-2; p->cpr_stage2_relax = 1.0; p->cpr_max_ell_iter = 25;                                       // external CPRPreconditioner (recollection, see opmgpu.h)
+    p->cpr_solver_tol = 1e-2; p->cpr_stage2_relax = 1.0; p->preconditioner_single = 0; p->cpr_max_ell_iter = 25;                                       // external CPRPreconditioner (recollection, see opmgpu.h)
 }
 
 int opmgpu_create_solver(opmgpu_ctx** ctx, int device, const opmgpu_params* params) { return make_ctx(ctx, device, params); }
@@ -273,7 +279,7 @@ int opmgpu_cpr_correction_factors(opmgpu_ctx* c, double* into_level0, double* be
 {
     if (!c || !c->ls) return OPMGPU_EINVAL;
     LinSolver& ls = *c->ls;
-    const bool f = c->cur_single == 1;
+    const bool f = c->cur_single == 1 || ls.mixed;
     if (f ? !(ls.work<float>().amg && ls.work<float>().amg->ready()) : !(ls.work<double>().amg && ls.work<double>().amg->ready())) return OPMGPU_EINVAL;
     if (into_level0) *into_level0 = f ? ls.work<float>().amg->pdamp0 : ls.work<double>().amg->pdamp0;
     if (below) *below = f ? ls.work<float>().amg->pdamp : ls.work<double>().amg->pdamp;

@@ -304,8 +304,9 @@ __global__ __launch_bounds__(kBlock) void k_ilu_factor(int lo, int hi, const int
                                                        const int32_t* __restrict__ trip_t, const S* __restrict__ A, const int16_t* __restrict__ rowlen,
                                                        S* __restrict__ lu, int32_t* __restrict__ flags, const int8_t* __restrict__ simple_row, int copy_upper)
 {
-    const int row = lo + blockIdx.x * kBlock + threadIdx.x;
-    if (row >= hi) return;
+    // grid-stride over the level's rows: the launch may be capped to a fraction of the device (LinSolver::factor_grid_cap) so that a
+    // factorisation running on its side stream leaves compute units and HBM queue slots to the latency-bound kernels of the main stream
+  for (int row = lo + blockIdx.x * kBlock + threadIdx.x; row < hi; row += gridDim.x * kBlock) {
     const int base = slice_ptr[row >> 6], lane = row & 63, nl = nlower[row];
     const int len = rowlen[row];
     const int32_t ed = (base + nl) * 64 + lane;
@@ -370,12 +371,13 @@ __global__ __launch_bounds__(kBlock) void k_ilu_factor(int lo, int hi, const int
     }
     const S c0 = m[4] * m[8] - m[5] * m[7], c1 = m[5] * m[6] - m[3] * m[8], c2 = m[3] * m[7] - m[4] * m[6];
     const S det = m[0] * c0 + m[1] * c1 + m[2] * c2;
-    if (det == S(0) || !(det == det)) { atomicOr(flags, 1); return; }
+    if (det == S(0) || !(det == det)) { atomicOr(flags, 1); continue; }
     const S id = S(1) / det;
     o[0] = c0 * id; o[1] = (m[2] * m[7] - m[1] * m[8]) * id; o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
     o[3] = c1 * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
     o[6] = c2 * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
     st9(lu, ed, o);
+  }
 }
 
 // copy the status fields to the host-mapped block (one thread; only when the solve stops / at the final check)
@@ -935,19 +937,6 @@ void DevPlan::upload(const Plan& P, hipStream_t s)
     trip_t.upload(P.trip_t.empty() ? one : P.trip_t, s);
     rowlen.upload(P.rowlen, s); nlower.upload(P.nlower, s); tpos.upload(P.tpos, s); simple.upload(P.simple, s);
     flux_perm.upload(P.flux_perm, s);
-    {
-        // the transposed entry by its slot: one byte per entry instead of tpos's four (the assembly kernel's per-entry stream)
-        bool fits = true;
-        std::vector<uint8_t> ts(P.nentries, 0);
-        for (int e = 0; e < P.nentries && fits; ++e) {
-            const int32_t tp = P.tpos[e];
-            if (tp < 0) continue;
-            const int j = P.sell_col[e];
-            const int slot = (tp >> 6) - P.slice_ptr[j >> 6];
-            if (slot < 0 || slot > 255 || (tp & 63) != (j & 63)) fits = false; else ts[e] = uint8_t(slot);
-        }
-        if (fits && P.nentries > 0) tslot.upload(ts, s); else tslot.release();
-    }
     level_ptr = P.level_ptr;
     OPMGPU_HIP(hipStreamSynchronize(s));      // the host vectors may go away
 }
@@ -983,6 +972,7 @@ LinSolver::LinSolver(hipStream_t s) : stream(s)
     if (const char* e = std::getenv("OPMGPU_HALO_OVERLAP")) halo_overlap = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_FACTOR_OVERLAP")) factor_overlap = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_FACTOR_EARLY")) factor_early_on = std::atoi(e) != 0;
+    if (const char* e = std::getenv("OPMGPU_FACTOR_GRID")) factor_grid_cap = std::atoi(e);
     if (const char* e = std::getenv("OPMGPU_CS_RECUR")) cs_recur = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_CS_FUSED")) cs_fused_env = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_AMG_AUTOTUNE")) amg_autotune = std::atoi(e) != 0;
@@ -1045,7 +1035,7 @@ template <class S> void LinSolver::ensure_work()
 
 void LinSolver::load_host_bsr(const double* val9)
 {
-    matrix_is_float = false; weights_from_assembly = false;
+    matrix_is_float = false; weights_from_assembly = false; float_copy_valid = false;
     new_step_hint = true;          // an external matrix: nothing is known about its relation to the previous one
     // every external matrix is its own "time step" with a single solve, which the correction-factor policy never scores -- one failed
     // solve would park it on the unscored larger factor for good: external matrices run the fixed first setting
@@ -1204,7 +1194,9 @@ template <class S> int LinSolver::factor(bool wait)
     for (int l = 0; l < plan.nlevels; ++l) {
         const int lo = plan.level_ptr[l], hi = plan.level_ptr[l + 1];
         if (hi == lo) continue;
-        hipLaunchKernelGGL((k_ilu_factor<S>), dim3(grid_for(hi - lo)), dim3(kBlock), 0, stream, lo, hi, dp.slice_ptr.p, dp.col.p,
+        const int gfull = grid_for(hi - lo);
+        const int gcap = (factor_throttled && factor_grid_cap > 0) ? std::min(gfull, factor_grid_cap) : gfull;
+        hipLaunchKernelGGL((k_ilu_factor<S>), dim3(gcap), dim3(kBlock), 0, stream, lo, hi, dp.slice_ptr.p, dp.col.p,
                            dp.nlower.p, dp.trip_ptr.p, dp.trip_l.p, dp.trip_u.p, dp.trip_t.p, ((emulate_what & 1) ? pre_matrix<S>() : matrix<S>()), dp.rowlen.p, w.LU.p, flags.p,
                            (const int8_t*)dp.simple.p, int(lu_copy_upper));
     }
@@ -1235,7 +1227,9 @@ template <class S> void LinSolver::factor_async()
     OPMGPU_HIP(hipStreamWaitEvent(factor_stream, ev_factor[0], 0));
     {
         StreamSwapGuard g(stream, factor_stream, kt.on);  // (event brackets belong to the main stream); restored also if factor() throws
-        (void)factor<S>(false);
+        factor_throttled = true;
+        try { (void)factor<S>(false); } catch (...) { factor_throttled = false; throw; }
+        factor_throttled = false;
     }
     OPMGPU_HIP(hipEventRecord(ev_factor[1], factor_stream));
     factor_pending = true;
@@ -2244,6 +2238,45 @@ const uint32_t* LinSolver::fetch_words(const void* src0, int nwords0, const void
     return h_pub;
 }
 
+// ---- mixed precision: float preconditioner inside a double Krylov method (opmgpu_params.preconditioner_single) ----
+void LinSolver::mixed_prepare(bool matrix_changed)
+{
+    ensure_work<float>();
+    if (matrix_is_float) { float_copy_valid = true; return; }        // (a float assembly widened for a double solve: the float buffer is the original)
+    if (float_copy_valid && !matrix_changed) return;
+    if (!float_copy_valid) {
+        const long n = long(plan.nentries) * 9;
+        hipLaunchKernelGGL((k_convert<double, float>), dim3(std::min(grid_for(n), kMaxRedBlocks)), dim3(kBlock), 0, stream, n, (const double*)Ad.p, wf.A.p);
+        float_copy_valid = true;
+    }
+}
+void LinSolver::cpr_prepare_mixed()
+{
+    const long n3 = long(3) * plan.nbp;
+    const int g = std::min(grid_for(n3), kMaxRedBlocks);
+    ensure_work<float>();
+    wf.cprw.alloc(size_t(n3));
+    if (weights_from_assembly)      // the assembly wrote the 0 / 1 weights next to the double matrix
+        hipLaunchKernelGGL((k_convert<double, float>), dim3(g), dim3(kBlock), 0, stream, n3, (const double*)wd.cprw.p, wf.cprw.p);
+    cpr_prepare<float>();
+    if (!weights_from_assembly) {   // users on the double side (the coarse-space recurrences of a decomposed BiCGStab) read wd.cprw
+        wd.cprw.alloc(size_t(n3));
+        hipLaunchKernelGGL((k_convert<float, double>), dim3(g), dim3(kBlock), 0, stream, n3, (const float*)wf.cprw.p, wd.cprw.p);
+    }
+}
+template <class S> void LinSolver::precond_apply(const S* d, S* out, double relax, const SolveCtl* ctl, bool cpr, const double* cr_given)
+{
+    if (!mixed || sizeof(S) == 4) {
+        if (cpr) cpr_apply<S>(d, out, relax, ctl, cr_given); else ilu_apply<S>(d, out, relax, ctl);
+        return;
+    }
+    const long n = long(3) * plan.nbp;
+    const int g = std::min(grid_for(n), kMaxRedBlocks);
+    hipLaunchKernelGGL((k_convert<S, float>), dim3(g), dim3(kBlock), 0, stream, n, d, wf.p.p);
+    if (cpr) cpr_apply<float>(wf.p.p, wf.y.p, relax, ctl, cr_given); else ilu_apply<float>(wf.p.p, wf.y.p, relax, ctl);
+    hipLaunchKernelGGL((k_convert<float, S>), dim3(g), dim3(kBlock), 0, stream, n, (const float*)wf.y.p, out);
+}
+
 template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
 {
     SolverWork<S>& w = work<S>();
@@ -2260,11 +2293,13 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
     // neighbours is a ghost whose entry of M^-1 p is overwritten by the halo exchange (multi-GPU: light_ok masks those rows out)
     const bool cpr = prm.use_cpr != 0;                   // multi-GPU: rank-local (additive Schwarz) AMG + block-Jacobi ILU0
     lag_allowed = prm.linear_solver_reduction >= 1e-4;
-    if (cpr) cpr_prepare<S>();
-    if (factor_deferred) { factor_deferred = false; factor_async<S>(); }
-    if (cpr && !w.amg->npost0_user) w.amg->npost0 = 2;            // post-sweeps on level 0: 2 under BiCGStab, 1 under GMRES (see gmres)
+    const bool mx = mixed && sizeof(S) == 8;
+    if (cpr) { if (mx) cpr_prepare_mixed(); else cpr_prepare<S>(); }
+    if (factor_deferred) { factor_deferred = false; if (mx) factor_async<float>(); else factor_async<S>(); }
+    if (cpr) { if (mx) { if (!wf.amg->npost0_user) wf.amg->npost0 = 2; } else if (!w.amg->npost0_user) w.amg->npost0 = 2; }   // post-sweeps on level 0: 2 under BiCGStab, 1 under GMRES (see gmres)
     // (with cpr_relax != 1 the pressure part of M^-1 p is scaled, which the closed form does not cover)
-    const bool closed = closed_form_level0 && emulate_ranks <= 1 && !(cpr && ell.relax != 1.0);      // (ell.relax = cpr_relax; under CPR prm.ilu_relaxation holds cpr_relax * cpr_stage2_relax: solve_loaded)
+    // (mixed precision: the float ILU0 is not the ILU0 of exactly the double matrix -- the closed form would be off by float rounding)
+    const bool closed = closed_form_level0 && emulate_ranks <= 1 && !(cpr && ell.relax != 1.0) && !mx;      // (ell.relax = cpr_relax; under CPR prm.ilu_relaxation holds cpr_relax * cpr_stage2_relax: solve_loaded)
     const int8_t* lightmask = nullptr;
     const bool overlap = comm && halo_overlap;
     if (comm && (closed || overlap)) {
@@ -2368,7 +2403,7 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
         hipLaunchKernelGGL((k_update_p<S>), dim3(gv), dim3(kBlock), 0, stream, n, j, eps, d_ctl, h_ctl_dev, (const double*)a_n2, (const double*)a_rho, np_n2,
                            w.r.p, w.v.p, w.p.p, csr_it);
         kt.end(KT_VECTOR, kt_a);
-        if (cpr) cpr_apply<S>(w.p.p, w.y.p, prm.ilu_relaxation, d_ctl, csr_it.Cp); else ilu_apply<S>(w.p.p, w.y.p, prm.ilu_relaxation, d_ctl);
+        precond_apply<S>(w.p.p, w.y.p, prm.ilu_relaxation, d_ctl, cpr, csr_it.Cp);
         kt_a = kt.begin();
         const int np_spmv1 = spmv_halo(std::integral_constant<int, 1>(), w.y.p, w.v.p, w.rt.p, P_h, (double*)nullptr, pin_p, zin_p);
         kt.end(KT_SPMV1, kt_a);
@@ -2380,7 +2415,7 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
         kt.end(KT_VECTOR, kt_a);
         double* a_n1 = P_n1; int np_n1 = gv; none = nullptr;
         bridge(a_n1, none, np_n1, 2, true);      // ||r||^2 of the half step is consumed by k_update_xr2: reduced together with <t,r>, <t,t> (slots 2..4)
-        if (cpr) cpr_apply<S>(w.r.p, w.y.p, prm.ilu_relaxation, d_ctl, csr_it.Cr); else ilu_apply<S>(w.r.p, w.y.p, prm.ilu_relaxation, d_ctl);
+        precond_apply<S>(w.r.p, w.y.p, prm.ilu_relaxation, d_ctl, cpr, csr_it.Cr);
         kt_a = kt.begin();
         const int np_spmv2 = spmv_halo(std::integral_constant<int, 2>(), w.y.p, w.t.p, w.r.p, P_tr, P_tt, pin_r, zin_r);
         kt.end(KT_SPMV2, kt_a);
@@ -2731,11 +2766,12 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
     // applies the lag policy of the BiCGStab path (cpr_prepare) -- measured: no gain on the 5-spot deck
     static const bool gm_lag = std::getenv("OPMGPU_GMRES_LAG") && std::atoi(std::getenv("OPMGPU_GMRES_LAG")) != 0;
     lag_allowed = gm_lag && prm.linear_solver_reduction >= 1e-4;
-    if (cpr) cpr_prepare<S>();
-    if (factor_deferred) { factor_deferred = false; factor_async<S>(); }
+    const bool mx = mixed && sizeof(S) == 8;
+    if (cpr) { if (mx) cpr_prepare_mixed(); else cpr_prepare<S>(); }
+    if (factor_deferred) { factor_deferred = false; if (mx) factor_async<float>(); else factor_async<S>(); }
     // one post-smoothing sweep on level 0 instead of two: measured over nine decks with wells +1..+5 % under GMRES (the same iteration
     // counts within 0.1, a cheaper cycle), -7..0 % under BiCGStab on the well-free decks (profiles/r02_amg_sweep_gmres.log)
-    if (cpr && !w.amg->npost0_user) w.amg->npost0 = 1;
+    if (cpr) { if (mx) { if (!wf.amg->npost0_user) wf.amg->npost0 = 1; } else if (!w.amg->npost0_user) w.amg->npost0 = 1; }
     w.kry.alloc(size_t(m + 1) * n);
     // newton_use_gmres = 2: flexible (right-preconditioned) GMRES -- z_i = M^-1 v_i is KEPT, w = A z_i is orthogonalised, x += sum y_i z_i.
     // Not the reference's solver: Dune's RestartedGMResSolver (value 1) applies M from the left, which costs one application more per
@@ -2792,7 +2828,7 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
                            (double*)nullptr, (double*)nullptr, (const S*)nullptr, (const S*)nullptr, 0, S(0), lowrank, (const int8_t*)nullptr);
     };
     auto V = [&](int k) { return w.kry.p + size_t(k) * n; };
-    auto precond = [&](const S* d, S* out) { if (cpr) cpr_apply<S>(d, out, prm.ilu_relaxation, d_ctl); else ilu_apply<S>(d, out, prm.ilu_relaxation, d_ctl); };
+    auto precond = [&](const S* d, S* out) { precond_apply<S>(d, out, prm.ilu_relaxation, d_ctl, cpr); };
     auto Z = [&](int k) { return w.kryz.p + size_t(k) * n; };
     auto normalize_start = [&](S* src, int first) {          // v0 = src / ||src||, s[0] = ||src||  (src = M^-1 defect, flexible: the defect)
         if (fuse_halo) {        // ||src||^2 over the owned rows and src's halo in one operation: v0 then carries the owners' ghost values
@@ -3079,6 +3115,7 @@ double LinSolver::time_kernel(int kernel, int reps, int single_precision)
     template void LinSolver::coarse_begin<S>();                                          \
     template void LinSolver::cpr_apply<S>(const S*, S*, double, const SolveCtl*, const double*);        \
     template void LinSolver::factor_async<S>();                                          \
+    template void LinSolver::precond_apply<S>(const S*, S*, double, const SolveCtl*, bool, const double*); \
     template SolveResult LinSolver::bicgstab<S>(const opmgpu_params&);                   \
     template SolveResult LinSolver::gmres<S>(const opmgpu_params&);                      \
     template void LinSolver::vec_from_host<S>(const double*, int, S*);                   \

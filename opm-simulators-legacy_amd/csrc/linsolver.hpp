@@ -17,7 +17,6 @@ struct DevPlan {
     DevArray<int32_t> slice_ptr, col, src, entry_of_block, nat, pos, trip_ptr, trip_l, trip_u, trip_t, tpos, flux_perm;
     DevArray<int16_t> rowlen, nlower;
     DevArray<int8_t> simple;
-    DevArray<uint8_t> tslot;        // [nentries] SLOT of the transposed entry in the neighbour's row (tpos = (slice_ptr[col >> 6] + tslot) * 64 + (col & 63)); empty when a row has > 255 slots
     std::vector<int32_t> level_ptr;
     void upload(const Plan& P, hipStream_t s);
 };
@@ -191,6 +190,13 @@ public:
     void correction_policy_report(int iterations, bool converged);
     bool amg_autotune = false;      // OPMGPU_AMG_AUTOTUNE=1: experiment, measured NOT robust; default: 1.9 (2.2 into level 0 on one well-free subdomain)
     // x0 = 0; rhs in work<S>().b; solution in work<S>().x
+    // opmgpu_params.preconditioner_single: a double solve whose preconditioner lives in the FLOAT work set (wf: float matrix copy, float ILU0
+    // factors, float pressure hierarchy); the Krylov method converts the vector it hands over and the one it gets back.  Set per solve.
+    bool mixed = false;
+    bool float_copy_valid = false;       // wf.A holds the current matrix (written by mixed_prepare; reset by whoever writes a new matrix)
+    void mixed_prepare(bool matrix_changed);
+    void cpr_prepare_mixed();
+    template <class S> void precond_apply(const S* d, S* out, double relax, const SolveCtl* ctl, bool cpr, const double* cr_given = nullptr);
     template <class S> SolveResult bicgstab(const opmgpu_params& prm);
     template <class S> SolveResult gmres(const opmgpu_params& prm);      // newton_use_gmres: restarted, left-preconditioned
 
@@ -280,6 +286,11 @@ public:
     // factorisation for the current matrix; solve_loaded then does not start another.  A/B: OPMGPU_FACTOR_EARLY=0
     bool factor_early_on = true;
     int factor_early = 0;          // 0 = not started; 4 / 8 = started for the float / double matrix
+    // A factorisation on its side stream has slack (it is needed by the first ILU0 sweep, ~0.6 ms later): capped to `factor_grid_cap` workgroups
+    // it runs longer but leaves the latency-bound kernels of the main stream their compute units and memory-queue slots.  0 = uncapped.
+    // A/B: OPMGPU_FACTOR_GRID
+    int factor_grid_cap = 0;
+    bool factor_throttled = false;
     DevArray<double> cgs_parts;          // decomposed GMRES, classical Gram-Schmidt: (restart + 1) partial arrays + their all-reduced sums
     bool factor_deferred = false;        // factor_async() is started by cpr_prepare() behind its pass over the matrix
     hipStream_t factor_stream = nullptr;

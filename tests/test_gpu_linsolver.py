@@ -288,6 +288,47 @@ def test_gmres_option(gpu_lib, oracle, single):
     s.close()
 
 
+@pytest.mark.parametrize("cpr", [0, 1])
+def test_float_preconditioner_inside_a_double_solve(gpu_lib, oracle, cpr):
+    """opmgpu_params.preconditioner_single (library extension): the double Krylov method with its preconditioner built and applied in float.
+    The solve is still a solve of the DOUBLE system: BiCGStab reaches 1e-10 on the true residual (checked with an independent product)
+    and the direct solution; GMRES (left-preconditioned: its recurrence sees a float M^-1) at the reductions Newton solves ask for."""
+    grid = decks.cartesian_grid(12, 10, 8, lognormal_sigma=0.8)
+    tab = decks.satfunc_standard_tables()
+    st = decks.initial_state(grid, tab, perturb=0.01)
+    prm0 = capi.default_params()
+    scale = np.asarray(prm0.matbalscale[:])
+    rowptr, col = oracle.pattern(grid)
+    nc = grid.nc
+    r, val, _, _ = oracle.assemble(grid, tab, 5 * decks.DAY, st, rowptr, col, scale=tuple(scale))
+    b = np.ascontiguousarray((r * np.repeat(scale, nc)).reshape(3, nc).T).ravel()
+    A = bsr_to_scipy(rowptr, col, val)
+    xe = spla.spsolve(A.tocsc(), b)
+    kw = dict(capi.CPR_AMG_VCYCLE) if cpr else dict()
+    its = {}
+    for mixed in (0, 1):
+        s = GpuNewtonIteration(capi.default_params(preconditioner_single=mixed, linear_solver_reduction=1e-10, linear_solver_maxiter=400, **kw))
+        x = s.computeNewtonIncrement(rowptr, col, val, b, False)
+        its[mixed] = s.iterations()
+        assert np.linalg.norm(b - A @ x) <= 1.01e-10 * np.linalg.norm(b), (cpr, mixed)
+        assert np.linalg.norm(x - xe) <= 1e-7 * np.linalg.norm(xe), (cpr, mixed)
+        s.close()
+    assert its[1] <= its[0] + max(2, its[0] // 5), its          # a float preconditioner is as good a preconditioner
+    for red in (1e-2, 1e-5):
+        s = GpuNewtonIteration(capi.default_params(preconditioner_single=1, newton_use_gmres=1, linear_solver_reduction=red, linear_solver_maxiter=200, **kw))
+        x = s.computeNewtonIncrement(rowptr, col, val, b, False)
+        s0 = GpuNewtonIteration(capi.default_params(newton_use_gmres=1, linear_solver_reduction=red, linear_solver_maxiter=200, **kw))
+        x0 = s0.computeNewtonIncrement(rowptr, col, val, b, False)
+        assert abs(s.iterations() - s0.iterations()) <= 1, (cpr, red, s.iterations(), s0.iterations())
+        assert np.linalg.norm(x - x0) <= 20 * red * np.linalg.norm(x0), (cpr, red)
+        s.close(); s0.close()
+    # a FLOAT solve ignores the switch (its preconditioner is float anyway)
+    s = GpuNewtonIteration(capi.default_params(preconditioner_single=1, linear_solver_reduction=1e-4, linear_solver_maxiter=200, **kw))
+    x = s.computeNewtonIncrement(rowptr, col, val, b, True)
+    assert np.linalg.norm(b - A @ x) <= 2e-4 * np.linalg.norm(b)
+    s.close()
+
+
 def test_gmres_verify_with_float_vectors(gpu_lib, oracle, monkeypatch):
     """gmres_verify_residual with a FLOAT solve: the documented range -- reductions down to 1e-3 -- is met on the TRUE residual
     (checked with an independent double product), also with the speculative product of the next column enqueued ahead of the verdict

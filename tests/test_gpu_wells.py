@@ -279,6 +279,8 @@ CPR_VARIANTS = {
     "amg_inner_cg": dict(use_cpr=1, cpr_use_amg=1, cpr_use_bicgstab=0),
     "amg_vcycle_relax_0.9": dict(use_cpr=1, cpr_use_amg=1, cpr_max_ell_iter=0, cpr_relax=0.9),
     "reference_defaults_relax_0.9_tight_inner": dict(use_cpr=1, cpr_relax=0.9, cpr_solver_tol=1e-4, cpr_max_ell_iter=60),
+    # library extension: the whole preconditioner (ILU0, pressure stage, stage-2 residual) in float inside the double Krylov method
+    "amg_vcycle_float_preconditioner": dict(use_cpr=1, cpr_use_amg=1, cpr_max_ell_iter=0, preconditioner_single=1),
 }
 
 
