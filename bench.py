@@ -591,11 +591,11 @@ def main(argv=None):
         else:
             lin_name = "ilu0(relax %g) + %s" % (prm.ilu_relaxation, kry)
         if prm.use_cpr and not single_main and prm.newton_use_gmres != 2:
-            equiv = "solver_approach=cpr cpr_use_amg=%s%s cpr_relax=%g in double (NewtonIterationBlackoilCPR.hpp:59-63, .cpp:61-64,117-140)" % (
+            equiv = "solver_approach=cpr cpr_use_amg=%s%s cpr_relax=%g in double (NewtonIterationBlackoilCPR.hpp:59-63, .cpp:117-140)" % (
                 "true" if prm.cpr_use_amg else "false", " newton_use_gmres=true" if prm.newton_use_gmres else "", prm.cpr_relax)
             if prm.cpr_use_amg and prm.cpr_max_ell_iter == 0:
-                equiv += ("; DIFFERS in the pressure stage: ONE AMG V-cycle per application (cpr_max_ell_iter=0, library extension) where the reference's external "
-                          "CPRPreconditioner runs an AMG-preconditioned inner BiCGStab -> variants.cpr_amg_inner_bicgstab")
+                equiv += ("; DIFFERS in the pressure stage: ONE V-cycle per application (cpr_max_ell_iter=0, library extension), the reference's "
+                          "CPRPreconditioner wraps the AMG in an inner BiCGStab -> variants.cpr_amg_inner_bicgstab")
         elif not prm.use_cpr and single_main == reference_single("ilu0", dt_main) and not prm.newton_use_gmres:
             equiv = "reference default (solver_approach=interleaved)"
         else:
@@ -621,8 +621,7 @@ def main(argv=None):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(main_sum["ms_per_step"], 4),
             "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
             "dtype": "f32" if single_main else "f64", "data": "synthetic",
-            "value_basis": "cells / median ms of the timed Newton iterations that include a linear solve (SURVEY 8d M1)" if res["solving_ms"] is not None
-                           else "cells / mean ms of the timed calls (no per-call marks in this mode)",
+            "value_basis": "cells / median ms of the timed calls with a linear solve (SURVEY 8d M1)" if res["solving_ms"] is not None else "cells / mean ms of the timed calls",
             "ms_per_solving_iteration_median": r3(main_sum["ms_per_solving_iteration_median"]),
             "ms_per_solving_iteration_mean": r3(main_sum["ms_per_solving_iteration_mean"]),
             "value_mean_solving": r3(main_sum["value_mean_solving"]), "value_all_calls_mean": r3(main_sum["value_all_calls_mean"]),
@@ -639,7 +638,7 @@ def main(argv=None):
                                                         if k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "ms_per_launch", "algorithmic_bytes")},
             "cpu_baseline": None if cpu is None else {"value": round(cpu["value"], 4), "unit": cpu["unit"], "cores": cpu["cores"], "kind": cpu["kind"], "sample": cpu["sample"]},
             "cpu_all_cores": None if cpu_all is None else {"value": round(cpu_all["value"], 4), "cores": cpu_all["cores"]},
-            "variants_columns": "[Mcell-updates/s, newton its per time step, ms per converged time step, ms per simulated day]",
+            "variants_columns": "[Mcell-updates/s, newton its / time step, ms / converged time step, ms / simulated day]",
             "variants": compact_variants(variants),
             "decks": compact_variants(other_decks),
             "detail": os.path.basename(args.detail),

@@ -13,7 +13,9 @@ export TMPDIR=/tmp
 python3 bench.py --detail $OUT/bench_detail.json > $OUT/bench_line.json 2> $OUT/bench.err
 echo "bench done"; tail -c 600 $OUT/bench_line.json; echo
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o run -- python3 $ROOT/bench.py --no-cpu-baseline --detail $OUT/bench_detail_under_rocprof.json > $OUT/bench_line_under_rocprof.json 2> $OUT/rocprof.err
+# (the profiled command leaves out the CPU baseline and the other decks: the per-kernel averages then belong to the 100^3 deck alone, which is what
+# bench.py's roofline object times -- with the SPE9-like / Norne-like legs in, k_spmv's average is a mix of 9 000-cell and 1 M-cell launches)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o run -- python3 $ROOT/bench.py --no-cpu-baseline --no-other-decks --detail $OUT/bench_detail_under_rocprof.json > $OUT/bench_line_under_rocprof.json 2> $OUT/rocprof.err
 find $OUT/trace -name 'run_kernel_trace.csv' -delete          # hundreds of MB for the whole run; the per-kernel statistics stay
 echo "stats done"
 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_main -o run -- python3 $ROOT/bench.py --only-main --no-cpu-baseline --stat-calls 20 --detail $OUT/bench_detail_trace_main.json > $OUT/bench_line_trace_main.json 2> $OUT/rocprof_main.err
