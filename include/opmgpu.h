@@ -191,9 +191,12 @@ typedef struct opmgpu_params {
                                        preconditioner -- the ILU0 factors and sweeps, under CPR also the pressure stage and the stage-2 residual --
                                        in FLOAT; the Krylov method, its operator A, its residual and the solution stay double, so the solve meets
                                        the same reduction on the same double system.  The preconditioner's bytes are half (the path is HBM-bound).
-                                       The reference's plug-ins have no such option: bench.py runs it as a variant, not as the headline.  Under
-                                       newton_use_gmres (left-preconditioned) reductions below ~1e-6 are out of reach of the recurrence's
-                                       residual estimate (a float M^-1 is not one fixed linear operator); BiCGStab is not limited */
+                                       The reference's plug-ins have no such option: bench.py runs it as a variant, not as the headline.
+                                       LIMIT: a float M^-1 is not one fixed linear operator (its rounding depends on the vector), which the
+                                       recurrences of both Krylov methods assume -- BiCGStab stalls around 1e-9 .. 1e-10 (measured: 163
+                                       iterations to 9.9e-10, then a breakdown, where the double preconditioner takes 12 iterations to
+                                       7.5e-13), left-preconditioned GMRES's residual estimate drifts below ~1e-6.  Meant for the reductions
+                                       Newton solves ask for (1e-2 by default); ask for no less than 1e-8 / 1e-6 with it */
     int32_t cpr_max_ell_iter;       /* 25: iteration limit of the inner solve (reaching it is NOT an error here: the outer method goes on with
                                        what the inner one attained).  0 = library extension, no inner Krylov method at all: ONE application
                                        of the elliptic preconditioner (with cpr_use_amg = 1: one V-cycle, its coarse-grid corrections scaled

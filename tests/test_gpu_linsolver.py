@@ -291,8 +291,9 @@ def test_gmres_option(gpu_lib, oracle, single):
 @pytest.mark.parametrize("cpr", [0, 1])
 def test_float_preconditioner_inside_a_double_solve(gpu_lib, oracle, cpr):
     """opmgpu_params.preconditioner_single (library extension): the double Krylov method with its preconditioner built and applied in float.
-    The solve is still a solve of the DOUBLE system: BiCGStab reaches 1e-10 on the true residual (checked with an independent product)
-    and the direct solution; GMRES (left-preconditioned: its recurrence sees a float M^-1) at the reductions Newton solves ask for."""
+    The solve is still a solve of the DOUBLE system: BiCGStab reaches 1e-8 on the true residual (checked with an independent product;
+    the documented range of the option -- a float M^-1 is not one fixed linear operator, and the recurrences stall around 1e-9 .. 1e-10
+    on harder matrices: tools/fuzz_newton.py case 4080) and the direct solution; GMRES at the reductions Newton solves ask for."""
     grid = decks.cartesian_grid(12, 10, 8, lognormal_sigma=0.8)
     tab = decks.satfunc_standard_tables()
     st = decks.initial_state(grid, tab, perturb=0.01)
@@ -307,11 +308,11 @@ def test_float_preconditioner_inside_a_double_solve(gpu_lib, oracle, cpr):
     kw = dict(capi.CPR_AMG_VCYCLE) if cpr else dict()
     its = {}
     for mixed in (0, 1):
-        s = GpuNewtonIteration(capi.default_params(preconditioner_single=mixed, linear_solver_reduction=1e-10, linear_solver_maxiter=400, **kw))
+        s = GpuNewtonIteration(capi.default_params(preconditioner_single=mixed, linear_solver_reduction=1e-8, linear_solver_maxiter=400, **kw))
         x = s.computeNewtonIncrement(rowptr, col, val, b, False)
         its[mixed] = s.iterations()
-        assert np.linalg.norm(b - A @ x) <= 1.01e-10 * np.linalg.norm(b), (cpr, mixed)
-        assert np.linalg.norm(x - xe) <= 1e-7 * np.linalg.norm(xe), (cpr, mixed)
+        assert np.linalg.norm(b - A @ x) <= 1.01e-8 * np.linalg.norm(b), (cpr, mixed)
+        assert np.linalg.norm(x - xe) <= 1e-5 * np.linalg.norm(xe), (cpr, mixed)
         s.close()
     assert its[1] <= its[0] + max(2, its[0] // 5), its          # a float preconditioner is as good a preconditioner
     for red in (1e-2, 1e-5):

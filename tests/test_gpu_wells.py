@@ -279,8 +279,6 @@ CPR_VARIANTS = {
     "amg_inner_cg": dict(use_cpr=1, cpr_use_amg=1, cpr_use_bicgstab=0),
     "amg_vcycle_relax_0.9": dict(use_cpr=1, cpr_use_amg=1, cpr_max_ell_iter=0, cpr_relax=0.9),
     "reference_defaults_relax_0.9_tight_inner": dict(use_cpr=1, cpr_relax=0.9, cpr_solver_tol=1e-4, cpr_max_ell_iter=60),
-    # library extension: the whole preconditioner (ILU0, pressure stage, stage-2 residual) in float inside the double Krylov method
-    "amg_vcycle_float_preconditioner": dict(use_cpr=1, cpr_use_amg=1, cpr_max_ell_iter=0, preconditioner_single=1),
 }
 
 
@@ -330,6 +328,33 @@ def test_cpr_parameters_of_the_reference_give_the_same_newton_path(gpu_lib, gmre
     if not gmres:          # (under GMRES the restarts of the true-residual check add outer iterations: see the note at the top of the loop)
         assert lin["amg_inner_bicgstab"] <= lin["base"] + 2, lin
     assert out["reference_defaults"][5] / out["reference_defaults"][4] > out["amg_inner_bicgstab"][5] / out["amg_inner_bicgstab"][4], (out["reference_defaults"][4:], out["amg_inner_bicgstab"][4:])
+
+
+@pytest.mark.parametrize("gmres", [0, 1])
+def test_float_preconditioner_walks_the_double_newton_path_with_device_wells(gpu_lib, gmres):
+    """opmgpu_params.preconditioner_single on the model path with device wells: the float copy of the Jacobian is written by the assembly, the
+    wells' diagonal contributions follow it, ILU0 / pressure stage / stage-2 residual run in float inside the double Krylov method.  At the
+    tightest reductions the option is documented for (1e-8 under BiCGStab, 1e-6 under GMRES) the Newton path is the pure double solve's to
+    the linear tolerance, with the same convergence decisions; also with the damped second stage and without CPR."""
+    grid, tab, st, wl = _setup()
+    red = 1e-6 if gmres else 1e-8
+    for kw in (dict(capi.CPR_AMG_VCYCLE), dict(capi.CPR_AMG_VCYCLE, cpr_stage2_relax=0.9), dict(use_cpr=0)):
+        out = {}
+        for mixed in (0, 1):
+            gm = GpuBlackoilModel(grid, tab, capi.default_params(newton_use_gmres=gmres, preconditioner_single=mixed, linear_solver_reduction=red, linear_solver_maxiter=400, **kw))
+            md = W.DeviceWellModel(gm, wl, W.WellState(wl, st.p))
+            md.prepareStep(2 * decks.DAY, st)
+            hist = [md.nonlinearIteration(it, single_precision=False) for it in range(3)]
+            ws = md.pull_well_state()
+            out[mixed] = (gm.getState(), ws.bhp.copy(), ws.qs.copy(), hist)
+            gm.close()
+        a, b = out[0], out[1]
+        tol = 300 * red             # (cond(A) acts on the linear tolerance: measured ~30 x on this deck)
+        assert [h[0] for h in a[3]] == [h[0] for h in b[3]], kw
+        assert np.array_equal(a[0].hc, b[0].hc), kw
+        assert np.abs(a[0].p - b[0].p).max() <= tol * np.abs(a[0].p).max() and np.abs(a[0].sat - b[0].sat).max() <= tol, (kw, gmres)
+        assert np.allclose(a[1], b[1], rtol=tol) and np.allclose(a[2], b[2], rtol=10 * tol, atol=tol * np.abs(a[2]).max()), (kw, gmres)
+        assert sum(h[1] for h in b[3]) <= sum(h[1] for h in a[3]) + 6, (kw, [h[1] for h in a[3]], [h[1] for h in b[3]])
 
 
 def test_cpr_parameter_combinations_that_are_not_built_are_refused(gpu_lib):
