@@ -169,7 +169,13 @@ typedef struct opmgpu_params {
                                         1 = the reference's formulation for comparability (NewtonIterationUtilities.cpp:253-287,
                                             NewtonIterationBlackoilCPR.cpp:117-131): the WHOLE system is row-transformed by L (per cell: its
                                             first equation is replaced by the sum of the dominant equations), the pressure row scaled by
-                                            200 bar, and the Krylov method iterates on (and measures) L A x = L b */
+                                            200 bar, and the Krylov method iterates on (and measures) L A x = L b;
+                                        2 = 1, and the second stage is the reference's own: a POINT ILU0 of L A taken as a scalar matrix in
+                                            equation-major order (`DuneMatrix istlA(A)`, NewtonIterationBlackoilCPR.cpp:129-133), where 0 and
+                                            1 keep the 3x3-block ILU0.  With ilu_ordering = OPMGPU_ORDER_NATURAL this is dune's elimination
+                                            order: linear iteration counts become comparable one to one with a solver_approach=cpr run of
+                                            flow_legacy.  Double, single GPU; a comparison mode (the scalar plan's index lists take ~3.6 GB
+                                            at 10^6 cells and a minute of host time per pattern) */
     /* --- the reference's CPR parameters (NewtonIterationBlackoilCPR.hpp:59-63 documents the first four with these defaults; they are read
      *     by the external opm-simulators CPRPreconditioner, whose source is NOT under /root/reference) ------------------------------------ */
     double cpr_relax;               /* 1.0: relaxation of the CPR preconditioner -- the ILU0 of stage 2 is built with it INSTEAD of
@@ -209,6 +215,9 @@ int opmgpu_get_matbalscale(opmgpu_ctx* ctx, double* scale3);
 /* CPR with an inner Krylov method on the elliptic part (cpr_max_ell_iter > 0; the reference's external CPRPreconditioner::solveElliptic,
  * reached from NewtonIterationBlackoilCPR.cpp:148-165): inner solves and inner iterations since the context was created */
 int opmgpu_cpr_elliptic_stats(opmgpu_ctx* ctx, int64_t* solves, int64_t* iterations);
+/* diagnostic of cpr_reference_transform = 2: v = relax * (L U)^-1 d with the point ILU0 of the last such solve's (transformed) matrix;
+ * d3 / v3 block-interleaved like opmgpu_ilu0_apply.  tests/test_gpu_linsolver.py checks it against a numpy ILU0 of the scalar matrix. */
+int opmgpu_point_ilu_apply(opmgpu_ctx* ctx, const double* d3, double* v3, double relax);
 /* diagnostic: the scaling of the pressure cycle's coarse-grid corrections the LAST CPR solve ran with (into level 0 / below it; DESIGN.md
  * section 4b: 1.9, or the per-time-step choice between 1.9 and 2.3 on matrices of the model's own assembly -- external matrices of the B1
  * path keep 1.9).  OPMGPU_EINVAL before the first CPR solve. */

@@ -137,12 +137,20 @@ template <class S> int solve_loaded(opmgpu_ctx* c, bool matrix_changed, SolveRes
     // the reference's CPR formulation (whole-system L transform, 200-bar pressure row, ||L r|| stopping) as an option; once per matrix
     if (prm.use_cpr && prm.cpr_reference_transform) ls.cpr_reference_transform<S>();
     else { ls.border_weights = nullptr; ls.border_colscale = 1.0; }
+    // cpr_reference_transform = 2: the reference's own second stage, a point ILU0 of the transformed system as a scalar equation-major matrix
+    ls.point_stage2 = prm.use_cpr && prm.cpr_reference_transform == 2;
+    if (ls.point_stage2) {
+        if (sizeof(S) != 8) return fail(c, OPMGPU_EINVAL, "cpr_reference_transform = 2 (point ILU0 of the scalar system) is double only, like the reference's CPR plug-in");
+        if (ls.comm || ls.emulate_ranks > 1) return fail(c, OPMGPU_EINVAL, "cpr_reference_transform = 2 is a single-GPU comparison mode");
+        if (ls.pilu.stale) { ls.point_ilu_factor(); ls.pilu.stale = false; }
+    }
     // next to the pressure stage's set-up (cpr_prepare, inside the solver); not in the emulated-decomposition diagnostics, whose cut copy of
     // the matrix is built lazily by whichever of the two asks first
     static const bool after_rows = !(std::getenv("OPMGPU_FACTOR_AFTER_ROWS") && std::atoi(std::getenv("OPMGPU_FACTOR_AFTER_ROWS")) == 0);      // measured +0.5 %
     const bool early = ls.factor_early == (mixed ? 4 : int(sizeof(S))) && matrix_changed && !prm.cpr_reference_transform;      // the model started it behind the assembly (LinSolver::factor_early)
     ls.factor_early = 0;
-    if (early) { /* running on the factor stream already; the first ILU0 sweep joins it */ }
+    if (ls.point_stage2) { /* the point ILU0 above is the second stage: no block factorisation */ }
+    else if (early) { /* running on the factor stream already; the first ILU0 sweep joins it */ }
     else if (ls.factor_overlap && prm.use_cpr && ls.emulate_ranks <= 1) { if (after_rows) ls.factor_deferred = true; else if (mixed) ls.factor_async<float>(); else ls.factor_async<S>(); }
     else if (mixed) (void)ls.factor<float>(false);
     else (void)ls.factor<S>(false);      // status read below: the solver's own final synchronisation covers it
@@ -163,7 +171,7 @@ template <class S> int solve_loaded(opmgpu_ctx* c, bool matrix_changed, SolveRes
         ls.force_refresh = true; ls.lag_block = 8;
         res = prm.newton_use_gmres ? ls.gmres<S>(prm) : ls.bicgstab<S>(prm);
     }
-    if (ls.factor_status() != OPMGPU_OK) { c->factored = false; return fail(c, OPMGPU_ESINGULAR, "singular diagonal block in ILU0"); }
+    if (!ls.point_stage2 && ls.factor_status() != OPMGPU_OK) { c->factored = false; return fail(c, OPMGPU_ESINGULAR, "singular diagonal block in ILU0"); }
     c->factored = true;
     if (res.status == OPMGPU_ELINSOLVE) c->err = "Convergence failure for linear solver.";
     if (res.status == OPMGPU_EBREAKDOWN) c->err = "breakdown in BiCGSTAB";
@@ -698,6 +706,20 @@ int opmgpu_ilu0_apply(opmgpu_ctx* c, const double* d3, double* v3)
         LinSolver& ls = *c->ls;
         if (c->cur_single) { auto& w = ls.work<float>(); ls.vec_from_host<float>(d3, VEC_BLOCK_INTERLEAVED, w.p.p); ls.ilu_apply<float>(w.p.p, w.y.p, c->prm.ilu_relaxation, nullptr); ls.vec_to_host<float>(w.y.p, VEC_BLOCK_INTERLEAVED, v3); }
         else { auto& w = ls.work<double>(); ls.vec_from_host<double>(d3, VEC_BLOCK_INTERLEAVED, w.p.p); ls.ilu_apply<double>(w.p.p, w.y.p, c->prm.ilu_relaxation, nullptr); ls.vec_to_host<double>(w.y.p, VEC_BLOCK_INTERLEAVED, v3); }
+        return int(OPMGPU_OK);
+    });
+}
+
+int opmgpu_point_ilu_apply(opmgpu_ctx* c, const double* d3, double* v3, double relax)
+{
+    if (!c || !d3 || !v3) return OPMGPU_EINVAL;
+    if (!c->ls || !c->ls->pilu.built || c->ls->pilu.stale) return fail(c, OPMGPU_EINVAL, "solve once with cpr_reference_transform = 2 first");
+    return guarded(c, [&]() {
+        LinSolver& ls = *c->ls;
+        auto& w = ls.work<double>();
+        ls.vec_from_host<double>(d3, VEC_BLOCK_INTERLEAVED, w.p.p);
+        ls.point_ilu_apply(w.p.p, w.y.p, relax);
+        ls.vec_to_host<double>(w.y.p, VEC_BLOCK_INTERLEAVED, v3);
         return int(OPMGPU_OK);
     });
 }

@@ -1013,6 +1013,7 @@ int LinSolver::set_pattern(int nb, const int32_t* rowptr, const int32_t* col, in
     plan.rowptr.clear();
     plan = std::move(P);
     cur_ordering = ordering;
+    ++plan_id;
     dp.upload(plan, stream);
     Ad.alloc(size_t(plan.nentries) * 9);
     Ad.zero(stream);
@@ -1864,6 +1865,7 @@ template <class S> void LinSolver::cpr_reference_transform()
         border_weights = w.cprw_orig.p; border_colscale = pscale;
         ref_transformed = true;
         pre_stale = true;
+        pilu.stale = true;
     }
     hipLaunchKernelGGL((k_ref_transform_vec<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, plan.nbp, pscale, (const S*)w.cprw_orig.p, w.b.p);
 }
@@ -2068,6 +2070,7 @@ static void allreduce_halo(CommBase* c, double* d, int n, float* v, hipStream_t 
 static void allreduce_halo(CommBase* c, double* d, int n, double* v, hipStream_t s);
 
 #include "elliptic.inl"
+#include "pointilu.inl"
 
 // M^-1 d = [x_p;0;0] + ILU0^-1 (d - A [x_p;0;0]),  x_p = Vcycle(sum of the equations of d) -- or the inner Krylov solve of elliptic.inl
 template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, const SolveCtl* ctl, const double* cr_given)
@@ -2179,7 +2182,8 @@ template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, con
                            2, (const int8_t*)light_ok.p);
     }
     kt.end(KT_CPR_OTHER, kt_a);
-    ilu_apply<S>(w.z.p, v, relax, ctl);
+    if (point_stage2 && sizeof(S) == 8) point_ilu_apply(reinterpret_cast<const double*>(w.z.p), reinterpret_cast<double*>(v), relax);      // the reference's own stage 2 (pointilu.inl)
+    else ilu_apply<S>(w.z.p, v, relax, ctl);
     kt_a = kt.begin();
     if (well_woodbury && wb_active && lowrank.nw > 0 && lowrank.P && !comm && wb_buf.p)
         hipLaunchKernelGGL((k_wb_apply<S>), dim3(lowrank.nw), dim3(kBlock), 0, stream, lowrank, plan.nbp, (const double*)wb_buf.p,
@@ -2299,7 +2303,7 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
     if (cpr) { if (mx) { if (!wf.amg->npost0_user) wf.amg->npost0 = 2; } else if (!w.amg->npost0_user) w.amg->npost0 = 2; }   // post-sweeps on level 0: 2 under BiCGStab, 1 under GMRES (see gmres)
     // (with cpr_relax != 1 the pressure part of M^-1 p is scaled, which the closed form does not cover)
     // (mixed precision: the float ILU0 is not the ILU0 of exactly the double matrix -- the closed form would be off by float rounding)
-    const bool closed = closed_form_level0 && emulate_ranks <= 1 && !(cpr && ell.relax != 1.0) && !mx;      // (ell.relax = cpr_relax; under CPR prm.ilu_relaxation holds cpr_relax * cpr_stage2_relax: solve_loaded)
+    const bool closed = closed_form_level0 && emulate_ranks <= 1 && !(cpr && ell.relax != 1.0) && !mx && !(cpr && point_stage2);      // (ell.relax = cpr_relax; under CPR prm.ilu_relaxation holds cpr_relax * cpr_stage2_relax: solve_loaded)
     const int8_t* lightmask = nullptr;
     const bool overlap = comm && halo_overlap;
     if (comm && (closed || overlap)) {

@@ -190,6 +190,21 @@ public:
     void correction_policy_report(int iterations, bool converged);
     bool amg_autotune = false;      // OPMGPU_AMG_AUTOTUNE=1: experiment, measured NOT robust; default: 1.9 (2.2 into level 0 on one well-free subdomain)
     // x0 = 0; rhs in work<S>().b; solution in work<S>().x
+    // opmgpu_params.cpr_reference_transform = 2 (pointilu.inl): the reference's second stage under CPR, a POINT ILU0 of the transformed system as
+    // a scalar equation-major matrix, on its own sparsity plan
+    struct PointIlu {
+        Plan plan; DevPlan dp;
+        DevArray<int64_t> gather;      // [nentries of the scalar plan] offset of the block component in the SELL-64 block matrix, -1 = padding
+        DevArray<int32_t> vmap;        // [nbp of the scalar plan] plane * nbp + row of the block vectors, -1 = padding
+        DevArray<double> val, lu, d, v;
+        bool built = false, stale = true;
+        int for_nb = 0, for_nnzb = 0, for_ordering = -1, for_plan_id = -1;
+    } pilu;
+    int plan_id = 0;                   // counts re-plans (set_pattern)
+    bool point_stage2 = false;         // set per solve (capi.hip)
+    void point_ilu_setup();
+    void point_ilu_factor();
+    void point_ilu_apply(const double* d, double* v, double relax);
     // opmgpu_params.preconditioner_single: a double solve whose preconditioner lives in the FLOAT work set (wf: float matrix copy, float ILU0
     // factors, float pressure hierarchy); the Krylov method converts the vector it hands over and the one it gets back.  Set per solve.
     bool mixed = false;

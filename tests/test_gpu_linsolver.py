@@ -288,6 +288,77 @@ def test_gmres_option(gpu_lib, oracle, single):
     s.close()
 
 
+@pytest.mark.parametrize("ordering", [capi.ORDER_NATURAL, capi.ORDER_MULTICOLOR])
+def test_reference_point_ilu0_second_stage(gpu_lib, ordering):
+    """cpr_reference_transform = 2: the reference's own second stage under CPR -- a POINT ILU0 of the row-transformed system
+    taken as a scalar equation-major matrix (NewtonIterationBlackoilCPR.cpp:129-133) -- instead of the 3x3-block ILU0.  Preconditioner-only:
+    the solution is the untransformed system's under BiCGStab and GMRES; and the point ILU0 ITSELF is checked against a numpy ILU0
+    (IKJ, dune's bilu0 for 1x1 blocks) of the transformed matrix read back from the device, in the natural (dune's) elimination order."""
+    import ctypes as C
+    from opmgpu.model import GpuBlackoilModel
+    grid = decks.cartesian_grid(6, 5, 4, lognormal_sigma=0.8, seed=2)
+    tab = decks.satfunc_standard_tables()
+    st = decks.initial_state(grid, tab, perturb=0.01, seed=2)
+    nc = grid.nc
+    out = {}
+    for tr in (0, 1, 2):
+        for gmres in (0, 1):
+            m = GpuBlackoilModel(grid, tab, capi.default_params(cpr_reference_transform=tr, newton_use_gmres=gmres, ilu_ordering=ordering,
+                                                               linear_solver_reduction=1e-10, linear_solver_maxiter=400, **capi.CPR_AMG_VCYCLE))
+            m.prepareStep(5 * decks.DAY, st)
+            m.assemble(True); m.getConvergence()
+            dx = m.solveJacobianSystem(want_dx=True, single_precision=False)
+            out[(tr, gmres)] = (dx, m.linear_iterations)
+            if tr == 2 and gmres == 0 and ordering == capi.ORDER_NATURAL:
+                rowptr, col, val = m.jacobian()                    # L A: the transform works in place
+                n = 3 * nc
+                A = np.zeros((n, n)); P = np.zeros((n, n), bool)
+                for i in range(nc):
+                    for s_ in range(rowptr[i], rowptr[i + 1]):
+                        j = col[s_]
+                        for e in range(3):
+                            for v in range(3):
+                                A[e * nc + i, v * nc + j] = val[s_][3 * e + v]; P[e * nc + i, v * nc + j] = True
+                LU = A.copy()
+                idx = np.arange(n)
+                for i in range(n):
+                    for k in np.where(P[i, :i])[0]:
+                        LU[i, k] /= LU[k, k]
+                        cols = np.where(P[i] & P[k] & (idx > k))[0]
+                        LU[i, cols] -= LU[i, k] * LU[k, cols]
+                rng = np.random.default_rng(0)
+                d = rng.standard_normal(n)
+                y = d.copy()
+                for i in range(n):
+                    ks = np.where(P[i, :i])[0]
+                    y[i] -= LU[i, ks] @ y[ks]
+                x = y.copy()
+                for i in range(n - 1, -1, -1):
+                    ks = np.where(P[i, i + 1:])[0] + i + 1
+                    x[i] = (x[i] - LU[i, ks] @ x[ks]) / LU[i, i]
+                d3 = np.ascontiguousarray(d.reshape(3, nc).T).ravel()
+                v3 = np.zeros(n)
+                m._chk(m.lib.opmgpu_point_ilu_apply(m.ctx, capi.dptr(d3), capi.dptr(v3), C.c_double(1.0)))
+                vg = np.ascontiguousarray(v3.reshape(nc, 3).T).ravel()
+                assert np.abs(vg - x).max() <= 1e-10 * np.abs(x).max(), np.abs(vg - x).max() / np.abs(x).max()
+            m.close()
+    for gmres in (0, 1):
+        ref = out[(0, gmres)][0]
+        for tr in (1, 2):
+            dx = out[(tr, gmres)][0]
+            for a in range(3):
+                blk = slice(a * nc, (a + 1) * nc)
+                assert np.abs(dx[blk] - ref[blk]).max() <= 2e-6 * np.abs(ref[blk]).max(), (tr, gmres, a)
+        # a point ILU0 is a weaker second stage than the block ILU0 of the same system, never a broken one
+        assert out[(2, gmres)][1] <= 3 * out[(1, gmres)][1] + 5, {k: v[1] for k, v in out.items()}
+    # float solves are refused in this mode (the reference's CPR plug-in is double only)
+    m = GpuBlackoilModel(grid, tab, capi.default_params(cpr_reference_transform=2, **capi.CPR_AMG_VCYCLE))
+    m.prepareStep(5 * decks.DAY, st); m.assemble(True); m.getConvergence()
+    with pytest.raises(Exception, match="double only"):
+        m.solveJacobianSystem(single_precision=True)
+    m.close()
+
+
 @pytest.mark.parametrize("cpr", [0, 1])
 def test_float_preconditioner_inside_a_double_solve(gpu_lib, oracle, cpr):
     """opmgpu_params.preconditioner_single (library extension): the double Krylov method with its preconditioner built and applied in float.

@@ -252,7 +252,7 @@ def test_reference_cpr_formulation_with_device_wells(gpu_lib, gmres):
     run's (tight linear tolerance), with the same convergence decisions."""
     grid, tab, st, wl = _setup()
     out = {}
-    for tr in (0, 1):
+    for tr in (0, 1, 2):         # 2: with the reference's own second stage, the point ILU0 of the transformed scalar system
         gm = GpuBlackoilModel(grid, tab, capi.default_params(cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1, newton_use_gmres=gmres, cpr_reference_transform=tr, linear_solver_reduction=1e-11, linear_solver_maxiter=400))
         md = W.DeviceWellModel(gm, wl, W.WellState(wl, st.p))
         md.prepareStep(2 * decks.DAY, st)
@@ -263,11 +263,13 @@ def test_reference_cpr_formulation_with_device_wells(gpu_lib, gmres):
         ws = md.pull_well_state()
         out[tr] = (gm.getState(), ws.bhp.copy(), ws.qs.copy(), hist)
         gm.close()
-    a, b = out[0], out[1]
-    assert [h[0] for h in a[3]] == [h[0] for h in b[3]]
-    assert np.array_equal(a[0].hc, b[0].hc)
-    assert np.abs(a[0].p - b[0].p).max() <= 1e-6 * np.abs(a[0].p).max() and np.abs(a[0].sat - b[0].sat).max() <= 1e-6
-    assert np.allclose(a[1], b[1], rtol=1e-7) and np.allclose(a[2], b[2], rtol=1e-6, atol=1e-9 * np.abs(a[2]).max())
+    a = out[0]
+    for tr in (1, 2):
+        b = out[tr]
+        assert [h[0] for h in a[3]] == [h[0] for h in b[3]], tr
+        assert np.array_equal(a[0].hc, b[0].hc), tr
+        assert np.abs(a[0].p - b[0].p).max() <= 1e-6 * np.abs(a[0].p).max() and np.abs(a[0].sat - b[0].sat).max() <= 1e-6, tr
+        assert np.allclose(a[1], b[1], rtol=1e-7) and np.allclose(a[2], b[2], rtol=1e-6, atol=1e-9 * np.abs(a[2]).max()), tr
 
 
 CPR_VARIANTS = {
