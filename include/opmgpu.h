@@ -536,7 +536,7 @@ typedef struct opmgpu_transport {
     /* OPTIONAL (may be NULL: the library then calls allreduce and exchange one after the other).  One all-reduce (sum) and one neighbour
      * exchange that do not depend on each other, as ONE operation -- the decomposed GMRES sends the new basis vector's halo together with
      * its projections, and the pressure correction's halo together with the coarse space's restricted residual: two latencies per column
-     * instead of four.  RCCL: one ncclGroupStart / ncclGroupEnd around the ncclAllReduce and the ncclSend / ncclRecv. */
+     * instead of four.  The built-in RCCL transport issues them back to back by default (OPMGPU_RCCL_FUSED=1: one ncclGroup). */
     int  (*allreduce_exchange)(void* self, double* dbuf, int n, int n_neigh, const int32_t* neigh_rank, const void* sbuf, const int64_t* soff,
                                const int64_t* scount, void* rbuf, const int64_t* roff, const int64_t* rcount, void* hip_stream);
 } opmgpu_transport;

@@ -145,10 +145,11 @@ struct RcclTransport : RcclComm::Transport {
     void allreduce_exchange(double* d, int n, const std::vector<int32_t>& neigh, const char* sb, const std::vector<int64_t>& soff,
                             const std::vector<int64_t>& sbytes, char* rb, const std::vector<int64_t>& roff, const std::vector<int64_t>& rbytes, hipStream_t s) override
     {
-        // one group: RCCL launches the collective and the point-to-point transfers together (one launch latency instead of two).  Mixing a
-        // collective with sends / receives in a group is NCCL API since 2.8; it has run here with ONE rank only (no multi-GPU node in this
-        // pool) -- OPMGPU_RCCL_FUSED=0 issues the two operations one after the other should a node's RCCL object to the mixture
-        static const bool fused = !(std::getenv("OPMGPU_RCCL_FUSED") && std::atoi(std::getenv("OPMGPU_RCCL_FUSED")) == 0);
+        // OPMGPU_RCCL_FUSED=1: one group -- RCCL launches the collective and the point-to-point transfers together (one launch latency instead
+        // of two).  Mixing a collective with sends / receives in one group is NCCL API since 2.8, but it has run here with ONE rank only (no
+        // multi-GPU node in this pool), so the DEFAULT issues the two operations back to back on the stream, the pattern every RCCL has
+        // run for years: the first multi-rank run of this library should not depend on the less-trodden path
+        static const bool fused = std::getenv("OPMGPU_RCCL_FUSED") && std::atoi(std::getenv("OPMGPU_RCCL_FUSED")) != 0;
         if (!fused) { allreduce(d, n, false, s); exchange(neigh, sb, soff, sbytes, rb, roff, rbytes, s); return; }
         rccl_check(g_rccl.GroupStart(), "ncclGroupStart");
         int rc = g_rccl.AllReduce(d, d, size_t(n), ncclFloat64, ncclSum, comm, s);
