@@ -130,6 +130,7 @@ def parse_args(argv):
                     help="fivespot (default, SURVEY 8d): 1 rate-controlled water injector + 4 BHP producers, full columns, device well model")
     ap.add_argument("--rate", type=float, default=1000.0, help="injection rate of the 5-spot, m3/day")
     ap.add_argument("--spin-up", type=int, default=2, help="time steps that pass before the measurement (deck set-up, untimed)")
+    ap.add_argument("--stage2-relax", type=float, default=1.0, help="opmgpu_params.cpr_stage2_relax (library extension: damping of the stage-2 ILU0 alone; 1.0 = the reference's form)")
     ap.add_argument("--stat-calls", type=int, default=60, help="calls (the K timed ones included) the per-time-step statistics are taken over")
     ap.add_argument("--only-main", action="store_true", help="skip the same-run variants, the other decks, the roofline micro-runs and the per-kernel pass (profiling)")
     ap.add_argument("--no-other-decks", action="store_true", help="skip the SPE9-like / SPE10-like / Norne-like legs")
@@ -232,8 +233,11 @@ def main(argv=None):
               "cpr_mixed": dict(capi.CPR_AMG_VCYCLE, preconditioner_single=1)}
 
     def make_params(solver=args.solver, krylov=args.krylov, verify=verify):
+        kw = dict(CPR_KW[solver])
+        if kw.get("use_cpr"):
+            kw["cpr_stage2_relax"] = args.stage2_relax
         return capi.default_params(ilu_ordering=ordering, newton_use_gmres={"gmres": 1, "fgmres": 2}.get(krylov, 0),
-                                   gmres_verify_residual=verify if krylov == "gmres" else 0, **CPR_KW[solver])
+                                   gmres_verify_residual=verify if krylov == "gmres" else 0, **kw)
 
     prm = make_params()
     spe10_spec = (200.0, 380.0)
@@ -587,7 +591,7 @@ def main(argv=None):
         if prm.use_cpr:
             stage1 = ("amg" if prm.cpr_use_amg else "ilu0(A_p)") + (" V-cycle" if (prm.cpr_use_amg and prm.cpr_max_ell_iter == 0) else
                                                                     " in %s(tol %g, <= %d)" % ("bicgstab" if prm.cpr_use_bicgstab else "cg", prm.cpr_solver_tol, prm.cpr_max_ell_iter))
-            lin_name = "cpr(%s + ilu0, relax %g) + %s" % (stage1, prm.cpr_relax, kry)
+            lin_name = "cpr(%s + ilu0, relax %g%s) + %s" % (stage1, prm.cpr_relax, "" if prm.cpr_stage2_relax == 1.0 else ", stage-2 damping %g" % prm.cpr_stage2_relax, kry)
         else:
             lin_name = "ilu0(relax %g) + %s" % (prm.ilu_relaxation, kry)
         if prm.use_cpr and not single_main and prm.newton_use_gmres != 2:
