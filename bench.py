@@ -130,7 +130,10 @@ def parse_args(argv):
                     help="fivespot (default, SURVEY 8d): 1 rate-controlled water injector + 4 BHP producers, full columns, device well model")
     ap.add_argument("--rate", type=float, default=1000.0, help="injection rate of the 5-spot, m3/day")
     ap.add_argument("--spin-up", type=int, default=2, help="time steps that pass before the measurement (deck set-up, untimed)")
-    ap.add_argument("--stage2-relax", type=float, default=1.0, help="opmgpu_params.cpr_stage2_relax (library extension: damping of the stage-2 ILU0 alone; 1.0 = the reference's form)")
+    ap.add_argument("--cut-axis", type=int, default=1, choices=[0, 1], help="N > 1, --deck spe10like: cut into slabs along i (0) or j (1, default); both keep the vertical wells whole")
+    ap.add_argument("--stage2-relax", type=float, default=None,
+                    help="opmgpu_params.cpr_stage2_relax (library extension: damping of the stage-2 ILU0 alone; 1.0 = the reference's form).  Default: 1.0 -- except on the "
+                         "DECOMPOSED SPE10-like deck, 0.9: with the undamped second stage the 4-rank run chops 9 of 12 steps (profiles/r04_z_dist_spe10_relax.log)")
     ap.add_argument("--stat-calls", type=int, default=60, help="calls (the K timed ones included) the per-time-step statistics are taken over")
     ap.add_argument("--only-main", action="store_true", help="skip the same-run variants, the other decks, the roofline micro-runs and the per-kernel pass (profiling)")
     ap.add_argument("--no-other-decks", action="store_true", help="skip the SPE9-like / SPE10-like / Norne-like legs")
@@ -220,9 +223,14 @@ def main(argv=None):
         return False if solver.startswith("cpr") else dt < 20 * decks.DAY
 
     single_main = {"reference": reference_single(args.solver, dt_main), "f32": True, "f64": False}[args.precision]
+    world_hint = int(os.environ.get("WORLD_SIZE", "1"))
     use_wells = args.wells == "fivespot"
+    decomposed_spe10 = args.deck == "spe10like" and world_hint > 1
+    if args.stage2_relax is None:
+        args.stage2_relax = 0.9 if decomposed_spe10 else 1.0
     if args.krylov == "auto":
-        args.krylov = "gmres" if (use_wells and args.solver == "cpr") else "bicgstab"
+        # (decomposed SPE10-like: BiCGStab -- 13.0 iterations per solve, no chopped step on 4 ranks, where dune's GMRES rule needs 23.3 and chops)
+        args.krylov = "bicgstab" if decomposed_spe10 else ("gmres" if (use_wells and args.solver == "cpr") else "bicgstab")
     verify = 1 if args.verify else 0
 
     # solver names: "ilu0" = solver_approach=interleaved; "cpr" = the headline's pressure stage (cpr_use_amg=true, ONE V-cycle per application:
@@ -255,7 +263,7 @@ def main(argv=None):
         from opmgpu import partition
         if args.deck == "spe10like":
             wells_fn = (lambda g: W.five_spot(g, rate_m3_per_day=spe10_spec[0], bhp_prod_bar=spe10_spec[1])) if use_wells else None
-            model, grid, st, info = partition.build_distributed_model(60, 220, 85, tab, prm, rank, world, local_rank, deck="spe10like", wells_fn=wells_fn)
+            model, grid, st, info = partition.build_distributed_model(60, 220, 85, tab, prm, rank, world, local_rank, deck="spe10like", wells_fn=wells_fn, axis=args.cut_axis)
         elif args.scaling == "strong":
             wells_fn = (lambda g: W.five_spot(g, rate_m3_per_day=args.rate, bhp_prod_bar=150.0)) if use_wells else None
             model, grid, st, info = partition.build_distributed_model(args.nx, args.ny, args.nz, tab, prm, rank, world, local_rank, wells_fn=wells_fn, axis=1)

@@ -540,6 +540,12 @@ typedef struct opmgpu_transport {
     int  (*allreduce_exchange)(void* self, double* dbuf, int n, int n_neigh, const int32_t* neigh_rank, const void* sbuf, const int64_t* soff,
                                const int64_t* scount, void* rbuf, const int64_t* roff, const int64_t* rcount, void* hip_stream);
 } opmgpu_transport;
+/* Coarse space of the decomposed pressure stage: by default one unknown per rank in runs with wells (index-range
+ * blocks of the owned cells would cut the wells, which was measured to hurt), m = 4 index-range blocks without.  A caller that knows the
+ * geometry supplies m <= 8 blocks per rank that keep every well inside ONE block -- e.g. sub-slabs along the cut direction for vertical
+ * wells: block_of_owned_cell[c] in [0, m) for the owned cells in local numbering.  Same m on every rank; m = 0 restores the default.
+ * Call after opmgpu_comm_init*, before the first CPR solve (the map is agreed collectively there). */
+int opmgpu_comm_set_coarse_blocks(opmgpu_ctx* ctx, int m, const int32_t* block_of_owned_cell);
 int opmgpu_comm_init_transport(opmgpu_ctx* ctx, int rank, int nranks, const opmgpu_transport* transport, int32_t n_owned,
                                int n_neigh, const int32_t* neigh_rank, const int32_t* send_ptr,
                                const int32_t* send_cells, const int32_t* recv_ptr, const int32_t* recv_cells);

@@ -862,6 +862,15 @@ int opmgpu_comm_init_transport(opmgpu_ctx* c, int rank, int nranks, const opmgpu
     return comm_init_common(c, rank, nranks, nullptr, transport, n_owned, n_neigh, neigh_rank, send_ptr, send_cells, recv_ptr, recv_cells);
 }
 
+int opmgpu_comm_set_coarse_blocks(opmgpu_ctx* c, int m, const int32_t* block_of_owned_cell)
+{
+    if (!c || !c->comm) return OPMGPU_EINVAL;
+    const int st = c->comm->set_coarse_blocks(m, block_of_owned_cell);
+    if (st != OPMGPU_OK) return fail(c, st, "opmgpu_comm_set_coarse_blocks: 0 <= block < m <= 8 for every owned cell");
+    c->ls->cs_for = nullptr;           // the subdomain map is rebuilt (collectively) at the next CPR solve
+    return OPMGPU_OK;
+}
+
 int opmgpu_plan_ordering(int nb, const int32_t* rowptr, const int32_t* col, int ordering, int32_t* position, int32_t* level, int32_t* nlevels)
 {
     Plan P;

@@ -258,7 +258,7 @@ void RcclComm::coarse_blocks_of_rows(const Plan& P, int m, hipStream_t s, std::v
     sub.assign(P.nbp, rank * m); blk.assign(P.nbp, int8_t(-1));
     std::vector<double> h(size_t(3) * P.nbp, 0.0);
     for (int c = 0; c < n_owned; ++c) {
-        const int b = int(std::min<long>(m - 1, long(c) * m / n_owned));
+        const int b = (user_m > 0 && m == user_m) ? user_blk[c] : int(std::min<long>(m - 1, long(c) * m / n_owned));
         sub[P.pos[c]] = rank * m + b; blk[P.pos[c]] = int8_t(b);
         h[P.pos[c]] = double(rank * m + b);
     }
@@ -269,6 +269,15 @@ void RcclComm::coarse_blocks_of_rows(const Plan& P, int m, hipStream_t s, std::v
     tmp.download(h.data(), h.size(), s);
     OPMGPU_HIP(hipStreamSynchronize(s));
     for (int c = n_owned; c < n_local; ++c) sub[P.pos[c]] = int32_t(h[P.pos[c]] + 0.5);
+}
+
+int RcclComm::set_coarse_blocks(int m, const int32_t* blk)
+{
+    if (m < 0 || m > 8 || (m > 0 && !blk)) return OPMGPU_EINVAL;
+    for (int c = 0; c < n_owned && m > 0; ++c) if (blk[c] < 0 || blk[c] >= m) return OPMGPU_EINVAL;
+    user_m = m;
+    user_blk.assign(blk, blk + (m > 0 ? n_owned : 0));
+    return OPMGPU_OK;
 }
 
 template <class S> void RcclComm::halo_t(S* v, hipStream_t s, double* red, int nred)

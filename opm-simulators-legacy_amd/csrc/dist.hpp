@@ -30,6 +30,10 @@ public:
     void subdomain_of_rows(const Plan& P, std::vector<int32_t>& sub) const override;
     void coarse_blocks_of_rows(const Plan& P, int m, hipStream_t s, std::vector<int32_t>& sub, std::vector<int8_t>& blk) override;
 
+    int user_coarse_blocks() const override { return user_m; }
+    int set_coarse_blocks(int m, const int32_t* block_of_owned_cell);      // 0 <= block < m per owned cell (local caller numbering); m <= 8
+    std::vector<int32_t> user_blk;
+    int user_m = 0;
     int rank = 0, nranks = 1, n_owned = 0, n_local = 0, nbp = 0;
     double pvsum_global = 0.0;
 

@@ -1712,7 +1712,8 @@ void LinSolver::coarse_domains()
     std::vector<int8_t> blk;
     // with wells ONE unknown per rank: measured with real ranks, blocks and the wells' rank-7 operator do not mix (2 ranks: 35 -> 77
     // iterations over six Newton iterations, 4 ranks: 43 -> 96), while one unknown per rank still pays there (4 ranks: 67 -> 43)
-    int m = (comm && !run_has_wells) ? std::max(1, std::min(cs_blocks_req, 8)) : 1;
+    // ... unless the CALLER supplies the blocks (opmgpu_comm_set_coarse_blocks: sub-slabs along the cut direction keep vertical wells whole)
+    int m = (comm && comm->user_coarse_blocks() > 0) ? comm->user_coarse_blocks() : (comm && !run_has_wells) ? std::max(1, std::min(cs_blocks_req, 8)) : 1;
     while (m > 1 && comm->num_ranks() * m > 64) m /= 2;
     for (;; m /= 2) {
         if (comm) comm->coarse_blocks_of_rows(plan, m, stream, sub, blk); else { sub.assign(plan.nbp, 0); blk.assign(plan.nbp, int8_t(0)); }

@@ -56,6 +56,9 @@ struct CommBase {
     // coarse-space unknown of every local row when every rank splits its owned cells into m index-range blocks: rank * m + block for
     // owned rows, the OWNER's value for ghost rows (one halo exchange); blk = own block of a row or -1 (ghost / padding)
     virtual void coarse_blocks_of_rows(const Plan& P, int m, hipStream_t s, std::vector<int32_t>& sub, std::vector<int8_t>& blk) = 0;
+    // caller-supplied coarse blocks of the owned cells (opmgpu_comm_set_coarse_blocks): > 0 = their number per rank; such blocks keep every
+    // well inside ONE block (the caller's contract), so they are used in runs with wells too
+    virtual int user_coarse_blocks() const { return 0; }
     int n_owned_global = 0;
 };
 

@@ -160,6 +160,7 @@ SIGNATURES = {
     "opmgpu_cpr_elliptic_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "opmgpu_cpr_correction_factors": (C.c_int, [C.c_void_p, _dp, _dp]),
     "opmgpu_point_ilu_apply": (C.c_int, [C.c_void_p, _dp, _dp, C.c_double]),
+    "opmgpu_comm_set_coarse_blocks": (C.c_int, [C.c_void_p, C.c_int, _ip]),
     "opmgpu_nonlinear_iteration": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_int, C.POINTER(NewtonCtl), C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, _dp]),
     "opmgpu_update_hysteresis": (C.c_int, [C.c_void_p]),
     "opmgpu_set_hysteresis": (C.c_int, [C.c_void_p, _dp, _dp]),

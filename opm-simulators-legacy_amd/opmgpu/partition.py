@@ -153,7 +153,7 @@ def build_distributed_model(nx, ny, nz, tables, params, rank, world, local_rank,
     if deck == "spe10like":
         grid = decks.cartesian_grid(60, 220, 85, dx=6.096, dy=3.048, dz=0.6096, tops=3657.6, lognormal_sigma=2.5, seed=10)
         st = decks.initial_state(grid, tables, p_ref=413.0 * decks.BAR, z_ref=3657.6, perturb=1e-4, seed=10, gas_cap_fraction=0.0, gas_only_fraction=0.0)
-        part = slab_partition(grid, world, axis=1)
+        part = slab_partition(grid, world, axis=axis if axis in (0, 1) else 1)      # vertical wells: along i or j only
     else:
         grid = decks.cartesian_grid(nx, ny, nz, lognormal_sigma=lognormal_sigma, seed=seed)
         st = decks.initial_state(grid, tables, perturb=perturb, seed=seed)
@@ -166,6 +166,18 @@ def build_distributed_model(nx, ny, nz, tables, params, rank, world, local_rank,
         idt.copy_(torch.frombuffer(bytearray(make_unique_id()), dtype=torch.uint8))
     dist.broadcast(idt, src=0)
     attach_comm(model, dom, rank, world, bytes(idt.cpu().numpy().tobytes()))
+    # coarse blocks of the pressure stage: sub-slabs of this rank's slab along the CUT direction (they keep vertical wells whole)
+    mblk = int(os.environ.get("OPMGPU_COARSE_SUBSLABS", "0"))
+    cut_axis = (axis if axis in (0, 1) else 1) if deck == "spe10like" else axis
+    if mblk > 1 and grid.dims is not None and cut_axis in (0, 1):
+        nxg, nyg, _ = grid.dims
+        gid = dom.global_of_local[:dom.n_owned]
+        coord = (gid % nxg) if cut_axis == 0 else ((gid // nxg) % nyg)
+        lo, hi = int(coord.min()), int(coord.max()) + 1
+        blk = capi.i32(np.minimum(mblk - 1, (coord - lo) * mblk // max(1, hi - lo)))
+        st_ = capi.load().opmgpu_comm_set_coarse_blocks(model.ctx, mblk, capi.iptr(blk))
+        if st_ != capi.OK:
+            raise RuntimeError("opmgpu_comm_set_coarse_blocks failed with status %d" % st_)
     info = {"n_owned": dom.n_owned, "n_global": grid.nc, "n_ghost": dom.n_ghost, "neighbours": dom.neigh_rank.tolist()}
     if wells_fn is not None:          # wells of the GLOBAL deck (every well inside one rank's cells) -> this rank's, in local numbering
         info["wells"] = dom.local_wells(wells_fn(grid), part)
