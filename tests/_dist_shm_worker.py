@@ -50,6 +50,17 @@ def run(cfg, rank, world, uid, out):
         dom = partition.LocalDomain(grid, part, rank)
         model = GpuBlackoilModel(dom.grid, tab, prm)
         partition.attach_comm(model, dom, rank, world, uid)
+        if cfg.get("subslabs"):
+            # caller-supplied coarse blocks of the pressure stage (opmgpu_comm_set_coarse_blocks): sub-slabs of this rank's slab along the cut
+            # direction j, which keep the vertical wells of the deck inside one block each
+            m = int(cfg["subslabs"])
+            gid = dom.global_of_local[:dom.n_owned]
+            coord = (gid // cfg["nx"]) % cfg["ny"]
+            lo, hi = int(coord.min()), int(coord.max()) + 1
+            blk = capi.i32(np.minimum(m - 1, (coord - lo) * m // max(1, hi - lo)))
+            assert model.lib.opmgpu_comm_set_coarse_blocks(model.ctx, m, capi.iptr(blk)) == capi.OK
+            bad = blk.copy(); bad[0] = m
+            assert model.lib.opmgpu_comm_set_coarse_blocks(model.ctx, m, capi.iptr(bad)) == capi.EINVAL      # out of range: refused, the valid map stays
         lst = dom.local_state(st)
         owned_global = dom.global_of_local[:dom.n_owned]
     driver = model

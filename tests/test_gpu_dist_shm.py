@@ -73,6 +73,8 @@ CASES = {
     "cpr_unstructured": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=800, cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1), wells=False, single=False, unstructured=True),
     "ilu0_j_slabs": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=1500), wells=False, single=False, axis=1),
     "cpr_wells": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=500, cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1), wells=True, single=False),
+    # coarse blocks supplied by the caller (sub-slabs along the cut direction: two per rank, wells whole) in a run WITH wells, where the default is one unknown per rank
+    "cpr_wells_caller_blocks": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=500, cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1), wells=True, single=False, axis=1, subslabs=2),
     # the reference's newton_use_gmres option decomposed: halo-exchanged basis vectors, owner-masked projections, one all-reduce each
     "cpr_gmres": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=500, cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1, newton_use_gmres=1), wells=False, single=False),
     "cpr_gmres_wells": dict(params=dict(linear_solver_reduction=1e-10, linear_solver_maxiter=500, cpr_use_amg=1, cpr_max_ell_iter=0, use_cpr=1, newton_use_gmres=1), wells=True, single=False),
