@@ -238,12 +238,14 @@ def main(argv=None):
     # pressure system, cpr_solver_tol / cpr_max_ell_iter at their defaults); "cpr_amg_inner" = cpr_use_amg=true behind that inner BiCGStab
     CPR_KW = {"ilu0": dict(use_cpr=0), "cpr": dict(capi.CPR_AMG_VCYCLE), "cpr_ref": dict(use_cpr=1, cpr_use_amg=0), "cpr_amg_inner": dict(use_cpr=1, cpr_use_amg=1),
               # library extension (opmgpu_params.preconditioner_single): the headline's solver with its preconditioner in float, Krylov method in double
-              "cpr_mixed": dict(capi.CPR_AMG_VCYCLE, preconditioner_single=1)}
+              "cpr_mixed": dict(capi.CPR_AMG_VCYCLE, preconditioner_single=1),
+              # library extension (opmgpu_params.cpr_stage2_relax = 0.9): the damped second stage of rounds 1-3 -- the recommended, most robust setting
+              "cpr_damped": dict(capi.CPR_AMG_VCYCLE, cpr_stage2_relax=0.9)}
 
     def make_params(solver=args.solver, krylov=args.krylov, verify=verify):
         kw = dict(CPR_KW[solver])
         if kw.get("use_cpr"):
-            kw["cpr_stage2_relax"] = args.stage2_relax
+            kw.setdefault("cpr_stage2_relax", args.stage2_relax)
         return capi.default_params(ilu_ordering=ordering, newton_use_gmres={"gmres": 1, "fgmres": 2}.get(krylov, 0),
                                    gmres_verify_residual=verify if krylov == "gmres" else 0, **kw)
 
@@ -490,6 +492,9 @@ def main(argv=None):
                 variant("cpr_f64_%s_f32_precond" % kry, "cpr_mixed", kry, dt_main, False,
                         note="library extension, not a reference option: the double solve (Krylov method, operator, residual, solution in double) with its whole "
                              "preconditioner -- ILU0, pressure stage, stage-2 residual -- built and applied in float (opmgpu_params.preconditioner_single)")
+            variant("cpr_f64_bicgstab_damped", "cpr_damped", "bicgstab", dt_main, False,
+                    note="library extension, the RECOMMENDED configuration: CPR + BiCGStab in double with the second stage damped by 0.9 (cpr_stage2_relax) -- "
+                         "the lowest ms per converged time step of the reference-arithmetic configurations and the robust one at long time steps and on the other decks")
             variant("cpr_f32_%s" % args.krylov, "cpr", args.krylov, dt_main, True,
                     note="NOT a configuration the reference can run (its CPR plug-in is double-only, NewtonIterationBlackoilCPR.cpp:117-140): kept for continuity")
         if use_wells:

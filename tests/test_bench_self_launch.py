@@ -38,3 +38,36 @@ def test_bench_self_launch_builds_the_drivers_command(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main(["--gpus", "2"])
     assert e.value.code == 3
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def test_per_time_step_statistics_count_whole_steps_only():
+    """bench.per_time_step_stats (VERDICT r3 item 2): the window runs from the call after the first step boundary to the last completed step;
+    chopped attempts inside it count towards the cost of the steps, calls before / after it do not."""
+    bench = _load_bench()
+    day = 86400.0
+    #          0       1        2       3        4       5        6       7        8       9
+    log = [(None, 5 * day), ("step", 5 * day), (None, 5 * day), (None, 5 * day), ("chop", 5 * day), (None, 1.65 * day), ("step", 1.65 * day),
+           (None, 3.3 * day), ("step", 3.3 * day), (None, 5 * day)]
+    ms = [1.0, 0.5, 2.0, 2.0, 2.0, 2.0, 0.5, 2.0, 0.5, 2.0]
+    solved = [1, 0, 1, 1, 1, 1, 0, 1, 0, 1]
+    lin = [3, 0, 4, 4, 5, 3, 0, 3, 0, 3]
+    p = bench.per_time_step_stats(log, ms, solved, lin)
+    assert p["time_steps"] == 2 and p["calls"] == 7 and p["chopped_attempts"] == 1          # calls 2..8
+    assert p["newton_iterations_per_time_step"] == 5 / 2 and p["linear_iterations_per_time_step"] == 19 / 2
+    assert abs(p["ms_per_converged_time_step"] - 11.0 / 2) < 1e-12
+    assert abs(p["simulated_days"] - 4.95) < 1e-12 and abs(p["ms_per_simulated_day"] - 11.0 / 4.95) < 1e-12
+    # no completed step behind the first boundary: nothing to report
+    assert bench.per_time_step_stats(log[:3], ms[:3], solved[:3], lin[:3]) is None
+    assert bench.per_time_step_stats([(None, day)] * 4, [1.0] * 4, [1] * 4, [1] * 4) is None
+
+
+def test_bench_line_budget_constant():
+    assert _load_bench().MAX_LINE_BYTES == 4096
