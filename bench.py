@@ -653,7 +653,7 @@ def main(argv=None):
             "breakdown_ms": {k: r3(v) for k, v in (res.get("breakdown") or {}).items() if k != "basis"} or None,
             "roofline": None if main_roof is None else {k: (round(v, 4) if isinstance(v, float) else v) for k, v in main_roof.items()
                                                         if k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "ms_per_launch", "algorithmic_bytes")},
-            "cpu_baseline": None if cpu is None else {"value": round(cpu["value"], 4), "unit": cpu["unit"], "cores": cpu["cores"], "kind": cpu["kind"], "sample": cpu["sample"]},
+            "cpu_baseline": None if cpu is None else {"value": round(cpu["value"], 4), "unit": cpu["unit"], "cores": cpu["cores"], "kind": cpu["kind"], "sample": cpu["sample_short"]},
             "cpu_all_cores": None if cpu_all is None else {"value": round(cpu_all["value"], 4), "cores": cpu_all["cores"]},
             "variants_columns": "[Mcell-updates/s, newton its / time step, ms / converged time step, ms / simulated day]",
             "variants": compact_variants(variants),
@@ -717,7 +717,9 @@ def cpu_baseline(grid, tab, st, wl, prm, dt, single, threads=1, budget_s=15.0, m
             l = ob.linear_iterations
         tot += time.perf_counter() - t1
         its += 1; lin.append(l)
-    return {"value": its * grid.nc / tot / 1e6, "unit": "Mcell-updates/s", "cores": threads, "kind": "port",
+    short = "first %d Newton iterations of the same deck%s from the same state: oracle assembly + natural-order ILU0/BiCGStab %s (reference default) + update, %.1f s" % (
+        its, " + 5-spot (host wells)" if wl is not None else "", "f32" if single else "f64", tot)
+    return {"value": its * grid.nc / tot / 1e6, "unit": "Mcell-updates/s", "cores": threads, "kind": "port", "sample_short": short,
             "sample": "first %d Newton iterations of the same deck%s and initial state: assembly + natural-order ILU0/BiCGStab %s (the reference's default "
                       "solver_approach=interleaved; linear its %s) + update, %.2f s"
                       % (its, " with its 5-spot (host well model, explicit Schur complement)" if wl is not None else "", "f32" if single else "f64", lin, tot),
