@@ -1993,6 +1993,16 @@ template <class S> void LinSolver::cpr_prepare()
     if (w.amg->border_nw() > 0)
         hipLaunchKernelGGL((k_cpr_border<S>), dim3(lowrank.nw), dim3(kBlock), 0, stream, lowrank, plan.nbp, border_weights ? (const S*)border_weights : (const S*)w.cprw.p, w.amg->levels[0]->val.p + w.amg->levels[0]->nentries, border_colscale);
     w.amg->galerkin();
+    {
+        // EXPERIMENT (emulated decomposition only, OPMGPU_EMULATE_L0_GLOBAL=1): the coarse operators come from the cut copy (rank-local
+        // Galerkin sums, as a decomposed run builds them), but LEVEL 0 -- smoothing and residual -- works on the uncut pressure matrix, which
+        // is what halo-exchanged level-0 vectors inside the cycle would give a real decomposed run
+        static const bool l0_global = std::getenv("OPMGPU_EMULATE_L0_GLOBAL") && std::atoi(std::getenv("OPMGPU_EMULATE_L0_GLOBAL")) != 0;
+        if (l0_global && emulated && (emulate_what & 2)) {
+            hipLaunchKernelGGL((k_extract_pressure<S>), dim3(grid_for(plan.nbp)), dim3(kBlock), 0, stream, plan.nb, plan.nbp, dp.slice_ptr.p, (const S*)w.cprw.p, matrix<S>(), w.amg->levels[0]->val.p);
+            w.amg->galerkin(false);
+        }
+    }
     if (ell.inner && !ell.use_amg) elliptic_factor<S>();
     new_step_hint = false; refreshed = true;
     if (coarse_nsub >= 1) { coarse_begin<S>(); coarse_setup<S>(false); }
