@@ -702,7 +702,13 @@ void AmgHierarchy<S>::vcycle(const SolveCtl* ctl, bool level0_presmoothed)
     for (int l = 0; l < nl - 1; ++l) {
         AmgLevel<S>& F = *levels[l]; AmgLevel<S>& C = *levels[l + 1];
         const int g = grid_for(F.n);
-        if (l == 0 && gs_level0() && F.nw == 0) {
+        if (l == 0 && level0_halo) {
+            // decomposed run: x0 = omega D^-1 b, ghost entries from their owners, then the residual on the global level-0 matrix
+            if (!presmoothed) hipLaunchKernelGGL((k_amg_smooth0<S>), dim3(grid_for(F.ntot())), dim3(kBlock), 0, stream, F.ntot(), om, F.dinv.p, F.b.p, F.x.p, ctl);
+            level0_halo(F.x.p, F.b.p);
+            hipLaunchKernelGGL((k_amg_residual<S, 0>), dim3(g + F.nw), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, F.x.p, om, F.dinv.p, F.r.p, ctl,
+                               (const int32_t*)nullptr, (const S*)nullptr, S(0), bord(F, g));
+        } else if (l == 0 && gs_level0() && F.nw == 0) {
             // x = D^-1 b (the first colour's sweep from zero; the caller's fused kernel did it with omega0() = 1), second colour in place,
             // then the residual: zero on the rows just solved, b - A x on the first colour
             const int n0 = gs_n0;
@@ -759,6 +765,13 @@ void AmgHierarchy<S>::vcycle(const SolveCtl* ctl, bool level0_presmoothed)
         int done_sweeps = 0;
         const int npost = l == 0 ? this->npost0 : this->npost;
         const double pdamp = l == 0 ? this->pdamp0 : this->pdamp;          // (shadows the member: the correction INTO level l)
+        if (l == 0 && level0_halo) {
+            // decomposed run: prolongation, then every post-smoothing sweep on an iterate whose ghost entries are the owners'
+            hipLaunchKernelGGL((k_amg_prolong<S>), dim3(grid_for(F.ntot())), dim3(kBlock), 0, stream, F.ntot(), F.agg.p, C.x.p, F.x.p, S(pdamp), ctl);
+            for (int sw = 0; sw < npost; ++sw) { level0_halo(F.x.p, F.b.p); sweep(F, ctl); }
+            mark("up L0");
+            continue;
+        }
         if (l == 0 && gs_level0() && F.nw == 0) {
             const int n0 = gs_n0;
             hipLaunchKernelGGL((k_amg_prolong<S>), dim3(g), dim3(kBlock), 0, stream, F.n, F.agg.p, C.x.p, F.x.p, S(pdamp), ctl);
@@ -804,7 +817,7 @@ template <class S>
 void AmgHierarchy<S>::vcycle_graph(const SolveCtl* ctl, bool level0_presmoothed)
 {
     const bool even = (npost % 2 == 0) && (npost0 % 2 == 0) && npre == 1;
-    if (!use_graph || !even) { vcycle(ctl, level0_presmoothed); return; }
+    if (!use_graph || !even || level0_halo) { vcycle(ctl, level0_presmoothed); return; }          // (the exchange is not capturable)
     join_inverse();          // an event of another stream cannot be waited for inside a capture
     // the captured launches carry the smoother / correction constants as baked-in kernel arguments: they are part of the cache key
     const double key[6] = { pdamp0, pdamp, omega0(), double(npost), double(npost0), double(npre) };

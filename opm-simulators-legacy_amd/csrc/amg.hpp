@@ -111,6 +111,11 @@ public:
     void residual_norm2(double* d_out);
     // levels[0].r = b - A x on level 0 (border rows included); one launch
     void residual0(const SolveCtl* ctl);
+    // Decomposed runs (set by LinSolver per application, empty otherwise): called with level 0's iterate before every level-0 operation
+    // that reads neighbours' entries of it -- the residual of the down leg and each post-smoothing sweep.  The callback refreshes the ghost
+    // entries from their owners (one halo exchange) so that level 0 of the cycle works on the GLOBAL pressure matrix; the coarse levels
+    // stay rank-local.  With the hook set the cycle takes the unfused level-0 launches (smooth / residual / prolong / sweeps).
+    std::function<void(S* x, S* b)> level0_halo;
     DevArray<double> tune_parts;
     // levels[0].b := A s for an algebraically smooth s (pseudo-random start, `sweeps` Jacobi sweeps on A s = 0): the kind of error the
     // coarse-grid correction of a cycle meets.  The caller's right-hand side is parked in tune_b until restore_rhs().

@@ -975,6 +975,7 @@ LinSolver::LinSolver(hipStream_t s) : stream(s)
     if (const char* e = std::getenv("OPMGPU_FACTOR_GRID")) factor_grid_cap = std::atoi(e);
     if (const char* e = std::getenv("OPMGPU_CS_RECUR")) cs_recur = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_CS_FUSED")) cs_fused_env = std::atoi(e) != 0;
+    if (const char* e = std::getenv("OPMGPU_CPR_L0_HALO")) cpr_l0_halo = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_AMG_AUTOTUNE")) amg_autotune = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_AMG_ADAPT")) corr_policy.on = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_AMG_ADAPT_ARM")) corr_policy.arm[1] = std::atof(e);
@@ -1398,6 +1399,17 @@ __global__ __launch_bounds__(kBlock) void k_cs_add_post(int nb, int ns, const in
     __syncthreads();
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i < nb) out[i] = S(double(out[i]) + e[sub[i]]);
+}
+
+// level 0 of the decomposed pressure cycle (LinSolver::cpr_l0_halo): the ghost entries of the iterate from the exchanged staging vector;
+// the ghost rows are identity rows, so their right-hand side follows (b = x: zero residual, stationary under the Jacobi sweep)
+template <class S>
+__global__ __launch_bounds__(kBlock) void k_l0_ghosts(int nb, const int8_t* __restrict__ owned, const S* __restrict__ hx, S* __restrict__ x, S* __restrict__ b,
+                                                      const SolveCtl* __restrict__ ctl)
+{
+    if (ctl && ctl->done) return;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < nb && !owned[i]) { const S v = hx[i]; x[i] = v; b[i] = v; }
 }
 
 // real multi-GPU (one subdomain per process): deterministic versions -- per-workgroup partials, re-reduced in a fixed order
@@ -2134,6 +2146,14 @@ template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, con
     }
     kt.end(KT_CPR_OTHER, kt_a);
     kt_a = kt.begin();
+    if (comm && cpr_l0_halo && !ell.inner) {
+        S* const hx = w.hx.p; CommBase* const cm = comm; const int nbl = plan.nb; hipStream_t st = stream;
+        w.amg->level0_halo = [=](S* x, S* b) {
+            OPMGPU_HIP(hipMemcpyAsync(hx, x, size_t(nbl) * sizeof(S), hipMemcpyDeviceToDevice, st));
+            halo_dispatch(cm, hx, st);
+            hipLaunchKernelGGL((k_l0_ghosts<S>), dim3(grid_for(nbl)), dim3(kBlock), 0, st, nbl, cm->owner_mask(), (const S*)hx, x, b, ctl);
+        };
+    } else w.amg->level0_halo = nullptr;
     if (ell.inner) elliptic_solve<S>(); else w.amg->vcycle_graph(ctl, true);
     kt.end(KT_VCYCLE, kt_a);
     kt_a = kt.begin();

@@ -328,6 +328,12 @@ public:
     // form x + P A_c^-1 R b (no residual pass) is unusable: 4 ranks 9.0 -> 13.9 iterations per solve with chopped time steps.
     // Off by default; OPMGPU_CS_FUSED=1 switches it on for further work.  Set by gmres() per solve.
     bool cs_fused_post = false, cs_fused_env = false;
+    // Decomposed CPR: level 0 of the pressure cycle on the GLOBAL matrix -- the iterate's ghost entries are refreshed from their owners before
+    // the down leg's residual and before every post-smoothing sweep (AmgHierarchy::level0_halo; one more halo exchange each, 2 per
+    // application under GMRES, 3 under BiCGStab).  The rank-local hierarchy is what fails on heterogeneous decks (SPE10-like: 4.7 -> 46
+    // iterations when only the AMG's matrix is cut, 9 with level 0 uncut: profiles/r04_ag_emulate_l0_global.log); on smooth decks the
+    // counts are the single-domain ones without it.  opmgpu_params has no field for it: OPMGPU_CPR_L0_HALO=1 / 0, default 1 (on).
+    bool cpr_l0_halo = true;
     DevArray<double> cs_state;     // [2 ns]: restricted residual of p, of r
     hipStream_t halo_stream = nullptr;
     hipEvent_t ev_halo[2] = { nullptr, nullptr };

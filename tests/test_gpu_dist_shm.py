@@ -156,10 +156,14 @@ def test_collective_operations_per_newton_iteration(gpu_lib):
     with tempfile.TemporaryDirectory() as tmp:
         for pyth in (1, 0):
             stats = os.path.join(tmp, "stats%d" % pyth)
-            got = _launch(cfg, 2, tmp, {"OPMGPU_GMRES_PYTH": str(pyth), "OPMGPU_SHM_STATS": stats})
+            got = _launch(cfg, 2, tmp, {"OPMGPU_GMRES_PYTH": str(pyth), "OPMGPU_SHM_STATS": stats, "OPMGPU_CPR_L0_HALO": "0"})
             calls = [tuple(int(x) for x in open("%s.%d" % (stats, r)).read().split()) for r in range(2)]
             assert len(set(calls)) == 1                               # every rank made the same collective calls
             res[pyth] = (got, calls[0])
+        # level 0 of the pressure cycle on the global matrix (LinSolver::cpr_l0_halo): two more exchanges per preconditioner application
+        stats = os.path.join(tmp, "stats_l0")
+        gl, cl = _launch(cfg, 2, tmp, {"OPMGPU_SHM_STATS": stats, "OPMGPU_CPR_L0_HALO": "1"}), None
+        cl = tuple(int(x) for x in open(stats + ".0").read().split())
     (g1, c1), (g0, c0) = res[1], res[0]
     newton = len(g1[3])
     lin1, lin0 = int(g1[3][:, 1].sum()), int(g0[3][:, 1].sum())
@@ -175,3 +179,8 @@ def test_collective_operations_per_newton_iteration(gpu_lib):
     assert c1[2] >= lin1                                              # at least one fused operation per column
     assert c0[0] - c1[0] >= lin1 - 2                                  # one all-reduce less per column
     assert np.abs(g1[0] - g0[0]).max() <= 2e-3 * np.abs(g0[0]).max()
+    linl = int(gl[3][:, 1].sum())
+    print("  with the level-0 exchanges: %.1f (%d + %d + %d, %d columns)" % (sum(cl) / newton, cl[0], cl[1], cl[2], linl))
+    assert linl <= lin1 + 1                                           # never a worse preconditioner
+    assert 2 * linl <= cl[1] - c1[1] + 2 * max(0, lin1 - linl) + 4 and cl[1] - c1[1] <= 2 * (linl + 2 * newton)
+    assert np.abs(gl[0] - g1[0]).max() <= 2e-3 * np.abs(g1[0]).max()
