@@ -705,7 +705,7 @@ void AmgHierarchy<S>::vcycle(const SolveCtl* ctl, bool level0_presmoothed)
         if (l == 0 && level0_halo) {
             // decomposed run: x0 = omega D^-1 b, ghost entries from their owners, then the residual on the global level-0 matrix
             if (!presmoothed) hipLaunchKernelGGL((k_amg_smooth0<S>), dim3(grid_for(F.ntot())), dim3(kBlock), 0, stream, F.ntot(), om, F.dinv.p, F.b.p, F.x.p, ctl);
-            level0_halo(F.x.p, F.b.p);
+            if (level0_halo_down) level0_halo(F.x.p, F.b.p);
             hipLaunchKernelGGL((k_amg_residual<S, 0>), dim3(g + F.nw), dim3(kBlock), 0, stream, F.n, F.slice_ptr, F.col, F.val.p, F.b.p, F.x.p, om, F.dinv.p, F.r.p, ctl,
                                (const int32_t*)nullptr, (const S*)nullptr, S(0), bord(F, g));
         } else if (l == 0 && gs_level0() && F.nw == 0) {

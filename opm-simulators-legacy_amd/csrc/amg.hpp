@@ -116,6 +116,7 @@ public:
     // entries from their owners (one halo exchange) so that level 0 of the cycle works on the GLOBAL pressure matrix; the coarse levels
     // stay rank-local.  With the hook set the cycle takes the unfused level-0 launches (smooth / residual / prolong / sweeps).
     std::function<void(S* x, S* b)> level0_halo;
+    bool level0_halo_down = true;          // false: only the post-smoothing sweeps see the neighbours (A/B: OPMGPU_CPR_L0_HALO=2)
     DevArray<double> tune_parts;
     // levels[0].b := A s for an algebraically smooth s (pseudo-random start, `sweeps` Jacobi sweeps on A s = 0): the kind of error the
     // coarse-grid correction of a cycle meets.  The caller's right-hand side is parked in tune_b until restore_rhs().

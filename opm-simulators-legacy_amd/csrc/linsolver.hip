@@ -975,7 +975,7 @@ LinSolver::LinSolver(hipStream_t s) : stream(s)
     if (const char* e = std::getenv("OPMGPU_FACTOR_GRID")) factor_grid_cap = std::atoi(e);
     if (const char* e = std::getenv("OPMGPU_CS_RECUR")) cs_recur = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_CS_FUSED")) cs_fused_env = std::atoi(e) != 0;
-    if (const char* e = std::getenv("OPMGPU_CPR_L0_HALO")) cpr_l0_halo = std::atoi(e) != 0;
+    if (const char* e = std::getenv("OPMGPU_CPR_L0_HALO")) { cpr_l0_halo = std::atoi(e) != 0; cpr_l0_halo_down = std::atoi(e) != 2; }
     if (const char* e = std::getenv("OPMGPU_AMG_AUTOTUNE")) amg_autotune = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_AMG_ADAPT")) corr_policy.on = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_AMG_ADAPT_ARM")) corr_policy.arm[1] = std::atof(e);
@@ -2153,6 +2153,7 @@ template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, con
             halo_dispatch(cm, hx, st);
             hipLaunchKernelGGL((k_l0_ghosts<S>), dim3(grid_for(nbl)), dim3(kBlock), 0, st, nbl, cm->owner_mask(), (const S*)hx, x, b, ctl);
         };
+        w.amg->level0_halo_down = cpr_l0_halo_down;
     } else w.amg->level0_halo = nullptr;
     if (ell.inner) elliptic_solve<S>(); else w.amg->vcycle_graph(ctl, true);
     kt.end(KT_VCYCLE, kt_a);

@@ -333,7 +333,7 @@ public:
     // application under GMRES, 3 under BiCGStab).  The rank-local hierarchy is what fails on heterogeneous decks (SPE10-like: 4.7 -> 46
     // iterations when only the AMG's matrix is cut, 9 with level 0 uncut: profiles/r04_ag_emulate_l0_global.log); on smooth decks the
     // counts are the single-domain ones without it.  opmgpu_params has no field for it: OPMGPU_CPR_L0_HALO=1 / 0, default 1 (on).
-    bool cpr_l0_halo = true;
+    bool cpr_l0_halo = true, cpr_l0_halo_down = true;
     DevArray<double> cs_state;     // [2 ns]: restricted residual of p, of r
     hipStream_t halo_stream = nullptr;
     hipEvent_t ev_halo[2] = { nullptr, nullptr };
