@@ -131,6 +131,7 @@ def parse_args(argv):
     ap.add_argument("--rate", type=float, default=1000.0, help="injection rate of the 5-spot, m3/day")
     ap.add_argument("--spin-up", type=int, default=2, help="time steps that pass before the measurement (deck set-up, untimed)")
     ap.add_argument("--cut-axis", type=int, default=1, choices=[0, 1], help="N > 1, --deck spe10like: cut into slabs along i (0) or j (1, default); both keep the vertical wells whole")
+    ap.add_argument("--ilu-fill", type=int, default=0, help="block ILU(n) with level-of-fill instead of the ILU0: cpr_ilu_n under --solver cpr, ilu_fillin_level otherwise (A/B; default 0)")
     ap.add_argument("--stage2-relax", type=float, default=None,
                     help="opmgpu_params.cpr_stage2_relax (library extension: damping of the stage-2 ILU0 alone; 1.0 = the reference's form).  Default: 1.0 -- except on the "
                          "DECOMPOSED SPE10-like deck, 0.9: with the undamped second stage the 4-rank run chops 9 of 12 steps (profiles/r04_z_dist_spe10_relax.log)")
@@ -240,12 +241,16 @@ def main(argv=None):
               # library extension (opmgpu_params.preconditioner_single): the headline's solver with its preconditioner in float, Krylov method in double
               "cpr_mixed": dict(capi.CPR_AMG_VCYCLE, preconditioner_single=1),
               # library extension (opmgpu_params.cpr_stage2_relax = 0.9): the damped second stage of rounds 1-3 -- the recommended, most robust setting
-              "cpr_damped": dict(capi.CPR_AMG_VCYCLE, cpr_stage2_relax=0.9)}
+              "cpr_damped": dict(capi.CPR_AMG_VCYCLE, cpr_stage2_relax=0.9),
+              # block ILU(1) with level-of-fill (csrc/fillilu.inl): the interleaved solver's ilu_fillin_level, the CPR plug-in's cpr_ilu_n
+              "ilu1": dict(use_cpr=0, ilu_fillin_level=1), "cpr_ilu1": dict(capi.CPR_AMG_VCYCLE, cpr_ilu_n=1)}
 
     def make_params(solver=args.solver, krylov=args.krylov, verify=verify):
         kw = dict(CPR_KW[solver])
         if kw.get("use_cpr"):
             kw.setdefault("cpr_stage2_relax", args.stage2_relax)
+        if args.ilu_fill:
+            kw.setdefault("cpr_ilu_n" if kw.get("use_cpr") else "ilu_fillin_level", args.ilu_fill)
         return capi.default_params(ilu_ordering=ordering, newton_use_gmres={"gmres": 1, "fgmres": 2}.get(krylov, 0),
                                    gmres_verify_residual=verify if krylov == "gmres" else 0, **kw)
 
@@ -471,6 +476,8 @@ def main(argv=None):
 
         variant("ref_default_ilu0", "ilu0", "bicgstab", dt_main, reference_single("ilu0", dt_main),
                 note="solver_approach=interleaved, the reference's DEFAULT: block-ILU0 + BiCGStab, float because dt < 20 d")
+        variant("ilu1_bicgstab", "ilu1", "bicgstab", dt_main, reference_single("ilu0", dt_main),
+                note="solver_approach=interleaved with ilu_fillin_level = 1 (ISTLSolver.hpp:205): block ILU(1) + BiCGStab, float because dt < 20 d")
         if args.solver == "cpr":
             variant("cpr_ref_defaults", "cpr_ref", "bicgstab", dt_main, False,
                     note="solver_approach=cpr with the plug-in's documented defaults (NewtonIterationBlackoilCPR.hpp:59-63): cpr_use_amg=false -- the pressure system "
@@ -495,6 +502,9 @@ def main(argv=None):
             variant("cpr_f64_bicgstab_damped", "cpr_damped", "bicgstab", dt_main, False,
                     note="library extension, the RECOMMENDED configuration: CPR + BiCGStab in double with the second stage damped by 0.9 (cpr_stage2_relax) -- "
                          "the lowest ms per converged time step of the reference-arithmetic configurations and the robust one at long time steps and on the other decks")
+            variant("cpr_f64_%s_ilu1" % args.krylov, "cpr_ilu1", args.krylov, dt_main, False,
+                    note="the headline's solver with cpr_ilu_n = 1 (NewtonIterationBlackoilCPR.hpp:61): block ILU(1) with level-of-fill as the second stage, "
+                         "multicolour elimination order of the filled pattern")
             variant("cpr_f32_%s" % args.krylov, "cpr", args.krylov, dt_main, True,
                     note="NOT a configuration the reference can run (its CPR plug-in is double-only, NewtonIterationBlackoilCPR.cpp:117-140): kept for continuity")
         if use_wells:
@@ -604,9 +614,9 @@ def main(argv=None):
         if prm.use_cpr:
             stage1 = ("amg" if prm.cpr_use_amg else "ilu0(A_p)") + (" V-cycle" if (prm.cpr_use_amg and prm.cpr_max_ell_iter == 0) else
                                                                     " in %s(tol %g, <= %d)" % ("bicgstab" if prm.cpr_use_bicgstab else "cg", prm.cpr_solver_tol, prm.cpr_max_ell_iter))
-            lin_name = "cpr(%s + ilu0, relax %g%s) + %s" % (stage1, prm.cpr_relax, "" if prm.cpr_stage2_relax == 1.0 else ", stage-2 damping %g" % prm.cpr_stage2_relax, kry)
+            lin_name = "cpr(%s + ilu%d, relax %g%s) + %s" % (stage1, prm.cpr_ilu_n, prm.cpr_relax, "" if prm.cpr_stage2_relax == 1.0 else ", stage-2 damping %g" % prm.cpr_stage2_relax, kry)
         else:
-            lin_name = "ilu0(relax %g) + %s" % (prm.ilu_relaxation, kry)
+            lin_name = "ilu%d(relax %g) + %s" % (prm.ilu_fillin_level, prm.ilu_relaxation, kry)
         if prm.use_cpr and not single_main and prm.newton_use_gmres != 2:
             equiv = "solver_approach=cpr cpr_use_amg=%s%s cpr_relax=%g in double (NewtonIterationBlackoilCPR.hpp:59-63, .cpp:117-140)" % (
                 "true" if prm.cpr_use_amg else "false", " newton_use_gmres=true" if prm.newton_use_gmres else "", prm.cpr_relax)

@@ -180,7 +180,8 @@ typedef struct opmgpu_params {
      *     by the external opm-simulators CPRPreconditioner, whose source is NOT under /root/reference) ------------------------------------ */
     double cpr_relax;               /* 1.0: relaxation of the CPR preconditioner -- the ILU0 of stage 2 is built with it INSTEAD of
                                        ilu_relaxation, and a value != 1 also scales the pressure correction of stage 1 */
-    int32_t cpr_ilu_n;              /* 0: fill-in level of stage 2's ILU(n).  Only 0 is built: > 0 -> OPMGPU_EINVAL at the first CPR solve */
+    int32_t cpr_ilu_n;              /* 0: fill-in level of stage 2's ILU(n) (NewtonIterationBlackoilCPR.hpp:61): n > 0 = block ILU(n) with level-of-fill, see
+                                       ilu_fillin_level below.  0..8; not with cpr_reference_transform = 2 */
     int32_t cpr_use_amg;            /* 0 = the elliptic (pressure) part is preconditioned by a POINT ILU0 of A_p (the documented default),
                                        1 = by one AMG V-cycle on A_p (amg.hip) */
     int32_t cpr_use_bicgstab;       /* 1 = BiCGStab for the elliptic part, 0 = CG */
@@ -207,6 +208,14 @@ typedef struct opmgpu_params {
                                        what the inner one attained).  0 = library extension, no inner Krylov method at all: ONE application
                                        of the elliptic preconditioner (with cpr_use_amg = 1: one V-cycle, its coarse-grid corrections scaled
                                        as DESIGN.md section 4b describes) -- what bench.py's headline runs, and says so */
+    int32_t ilu_fillin_level;       /* 0: `ilu_fillin_level` of the interleaved solver (ISTLSolver.hpp:205, handed to ParallelOverlappingILU0):
+                                       n > 0 = block ILU(n) with level-of-fill instead of the ILU0.  Under use_cpr the second stage takes
+                                       cpr_ilu_n (above) instead.  Both run csrc/fillilu.inl: the level-of-fill rule for the pattern
+                                       (lev(i,j) = min lev(i,k) + lev(k,j) + 1 <= n, rows in the caller's order; dune-istl is not in the
+                                       reference tree: parity unpinned), this library's block ILU kernels on that pattern's own plan.  With
+                                       ilu_ordering = OPMGPU_ORDER_NATURAL the elimination order is the caller's (dune's); MULTICOLOR colours
+                                       the filled graph.  n <= 8; a filled pattern beyond 12 x the matrix's blocks is refused.  Measured
+                                       (profiles/r04_aj_ilu_n.log): fewer iterations, never less time -- an option for parity of settings */
 } opmgpu_params;
 
 void opmgpu_default_params(opmgpu_params* p);

@@ -1608,7 +1608,7 @@ void BlackoilDevice::assemble(double dt, bool initial)
     }
     // the matrix is final (the host well model, if any, adds its blocks later: not then): start its ILU0 factorisation now, see LinSolver::factor_early
     ls.factor_early = 0;
-    if (ls.factor_early_on && ls.factor_overlap && prm.use_cpr && !prm.cpr_reference_transform && ls.emulate_ranks <= 1 && !host_wells) {
+    if (ls.factor_early_on && ls.factor_overlap && prm.use_cpr && !prm.cpr_reference_transform && ls.emulate_ranks <= 1 && !host_wells && prm.cpr_ilu_n == 0 && ls.fill_level == 0) {
         ls.wb_relax = prm.cpr_relax * prm.cpr_stage2_relax;
         if (dual_written && !ls.matrix_is_float) {       // the float copy came with the assembly; the wells' diagonal contributions follow it
             if (device_wells && nperf > 0)

@@ -111,6 +111,8 @@ struct Timed {
     ~Timed() { if (e1) { (void)hipEventRecord(e1, c->stream); return; } (void)hipEventRecord(c->evp[ph][1], c->stream); c->ev_pending[ph] = true; }
 };
 
+static inline int fill_level_of(const opmgpu_params& prm) { return prm.use_cpr ? prm.cpr_ilu_n : prm.ilu_fillin_level; }
+
 template <class S> int solve_loaded(opmgpu_ctx* c, bool matrix_changed, SolveResult& res)
 {
     LinSolver& ls = *c->ls;
@@ -118,7 +120,7 @@ template <class S> int solve_loaded(opmgpu_ctx* c, bool matrix_changed, SolveRes
     // the interleaved solver's ilu_relaxation: the solvers below read ONE relaxation field
     opmgpu_params prm = c->prm;
     if (prm.use_cpr) {
-        if (prm.cpr_ilu_n != 0) return fail(c, OPMGPU_EINVAL, "cpr_ilu_n > 0 (ILU(n) with fill-in) is not built: only cpr_ilu_n = 0");
+        if (prm.cpr_ilu_n > 0 && prm.cpr_reference_transform == 2) return fail(c, OPMGPU_EINVAL, "cpr_ilu_n > 0 with cpr_reference_transform = 2: the point ILU of the scalar system is an ILU0");
         if (!(prm.cpr_relax > 0.0) || !(prm.cpr_solver_tol > 0.0) || prm.cpr_max_ell_iter < 0) return fail(c, OPMGPU_EINVAL, "cpr_relax / cpr_solver_tol must be positive, cpr_max_ell_iter >= 0");
         if (!(prm.cpr_stage2_relax > 0.0)) return fail(c, OPMGPU_EINVAL, "cpr_stage2_relax must be positive");
         prm.ilu_relaxation = prm.cpr_relax * prm.cpr_stage2_relax;
@@ -128,6 +130,10 @@ template <class S> int solve_loaded(opmgpu_ctx* c, bool matrix_changed, SolveRes
         ls.ell.tol = prm.cpr_solver_tol; ls.ell.maxit = prm.cpr_max_ell_iter; ls.ell.relax = prm.cpr_relax;
     }
     ls.wb_relax = prm.ilu_relaxation;
+    // block ILU(n) instead of the ILU0 (fillilu.inl): cpr_ilu_n under CPR, the interleaved solver's ilu_fillin_level otherwise
+    const int fill = fill_level_of(prm);
+    if (fill < 0 || fill > 8) return fail(c, OPMGPU_EINVAL, "cpr_ilu_n / ilu_fillin_level must be in 0..8");
+    if (fill != ls.fill_level) { ls.join_factor(); ls.factor_early = 0; ls.fill_level = fill; }        // (an early factorisation of the other kind is void)
     if (prm.use_cpr) ls.correction_policy_choose();
     // mixed precision (preconditioner_single): a double solve with its preconditioner in the float work set; not with the in-place transform
     const bool mixed = prm.preconditioner_single && sizeof(S) == 8 && !(prm.use_cpr && prm.cpr_reference_transform) && ls.emulate_ranks <= 1;
@@ -202,6 +208,7 @@ void opmgpu_default_params(opmgpu_params* p)
     p->newton_use_gmres = 0; p->linear_solver_restart = 40;                                // NewtonIterationBlackoilCPR.cpp:61-64
     p->solve_welleq_initially = 1; p->tolerance_wells = 1e-4; p->tolerance_well_control = 1e-7; p->dbhp_max_rel = 1.0; p->update_equations_scaling = 0; p->gmres_verify_residual = 0; p->cpr_reference_transform = 0;   // BlackoilModelParameters.cpp:80-96
     p->cpr_relax = 1.0; p->cpr_ilu_n = 0; p->cpr_use_amg = 0; p->cpr_use_bicgstab = 1;       // NewtonIterationBlackoilCPR.hpp:59-63
+    p->ilu_fillin_level = 0;                                                                   // ISTLSolver.hpp:205
     p->cpr_solver_tol = 1e-2; p->cpr_stage2_relax = 1.0; p->preconditioner_single = 0; p->cpr_max_ell_iter = 25;                                       // external CPRPreconditioner (recollection, see opmgpu.h)
 }
 
@@ -692,6 +699,9 @@ int opmgpu_ilu0_factor(opmgpu_ctx* c)
     if (!c) return OPMGPU_EINVAL;
     return guarded(c, [&]() {
         const int st = ensure_prepared(c); if (st) return st;
+        const int fill = fill_level_of(c->prm);
+        if (fill < 0 || fill > 8) return fail(c, OPMGPU_EINVAL, "cpr_ilu_n / ilu_fillin_level must be in 0..8");
+        c->ls->fill_level = fill;
         const int s2 = c->cur_single ? c->ls->factor<float>() : c->ls->factor<double>();
         c->factored = (s2 == OPMGPU_OK);
         return s2 == OPMGPU_OK ? int(OPMGPU_OK) : fail(c, s2, "singular diagonal block in ILU0");
@@ -728,6 +738,7 @@ int opmgpu_ilu0_get(opmgpu_ctx* c, double* val9)
 {
     if (!c || !val9) return OPMGPU_EINVAL;
     if (!c->factored) return fail(c, OPMGPU_EINVAL, "call opmgpu_ilu0_factor first");
+    if (c->ls->fill_level > 0) return fail(c, OPMGPU_EINVAL, "opmgpu_ilu0_get returns the ILU0 factors on the matrix's pattern: not with cpr_ilu_n / ilu_fillin_level > 0");
     return guarded(c, [&]() { if (c->cur_single) c->ls->get_lu_bsr<float>(val9); else c->ls->get_lu_bsr<double>(val9); return OPMGPU_OK; });
 }
 

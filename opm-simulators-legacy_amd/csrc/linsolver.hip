@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 
 namespace opmgpu {
 
@@ -1188,8 +1189,12 @@ __global__ __launch_bounds__(kBlock) void k_wb_apply(LowRankOp lr, int nbp, cons
     }
 }
 
+template <> LinSolver::FillWork<float>& LinSolver::FillIlu::work<float>() { return wf; }
+template <> LinSolver::FillWork<double>& LinSolver::FillIlu::work<double>() { return wd; }
+
 template <class S> int LinSolver::factor(bool wait)
 {
+    if (fill_level > 0) return fill_factor<S>(wait);
     SolverWork<S>& w = work<S>();
     KtScope kts(kt, KT_ILU_FACTOR);
     flags.zero(stream);
@@ -1247,6 +1252,7 @@ template <class S> void LinSolver::ilu_apply(const S* d, S* v, double relax, con
 {
     join_factor();
     KtScope kts(kt, KT_ILU_APPLY);
+    if (fill_level > 0) { fill_apply<S>(d, v, relax, ctl); return; }
     SolverWork<S>& w = work<S>();
     const int L = plan.nlevels;
     const int n0 = plan.level_ptr[1];
@@ -2093,6 +2099,7 @@ static void allreduce_halo(CommBase* c, double* d, int n, float* v, hipStream_t 
 static void allreduce_halo(CommBase* c, double* d, int n, double* v, hipStream_t s);
 
 #include "elliptic.inl"
+#include "fillilu.inl"
 #include "pointilu.inl"
 
 // M^-1 d = [x_p;0;0] + ILU0^-1 (d - A [x_p;0;0]),  x_p = Vcycle(sum of the equations of d) -- or the inner Krylov solve of elliptic.inl
@@ -2217,7 +2224,7 @@ template <class S> void LinSolver::cpr_apply(const S* d, S* v, double relax, con
     if (point_stage2 && sizeof(S) == 8) point_ilu_apply(reinterpret_cast<const double*>(w.z.p), reinterpret_cast<double*>(v), relax);      // the reference's own stage 2 (pointilu.inl)
     else ilu_apply<S>(w.z.p, v, relax, ctl);
     kt_a = kt.begin();
-    if (well_woodbury && wb_active && lowrank.nw > 0 && lowrank.P && !comm && wb_buf.p)
+    if (well_woodbury && wb_active && lowrank.nw > 0 && lowrank.P && !comm && wb_buf.p && fill_level == 0)
         hipLaunchKernelGGL((k_wb_apply<S>), dim3(lowrank.nw), dim3(kBlock), 0, stream, lowrank, plan.nbp, (const double*)wb_buf.p,
                            (const double*)(wb_buf.p + size_t(21) * lowrank.nperf), v, ctl);
     hipLaunchKernelGGL((k_cpr_add_p<S>), dim3(g), dim3(kBlock), 0, stream, plan.nb, xp, v, ctl, S(ell.relax));
@@ -2335,7 +2342,7 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
     if (cpr) { if (mx) { if (!wf.amg->npost0_user) wf.amg->npost0 = 2; } else if (!w.amg->npost0_user) w.amg->npost0 = 2; }   // post-sweeps on level 0: 2 under BiCGStab, 1 under GMRES (see gmres)
     // (with cpr_relax != 1 the pressure part of M^-1 p is scaled, which the closed form does not cover)
     // (mixed precision: the float ILU0 is not the ILU0 of exactly the double matrix -- the closed form would be off by float rounding)
-    const bool closed = closed_form_level0 && emulate_ranks <= 1 && !(cpr && ell.relax != 1.0) && !mx && !(cpr && point_stage2);      // (ell.relax = cpr_relax; under CPR prm.ilu_relaxation holds cpr_relax * cpr_stage2_relax: solve_loaded)
+    const bool closed = closed_form_level0 && emulate_ranks <= 1 && !(cpr && ell.relax != 1.0) && !mx && !(cpr && point_stage2) && fill_level == 0;      // (ell.relax = cpr_relax; under CPR prm.ilu_relaxation holds cpr_relax * cpr_stage2_relax: solve_loaded)
     const int8_t* lightmask = nullptr;
     const bool overlap = comm && halo_overlap;
     if (comm && (closed || overlap)) {

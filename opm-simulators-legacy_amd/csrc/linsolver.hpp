@@ -203,6 +203,22 @@ public:
         bool built = false, stale = true;
         int for_nb = 0, for_nnzb = 0, for_ordering = -1, for_plan_id = -1;
     } pilu;
+    // block ILU(n) with level-of-fill (fillilu.inl): opmgpu_params.cpr_ilu_n / ilu_fillin_level.  fill_level > 0 reroutes factor<S>() and
+    // ilu_apply<S>() to the filled pattern's own plan; 0 = the ILU0 on the matrix's pattern
+    template <class S> struct FillWork { DevArray<S> val, lu, d, v; };
+    struct FillIlu {
+        Plan plan; DevPlan dp;
+        DevArray<int32_t> src;         // [nentries of the filled plan] entry of the block in the matrix's SELL-64 layout, -1 = fill / padding
+        DevArray<int32_t> vmap;        // [nb] row of the matrix's plan for each row of the filled plan
+        FillWork<float> wf; FillWork<double> wd;
+        template <class S> FillWork<S>& work();
+        bool built = false;
+        int for_level = -1, for_ordering = -1, for_plan_id = -1, nnzb_filled = 0;
+    } fill;
+    int fill_level = 0;
+    void fill_setup();
+    template <class S> int fill_factor(bool wait);
+    template <class S> void fill_apply(const S* d, S* v, double relax, const SolveCtl* ctl);
     int plan_id = 0;                   // counts re-plans (set_pattern)
     bool point_stage2 = false;         // set per solve (capi.hip)
     void point_ilu_setup();

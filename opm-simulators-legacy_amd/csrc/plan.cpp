@@ -84,12 +84,31 @@ int build_plan(int nb, const int32_t* rowptr, const int32_t* col, int ordering, 
         }
         if (!diag) return OPMGPU_EINVAL;
     }
+    // --- structurally non-symmetric patterns (the ILU(n) fill of fillilu.inl from n = 2 on): the two sweeps of the ILU need every coupled
+    // pair of rows in DIFFERENT levels, ordered like the elimination order, whichever of (i,j), (j,i) exists -- the dependency graph is the
+    // undirected one.  xadj lists, per row, the neighbours that appear only in the OTHER row's pattern (empty for the Jacobian's pattern).
+    std::vector<int32_t> xptr(size_t(nb) + 1, 0), xadj;
+    {
+        std::vector<std::pair<int32_t, int32_t> > miss;          // (j, i): entry (i,j) without (j,i)
+        for (int i = 0; i < nb; ++i)
+            for (int s = rowptr[i]; s < rowptr[i + 1]; ++s) {
+                const int j = col[s];
+                if (j != i && !std::binary_search(col + rowptr[j], col + rowptr[j + 1], i)) miss.push_back(std::make_pair(j, i));
+            }
+        if (!miss.empty()) {
+            std::sort(miss.begin(), miss.end());
+            xadj.resize(miss.size());
+            for (size_t q = 0; q < miss.size(); ++q) { xptr[size_t(miss[q].first) + 1]++; xadj[q] = miss[q].second; }
+            for (int i = 0; i < nb; ++i) xptr[size_t(i) + 1] += xptr[i];
+        }
+    }
     // --- orientation key: NATURAL = caller index; MULTICOLOR = (greedy first-fit colour, caller index)
     std::vector<int32_t> colour(nb, 0);
     if (ordering == OPMGPU_ORDER_MULTICOLOR) {
         std::vector<int32_t> mark(nb + 1, -1);          // mark[c] == i  <=> colour c used by a neighbour of i
         for (int i = 0; i < nb; ++i) {
             for (int s = rowptr[i]; s < rowptr[i + 1]; ++s) { const int j = col[s]; if (j < i) mark[colour[j]] = i; }
+            for (int s = xptr[i]; s < xptr[i + 1]; ++s) { const int j = xadj[s]; if (j < i) mark[colour[j]] = i; }
             int c = 0; while (mark[c] == i) ++c;
             colour[i] = c;
         }
@@ -103,6 +122,7 @@ int build_plan(int nb, const int32_t* rowptr, const int32_t* col, int ordering, 
     for (int t = 0; t < nb; ++t) {
         const int i = topo[t]; int l = 0;
         for (int s = rowptr[i]; s < rowptr[i + 1]; ++s) { const int j = col[s]; if (j != i && before(j, i)) l = std::max(l, lev[j] + 1); }
+        for (int s = xptr[i]; s < xptr[i + 1]; ++s) { const int j = xadj[s]; if (before(j, i)) l = std::max(l, lev[j] + 1); }
         lev[i] = l; nlev = std::max(nlev, l + 1);
     }
     // --- internal numbering: sort by (level, caller index).  (A/B on MI355X, 100^3: re-grouping the rows of a level
@@ -215,6 +235,7 @@ int build_plan(int nb, const int32_t* rowptr, const int32_t* col, int ordering, 
             for (int b = P.nlower[j] + 1; b < P.rowlen[j]; ++b) {
                 const int ejk = P.entry(j, b); const int k = P.sell_col[ejk];
                 if (slot_of[k] < 0) continue;
+                if (P.trip_l.size() >= size_t(0x7fff0000)) return OPMGPU_EINVAL;          // (int32 triple ids: a pattern this dense is not an ILU pattern)
                 P.trip_l.push_back(eij); P.trip_u.push_back(ejk); P.trip_t.push_back(P.entry(i, slot_of[k]));
             }
         }
@@ -229,6 +250,46 @@ int build_plan(int nb, const int32_t* rowptr, const int32_t* col, int ordering, 
         P.simple[i] = sm ? 1 : 0;
     }
     return OPMGPU_OK;
+}
+
+// symbolic ILU(n) of the caller's pattern, level-of-fill (csrc/fillilu.inl): rows in the caller's order; entries of A have level 0, the
+// elimination of (i,k) by row k offers (i,j) the level lev(i,k) + lev(k,j) + 1 for every kept (k,j), j > k; an entry is kept at its
+// smallest offer when that is <= n.  src2[b2] = block of the caller's pattern, -1 for fill
+void build_fill_pattern(const Plan& P, int n, std::vector<int32_t>& rowptr2, std::vector<int32_t>& col2, std::vector<int32_t>& src2)
+{
+    const int nb = P.nb;
+    std::vector<std::vector<std::pair<int32_t, int8_t>>> rows(nb);       // (column, level), ascending columns
+    std::vector<int32_t> diag_at(nb, 0);
+    std::map<int32_t, int> pat;
+    rowptr2.assign(size_t(nb) + 1, 0);
+    for (int i = 0; i < nb; ++i) {
+        pat.clear();
+        for (int s = P.rowptr[i]; s < P.rowptr[i + 1]; ++s) pat[P.col[s]] = 0;
+        for (auto ik = pat.begin(); ik != pat.end() && ik->first < i; ++ik) {          // (entries inserted below sit behind ik: columns > k)
+            const auto& rk = rows[ik->first];
+            for (size_t q = size_t(diag_at[ik->first]) + 1; q < rk.size(); ++q) {
+                const int lev = ik->second + rk[q].second + 1;
+                if (lev > n) continue;
+                auto it = pat.find(rk[q].first);
+                if (it == pat.end()) pat[rk[q].first] = lev; else if (lev < it->second) it->second = lev;
+            }
+        }
+        auto& ri = rows[i];
+        ri.reserve(pat.size());
+        for (const auto& e : pat) { if (e.first == i) diag_at[i] = int32_t(ri.size()); ri.emplace_back(e.first, int8_t(e.second)); }
+        rowptr2[size_t(i) + 1] = rowptr2[i] + int32_t(ri.size());
+    }
+    col2.resize(size_t(rowptr2[nb])); src2.assign(size_t(rowptr2[nb]), -1);
+    for (int i = 0; i < nb; ++i) {
+        int s = P.rowptr[i];
+        int32_t o = rowptr2[i];
+        for (const auto& e : rows[i]) {
+            col2[o] = e.first;
+            while (s < P.rowptr[i + 1] && P.col[s] < e.first) ++s;
+            if (s < P.rowptr[i + 1] && P.col[s] == e.first) src2[o] = s;
+            ++o;
+        }
+    }
 }
 
 } // namespace opmgpu

@@ -58,6 +58,10 @@ struct Plan {
 // pattern without full diagonal / unsorted or duplicate columns / rows longer than 32767 blocks.
 int build_plan(int nb, const int32_t* rowptr, const int32_t* col, int ordering, Plan& plan);
 
+// symbolic block ILU(n) of P's caller pattern (level-of-fill, dune-istl's generation rule; csrc/fillilu.inl): the filled pattern in the
+// caller's numbering, src2[b2] = block of the caller's pattern or -1 for a fill entry
+void build_fill_pattern(const Plan& P, int n, std::vector<int32_t>& rowptr2, std::vector<int32_t>& col2, std::vector<int32_t>& src2);
+
 // structure of the reservoir Jacobian: {c} U face/NNC neighbours U well cliques (formInterleavedSystem
 // + the Schur fill of NewtonIterationUtilities.cpp:98-115).  conn_of_block[b] = (conn << 1 | side)
 // for the block in row c coupling to the other cell of connection `conn` (side 1 = c is c2),

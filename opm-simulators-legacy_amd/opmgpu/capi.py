@@ -86,7 +86,7 @@ class Params(C.Structure):
                 ("dbhp_max_rel", C.c_double), ("update_equations_scaling", C.c_int32),
                 ("gmres_verify_residual", C.c_int32), ("cpr_reference_transform", C.c_int32),
                 ("cpr_relax", C.c_double), ("cpr_ilu_n", C.c_int32), ("cpr_use_amg", C.c_int32), ("cpr_use_bicgstab", C.c_int32),
-                ("cpr_solver_tol", C.c_double), ("cpr_stage2_relax", C.c_double), ("preconditioner_single", C.c_int32), ("cpr_max_ell_iter", C.c_int32)]
+                ("cpr_solver_tol", C.c_double), ("cpr_stage2_relax", C.c_double), ("preconditioner_single", C.c_int32), ("cpr_max_ell_iter", C.c_int32), ("ilu_fillin_level", C.c_int32)]
 
 
 # use_cpr = 1 with the pressure stage this library was built around: ONE AMG V-cycle per application (cpr_use_amg = 1 without the inner
@@ -107,6 +107,7 @@ def default_params(**over):
     p.update_equations_scaling = 0
     p.gmres_verify_residual, p.cpr_reference_transform = 0, 0
     p.cpr_relax, p.cpr_ilu_n, p.cpr_use_amg, p.cpr_use_bicgstab = 1.0, 0, 0, 1            # NewtonIterationBlackoilCPR.hpp:59-63
+    p.ilu_fillin_level = 0                                                                                                                   # ISTLSolver.hpp:205
     p.cpr_solver_tol, p.cpr_stage2_relax, p.preconditioner_single, p.cpr_max_ell_iter = 1e-2, 1.0, 0, 25                                       # external CPRPreconditioner (recollection)
     for k, v in over.items():
         if k == "matbalscale":

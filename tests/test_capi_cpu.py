@@ -53,6 +53,7 @@ def test_default_params_match_reference(lib):
     # the elliptic part); the inner solve's tolerance / iteration limit live in the external CPRPreconditioner: recalled, parameters here
     assert (c.cpr_relax, c.cpr_ilu_n, c.cpr_use_amg, c.cpr_use_bicgstab) == (1.0, 0, 0, 1)
     assert (c.cpr_solver_tol, c.cpr_max_ell_iter, c.cpr_stage2_relax, c.preconditioner_single) == (1e-2, 25, 1.0, 0)
+    assert c.ilu_fillin_level == 0 and p.ilu_fillin_level == 0          # ISTLSolver.hpp:205 reads it; its default lives outside the tree (recalled: 0)
     v = capi.default_params(**capi.CPR_AMG_VCYCLE)
     assert (v.use_cpr, v.cpr_use_amg, v.cpr_max_ell_iter, v.linear_solver_maxiter) == (1, 1, 0, 50)
 

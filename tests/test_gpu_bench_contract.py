@@ -61,7 +61,7 @@ def test_bench_line_contract(gpu_lib):
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == d["unit"] and cb["sample"]
     v = d["variants"]
-    names = {"ref_default_ilu0", "cpr_ref_defaults", "cpr_amg_inner_bicgstab", "without_wells", "cpr_f64_bicgstab", "cpr_f64_gmres_verified", "cpr_f64_gmres_fixed_factor",
+    names = {"ref_default_ilu0", "ilu1_bicgstab", "cpr_f64_gmres_ilu1", "cpr_ref_defaults", "cpr_amg_inner_bicgstab", "without_wells", "cpr_f64_bicgstab", "cpr_f64_gmres_verified", "cpr_f64_gmres_fixed_factor",
              "cpr_f32_gmres", "cpr_f64_gmres_f32_precond", "cpr_f64_bicgstab_f32_precond", "cpr_f64_bicgstab_damped", "dt30_f64_ilu0", "dt30_f64_cpr_gmres", "dt30_f64_cpr_bicgstab", "dt1_f32_ilu0", "dt1_f64_cpr_gmres", "dt20_f64_ilu0", "dt20_f64_cpr_gmres"}
     assert names <= set(v), names - set(v)
     assert all(x != "failed" and x[0] > 0 for x in v.values()), v

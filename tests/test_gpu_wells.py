@@ -281,6 +281,9 @@ CPR_VARIANTS = {
     "amg_inner_cg": dict(use_cpr=1, cpr_use_amg=1, cpr_use_bicgstab=0),
     "amg_vcycle_relax_0.9": dict(use_cpr=1, cpr_use_amg=1, cpr_max_ell_iter=0, cpr_relax=0.9),
     "reference_defaults_relax_0.9_tight_inner": dict(use_cpr=1, cpr_relax=0.9, cpr_solver_tol=1e-4, cpr_max_ell_iter=60),
+    # cpr_ilu_n: block ILU(n) with level-of-fill as the second stage (csrc/fillilu.inl)
+    "reference_defaults_ilu1": dict(use_cpr=1, cpr_ilu_n=1),
+    "amg_vcycle_ilu2": dict(use_cpr=1, cpr_use_amg=1, cpr_max_ell_iter=0, cpr_ilu_n=2),
 }
 
 
@@ -360,10 +363,11 @@ def test_float_preconditioner_walks_the_double_newton_path_with_device_wells(gpu
 
 
 def test_cpr_parameter_combinations_that_are_not_built_are_refused(gpu_lib):
-    """cpr_ilu_n > 0 (ILU(n) with fill-in) and the one-application stage without the AMG are errors at the first solve, not silent fallbacks"""
+    """cpr_ilu_n outside 0..8 (or with the point-ILU0 comparison mode) and the one-application stage without the AMG are errors at the first solve,
+    not silent fallbacks"""
     from opmgpu.model import LinearSolverProblem  # noqa: F401
     grid, tab, st, _ = _setup()
-    for kw, text in ((dict(use_cpr=1, cpr_ilu_n=1), "cpr_ilu_n"), (dict(use_cpr=1, cpr_use_amg=0, cpr_max_ell_iter=0), "cpr_max_ell_iter"), (dict(use_cpr=1, cpr_relax=0.0), "cpr_relax")):
+    for kw, text in ((dict(use_cpr=1, cpr_ilu_n=9), "cpr_ilu_n"), (dict(use_cpr=1, cpr_ilu_n=1, cpr_reference_transform=2, cpr_use_amg=1, cpr_max_ell_iter=0), "cpr_ilu_n"), (dict(use_cpr=1, cpr_use_amg=0, cpr_max_ell_iter=0), "cpr_max_ell_iter"), (dict(use_cpr=1, cpr_relax=0.0), "cpr_relax")):
         gm = GpuBlackoilModel(grid, tab, capi.default_params(**kw))
         gm.prepareStep(2 * decks.DAY, st)
         gm.assemble(True); gm.getConvergence()
