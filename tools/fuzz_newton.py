@@ -37,6 +37,8 @@ for case in range(ncases):
     pk = [dict(use_cpr=0), dict(capi.CPR_AMG_VCYCLE), dict(use_cpr=1), dict(use_cpr=1, cpr_use_bicgstab=0), dict(use_cpr=1, cpr_use_amg=1)][stage]
     if rng.random() < 0.4: pk["preconditioner_single"] = 1
     if stage and rng.random() < 0.4: pk["cpr_stage2_relax"] = 0.9
+    # block ILU(n) with level-of-fill instead of the ILU0 (csrc/fillilu.inl): cpr_ilu_n under CPR, ilu_fillin_level otherwise
+    if rng.random() < 0.3: pk["cpr_ilu_n" if stage else "ilu_fillin_level"] = int(rng.integers(1, 4))
     # (a float preconditioner is not one fixed linear operator: BiCGStab's recurrences stall around 1e-9 .. 1e-10 with it -- case 4080 of this
     # campaign: 163 iterations to 9.9e-10, then a breakdown, where the double preconditioner needs 12 iterations for 7.5e-13 -- so the mixed
     # cases ask for 1e-8 and are compared at 1e-5; the Newton solves the option is meant for ask for 1e-2)
