@@ -1607,19 +1607,27 @@ void BlackoilDevice::assemble(double dt, bool initial)
         wells_assemble(initial);
     }
     // the matrix is final (the host well model, if any, adds its blocks later: not then): start its ILU0 factorisation now, see LinSolver::factor_early
+    // -- or, factor_early_mode 2, behind the kernels of the convergence check that follows (convergence()): the factorisation then has the device
+    // to itself while the host reads the check's result back, instead of slowing the check's small kernels down
     ls.factor_early = 0;
-    if (ls.factor_early_on && ls.factor_overlap && prm.use_cpr && !prm.cpr_reference_transform && ls.emulate_ranks <= 1 && !host_wells && prm.cpr_ilu_n == 0 && ls.fill_level == 0) {
-        ls.wb_relax = prm.cpr_relax * prm.cpr_stage2_relax;
-        if (dual_written && !ls.matrix_is_float) {       // the float copy came with the assembly; the wells' diagonal contributions follow it
-            if (device_wells && nperf > 0)
-                hipLaunchKernelGGL(k_refresh_f32_diag, dim3(grid_for(nperf)), dim3(kBlock), 0, stream, nperf, (const int32_t*)d_perf_cells.p, ls.dp.slice_ptr.p, ls.dp.nlower.p,
-                                   (const double*)ls.matrix_d(), ls.matrix_f());
-            ls.float_copy_valid = true;
-        }
-        if (ls.matrix_is_float) { ls.ensure_work<float>(); ls.factor_async<float>(); ls.factor_early = 4; }
-        else if (prm.preconditioner_single) { ls.mixed_prepare(true); ls.factor_async<float>(); ls.factor_early = 4; }      // mixed precision: the float copy, then its factors
-        else { ls.ensure_work<double>(); ls.factor_async<double>(); ls.factor_early = 8; }
+    early_factor_pending = ls.factor_early_on && ls.factor_overlap && prm.use_cpr && !prm.cpr_reference_transform && ls.emulate_ranks <= 1 && !host_wells && prm.cpr_ilu_n == 0 && ls.fill_level == 0;
+    if (early_factor_pending && ls.factor_early_mode == 1) start_early_factor();
+}
+
+void BlackoilDevice::start_early_factor()
+{
+    if (!early_factor_pending) return;
+    early_factor_pending = false;
+    ls.wb_relax = prm.cpr_relax * prm.cpr_stage2_relax;
+    if (dual_written && !ls.matrix_is_float) {       // the float copy came with the assembly; the wells' diagonal contributions follow it
+        if (device_wells && nperf > 0)
+            hipLaunchKernelGGL(k_refresh_f32_diag, dim3(grid_for(nperf)), dim3(kBlock), 0, stream, nperf, (const int32_t*)d_perf_cells.p, ls.dp.slice_ptr.p, ls.dp.nlower.p,
+                               (const double*)ls.matrix_d(), ls.matrix_f());
+        ls.float_copy_valid = true;
     }
+    if (ls.matrix_is_float) { ls.ensure_work<float>(); ls.factor_async<float>(); ls.factor_early = 4; }
+    else if (prm.preconditioner_single) { ls.mixed_prepare(true); ls.factor_async<float>(); ls.factor_early = 4; }      // mixed precision: the float copy, then its factors
+    else { ls.ensure_work<double>(); ls.factor_async<double>(); ls.factor_early = 8; }
 }
 
 double BlackoilDevice::time_assemble(int reps, int props_only)
@@ -1665,6 +1673,7 @@ int BlackoilDevice::convergence(double dt, double* B3, double* CNV3, double* MB3
         ls.comm->allreduce_sum(d_gather.p, nr * nv, stream);
         hipLaunchKernelGGL(k_conv_gather, dim3(1), dim3(kBlock), 0, stream, 1, nv, nr, ls.comm->my_rank(), d_red.p, d_gather.p);
     }
+    start_early_factor();          // (factor_early_mode 2: behind the check's kernels, beside the read-back below)
     // (polled host-mapped copy: no stream synchronisation); the device wells' residuals and error flags come along for well_convergence()
     const void *we = nullptr, *wf = nullptr; int nwe = 0;
     const bool with_wells = !ls.comm && well_words_sources(we, nwe, wf) && 26 + nwe + 1 <= LinSolver::kPubWords;

@@ -41,6 +41,8 @@ public:
     void assemble(double dt, bool initial);
     template <class MS> void assemble_kernels(double dt, bool initial, MS* A, bool props_only = false);
     bool assemble_single = false;      // precision of the coming solve (opmgpu_set_solve_precision)
+    bool early_factor_pending = false;      // the assembly left the early ILU0 factorisation to the convergence check (LinSolver::factor_early_mode 2)
+    void start_early_factor();
     int convergence(double dt, double* B3, double* CNV3, double* MB3, double* linf3, int* converged);
     void perf_props(double* out);
     void perf_pvt(const double* press, double* out);                 // host well model: PVT of the perforated cells at given pressures

@@ -356,6 +356,7 @@ int opmgpu_solve(opmgpu_ctx* c, int single_precision, double* dx, int* iters, do
         int st;
         {
             Timed t(c, PH_SOLVE);
+            c->model->early_factor_pending = false;          // (no convergence check between the assembly and this solve: the solve starts the factorisation itself)
             if (single_precision) { c->ls->ensure_work<float>(); c->model->build_rhs<float>(); st = solve_loaded<float>(c, true, res); if (st == OPMGPU_OK || st == OPMGPU_ELINSOLVE) c->model->store_dx<float>(); }
             else { c->ls->ensure_work<double>(); c->model->build_rhs<double>(); st = solve_loaded<double>(c, true, res); if (st == OPMGPU_OK || st == OPMGPU_ELINSOLVE) c->model->store_dx<double>(); }
         }

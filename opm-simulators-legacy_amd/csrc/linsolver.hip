@@ -972,7 +972,7 @@ LinSolver::LinSolver(hipStream_t s) : stream(s)
     if (const char* e = std::getenv("OPMGPU_CPR_HALO_XP")) cpr_halo_xp = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_HALO_OVERLAP")) halo_overlap = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_FACTOR_OVERLAP")) factor_overlap = std::atoi(e) != 0;
-    if (const char* e = std::getenv("OPMGPU_FACTOR_EARLY")) factor_early_on = std::atoi(e) != 0;
+    if (const char* e = std::getenv("OPMGPU_FACTOR_EARLY")) { factor_early_on = std::atoi(e) != 0; if (factor_early_on) factor_early_mode = std::atoi(e) == 2 ? 2 : 1; }
     if (const char* e = std::getenv("OPMGPU_FACTOR_GRID")) factor_grid_cap = std::atoi(e);
     if (const char* e = std::getenv("OPMGPU_CS_RECUR")) cs_recur = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_CS_FUSED")) cs_fused_env = std::atoi(e) != 0;

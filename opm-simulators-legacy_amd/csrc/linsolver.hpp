@@ -319,6 +319,7 @@ public:
     // factorised for nothing (device time only; such a call is 0.5 ms against 2.8).  factor_early: set by the model when it has started the
     // factorisation for the current matrix; solve_loaded then does not start another.  A/B: OPMGPU_FACTOR_EARLY=0
     bool factor_early_on = true;
+    int factor_early_mode = 1;     // OPMGPU_FACTOR_EARLY: 1 = behind the assembly, 2 = behind the convergence check's kernels (runs while the host reads them back)
     int factor_early = 0;          // 0 = not started; 4 / 8 = started for the float / double matrix
     // A factorisation on its side stream has slack (it is needed by the first ILU0 sweep, ~0.6 ms later): capped to `factor_grid_cap` workgroups
     // it runs longer but leaves the latency-bound kernels of the main stream their compute units and memory-queue slots.  0 = uncapped.
