@@ -131,6 +131,9 @@ def parse_args(argv):
     ap.add_argument("--rate", type=float, default=1000.0, help="injection rate of the 5-spot, m3/day")
     ap.add_argument("--spin-up", type=int, default=2, help="time steps that pass before the measurement (deck set-up, untimed)")
     ap.add_argument("--cut-axis", type=int, default=1, choices=[0, 1], help="N > 1, --deck spe10like: cut into slabs along i (0) or j (1, default); both keep the vertical wells whole")
+    ap.add_argument("--weak-axis", type=int, default=2, choices=[1, 2], help="weak scaling: the N copies of the workload are put side by side along j (1) or stacked along k (2)")
+    ap.add_argument("--stack", type=int, default=1, help="N = 1 only: the weak-scaling deck of N ranks (N copies of the workload stacked along k, one 5-spot per copy) on ONE GPU -- "
+                    "the single-domain iteration counts the decomposed run is compared with (diagnostic)")
     ap.add_argument("--ilu-fill", type=int, default=0, help="block ILU(n) with level-of-fill instead of the ILU0: cpr_ilu_n under --solver cpr, ilu_fillin_level otherwise (A/B; default 0)")
     ap.add_argument("--stage2-relax", type=float, default=None,
                     help="opmgpu_params.cpr_stage2_relax (library extension: damping of the stage-2 ILU0 alone; 1.0 = the reference's form).  Default: 1.0 -- except on the "
@@ -275,15 +278,21 @@ def main(argv=None):
             wells_fn = (lambda g: W.five_spot(g, rate_m3_per_day=args.rate, bhp_prod_bar=150.0)) if use_wells else None
             model, grid, st, info = partition.build_distributed_model(args.nx, args.ny, args.nz, tab, prm, rank, world, local_rank, wells_fn=wells_fn, axis=1)
         else:
-            wells_fn = (lambda g: W.five_spot(g, rate_m3_per_day=args.rate, bhp_prod_bar=150.0, slabs=world)) if use_wells else None
-            model, grid, st, info = partition.build_distributed_model(args.nx, args.ny, args.nz * world, tab, prm, rank, world, local_rank, wells_fn=wells_fn)
+            wells_fn = (lambda g: W.five_spot(g, rate_m3_per_day=args.rate, bhp_prod_bar=150.0, slabs=world, slab_axis=args.weak_axis)) if use_wells else None
+            dims = (args.nx, args.ny * world, args.nz) if args.weak_axis == 1 else (args.nx, args.ny, args.nz * world)
+            model, grid, st, info = partition.build_distributed_model(dims[0], dims[1], dims[2], tab, prm, rank, world, local_rank, wells_fn=wells_fn, axis=args.weak_axis)
         well_spec = None
         main_wells = info["wells"] if use_wells else None
     else:
+        if args.stack > 1:
+            if args.weak_axis == 1:
+                args.ny *= args.stack
+            else:
+                args.nz *= args.stack
         grid, st, well_spec = make_deck()
         model = GpuBlackoilModel(grid, tab, prm, device=local_rank)
         info = {"n_owned": grid.nc, "n_global": grid.nc}
-        main_wells = W.five_spot(grid, rate_m3_per_day=well_spec[0], bhp_prod_bar=well_spec[1]) if use_wells else None
+        main_wells = W.five_spot(grid, rate_m3_per_day=well_spec[0], bhp_prod_bar=well_spec[1], slabs=args.stack, slab_axis=args.weak_axis) if use_wells else None
     nc_global = info["n_global"]
 
     def barrier():
@@ -652,7 +661,7 @@ def main(argv=None):
             "ms_per_solving_iteration_median": r3(main_sum["ms_per_solving_iteration_median"]),
             "ms_per_solving_iteration_mean": r3(main_sum["ms_per_solving_iteration_mean"]),
             "value_mean_solving": r3(main_sum["value_mean_solving"]), "value_all_calls_mean": r3(main_sum["value_all_calls_mean"]),
-            "config": {"workload": "%s%dx%dx%d_3phase_blackoil%s" % ("spe10like_" if args.deck == "spe10like" else "cart", args.nx, args.ny, args.nz * (world if weak else 1),
+            "config": {"workload": "%s%dx%dx%d_3phase_blackoil%s" % ("spe10like_" if args.deck == "spe10like" else "cart", args.nx, args.ny * (world if (weak and args.weak_axis == 1 and args.deck != "spe10like") else 1), args.nz * (world if (weak and args.weak_axis == 2) else 1),
                                                                      "_fivespot" if use_wells else ""),
                        "cells": nc_global, "cells_per_gpu": info["n_owned"], "dt_days": args.dt_days, "linear_solver": lin_name,
                        "arithmetic": main_sum["arithmetic"], "reference_equivalence": equiv,

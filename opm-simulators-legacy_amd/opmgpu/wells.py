@@ -683,7 +683,7 @@ class DeviceWellModel:
         return converged, lin
 
 
-def five_spot(grid, rate_m3_per_day=500.0, bhp_prod_bar=150.0, wi=None, slabs=1):
+def five_spot(grid, rate_m3_per_day=500.0, bhp_prod_bar=150.0, wi=None, slabs=1, slab_axis=2):
     """SURVEY 8d synthetic wells: one water injector (rate controlled, full column) in the centre and four
     BHP-controlled producers in the corners of a Cartesian grid.  Peaceman-like WI from the cell transmissibility scale.
     slabs > 1 (weak-scaling decks stacked along k): one such 5-spot per slab of nz / slabs layers, every well inside its slab (a well lives
@@ -693,6 +693,18 @@ def five_spot(grid, rate_m3_per_day=500.0, bhp_prod_bar=150.0, wi=None, slabs=1)
     wells = Wells()
     WI = wi if wi is not None else 10.0 * float(np.median(grid.trans))
     z = grid.z
+    if slabs > 1 and slab_axis == 1:
+        # copies of the deck side by side along j: one 5-spot of full columns per slab of ny / slabs rows (all at the same depth)
+        per = ny // slabs
+        for s in range(slabs):
+            j0, j1 = s * per, (ny if s == slabs - 1 else (s + 1) * per)
+            col = lambda i, j: [i + nx * j + nx * ny * k for k in range(nz)]      # noqa: E731
+            tag = "_S%d" % s
+            wells.add_well("INJ" + tag, INJECTOR, z[col(nx // 2, (j0 + j1) // 2)[0]], col(nx // 2, (j0 + j1) // 2), WI, (1.0, 0.0, 0.0),
+                           (SURFACE_RATE, rate_m3_per_day / 86400.0, (1.0, 0.0, 0.0)))
+            for k, (i, j) in enumerate([(0, j0), (nx - 1, j0), (0, j1 - 1), (nx - 1, j1 - 1)]):
+                wells.add_well("PROD%d%s" % (k, tag), PRODUCER, z[col(i, j)[0]], col(i, j), WI, (0.0, 1.0, 0.0), (BHP, bhp_prod_bar * 1e5))
+        return wells
     per = nz // slabs
     for s in range(slabs):
         k0, k1 = s * per, (nz if s == slabs - 1 else (s + 1) * per)
