@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 
 namespace opmgpu {
 
@@ -2019,6 +2020,32 @@ template <class S> void LinSolver::cpr_prepare()
         if (l0_global && emulated && (emulate_what & 2)) {
             hipLaunchKernelGGL((k_extract_pressure<S>), dim3(grid_for(plan.nbp)), dim3(kBlock), 0, stream, plan.nb, plan.nbp, dp.slice_ptr.p, (const S*)w.cprw.p, matrix<S>(), w.amg->levels[0]->val.p);
             w.amg->galerkin(false);
+        }
+    }
+    {
+        // EXPERIMENT (emulated decomposition only, OPMGPU_EMULATE_GLOBAL_LEVELS=q): the q COARSEST levels of the hierarchy take the Galerkin
+        // operators of the UNCUT pressure matrix (through the same aggregates, which never cross a cut: cut entries are not strong), the finer
+        // levels keep the cut ones -- what a decomposed run with replicated / all-gathered coarse levels would cycle through.  How many
+        // levels have to be global before the single-domain iteration counts come back tells how far a distributed hierarchy has to reach.
+        static const int gq = std::getenv("OPMGPU_EMULATE_GLOBAL_LEVELS") ? std::atoi(std::getenv("OPMGPU_EMULATE_GLOBAL_LEVELS")) : 0;
+        if (gq > 0 && emulated && (emulate_what & 2) && w.amg->levels.size() >= 2) {
+            AmgHierarchy<S>& A = *w.amg;
+            const int nl = int(A.levels.size()), k = std::max(1, nl - gq);          // levels k .. nl-1 become global
+            std::vector<std::unique_ptr<DevArray<S>>> keep;
+            for (int l = 0; l < k; ++l)
+                for (DevArray<S>* src : { &A.levels[l]->val, &A.levels[l]->dinv }) {
+                    keep.emplace_back(new DevArray<S>()); keep.back()->alloc(src->n);
+                    OPMGPU_HIP(hipMemcpyAsync(keep.back()->p, src->p, src->n * sizeof(S), hipMemcpyDeviceToDevice, stream));
+                }
+            A.join_inverse();
+            hipLaunchKernelGGL((k_extract_pressure<S>), dim3(grid_for(plan.nbp)), dim3(kBlock), 0, stream, plan.nb, plan.nbp, dp.slice_ptr.p, (const S*)w.cprw.p, matrix<S>(), A.levels[0]->val.p);
+            A.galerkin();
+            size_t q = 0;
+            for (int l = 0; l < k; ++l)
+                for (DevArray<S>* dst : { &A.levels[l]->val, &A.levels[l]->dinv }) {
+                    OPMGPU_HIP(hipMemcpyAsync(dst->p, keep[q]->p, dst->n * sizeof(S), hipMemcpyDeviceToDevice, stream)); ++q;
+                }
+            OPMGPU_HIP(hipStreamSynchronize(stream));          // (the stash is freed on return)
         }
     }
     if (ell.inner && !ell.use_amg) elliptic_factor<S>();
