@@ -382,6 +382,34 @@ class StandardWellsHost:
         Ev = np.array([e.v[0] for e in E]); Ej = np.vstack([e.j for e in E])
         return cq_s, Ev, Ej
 
+    # computeWellPotentials (StandardWells_impl.hpp:1003-1095; called at the start of a report step when the deck has group controls,
+    # BlackoilModelBase_impl.hpp:2576-2619): the surface rates each well would deliver at its MOST RESTRICTIVE bhp limit -- the target of a
+    # BHP control, or the bhp a THP control implies at the well's current rates through its VFP table (hydrostatic correction applied):
+    # the smallest such bhp for an injector, the largest for a producer -- with the cells' explicit state.  The search starts from 0 like
+    # the reference's `Vector::Zero(nw)`, so a well without any BHP / THP control is evaluated at bhp = 0, and an injector's THP limit
+    # only counts when it lies below a BHP target seen earlier in the list.  Returns [nw, 3] (sum of computeWellFlux's cq_s per well).
+    def compute_well_potentials(self, pp, ws):
+        W = self.w
+        ws0 = ws.copy()
+        for w in range(W.nw):
+            bhp = 0.0
+            for ctrl in W.controls[w]:
+                if ctrl[0] == BHP:
+                    bhp = ctrl[1]
+                if ctrl[0] == THP:
+                    v, _ = self._bhp_from_thp(w, ctrl, ws.qs[w])
+                    if W.type[w] == INJECTOR:
+                        if v < bhp:
+                            bhp = v
+                    elif v > bhp:
+                        bhp = v
+            ws0.bhp[w] = bhp
+        pot = np.zeros((W.nw, 3))
+        for w in range(W.nw):
+            cq_s, _, _ = self._well_system(w, pp, ws0, const_cells=True)
+            pot[w] = [cq_s[a].v.sum() for a in range(3)]
+        return pot
+
     # computeWellFlux + addWellFluxEq + addWellControlEq for all wells; Schur-reduce every well onto its cells
     def assemble(self, pp, ws):
         W = self.w
@@ -532,6 +560,11 @@ class WellCoupledModel:
         m.addWellTerms(resid_delta, rc, blocks)
         m.addWellRhs(rhs_delta)
 
+    def computeWellPotentials(self):
+        """well potentials from the resident state (StandardWells::computeWellPotentials): [nw, 3]"""
+        pp = self.m.perfProps(self.nperf).reshape(self.nperf, 9, 4)
+        return self.wh.compute_well_potentials(pp, self.ws)
+
     def nonlinearIteration(self, iteration, single_precision=None, nonlinear_solver=None):
         """BlackoilModelBase::nonlinearIteration (BlackoilModelBase_impl.hpp:239-326)"""
         m, wh, ws = self.m, self.wh, self.ws
@@ -648,6 +681,19 @@ class DeviceWellModel:
 
     def relativeChange(self):
         return self.m.relativeChange()
+
+    def computeWellPotentials(self, z_cells, surface_density_wog, vfp_tables=()):
+        """StandardWells::computeWellPotentials with the wells on the device: a once-per-report-step host evaluation (as in the reference) from
+        the device's well state and the perforated cells' properties; the connection pressure differences are the device's own
+        (perfPress - bhp, StandardWells_impl.hpp:664-673)."""
+        ws = self.pull_well_state()
+        host = StandardWellsHost(self.w, z_cells, surface_density_wog, vfp_tables=vfp_tables)
+        pp = self.m.perfProps(self.w.nperf).reshape(self.w.nperf, 9, 4)
+        if host.vfp_active:
+            host.compute_connection_pressures(pp, ws, getattr(self.m, "perfPvtAt", None))          # densities for the hydrostatic correction
+        perf_well = np.repeat(np.arange(self.w.nw), np.diff(np.asarray(self.w.connpos)))
+        host.cdp = np.asarray(ws.perf_press) - np.asarray(ws.bhp)[perf_well]
+        return host.compute_well_potentials(pp, ws)
 
     def wellConvergence(self):
         from . import capi

@@ -163,6 +163,19 @@ class CoupledOracleModel:
         cq_s = cq_ps + cmix * cqt_is[:, None]
         return cq_s, ~dead
 
+    def well_potentials(self, props):
+        """StandardWells::computeWellPotentials (StandardWells_impl.hpp:1003-1095) for BHP limits (THP is outside this restatement): every
+        well at the last BHP target of its control list (0 without one), rates from the explicit cell properties: [nw, 3]"""
+        bhp = np.zeros(self.nw)
+        for w in range(self.nw):
+            for typ, target, _ in self.controls[w]:
+                if typ == BHP:
+                    bhp[w] = target
+        cq_s, _ = self.well_flux(props["p"], props["mob"], props["b"], props["rs"], props["rv"], bhp, self.ws.qs)
+        pot = np.zeros((self.nw, 3))
+        np.add.at(pot, self.perf_well, cq_s)
+        return pot
+
     def equations(self, props, bhp, qs):
         """flux equations [nw, 3], control equations [nw], cq_s [nperf, 3], alive"""
         cq_s, alive = self.well_flux(props["p"], props["mob"], props["b"], props["rs"], props["rv"], bhp, qs)

@@ -110,6 +110,59 @@ def test_independent_well_model_agrees_with_the_host_well_model(oracle, case):
         assert switched
 
 
+@pytest.mark.parametrize("case", CASES)
+def test_well_potentials_host_model_against_the_independent_one(oracle, case):
+    """StandardWells::computeWellPotentials (StandardWells_impl.hpp:1003-1095): opmgpu/wells.py (per-well dense AD system) against
+    oracle/wells.py (vectorised computeWellFlux) after two Newton iterations of the same deck -- each well at its most restrictive bhp limit,
+    rates from the explicit cell state.  Signs: producers deliver negative surface rates, injectors positive ones; a well whose limit equals
+    its current BHP control reproduces its current rates."""
+    from oracle.wells import CoupledOracleModel
+    grid, tab, st, make, start = _deck(case)
+    prm = capi.default_params(linear_solver_reduction=1e-12, linear_solver_maxiter=2000)
+    wl_i, wl_h = make(), make()
+    mi = CoupledOracleModel(grid, tab, prm, wl_i, _arrays(start(wl_i)))
+    ob = OracleBackend(oracle, grid, tab, prm, wells=wl_h.arrays())
+    mh = W.WellCoupledModel(ob, W.StandardWellsHost(wl_h, grid.z, tab.surface_density[0]), start(wl_h))
+    mi.prepareStep(5 * decks.DAY, st); mh.prepareStep(5 * decks.DAY, st)
+    for it in range(2):
+        mi.nonlinearIteration(it); mh.nonlinearIteration(it, single_precision=False)
+    ph = mh.computeWellPotentials()
+    vals, _ = mi.perf_props(mi.st)
+    pi = mi.well_potentials(vals)
+    assert ph.shape == (wl_h.nw, 3)
+    assert np.allclose(ph, pi, rtol=1e-7, atol=1e-12 * np.abs(pi).max()), (ph, pi)
+    for w in range(wl_h.nw):
+        has_bhp = any(c[0] == W.BHP for c in wl_h.controls[w])
+        if has_bhp and wl_h.type[w] == W.PRODUCER:
+            assert (ph[w] <= 0).all() and ph[w].min() < 0, (w, ph[w])
+        if has_bhp and wl_h.type[w] == W.INJECTOR:
+            assert (ph[w] >= 0).all() and ph[w].max() > 0, (w, ph[w])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_well_potentials_with_device_wells(gpu_lib, oracle, case):
+    """The same quantity with the wells on the device: DeviceWellModel.computeWellPotentials evaluates the reference's once-per-report-step
+    host formula from the device's well state, connection pressures and perforated-cell properties; against oracle/wells.py on the
+    oracle's own Newton path."""
+    from opmgpu.model import GpuBlackoilModel
+    from oracle.wells import CoupledOracleModel
+    grid, tab, st, make, start = _deck(case)
+    prm = capi.default_params(linear_solver_reduction=1e-11, linear_solver_maxiter=500)
+    wl_d, wl_i = make(), make()
+    gm = GpuBlackoilModel(grid, tab, prm)
+    md = W.DeviceWellModel(gm, wl_d, start(wl_d))
+    mi = CoupledOracleModel(grid, tab, prm, wl_i, _arrays(start(wl_i)))
+    md.prepareStep(5 * decks.DAY, st); mi.prepareStep(5 * decks.DAY, st)
+    for it in range(2):
+        md.nonlinearIteration(it, single_precision=False); mi.nonlinearIteration(it)
+    pd = md.computeWellPotentials(grid.z, tab.surface_density[0])
+    vals, _ = mi.perf_props(mi.st)
+    pi = mi.well_potentials(vals)
+    assert np.allclose(pd, pi, rtol=1e-5, atol=1e-9 * np.abs(pi).max()), (pd, pi)
+    gm.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("cpr", [0, 1])
 @pytest.mark.parametrize("case", CASES)

@@ -285,6 +285,35 @@ def test_thp_controlled_producer(oracle):
     assert 150 * decks.BAR < ws.bhp[1] < 250 * decks.BAR and ws.qs[1, 1] < 0
 
 
+def test_well_potentials_take_the_most_restrictive_bhp_limit(oracle):
+    """computeWellPotentials (StandardWells_impl.hpp:1003-1095) walks a well's control list: a BHP control ASSIGNS its target, a THP control
+    replaces it only when the bhp it implies (VFP table at the current rates, hydrostatic correction applied) is more restrictive -- larger
+    for a producer.  The THP-controlled producer of this deck (THP 30 bar -> bhp > 150 bar; BHP limit 100 bar) is evaluated at the THP's bhp
+    when the BHP limit comes first in the list and at 100 bar when it comes last (the assignment wins): the reference's order dependence,
+    restated as it is.  A lower bhp means a larger drawdown, so the second potential is the larger one."""
+    grid, tab, st, wl, tables = _limits_setup(thp=True)
+    prm = capi.default_params(linear_solver_reduction=1e-10, linear_solver_maxiter=500)
+    be = OracleBackend(oracle, grid, tab, prm, wells=wl.arrays())
+    wh = W.StandardWellsHost(wl, grid.z, tab.surface_density[0], vfp_tables=tables)
+    ws = W.WellState(wl, st.p)
+    mo = W.WellCoupledModel(be, wh, ws)
+    its, conv = _time_step(mo, decks.DAY, st)
+    assert conv
+    assert [c[0] for c in wl.controls[1]] == [W.THP, W.BHP]
+    pot_thp_first = mo.computeWellPotentials()
+    # at the converged state the well sits on its THP control: bhp(THP) is its current bhp, the BHP limit (100 bar) is far below
+    v, _ = wh._bhp_from_thp(1, wl.controls[1][0], ws.qs[1])
+    assert v == pytest.approx(ws.bhp[1], rel=1e-6) and v > 100 * decks.BAR
+    wl.controls[1] = [wl.controls[1][1], wl.controls[1][0]]            # BHP limit first, THP control last
+    pot_bhp_first = mo.computeWellPotentials()
+    wl.controls[1] = [wl.controls[1][1], wl.controls[1][0]]
+    # THP last: evaluated at the well's own bhp -> its current rates; BHP last: at 100 bar -> a larger production
+    assert np.allclose(pot_bhp_first[1], ws.qs[1], rtol=1e-5, atol=1e-9 * np.abs(ws.qs[1]).max())
+    assert pot_thp_first[1, 1] < pot_bhp_first[1, 1] < 0
+    # the rate-controlled injector with a BHP limit: evaluated at the limit (400 bar), above its operating bhp -> more injection than its target
+    assert pot_thp_first[0, 0] > ws.qs[0, 0] > 0 and np.allclose(pot_thp_first[0], pot_bhp_first[0])
+
+
 def test_first_broken_constraint_wins_in_wellsmanagers_order(tmp_path):
     """updateWellControls switches to the FIRST broken constraint (StandardWells_impl.hpp:709-780), so the order of a well's controls
     decides which one wins when two are broken.  WellsManager keeps a fixed order (ORAT, WRAT, GRAT, LRAT, RESV, BHP, THP) and stores the
