@@ -134,6 +134,7 @@ def parse_args(argv):
     ap.add_argument("--weak-axis", type=int, default=2, choices=[1, 2], help="weak scaling: the N copies of the workload are put side by side along j (1) or stacked along k (2)")
     ap.add_argument("--stack", type=int, default=1, help="N = 1 only: the weak-scaling deck of N ranks (N copies of the workload stacked along k, one 5-spot per copy) on ONE GPU -- "
                     "the single-domain iteration counts the decomposed run is compared with (diagnostic)")
+    ap.add_argument("--reduction", type=float, default=None, help="linear_solver_reduction (default: the reference's 1e-2); a sweep shows what dune's GMRES rule costs per time step")
     ap.add_argument("--ilu-fill", type=int, default=0, help="block ILU(n) with level-of-fill instead of the ILU0: cpr_ilu_n under --solver cpr, ilu_fillin_level otherwise (A/B; default 0)")
     ap.add_argument("--stage2-relax", type=float, default=None,
                     help="opmgpu_params.cpr_stage2_relax (library extension: damping of the stage-2 ILU0 alone; 1.0 = the reference's form).  Default: 1.0 -- except on the "
@@ -254,6 +255,8 @@ def main(argv=None):
             kw.setdefault("cpr_stage2_relax", args.stage2_relax)
         if args.ilu_fill:
             kw.setdefault("cpr_ilu_n" if kw.get("use_cpr") else "ilu_fillin_level", args.ilu_fill)
+        if args.reduction:
+            kw.setdefault("linear_solver_reduction", args.reduction)
         return capi.default_params(ilu_ordering=ordering, newton_use_gmres={"gmres": 1, "fgmres": 2}.get(krylov, 0),
                                    gmres_verify_residual=verify if krylov == "gmres" else 0, **kw)
 
