@@ -162,11 +162,11 @@ template <class S> int solve_loaded(opmgpu_ctx* c, bool matrix_changed, SolveRes
     else (void)ls.factor<S>(false);      // status read below: the solver's own final synchronisation covers it
     res = prm.newton_use_gmres ? ls.gmres<S>(prm) : ls.bicgstab<S>(prm);
     if (prm.use_cpr) ls.correction_policy_report(res.iterations, res.status == OPMGPU_OK);
-    if (res.status != OPMGPU_OK && prm.use_cpr && ls.corr_policy.active && ls.corr_policy.cur == 1 && ls.factor_status() == OPMGPU_OK) {
-        // the solve ran with the larger correction factor of the adaptive policy: once more with the conservative one before anything is reported
-        // (the rest of the step stays on it; the failure counts against the larger factor at once, the step's tallies start over)
-        { auto& P = ls.corr_policy; P.avg[1] = P.avg[1] < 0.0 ? 4.0 * std::max(res.iterations, 1) : 2.0 * P.avg[1]; P.step_its = P.step_solves = 0; P.step_failed = false; }
-        ls.corr_policy.cur = 0;
+    if (res.status != OPMGPU_OK && prm.use_cpr && ls.corr_policy.active && ls.corr_policy.cur > 0 && ls.factor_status() == OPMGPU_OK) {
+        // the solve ran with a scaled coarse-grid correction: once more with the plain Galerkin correction (factor 1.0, the safe end of the policy's
+        // ladder) before anything is reported -- a failed linear solve costs the caller a chopped time step.  The rest of the step stays on it;
+        // the failure counts against the factor at once and bans it and every larger one for a while (LinSolver::CorrectionPolicy)
+        ls.corr_policy.fail_at_current(res.iterations);
         if (mixed) ls.work<float>().amg->pdamp0 = ls.work<float>().amg->pdamp = ls.corr_policy.arm[0];
         else ls.work<S>().amg->pdamp0 = ls.work<S>().amg->pdamp = ls.corr_policy.arm[0];
         res = prm.newton_use_gmres ? ls.gmres<S>(prm) : ls.bicgstab<S>(prm);

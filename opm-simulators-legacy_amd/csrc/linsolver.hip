@@ -980,7 +980,7 @@ LinSolver::LinSolver(hipStream_t s) : stream(s)
     if (const char* e = std::getenv("OPMGPU_CPR_L0_HALO")) { cpr_l0_halo = std::atoi(e) != 0; cpr_l0_halo_down = std::atoi(e) != 2; }
     if (const char* e = std::getenv("OPMGPU_AMG_AUTOTUNE")) amg_autotune = std::atoi(e) != 0;
     if (const char* e = std::getenv("OPMGPU_AMG_ADAPT")) corr_policy.on = std::atoi(e) != 0;
-    if (const char* e = std::getenv("OPMGPU_AMG_ADAPT_ARM")) corr_policy.arm[1] = std::atof(e);
+    if (const char* e = std::getenv("OPMGPU_AMG_ADAPT_ARM")) corr_policy.arm[CorrectionPolicy::kBase + 1] = std::atof(e);
     if (const char* e = std::getenv("OPMGPU_AMG_ADAPT_MARGIN")) corr_policy.margin = std::atof(e);
     if (const char* e = std::getenv("OPMGPU_EMULATE_RANKS")) emulate_ranks = std::atoi(e);
     if (const char* e = std::getenv("OPMGPU_EMULATE_WHAT")) emulate_what = std::atoi(e);
@@ -1043,7 +1043,7 @@ void LinSolver::load_host_bsr(const double* val9)
     new_step_hint = true;          // an external matrix: nothing is known about its relation to the previous one
     // every external matrix is its own "time step" with a single solve, which the correction-factor policy never scores -- one failed
     // solve would park it on the unscored larger factor for good: external matrices run the fixed first setting
-    corr_policy.external = true; corr_policy.cur = 0;
+    corr_policy.external = true; corr_policy.cur = CorrectionPolicy::kBase;
     stage.ensure(std::max(size_t(plan.nnzb) * 9, size_t(3) * plan.nbp));
     OPMGPU_HIP(hipMemcpyAsync(stage.p, val9, size_t(plan.nnzb) * 9 * sizeof(double), hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(k_bsr_to_sell, dim3(grid_for(plan.nentries)), dim3(kBlock), 0, stream, plan.nentries, dp.src.p, stage.p, Ad.p);
@@ -2097,6 +2097,14 @@ template <class S> void LinSolver::cpr_tune()
     hipLaunchKernelGGL((k_amg_restore_x0<S>), dim3(grid_for(L0.ntot())), dim3(kBlock), 0, stream, L0.ntot(), S(A.omega0()), (const S*)L0.dinv.p, (const S*)L0.b.p, L0.x.p);
 }
 
+void LinSolver::CorrectionPolicy::fail_at_current(int iterations)
+{
+    avg[cur] = avg[cur] < 0.0 ? 4.0 * std::max(iterations, 1) : 2.0 * avg[cur];
+    for (int k = cur; k < kArms; ++k) banned_until[k] = steps + ban;
+    step_its = step_solves = 0; step_failed = false;
+    cur = 0;
+}
+
 void LinSolver::correction_policy_choose()
 {
     CorrectionPolicy& P = corr_policy;
@@ -2105,14 +2113,26 @@ void LinSolver::correction_policy_choose()
         const double score = (P.step_failed ? 4.0 : 1.0) * double(P.step_its) / double(std::max(P.step_solves, 1));
         P.avg[P.cur] = P.avg[P.cur] < 0.0 ? score : 0.5 * P.avg[P.cur] + 0.5 * score;
         ++P.steps;
+        if (P.step_failed && P.cur > 0) for (int k = P.cur; k < P.kArms; ++k) P.banned_until[k] = P.steps + P.ban;
     }
     P.step_its = P.step_solves = 0; P.step_failed = false;
-    if (P.avg[0] < 0.0) P.cur = 0;
-    else if (P.avg[1] < 0.0) P.cur = 1;
-    else {
-        const int best = P.avg[1] < P.margin * P.avg[0] ? 1 : 0;
-        P.cur = (P.steps % P.period == P.period - 1) ? 1 - best : best;
+    // best of what was tried and is allowed: a larger factor has to beat a smaller one by the margin
+    int best = -1;
+    for (int k = 0; k < P.kArms; ++k)
+        if (P.allowed(k) && P.avg[k] >= 0.0 && (best < 0 || P.avg[k] < P.margin * P.avg[best])) best = k;
+    if (best < 0) {          // nothing scored yet (or everything scored is banned): the base setting, else the largest allowed below it
+        int k = P.kBase; while (k > 0 && !P.allowed(k)) --k;
+        P.cur = k;
+        return;
     }
+    int next = best;
+    if (best == P.kBase && P.allowed(P.kBase + 1) && P.avg[P.kBase + 1] < 0.0) next = P.kBase + 1;           // the pair of round 3: the larger factor once
+    else if (P.avg[best] > P.trouble_its && best > 0 && P.avg[best - 1] < 0.0) next = best - 1;              // many iterations: one arm down, once
+    else if (P.steps % P.period == P.period - 1) {                                                            // periodic second look at a neighbour
+        if (best == P.kBase + 1) next = P.kBase;
+        else if (P.allowed(best + 1)) next = best + 1;
+    }
+    P.cur = next;
 }
 void LinSolver::correction_policy_report(int iterations, bool converged)
 {

@@ -180,14 +180,23 @@ public:
     // run decides alike.  OPMGPU_AMG_ADAPT=0: the fixed 1.9.
     struct CorrectionPolicy {
         bool on = true;
-        double arm[2] = { 1.9, 2.3 };
-        double avg[2] = { -1.0, -1.0 }; // running mean of (linear iterations / solve) of the steps run under each setting (< 0: none yet)
-        double margin = 0.93;
-        int cur = 0, steps = 0, period = 8;
+        // a LADDER of settings: index kBase (1.9) and the one above (2.3) are the pair of round 3 and all a deck ever sees while nothing goes
+        // wrong; the two below exist for decks on which the scaled correction is not a contraction at all (round 4: the Norne-like deck --
+        // 60 % inactive cells at random, NNCs, 36 wells -- fails 76 of 105 sub-steps at 1.9 and none at 1.0 .. 1.3: profiles/r04_ay_*).
+        // A FAILED solve is repeated at once with the plain Galerkin correction (arm 0) and bans its own and every larger factor for `ban`
+        // time steps; many iterations without a failure make the policy look one arm down once; scoring picks among what was tried.
+        static constexpr int kArms = 4, kBase = 2;
+        double arm[kArms] = { 1.0, 1.45, 1.9, 2.3 };
+        double avg[kArms] = { -1.0, -1.0, -1.0, -1.0 }; // running mean of (linear iterations / solve) of the steps run under each setting (< 0: none yet)
+        int banned_until[kArms] = { 0, 0, 0, 0 };       // in scored time steps
+        double margin = 0.93, trouble_its = 12.0;
+        int cur = kBase, steps = 0, period = 8, ban = 12;
         int step_its = 0, step_solves = 0;
         bool step_failed = false;
         bool active = false;            // set by cpr_prepare: this solve's factors come from the policy
-        bool external = false;          // the current matrix came through load_host_bsr (B1): one solve per "time step", nothing to score -- fixed first setting
+        bool external = false;          // the current matrix came through load_host_bsr (B1): one solve per "time step", nothing to score -- fixed base setting
+        bool allowed(int k) const { return k >= 0 && k < kArms && steps >= banned_until[k]; }
+        void fail_at_current(int iterations);      // a solve failed under arm `cur` (> 0): penalty, ban, tallies reset, cur = 0
     } corr_policy;
     void correction_policy_choose();
     void correction_policy_report(int iterations, bool converged);

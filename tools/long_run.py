@@ -34,7 +34,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--days", type=float, default=365.0)
     ap.add_argument("--report-days", type=float, default=30.0)
-    ap.add_argument("--deck", default="cart100", choices=["cart100", "spe10like", "cart60"])
+    ap.add_argument("--deck", default="cart100", choices=["cart100", "spe10like", "cart60", "spe9like", "nornelike"])
     ap.add_argument("--configs", default="cpr_bicgstab,cpr_gmres,ilu0_default")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
@@ -64,6 +64,7 @@ def main():
         ats = ts.AdaptiveTimeStepping(initial_timestep_days=1.0)
         solver = Solver()
         t, newton, linear, substeps, failed = 0.0, 0, 0, 0, 0
+        causes = {}
         t0 = time.time()
         status = "ok"
         try:
@@ -73,6 +74,8 @@ def main():
                 # (rates of failed sub-steps never reach `produced`: Solver.step adds only after a converged NonlinearSolver.step)
                 newton += rep["newton_iterations"]; linear += rep["linear_iterations"]; substeps += len(rep["substeps"]); failed += len(rep["failed"])
                 t += step
+                for _, cause in rep["failed"]:
+                    causes[cause] = causes.get(cause, 0) + 1
         except Exception as e:          # solver_restart_max consecutive failures
             status = repr(e)
         import torch
@@ -83,7 +86,7 @@ def main():
         # the default tolerances (tolerance_mb 1e-5 of the pore volume per step) bound the imbalance; report it relative to what the wells moved
         moved = np.abs(produced).max()
         out["runs"][name] = {
-            "status": status, "simulated_days": t / decks.DAY, "wall_s": round(wall, 2), "substeps": substeps, "failed_substeps": failed,
+            "status": status, "failure_causes": causes, "simulated_days": t / decks.DAY, "wall_s": round(wall, 2), "substeps": substeps, "failed_substeps": failed,
             "newton_iterations": newton, "linear_iterations": linear, "ms_per_simulated_day": round(1e3 * wall / max(t / decks.DAY, 1e-9), 3),
             "newton_per_substep": round(newton / max(substeps, 1), 2), "linear_per_newton": round(linear / max(newton, 1), 2),
             "in_place_change_wog_sm3": [float(x) for x in change], "wells_integrated_wog_sm3": [float(x) for x in produced],
