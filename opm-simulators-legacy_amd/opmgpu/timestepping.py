@@ -198,7 +198,9 @@ class AdaptiveTimeStepping:
                 self.failed_substeps += 1
                 report["failed"].append((dt, cause))
                 if restarts >= self.solver_restart_max:
-                    raise NumericalIssue("Solver failed to converge after cutting timestep %d times." % restarts)
+                    err = NumericalIssue("Solver failed to converge after cutting timestep %d times." % restarts)
+                    err.report = report          # what was tried: sub-steps taken, (dt, cause) of every failure
+                    raise err
                 timer.provideTimeStepEstimate(self.restart_factor * dt)
                 model.restoreState()                        # state = last_state (:346)
                 if well_state is not None:
