@@ -25,6 +25,14 @@ CONFIGS = {
     "cpr_bicgstab_damped": (dict(capi.CPR_AMG_VCYCLE, cpr_stage2_relax=0.9), False),
     # the bench headline: newton_use_gmres, dune's stopping rule
     "cpr_gmres": (dict(capi.CPR_AMG_VCYCLE, newton_use_gmres=1), False),
+    # library extension: the double solve with its preconditioner in float
+    "cpr_bicgstab_mixed": (dict(capi.CPR_AMG_VCYCLE, preconditioner_single=1), False),
+    # block ILU(1) as the second stage (cpr_ilu_n) / as the interleaved solver's preconditioner (ilu_fillin_level)
+    "cpr_bicgstab_ilu1": (dict(capi.CPR_AMG_VCYCLE, cpr_ilu_n=1), False),
+    "ilu1_default": (dict(use_cpr=0, ilu_fillin_level=1), "reference"),
+    # the CPR plug-in's documented defaults: ILU0-preconditioned inner BiCGStab on the pressure system
+    "cpr_ref_defaults": (dict(use_cpr=1), False),
+    "cpr_amg_inner": (dict(use_cpr=1, cpr_use_amg=1), False),
     # the reference's default: solver_approach=interleaved, ILU0 + BiCGStab, float below dt = 20 d
     "ilu0_default": (dict(use_cpr=0), "reference"),
 }
