@@ -115,6 +115,52 @@ def test_correction_factor_policy_is_preconditioner_only(gpu_lib):
             assert lin <= 1.6 * lin0, (lin, lin0)          # the bad setting costs the steps it is tried on, not the run
 
 
+@pytest.mark.parametrize("gmres", [0, 1])
+def test_correction_factor_ladder_rescues_the_norne_like_deck(gpu_lib, gmres):
+    """Round 4, found by a simulated year (tools/long_run.py): on the Norne-like deck (60 % of the cells inactive at random, NNCs, threshold
+    pressures, 36 wells) the pressure stage's coarse-grid corrections scaled by 1.9 / 2.3 -- tuned on Cartesian decks -- make CPR fail 76 of
+    105 sub-steps with "Convergence failure for linear solver"; with the plain Galerkin correction none fails.  The policy is a ladder
+    now: a failed solve is repeated at once with factor 1.0 and bans the larger factors for a while.  120 days through
+    AdaptiveTimeStepping + NonlinearSolver with device wells: no linear-solver failure reaches the time stepper, and the policy has left
+    the scaled settings; with the policy off (fixed 1.9) the failures are there."""
+    from opmgpu import baseline_decks, timestepping as ts, wells as W
+    from opmgpu.model import NonlinearSolver
+    grid, tab, st, wl = baseline_decks.make("nornelike")
+
+    def run(adapt):
+        old = os.environ.get("OPMGPU_AMG_ADAPT")
+        os.environ["OPMGPU_AMG_ADAPT"] = str(adapt)
+        try:
+            gm = GpuBlackoilModel(grid, tab, capi.default_params(newton_use_gmres=gmres, **capi.CPR_AMG_VCYCLE))
+        finally:
+            if old is None:
+                os.environ.pop("OPMGPU_AMG_ADAPT", None)
+            else:
+                os.environ["OPMGPU_AMG_ADAPT"] = old
+        model = W.DeviceWellModel(gm, wl, W.WellState(wl, st.p))
+        gm.setState(st)
+        ats, solver = ts.AdaptiveTimeStepping(initial_timestep_days=1.0), NonlinearSolver()
+
+        class S:
+            def step(self, m):
+                return solver.step(m, single_precision=False)
+        causes, t = {}, 0.0
+        for _ in range(4):
+            rep = ats.step(t, 30 * decks.DAY, S(), model)
+            t += 30 * decks.DAY
+            for _, c in rep["failed"]:
+                causes[c] = causes.get(c, 0) + 1
+        a, b = np.zeros(1), np.zeros(1)
+        assert gm.lib.opmgpu_cpr_correction_factors(gm.ctx, capi.dptr(a), capi.dptr(b)) == 0
+        gm.close()
+        return causes, float(a[0])
+    causes, factor = run(1)
+    assert "Linear solver convergence failure" not in causes, causes
+    assert factor <= 1.45, factor
+    causes_fixed, factor_fixed = run(0)
+    assert factor_fixed == 1.9 and causes_fixed.get("Linear solver convergence failure", 0) >= 5, (causes_fixed, factor_fixed)
+
+
 def test_external_matrices_keep_the_fixed_correction_factor(gpu_lib):
     """through the B1 path (opmgpu_solve_bsr: a matrix the reference's own assembly supplies) every solve is its own "time step",
     which the correction-factor policy never scores -- a single failed solve used to park it on the unscored larger factor for good.
