@@ -228,8 +228,8 @@ int opmgpu_cpr_elliptic_stats(opmgpu_ctx* ctx, int64_t* solves, int64_t* iterati
  * d3 / v3 block-interleaved like opmgpu_ilu0_apply.  tests/test_gpu_linsolver.py checks it against a numpy ILU0 of the scalar matrix. */
 int opmgpu_point_ilu_apply(opmgpu_ctx* ctx, const double* d3, double* v3, double relax);
 /* diagnostic: the scaling of the pressure cycle's coarse-grid corrections the LAST CPR solve ran with (into level 0 / below it; DESIGN.md
- * section 4b: 1.9, or the per-time-step choice between 1.9 and 2.3 on matrices of the model's own assembly -- external matrices of the B1
- * path keep 1.9).  OPMGPU_EINVAL before the first CPR solve. */
+ * section 5: 1.9, or on matrices of the model's own assembly the per-time-step choice between 1.9 and 2.3 -- and, after a failed solve, which is
+ * repeated with 1.0, from the ladder 1.0 / 1.45 / 1.9 / 2.3; external matrices of the B1 path keep 1.9).  OPMGPU_EINVAL before the first CPR solve. */
 int opmgpu_cpr_correction_factors(opmgpu_ctx* ctx, double* into_level0, double* below);
 
 /* ------------------------------------------------------------------------------------------
