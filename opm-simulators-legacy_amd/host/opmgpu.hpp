@@ -350,6 +350,8 @@ struct PIDTimeStepControl {
 struct AdaptiveTimeSteppingGpu {
     double restart_factor = 0.33, growth_factor = 2.0, max_growth = 3.0, max_time_step = 365.0 * 86400.0;     // :101-112
     int solver_restart_max = 10;
+    double min_time_step_fraction = 1e-12;             // NOT in the reference: a failed sub-step shorter than this fraction of the report step ends it (the
+                                                       // reference's loop resets its restart counter after every converged sub-step and can shrink for ever); 0 = off
     double suggested_next_timestep = 86400.0;
     PIDTimeStepControl control;
     std::vector<double> substeps;                      // of the last report step
@@ -392,6 +394,7 @@ struct AdaptiveTimeSteppingGpu {
                 model.saveState();
             } else {
                 ++failed_substeps;
+                if (min_time_step_fraction > 0 && dt < min_time_step_fraction * timestep) throw NumericalIssue("Solver failed to converge with a time step of " + std::to_string(dt) + " s: giving up.");
                 if (restarts >= solver_restart_max) throw NumericalIssue("Solver failed to converge after cutting timestep " + std::to_string(restarts) + " times.");
                 dt = clip(restart_factor * dt, timestep - done, max_time_step);
                 model.restoreState();

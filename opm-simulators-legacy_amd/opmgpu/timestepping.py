@@ -123,7 +123,7 @@ class AdaptiveTimeStepping:
 
     def __init__(self, control="pid", restart_factor=0.33, growth_factor=2.0, max_growth=3.0, max_time_step_days=365.0,
                  solver_restart_max=10, initial_timestep_days=1.0, full_timestep_initially=False, timestep_after_event_days=-1.0,
-                 tol=1e-1, target_iterations=None, decayrate=0.75, growthrate=1.25, hardcoded=None):
+                 tol=1e-1, target_iterations=None, decayrate=0.75, growthrate=1.25, hardcoded=None, min_time_step_fraction=1e-12):
         self.restart_factor, self.growth_factor, self.max_growth = restart_factor, growth_factor, max_growth
         assert growth_factor >= 1.0
         self.max_time_step = max_time_step_days * DAY
@@ -146,6 +146,11 @@ class AdaptiveTimeStepping:
         else:
             raise RuntimeError("Unsupported time step control selected " + str(control))
         self.failed_substeps = 0
+        # NOT in the reference: a failed sub-step shorter than this fraction of the report step ends the report step with NumericalIssue.
+        # The reference's loop resets its restart counter after every converged sub-step (:285-289), so a state in which steps of 1e-17 d
+        # converge and steps of 2e-17 d do not (seen on a generated deck whose well controls flip-flop: profiles/r04_ba_*) never reaches
+        # solver_restart_max and never ends.  0 switches the guard off.
+        self.min_time_step_fraction = min_time_step_fraction
 
     def step(self, start_time, timestep, solver, model, event=False, well_state=None):
         """One report step of length `timestep` [s] from the model's resident state.  `solver.step(model)` runs one
@@ -197,6 +202,10 @@ class AdaptiveTimeStepping:
                 timer.last_step_failed = True
                 self.failed_substeps += 1
                 report["failed"].append((dt, cause))
+                if self.min_time_step_fraction > 0 and dt < self.min_time_step_fraction * timestep:
+                    err = NumericalIssue("Solver failed to converge with a time step of %.3g s (%.1e of the report step): giving up." % (dt, dt / timestep))
+                    err.report = report
+                    raise err
                 if restarts >= self.solver_restart_max:
                     err = NumericalIssue("Solver failed to converge after cutting timestep %d times." % restarts)
                     err.report = report          # what was tried: sub-steps taken, (dt, cause) of every failure

@@ -104,6 +104,33 @@ def test_gives_up_after_solver_restart_max():
     assert a.failed_substeps == 5
 
 
+def test_livelock_guard_ends_a_report_step_whose_sub_steps_shrink_without_end():
+    """Not in the reference (its loop resets the restart counter after every converged sub-step, AdaptiveTimeStepping_impl.hpp:285-289): a
+    model whose sub-steps converge only every other time -- found on a generated deck with flip-flopping well controls, where sub-steps
+    of 1e-17 d alternated between converging and failing for ever -- ends in NumericalIssue once a failed sub-step is shorter than
+    min_time_step_fraction of the report step; the exception carries the report.  With the guard off the reference's behaviour is kept
+    (checked with a bounded number of calls)."""
+    class Alternating:
+        def __init__(self, limit):
+            self.calls, self.limit = 0, limit
+
+        def step(self, model):
+            self.calls += 1
+            if self.calls > self.limit:
+                raise KeyboardInterrupt          # the test's own way out of the livelock
+            if self.calls % 2 == 0 or model.dt > 1e-3 * DAY:
+                raise TooManyIterations("too many")
+            return 2, 1                                # converges without changing anything
+    m = FakeModel()
+    with pytest.raises(NumericalIssue, match="giving up") as e:
+        ts.AdaptiveTimeStepping(initial_timestep_days=1.0).step(0.0, 30 * DAY, Alternating(10 ** 6), m)
+    rep = e.value.report
+    assert len(rep["failed"]) > 10 and min(d for d, _ in rep["failed"]) < 1e-12 * 30 * DAY * 3
+    m = FakeModel()
+    with pytest.raises(KeyboardInterrupt):
+        ts.AdaptiveTimeStepping(initial_timestep_days=1.0, min_time_step_fraction=0.0).step(0.0, 30 * DAY, Alternating(2000), m)
+
+
 def test_defaults_are_the_references():
     """The host mirrors' defaults against the lines of the reference that set them: NonlinearSolver::SolverParameters::reset
     (NonlinearSolver_impl.hpp:183-188) and AdaptiveTimeStepping's parameter defaults (AdaptiveTimeStepping_impl.hpp:101-112, :123-147)."""

@@ -46,9 +46,21 @@ for case in range(ncases):
         ats = ts.AdaptiveTimeStepping(initial_timestep_days=1.0)
         solver = NonlinearSolver()
 
+        trace = bool(os.environ.get("OPMGPU_SWEEP_TRACE"))
+
         class S:
             def step(self, m):
-                return solver.step(m, single_precision=False)
+                if trace:
+                    print("   %s substep dt %.3e d" % (c, m.m.dt / decks.DAY), flush=True)
+                try:
+                    out = solver.step(m, single_precision=False)
+                except Exception as e:
+                    if trace:
+                        print("      failed: %r" % (e,), flush=True)
+                    raise
+                if trace:
+                    print("      newton %d linear %d relative change %.3e" % (out[0], out[1], m.relativeChange()), flush=True)
+                return out
         t, sub, failed, causes, status = 0.0, 0, 0, {}, "ok"
         t0 = time.time()
         try:
