@@ -765,11 +765,14 @@ def five_spot(grid, rate_m3_per_day=500.0, bhp_prod_bar=150.0, wi=None, slabs=1,
 
 
 def column_wells(grid, n_wells, n_injectors=1, seed=0, inj_layers=None, prod_layers=None, inj_rate_m3_per_day=800.0,
-                 prod_bhp_bar=150.0, prod_oil_rate_m3_per_day=None, wi=None):
+                 prod_bhp_bar=150.0, prod_oil_rate_m3_per_day=None, wi=None, rate_wells_bhp_limits_bar=None):
     """Vertical wells in distinct random (i, j) columns of a Cartesian deck with inactive cells (SPE9-like: 1 rate-controlled water
     injector + 25 producers; Norne-like: 36 wells through whatever is active in their column).  A well perforates the ACTIVE cells of
     its column inside the layer range; columns without an active cell there are skipped.  Producers alternate between BHP control and
-    (if `prod_oil_rate_m3_per_day` is given) oil SURFACE_RATE control, so both control equations occur."""
+    (if `prod_oil_rate_m3_per_day` is given) oil SURFACE_RATE control, so both control equations occur.  rate_wells_bhp_limits_bar =
+    (injectors' upper, producers' lower BHP limit): what every real deck gives its rate-controlled wells; without it (the BASELINE-like
+    decks of baseline_decks.py, kept as they were measured) a rate target a pocket cannot deliver drives the well's bhp to zero and the well
+    equations stop converging at any step length (tools/robust_sweep.py, deck 6057)."""
     nx, ny, nz = grid.dims
     act = np.asarray(grid.active_index)
     rng = np.random.Generator(np.random.PCG64(seed))
@@ -786,9 +789,11 @@ def column_wells(grid, n_wells, n_injectors=1, seed=0, inj_layers=None, prod_lay
             continue
         zref = grid.z[cells[0]]
         if inj:
-            wells.add_well("INJ%d" % w, INJECTOR, zref, cells, WI, (1.0, 0.0, 0.0), (SURFACE_RATE, inj_rate_m3_per_day / 86400.0, (1.0, 0.0, 0.0)))
+            wells.add_well("INJ%d" % w, INJECTOR, zref, cells, WI, (1.0, 0.0, 0.0), (SURFACE_RATE, inj_rate_m3_per_day / 86400.0, (1.0, 0.0, 0.0)),
+                           limits=[] if rate_wells_bhp_limits_bar is None else [(BHP, rate_wells_bhp_limits_bar[0] * 1e5)])
         elif prod_oil_rate_m3_per_day is not None and w % 2 == 0:
-            wells.add_well("PROD%d" % w, PRODUCER, zref, cells, WI, (0.0, 1.0, 0.0), (SURFACE_RATE, -prod_oil_rate_m3_per_day / 86400.0, (0.0, 1.0, 0.0)))
+            wells.add_well("PROD%d" % w, PRODUCER, zref, cells, WI, (0.0, 1.0, 0.0), (SURFACE_RATE, -prod_oil_rate_m3_per_day / 86400.0, (0.0, 1.0, 0.0)),
+                           limits=[] if rate_wells_bhp_limits_bar is None else [(BHP, rate_wells_bhp_limits_bar[1] * 1e5)])
         else:
             wells.add_well("PROD%d" % w, PRODUCER, zref, cells, WI, (0.0, 1.0, 0.0), (BHP, prod_bhp_bar * 1e5))
     if wells.nw < n_wells:

@@ -37,7 +37,8 @@ for case in range(ncases):
     st = decks.initial_state(grid, tab, p_ref=270.0 * decks.BAR, z_ref=2500.0, perturb=0.005, seed=seed0 + case)
     nwells = int(rng.integers(3, 20))
     wl = W.column_wells(grid, nwells, n_injectors=max(1, nwells // 6), seed=seed0 + case, inj_rate_m3_per_day=float(rng.uniform(50, 400)),
-                        prod_bhp_bar=float(rng.uniform(150, 230)), prod_oil_rate_m3_per_day=float(rng.uniform(10, 60)))
+                        prod_bhp_bar=float(rng.uniform(150, 230)), prod_oil_rate_m3_per_day=float(rng.uniform(10, 60)),
+                        rate_wells_bhp_limits_bar=None if os.environ.get("OPMGPU_SWEEP_NO_LIMITS") else (450.0, 80.0))
     line = "case %d: %dx%dx%d, %d active, inactive %.2f, sigma %.2f, %d wells" % (seed0 + case, nx, ny, nz, grid.nc, inactive, kw["lognormal_sigma"], wl.nw)
     for c in configs:
         gm = GpuBlackoilModel(grid, tab, capi.default_params(**KW[c]))
