@@ -180,7 +180,7 @@ template <class S> int solve_loaded(opmgpu_ctx* c, bool matrix_changed, SolveRes
     if (!ls.point_stage2 && ls.factor_status() != OPMGPU_OK) { c->factored = false; return fail(c, OPMGPU_ESINGULAR, "singular diagonal block in ILU0"); }
     c->factored = true;
     if (res.status == OPMGPU_ELINSOLVE) c->err = "Convergence failure for linear solver.";
-    if (res.status == OPMGPU_EBREAKDOWN) c->err = "breakdown in BiCGSTAB";
+    if (res.status == OPMGPU_EBREAKDOWN) c->err = ls.breakdown_note.empty() ? std::string("breakdown in the Krylov method") : ls.breakdown_note;
     return res.status;
 }
 
@@ -441,7 +441,14 @@ int opmgpu_average_b(opmgpu_ctx* c, double* B3)
 int opmgpu_well_convergence(opmgpu_ctx* c, double* flux3, double* ctrl)
 {
     if (!c || !c->model) return OPMGPU_EINVAL;
-    return guarded(c, [&]() { return c->model->well_convergence(flux3, ctrl); });
+    return guarded(c, [&]() {
+        const int st = c->model->well_convergence(flux3, ctrl);
+        // the statuses the reference's time stepper catches, with a text: a singular 4 x 4 well block is Dune::MatrixBlockError's case (the inverse in
+        // eliminateVariable / solveWellEq), the other marks are NumericalIssue's (StandardWells_impl.hpp:742-748, NonlinearSolver_impl.hpp:165)
+        if (st == OPMGPU_ESINGULAR) return fail(c, st, "singular well equation block (no open perforation can carry the well's flow)");
+        if (st == OPMGPU_ENUMERICAL) return fail(c, st, "well model: non-finite or too large well residual, no consistent control, or the pre-solve gave up");
+        return st;
+    });
 }
 
 static int nonlinear_iteration_body(opmgpu_ctx* c, double dt, int iteration, int single_precision, const opmgpu_newton_ctl* ctl, int* converged,

@@ -2550,7 +2550,12 @@ template <class S> SolveResult LinSolver::bicgstab(const opmgpu_params& prm)
     res.converged = h_ctl->done && h_ctl->flag == 0;
     res.iterations = h_ctl->done ? h_ctl->iters : maxit;
     res.reduction = norm0 > 0 ? norm / norm0 : 0.0;
-    if (h_ctl->flag != 0 || !(norm0 == norm0)) res.status = OPMGPU_EBREAKDOWN;
+    if (h_ctl->flag != 0 || !(norm0 == norm0)) {
+        res.status = OPMGPU_EBREAKDOWN;
+        char buf[160];
+        std::snprintf(buf, sizeof buf, "breakdown in BiCGSTAB (%s; ||r0|| = %.3e)", !(norm0 == norm0) ? "non-finite initial defect" : (h_ctl->flag == 1 ? "|h| < eps" : "|rho| or |omega| <= eps"), norm0);
+        breakdown_note = buf;
+    }
     else if (!res.converged && !prm.ignore_convergence_failure) res.status = OPMGPU_ELINSOLVE;      // ISTLSolver.hpp:358-368
     last_its = res.iterations;
     if (refreshed) its_ref = res.iterations;
@@ -3067,7 +3072,12 @@ template <class S> SolveResult LinSolver::gmres(const opmgpu_params& prm)
     res.reduction = norm0 > 0 ? norm / norm0 : 0.0;
     (void)verified;
     last_verify_rounds = verify_rounds;
-    if (h_ctl->flag != 0 || !(norm0 == norm0)) res.status = OPMGPU_EBREAKDOWN;
+    if (h_ctl->flag != 0 || !(norm0 == norm0)) {
+        res.status = OPMGPU_EBREAKDOWN;
+        char buf[160];
+        std::snprintf(buf, sizeof buf, "breakdown in GMRes (%s; column %d, ||M^-1 r0|| = %.3e)", !(norm0 == norm0) ? "non-finite initial defect" : (h_ctl->flag == 2 ? "|w| == 0" : "non-finite Hessenberg entry"), j, norm0);
+        breakdown_note = buf;
+    }
     else if (!res.converged && !prm.ignore_convergence_failure) res.status = OPMGPU_ELINSOLVE;
     last_its = res.iterations;              // the back-off of the lag policy, as at the end of bicgstab (see cpr_prepare)
     if (refreshed) its_ref = res.iterations;

@@ -228,6 +228,7 @@ public:
     void fill_setup();
     template <class S> int fill_factor(bool wait);
     template <class S> void fill_apply(const S* d, S* v, double relax, const SolveCtl* ctl);
+    std::string breakdown_note;        // what the last OPMGPU_EBREAKDOWN was (for the error text)
     int plan_id = 0;                   // counts re-plans (set_pattern)
     bool point_stage2 = false;         // set per solve (capi.hip)
     void point_ilu_setup();
