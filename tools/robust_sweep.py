@@ -19,7 +19,8 @@ ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
 configs = (sys.argv[3] if len(sys.argv) > 3 else "cpr_bicgstab,cpr_gmres").split(",")
 KW = {"cpr_bicgstab": dict(capi.CPR_AMG_VCYCLE), "cpr_gmres": dict(capi.CPR_AMG_VCYCLE, newton_use_gmres=1), "ilu0": dict(use_cpr=0),
-      "cpr_ref_defaults": dict(use_cpr=1)}
+      "cpr_ref_defaults": dict(use_cpr=1), "cpr_mixed": dict(capi.CPR_AMG_VCYCLE, preconditioner_single=1), "cpr_ilu1": dict(capi.CPR_AMG_VCYCLE, cpr_ilu_n=1),
+      "ilu1": dict(use_cpr=0, ilu_fillin_level=1)}
 tot = {c: {"substeps": 0, "failed": 0, "causes": {}, "wall": 0.0, "aborted": 0} for c in configs}
 for case in range(ncases):
     rng = np.random.default_rng(seed0 + case)
@@ -33,13 +34,21 @@ for case in range(ncases):
     if rng.random() < 0.4:
         kw["thpres"] = float(rng.uniform(0.01, 0.05)) * decks.BAR
     grid = decks.cartesian_grid(nx, ny, nz, **kw)
-    tab = decks.satfunc_standard_tables()
+    tkw, opts = {}, []
+    if os.environ.get("OPMGPU_SWEEP_OPTIONS"):          # the saturation-function / rock options the parity fuzzers draw, through whole time steps
+        if rng.random() < 0.4:
+            tkw["vappars"] = (float(rng.uniform(0.1, 2.0)), float(rng.uniform(0.1, 2.0))); opts.append("vappars")
+        if rng.random() < 0.4:
+            tkw["rocktab"] = [(100.0, 0.97, 0.94), (200.0, 1.0, 1.0), (300.0, 1.02, 1.07), (500.0, 1.05, 1.1)]; opts.append("rocktab")
+    tab = decks.satfunc_standard_tables(**tkw)
+    if os.environ.get("OPMGPU_SWEEP_OPTIONS") and rng.random() < 0.5:
+        grid = decks.with_endpoints(grid, decks.random_endpoints(grid, seed=seed0 + case)); opts.append("endscale")
     st = decks.initial_state(grid, tab, p_ref=270.0 * decks.BAR, z_ref=2500.0, perturb=0.005, seed=seed0 + case)
     nwells = int(rng.integers(3, 20))
     wl = W.column_wells(grid, nwells, n_injectors=max(1, nwells // 6), seed=seed0 + case, inj_rate_m3_per_day=float(rng.uniform(50, 400)),
                         prod_bhp_bar=float(rng.uniform(150, 230)), prod_oil_rate_m3_per_day=float(rng.uniform(10, 60)),
                         rate_wells_bhp_limits_bar=None if os.environ.get("OPMGPU_SWEEP_NO_LIMITS") else (450.0, 80.0))
-    line = "case %d: %dx%dx%d, %d active, inactive %.2f, sigma %.2f, %d wells" % (seed0 + case, nx, ny, nz, grid.nc, inactive, kw["lognormal_sigma"], wl.nw)
+    line = "case %d: %dx%dx%d, %d active, inactive %.2f, sigma %.2f, %d wells" % (seed0 + case, nx, ny, nz, grid.nc, inactive, kw["lognormal_sigma"], wl.nw) + (" " + "+".join(opts) if opts else "")
     for c in configs:
         gm = GpuBlackoilModel(grid, tab, capi.default_params(**KW[c]))
         model = W.DeviceWellModel(gm, wl, W.WellState(wl, st.p))
