@@ -42,11 +42,21 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--days", type=float, default=365.0)
     ap.add_argument("--report-days", type=float, default=30.0)
-    ap.add_argument("--deck", default="cart100", choices=["cart100", "spe10like", "cart60", "spe9like", "nornelike"])
+    ap.add_argument("--deck", default="cart100", choices=["cart100", "spe10like", "cart60", "spe9like", "nornelike", "irregular_big"])
     ap.add_argument("--configs", default="cpr_bicgstab,cpr_gmres,ilu0_default")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
-    grid, tab, st, wl = baseline_decks.make(args.deck)
+    if args.deck == "irregular_big":
+        # the Norne-like recipe at 10^6 cells of box: 100 x 200 x 50 with 40 % of the cells inactive at random (~600 k active), 3 % extra NNCs, threshold
+        # pressures, sigma_lnK = 1.2, 60 vertical wells on mixed controls with BHP limits
+        rng = np.random.default_rng(77)
+        act = rng.random(100 * 200 * 50) > 0.4
+        grid = decks.cartesian_grid(100, 200, 50, dx=60.0, dy=60.0, dz=3.0, tops=2500.0, actnum=act, nnc_fraction=0.03, lognormal_sigma=1.2, thpres=0.02 * decks.BAR, seed=77)
+        tab = decks.satfunc_standard_tables()
+        st = decks.initial_state(grid, tab, p_ref=270.0 * decks.BAR, z_ref=2500.0, perturb=0.005, seed=77)
+        wl = W.column_wells(grid, 60, n_injectors=10, seed=77, inj_rate_m3_per_day=400.0, prod_bhp_bar=200.0, prod_oil_rate_m3_per_day=60.0, rate_wells_bhp_limits_bar=(450.0, 80.0))
+    else:
+        grid, tab, st, wl = baseline_decks.make(args.deck)
     out = {"deck": args.deck, "cells": int(grid.nc), "days": args.days, "report_days": args.report_days, "runs": {}}
     for name in args.configs.split(","):
         kw, single = CONFIGS[name]
