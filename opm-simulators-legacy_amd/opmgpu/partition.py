@@ -25,6 +25,17 @@ def slab_partition(grid, nranks, axis=2):
         i, j, k = np.arange(n) % nx, (np.arange(n) // nx) % ny, np.arange(n) // (nx * ny)
         coord, extent = ((i, nx), (j, ny), (k, nz))[axis]
         return ((coord.astype(np.int64) * nranks) // extent).astype(np.int32)
+    act = getattr(grid, "active_index", None)
+    if grid.dims is not None and act is not None and axis in (0, 1) and len(act) == grid.dims[0] * grid.dims[1] * grid.dims[2]:
+        # inactive cells (ACTNUM): slabs of whole i- or j-rows of the Cartesian BOX, the cut positions chosen so that every rank gets about the
+        # same number of ACTIVE cells -- whole columns stay together, so vertical wells stay on one rank here too
+        nx, ny, nz = grid.dims
+        box = np.flatnonzero(np.asarray(act) >= 0)                     # Cartesian index of every active cell, in active order
+        coord, extent = ((box % nx, nx), ((box // nx) % ny, ny))[axis]
+        per_row = np.bincount(coord, minlength=extent)
+        cum = np.cumsum(per_row)
+        owner_of_row = np.minimum(nranks - 1, (np.maximum(cum - 1, 0).astype(np.int64) * nranks) // max(1, n)).astype(np.int32)
+        return owner_of_row[coord]
     return ((np.arange(n, dtype=np.int64) * nranks) // n).astype(np.int32)
 
 
@@ -150,7 +161,11 @@ def build_distributed_model(nx, ny, nz, tables, params, rank, world, local_rank,
     import torch.distributed as dist
     from . import decks
     from .model import GpuBlackoilModel
-    if deck == "spe10like":
+    if isinstance(deck, tuple):
+        # a deck the caller built (grid, state): every rank passes the same one; cut into slabs of whole j-rows (vertical wells stay whole)
+        grid, st = deck
+        part = slab_partition(grid, world, axis=axis if axis in (0, 1) else 1)
+    elif deck == "spe10like":
         grid = decks.cartesian_grid(60, 220, 85, dx=6.096, dy=3.048, dz=0.6096, tops=3657.6, lognormal_sigma=2.5, seed=10)
         st = decks.initial_state(grid, tables, p_ref=413.0 * decks.BAR, z_ref=3657.6, perturb=1e-4, seed=10, gas_cap_fraction=0.0, gas_only_fraction=0.0)
         part = slab_partition(grid, world, axis=axis if axis in (0, 1) else 1)      # vertical wells: along i or j only
@@ -168,7 +183,7 @@ def build_distributed_model(nx, ny, nz, tables, params, rank, world, local_rank,
     attach_comm(model, dom, rank, world, bytes(idt.cpu().numpy().tobytes()))
     # coarse blocks of the pressure stage: sub-slabs of this rank's slab along the CUT direction (they keep vertical wells whole)
     mblk = int(os.environ.get("OPMGPU_COARSE_SUBSLABS", "0"))
-    cut_axis = (axis if axis in (0, 1) else 1) if deck == "spe10like" else axis
+    cut_axis = (axis if axis in (0, 1) else 1) if (deck == "spe10like" or isinstance(deck, tuple)) else axis
     if mblk > 1 and grid.dims is not None and cut_axis in (0, 1):
         nxg, nyg, _ = grid.dims
         gid = dom.global_of_local[:dom.n_owned]

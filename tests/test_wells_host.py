@@ -139,6 +139,21 @@ def test_partition_keeps_wells_on_one_rank():
         partition.LocalDomain(grid, part_k, 0).local_wells(wl, part_k)
 
 
+def test_row_slabs_of_an_actnum_deck_keep_vertical_wells_whole():
+    """slab_partition(axis = 1) on a deck with inactive cells (the Norne-like deck of BASELINE configs[4]): slabs of whole j-rows of the Cartesian
+    box, balanced by ACTIVE cells, so that every vertical well stays on one rank (bench.py --deck nornelike --gpus N)."""
+    from opmgpu import baseline_decks, partition
+    g, _, _, wl = baseline_decks.norne_like()
+    for n in (2, 4, 8):
+        part = partition.slab_partition(g, n, axis=1)
+        counts = np.bincount(part, minlength=n)
+        assert counts.min() > 0.8 * g.nc / n and counts.max() < 1.2 * g.nc / n, counts
+        seen = 0
+        for r in range(n):
+            seen += len(partition.LocalDomain(g, part, r).local_wells(wl, part).name)
+        assert seen == wl.nw
+
+
 def test_weak_scaling_five_spots_live_inside_their_copy():
     """bench.py's weak-scaling decks: N copies of the workload with one 5-spot each, stacked along k (slab_axis 2) or side by side along j
     (slab_axis 1, --weak-axis 1).  Every well lies inside its copy, so the matching slab partition leaves every well on one rank."""
