@@ -125,7 +125,8 @@ def parse_args(argv):
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N > 1: weak = every GPU keeps an nx x ny x nz copy of the workload with its own 5-spot (global deck nx x ny*N x nz, see --weak-axis); strong = the fixed nx x ny x nz deck "
                          "is cut into N slabs along j, which keeps its vertical wells whole")
-    ap.add_argument("--deck", choices=["cart", "spe10like", "nornelike"], default="cart",
+    ap.add_argument("--seed", type=int, default=7000, help="--deck random: the deck of tools/robust_sweep.py with this seed")
+    ap.add_argument("--deck", choices=["cart", "spe10like", "nornelike", "random"], default="cart",
                     help="spe10like: 60 x 220 x 85 cells, sigma_lnK = 2.5 (BASELINE configs[3]); nornelike: Norne's 46 x 112 x 22 box with 60 %% of the cells inactive, NNCs, "
                          "threshold pressures and 36 wells (BASELINE configs[4]; N > 1: slabs of j-rows); both imply their own dimensions and wells")
     ap.add_argument("--wells", choices=["none", "fivespot"], default="fivespot",
@@ -224,6 +225,12 @@ def main(argv=None):
         args.nx, args.ny, args.nz = 60, 220, 85
     if args.deck == "nornelike":
         args.nx, args.ny, args.nz = 46, 112, 22
+    irregular = None          # (grid, tables, state, wells) of the decks that bring their own wells
+    if args.deck == "nornelike":
+        irregular = baseline_decks.norne_like()
+    if args.deck == "random":
+        irregular = baseline_decks.random_irregular(args.seed)[:4]
+        args.nx, args.ny, args.nz = irregular[0].dims
     ordering = capi.ORDER_MULTICOLOR if args.ordering == "multicolor" else capi.ORDER_NATURAL
     tab = decks.satfunc_standard_tables()
     dt_main = args.dt_days * decks.DAY
@@ -273,9 +280,8 @@ def main(argv=None):
         if args.deck == "spe10like":
             g, _, s, _ = baseline_decks.spe10_like()
             return g, s, spe10_spec
-        if args.deck == "nornelike":
-            g, _, s, _ = baseline_decks.norne_like()
-            return g, s, None
+        if irregular is not None:
+            return irregular[0], irregular[2], None
         g = decks.cartesian_grid(args.nx, args.ny, args.nz, lognormal_sigma=0.5, seed=12345)
         return g, decks.initial_state(g, tab, perturb=0.002, seed=12345), (args.rate, 150.0)
 
@@ -283,9 +289,9 @@ def main(argv=None):
     # stacked along k (2), one 5-spot per copy; strong scaling and the SPE10-like deck: slabs of whole j-rows, which keeps the deck's own vertical wells whole
     if use_dist:
         from opmgpu import partition
-        if args.deck == "nornelike":
-            g0, _, s0, wl0 = baseline_decks.norne_like()
-            model, grid, st, info = partition.build_distributed_model(46, 112, 22, tab, prm, rank, world, local_rank, deck=(g0, s0), wells_fn=(lambda g: wl0) if use_wells else None, axis=1)
+        if irregular is not None:
+            g0, _, s0, wl0 = irregular
+            model, grid, st, info = partition.build_distributed_model(args.nx, args.ny, args.nz, tab, prm, rank, world, local_rank, deck=(g0, s0), wells_fn=(lambda g: wl0) if use_wells else None, axis=1)
         elif args.deck == "spe10like":
             wells_fn = (lambda g: W.five_spot(g, rate_m3_per_day=spe10_spec[0], bhp_prod_bar=spe10_spec[1])) if use_wells else None
             model, grid, st, info = partition.build_distributed_model(60, 220, 85, tab, prm, rank, world, local_rank, deck="spe10like", wells_fn=wells_fn, axis=args.cut_axis)
@@ -307,8 +313,8 @@ def main(argv=None):
         grid, st, well_spec = make_deck()
         model = GpuBlackoilModel(grid, tab, prm, device=local_rank)
         info = {"n_owned": grid.nc, "n_global": grid.nc}
-        if args.deck == "nornelike":
-            main_wells = baseline_decks.norne_like()[3] if use_wells else None
+        if irregular is not None:
+            main_wells = irregular[3] if use_wells else None
         else:
             main_wells = W.five_spot(grid, rate_m3_per_day=well_spec[0], bhp_prod_bar=well_spec[1], slabs=args.stack, slab_axis=args.weak_axis) if use_wells else None
     nc_global = info["n_global"]
@@ -629,8 +635,8 @@ def main(argv=None):
             if ncores > args.cpu_threads:
                 cpu_all = cpu_baseline(grid, tab, st, main_wells, prm, dt_main, cpu_single, threads=ncores, budget_s=8.0, max_newton=2)
 
-        if use_wells and args.deck == "nornelike":
-            wells_txt = "36 vertical wells on the device (4 water injectors, producers on BHP or oil-rate control)" + ("" if world == 1 else "; cut along j, every well on one rank")
+        if use_wells and irregular is not None:
+            wells_txt = "%d vertical wells on the device (water injectors on rate control, producers on BHP or oil-rate control)" % irregular[3].nw + ("" if world == 1 else "; cut along j, every well on one rank")
         elif use_wells:
             spec = well_spec if well_spec else (spe10_spec if args.deck == "spe10like" else (args.rate, 150.0))
             wells_txt = ("5-spot on the device: 1 water injector (%.0f m3/d) + 4 BHP producers (%.0f bar), %d perforations each%s" %
@@ -681,8 +687,8 @@ def main(argv=None):
             "ms_per_solving_iteration_median": r3(main_sum["ms_per_solving_iteration_median"]),
             "ms_per_solving_iteration_mean": r3(main_sum["ms_per_solving_iteration_mean"]),
             "value_mean_solving": r3(main_sum["value_mean_solving"]), "value_all_calls_mean": r3(main_sum["value_all_calls_mean"]),
-            "config": {"workload": "%s%dx%dx%d_3phase_blackoil%s" % ({"spe10like": "spe10like_", "nornelike": "nornelike_"}.get(args.deck, "cart"), args.nx, args.ny * (world if (weak and args.weak_axis == 1 and args.deck == "cart") else 1), args.nz * (world if (weak and args.weak_axis == 2) else 1),
-                                                                     ("_36wells" if args.deck == "nornelike" else "_fivespot") if use_wells else ""),
+            "config": {"workload": "%s%dx%dx%d_3phase_blackoil%s" % ({"spe10like": "spe10like_", "nornelike": "nornelike_", "random": "random%d_" % args.seed}.get(args.deck, "cart"), args.nx, args.ny * (world if (weak and args.weak_axis == 1 and args.deck == "cart") else 1), args.nz * (world if (weak and args.weak_axis == 2) else 1),
+                                                                     (("_%dwells" % irregular[3].nw) if irregular is not None else "_fivespot") if use_wells else ""),
                        "cells": nc_global, "cells_per_gpu": info["n_owned"], "dt_days": args.dt_days, "linear_solver": lin_name,
                        "arithmetic": main_sum["arithmetic"], "reference_equivalence": equiv,
                        "solving_iterations": res.get("n_solving"), "linear_its_per_solve": r3(res.get("lin_per_solving")),

@@ -55,6 +55,39 @@ def spe9_like():
                                          inj_rate_m3_per_day=800.0, prod_bhp_bar=150.0, prod_oil_rate_m3_per_day=60.0)
 
 
+def random_irregular(seed, options=False, bhp_limits=True):
+    """One deck of the robustness sweep (tools/robust_sweep.py): a 20-50 x 20-50 x 5-20 box with up to 60 % of its cells inactive at random, NNCs and
+    threshold pressures in some, sigma_lnK 0.3 .. 2, 3-19 vertical wells on mixed controls (rate-controlled wells with BHP limits, as real decks
+    have them); options: VAPPARS / ROCKTAB / end-point scaling drawn at random as well.  Returns (grid, tables, state, wells, description)."""
+    rng = np.random.default_rng(seed)
+    nx, ny, nz = int(rng.integers(20, 50)), int(rng.integers(20, 50)), int(rng.integers(5, 20))
+    inactive = float(rng.uniform(0.0, 0.6))
+    kw = dict(dx=float(rng.uniform(30, 120)), dy=float(rng.uniform(30, 120)), dz=float(rng.uniform(2, 8)), tops=2500.0, lognormal_sigma=float(rng.uniform(0.3, 2.0)), seed=seed)
+    if inactive > 0.05:
+        kw["actnum"] = rng.random(nx * ny * nz) > inactive
+    if rng.random() < 0.6:
+        kw["nnc_fraction"] = float(rng.uniform(0.01, 0.06))
+    if rng.random() < 0.4:
+        kw["thpres"] = float(rng.uniform(0.01, 0.05)) * decks.BAR
+    grid = decks.cartesian_grid(nx, ny, nz, **kw)
+    tkw, opts = {}, []
+    if options:
+        if rng.random() < 0.4:
+            tkw["vappars"] = (float(rng.uniform(0.1, 2.0)), float(rng.uniform(0.1, 2.0))); opts.append("vappars")
+        if rng.random() < 0.4:
+            tkw["rocktab"] = [(100.0, 0.97, 0.94), (200.0, 1.0, 1.0), (300.0, 1.02, 1.07), (500.0, 1.05, 1.1)]; opts.append("rocktab")
+    tab = decks.satfunc_standard_tables(**tkw)
+    if options and rng.random() < 0.5:
+        grid = decks.with_endpoints(grid, decks.random_endpoints(grid, seed=seed)); opts.append("endscale")
+    st = decks.initial_state(grid, tab, p_ref=270.0 * decks.BAR, z_ref=2500.0, perturb=0.005, seed=seed)
+    nwells = int(rng.integers(3, 20))
+    wl = W.column_wells(grid, nwells, n_injectors=max(1, nwells // 6), seed=seed, inj_rate_m3_per_day=float(rng.uniform(50, 400)),
+                        prod_bhp_bar=float(rng.uniform(150, 230)), prod_oil_rate_m3_per_day=float(rng.uniform(10, 60)),
+                        rate_wells_bhp_limits_bar=(450.0, 80.0) if bhp_limits else None)
+    desc = "%dx%dx%d, %d active, inactive %.2f, sigma %.2f, %d wells%s" % (nx, ny, nz, grid.nc, inactive, kw["lognormal_sigma"], wl.nw, (" " + "+".join(opts)) if opts else "")
+    return grid, tab, st, wl, desc
+
+
 def cart60():
     """the bench deck's recipe at 60^3 = 216 k cells: the size at which the CPU checker's ILU0-preconditioned GMRES(40) is still
     affordable, so that device GMRES and checker GMRES can run whole time steps side by side"""

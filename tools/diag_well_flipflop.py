@@ -10,29 +10,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "opm-simulators-legacy_amd"))
 import numpy as np  # noqa: E402
 
-from opmgpu import capi, decks, timestepping as ts, wells as W  # noqa: E402
+from opmgpu import baseline_decks, capi, decks, timestepping as ts, wells as W  # noqa: E402
 from opmgpu.model import GpuBlackoilModel, NonlinearSolver  # noqa: E402
 
 seed = int(sys.argv[1])
 cfg = sys.argv[2] if len(sys.argv) > 2 else "cpr_bicgstab"
 KW = {"cpr_bicgstab": dict(capi.CPR_AMG_VCYCLE), "cpr_gmres": dict(capi.CPR_AMG_VCYCLE, newton_use_gmres=1), "ilu0": dict(use_cpr=0)}
-rng = np.random.default_rng(seed)
-nx, ny, nz = int(rng.integers(20, 50)), int(rng.integers(20, 50)), int(rng.integers(5, 20))
-inactive = float(rng.uniform(0.0, 0.6))
-kw = dict(dx=float(rng.uniform(30, 120)), dy=float(rng.uniform(30, 120)), dz=float(rng.uniform(2, 8)), tops=2500.0, lognormal_sigma=float(rng.uniform(0.3, 2.0)), seed=seed)
-if inactive > 0.05:
-    kw["actnum"] = rng.random(nx * ny * nz) > inactive
-if rng.random() < 0.6:
-    kw["nnc_fraction"] = float(rng.uniform(0.01, 0.06))
-if rng.random() < 0.4:
-    kw["thpres"] = float(rng.uniform(0.01, 0.05)) * decks.BAR
-grid = decks.cartesian_grid(nx, ny, nz, **kw)
-tab = decks.satfunc_standard_tables()
-st = decks.initial_state(grid, tab, p_ref=270.0 * decks.BAR, z_ref=2500.0, perturb=0.005, seed=seed)
-nwells = int(rng.integers(3, 20))
-wl = W.column_wells(grid, nwells, n_injectors=max(1, nwells // 6), seed=seed, inj_rate_m3_per_day=float(rng.uniform(50, 400)),
-                    prod_bhp_bar=float(rng.uniform(150, 230)), prod_oil_rate_m3_per_day=float(rng.uniform(10, 60)),
-                        rate_wells_bhp_limits_bar=None if os.environ.get("OPMGPU_SWEEP_NO_LIMITS") else (450.0, 80.0))
+grid, tab, st, wl, desc = baseline_decks.random_irregular(seed, bhp_limits=not os.environ.get("OPMGPU_SWEEP_NO_LIMITS"))
+nx, ny, nz = grid.dims
 print("deck %d: %dx%dx%d, %d active, %d wells" % (seed, nx, ny, nz, grid.nc, wl.nw))
 for w in range(wl.nw):
     print("  well %d %s type %d perforations %d controls %s" % (w, wl.name[w], wl.type[w], wl.connpos[w + 1] - wl.connpos[w], [(c[0], c[1]) for c in wl.controls[w]]))
