@@ -78,3 +78,22 @@ def test_bench_distributed_path_with_one_rank(gpu_lib):
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "1 GPU"
     assert d["config"]["linear_solver"].endswith("gmres(40)") and d["config"]["workload"].endswith("_fivespot")
     assert d["value"] == pytest.approx(d["config"]["cells"] / (d["ms_per_solving_iteration_median"] * 1e-3) / 1e6, rel=2e-3)
+
+
+def test_bench_norne_like_deck_decomposed_over_the_test_transport(gpu_lib):
+    """BASELINE configs[4] decomposed: `bench.py --deck nornelike --gpus 2` launched like the driver launches it (torch.distributed.run, one rank
+    per process; here both ranks on cuda:0, coupled by the shared-memory TEST transport and gloo): the ACTNUM deck is cut into slabs of whole
+    j-rows balanced by active cells, every vertical well stays on one rank, the run prints the contract line and chops no time step."""
+    dpath = os.path.join(ROOT, "gpurun_out", "bench_detail_test_norne2.json")
+    env = dict(os.environ, OPMGPU_COMM_TRANSPORT="shm")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29977",
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--deck", "nornelike", "--steps", "30", "--warmup", "2", "--stat-calls", "30", "--no-cpu-baseline",
+                          "--detail", dpath], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 4096
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["workload"] == "nornelike_46x112x22_3phase_blackoil_36wells"
+    assert 0.4 * d["config"]["cells"] < d["config"]["cells_per_gpu"] < 0.6 * d["config"]["cells"]
+    assert d["per_time_step"]["chopped_attempts"] == 0 and d["per_time_step"]["time_steps"] >= 5, d["per_time_step"]
+    assert d["config"]["linear_its_per_solve"] < 20, d["config"]
