@@ -20,7 +20,9 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
 configs = (sys.argv[3] if len(sys.argv) > 3 else "cpr_bicgstab,cpr_gmres").split(",")
 KW = {"cpr_bicgstab": dict(capi.CPR_AMG_VCYCLE), "cpr_gmres": dict(capi.CPR_AMG_VCYCLE, newton_use_gmres=1), "ilu0": dict(use_cpr=0),
       "cpr_ref_defaults": dict(use_cpr=1), "cpr_mixed": dict(capi.CPR_AMG_VCYCLE, preconditioner_single=1), "cpr_ilu1": dict(capi.CPR_AMG_VCYCLE, cpr_ilu_n=1),
-      "ilu1": dict(use_cpr=0, ilu_fillin_level=1)}
+      "ilu1": dict(use_cpr=0, ilu_fillin_level=1),
+      # "_ref" suffix: the reference default solver's precision switch (float below dt = 20 d, BlackoilModelBase_impl.hpp:284); "_f32": float always
+      "ilu0_ref": dict(use_cpr=0), "ilu0_f32": dict(use_cpr=0), "cpr_f32": dict(capi.CPR_AMG_VCYCLE)}
 tot = {c: {"substeps": 0, "failed": 0, "causes": {}, "wall": 0.0, "aborted": 0} for c in configs}
 for case in range(ncases):
     grid, tab, st, wl, desc = baseline_decks.random_irregular(seed0 + case, options=bool(os.environ.get("OPMGPU_SWEEP_OPTIONS")), bhp_limits=not os.environ.get("OPMGPU_SWEEP_NO_LIMITS"))
@@ -39,7 +41,8 @@ for case in range(ncases):
                 if trace:
                     print("   %s substep dt %.3e d" % (c, m.m.dt / decks.DAY), flush=True)
                 try:
-                    out = solver.step(m, single_precision=False)
+                    sp = True if c.endswith("_f32") else ((m.m.dt < 20 * decks.DAY) if c.endswith("_ref") else False)
+                    out = solver.step(m, single_precision=sp)
                 except Exception as e:
                     if trace:
                         print("      failed: %r" % (e,), flush=True)
