@@ -763,7 +763,7 @@ def cpu_baseline(grid, tab, st, wl, prm, dt, single, threads=1, budget_s=15.0, m
         tot += time.perf_counter() - t1
         its += 1; lin.append(l)
     short = "first %d Newton iterations of the same deck%s from the same state: oracle assembly + natural-order ILU0/BiCGStab %s (reference default) + update, %.1f s" % (
-        its, " + 5-spot (host wells)" if wl is not None else "", "f32" if single else "f64", tot)
+        its, " + its wells (host well model)" if wl is not None else "", "f32" if single else "f64", tot)
     return {"value": its * grid.nc / tot / 1e6, "unit": "Mcell-updates/s", "cores": threads, "kind": "port", "sample_short": short,
             "sample": "first %d Newton iterations of the same deck%s and initial state: assembly + natural-order ILU0/BiCGStab %s (the reference's default "
                       "solver_approach=interleaved; linear its %s) + update, %.2f s"
