@@ -154,6 +154,25 @@ def test_row_slabs_of_an_actnum_deck_keep_vertical_wells_whole():
         assert seen == wl.nw
 
 
+def test_random_irregular_decks_are_reproducible_and_decompose_with_whole_wells():
+    """opmgpu/baseline_decks.py::random_irregular (tools/robust_sweep.py, bench.py --deck random --seed N): the same seed gives the same deck, and
+    slabs of j-rows keep every (vertical) well of every deck on one rank at 2, 3 and 4 ranks -- with inactive cells (balanced by active
+    cells) and without."""
+    from opmgpu import baseline_decks, partition
+    for seed in range(8100, 8112):
+        g, _, st, wl, desc = baseline_decks.random_irregular(seed)
+        g2, _, st2, wl2, desc2 = baseline_decks.random_irregular(seed)
+        assert desc == desc2 and g.nc == g2.nc and np.array_equal(g.trans, g2.trans) and np.array_equal(st.p, st2.p) and list(wl.cells) == list(wl2.cells)
+        assert all(any(c[0] == W.BHP for c in wl.controls[w]) for w in range(wl.nw))          # every well has a BHP control or limit
+        for n in (2, 3, 4):
+            part = partition.slab_partition(g, n, axis=1)
+            assert np.unique(part).size == n, (seed, n)
+            seen = 0
+            for r in range(n):
+                seen += len(partition.LocalDomain(g, part, r).local_wells(wl, part).name)
+            assert seen == wl.nw, (seed, n)
+
+
 def test_weak_scaling_five_spots_live_inside_their_copy():
     """bench.py's weak-scaling decks: N copies of the workload with one 5-spot each, stacked along k (slab_axis 2) or side by side along j
     (slab_axis 1, --weak-axis 1).  Every well lies inside its copy, so the matching slab partition leaves every well on one rank."""
