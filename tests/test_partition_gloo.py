@@ -38,6 +38,11 @@ def _worker(rank, world, port, kind, out_q):
         if kind == "cart":
             grid = decks.cartesian_grid(6, 5, 8, lognormal_sigma=0.6)
             part = partition.slab_partition(grid, world)
+        elif kind == "actnum_rows":   # holes + NNCs with the box known: slabs of whole j-rows balanced by active cells (bench.py --deck nornelike / random, N > 1)
+            act = np.random.default_rng(4).random(8 * 9 * 5) > 0.4
+            grid = decks.cartesian_grid(8, 9, 5, actnum=act, nnc_fraction=0.05)
+            part = partition.slab_partition(grid, world, axis=1)
+            assert np.unique(part).size == world
         else:   # unstructured: holes + NNCs, index-range partition
             act = np.random.default_rng(2).random(7 * 6 * 6) > 0.25
             grid = decks.cartesian_grid(7, 6, 6, actnum=act, nnc_fraction=0.05)
@@ -119,7 +124,7 @@ def _worker(rank, world, port, kind, out_q):
         out_q.put((rank, "FAIL: " + traceback.format_exc()))
 
 
-@pytest.mark.parametrize("kind", ["cart", "unstructured"])
+@pytest.mark.parametrize("kind", ["cart", "unstructured", "actnum_rows"])
 def test_partition_world2_gloo(kind):
     world = 2
     ctx = mp.get_context("spawn")
